@@ -1,0 +1,276 @@
+"""Oracle for the integer / host-side rows of the hot path.
+TEST INFRASTRUCTURE ONLY.  numpy / torch-CPU restatements; each function cites what it follows.
+``hf:`` = site-packages/transformers (5.15.0), other paths are relative to /root/reference.
+"""
+from __future__ import annotations
+
+import json
+import math
+import re
+
+import numpy as np
+import torch
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+# ----------------------------------------------------------------------------- A3 / A4 image side
+def smart_resize(height, width, factor=28, min_pixels=56 * 56, max_pixels=768 * 768):
+    """hf:models/qwen2_vl/image_processing_pil_qwen2_vl.py:57-83; defaults as the reference binds them at
+    roll/pipeline/rlvr/rlvr_socioseg_vlm_pipeline_infer.py:518-521 (the YAML max/min_pixels are dropped)."""
+    if max(height, width) / min(height, width) > 200:
+        raise ValueError("absolute aspect ratio must be smaller than 200")
+    h_bar = round(height / factor) * factor
+    w_bar = round(width / factor) * factor
+    if h_bar * w_bar > max_pixels:
+        beta = math.sqrt((height * width) / max_pixels)
+        h_bar = max(factor, math.floor(height / beta / factor) * factor)
+        w_bar = max(factor, math.floor(width / beta / factor) * factor)
+    elif h_bar * w_bar < min_pixels:
+        beta = math.sqrt(min_pixels / (height * width))
+        h_bar = math.ceil(height * beta / factor) * factor
+        w_bar = math.ceil(width * beta / factor) * factor
+    return h_bar, w_bar
+
+
+def normalize_u8(img_hwc: np.ndarray) -> np.ndarray:
+    """hf:image_transforms.py:89-124 (float64 multiply, float32 downcast) and :384-440 (float32 (x-mean)/std)."""
+    x = (img_hwc.astype(np.float64) * (1 / 255)).astype(np.float32)
+    mean = np.array(CLIP_MEAN, dtype=np.float32)
+    std = np.array(CLIP_STD, dtype=np.float32)
+    return (x - mean) / std  # HWC, float32
+
+
+def patchify(img_hwc_u8: np.ndarray, patch=14, merge=2, temporal=2):
+    """hf:models/qwen2_vl/image_processing_pil_qwen2_vl.py:153-185: rows (gh/m, gw/m, m, m), cols (C, T, p, p);
+    the single frame is duplicated along T.  Returns (float32 [N, C*T*p*p], (1, gh, gw))."""
+    x = normalize_u8(img_hwc_u8).transpose(2, 0, 1)  # CHW
+    c, h, w = x.shape
+    gh, gw = h // patch, w // patch
+    p = x.reshape(c, gh // merge, merge, patch, gw // merge, merge, patch)
+    p = p.transpose(1, 4, 2, 5, 0, 3, 6)
+    p = np.broadcast_to(p[:, :, :, :, :, None, :, :], (*p.shape[:5], temporal, *p.shape[5:]))
+    return np.ascontiguousarray(p.reshape(gh * gw, c * temporal * patch * patch)), (1, gh, gw)
+
+
+# ----------------------------------------------------------------------------- A5 mRoPE position ids
+def get_rope_index(input_ids: np.ndarray, image_grid_thw, attention_mask=None, *, merge=2,
+                   image_token_id=151655, vision_start_token_id=151652):
+    """mcore_adapter/src/mcore_adapter/models/qwen2_5_vl/modeling_qwen2_5_vl.py:319-441 (image-only branch; the
+    infer pipeline has no videos).  input_ids [B,S] int64 -> (position_ids [3,B,S] int64, deltas [B,1])."""
+    input_ids = np.asarray(input_ids, dtype=np.int64)
+    B, S = input_ids.shape
+    if attention_mask is None:
+        attention_mask = np.ones_like(input_ids)
+    attention_mask = np.asarray(attention_mask)
+    if image_grid_thw is None or len(image_grid_thw) == 0:
+        pos = np.cumsum(attention_mask.astype(np.int64), -1) - 1
+        pos[attention_mask == 0] = 1
+        pos3 = np.broadcast_to(pos[None], (3, B, S)).copy()
+        deltas = pos3.max(0).max(-1, keepdims=True) + 1 - S
+        return pos3, deltas
+    pos3 = np.ones((3, B, S), dtype=np.int64)
+    deltas = []
+    img_i = 0
+    for b in range(B):
+        ids = input_ids[b][attention_mask[b] == 1]
+        toks = ids.tolist()
+        starts = np.nonzero(ids == vision_start_token_id)[0]
+        n_img = int((ids[starts + 1] == image_token_id).sum()) if len(starts) else 0
+        chunks, st = [], 0
+        for _ in range(n_img):
+            ed = toks.index(image_token_id, st)
+            t, h, w = (int(v) for v in image_grid_thw[img_i])
+            img_i += 1
+            lt, lh, lw = t, h // merge, w // merge
+            text_len = ed - st
+            st_idx = int(chunks[-1].max()) + 1 if chunks else 0
+            chunks.append(np.broadcast_to(np.arange(text_len)[None], (3, text_len)) + st_idx)
+            ti = np.repeat(np.arange(lt), lh * lw) * 0  # second_per_grid_t = 0 for images
+            hi = np.tile(np.repeat(np.arange(lh), lw), lt)
+            wi = np.tile(np.arange(lw), lt * lh)
+            chunks.append(np.stack([ti, hi, wi]) + text_len + st_idx)
+            st = ed + lt * lh * lw
+        if st < len(toks):
+            st_idx = int(chunks[-1].max()) + 1 if chunks else 0
+            tl = len(toks) - st
+            chunks.append(np.broadcast_to(np.arange(tl)[None], (3, tl)) + st_idx)
+        llm = np.concatenate(chunks, axis=1).reshape(3, -1)
+        pos3[:, b, attention_mask[b] == 1] = llm
+        deltas.append(int(llm.max()) + 1 - S)
+    return pos3, np.array(deltas, dtype=np.int64)[:, None]
+
+
+# ----------------------------------------------------------------------------- A6 / A8 output layout
+def gather_outputs_to_pad_tensor(token_lists, pad_token_id):
+    """roll/distributed/strategy/vllm_strategy.py:279-286 (pad_sequence, batch_first, right pad)."""
+    L = max((len(t) for t in token_lists), default=0)
+    out = np.full((len(token_lists), L), pad_token_id, dtype=np.int64)
+    for i, t in enumerate(token_lists):
+        out[i, : len(t)] = t
+    return out
+
+
+def concatenate_input_and_output(input_ids, output_ids, num_return_sequences=1):
+    """roll/utils/functionals.py:364-373."""
+    rep = np.repeat(np.asarray(input_ids), num_return_sequences, axis=0)
+    return np.concatenate([rep, np.asarray(output_ids)], axis=1)
+
+
+def postprocess_generate(input_ids, attention_mask, position_ids, output, num_return_sequences, sequence_length,
+                         eos_token_id, pad_token_id, fill_eos_token=False):
+    """roll/utils/functionals.py:768-872, mRoPE (3-D position_ids) branch.  numpy in, dict of numpy out."""
+    output = np.array(output, dtype=np.int64, copy=True)
+    if fill_eos_token:
+        last = output.shape[1] - 1
+        need = output[:, last] != pad_token_id
+        output[need, last] = eos_token_id
+    input_ids = np.asarray(input_ids)
+    attention_mask = np.asarray(attention_mask)
+    obs = output.shape[0]
+    P = input_ids.shape[1]
+    if output.shape[1] >= sequence_length:  # pad_to_length :351-361
+        output = output[:, :sequence_length]
+    else:
+        pad = np.full((obs, sequence_length - output.shape[1]), pad_token_id, dtype=output.dtype)
+        output = np.concatenate([output, pad], axis=1)
+    prompt = output[:, :P].copy()
+    response = output[:, P:].copy()
+    attention_mask = np.repeat(attention_mask, num_return_sequences, axis=0)
+    response_mask = (response != pad_token_id).astype(attention_mask.dtype)  # get_pad_mask :301-313
+    assert not ((response_mask[:, 0] == 0) & (response_mask.sum(-1) != 0)).any()
+    attention_mask = np.concatenate([attention_mask, response_mask], axis=-1)
+    position_ids = np.repeat(np.asarray(position_ids), num_return_sequences, axis=0)  # [B,3,P]
+    delta = np.arange(1, sequence_length - P + 1)[None, None, :]
+    out_pos = np.concatenate([position_ids, position_ids[..., -1:] + delta], axis=-1)
+    assert attention_mask.any(axis=1).all()
+    first_one = attention_mask.astype(np.float32).argmax(axis=1)
+    new_response_mask = np.zeros_like(attention_mask)
+    for i in range(obs):
+        shift = int(first_one[i])
+        if shift > 0:
+            output[i, :-shift] = output[i, shift:].copy()
+        valid = int(attention_mask[i].sum())
+        rl = int(response_mask[i].sum())
+        attention_mask[i][:valid] = 1
+        attention_mask[i][valid:] = 0
+        new_response_mask[i][valid - rl: valid] = 1
+        if shift > 0:
+            out_pos[i, ..., :-shift] = out_pos[i, ..., shift:].copy()
+            if P > rl:
+                output[i, -shift:] = pad_token_id
+    prompt_mask = (attention_mask == 1) & (new_response_mask == 0)
+    return {
+        "prompts": prompt, "responses": response, "input_ids": output, "attention_mask": attention_mask,
+        "position_ids": out_pos, "prompt_mask": prompt_mask, "response_mask": new_response_mask,
+    }
+
+
+# ----------------------------------------------------------------------------- A10 parsers
+_ANSWER = re.compile(r"<answer>(.*?)</answer>", re.DOTALL)
+
+
+def parse_points_text_from_content(content: str) -> str:
+    """roll/pipeline/multi_utils.py:4-15."""
+    m = _ANSWER.search(content)
+    return m.group(1).strip() if m else ""
+
+
+def parse_visual_prompt_from_json_s2(content: str):
+    """roll/pipeline/rlvr/seg_worker.py:199-259."""
+    out = []
+    m = _ANSWER.search(content)
+    if not m:
+        return out
+    try:
+        data = json.loads(m.group(1).strip())
+    except json.JSONDecodeError:
+        return out
+    if not isinstance(data, list):
+        return []
+    for obj in data:
+        try:
+            if not isinstance(obj, dict):
+                continue
+            box = obj.get("bbox_2d", [])
+            pts = [[p[0], p[1]] for p in obj.get("points", [])]
+            labels = [1] * len(pts)
+            if isinstance(box, list) and len(box) == 4:
+                out.append({"box": box, "points": pts, "labels": labels})
+        except Exception:
+            continue
+    return out
+
+
+# ----------------------------------------------------------------------------- A11-A13 raster (numpy mirror of raster_ref.c)
+def mask_union(masks):
+    """roll/distributed/strategy/seg_strategy.py:58-60: acc = logical_or(acc, m).astype(uint8)."""
+    acc = np.zeros_like(masks[0], dtype=np.uint8)
+    for m in masks:
+        acc = np.logical_or(acc, m).astype(np.uint8)
+    return acc
+
+
+def resize_nearest(src: np.ndarray, H: int, W: int) -> np.ndarray:
+    """cv2.INTER_NEAREST as called at seg_strategy.py:65 and rlvr_socioseg_vlm_pipeline_infer.py:399.
+    cv2 is not installed here (parity of this rule is UNPINNED): documented rule
+    sx = min(floor(dx * sw / dw), sw - 1) evaluated in double like OpenCV's resizeNN."""
+    h, w = src.shape[:2]
+    ys = np.minimum(np.floor(np.arange(H) * (h / H)).astype(np.int64), h - 1)
+    xs = np.minimum(np.floor(np.arange(W) * (w / W)).astype(np.int64), w - 1)
+    return src[ys][:, xs]
+
+
+def iou_counts(pred: np.ndarray, gt: np.ndarray):
+    """rlvr_socioseg_vlm_pipeline_infer.py:45-58 integer part."""
+    p, g = pred > 0, gt > 0
+    return int(np.logical_and(p, g).sum()), int(np.logical_or(p, g).sum())
+
+
+def compute_giou(pred, gt) -> float:
+    i, u = iou_counts(pred, gt)
+    return 1.0 if u == 0 else i / u
+
+
+def render_overlay(img_rgb: np.ndarray, mask: np.ndarray, bboxes, alpha=102, color=(255, 0, 0)):
+    """rlvr_socioseg_vlm_pipeline_infer.py:383-452 for one image, integer-exact restatement of the PIL calls:
+    RGB->RGBA(A=255), ImageDraw.rectangle(outline=blue, width=2) per bbox, then
+    Image.alpha_composite with an overlay that is (255,0,0,102) where mask>0 else (0,0,0,0), -> RGB.
+    The rectangles are drawn BEFORE the overlay is composited (reference order)."""
+    h, w = img_rgb.shape[:2]
+    out = img_rgb.astype(np.int64).copy()
+    for bb in bboxes:
+        if len(bb) != 4:
+            continue
+        x0, y0, x1, y1 = (int(v) for v in bb)  # PIL truncates float coordinates
+        if x1 < x0 or y1 < y0:
+            continue  # PIL raises ValueError -> the reference swallows it (:431-432)
+        draw_rect_outline(out, x0, y0, x1, y1, 2, (0, 0, 255))
+    if mask is None:
+        return out.astype(np.uint8)
+    m = resize_nearest((mask > 0).astype(np.uint8), h, w) > 0
+    # PIL AlphaComposite.c with dst.a == 255 (verified against PIL 12.2 in tools/make_golden.py):
+    #   coef1 = a*128, coef2 = (255-a)*128, out = SHIFTFORDIV255(src*coef1 + dst*coef2 + (0x80<<7)) >> 7
+    for c in range(3):
+        t = (np.int64(color[c]) * alpha + out[..., c] * (255 - alpha)) * 128 + (128 << 7)
+        blended = (((t >> 8) + t) >> 8) >> 7
+        out[..., c] = np.where(m, blended, out[..., c])
+    return out.astype(np.uint8)
+
+
+def draw_rect_outline(img, x0, y0, x1, y1, width, color):
+    """PIL ImageDraw.rectangle(outline, width): inclusive coordinates, border grows inwards."""
+    h, w = img.shape[:2]
+
+    def fill(xa, ya, xb, yb):
+        xa, ya = max(xa, 0), max(ya, 0)
+        xb, yb = min(xb, w - 1), min(yb, h - 1)
+        if xb >= xa and yb >= ya:
+            img[ya: yb + 1, xa: xb + 1] = color
+
+    for i in range(width):
+        fill(x0, y0 + i, x1, y0 + i)
+        fill(x0, y1 - i, x1, y1 - i)
+        fill(x0 + i, y0, x0 + i, y1)
+        fill(x1 - i, y0, x1 - i, y1)

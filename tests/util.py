@@ -1,0 +1,31 @@
+"""Shared helpers for parity tests."""
+import numpy as np
+import torch
+
+
+def bits_to_f32(bits: np.ndarray) -> torch.Tensor:
+    """uint16 bf16 bit patterns -> float32 tensor."""
+    return torch.from_numpy(bits.astype(np.uint16).view(np.int16).copy()).view(torch.bfloat16).float()
+
+
+def bf16_ulp(x: torch.Tensor) -> torch.Tensor:
+    """Spacing of bf16 numbers at |x| (>= the smallest normal spacing)."""
+    e = torch.floor(torch.log2(x.abs().clamp_min(1e-30)))
+    return torch.pow(2.0, e - 7)
+
+
+def bf16_compare(got: torch.Tensor, want: torch.Tensor):
+    """Returns (max error in bf16 ulps of ``want``, fraction of elements that differ, max abs error)."""
+    got, want = got.float().flatten(), want.float().flatten()
+    d = (got - want).abs()
+    # near-zero outputs of a cancelling sum carry the absolute error of the typical output: floor the
+    # magnitude at the tensor rms so that "1 ulp" means one bf16 step of a typically sized element
+    floor = want.pow(2).mean().sqrt()
+    ulps = d / bf16_ulp(torch.maximum(torch.maximum(got.abs(), want.abs()), floor))
+    return float(ulps.max()), float((d > 0).float().mean()), float(d.max())
+
+
+def assert_bf16_close(got, want, max_ulp=1.0, max_frac=0.01, what=""):
+    mu, frac, mad = bf16_compare(got, want)
+    assert mu <= max_ulp + 1e-6 and frac <= max_frac, f"{what}: max {mu:.2f} ulp, {frac:.4%} differ, max abs {mad:.3e}"
+    return mu, frac, mad
