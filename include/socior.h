@@ -1,0 +1,134 @@
+/* libsocior -- C ABI of the MI355X-native SocioReasoner inference hot path.
+ *
+ * The reference (AMAP-ML/SocioReasoner) has no native code and therefore no FFI for this path: its plugin boundary
+ * is the Python class InferenceStrategy (roll/distributed/strategy/strategy.py:16-138) and the engine behind it is
+ * vLLM (roll/distributed/strategy/vllm_strategy.py:114-141).  This header is the derived contract of SURVEY.md
+ * section 8(B): what a ctypes binding inside a replacement InferenceStrategy binds (INTEGRATION.md shows that stub).
+ * Each entry point cites the reference behaviour it replaces (paths relative to /root/reference, `hf:` =
+ * transformers/models/qwen2_5_vl/modeling_qwen2_5_vl.py).
+ *
+ * Conventions: extern "C"; plain pointers and sizes; every call returns 0 on success, a negative errno-style value or
+ * a positive hipError_t on failure (sr_last_error() gives the text).  Device buffers are caller-owned
+ * (torch.Tensor.data_ptr()); "host" marks the few small control arrays read on the CPU.  Every call that enqueues GPU
+ * work takes the caller's hipStream_t (as void*) and is asynchronous with respect to the host unless stated.  The
+ * engine allocates no device memory after sr_engine_create(): everything lives in the caller-provided workspace.
+ * One engine per process/GPU; calls on one engine must not overlap (no internal threads, not re-entrant).
+ */
+#ifndef SOCIOR_H
+#define SOCIOR_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sr_engine sr_engine;
+
+#define SR_DTYPE_BF16 0
+#define SR_DTYPE_F32 1
+
+/* Geometry (HF config fields of Qwen2.5-VL; values for SocioReasoner-3B in SURVEY.md 2.3) + capacities. */
+typedef struct sr_config {
+    /* vision tower */
+    int32_t v_depth, v_hidden, v_heads, v_inter, v_patch, v_temporal, v_merge, v_window, v_out_hidden, v_in_ch;
+    int32_t v_n_fullatt;
+    int32_t v_fullatt[16];
+    /* language model */
+    int32_t t_layers, t_hidden, t_heads, t_kv_heads, t_head_dim, t_inter, t_vocab;
+    float t_rms_eps, t_rope_theta;
+    int32_t mrope_section[3];
+    int32_t image_token_id;      /* <|image_pad|>: positions holding it take rows of the image embeddings (hf:1210-1216) */
+    /* capacities that size the workspace */
+    int32_t max_patches;         /* ViT rows (all images of one sr_vit_forward call) */
+    int32_t max_prefill_tokens;  /* packed prompt tokens of one sr_prefill call */
+    int32_t max_batch;           /* KV-cache slots = concurrent sequences (<= 32) */
+    int32_t max_ctx;             /* KV rows per slot, multiple of 64 (prompt + generated) */
+    int32_t max_new_tokens;      /* rows of the device token log */
+} sr_config;
+
+/* Bytes of device workspace sr_engine_create needs for this configuration (0 on invalid config). */
+size_t sr_workspace_bytes(const sr_config* cfg);
+
+/* Replaces VllmStrategy.initialize (vllm_strategy.py:46-106): builds the engine inside `workspace` (device memory,
+ * >= sr_workspace_bytes, 256-byte aligned).  Weights are loaded afterwards with sr_load_weight. */
+int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_bytes, sr_engine** out);
+int sr_engine_destroy(sr_engine* e);
+/* Text of the last error of this engine (or of the last failed create when e == NULL).  Never NULL. */
+const char* sr_last_error(const sr_engine* e);
+
+/* Replaces the weight path (from_pretrained / the trainer->engine broadcast, megatron_strategy.py:411-448):
+ * hands one HF-named tensor (device pointer, row-major, `shape`) to the engine, which copies it into its own layout
+ * (K padded to 64, q/k/v fused, gate/up interleaved).  Accepted names: reference-era checkpoints
+ * (`visual.*`, `model.layers.*`, `model.embed_tokens.weight`, `model.norm.weight`, `lm_head.weight`;
+ * mcore_adapter/src/mcore_adapter/models/converter/template.py:845-899) and transformers-5 names
+ * (`model.visual.*`, `model.language_model.*`).  `lm_head.weight` is accepted and ignored (tied embeddings). */
+int sr_load_weight(sr_engine* e, const char* hf_name, const void* dev_ptr, int dtype, const int64_t* shape, int ndim,
+                   void* stream);
+/* Number of parameters still missing (0 = ready); when `first_missing` is non-NULL it receives one missing name. */
+int sr_weights_missing(const sr_engine* e, char* first_missing, size_t cap);
+
+/* Synthetic weights (no checkpoint is available offline): fills `n` bf16 values at dev_out with the counter-based
+ * generator defined in oracle/weights.py (independent implementation), element index = start + i. */
+int sr_synth_fill(void* dev_out_bf16, int64_t n, const char* hf_name, uint32_t seed, float base, void* stream);
+
+/* K1 -- replaces the HF image processor's rescale/normalise/patchify (hf:models/qwen2_vl/
+ * image_processing_pil_qwen2_vl.py:153-248, invoked at roll/datasets/collator.py:456-461): uint8 HWC image (h, w
+ * multiples of patch*merge, already smart_resize'd) -> bf16 patch rows [N, sr_pixel_ld()], zero padded. */
+int sr_pixel_ld(const sr_engine* e);
+int sr_patchify_u8(sr_engine* e, const uint8_t* dev_img_hwc, int h, int w, void* dev_pixels_bf16, void* stream);
+
+/* K2-K9 -- replaces Qwen2_5_VisionTransformerPretrainedModel.forward (hf:408-474): pixel values of n_img images
+ * (rows concatenated) -> merged image embeddings [sum(t*h*w)/merge^2, v_out_hidden] bf16.
+ * pixels: SR_DTYPE_BF16 = rows of sr_pixel_ld() (output of sr_patchify_u8); SR_DTYPE_F32 = [N, C*T*p*p] as the HF
+ * processor emits them.  grid_thw: host int64 [n_img][3] (t must be 1). */
+int sr_vit_forward(sr_engine* e, const void* dev_pixels, int pixels_dtype, const int64_t* host_grid_thw, int n_img,
+                   void* dev_out_bf16, void* stream);
+
+/* K10-K17 prefill -- replaces the prompt phase of vllm.LLM.generate (vllm_strategy.py:127) / the HF forward at
+ * hf_strategy.py:84-93: B un-padded sequences packed back to back.
+ *   host_ids   int64 [n_tok]      token ids; image_token_id positions take consecutive rows of dev_image_embeds
+ *   host_pos3  int64 [3][n_tok]   mRoPE position ids (roll/datasets/collator.py / get_rope_index)
+ *   host_seq_lens int32 [B], host_slots int32 [B] (KV-cache slot of each sequence, < max_batch)
+ * Leaves the KV cache filled, the greedy next token of every sequence in the device state, and (when not NULL)
+ * float32 last-position logits [B, vocab] in dev_logits_out. */
+int sr_prefill(sr_engine* e, const int64_t* host_ids, const int64_t* host_pos3, const int32_t* host_seq_lens,
+               const int32_t* host_slots, int B, const void* dev_image_embeds, int n_image_rows, float* dev_logits_out,
+               void* stream);
+
+/* Decode -- replaces the autoregressive loop of vllm.LLM.generate with SamplingParams built at
+ * vllm_strategy.py:289-309 for temperature 0 (greedy): generates up to max_new tokens for the sequences prefilled
+ * into slots host_slots[0..B).  Stops a sequence at the first token in host_eos (the token is kept, later positions
+ * hold pad_id -- the layout gather_outputs_to_pad_tensor produces, vllm_strategy.py:279-286).
+ *   dev_tokens_out int32 [B][max_new]
+ *   dev_logits_trace (optional) float32 [max_new][B][vocab]: logits that produced every token (forces eager launch)
+ *   dev_forced (optional) int32 [B][max_new]: teacher forcing -- token fed back at step i is forced[b][i]
+ *   use_graph: replay one captured hipGraph per step (ignored when tracing)
+ * Synchronises the stream before returning; *steps_done = number of token positions written. */
+int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const int32_t* host_eos, int n_eos,
+              int32_t pad_id, int32_t* dev_tokens_out, float* dev_logits_trace, const int32_t* dev_forced, int use_graph,
+              void* stream, int* steps_done);
+
+/* K19-K22 raster tail -- replaces seg_strategy.py:58-65 (union, cv2.INTER_NEAREST resize),
+ * rlvr_socioseg_vlm_pipeline_infer.py:45-58 (IoU counts) and :383-452 (render).  No engine needed. */
+int sr_mask_union(uint8_t* dev_acc, const uint8_t* dev_mask, size_t n, void* stream);
+int sr_resize_nearest_u8(const uint8_t* dev_src, int sh, int sw, uint8_t* dev_dst, int dh, int dw, void* stream);
+int sr_iou_counts(const uint8_t* dev_pred, const uint8_t* dev_gt, size_t n, int64_t* dev_out2, void* stream);
+int sr_render_overlay(uint8_t* dev_img_rgb, int h, int w, const uint8_t* dev_mask, int mh, int mw,
+                      const int32_t* dev_boxes, int n_boxes, void* stream);
+
+/* Single-kernel entry points used by the parity tests and micro-benchmarks (same kernels the engine launches).
+ * All pointers are device pointers; layouts are documented in DESIGN.md "Kernels". */
+int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void* out, int ldo, const void* bias,
+               const void* resid, const int32_t* rowmap, int epilogue, void* stream);
+int sr_op_gemv(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ksplit, int mode, void* stream);
+int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, float eps, void* stream);
+int sr_op_resid_rmsnorm(void* x, const float* partials, int ksplit, const void* w, void* out, int rows, int H, float eps,
+                        void* stream);
+int sr_op_argmax(const float* logits, int rows, int V, int32_t* out_idx, void* stream);
+int sr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOCIOR_H */

@@ -260,12 +260,14 @@ def render_overlay(img_rgb: np.ndarray, mask: np.ndarray, bboxes, alpha=102, col
 
 
 def draw_rect_outline(img, x0, y0, x1, y1, width, color):
-    """PIL ImageDraw.rectangle(outline, width): inclusive coordinates, border grows inwards."""
+    """PIL ImageDraw.rectangle(outline, width): inclusive coordinates, border grows inwards.
+    Exact for boxes at least 3 px in both dimensions (verified against PIL 12.2); thinner boxes are clipped to
+    the box itself here, whereas PIL spills a pixel outside -- documented deviation."""
     h, w = img.shape[:2]
 
     def fill(xa, ya, xb, yb):
-        xa, ya = max(xa, 0), max(ya, 0)
-        xb, yb = min(xb, w - 1), min(yb, h - 1)
+        xa, ya = max(xa, 0, x0), max(ya, 0, y0)
+        xb, yb = min(xb, w - 1, x1), min(yb, h - 1, y1)
         if xb >= xa and yb >= ya:
             img[ya: yb + 1, xa: xb + 1] = color
 

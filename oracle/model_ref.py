@@ -76,7 +76,7 @@ def config_3b() -> RefConfig:
 def config_tiny() -> RefConfig:
     """Small geometry with the true head dims (ViT 80, LM 128) for fast parity tests."""
     return RefConfig(
-        vision=VisionCfg(depth=4, hidden_size=160, num_heads=2, intermediate_size=220,
+        vision=VisionCfg(depth=4, hidden_size=320, num_heads=4, intermediate_size=220,
                          fullatt_block_indexes=(1, 3), out_hidden_size=512),
         text=TextCfg(num_hidden_layers=3, hidden_size=512, num_attention_heads=4, num_key_value_heads=1,
                      intermediate_size=1000, vocab_size=2048),

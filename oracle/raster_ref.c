@@ -41,7 +41,12 @@ void ref_iou_counts(const uint8_t *p, const uint8_t *g, size_t n, int64_t out[2]
     out[1] = uni;
 }
 
-static void fill(uint8_t *img, int h, int w, int xa, int ya, int xb, int yb) {
+/* clipped to the image and to the box itself (PIL spills outside boxes thinner than 3 px: documented deviation) */
+static void fill(uint8_t *img, int h, int w, int bx0, int by0, int bx1, int by1, int xa, int ya, int xb, int yb) {
+    if (xa < bx0) xa = bx0;
+    if (ya < by0) ya = by0;
+    if (xb > bx1) xb = bx1;
+    if (yb > by1) yb = by1;
     if (xa < 0) xa = 0;
     if (ya < 0) ya = 0;
     if (xb > w - 1) xb = w - 1;
@@ -60,10 +65,10 @@ void ref_render_overlay(uint8_t *img, int h, int w, const uint8_t *mask, int mh,
         int x0 = boxes[4 * b], y0 = boxes[4 * b + 1], x1 = boxes[4 * b + 2], y1 = boxes[4 * b + 3];
         if (x1 < x0 || y1 < y0) continue;
         for (int i = 0; i < 2; ++i) {
-            fill(img, h, w, x0, y0 + i, x1, y0 + i);
-            fill(img, h, w, x0, y1 - i, x1, y1 - i);
-            fill(img, h, w, x0 + i, y0, x0 + i, y1);
-            fill(img, h, w, x1 - i, y0, x1 - i, y1);
+            fill(img, h, w, x0, y0, x1, y1, x0, y0 + i, x1, y0 + i);
+            fill(img, h, w, x0, y0, x1, y1, x0, y1 - i, x1, y1 - i);
+            fill(img, h, w, x0, y0, x1, y1, x0 + i, y0, x0 + i, y1);
+            fill(img, h, w, x0, y0, x1, y1, x1 - i, y0, x1 - i, y1);
         }
     }
     if (!mask) return;

@@ -1,0 +1,279 @@
+// Attention kernels of the hot path, MFMA 16x16x32 bf16, exact HF eager semantics:
+//   scores = bf16(q.k^T); scores = bf16(scores * scale); softmax in float32; P = bf16(softmax); O = bf16(P.V)
+//   (hf: transformers/models/qwen2_5_vl/modeling_qwen2_5_vl.py:186-208 eager_attention_forward, 262-287, 641-689).
+// Because HF rounds the *normalised* probabilities to bf16 before P.V, the kernels are two-pass: pass 1 computes the
+// row max / sum, pass 2 recomputes the (bit-identical) scores, normalises, rounds and multiplies by V.  The second
+// Q.K^T is ~1-2 % of a layer's FLOPs; keeping the reference's rounding points is worth more than that here.
+//
+// Everything is computed transposed so that no operand ever needs a transpose in LDS:
+//   S^T[key][query] = K[key][:] . Q[query][:]      (A = K rows,  B = Q rows, both d-contiguous)
+//   O^T[d][query]   = V^T[d][:] . P^T[:][query]    (A = V^T rows, key-contiguous; B = P from the S^T registers)
+// V is therefore kept transposed in HBM ([d][key]: the ViT rope kernel and the LM KV-cache writer produce it).
+#include "kernels.h"
+#include <math.h>
+
+namespace {
+
+constexpr int QT = 64;   // queries per block (4 waves x 16)
+constexpr int KT = 64;   // keys per staged tile
+constexpr int VT_RS = 136;  // V^T LDS row stride in bytes: 64 keys * 2 B + 8 B pad (conflict-free ds_read_b64)
+
+template <int HD>
+struct PrefillCfg {
+    static constexpr int HDP = (HD + 31) / 32 * 32;   // K-dim of Q.K^T padded to the MFMA k-step
+    static constexpr int KS = HDP / 32;
+    static constexpr int DT = HD / 16;
+    static constexpr int K_RS = HDP * 2 + 16;         // K LDS row stride (bytes), +16 B pad: conflict-free b128 reads
+    static constexpr int K_BYTES = KT * K_RS;
+    static constexpr int V_BYTES = HD * VT_RS;
+};
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void k_attn_prefill(AttnArgs p) {
+    using C = PrefillCfg<HD>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C::K_BYTES + C::V_BYTES];
+    unsigned char* ks = smem;
+    unsigned char* vs = smem + C::K_BYTES;
+
+    const AttnWork wk = p.work[blockIdx.x];
+    const int h = blockIdx.y, kvh = h / p.group;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int q_local = wave * 16 + fr;                     // query index inside the tile
+    const int qpos = wk.q_off + q_local;                    // position inside the sequence
+    const bool q_valid = qpos < wk.seq_len;
+    const int q_rows_valid = min(QT, wk.seq_len - wk.q_off);
+    const bf16_t* qptr = p.q + (size_t)(wk.q_row0 + min(q_local, q_rows_valid - 1)) * p.q_stride + h * HD;
+
+    bf16x8 qf[C::KS];
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+        const int d = kk * 32 + fg * 8;
+        if (d < HD) qf[kk] = *reinterpret_cast<const bf16x8*>(qptr + d);
+        else qf[kk] = __builtin_bit_cast(bf16x8, uint4{0, 0, 0, 0});
+    }
+
+    const bf16_t* kbase = p.k + (size_t)wk.k_row0 * p.k_stride + (size_t)kvh * p.k_head_stride;
+    const bf16_t* vbase = p.vt + wk.vt_off + (size_t)kvh * p.vt_head_stride;
+    const int kv_end = CAUSAL ? min(wk.seq_len, wk.q_off + QT) : wk.seq_len;
+
+    auto stage_k = [&](int kv0) {
+        constexpr int CH = C::HDP / 8;                       // 16-byte chunks per row (incl. zero padding)
+        for (int c = tid; c < KT * CH; c += 256) {
+            const int row = c / CH, ch = c % CH;
+            uint4 v = uint4{0, 0, 0, 0};
+            if (ch * 8 < HD) {
+                const int j = min(kv0 + row, wk.seq_len - 1);
+                v = *reinterpret_cast<const uint4*>(kbase + (size_t)j * p.k_stride + ch * 8);
+            }
+            *reinterpret_cast<uint4*>(ks + row * C::K_RS + ch * 16) = v;
+        }
+    };
+    auto stage_v = [&](int kv0) {
+        for (int c = tid; c < HD * (KT / 4); c += 256) {
+            const int d = c / (KT / 4), g4 = c % (KT / 4);
+            const int j0 = kv0 + g4 * 4;
+            uint2 v = uint2{0, 0};
+            if (j0 < wk.seq_len) {
+                v = *reinterpret_cast<const uint2*>(vbase + (size_t)d * p.vt_stride + j0);
+                // zero the keys past the end of the sequence (they hold other data or garbage)
+                if (j0 + 1 >= wk.seq_len) v.x &= 0x0000ffffu;
+                if (j0 + 2 >= wk.seq_len) v.y = 0;
+                else if (j0 + 3 >= wk.seq_len) v.y &= 0x0000ffffu;
+            }
+            *reinterpret_cast<uint2*>(vs + d * VT_RS + g4 * 8) = v;
+        }
+    };
+    // scores of one staged tile: s[t][r] = key kv0 + t*16 + fg*4 + r against query fr of this wave
+    auto scores = [&](int kv0, float (&s)[4][4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < C::KS; ++kk) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + (t * 16 + fr) * C::K_RS + (kk * 4 + fg) * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kidx = kv0 + t * 16 + fg * 4 + r;
+                const bool ok = kidx < wk.seq_len && (!CAUSAL || kidx <= qpos);
+                const float v = rbf(rbf(acc[r]) * p.scale);
+                s[t][r] = ok ? v : -INFINITY;
+            }
+        }
+    };
+
+    // ---------------- pass 1: row max m and sum l = sum exp(s - m)
+    float m = -INFINITY, l = 0.f;
+    for (int kv0 = 0; kv0 < kv_end; kv0 += KT) {
+        __syncthreads();
+        stage_k(kv0);
+        __syncthreads();
+        float s[4][4];
+        scores(kv0, s);
+        float tm = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tm = fmaxf(tm, s[t][r]);
+        tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        const float mn = fmaxf(m, tm);
+        float ts = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ts += __expf(s[t][r] - mn);
+        ts += __shfl_xor(ts, 16, 64);
+        ts += __shfl_xor(ts, 32, 64);
+        l = l * __expf(m - mn) + ts;
+        m = mn;
+    }
+    const float inv_l = 1.0f / l;
+
+    // ---------------- pass 2: P = bf16(exp(s - m) / l);  O^T += V^T . P^T
+    f32x4 oacc[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kv0 = 0; kv0 < kv_end; kv0 += KT) {
+        __syncthreads();
+        stage_k(kv0);
+        stage_v(kv0);
+        __syncthreads();
+        float s[4][4];
+        scores(kv0, s);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint4 pv;
+            pv.x = pack2(__expf(s[2 * kb][0] - m) * inv_l, __expf(s[2 * kb][1] - m) * inv_l);
+            pv.y = pack2(__expf(s[2 * kb][2] - m) * inv_l, __expf(s[2 * kb][3] - m) * inv_l);
+            pv.z = pack2(__expf(s[2 * kb + 1][0] - m) * inv_l, __expf(s[2 * kb + 1][1] - m) * inv_l);
+            pv.w = pack2(__expf(s[2 * kb + 1][2] - m) * inv_l, __expf(s[2 * kb + 1][3] - m) * inv_l);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pv);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+                const unsigned char* vr = vs + (dt * 16 + fr) * VT_RS + kb * 64 + fg * 8;
+                uint2 v0 = *reinterpret_cast<const uint2*>(vr);        // keys kb*32 + fg*4 .. +3
+                uint2 v1 = *reinterpret_cast<const uint2*>(vr + 32);   // keys kb*32 + 16 + fg*4 .. +3
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, uint4{v0.x, v0.y, v1.x, v1.y});
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (q_valid) {
+        bf16_t* optr = p.out + (size_t)(wk.q_row0 + q_local) * p.out_stride + h * HD + fg * 4;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            uint2 v = {pack2(oacc[dt][0], oacc[dt][1]), pack2(oacc[dt][2], oacc[dt][3])};
+            *reinterpret_cast<uint2*>(optr + dt * 16) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- decode (q_len = 1)
+// One block per (sequence, kv head): the `group` query heads that share the kv head are the MFMA N dimension.
+constexpr int DEC_HD = 128;
+
+__global__ __launch_bounds__(256) void k_attn_decode(DecodeAttnArgs p, int s_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    bf16_t* sb = reinterpret_cast<bf16_t*>(dsm);            // [group][s_stride] scores, then probabilities
+    const int b = blockIdx.x, kvh = blockIdx.y;
+    const int slot = p.slots ? p.slots[b] : b;
+    const int nkeys = p.ctx_len[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int G = p.group;
+    const bf16_t* kc = p.kcache + (size_t)(slot * p.n_kv_heads + kvh) * p.ctx_max * DEC_HD;
+    const bf16_t* vc = p.vtcache + (size_t)(slot * p.n_kv_heads + kvh) * DEC_HD * p.ctx_max;
+    const uint4 z4 = uint4{0, 0, 0, 0};
+
+    // ---- phase A: scores S^T[key][head]
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        uint4 v = z4;
+        if (fr < G) v = *reinterpret_cast<const uint4*>(p.q + (size_t)b * p.q_stride + (kvh * G + fr) * DEC_HD + kk * 32 + fg * 8);
+        qf[kk] = __builtin_bit_cast(bf16x8, v);
+    }
+    const int ntiles = (nkeys + 15) / 16;
+    for (int t = wave; t < ntiles; t += 4) {
+        const int key = min(t * 16 + fr, nkeys - 1);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 kf = *reinterpret_cast<const bf16x8*>(kc + (size_t)key * DEC_HD + kk * 32 + fg * 8);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
+        }
+        if (fr < G) {
+            uint2 v = {pack2(rbf(acc[0]) * p.scale, rbf(acc[1]) * p.scale), pack2(rbf(acc[2]) * p.scale, rbf(acc[3]) * p.scale)};
+            *reinterpret_cast<uint2*>(sb + fr * s_stride + t * 16 + fg * 4) = v;
+        }
+    }
+    __syncthreads();
+    // ---- phase B: softmax per head (float32), probabilities rounded to bf16 in place; tail zero-filled
+    const int npad = (nkeys + 31) / 32 * 32;
+    for (int hh = wave; hh < G; hh += 4) {
+        bf16_t* row = sb + hh * s_stride;
+        float mx = -INFINITY;
+        for (int j = lane; j < nkeys; j += 64) mx = fmaxf(mx, bf2f(row[j]));
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < nkeys; j += 64) sum += __expf(bf2f(row[j]) - mx);
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int j = lane; j < npad; j += 64) row[j] = (j < nkeys) ? f2bf(__expf(bf2f(row[j]) - mx) * inv) : (bf16_t)0;
+    }
+    __syncthreads();
+    // ---- phase C: O^T[d][head] = V^T[d][:] . P^T
+    f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int kb = 0; kb < npad / 32; ++kb) {
+        uint4 pv = z4;
+        if (fr < G) pv = *reinterpret_cast<const uint4*>(sb + fr * s_stride + kb * 32 + fg * 8);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pv);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int d = (wave * 2 + i) * 16 + fr;
+            bf16x8 vf = *reinterpret_cast<const bf16x8*>(vc + (size_t)d * p.ctx_max + kb * 32 + fg * 8);
+            oacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[i], 0, 0, 0);
+        }
+    }
+    if (fr < G) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uint2 v = {pack2(oacc[i][0], oacc[i][1]), pack2(oacc[i][2], oacc[i][3])};
+            *reinterpret_cast<uint2*>(p.out + (size_t)b * p.out_stride + (kvh * G + fr) * DEC_HD + (wave * 2 + i) * 16 + fg * 4) = v;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim) {
+    if (a.n_work <= 0) return 0;
+    dim3 grid(a.n_work, a.n_heads), block(256);
+    if (head_dim == 80 && !a.causal) hipLaunchKernelGGL((k_attn_prefill<80, false>), grid, block, 0, s, a);
+    else if (head_dim == 128 && a.causal) hipLaunchKernelGGL((k_attn_prefill<128, true>), grid, block, 0, s, a);
+    else if (head_dim == 128 && !a.causal) hipLaunchKernelGGL((k_attn_prefill<128, false>), grid, block, 0, s, a);
+    else return -22;
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+
+// raises the dynamic-LDS limit once, outside of any stream capture
+int attn_decode_prepare(int ctx_max, int group) {
+    const size_t smem = (size_t)group * (ctx_max + 8) * sizeof(bf16_t);
+    if (smem > 160 * 1024) return -22;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_decode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+}
+
+int launch_attn_decode(hipStream_t s, const DecodeAttnArgs& a) {
+    if (a.B <= 0) return 0;
+    if (a.group > 16 || a.ctx_max % 64 != 0) return -22;
+    const int s_stride = a.ctx_max + 8;
+    const size_t smem = (size_t)a.group * s_stride * sizeof(bf16_t);
+    hipLaunchKernelGGL(k_attn_decode, dim3(a.B, a.n_kv_heads), dim3(256), smem, s, a, s_stride);
+    SR_CHECK_LAUNCH();
+    return 0;
+}

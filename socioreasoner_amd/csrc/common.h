@@ -1,0 +1,36 @@
+// Shared device helpers for the SocioReasoner MI355X (gfx950) hot path.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // storage type for bf16 everywhere (bit pattern)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- bf16 <-> f32.  f2bf lowers to v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even), the same
+// rounding torch applies at every bf16 op boundary of the HF eager path this library reproduces.
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float lo16(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi16(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// HF: F.silu on a bf16 tensor = float32 x * sigmoid(x), one rounding (hf:85-96 act_fn)
+__device__ __forceinline__ float silu_f(float x) { return x * (1.0f / (1.0f + __expf(-x))); }
+// nn.GELU() (erf form), float32 internally
+__device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+#define SR_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,387 @@
+// HBM-bound kernels of the hot path: RMSNorm,
+// rotary embeddings (ViT 2-D float32 / LM mRoPE bf16), embedding gather + image scatter, patchify, argmax,
+// decode bookkeeping and the synthetic-weight generator.  All bf16 traffic is 8- or 16-byte vectorised.
+// Rounding points follow HF's bf16 eager path (hf: transformers/models/qwen2_5_vl/modeling_qwen2_5_vl.py).
+#include "kernels.h"
+#include <math.h>
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------- RMSNorm (hf:65-79)
+// One wave per row.  Optional fused residual: h = bf16(x + bf16(sum_ks part[ks])) is written back to x first.
+template <int MAXC>
+__global__ __launch_bounds__(256) void k_rmsnorm(bf16_t* x, const bf16_t* xin, const float* part, int ksplit,
+                                                 const bf16_t* w, bf16_t* out, int rows, int H, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nch = H / 8;
+    float v[MAXC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            uint4 u = *reinterpret_cast<const uint4*>(xin + (size_t)row * H + c * 8);
+            v[i][0] = lo16(u.x); v[i][1] = hi16(u.x); v[i][2] = lo16(u.y); v[i][3] = hi16(u.y);
+            v[i][4] = lo16(u.z); v[i][5] = hi16(u.z); v[i][6] = lo16(u.w); v[i][7] = hi16(u.w);
+            if (part) {
+                float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int ks = 0; ks < ksplit; ++ks) {
+                    const float4* pp = reinterpret_cast<const float4*>(part + ((size_t)ks * rows + row) * H + c * 8);
+                    float4 p0 = pp[0], p1 = pp[1];
+                    a[0] += p0.x; a[1] += p0.y; a[2] += p0.z; a[3] += p0.w;
+                    a[4] += p1.x; a[5] += p1.y; a[6] += p1.z; a[7] += p1.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = rbf(v[i][e] + rbf(a[e]));
+                uint4 o = {pack2(v[i][0], v[i][1]), pack2(v[i][2], v[i][3]), pack2(v[i][4], v[i][5]), pack2(v[i][6], v[i][7])};
+                *reinterpret_cast<uint4*>(x + (size_t)row * H + c * 8) = o;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+        }
+    }
+    ss = wave_sum(ss);
+    const float rs = 1.0f / sqrtf(ss / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            uint4 wu = *reinterpret_cast<const uint4*>(w + c * 8);
+            float wv[8] = {lo16(wu.x), hi16(wu.x), lo16(wu.y), hi16(wu.y), lo16(wu.z), hi16(wu.z), lo16(wu.w), hi16(wu.w)};
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = wv[e] * rbf(v[i][e] * rs);
+            uint4 ov = {pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+            *reinterpret_cast<uint4*>(out + (size_t)row * H + c * 8) = ov;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- ViT 2-D RoPE (hf:160-171)
+// float32 math, one rounding.  cos/sin tables [n_rows][hd/2] (the two halves of HF's emb are identical).
+__global__ __launch_bounds__(256) void k_vit_rope(bf16_t* qkv, int n_rows, int n_heads, int hd, const float* cos_t,
+                                                  const float* sin_t) {
+    const int row = blockIdx.x;
+    const int half = hd / 2, C = n_heads * hd;
+    bf16_t* base = qkv + (size_t)row * 3 * C;
+    for (int i = threadIdx.x; i < 2 * n_heads * half; i += blockDim.x) {
+        const int sec = i / (n_heads * half), rem = i % (n_heads * half);
+        const int h = rem / half, d = rem % half;
+        bf16_t* p = base + sec * C + h * hd + d;
+        const float x1 = bf2f(p[0]), x2 = bf2f(p[half]);
+        const float c = cos_t[(size_t)row * half + d], s = sin_t[(size_t)row * half + d];
+        p[0] = f2bf(x1 * c + (-x2) * s);
+        p[half] = f2bf(x2 * c + x1 * s);
+    }
+}
+
+// V^T for the attention kernel: vt[h][d][row] = qkv[row][2C + h*hd + d]; 64 rows x one head per block via LDS
+__global__ __launch_bounds__(256) void k_vit_vtranspose(const bf16_t* qkv, int n_rows, int n_heads, int hd, bf16_t* vt,
+                                                        int vt_stride) {
+    __shared__ bf16_t tile[64][130];
+    const int r0 = blockIdx.x * 64, h = blockIdx.y, C = n_heads * hd;
+    for (int i = threadIdx.x; i < 64 * hd; i += 256) {
+        const int r = i / hd, d = i % hd;
+        tile[r][d] = (r0 + r < n_rows) ? qkv[(size_t)(r0 + r) * 3 * C + 2 * C + h * hd + d] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < hd * 64; i += 256) {
+        const int d = i / 64, r = i % 64;
+        vt[((size_t)h * hd + d) * vt_stride + r0 + r] = tile[r][d];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- LM mRoPE (hf:486-599)
+// cos/sin are bf16 (hf:538); q*cos, rot(q)*sin and their sum are three separate bf16 ops -> three roundings.
+__device__ __forceinline__ void rope_pair_bf16(float x1, float x2, float c, float s, float& o1, float& o2) {
+    o1 = rbf(rbf(x1 * c) + rbf((-x2) * s));
+    o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
+}
+
+__global__ __launch_bounds__(256) void k_lm_rope_prefill(LmRopeArgs p) {
+    __shared__ float cs[64], sn[64];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) {
+        const int axis = tid < p.sec0 ? 0 : (tid < p.sec1 ? 1 : 2);
+        const float ang = (float)p.pos3[(size_t)axis * p.n_tok + t] * p.inv_freq[tid];
+        cs[tid] = rbf(cosf(ang));
+        sn[tid] = rbf(sinf(ang));
+    }
+    __syncthreads();
+    const int HQ = p.n_q_heads, HK = p.n_kv_heads;
+    bf16_t* row = p.qkv + (size_t)t * (HQ + 2 * HK) * 128;
+    const int slot = p.tok_slot[t], idx = p.tok_idx[t];
+    for (int i = tid; i < (HQ + HK) * 64; i += 256) {
+        const int h = i >> 6, d = i & 63;
+        bf16_t* q = row + h * 128 + d;
+        float o1, o2;
+        rope_pair_bf16(bf2f(q[0]), bf2f(q[64]), cs[d], sn[d], o1, o2);
+        if (h < HQ) {
+            q[0] = f2bf(o1);
+            q[64] = f2bf(o2);
+        } else {
+            bf16_t* kc = p.kcache + ((size_t)(slot * HK + (h - HQ)) * p.ctx_max + idx) * 128 + d;
+            kc[0] = f2bf(o1);
+            kc[64] = f2bf(o2);
+        }
+    }
+    for (int i = tid; i < HK * 128; i += 256) {
+        const int h = i >> 7, d = i & 127;
+        p.vtcache[((size_t)(slot * HK + h) * 128 + d) * p.ctx_max + idx] = row[(HQ + HK) * 128 + i];
+    }
+}
+
+// decode: qkv row = bf16(sum_ks part + bias) (the q/k/v Linear outputs, hf:626-629), then rope, then cache append
+__global__ __launch_bounds__(256) void k_lm_decode_qkv(LmDecodeQkvArgs p) {
+    extern __shared__ float dq[];   // [(HQ+2HK)*128] + cos[64] + sin[64]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int HQ = p.n_q_heads, HK = p.n_kv_heads, N = (HQ + 2 * HK) * 128;
+    float* cs = dq + N;
+    float* sn = cs + 64;
+    if (tid < 64) {
+        const float ang = (float)p.pos[b] * p.inv_freq[tid];
+        cs[tid] = rbf(cosf(ang));
+        sn[tid] = rbf(sinf(ang));
+    }
+    for (int n = tid; n < N; n += 256) {
+        float a = 0.f;
+        for (int ks = 0; ks < p.ksplit; ++ks) a += p.part[((size_t)ks * p.B + b) * N + n];
+        dq[n] = rbf(a + bf2f(p.bias[n]));
+    }
+    __syncthreads();
+    const int slot = p.slots ? p.slots[b] : b;
+    const int idx = p.ctx_len[b] - 1;
+    for (int i = tid; i < (HQ + HK) * 64; i += 256) {
+        const int h = i >> 6, d = i & 63;
+        float o1, o2;
+        rope_pair_bf16(dq[h * 128 + d], dq[h * 128 + d + 64], cs[d], sn[d], o1, o2);
+        if (h < HQ) {
+            bf16_t* q = p.qout + (size_t)b * HQ * 128 + h * 128 + d;
+            q[0] = f2bf(o1);
+            q[64] = f2bf(o2);
+        } else {
+            bf16_t* kc = p.kcache + ((size_t)(slot * HK + (h - HQ)) * p.ctx_max + idx) * 128 + d;
+            kc[0] = f2bf(o1);
+            kc[64] = f2bf(o2);
+        }
+    }
+    for (int i = tid; i < HK * 128; i += 256) {
+        const int h = i >> 7, d = i & 127;
+        p.vtcache[((size_t)(slot * HK + h) * 128 + d) * p.ctx_max + idx] = f2bf(dq[(HQ + HK) * 128 + i]);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- gathers
+// src >= 0: token id -> embedding row; src < 0: image feature row -(src+1)  (hf:1210-1216 masked_scatter)
+__global__ __launch_bounds__(256) void k_embed(const int* src, const bf16_t* table, const bf16_t* img, bf16_t* out, int H) {
+    const int t = blockIdx.x, s = src[t];
+    const bf16_t* from = s >= 0 ? table + (size_t)s * H : img + (size_t)(-s - 1) * H;
+    for (int c = threadIdx.x; c < H / 8; c += blockDim.x)
+        reinterpret_cast<uint4*>(out + (size_t)t * H)[c] = reinterpret_cast<const uint4*>(from)[c];
+}
+__global__ __launch_bounds__(256) void k_gather_rows(const bf16_t* in, const int* rows, bf16_t* out, int H) {
+    const int t = blockIdx.x;
+    const bf16_t* from = in + (size_t)rows[t] * H;
+    for (int c = threadIdx.x; c < H / 8; c += blockDim.x)
+        reinterpret_cast<uint4*>(out + (size_t)t * H)[c] = reinterpret_cast<const uint4*>(from)[c];
+}
+
+// uint8 HWC image -> normalised bf16 patches [N, ld_out], rows in (gh/m, gw/m, m, m) order, cols (C, T, p, p)
+// (hf: models/qwen2_vl/image_processing_pil_qwen2_vl.py:153-185); lut[c*256+u] = bf16((u/255 - mean_c)/std_c)
+__global__ __launch_bounds__(256) void k_patchify(const uint8_t* img, int h, int w, const bf16_t* lut, bf16_t* out,
+                                                  int ld_out, int P, int mg, int T) {
+    const int row = blockIdx.x;
+    const int gw = w / P;
+    const int mw = row % mg, mh = (row / mg) % mg, bw = (row / (mg * mg)) % (gw / mg), bh = row / (mg * mg * (gw / mg));
+    const int y0 = (bh * mg + mh) * P, x0 = (bw * mg + mw) * P;
+    const int ncol = 3 * T * P * P;
+    for (int col = threadIdx.x; col < ld_out; col += blockDim.x) {
+        bf16_t v = 0;
+        if (col < ncol) {
+            const int px = col % P, py = (col / P) % P, c = col / (T * P * P);
+            v = lut[c * 256 + img[((size_t)(y0 + py) * w + x0 + px) * 3 + c]];
+        }
+        out[(size_t)row * ld_out + col] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_f32_to_bf16_pad(const float* in, int cols, bf16_t* out, int ld_out) {
+    const int row = blockIdx.x;
+    for (int c = threadIdx.x; c < ld_out; c += blockDim.x)
+        out[(size_t)row * ld_out + c] = c < cols ? f2bf(in[(size_t)row * cols + c]) : (bf16_t)0;
+}
+
+// ----------------------------------------------------------------------------------------------- greedy argmax
+// lowest index among the maxima (torch.argmax on the reference's CPU path)
+__global__ __launch_bounds__(1024) void k_argmax(const float* logits, int V, int* out_idx) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const float* row = logits + (size_t)blockIdx.x * V;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        const float v = row[i];
+        if (v > bv) { bv = v; bi = i; }   // strided ascending scan keeps the lowest index per thread
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+            if (sv[k] > bv || (sv[k] == bv && si[k] < bi)) { bv = sv[k]; bi = si[k]; }
+        out_idx[blockIdx.x] = bi;
+    }
+}
+
+// per-step bookkeeping on the device so that one captured graph replays for every step
+__global__ void k_step_advance(StepArgs a) {
+    const int b = threadIdx.x;
+    const int step = *a.step;
+    if (b < a.B) {
+        int tok = a.argmax[b];
+        const int fin = a.finished[b];
+        if (fin) tok = a.pad_id;
+        if (step < a.max_new) a.tokens_out[(size_t)b * a.max_new + step] = tok;
+        bool is_eos = false;
+        for (int k = 0; k < a.n_eos; ++k) is_eos |= (tok == a.eos[k]);
+        if (!fin && is_eos) a.finished[b] = 1;
+        a.cur_tok[b] = tok;
+        int feed = tok;
+        if (a.forced && step < a.max_new) feed = a.forced[(size_t)b * a.max_new + step];
+        a.embed_src[b] = fin ? 0 : feed;
+        if (!fin && !is_eos) { a.ctx_len[b] += 1; a.pos[b] += 1; }
+    }
+    __syncthreads();
+    if (b == 0) *a.step = step + 1;
+}
+
+// counter-based synthetic weights; definition shared with oracle/weights.py (independent implementations)
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void k_synth_fill(bf16_t* out, long long n, uint32_t key, float base, float scale) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const uint32_t h = mix32((uint32_t)i * 0x9E3779B1u + key);
+        const int s = (int)((h & 255u) + ((h >> 8) & 255u) + ((h >> 16) & 255u) + (h >> 24)) - 510;
+        out[i] = f2bf(base + (float)s * scale);
+    }
+}
+
+// weight loader: HF tensor [rows, cols] (bf16 or f32) -> engine layout.  mode 0: dst row = r + row_off;
+// mode 1 / 2: gate / up rows interleaved in blocks of 16 (dst row = (r/16)*32 + r%16 (+16 for up))
+__global__ __launch_bounds__(256) void k_load2d(const void* src, int dtype, long long rows, long long cols, bf16_t* dst,
+                                                long long dst_ld, int mode, long long row_off) {
+    const long long n = rows * cols;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / cols, c = i % cols;
+        const long long dr = mode == 0 ? r + row_off : (r / 16) * 32 + (r % 16) + (mode == 2 ? 16 : 0);
+        const bf16_t v = dtype == 0 ? reinterpret_cast<const bf16_t*>(src)[i] : f2bf(reinterpret_cast<const float*>(src)[i]);
+        dst[dr * dst_ld + c] = v;
+    }
+}
+
+}  // namespace
+
+int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, long long cols, bf16_t* dst, long long dst_ld,
+                  int mode, long long row_off) {
+    const long long n = rows * cols;
+    if (n <= 0) return 0;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_load2d, dim3((unsigned)blocks), dim3(256), 0, s, src, dtype, rows, cols, dst, dst_ld, mode, row_off);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int H, float eps) {
+    if (rows <= 0) return 0;
+    if (H % 8 != 0 || H > 64 * 8 * 12) return -22;
+    dim3 g(cdiv(rows, 4)), b(256);
+    if (H <= 2048) hipLaunchKernelGGL((k_rmsnorm<4>), g, b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps);
+    else hipLaunchKernelGGL((k_rmsnorm<12>), g, b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_resid_rmsnorm(hipStream_t s, bf16_t* x, const float* part, int ksplit, const bf16_t* w, bf16_t* out, int rows,
+                         int H, float eps) {
+    if (rows <= 0) return 0;
+    if (H % 8 != 0 || H > 2048) return -22;
+    hipLaunchKernelGGL((k_rmsnorm<4>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, (const bf16_t*)x, part, ksplit, w, out, rows, H, eps);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_vit_rope(hipStream_t s, bf16_t* qkv, int n_rows, int n_heads, int head_dim, const float* cos_t,
+                    const float* sin_t, bf16_t* vt, int vt_stride) {
+    if (n_rows <= 0) return 0;
+    if (head_dim > 128) return -22;
+    hipLaunchKernelGGL(k_vit_rope, dim3(n_rows), dim3(256), 0, s, qkv, n_rows, n_heads, head_dim, cos_t, sin_t);
+    hipLaunchKernelGGL(k_vit_vtranspose, dim3(cdiv(n_rows, 64), n_heads), dim3(256), 0, s, (const bf16_t*)qkv, n_rows, n_heads,
+                       head_dim, vt, vt_stride);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_lm_rope_prefill(hipStream_t s, const LmRopeArgs& a) {
+    if (a.n_tok <= 0) return 0;
+    hipLaunchKernelGGL(k_lm_rope_prefill, dim3(a.n_tok), dim3(256), 0, s, a);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_lm_decode_qkv(hipStream_t s, const LmDecodeQkvArgs& a) {
+    if (a.B <= 0) return 0;
+    const size_t smem = ((size_t)(a.n_q_heads + 2 * a.n_kv_heads) * 128 + 128) * sizeof(float);
+    hipLaunchKernelGGL(k_lm_decode_qkv, dim3(a.B), dim3(256), smem, s, a);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_embed(hipStream_t s, const int* src, const bf16_t* table, const bf16_t* image_embeds, bf16_t* out, int n_tok, int H) {
+    if (n_tok <= 0) return 0;
+    hipLaunchKernelGGL(k_embed, dim3(n_tok), dim3(256), 0, s, src, table, image_embeds, out, H);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_gather_rows(hipStream_t s, const bf16_t* in, const int* rows, bf16_t* out, int n, int H) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_gather_rows, dim3(n), dim3(256), 0, s, in, rows, out, H);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_patchify(hipStream_t s, const uint8_t* img, int h, int w, const bf16_t* lut, bf16_t* out, int ld_out, int patch,
+                    int merge, int temporal) {
+    const int n = (h / patch) * (w / patch);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_patchify, dim3(n), dim3(256), 0, s, img, h, w, lut, out, ld_out, patch, merge, temporal);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_f32_to_bf16_pad(hipStream_t s, const float* in, int rows, int cols, bf16_t* out, int ld_out) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_f32_to_bf16_pad, dim3(rows), dim3(256), 0, s, in, cols, out, ld_out);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_argmax(hipStream_t s, const float* logits, int rows, int V, int* out_idx) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_argmax, dim3(rows), dim3(1024), 0, s, logits, V, out_idx);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_step_advance(hipStream_t s, const StepArgs& a) {
+    hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(64), 0, s, a);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_synth_fill(hipStream_t s, bf16_t* out, long long n, uint32_t key, float base, float scale) {
+    if (n <= 0) return 0;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_synth_fill, dim3((unsigned)blocks), dim3(256), 0, s, out, n, key, base, scale);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_fill_zero(hipStream_t s, void* p, size_t bytes) { return (int)hipMemsetAsync(p, 0, bytes, s); }

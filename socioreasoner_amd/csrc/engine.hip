@@ -1,0 +1,871 @@
+// libsocior engine: the C ABI of include/socior.h and the host-side orchestration of the hot path
+// (ViT -> merger -> LM prefill -> greedy decode), one engine per GPU/process.
+//
+// What it replaces in the reference (paths relative to /root/reference): the engine behind
+// VllmStrategy.generate (roll/distributed/strategy/vllm_strategy.py:114-141), i.e. vLLM's Qwen2.5-VL executor; the
+// arithmetic follows HF's eager implementation (`hf:` = transformers/models/qwen2_5_vl/modeling_qwen2_5_vl.py) which
+// is the reference's CPU/eager path (roll/distributed/strategy/hf_strategy.py:49-94).
+//
+// Memory: one caller-provided workspace carved by a bump allocator: weights (engine layout), activations sized by the
+// capacities in sr_config, KV cache (K [layer][slot][kvh][ctx][128], V^T [layer][slot][kvh][128][ctx]), control arrays.
+// Decode runs from device-resident state (ctx_len, positions, current token, step) so that ONE captured hipGraph
+// replays for every step (launch-bound inner loop -> graph, per the MI355X guide).
+#include "../../include/socior.h"
+#include "kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "ok";
+
+struct VitBlockW { bf16_t *norm1, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2, *gu_w, *gu_b, *down_w, *down_b; };
+struct LmLayerW { bf16_t *ln1, *qkv_w, *qkv_b, *o_w, *ln2, *gu_w, *down_w; };
+
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0, cap = 0;
+    template <class T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+inline int rup(int a, int b) { return (a + b - 1) / b * b; }
+
+uint32_t fnv1a32(const char* s) {
+    uint32_t h = 2166136261u;
+    for (; *s; ++s) { h ^= (unsigned char)*s; h *= 16777619u; }
+    return h;
+}
+uint32_t mix32h(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+bf16_t host_f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+}  // namespace
+
+struct sr_engine {
+    sr_config c;
+    // derived geometry
+    int v_hd, v_pd, v_pd_pad, v_inter_pad, v_mh, t_inter_pad, t_qn, t_group;
+    int ks_h, ks_q, ks_down;     // split-K factors of the decode GEMVs
+    Arena ar;
+    size_t weights_begin = 0, weights_end = 0;
+    // ---- weights
+    bf16_t* patch_w;
+    std::vector<VitBlockW> vb;
+    bf16_t *ln_q, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+    bf16_t *embed, *final_norm;
+    std::vector<LmLayerW> ll;
+    bf16_t* lut;       // [3*256] normalise LUT
+    float* inv_freq;   // [64]
+    // ---- ViT activations
+    bf16_t *v_pix, *v_x, *v_xn, *v_qkv, *v_attn, *v_act, *v_vt, *v_m1;
+    int v_vt_stride;
+    float *v_cos, *v_sin;
+    int *v_rowmap_embed, *v_rowmap_merge;
+    AttnWork *v_work_win, *v_work_full;
+    int v_nwork_win = 0, v_nwork_full = 0;
+    std::vector<int64_t> v_grid_cached;
+    // ---- LM activations
+    bf16_t *t_x, *t_xn, *t_qkv, *t_attn, *t_act;
+    int *t_src, *t_pos3, *t_slot, *t_idx, *t_lastrow;
+    AttnWork* t_work;
+    // ---- decode state (device)
+    bf16_t *d_x, *d_xn, *d_q, *d_attn, *d_act;
+    float *d_logits, *d_part_qkv, *d_part_o, *d_part_down;
+    int *d_argmax, *d_cur_tok, *d_embed_src, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
+    int* d_state_init;   // staging copy of [ctx_len | pos | slots] uploaded by prefill
+    bf16_t *kcache, *vtcache;
+    size_t kv_layer_elems;
+    // ---- host staging (pinned) + its device mirror
+    char* h_stage = nullptr;
+    size_t stage_bytes = 0;
+    char* d_stage = nullptr;
+    hipEvent_t ev_copy = nullptr;
+    bool copy_pending = false;
+    // ---- decode graph cache
+    hipGraphExec_t graph = nullptr;
+    int graph_B = -1, graph_neos = -1, graph_pad = 0;
+    // ---- bookkeeping
+    std::map<std::string, bool> loaded;
+    char err[512];
+};
+
+namespace {
+
+int fail(sr_engine* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    snprintf(g_err, sizeof g_err, "%s", buf);
+    if (e) snprintf(e->err, sizeof e->err, "%s", buf);
+    return code;
+}
+#define SR_TRY(expr)                                                                                          \
+    do {                                                                                                      \
+        int rc_ = (expr);                                                                                     \
+        if (rc_ != 0) return fail(e, rc_, "%s failed with %d (%s) at %s:%d", #expr, rc_,                       \
+                                  rc_ > 0 ? hipGetErrorString((hipError_t)rc_) : "invalid argument", __FILE__, __LINE__); \
+    } while (0)
+
+const char* validate(const sr_config& c) {
+    if (c.v_hidden <= 0 || c.v_heads <= 0 || c.v_hidden % c.v_heads) return "v_hidden/v_heads";
+    const int hd = c.v_hidden / c.v_heads;
+    if (hd != 80 && hd != 128) return "vision head_dim must be 80 or 128";
+    if (c.v_hidden % 64) return "v_hidden must be a multiple of 64";
+    if (c.v_merge != 2 || c.v_temporal < 1 || c.v_patch < 1) return "v_merge must be 2";
+    if (c.v_out_hidden != c.t_hidden) return "v_out_hidden must equal t_hidden";
+    if (c.t_head_dim != 128) return "t_head_dim must be 128";
+    if (c.t_hidden % 64 || c.t_vocab % 16) return "t_hidden % 64, t_vocab % 16";
+    if (c.t_heads % c.t_kv_heads || c.t_heads / c.t_kv_heads > 16) return "GQA group must divide and be <= 16";
+    if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] != 64) return "mrope_section must sum to 64";
+    if (c.max_batch < 1 || c.max_batch > 32) return "max_batch in 1..32";
+    if (c.max_ctx < 64 || c.max_ctx % 64) return "max_ctx multiple of 64";
+    if (c.max_patches < 4 || c.max_patches % 4 || c.max_prefill_tokens < 1 || c.max_new_tokens < 1) return "capacities";
+    if (c.v_n_fullatt < 0 || c.v_n_fullatt > 16 || c.v_depth < 1 || c.t_layers < 1) return "depths";
+    return nullptr;
+}
+
+int pick_ks(int K) {
+    const int ch = K / 64;
+    for (int ks : {4, 2}) if (ch % ks == 0 && ch / ks >= 2) return ks;
+    return 1;
+}
+
+// Carves every buffer.  With ar.base == nullptr this is a dry run that only measures.
+void carve(sr_engine* e) {
+    const sr_config& c = e->c;
+    Arena& ar = e->ar;
+    e->v_hd = c.v_hidden / c.v_heads;
+    e->v_pd = c.v_in_ch * c.v_temporal * c.v_patch * c.v_patch;
+    e->v_pd_pad = rup(e->v_pd, 64);
+    e->v_inter_pad = rup(c.v_inter, 64);
+    e->v_mh = c.v_hidden * c.v_merge * c.v_merge;
+    e->t_inter_pad = rup(c.t_inter, 64);
+    e->t_qn = (c.t_heads + 2 * c.t_kv_heads) * 128;
+    e->t_group = c.t_heads / c.t_kv_heads;
+    e->ks_h = pick_ks(c.t_hidden);
+    e->ks_q = pick_ks(c.t_heads * 128);
+    e->ks_down = pick_ks(e->t_inter_pad);
+    const int C = c.v_hidden, H = c.t_hidden;
+
+    e->weights_begin = (ar.off + 255) & ~(size_t)255;
+    e->patch_w = ar.take<bf16_t>((size_t)C * e->v_pd_pad);
+    e->vb.resize(c.v_depth);
+    for (auto& b : e->vb) {
+        b.norm1 = ar.take<bf16_t>(C);
+        b.qkv_w = ar.take<bf16_t>((size_t)3 * C * C);
+        b.qkv_b = ar.take<bf16_t>(3 * C);
+        b.proj_w = ar.take<bf16_t>((size_t)C * C);
+        b.proj_b = ar.take<bf16_t>(C);
+        b.norm2 = ar.take<bf16_t>(C);
+        b.gu_w = ar.take<bf16_t>((size_t)2 * e->v_inter_pad * C);
+        b.gu_b = ar.take<bf16_t>(2 * e->v_inter_pad);
+        b.down_w = ar.take<bf16_t>((size_t)C * e->v_inter_pad);
+        b.down_b = ar.take<bf16_t>(C);
+    }
+    e->ln_q = ar.take<bf16_t>(C);
+    e->fc1_w = ar.take<bf16_t>((size_t)e->v_mh * e->v_mh);
+    e->fc1_b = ar.take<bf16_t>(e->v_mh);
+    e->fc2_w = ar.take<bf16_t>((size_t)c.v_out_hidden * e->v_mh);
+    e->fc2_b = ar.take<bf16_t>(c.v_out_hidden);
+    e->embed = ar.take<bf16_t>((size_t)c.t_vocab * H);
+    e->final_norm = ar.take<bf16_t>(H);
+    e->ll.resize(c.t_layers);
+    for (auto& l : e->ll) {
+        l.ln1 = ar.take<bf16_t>(H);
+        l.qkv_w = ar.take<bf16_t>((size_t)e->t_qn * H);
+        l.qkv_b = ar.take<bf16_t>(e->t_qn);
+        l.o_w = ar.take<bf16_t>((size_t)H * c.t_heads * 128);
+        l.ln2 = ar.take<bf16_t>(H);
+        l.gu_w = ar.take<bf16_t>((size_t)2 * e->t_inter_pad * H);
+        l.down_w = ar.take<bf16_t>((size_t)H * e->t_inter_pad);
+    }
+    e->lut = ar.take<bf16_t>(3 * 256);
+    e->inv_freq = ar.take<float>(64);
+    e->weights_end = ar.off;
+
+    // ViT activations
+    const size_t NP = c.max_patches;
+    e->v_pix = ar.take<bf16_t>(NP * e->v_pd_pad);
+    e->v_x = ar.take<bf16_t>(NP * C);
+    e->v_xn = ar.take<bf16_t>(NP * C);
+    e->v_qkv = ar.take<bf16_t>(NP * 3 * C);
+    e->v_attn = ar.take<bf16_t>(NP * C);
+    e->v_act = ar.take<bf16_t>(NP * e->v_inter_pad);
+    e->v_vt_stride = rup((int)NP, 64) + 64;
+    e->v_vt = ar.take<bf16_t>((size_t)C * e->v_vt_stride);
+    e->v_m1 = ar.take<bf16_t>(NP / 4 * e->v_mh);
+    e->v_cos = ar.take<float>(NP * (e->v_hd / 2));
+    e->v_sin = ar.take<float>(NP * (e->v_hd / 2));
+    e->v_rowmap_embed = ar.take<int>(NP);
+    e->v_rowmap_merge = ar.take<int>(NP / 4);
+    e->v_work_win = ar.take<AttnWork>(NP / 4 + 64);
+    e->v_work_full = ar.take<AttnWork>(NP / 64 + 64);
+
+    // LM prefill activations
+    const size_t TP = c.max_prefill_tokens;
+    e->t_x = ar.take<bf16_t>(TP * H);
+    e->t_xn = ar.take<bf16_t>(TP * H);
+    e->t_qkv = ar.take<bf16_t>(TP * e->t_qn);
+    e->t_attn = ar.take<bf16_t>(TP * c.t_heads * 128);
+    e->t_act = ar.take<bf16_t>(TP * e->t_inter_pad);
+    e->t_src = ar.take<int>(TP);
+    e->t_pos3 = ar.take<int>(3 * TP);
+    e->t_slot = ar.take<int>(TP);
+    e->t_idx = ar.take<int>(TP);
+    e->t_lastrow = ar.take<int>(32);
+    e->t_work = ar.take<AttnWork>(TP / 64 + 64);
+
+    // decode
+    const size_t B = c.max_batch;
+    e->d_x = ar.take<bf16_t>(B * H);
+    e->d_xn = ar.take<bf16_t>(B * H);
+    e->d_q = ar.take<bf16_t>(B * c.t_heads * 128);
+    e->d_attn = ar.take<bf16_t>(B * c.t_heads * 128);
+    e->d_act = ar.take<bf16_t>(B * e->t_inter_pad);
+    e->d_logits = ar.take<float>(B * c.t_vocab);
+    e->d_part_qkv = ar.take<float>(4 * B * e->t_qn);
+    e->d_part_o = ar.take<float>(4 * B * H);
+    e->d_part_down = ar.take<float>(4 * B * H);
+    e->d_argmax = ar.take<int>(32);
+    e->d_cur_tok = ar.take<int>(32);
+    e->d_embed_src = ar.take<int>(32);
+    e->d_ctx_len = ar.take<int>(32);
+    e->d_pos = ar.take<int>(32);
+    e->d_finished = ar.take<int>(32);
+    e->d_step = ar.take<int>(32);
+    e->d_slots = ar.take<int>(32);
+    e->d_eos = ar.take<int>(32);
+    e->d_state_init = ar.take<int>(3 * 32);
+    e->d_tokens = ar.take<int>(B * c.max_new_tokens);
+    e->kv_layer_elems = B * c.t_kv_heads * (size_t)c.max_ctx * 128;
+    e->kcache = ar.take<bf16_t>(e->kv_layer_elems * c.t_layers);
+    e->vtcache = ar.take<bf16_t>(e->kv_layer_elems * c.t_layers);
+
+    // control staging: ViT needs NP*(8 + 4*hd) + work lists; prefill needs ~24 B per token + work lists
+    e->stage_bytes = NP * (8 + 4 * (size_t)e->v_hd) + (NP / 4 + NP / 64 + 128) * sizeof(AttnWork) + TP * 28 +
+                     (TP / 64 + 64) * sizeof(AttnWork) + 4096;
+    e->d_stage = ar.take<char>(e->stage_bytes);
+}
+
+void register_expected(sr_engine* e) {
+    const sr_config& c = e->c;
+    char n[160];
+    auto add = [&](const char* s) { e->loaded[s] = false; };
+    add("visual.patch_embed.proj.weight");
+    for (int i = 0; i < c.v_depth; ++i)
+        for (const char* s : {"norm1.weight", "norm2.weight", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
+                              "attn.proj.bias", "mlp.gate_proj.weight", "mlp.gate_proj.bias", "mlp.up_proj.weight",
+                              "mlp.up_proj.bias", "mlp.down_proj.weight", "mlp.down_proj.bias"}) {
+            snprintf(n, sizeof n, "visual.blocks.%d.%s", i, s);
+            add(n);
+        }
+    for (const char* s : {"visual.merger.ln_q.weight", "visual.merger.mlp.0.weight", "visual.merger.mlp.0.bias",
+                          "visual.merger.mlp.2.weight", "visual.merger.mlp.2.bias", "model.embed_tokens.weight",
+                          "model.norm.weight"})
+        add(s);
+    for (int i = 0; i < c.t_layers; ++i)
+        for (const char* s : {"input_layernorm.weight", "post_attention_layernorm.weight", "self_attn.q_proj.weight",
+                              "self_attn.q_proj.bias", "self_attn.k_proj.weight", "self_attn.k_proj.bias",
+                              "self_attn.v_proj.weight", "self_attn.v_proj.bias", "self_attn.o_proj.weight",
+                              "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"}) {
+            snprintf(n, sizeof n, "model.layers.%d.%s", i, s);
+            add(n);
+        }
+}
+
+// waits until the previous control upload has left the pinned staging buffer
+int stage_begin(sr_engine* e) {
+    if (e->copy_pending) {
+        hipError_t r = hipEventSynchronize(e->ev_copy);
+        if (r != hipSuccess) return (int)r;
+        e->copy_pending = false;
+    }
+    return 0;
+}
+int stage_upload(sr_engine* e, size_t off, size_t bytes, hipStream_t s) {
+    hipError_t r = hipMemcpyAsync(e->d_stage + off, e->h_stage + off, bytes, hipMemcpyHostToDevice, s);
+    if (r != hipSuccess) return (int)r;
+    r = hipEventRecord(e->ev_copy, s);
+    if (r != hipSuccess) return (int)r;
+    e->copy_pending = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ ViT control data
+// window index / cu_seqlens / rotary tables: hf vision_utils.get_vision_window_index (transformers/vision_utils.py:130-188),
+// get_vision_position_ids, Qwen2_5_VisionRotaryEmbedding (hf:125-134), written from the definitions.
+int vit_prepare(sr_engine* e, const int64_t* grid, int n_img, hipStream_t s, int* n_rows_out) {
+    const sr_config& c = e->c;
+    int N = 0;
+    for (int i = 0; i < n_img; ++i) {
+        if (grid[3 * i] != 1) return fail(e, -22, "grid t must be 1 (images only)");
+        const int h = (int)grid[3 * i + 1], w = (int)grid[3 * i + 2];
+        if (h <= 0 || w <= 0 || h % c.v_merge || w % c.v_merge) return fail(e, -22, "grid h,w must be multiples of merge");
+        N += h * w;
+    }
+    if (N > c.max_patches) return fail(e, -22, "%d patches exceed max_patches %d", N, c.max_patches);
+    *n_rows_out = N;
+    std::vector<int64_t> key(grid, grid + 3 * n_img);
+    if (key == e->v_grid_cached) return 0;
+
+    SR_TRY(stage_begin(e));
+    const int half = e->v_hd / 2, nf = half / 2;        // 40 rotary values per row = 20 h-freqs + 20 w-freqs
+    const int mg = c.v_merge, unit = mg * mg;
+    const int ws = c.v_window / mg / c.v_patch;          // window side in merged units (4)
+    std::vector<float> inv(nf);
+    for (int i = 0; i < nf; ++i) inv[i] = (float)(1.0 / pow(10000.0, (double)(2 * i) / (double)half));
+
+    char* hp = e->h_stage;
+    float* h_cos = reinterpret_cast<float*>(hp);
+    float* h_sin = h_cos + (size_t)N * half;
+    int* h_rm_embed = reinterpret_cast<int*>(h_sin + (size_t)N * half);
+    int* h_rm_merge = h_rm_embed + N;
+    AttnWork* h_win = reinterpret_cast<AttnWork*>(((uintptr_t)(h_rm_merge + N / unit) + 15) & ~(uintptr_t)15);
+    int n_win = 0;
+    std::vector<AttnWork> full;
+
+    int unit_base = 0, row_base = 0, new_unit = 0;
+    for (int im = 0; im < n_img; ++im) {
+        const int gh = (int)grid[3 * im + 1], gw = (int)grid[3 * im + 2];
+        const int lh = gh / mg, lw = gw / mg;
+        const int nh = (lh + (ws - lh % ws)) / ws, nw = (lw + (ws - lw % ws)) / ws;   // HF pads a full window when aligned
+        for (int wy = 0; wy < nh; ++wy)
+            for (int wx = 0; wx < nw; ++wx) {
+                const int start_unit = new_unit;
+                for (int iy = 0; iy < ws; ++iy)
+                    for (int ix = 0; ix < ws; ++ix) {
+                        const int uy = wy * ws + iy, ux = wx * ws + ix;
+                        if (uy >= lh || ux >= lw) continue;
+                        const int old_unit = unit_base + uy * lw + ux;
+                        h_rm_merge[new_unit] = old_unit;                      // merger output row of window-order unit
+                        for (int k = 0; k < unit; ++k) {
+                            const int old_row = old_unit * unit + k, new_row = new_unit * unit + k;
+                            h_rm_embed[old_row] = new_row;
+                            const int py = uy * mg + k / mg, px = ux * mg + k % mg;     // patch (h, w) position
+                            for (int f = 0; f < nf; ++f) {
+                                const float ah = (float)py * inv[f], aw = (float)px * inv[f];
+                                h_cos[(size_t)new_row * half + f] = cosf(ah);
+                                h_sin[(size_t)new_row * half + f] = sinf(ah);
+                                h_cos[(size_t)new_row * half + nf + f] = cosf(aw);
+                                h_sin[(size_t)new_row * half + nf + f] = sinf(aw);
+                            }
+                        }
+                        ++new_unit;
+                    }
+                const int len = (new_unit - start_unit) * unit;
+                for (int q0 = 0; q0 < len; q0 += 64)
+                    h_win[n_win++] = AttnWork{start_unit * unit + q0, len, q0, start_unit * unit, (long long)start_unit * unit};
+            }
+        const int len = gh * gw;
+        for (int q0 = 0; q0 < len; q0 += 64) full.push_back(AttnWork{row_base + q0, len, q0, row_base, (long long)row_base});
+        unit_base += lh * lw;
+        row_base += len;
+    }
+    AttnWork* h_full = h_win + n_win;
+    memcpy(h_full, full.data(), full.size() * sizeof(AttnWork));
+    const size_t total = reinterpret_cast<char*>(h_full + full.size()) - hp;
+    if (total > e->stage_bytes) return fail(e, -12, "control staging too small");
+    SR_TRY(stage_upload(e, 0, total, s));
+    // device-side views into the mirror; copied out so that later prefill uploads cannot clobber them
+    auto dmirror = [&](const void* hptr) { return e->d_stage + (reinterpret_cast<const char*>(hptr) - hp); };
+    SR_TRY((int)hipMemcpyAsync(e->v_cos, dmirror(h_cos), (size_t)N * half * 4, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->v_sin, dmirror(h_sin), (size_t)N * half * 4, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->v_rowmap_embed, dmirror(h_rm_embed), (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->v_rowmap_merge, dmirror(h_rm_merge), (size_t)N / unit * 4, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->v_work_win, dmirror(h_win), n_win * sizeof(AttnWork), hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->v_work_full, dmirror(h_full), full.size() * sizeof(AttnWork), hipMemcpyDeviceToDevice, s));
+    e->v_nwork_win = n_win;
+    e->v_nwork_full = (int)full.size();
+    e->v_grid_cached = key;
+    return 0;
+}
+
+bool is_fullatt(const sr_config& c, int blk) {
+    for (int i = 0; i < c.v_n_fullatt; ++i) if (c.v_fullatt[i] == blk) return true;
+    return false;
+}
+
+int gemm(sr_engine* e, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, void* out, int ldo,
+         const bf16_t* bias, const bf16_t* resid, const int* rowmap, int epi) {
+    GemmArgs a{A, lda, W, M, N, K, out, ldo, bias, resid, rowmap};
+    SR_TRY(launch_gemm(s, a, epi));
+    return 0;
+}
+
+// one decode forward pass for rows 0..B-1 (device state decides tokens / positions / context lengths)
+int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
+    const sr_config& c = e->c;
+    const int H = c.t_hidden, QD = c.t_heads * 128;
+    SR_TRY(launch_embed(s, e->d_embed_src, e->embed, nullptr, e->d_x, B, H));
+    for (int l = 0; l < c.t_layers; ++l) {
+        const LmLayerW& w = e->ll[l];
+        if (l == 0) SR_TRY(launch_rmsnorm(s, e->d_x, w.ln1, e->d_xn, B, H, c.t_rms_eps));
+        else SR_TRY(launch_resid_rmsnorm(s, e->d_x, e->d_part_down, e->ks_down, w.ln1, e->d_xn, B, H, c.t_rms_eps));
+        GemvArgs gq{e->d_xn, H, w.qkv_w, B, e->t_qn, H, e->d_part_qkv, e->ks_h};
+        SR_TRY(launch_gemv(s, gq, GV_PARTIAL));
+        bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
+        bf16_t* vc = e->vtcache + (size_t)l * e->kv_layer_elems;
+        LmDecodeQkvArgs qa{e->d_part_qkv, e->ks_h, w.qkv_b, B, c.t_heads, c.t_kv_heads, e->d_pos, e->d_ctx_len, e->d_slots,
+                           e->inv_freq, e->d_q, kc, vc, c.max_ctx};
+        SR_TRY(launch_lm_decode_qkv(s, qa));
+        DecodeAttnArgs da{e->d_q, QD, kc, vc, e->d_ctx_len, e->d_slots, e->d_attn, QD, B, c.t_kv_heads, e->t_group, c.max_ctx,
+                          (float)(1.0 / sqrt(128.0))};
+        SR_TRY(launch_attn_decode(s, da));
+        GemvArgs go{e->d_attn, QD, w.o_w, B, H, QD, e->d_part_o, e->ks_q};
+        SR_TRY(launch_gemv(s, go, GV_PARTIAL));
+        SR_TRY(launch_resid_rmsnorm(s, e->d_x, e->d_part_o, e->ks_q, w.ln2, e->d_xn, B, H, c.t_rms_eps));
+        GemvArgs gg{e->d_xn, H, w.gu_w, B, 2 * e->t_inter_pad, H, e->d_act, 1};
+        SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
+        GemvArgs gd{e->d_act, e->t_inter_pad, w.down_w, B, H, e->t_inter_pad, e->d_part_down, e->ks_down};
+        SR_TRY(launch_gemv(s, gd, GV_PARTIAL));
+    }
+    SR_TRY(launch_resid_rmsnorm(s, e->d_x, e->d_part_down, e->ks_down, e->final_norm, e->d_xn, B, H, c.t_rms_eps));
+    GemvArgs gl{e->d_xn, H, e->embed, B, c.t_vocab, H, e->d_logits, 1};
+    SR_TRY(launch_gemv(s, gl, GV_F32));
+    SR_TRY(launch_argmax(s, e->d_logits, B, c.t_vocab, e->d_argmax));
+    return 0;
+}
+
+int enqueue_step_advance(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, hipStream_t s) {
+    StepArgs a{e->d_argmax, e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished, e->d_tokens,
+               e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, e->d_embed_src, forced};
+    SR_TRY(launch_step_advance(s, a));
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" {
+
+int sr_version(void) { return 1; }
+
+const char* sr_last_error(const sr_engine* e) { return e ? e->err : g_err; }
+
+size_t sr_workspace_bytes(const sr_config* cfg) {
+    if (!cfg || validate(*cfg)) return 0;
+    sr_engine tmp;
+    tmp.c = *cfg;
+    carve(&tmp);
+    return tmp.ar.off + 4096;
+}
+
+int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_bytes, sr_engine** out) {
+    if (!cfg || !workspace || !out) return fail(nullptr, -22, "null argument");
+    if (const char* why = validate(*cfg)) return fail(nullptr, -22, "invalid sr_config: %s", why);
+    if ((uintptr_t)workspace & 255) return fail(nullptr, -22, "workspace must be 256-byte aligned");
+    sr_engine* e = new sr_engine();
+    e->c = *cfg;
+    snprintf(e->err, sizeof e->err, "ok");
+    e->ar.base = static_cast<char*>(workspace);
+    e->ar.cap = workspace_bytes;
+    carve(e);
+    if (e->ar.off > workspace_bytes) {
+        size_t need = e->ar.off;
+        delete e;
+        return fail(nullptr, -12, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    }
+    register_expected(e);
+    hipError_t r = hipHostMalloc(reinterpret_cast<void**>(&e->h_stage), e->stage_bytes, hipHostMallocDefault);
+    if (r != hipSuccess) { delete e; return fail(nullptr, (int)r, "hipHostMalloc: %s", hipGetErrorString(r)); }
+    r = hipEventCreateWithFlags(&e->ev_copy, hipEventDisableTiming);
+    if (r != hipSuccess) { (void)hipHostFree(e->h_stage); delete e; return fail(nullptr, (int)r, "hipEventCreate"); }
+    // zero weights (padding must be 0), KV cache (0 * stale must stay finite) and decode state
+    r = hipMemset(e->ar.base + e->weights_begin, 0, e->weights_end - e->weights_begin);
+    if (r == hipSuccess) r = hipMemset(e->kcache, 0, e->kv_layer_elems * e->c.t_layers * sizeof(bf16_t));
+    if (r == hipSuccess) r = hipMemset(e->vtcache, 0, e->kv_layer_elems * e->c.t_layers * sizeof(bf16_t));
+    if (r == hipSuccess) r = hipMemset(e->d_argmax, 0, (char*)e->d_tokens - (char*)e->d_argmax);
+    if (r == hipSuccess) r = hipMemset(e->v_vt, 0, (size_t)e->c.v_hidden * e->v_vt_stride * sizeof(bf16_t));
+    // normalise LUT (hf image_transforms.py:89-124, 384-440) and rotary inverse frequencies (hf:506-523)
+    std::vector<bf16_t> lut(768);
+    const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f}, stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+    for (int ch = 0; ch < 3; ++ch)
+        for (int u = 0; u < 256; ++u) {
+            const float x = (float)((double)u * (1.0 / 255.0));
+            lut[ch * 256 + u] = host_f2bf((x - mean[ch]) / stdv[ch]);
+        }
+    std::vector<float> inv(64);
+    for (int i = 0; i < 64; ++i) inv[i] = (float)(1.0 / pow((double)e->c.t_rope_theta, (double)(2 * i) / 128.0));
+    if (r == hipSuccess) r = hipMemcpy(e->lut, lut.data(), 768 * sizeof(bf16_t), hipMemcpyHostToDevice);
+    if (r == hipSuccess) r = hipMemcpy(e->inv_freq, inv.data(), 64 * sizeof(float), hipMemcpyHostToDevice);
+    if (r == hipSuccess) r = (hipError_t)attn_decode_prepare(e->c.max_ctx, e->t_group);
+    if (r != hipSuccess) {
+        int rc = fail(nullptr, (int)r, "engine init: %s", hipGetErrorString(r));
+        sr_engine_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return 0;
+}
+
+int sr_engine_destroy(sr_engine* e) {
+    if (!e) return 0;
+    if (e->graph) (void)hipGraphExecDestroy(e->graph);
+    if (e->ev_copy) (void)hipEventDestroy(e->ev_copy);
+    if (e->h_stage) (void)hipHostFree(e->h_stage);
+    delete e;
+    return 0;
+}
+
+int sr_weights_missing(const sr_engine* e, char* first_missing, size_t cap) {
+    int n = 0;
+    for (const auto& kv : e->loaded)
+        if (!kv.second) {
+            if (n == 0 && first_missing && cap) snprintf(first_missing, cap, "%s", kv.first.c_str());
+            ++n;
+        }
+    return n;
+}
+
+int sr_synth_fill(void* dev_out_bf16, int64_t n, const char* hf_name, uint32_t seed, float base, void* stream) {
+    const uint32_t key = mix32h(fnv1a32(hf_name) ^ mix32h(seed + 0x9E3779B9u));
+    int rc = launch_synth_fill((hipStream_t)stream, (bf16_t*)dev_out_bf16, n, key, base, 1.3531647e-4f);
+    if (rc) return fail(nullptr, rc, "synth_fill launch failed (%d)", rc);
+    return 0;
+}
+
+int sr_load_weight(sr_engine* e, const char* hf_name, const void* p, int dtype, const int64_t* shape, int ndim, void* stream) {
+    if (!e || !hf_name || !p || !shape || ndim < 1) return fail(e, -22, "sr_load_weight: null argument");
+    if (dtype != SR_DTYPE_BF16 && dtype != SR_DTYPE_F32) return fail(e, -22, "sr_load_weight: dtype");
+    hipStream_t s = (hipStream_t)stream;
+    const sr_config& c = e->c;
+    std::string name = hf_name;
+    if (name.rfind("model.visual.", 0) == 0) name = name.substr(6);
+    else if (name.rfind("model.language_model.", 0) == 0) name = "model." + name.substr(21);
+    if (name == "lm_head.weight") return 0;   // tied to model.embed_tokens.weight
+    long long rows = shape[0], cols = 1;
+    for (int i = 1; i < ndim; ++i) cols *= shape[i];
+    const int C = c.v_hidden, H = c.t_hidden;
+    bf16_t* dst = nullptr;
+    long long ld = cols, exp_rows = -1, exp_cols = -1, row_off = 0;
+    int mode = 0;
+    int idx = -1;
+    char sub[96] = "";
+    if (name == "visual.patch_embed.proj.weight") { dst = e->patch_w; ld = e->v_pd_pad; exp_rows = C; exp_cols = e->v_pd; }
+    else if (sscanf(name.c_str(), "visual.blocks.%d.%95s", &idx, sub) == 2 && idx >= 0 && idx < c.v_depth) {
+        VitBlockW& b = e->vb[idx];
+        const std::string t = sub;
+        if (t == "norm1.weight") { dst = b.norm1; exp_rows = C; exp_cols = 1; }
+        else if (t == "norm2.weight") { dst = b.norm2; exp_rows = C; exp_cols = 1; }
+        else if (t == "attn.qkv.weight") { dst = b.qkv_w; exp_rows = 3 * C; exp_cols = C; }
+        else if (t == "attn.qkv.bias") { dst = b.qkv_b; exp_rows = 3 * C; exp_cols = 1; }
+        else if (t == "attn.proj.weight") { dst = b.proj_w; exp_rows = C; exp_cols = C; }
+        else if (t == "attn.proj.bias") { dst = b.proj_b; exp_rows = C; exp_cols = 1; }
+        else if (t == "mlp.gate_proj.weight") { dst = b.gu_w; exp_rows = c.v_inter; exp_cols = C; mode = 1; }
+        else if (t == "mlp.gate_proj.bias") { dst = b.gu_b; exp_rows = c.v_inter; exp_cols = 1; mode = 1; }
+        else if (t == "mlp.up_proj.weight") { dst = b.gu_w; exp_rows = c.v_inter; exp_cols = C; mode = 2; }
+        else if (t == "mlp.up_proj.bias") { dst = b.gu_b; exp_rows = c.v_inter; exp_cols = 1; mode = 2; }
+        else if (t == "mlp.down_proj.weight") { dst = b.down_w; exp_rows = C; exp_cols = c.v_inter; ld = e->v_inter_pad; }
+        else if (t == "mlp.down_proj.bias") { dst = b.down_b; exp_rows = C; exp_cols = 1; }
+    }
+    else if (name == "visual.merger.ln_q.weight") { dst = e->ln_q; exp_rows = C; exp_cols = 1; }
+    else if (name == "visual.merger.mlp.0.weight") { dst = e->fc1_w; exp_rows = e->v_mh; exp_cols = e->v_mh; }
+    else if (name == "visual.merger.mlp.0.bias") { dst = e->fc1_b; exp_rows = e->v_mh; exp_cols = 1; }
+    else if (name == "visual.merger.mlp.2.weight") { dst = e->fc2_w; exp_rows = c.v_out_hidden; exp_cols = e->v_mh; }
+    else if (name == "visual.merger.mlp.2.bias") { dst = e->fc2_b; exp_rows = c.v_out_hidden; exp_cols = 1; }
+    else if (name == "model.embed_tokens.weight") { dst = e->embed; exp_rows = c.t_vocab; exp_cols = H; }
+    else if (name == "model.norm.weight") { dst = e->final_norm; exp_rows = H; exp_cols = 1; }
+    else if (sscanf(name.c_str(), "model.layers.%d.%95s", &idx, sub) == 2 && idx >= 0 && idx < c.t_layers) {
+        LmLayerW& l = e->ll[idx];
+        const std::string t = sub;
+        const int QD = c.t_heads * 128, KD = c.t_kv_heads * 128;
+        if (t == "input_layernorm.weight") { dst = l.ln1; exp_rows = H; exp_cols = 1; }
+        else if (t == "post_attention_layernorm.weight") { dst = l.ln2; exp_rows = H; exp_cols = 1; }
+        else if (t == "self_attn.q_proj.weight") { dst = l.qkv_w; exp_rows = QD; exp_cols = H; }
+        else if (t == "self_attn.q_proj.bias") { dst = l.qkv_b; exp_rows = QD; exp_cols = 1; }
+        else if (t == "self_attn.k_proj.weight") { dst = l.qkv_w; exp_rows = KD; exp_cols = H; row_off = QD; }
+        else if (t == "self_attn.k_proj.bias") { dst = l.qkv_b; exp_rows = KD; exp_cols = 1; row_off = QD; }
+        else if (t == "self_attn.v_proj.weight") { dst = l.qkv_w; exp_rows = KD; exp_cols = H; row_off = QD + KD; }
+        else if (t == "self_attn.v_proj.bias") { dst = l.qkv_b; exp_rows = KD; exp_cols = 1; row_off = QD + KD; }
+        else if (t == "self_attn.o_proj.weight") { dst = l.o_w; exp_rows = H; exp_cols = QD; }
+        else if (t == "mlp.gate_proj.weight") { dst = l.gu_w; exp_rows = c.t_inter; exp_cols = H; mode = 1; }
+        else if (t == "mlp.up_proj.weight") { dst = l.gu_w; exp_rows = c.t_inter; exp_cols = H; mode = 2; }
+        else if (t == "mlp.down_proj.weight") { dst = l.down_w; exp_rows = H; exp_cols = c.t_inter; ld = e->t_inter_pad; }
+    }
+    if (!dst) return fail(e, -2, "sr_load_weight: unknown parameter '%s'", hf_name);
+    if (rows != exp_rows || cols != exp_cols)
+        return fail(e, -22, "sr_load_weight: '%s' has shape [%lld, %lld], expected [%lld, %lld]", hf_name, rows, cols, exp_rows, exp_cols);
+    SR_TRY(launch_load2d(s, p, dtype, rows, cols, dst, ld, mode, row_off));
+    e->loaded[name] = true;
+    return 0;
+}
+
+int sr_pixel_ld(const sr_engine* e) { return e->v_pd_pad; }
+
+int sr_patchify_u8(sr_engine* e, const uint8_t* img, int h, int w, void* out, void* stream) {
+    const sr_config& c = e->c;
+    const int f = c.v_patch * c.v_merge;
+    if (c.v_in_ch != 3 || h % f || w % f || h <= 0 || w <= 0) return fail(e, -22, "sr_patchify_u8: h,w must be multiples of %d", f);
+    SR_TRY(launch_patchify((hipStream_t)stream, img, h, w, e->lut, (bf16_t*)out, e->v_pd_pad, c.v_patch, c.v_merge, c.v_temporal));
+    return 0;
+}
+
+int sr_vit_forward(sr_engine* e, const void* pixels, int pixels_dtype, const int64_t* grid, int n_img, void* out, void* stream) {
+    if (!e || !pixels || !grid || !out || n_img < 1) return fail(e, -22, "sr_vit_forward: null argument");
+    char miss[160];
+    if (sr_weights_missing(e, miss, sizeof miss)) return fail(e, -61, "weights missing, e.g. '%s'", miss);
+    hipStream_t s = (hipStream_t)stream;
+    const sr_config& c = e->c;
+    int N = 0;
+    if (int rc = vit_prepare(e, grid, n_img, s, &N)) return rc;
+    const int C = c.v_hidden, hd = e->v_hd;
+    const bf16_t* pix = static_cast<const bf16_t*>(pixels);
+    if (pixels_dtype == SR_DTYPE_F32) {
+        SR_TRY(launch_f32_to_bf16_pad(s, static_cast<const float*>(pixels), N, e->v_pd, e->v_pix, e->v_pd_pad));
+        pix = e->v_pix;
+    } else if (pixels_dtype != SR_DTYPE_BF16) return fail(e, -22, "pixels dtype");
+    // patch embed (Conv3d k=s, no bias, hf:99-122) with the window permutation fused into the store (hf:433-441)
+    if (int rc = gemm(e, s, pix, e->v_pd_pad, e->patch_w, N, C, e->v_pd_pad, e->v_x, C, nullptr, nullptr, e->v_rowmap_embed, EPI_STORE)) return rc;
+    const float scale = (float)(1.0 / sqrt((double)hd));
+    for (int blk = 0; blk < c.v_depth; ++blk) {
+        const VitBlockW& w = e->vb[blk];
+        SR_TRY(launch_rmsnorm(s, e->v_x, w.norm1, e->v_xn, N, C, 1e-6f));
+        if (int rc = gemm(e, s, e->v_xn, C, w.qkv_w, N, 3 * C, C, e->v_qkv, 3 * C, w.qkv_b, nullptr, nullptr, EPI_STORE)) return rc;
+        SR_TRY(launch_vit_rope(s, e->v_qkv, N, c.v_heads, hd, e->v_cos, e->v_sin, e->v_vt, e->v_vt_stride));
+        const bool full = is_fullatt(c, blk);
+        AttnArgs a{e->v_qkv, 3 * C, e->v_qkv + C, 3 * C, hd, e->v_vt, e->v_vt_stride, (long long)hd * e->v_vt_stride,
+                   e->v_attn, C, full ? e->v_work_full : e->v_work_win, full ? e->v_nwork_full : e->v_nwork_win,
+                   c.v_heads, 1, scale, 0};
+        SR_TRY(launch_attn_prefill(s, a, hd));
+        if (int rc = gemm(e, s, e->v_attn, C, w.proj_w, N, C, C, e->v_x, C, w.proj_b, e->v_x, nullptr, EPI_RESID)) return rc;
+        SR_TRY(launch_rmsnorm(s, e->v_x, w.norm2, e->v_xn, N, C, 1e-6f));
+        if (int rc = gemm(e, s, e->v_xn, C, w.gu_w, N, 2 * e->v_inter_pad, C, e->v_act, e->v_inter_pad, w.gu_b, nullptr, nullptr, EPI_SWIGLU)) return rc;
+        if (int rc = gemm(e, s, e->v_act, e->v_inter_pad, w.down_w, N, C, e->v_inter_pad, e->v_x, C, w.down_b, e->v_x, nullptr, EPI_RESID)) return rc;
+    }
+    // merger (hf:137-150) with the inverse window permutation fused into the last store (hf:463-465)
+    SR_TRY(launch_rmsnorm(s, e->v_x, e->ln_q, e->v_xn, N, C, 1e-6f));
+    const int T = N / (c.v_merge * c.v_merge);
+    if (int rc = gemm(e, s, e->v_xn, e->v_mh, e->fc1_w, T, e->v_mh, e->v_mh, e->v_m1, e->v_mh, e->fc1_b, nullptr, nullptr, EPI_GELU)) return rc;
+    if (int rc = gemm(e, s, e->v_m1, e->v_mh, e->fc2_w, T, c.v_out_hidden, e->v_mh, out, c.v_out_hidden, e->fc2_b, nullptr, e->v_rowmap_merge, EPI_STORE)) return rc;
+    return 0;
+}
+
+int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_t* seq_lens, const int32_t* slots, int B,
+               const void* image_embeds, int n_image_rows, float* logits_out, void* stream) {
+    if (!e || !ids || !pos3 || !seq_lens || !slots) return fail(e, -22, "sr_prefill: null argument");
+    char miss[160];
+    if (sr_weights_missing(e, miss, sizeof miss)) return fail(e, -61, "weights missing, e.g. '%s'", miss);
+    const sr_config& c = e->c;
+    if (B < 1 || B > c.max_batch) return fail(e, -22, "sr_prefill: B=%d outside 1..%d", B, c.max_batch);
+    hipStream_t s = (hipStream_t)stream;
+    int n_tok = 0;
+    for (int b = 0; b < B; ++b) {
+        if (seq_lens[b] < 1 || seq_lens[b] + 1 > c.max_ctx)
+            return fail(e, -22, "sequence %d length %d does not fit max_ctx %d", b, seq_lens[b], c.max_ctx);
+        if (slots[b] < 0 || slots[b] >= c.max_batch) return fail(e, -22, "slot %d out of range", slots[b]);
+        n_tok += seq_lens[b];
+    }
+    if (n_tok > c.max_prefill_tokens) return fail(e, -22, "%d prompt tokens exceed max_prefill_tokens %d", n_tok, c.max_prefill_tokens);
+
+    // ---- control arrays (host) -> device
+    SR_TRY(stage_begin(e));
+    int* h_src = reinterpret_cast<int*>(e->h_stage);
+    int* h_pos = h_src + n_tok;
+    int* h_slot = h_pos + 3 * n_tok;
+    int* h_idx = h_slot + n_tok;
+    int* h_last = h_idx + n_tok;
+    int* h_state = h_last + 32;             // [ctx_len(32) | pos(32) | slots(32)]
+    AttnWork* h_work = reinterpret_cast<AttnWork*>(((uintptr_t)(h_state + 96) + 15) & ~(uintptr_t)15);
+    int n_work = 0, img_row = 0, t0 = 0;
+    const int KVH = c.t_kv_heads;
+    for (int b = 0; b < B; ++b) {
+        const int S = seq_lens[b];
+        long long maxpos = 0;
+        for (int i = 0; i < S; ++i) {
+            const int t = t0 + i;
+            const int64_t id = ids[t];
+            if (id < 0 || id >= c.t_vocab) return fail(e, -22, "token id %lld out of range", (long long)id);
+            // image placeholders consume the image feature rows in order (hf:1210-1216 masked_scatter)
+            h_src[t] = (image_embeds && id == c.image_token_id) ? -(img_row++) - 1 : (int)id;
+            for (int a = 0; a < 3; ++a) {
+                const int64_t p = pos3[(size_t)a * n_tok + t];
+                h_pos[(size_t)a * n_tok + t] = (int)p;
+                if (p > maxpos) maxpos = p;
+            }
+            h_slot[t] = slots[b];
+            h_idx[t] = i;
+        }
+        for (int q0 = 0; q0 < S; q0 += 64)
+            h_work[n_work++] = AttnWork{t0 + q0, S, q0, slots[b] * KVH * c.max_ctx, (long long)slots[b] * KVH * 128 * c.max_ctx};
+        h_last[b] = t0 + S - 1;
+        h_state[b] = S;                     // keys in the cache; k_step_advance adds the new token before each forward
+        h_state[32 + b] = (int)maxpos;      // decode positions continue at max+1 on all three axes
+                                            // (reference rule: roll/utils/functionals.py:816-818)
+        h_state[64 + b] = slots[b];
+        t0 += S;
+    }
+    if (image_embeds && img_row != n_image_rows)
+        return fail(e, -22, "image features and image tokens do not match: %d tokens, %d feature rows", img_row, n_image_rows);
+    const size_t total = reinterpret_cast<char*>(h_work + n_work) - e->h_stage;
+    if (total > e->stage_bytes) return fail(e, -12, "control staging too small");
+    SR_TRY(stage_upload(e, 0, total, s));
+    auto dmirror = [&](const void* hptr) { return e->d_stage + (reinterpret_cast<const char*>(hptr) - e->h_stage); };
+    SR_TRY((int)hipMemcpyAsync(e->t_src, dmirror(h_src), (size_t)n_tok * 4, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->t_pos3, dmirror(h_pos), (size_t)n_tok * 12, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->t_slot, dmirror(h_slot), (size_t)n_tok * 4, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->t_idx, dmirror(h_idx), (size_t)n_tok * 4, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->t_lastrow, dmirror(h_last), 32 * 4, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->t_work, dmirror(h_work), n_work * sizeof(AttnWork), hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->d_ctx_len, dmirror(h_state), 32 * 4, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->d_pos, dmirror(h_state + 32), 32 * 4, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->d_slots, dmirror(h_state + 64), 32 * 4, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemsetAsync(e->d_finished, 0, 32 * 4, s));
+    SR_TRY((int)hipMemsetAsync(e->d_step, 0, 4, s));
+
+    // ---- forward over the packed tokens
+    const int H = c.t_hidden, QD = c.t_heads * 128;
+    SR_TRY(launch_embed(s, e->t_src, e->embed, static_cast<const bf16_t*>(image_embeds), e->t_x, n_tok, H));
+    const float scale = (float)(1.0 / sqrt(128.0));
+    for (int l = 0; l < c.t_layers; ++l) {
+        const LmLayerW& w = e->ll[l];
+        bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
+        bf16_t* vc = e->vtcache + (size_t)l * e->kv_layer_elems;
+        SR_TRY(launch_rmsnorm(s, e->t_x, w.ln1, e->t_xn, n_tok, H, c.t_rms_eps));
+        if (int rc = gemm(e, s, e->t_xn, H, w.qkv_w, n_tok, e->t_qn, H, e->t_qkv, e->t_qn, w.qkv_b, nullptr, nullptr, EPI_STORE)) return rc;
+        LmRopeArgs ra{e->t_qkv, n_tok, c.t_heads, c.t_kv_heads, e->t_pos3, e->t_slot, e->t_idx, e->inv_freq,
+                      c.mrope_section[0], c.mrope_section[0] + c.mrope_section[1], kc, vc, c.max_ctx};
+        SR_TRY(launch_lm_rope_prefill(s, ra));
+        AttnArgs a{e->t_qkv, e->t_qn, kc, 128, (long long)c.max_ctx * 128, vc, c.max_ctx, (long long)128 * c.max_ctx,
+                   e->t_attn, QD, e->t_work, n_work, c.t_heads, e->t_group, scale, 1};
+        SR_TRY(launch_attn_prefill(s, a, 128));
+        if (int rc = gemm(e, s, e->t_attn, QD, w.o_w, n_tok, H, QD, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID)) return rc;
+        SR_TRY(launch_rmsnorm(s, e->t_x, w.ln2, e->t_xn, n_tok, H, c.t_rms_eps));
+        if (int rc = gemm(e, s, e->t_xn, H, w.gu_w, n_tok, 2 * e->t_inter_pad, H, e->t_act, e->t_inter_pad, nullptr, nullptr, nullptr, EPI_SWIGLU)) return rc;
+        if (int rc = gemm(e, s, e->t_act, e->t_inter_pad, w.down_w, n_tok, H, e->t_inter_pad, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID)) return rc;
+    }
+    // last position of every sequence -> final norm -> tied LM head (hf:1386-1387) -> greedy token
+    SR_TRY(launch_gather_rows(s, e->t_x, e->t_lastrow, e->d_x, B, H));
+    SR_TRY(launch_rmsnorm(s, e->d_x, e->final_norm, e->d_xn, B, H, c.t_rms_eps));
+    GemvArgs gl{e->d_xn, H, e->embed, B, c.t_vocab, H, e->d_logits, 1};
+    SR_TRY(launch_gemv(s, gl, GV_F32));
+    SR_TRY(launch_argmax(s, e->d_logits, B, c.t_vocab, e->d_argmax));
+    if (logits_out) SR_TRY((int)hipMemcpyAsync(logits_out, e->d_logits, (size_t)B * c.t_vocab * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const int32_t* host_eos, int n_eos, int32_t pad_id,
+              int32_t* tokens_out, float* logits_trace, const int32_t* forced, int use_graph, void* stream, int* steps_done) {
+    if (!e || !tokens_out) return fail(e, -22, "sr_decode: null argument");
+    const sr_config& c = e->c;
+    if (B < 1 || B > c.max_batch || max_new < 1 || max_new > c.max_new_tokens || n_eos < 0 || n_eos > 32)
+        return fail(e, -22, "sr_decode: B=%d max_new=%d n_eos=%d out of range", B, max_new, n_eos);
+    (void)host_slots;   // slots were fixed by sr_prefill (kept in the signature for the continuous-batching scheduler)
+    hipStream_t s = (hipStream_t)stream;
+    if (n_eos) SR_TRY((int)hipMemcpyAsync(e->d_eos, host_eos, n_eos * 4, hipMemcpyHostToDevice, s));
+    const size_t V = c.t_vocab;
+    if (logits_trace) SR_TRY((int)hipMemcpyAsync(logits_trace, e->d_logits, B * V * 4, hipMemcpyDeviceToDevice, s));
+    // forced tokens are laid out [B][max_new] by the caller; the device log uses the engine's row stride
+    const int* forced_dev = nullptr;
+    if (forced) {
+        if (max_new != c.max_new_tokens) return fail(e, -22, "teacher forcing requires max_new == max_new_tokens (%d)", c.max_new_tokens);
+        forced_dev = forced;
+    }
+    const bool graph_ok = use_graph && !logits_trace && !forced;
+    if (graph_ok && (e->graph == nullptr || e->graph_B != B || e->graph_neos != n_eos || e->graph_pad != pad_id)) {
+        if (e->graph) { (void)hipGraphExecDestroy(e->graph); e->graph = nullptr; }
+        hipGraph_t g = nullptr;
+        SR_TRY((int)hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        int rc = enqueue_step_advance(e, B, n_eos, pad_id, nullptr, s);
+        if (!rc) rc = enqueue_decode_forward(e, B, s);
+        hipError_t er = hipStreamEndCapture(s, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        SR_TRY((int)er);
+        er = hipGraphInstantiate(&e->graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        SR_TRY((int)er);
+        e->graph_B = B; e->graph_neos = n_eos; e->graph_pad = pad_id;
+    }
+    int done = 0;
+    std::vector<int> fin(B);
+    for (int i = 0; i < max_new; ++i) {
+        if (i == max_new - 1) {   // the last token only needs to be recorded
+            if (int rc = enqueue_step_advance(e, B, n_eos, pad_id, forced_dev, s)) return rc;
+            done = max_new;
+            break;
+        }
+        if (graph_ok) SR_TRY((int)hipGraphLaunch(e->graph, s));
+        else {
+            if (int rc = enqueue_step_advance(e, B, n_eos, pad_id, forced_dev, s)) return rc;
+            if (int rc = enqueue_decode_forward(e, B, s)) return rc;
+            if (logits_trace)
+                SR_TRY((int)hipMemcpyAsync(logits_trace + (size_t)(i + 1) * B * V, e->d_logits, B * V * 4, hipMemcpyDeviceToDevice, s));
+        }
+        done = i + 1;
+        if (n_eos && (i % 16) == 15) {   // early exit once every sequence has emitted an eos token
+            SR_TRY((int)hipMemcpyAsync(fin.data(), e->d_finished, B * 4, hipMemcpyDeviceToHost, s));
+            SR_TRY((int)hipStreamSynchronize(s));
+            bool all = true;
+            for (int b = 0; b < B; ++b) all &= fin[b] != 0;
+            if (all) break;
+        }
+    }
+    // token log [B][max_new_tokens] -> caller layout [B][max_new]; unwritten positions read as pad
+    if (done < max_new) {
+        // fill the tail of the device log with pad before copying out
+        std::vector<int> padrow(max_new, pad_id);
+        for (int b = 0; b < B; ++b)
+            SR_TRY((int)hipMemcpyAsync(e->d_tokens + (size_t)b * c.max_new_tokens + done, padrow.data(), (max_new - done) * 4, hipMemcpyHostToDevice, s));
+        SR_TRY((int)hipStreamSynchronize(s));
+    }
+    SR_TRY((int)hipMemcpy2DAsync(tokens_out, (size_t)max_new * 4, e->d_tokens, (size_t)c.max_new_tokens * 4, (size_t)max_new * 4, B,
+                                 hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipStreamSynchronize(s));
+    if (steps_done) *steps_done = done;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- raster + ops
+#define SR_WRAP(call) do { int rc_ = (call); if (rc_) return fail(nullptr, rc_, #call " failed with %d", rc_); return 0; } while (0)
+
+int sr_mask_union(uint8_t* acc, const uint8_t* m, size_t n, void* stream) { SR_WRAP(launch_mask_union((hipStream_t)stream, acc, m, n)); }
+int sr_resize_nearest_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, void* stream) {
+    SR_WRAP(launch_resize_nearest_u8((hipStream_t)stream, src, sh, sw, dst, dh, dw));
+}
+int sr_iou_counts(const uint8_t* p, const uint8_t* g, size_t n, int64_t* out2, void* stream) {
+    SR_WRAP(launch_iou_counts((hipStream_t)stream, p, g, n, reinterpret_cast<long long*>(out2)));
+}
+int sr_render_overlay(uint8_t* img, int h, int w, const uint8_t* mask, int mh, int mw, const int32_t* boxes, int nb, void* stream) {
+    SR_WRAP(launch_render_overlay((hipStream_t)stream, img, h, w, mask, mh, mw, boxes, nb));
+}
+int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void* out, int ldo, const void* bias, const void* resid,
+               const int32_t* rowmap, int epilogue, void* stream) {
+    GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, M, N, K, out, ldo, (const bf16_t*)bias, (const bf16_t*)resid, rowmap};
+    SR_WRAP(launch_gemm((hipStream_t)stream, a, epilogue));
+}
+int sr_op_gemv(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ksplit, int mode, void* stream) {
+    GemvArgs a{(const bf16_t*)x, ldx, (const bf16_t*)W, M, N, K, out, ksplit};
+    SR_WRAP(launch_gemv((hipStream_t)stream, a, mode));
+}
+int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, float eps, void* stream) {
+    SR_WRAP(launch_rmsnorm((hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out, rows, H, eps));
+}
+int sr_op_resid_rmsnorm(void* x, const float* partials, int ksplit, const void* w, void* out, int rows, int H, float eps, void* stream) {
+    SR_WRAP(launch_resid_rmsnorm((hipStream_t)stream, (bf16_t*)x, partials, ksplit, (const bf16_t*)w, (bf16_t*)out, rows, H, eps));
+}
+int sr_op_argmax(const float* logits, int rows, int V, int32_t* out_idx, void* stream) {
+    SR_WRAP(launch_argmax((hipStream_t)stream, logits, rows, V, out_idx));
+}
+
+}  // extern "C"

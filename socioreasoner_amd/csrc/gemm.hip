@@ -1,0 +1,217 @@
+// bf16 MFMA GEMM for the MFMA-bound rows of the hot path:
+//   out[M,N] = A[M,K] . W[N,K]^T  with W in nn.Linear layout, float32 accumulation, fused epilogues that
+//   reproduce HF's bf16 rounding points (hf: transformers/models/qwen2_5_vl/modeling_qwen2_5_vl.py:85-96, 137-150,
+//   211-322, 541-554, 602-758).
+// Tile: BM x 128 x 64 (BM = 128 or 64), 256 threads = 4 waves in 2x2, each wave (BM/2) x 64 as 16x16x32 MFMA tiles.
+// LDS: double-buffered, rows of 64 bf16 (128 B) with the 16-byte chunk index XOR-ed with (row & 7) so that the
+// ds_read_b128 fragment reads (lane = row, 4 lane-groups = 4 k-chunks) are bank-conflict free.
+// The MFMA is issued as D = Wfrag x Afrag, i.e. D[i = n][j = m]: a lane then owns 4 CONSECUTIVE output columns of
+// one output row, which makes the epilogue an 8-byte store per lane and keeps gate/up pairs in the same lane.
+#include "kernels.h"
+
+namespace {
+
+constexpr int BN = 128, BK = 64, NTHREADS = 256;
+
+template <int BM>
+struct Smem {
+    bf16_t a[2][BM * BK];
+    bf16_t w[2][BN * BK];
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * (BK * 2) + ((chunk ^ (row & 7)) << 4); }
+
+template <int BM, int EPI>
+__global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem<BM>& sm = *reinterpret_cast<Smem<BM>*>(smem_raw);
+    constexpr int MI = BM / 32;       // 16-row m-tiles per wave
+    constexpr int A_LOADS = BM * 8 / NTHREADS;
+    constexpr int W_LOADS = BN * 8 / NTHREADS;
+
+    // ---- block -> tile: XCD-aware (block b runs on XCD b % 8: give each XCD a contiguous run of tiles), then
+    // grouped ordering (8 m-tiles share their W panels while walking n)
+    int bid = blockIdx.x, nblk = gridDim.x;
+    {
+        int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP = 8;
+    int per_group = GROUP * ntn;
+    int gid = bid / per_group;
+    int first_m = gid * GROUP;
+    int gsz = min(ntm - first_m, GROUP);
+    int tm = first_m + (bid % per_group) % gsz;
+    int tn = (bid % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    // ---- global -> register staging (16 B per load), rows clamped so edge tiles stay in bounds
+    uint4 ra[A_LOADS], rw[W_LOADS];
+    const bf16_t* aptr[A_LOADS];
+    const bf16_t* wptr[W_LOADS];
+    int a_dst[A_LOADS], w_dst[W_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        int c = tid + i * NTHREADS, row = c >> 3, ch = c & 7;
+        int gm = min(m0 + row, p.M - 1);
+        aptr[i] = p.A + (size_t)gm * p.lda + ch * 8;
+        a_dst[i] = swz(row, ch);
+    }
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i) {
+        int c = tid + i * NTHREADS, row = c >> 3, ch = c & 7;
+        int gn = min(n0 + row, p.N - 1);
+        wptr[i] = p.W + (size_t)gn * p.K + ch * 8;
+        w_dst[i] = swz(row, ch);
+    }
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) ra[i] = *reinterpret_cast<const uint4*>(aptr[i] + kt * BK);
+#pragma unroll
+        for (int i = 0; i < W_LOADS; ++i) rw[i] = *reinterpret_cast<const uint4*>(wptr[i] + kt * BK);
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* ab = reinterpret_cast<unsigned char*>(sm.a[buf]);
+        unsigned char* wb = reinterpret_cast<unsigned char*>(sm.w[buf]);
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<uint4*>(ab + a_dst[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < W_LOADS; ++i) *reinterpret_cast<uint4*>(wb + w_dst[i]) = rw[i];
+    };
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const unsigned char* ab = reinterpret_cast<const unsigned char*>(sm.a[cur]);
+        const unsigned char* wb = reinterpret_cast<const unsigned char*>(sm.w[cur]);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[MI], wf[4];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                int row = wm * (BM / 2) + i * 16 + fr;
+                af[i] = *reinterpret_cast<const bf16x8*>(ab + swz(row, kk * 4 + fg));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int row = wn * 64 + j * 16 + fr;
+                wf[j] = *reinterpret_cast<const bf16x8*>(wb + swz(row, kk * 4 + fg));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  lane owns row m = .. + fr and columns n = .. + fg*4 + {0,1,2,3} of every 16x16 tile
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + fr;
+        if (m >= p.M) continue;
+        const int orow = p.rowmap ? p.rowmap[m] : m;
+        if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                const int ng = n0 + wn * 64 + jp * 32 + fg * 4;       // gate columns (interleaved index)
+                if (ng >= p.N) continue;
+                const int nu = ng + 16;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float g = acc[i][2 * jp][r], u = acc[i][2 * jp + 1][r];
+                    if (p.bias) { g += bf2f(p.bias[ng + r]); u += bf2f(p.bias[nu + r]); }
+                    g = rbf(g); u = rbf(u);
+                    o[r] = rbf(silu_f(g)) * u;
+                }
+                const int no = (n0 + wn * 64) / 2 + jp * 16 + fg * 4;
+                uint2 v = {pack2(o[0], o[1]), pack2(o[2], o[3])};
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + no) = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fg * 4;
+                if (n >= p.N) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[i][j][r];
+                if constexpr (EPI == EPI_F32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow * p.ldo + n) =
+                        float4{o[0], o[1], o[2], o[3]};
+                } else {
+                    if (p.bias) {
+                        uint2 b = *reinterpret_cast<const uint2*>(p.bias + n);
+                        o[0] += lo16(b.x); o[1] += hi16(b.x); o[2] += lo16(b.y); o[3] += hi16(b.y);
+                    }
+                    bf16_t* optr = reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + n;
+                    if constexpr (EPI == EPI_RESID) {
+                        uint2 rv = *reinterpret_cast<const uint2*>(p.resid + (size_t)orow * p.ldo + n);
+                        o[0] = lo16(rv.x) + rbf(o[0]); o[1] = hi16(rv.x) + rbf(o[1]);
+                        o[2] = lo16(rv.y) + rbf(o[2]); o[3] = hi16(rv.y) + rbf(o[3]);
+                    } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = gelu_f(rbf(o[r]));
+                    }
+                    uint2 v = {pack2(o[0], o[1]), pack2(o[2], o[3])};
+                    *reinterpret_cast<uint2*>(optr) = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int EPI>
+int launch_t(hipStream_t s, const GemmArgs& a) {
+    int ntm = cdiv(a.M, BM), ntn = cdiv(a.N, BN);
+    size_t smem = sizeof(Smem<BM>);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_gemm<BM, EPI>), dim3(ntm * ntn), dim3(NTHREADS), smem, s, a, ntm, ntn);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int EPI>
+int launch_e(hipStream_t s, const GemmArgs& a) {
+    // 128-row tiles only when they still give every CU work; otherwise 64-row tiles double the block count
+    long blocks128 = (long)cdiv(a.M, 128) * cdiv(a.N, BN);
+    if (blocks128 >= 512) return launch_t<128, EPI>(s, a);
+    return launch_t<64, EPI>(s, a);
+}
+
+}  // namespace
+
+int launch_gemm(hipStream_t s, const GemmArgs& a, int epi) {
+    if (a.M <= 0) return 0;
+    if (a.K % BK != 0 || a.N % 16 != 0 || (epi == EPI_SWIGLU && a.N % 32 != 0)) return -22;
+    switch (epi) {
+        case EPI_STORE: return launch_e<EPI_STORE>(s, a);
+        case EPI_RESID: return launch_e<EPI_RESID>(s, a);
+        case EPI_SWIGLU: return launch_e<EPI_SWIGLU>(s, a);
+        case EPI_GELU: return launch_e<EPI_GELU>(s, a);
+        case EPI_F32: return launch_e<EPI_F32>(s, a);
+    }
+    return -22;
+}

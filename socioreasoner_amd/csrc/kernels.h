@@ -1,0 +1,109 @@
+// Host-side launchers of every device kernel of the hot path (one .hip file per family).
+// All take the caller's stream, launch asynchronously, and return 0 or a hipError_t value.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------ gemm.hip (MFMA, M large)
+// out[M,N] = A[M,K] . W[N,K]^T, bf16 operands, float32 accumulate.  K % 64 == 0, N % 16 == 0.
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32 = 4 };
+struct GemmArgs {
+    const bf16_t* A; int lda;
+    const bf16_t* W;            // [N,K] row-major (nn.Linear layout); SWIGLU: rows interleaved 16 gate / 16 up
+    int M, N, K;
+    void* out; int ldo;         // bf16 (float for EPI_F32); SWIGLU writes N/2 columns
+    const bf16_t* bias;         // [N] or null
+    const bf16_t* resid;        // EPI_RESID: [M, ldo] (may alias out)
+    const int* rowmap;          // optional destination row per source row
+};
+int launch_gemm(hipStream_t s, const GemmArgs& a, int epi);
+
+// ------------------------------------------------------------------ gemv.hip (weight streaming, M <= 32)
+enum { GV_PARTIAL = 0, GV_SWIGLU = 1, GV_F32 = 2 };
+struct GemvArgs {
+    const bf16_t* x; int ldx;   // [M, K]
+    const bf16_t* W;            // [N, K]
+    int M, N, K;
+    void* out;                  // PARTIAL: float [ksplit][M][N]; SWIGLU: bf16 [M][N/2]; F32: float [M][N]
+    int ksplit;                 // PARTIAL only; (K/64) % ksplit == 0
+};
+int launch_gemv(hipStream_t s, const GemvArgs& a, int mode);
+
+// ------------------------------------------------------------------ attention.hip
+// one 64-query tile of one sequence.  K element (kvh, key j, d) = k[(k_row0 + j)*k_stride + kvh*k_head_stride + d];
+// V^T element (kvh, d, key j) = vt[vt_off + kvh*vt_head_stride + d*vt_stride + j]
+struct AttnWork { int q_row0; int seq_len; int q_off; int k_row0; long long vt_off; };
+struct AttnArgs {
+    const bf16_t* q; int q_stride;        // element (row, h*HD + d) at q[row*q_stride + h*HD + d]
+    const bf16_t* k; int k_stride; long long k_head_stride;
+    const bf16_t* vt; int vt_stride; long long vt_head_stride;
+    bf16_t* out; int out_stride;          // out[row*out_stride + h*HD + d]
+    const AttnWork* work; int n_work;
+    int n_heads, group;                   // kv head = h / group
+    float scale;
+    int causal;
+};
+int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim);
+
+struct DecodeAttnArgs {
+    const bf16_t* q; int q_stride;        // [B, Hq*128] after rope
+    const bf16_t* kcache;                 // [slot][kvh][ctx_max][128]
+    const bf16_t* vtcache;                // [slot][kvh][128][ctx_max]
+    const int* ctx_len;                   // [B] keys already in the cache INCLUDING the new token
+    const int* slots;                     // [B] cache slot of each row (null: identity)
+    bf16_t* out; int out_stride;
+    int B, n_kv_heads, group, ctx_max;
+    float scale;
+};
+int launch_attn_decode(hipStream_t s, const DecodeAttnArgs& a);
+int attn_decode_prepare(int ctx_max, int group);
+
+// ------------------------------------------------------------------ elementwise.hip
+int launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int H, float eps);
+// h = r(x + r(sum_ks part[ks] + bias)) written back to x; out = rmsnorm(h) * w.   part may be null (plain norm).
+int launch_resid_rmsnorm(hipStream_t s, bf16_t* x, const float* part, int ksplit, const bf16_t* w, bf16_t* out,
+                         int rows, int H, float eps);
+int launch_vit_rope(hipStream_t s, bf16_t* qkv, int n_rows, int n_heads, int head_dim, const float* cos_t,
+                    const float* sin_t, bf16_t* vt, int vt_stride);
+// prefill: rope q,k in place in qkv [T, (Hq+2Hkv)*128]; write K / V^T into the cache at (slot, pos_in_seq)
+struct LmRopeArgs {
+    bf16_t* qkv; int n_tok; int n_q_heads, n_kv_heads;
+    const int* pos3;            // [3][n_tok] mRoPE position ids
+    const int* tok_slot;        // [n_tok] cache slot
+    const int* tok_idx;         // [n_tok] index of the token inside its sequence (cache row)
+    const float* inv_freq;      // [64]
+    int sec0, sec1;             // mrope_section boundaries in rotary pairs (16, 40)
+    bf16_t* kcache; bf16_t* vtcache; int ctx_max;
+};
+int launch_lm_rope_prefill(hipStream_t s, const LmRopeArgs& a);
+// decode: qkv = r(sum partials + bias); rope at pos[b]; q -> qout [B, Hq*128]; K/V -> cache row ctx_len[b]-1
+struct LmDecodeQkvArgs {
+    const float* part; int ksplit; const bf16_t* bias;
+    int B, n_q_heads, n_kv_heads;
+    const int* pos; const int* ctx_len; const int* slots; const float* inv_freq;
+    bf16_t* qout; bf16_t* kcache; bf16_t* vtcache; int ctx_max;
+};
+int launch_lm_decode_qkv(hipStream_t s, const LmDecodeQkvArgs& a);
+int launch_embed(hipStream_t s, const int* src, const bf16_t* table, const bf16_t* image_embeds, bf16_t* out,
+                 int n_tok, int H);
+int launch_gather_rows(hipStream_t s, const bf16_t* in, const int* rows, bf16_t* out, int n, int H);
+int launch_patchify(hipStream_t s, const uint8_t* img, int h, int w, const bf16_t* lut, bf16_t* out, int ld_out,
+                    int patch, int merge, int temporal);
+int launch_f32_to_bf16_pad(hipStream_t s, const float* in, int rows, int cols, bf16_t* out, int ld_out);
+int launch_argmax(hipStream_t s, const float* logits, int rows, int V, int* out_idx);
+struct StepArgs {
+    const int* argmax; int* cur_tok; int* ctx_len; int* pos; int* step; int* finished; int* tokens_out;
+    int max_new; const int* eos; int n_eos; int pad_id; int B; int* embed_src;
+    const int* forced;          // optional [B][max_new]: token fed back instead of the greedy one (teacher forcing)
+};
+int launch_step_advance(hipStream_t s, const StepArgs& a);
+int launch_synth_fill(hipStream_t s, bf16_t* out, long long n, uint32_t key, float base, float scale);
+int launch_fill_zero(hipStream_t s, void* p, size_t bytes);
+int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, long long cols, bf16_t* dst, long long dst_ld,
+                  int mode, long long row_off);
+
+// ------------------------------------------------------------------ raster.hip
+int launch_mask_union(hipStream_t s, uint8_t* acc, const uint8_t* m, size_t n);
+int launch_resize_nearest_u8(hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
+int launch_iou_counts(hipStream_t s, const uint8_t* p, const uint8_t* g, size_t n, long long* out2);
+int launch_render_overlay(hipStream_t s, uint8_t* img, int h, int w, const uint8_t* mask, int mh, int mw,
+                          const int* boxes, int nb);

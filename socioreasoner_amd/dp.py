@@ -1,0 +1,60 @@
+"""Data-parallel sharding of tiles over the GPUs of one node.
+
+The reference shards a batch over its ``actor_infer`` workers in contiguous ``np.array_split``-sized chunks and
+concatenates results in rank order (/root/reference/roll/distributed/scheduler/decorator.py:106-181,
+protocol.py:550-617).  Here: one process per GPU (torchrun), no data-path collective while generating, and ONE
+all-gather of the (small) results at the end over RCCL/xGMI (backend "nccl" on ROCm; "gloo" in CPU tests)."""
+from __future__ import annotations
+
+import os
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+def split_sizes(n: int, world: int) -> List[int]:
+    """Sizes of np.array_split(range(n), world): the first n % world chunks get one extra element."""
+    q, r = divmod(n, world)
+    return [q + 1 if i < r else q for i in range(world)]
+
+
+def shard_range(n: int, rank: int, world: int):
+    sizes = split_sizes(n, world)
+    start = sum(sizes[:rank])
+    return start, start + sizes[rank]
+
+
+def init_distributed(backend: str | None = None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Concatenates the per-rank row blocks (array_split sizes) in rank order; every rank gets the full tensor."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    sizes = split_sizes(n_total, world)
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()

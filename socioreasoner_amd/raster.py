@@ -1,0 +1,59 @@
+"""Device raster tail (K19-K22): thin wrappers over the C ABI, torch uint8 CUDA tensors in and out.
+Reference behaviour: /root/reference/roll/distributed/strategy/seg_strategy.py:37-69 and
+/root/reference/roll/pipeline/rlvr/rlvr_socioseg_vlm_pipeline_infer.py:45-58, 383-452."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def _s(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def mask_union_(acc: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """acc = logical_or(acc, mask).astype(uint8), in place."""
+    assert acc.dtype == torch.uint8 and mask.dtype == torch.uint8 and acc.is_cuda and acc.numel() == mask.numel()
+    mask = mask.contiguous()
+    L.check(L.load().sr_mask_union(C.c_void_p(acc.data_ptr()), C.c_void_p(mask.data_ptr()), acc.numel(), _s(acc)), None, "sr_mask_union")
+    return acc
+
+
+def resize_nearest(src: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    assert src.dtype == torch.uint8 and src.is_cuda and src.dim() == 2
+    src = src.contiguous()
+    dst = torch.empty(H, W, dtype=torch.uint8, device=src.device)
+    L.check(L.load().sr_resize_nearest_u8(C.c_void_p(src.data_ptr()), src.shape[0], src.shape[1], C.c_void_p(dst.data_ptr()), H, W, _s(src)),
+            None, "sr_resize_nearest_u8")
+    return dst
+
+
+def iou_counts(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    """int64 [2] = (intersection, union) on the device."""
+    assert pred.dtype == torch.uint8 and gt.dtype == torch.uint8 and pred.numel() == gt.numel()
+    pred, gt = pred.contiguous(), gt.contiguous()
+    out = torch.empty(2, dtype=torch.int64, device=pred.device)
+    L.check(L.load().sr_iou_counts(C.c_void_p(pred.data_ptr()), C.c_void_p(gt.data_ptr()), pred.numel(), C.c_void_p(out.data_ptr()), _s(pred)),
+            None, "sr_iou_counts")
+    return out
+
+
+def compute_giou(pred: torch.Tensor, gt: torch.Tensor) -> float:
+    i, u = iou_counts(pred, gt).tolist()
+    return 1.0 if u == 0 else i / u
+
+
+def render_overlay_(img_rgb: torch.Tensor, mask: torch.Tensor | None, boxes) -> torch.Tensor:
+    """In place on a uint8 [H,W,3] CUDA image: 2-px blue outlines for ``boxes`` then the 40 % red overlay where mask>0."""
+    assert img_rgb.dtype == torch.uint8 and img_rgb.is_cuda and img_rgb.is_contiguous()
+    bx = torch.as_tensor([[int(v) for v in b] for b in boxes if len(b) == 4], dtype=torch.int32).reshape(-1, 4).to(img_rgb.device)
+    h, w = img_rgb.shape[:2]
+    if mask is not None:
+        mask = mask.contiguous()
+    L.check(L.load().sr_render_overlay(C.c_void_p(img_rgb.data_ptr()), h, w, C.c_void_p(mask.data_ptr()) if mask is not None else None,
+                                       mask.shape[0] if mask is not None else 0, mask.shape[1] if mask is not None else 0,
+                                       C.c_void_p(bx.data_ptr()) if bx.numel() else None, bx.shape[0], _s(img_rgb)), None, "sr_render_overlay")
+    return img_rgb

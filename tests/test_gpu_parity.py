@@ -1,0 +1,342 @@
+"""GPU parity tests: every call goes through the C ABI of libsocior.so and is compared with the CPU oracle.
+
+Tolerances (written here, derived in DESIGN.md "Numerics"):
+  * integer / byte / index work: bit exact;
+  * a single bf16-output op on identical inputs: <= 1 bf16 ulp (of a typically sized element) on <= 1 % of the
+    elements -- only float32 accumulation-order flips of a rounding are allowed;
+  * float32 outputs computed from identical inputs (logits from a given hidden state): abs 1e-3;
+  * composites of many rounding stages (a block, the tiny model end to end): the bf16 noise floor, bounded by
+    a few ulps of the largest element -- the same bound the oracle itself meets against HF (test_oracle_golden.py).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_bf16_close, bf16_compare, bits_to_f32
+
+pytestmark = pytest.mark.gpu
+
+EPI_STORE, EPI_RESID, EPI_SWIGLU, EPI_GELU, EPI_F32 = range(5)
+GV_PARTIAL, GV_SWIGLU, GV_F32 = range(3)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from socioreasoner_amd import lib
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return lib.load()
+
+
+def sp():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def interleave16(gate, up):
+    """engine layout of gate/up rows: blocks of 16 gate rows then 16 up rows."""
+    n, k = gate.shape
+    out = torch.empty(2 * n, k, dtype=gate.dtype)
+    o = out.view(n // 16, 2, 16, k)
+    o[:, 0] = gate.view(n // 16, 16, k)
+    o[:, 1] = up.view(n // 16, 16, k)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ generator
+def test_synth_fill_bit_exact(L):
+    from oracle import weights as WG
+    for name, shape, base, seed in [("model.layers.3.mlp.gate_proj.weight", (1000, 333), 0.0, 0),
+                                    ("visual.blocks.0.norm1.weight", (1280,), 1.0, 0),
+                                    ("model.embed_tokens.weight", (4096, 257), 0.0, 5)]:
+        n = int(np.prod(shape))
+        out = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        assert L.sr_synth_fill(P(out), n, name.encode(), seed, C.c_float(base), sp()) == 0
+        want = torch.from_numpy(WG.synth_f32(name, shape, seed, base)).reshape(-1)
+        assert torch.equal(out.float().cpu(), want), name
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(1024, 1280, 1280), (448, 2560, 2048), (200, 320, 1216), (77, 512, 64), (4096, 3840, 1280)])
+def test_gemm_store_bias_rowmap(L, M, N, K):
+    from oracle import model_ref as MR
+    a, w, b = rnd((M, K), 1), rnd((N, K), 2, 0.05), rnd((N,), 3, 0.1)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(4)).int()
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    rc = L.sr_op_gemm(P(a.cuda()), K, P(w.cuda()), M, N, K, P(out), N, P(b.cuda()), None, P(perm.cuda()), EPI_STORE, sp())
+    assert rc == 0
+    want = torch.empty(M, N)
+    want[perm.long()] = MR.linear(a.float(), w.float(), b.float())
+    assert_bf16_close(out.float().cpu(), want, 1, 0.01, f"gemm store {M}x{N}x{K}")
+
+
+def test_gemm_resid_inplace_and_gelu_and_f32(L):
+    from oracle import model_ref as MR
+    M, N, K = 300, 1280, 3456
+    a, w, b, x = rnd((M, K), 5), rnd((N, K), 6, 0.03), rnd((N,), 7, 0.1), rnd((M, N), 8)
+    xd = x.cuda().clone()
+    assert L.sr_op_gemm(P(a.cuda()), K, P(w.cuda()), M, N, K, P(xd), N, P(b.cuda()), P(xd), None, EPI_RESID, sp()) == 0
+    want = MR.r(x.float() + MR.linear(a.float(), w.float(), b.float()))
+    assert_bf16_close(xd.float().cpu(), want, 1, 0.01, "gemm resid")
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    assert L.sr_op_gemm(P(a.cuda()), K, P(w.cuda()), M, N, K, P(out), N, P(b.cuda()), None, None, EPI_GELU, sp()) == 0
+    assert_bf16_close(out.float().cpu(), MR.gelu_bf16(MR.linear(a.float(), w.float(), b.float())), 1, 0.01, "gemm gelu")
+    o32 = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    assert L.sr_op_gemm(P(a.cuda()), K, P(w.cuda()), M, N, K, P(o32), N, None, None, None, EPI_F32, sp()) == 0
+    ref = a.double() @ w.double().t()
+    assert float((o32.cpu().double() - ref).abs().max()) <= 1e-3   # float32 accumulate vs float64
+
+
+@pytest.mark.parametrize("M,I,K,bias", [(1024, 3456, 1280, True), (130, 11008, 2048, False), (64, 256, 320, True)])
+def test_gemm_swiglu(L, M, I, K, bias):
+    from oracle import model_ref as MR
+    a, wg, wu = rnd((M, K), 9), rnd((I, K), 10, 0.03), rnd((I, K), 11, 0.03)
+    bg, bu = (rnd((I,), 12, 0.1), rnd((I,), 13, 0.1)) if bias else (None, None)
+    w = interleave16(wg, wu).cuda()
+    b = interleave16(bg[:, None], bu[:, None]).reshape(-1).cuda() if bias else None
+    out = torch.zeros(M, I, dtype=torch.bfloat16, device="cuda")
+    assert L.sr_op_gemm(P(a.cuda()), K, P(w), M, 2 * I, K, P(out), I, P(b), None, None, EPI_SWIGLU, sp()) == 0
+    g = MR.linear(a.float(), wg.float(), bg.float() if bias else None)
+    u = MR.linear(a.float(), wu.float(), bu.float() if bias else None)
+    assert_bf16_close(out.float().cpu(), MR.r(MR.silu_bf16(g) * u), 1, 0.01, "gemm swiglu")
+
+
+# ------------------------------------------------------------------------------------------------ GEMV (decode)
+@pytest.mark.parametrize("M", [1, 5, 16, 17, 32])
+def test_gemv_modes(L, M):
+    from oracle import model_ref as MR
+    K, N = 2048, 2560
+    x, w = rnd((M, K), 20), rnd((N, K), 21, 0.03)
+    for ks in (1, 2, 4):
+        part = torch.zeros(ks, M, N, dtype=torch.float32, device="cuda")
+        assert L.sr_op_gemv(P(x.cuda()), K, P(w.cuda()), M, N, K, P(part), ks, GV_PARTIAL, sp()) == 0
+        got = part.sum(0).cpu()
+        ref = (x.double() @ w.double().t())
+        assert float((got.double() - ref).abs().max()) <= 1e-3, ("partial", M, ks)
+    V = 4096
+    wv = rnd((V, K), 22, 0.03)
+    lg = torch.zeros(M, V, dtype=torch.float32, device="cuda")
+    assert L.sr_op_gemv(P(x.cuda()), K, P(wv.cuda()), M, V, K, P(lg), 1, GV_F32, sp()) == 0
+    assert float((lg.cpu().double() - x.double() @ wv.double().t()).abs().max()) <= 1e-3
+    I, K2 = 11008, 2048
+    wg, wu = rnd((I, K2), 23, 0.03), rnd((I, K2), 24, 0.03)
+    act = torch.zeros(M, I, dtype=torch.bfloat16, device="cuda")
+    assert L.sr_op_gemv(P(x.cuda()), K2, P(interleave16(wg, wu).cuda()), M, 2 * I, K2, P(act), 1, GV_SWIGLU, sp()) == 0
+    want = MR.r(MR.silu_bf16(MR.linear(x.float(), wg.float())) * MR.linear(x.float(), wu.float()))
+    assert_bf16_close(act.float().cpu(), want, 1, 0.01, f"gemv swiglu M={M}")
+    # K = 11008 down projection, split 4
+    xd, wd = rnd((M, I), 25), rnd((2048, I), 26, 0.02)
+    part = torch.zeros(4, M, 2048, dtype=torch.float32, device="cuda")
+    assert L.sr_op_gemv(P(xd.cuda()), I, P(wd.cuda()), M, 2048, I, P(part), 4, GV_PARTIAL, sp()) == 0
+    assert float((part.sum(0).cpu().double() - xd.double() @ wd.double().t()).abs().max()) <= 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ norms / argmax
+@pytest.mark.parametrize("rows,H", [(1024, 1280), (448, 2048), (3, 512), (1, 2048), (9, 320)])
+def test_rmsnorm_and_resid(L, rows, H):
+    from oracle import model_ref as MR
+    x, w = rnd((rows, H), 30, 2.0), (1 + rnd((H,), 31, 0.05).float()).to(torch.bfloat16)
+    out = torch.zeros(rows, H, dtype=torch.bfloat16, device="cuda")
+    assert L.sr_op_rmsnorm(P(x.cuda()), P(w.cuda()), P(out), rows, H, C.c_float(1e-6), sp()) == 0
+    assert_bf16_close(out.float().cpu(), MR.rmsnorm(x.float(), w.float(), 1e-6), 1, 0.002, "rmsnorm")
+    if rows <= 32 and H <= 2048:
+        part = torch.randn(3, rows, H, generator=torch.Generator().manual_seed(32))
+        xd = x.cuda().clone()
+        assert L.sr_op_resid_rmsnorm(P(xd), P(part.cuda()), 3, P(w.cuda()), P(out), rows, H, C.c_float(1e-6), sp()) == 0
+        h = MR.r(x.float() + MR.r(part[0] + part[1] + part[2]))
+        assert_bf16_close(xd.float().cpu(), h, 1, 0.002, "resid")
+        assert_bf16_close(out.float().cpu(), MR.rmsnorm(h, w.float(), 1e-6), 1, 0.01, "resid norm")
+
+
+def test_argmax_lowest_index_on_ties(L):
+    V = 151936
+    lg = torch.randn(4, V, generator=torch.Generator().manual_seed(40))
+    lg[1, 77] = lg[1, 150000] = 9.0
+    lg[2, V - 1] = 11.0
+    lg[3, 0] = 12.0
+    out = torch.zeros(4, dtype=torch.int32, device="cuda")
+    assert L.sr_op_argmax(P(lg.cuda()), 4, V, P(out), sp()) == 0
+    assert out.cpu().tolist() == [int(lg[0].argmax()), 77, V - 1, 0]
+
+
+# ------------------------------------------------------------------------------------------------ raster (bit exact)
+def test_raster_tail_bit_exact(L):
+    from oracle import raster_ref as R
+    from socioreasoner_amd import raster, synthetic
+    for i in range(3):
+        masks, gt = synthetic.tile_masks(i)
+        masks[2] *= 255      # any non-zero byte counts
+        acc = torch.zeros(756, 756, dtype=torch.uint8, device="cuda")
+        for m in masks:
+            raster.mask_union_(acc, torch.from_numpy(m).cuda())
+        want = R.mask_union(list(masks))
+        assert np.array_equal(acc.cpu().numpy(), want)
+        up = raster.resize_nearest(acc, 768, 768)
+        wup = R.resize_nearest(want, 768, 768)
+        assert np.array_equal(up.cpu().numpy(), wup)
+        assert raster.iou_counts(up, torch.from_numpy(gt).cuda()).tolist() == list(R.iou_counts(wup, gt))
+        img = synthetic.tile_pixels(i)
+        boxes = [[10, 20, 200, 220], [300, 5, 447, 100], [-5, -5, 30, 40], [400, 400, 500, 500], [50, 50, 40, 60]]
+        got = raster.render_overlay_(torch.from_numpy(img).cuda().contiguous(), up, boxes)
+        assert np.array_equal(got.cpu().numpy(), R.render_overlay(img, wup, [b for b in boxes]))
+    # odd sizes, empty masks, idempotence, 896 tile
+    assert raster.iou_counts(torch.zeros(64, dtype=torch.uint8, device="cuda"), torch.zeros(64, dtype=torch.uint8, device="cuda")).tolist() == [0, 0]
+    assert raster.compute_giou(torch.zeros(64, dtype=torch.uint8, device="cuda"), torch.zeros(64, dtype=torch.uint8, device="cuda")) == 1.0
+    big = (torch.rand(756, 756, generator=torch.Generator().manual_seed(1)) > 0.5).to(torch.uint8)
+    assert np.array_equal(raster.resize_nearest(big.cuda(), 896, 896).cpu().numpy(), R.resize_nearest(big.numpy(), 896, 896))
+    same = raster.resize_nearest(big.cuda(), 756, 756)
+    assert torch.equal(same.cpu(), big)
+
+
+# ------------------------------------------------------------------------------------------------ engine, tiny geometry
+@pytest.fixture(scope="module")
+def tiny_engine():
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.engine import Engine
+    e = Engine(geometry_tiny(), max_patches=512, max_prefill_tokens=256, max_batch=4, max_ctx=192, max_new_tokens=16)
+    e.load_synthetic_weights(seed=0)
+    yield e
+    e.close()
+
+
+def test_patchify_bit_exact(tiny_engine):
+    from oracle import host_ref as H
+    from socioreasoner_amd import synthetic
+    for (h, w) in [(56, 84), (448, 448), (112, 28)]:
+        img = synthetic.tile_pixels(h * 7 + w, h, w)
+        pv, grid = H.patchify(img)
+        got = tiny_engine.patchify(torch.from_numpy(img).cuda())
+        assert got.shape == (pv.shape[0], tiny_engine.pixel_ld)
+        want = torch.from_numpy(pv).to(torch.bfloat16)
+        assert torch.equal(got[:, : pv.shape[1]].cpu(), want)
+        assert int(got[:, pv.shape[1]:].float().abs().sum()) == 0
+
+
+def test_tiny_vit_and_prefill_and_decode(tiny_engine, golden_dir):
+    """Whole tiny model against the oracle on the golden inputs (which are also pinned to HF)."""
+    from oracle import model_ref as MR
+    from oracle import weights as WG
+    g = np.load(os.path.join(golden_dir, "hf_tiny.npz"))
+    cfg = MR.config_tiny()
+    W = WG.LazyWeights(cfg, seed=0)
+    grids = [tuple(x) for x in g["grids"].tolist()]
+    pix = bits_to_f32(g["pix"])
+    img_ref = MR.vit_forward(W, cfg, pix, grids)
+    img = tiny_engine.vit_forward(pix.cuda(), grids)
+    mu, frac, mad = bf16_compare(img.float().cpu(), img_ref)
+    assert mad <= 3 * float(img_ref.abs().max()) * 2 ** -8, ("vit", mu, frac, mad)
+    # LM fed with the ORACLE's image embeddings, so that the LM comparison starts from identical inputs
+    ids = g["ids"]
+    pos3 = g["pos3"]
+    emb = img_ref.to(torch.bfloat16).cuda()
+    logits = tiny_engine.prefill([ids], [pos3], emb, return_logits=True)
+    x = MR.embed_with_images(W, cfg, torch.from_numpy(ids), img_ref)
+    caches = MR.new_caches(cfg)
+    ref_logits = MR.lm_forward(W, cfg, x, torch.from_numpy(pos3), caches)[0]
+    d = (logits[0].cpu() - ref_logits).abs()
+    assert float(d.max()) <= 0.03, ("prefill logits", float(d.max()))
+    # teacher-forced greedy decode: per-step logits within the noise floor, tokens equal where the margin is clear
+    n_new = 12
+    toks_ref, lg_ref = MR.generate_greedy(W, cfg, torch.from_numpy(ids), torch.from_numpy(pos3), img_ref, n_new)
+    forced = torch.tensor([toks_ref + [0] * (16 - len(toks_ref))], dtype=torch.int32)
+    tiny_engine.prefill([ids], [pos3], emb)
+    toks, trace = tiny_engine.decode(16, trace=True, forced=forced, use_graph=False)
+    for i in range(n_new):
+        dd = (trace[i, 0].cpu() - lg_ref[i]).abs()
+        assert float(dd.max()) <= 0.04, (i, float(dd.max()))
+        top2 = lg_ref[i].topk(2).values
+        if float(top2[0] - top2[1]) > 0.08:
+            assert int(toks[0, i]) == toks_ref[i], i
+
+
+def test_decode_graph_equals_eager_and_batch_invariance(tiny_engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, "hf_tiny.npz"))
+    grids = [tuple(x) for x in g["grids"].tolist()]
+    emb = tiny_engine.vit_forward(bits_to_f32(g["pix"]).cuda(), grids)
+    ids, pos3 = g["ids"], g["pos3"]
+    tiny_engine.prefill([ids], [pos3], emb)
+    eager = tiny_engine.decode(16, use_graph=False)
+    tiny_engine.prefill([ids], [pos3], emb)
+    graph = tiny_engine.decode(16, use_graph=True)
+    assert torch.equal(eager, graph)
+    # the same sequence in three slots of a batch, plus a shorter text-only neighbour: identical tokens
+    other = ids[:9].copy()
+    other[other >= 2040] = 5
+    pos_o = np.tile(np.arange(9), (3, 1))
+    emb3 = torch.cat([emb, emb, emb])
+    tiny_engine.prefill([ids, other, ids, ids], [pos3, pos_o, pos3, pos3], emb3)
+    bt = tiny_engine.decode(16, use_graph=True)
+    assert torch.equal(bt[0], eager[0]) and torch.equal(bt[2], eager[0]) and torch.equal(bt[3], eager[0])
+    # eos handling: stop at the first generated token, pad afterwards
+    first = int(eager[0, 0])
+    tiny_engine.prefill([ids], [pos3], emb)
+    st = tiny_engine.decode(16, eos=[first], pad_id=2045, use_graph=False)
+    assert st[0].tolist() == [first] + [2045] * 15
+
+
+# ------------------------------------------------------------------------------------------------ true dimensions
+def _truedim(full: bool):
+    from oracle import model_ref as MR
+    from socioreasoner_amd.config import geometry_3b
+    geom, cfg = geometry_3b(), MR.config_3b()
+    for c in (geom, cfg):
+        c.vision.depth, c.text.num_hidden_layers, c.text.vocab_size = 1, 1, 4096
+        c.vision.fullatt_block_indexes = (0,) if full else ()
+        c.image_token_id, c.vision_start_token_id, c.vision_end_token_id = 4000, 4001, 4002
+    return geom, cfg
+
+
+def test_truedim_single_block_and_layer():
+    """3B dimensions, one ViT block (window / full attention) + merger, one LM layer + LM head slice, one decode
+    step through the KV cache: engine vs oracle."""
+    from oracle import host_ref as H
+    from oracle import model_ref as MR
+    from oracle import weights as WG
+    from socioreasoner_amd import hostops, synthetic
+    from socioreasoner_amd.engine import Engine
+    img = synthetic.tile_pixels(0)
+    pv, grid = H.patchify(img)
+    ref_img = None
+    for full in (False, True):
+        geom, cfg = _truedim(full)
+        W = WG.LazyWeights(cfg, seed=0)
+        e = Engine(geom, max_patches=1024, max_prefill_tokens=512, max_batch=2, max_ctx=576, max_new_tokens=8)
+        e.load_synthetic_weights(seed=0)
+        ref = MR.vit_forward(W, cfg, torch.from_numpy(pv), [grid])
+        got = e.vit_forward(e.patchify(torch.from_numpy(img).cuda()), [grid]) if not full else \
+            e.vit_forward(torch.from_numpy(pv).cuda(), [grid])                    # float32 pixel input path
+        mu, frac, mad = bf16_compare(got.float().cpu(), ref)
+        assert mad <= 2 * float(ref.abs().max()) * 2 ** -8, ("vit block full=%s" % full, mu, frac, mad)
+        if full:
+            e.close()
+            continue
+        ref_img = ref
+        ids = synthetic.tile_prompt(geom, 0, grid)
+        assert len(ids) == 448
+        pos3, _ = hostops.get_rope_index(torch.from_numpy(ids)[None], [grid], None, image_token_id=4000, vision_start_token_id=4001)
+        pos3 = pos3[:, 0].numpy()
+        logits = e.prefill([ids], [pos3], ref_img.to(torch.bfloat16).cuda(), return_logits=True)
+        x = MR.embed_with_images(W, cfg, torch.from_numpy(ids), ref_img)
+        caches = MR.new_caches(cfg)
+        ref_logits = MR.lm_forward(W, cfg, x, torch.from_numpy(pos3), caches)[0]
+        d = (logits[0].cpu() - ref_logits).abs()
+        assert float(d.max()) <= 0.02, ("1-layer logits", float(d.max()), float(ref_logits.abs().max()))
+        tok = int(ref_logits.argmax())
+        forced = torch.full((1, 8), tok, dtype=torch.int32)
+        _, trace = e.decode(8, trace=True, forced=forced, use_graph=False)
+        xx = W["model.embed_tokens.weight"][torch.tensor([tok])]
+        p3 = torch.full((3, 1), int(pos3.max()) + 1, dtype=torch.int64)
+        ref_step = MR.lm_forward(W, cfg, xx, p3, caches)[0]
+        d = (trace[1, 0].cpu() - ref_step).abs()
+        assert float(d.max()) <= 0.02, ("decode step logits", float(d.max()))
+        e.close()

@@ -1,0 +1,120 @@
+"""CPU: product-side host logic against the golden vectors, the C-ABI surface, and the 2-rank DP path (gloo)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from socioreasoner_amd import dp, hostops, lib
+from socioreasoner_amd.config import geometry_3b, geometry_tiny
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """include/socior.h is the contract: every function it declares must be exported, and bound by lib.py."""
+    hdr = open(os.path.join(ROOT, "include", "socior.h")).read()
+    declared = set(re.findall(r"\b(sr_[a-z0-9_]+)\s*\(", hdr)) - {"sr_engine", "sr_config"}
+    assert declared, "no declarations parsed"
+    assert os.path.exists(lib.LIB_PATH), "libsocior.so not built: run __graft_entry__.build()"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (sr_[a-z0-9_]+)", out))
+    assert declared <= exported, f"missing from libsocior.so: {sorted(declared - exported)}"
+    assert declared == set(lib.SIGNATURES), f"lib.py binding drift: {sorted(declared ^ set(lib.SIGNATURES))}"
+    L = lib.load()          # loads (hip runtime present), no compute call
+    assert L.sr_version() == 1
+
+
+def test_product_fails_loudly_without_gpu():
+    from socioreasoner_amd.engine import Engine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(lib.SocioRError):
+        Engine(geometry_tiny())
+
+
+def test_workspace_sizing_is_pure_host():
+    from socioreasoner_amd.engine import _sr_config
+    import ctypes as C
+    L = lib.load()
+    cfg = _sr_config(geometry_3b(), 1024, 512, 1, 640, 128)
+    n1 = L.sr_workspace_bytes(C.byref(cfg))
+    cfg32 = _sr_config(geometry_3b(), 32768, 16384, 32, 640, 128)
+    n32 = L.sr_workspace_bytes(C.byref(cfg32))
+    assert 7.5e9 < n1 < 9e9 and n1 < n32 < 20e9, (n1, n32)   # 7.5 GB of bf16 weights + activations + KV
+    bad = _sr_config(geometry_3b(), 1024, 512, 1, 100, 128)  # max_ctx not a multiple of 64
+    assert L.sr_workspace_bytes(C.byref(bad)) == 0
+
+
+def test_rope_index_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "index.npz"))
+    pos3, deltas = hostops.get_rope_index(torch.from_numpy(g["rope_ids"]), g["rope_grids"], torch.from_numpy(g["rope_mask"]))
+    assert (pos3.numpy() == g["rope_pos3"]).all() and (deltas.numpy() == g["rope_deltas"]).all()
+    p2, d2 = hostops.get_rope_index(torch.from_numpy(g["rope_ids"]), None, torch.from_numpy(g["rope_mask"]))
+    assert (p2.numpy() == g["rope_text_pos3"]).all() and (d2.numpy() == g["rope_text_deltas"]).all()
+
+
+def test_smart_resize_matches_hf(golden_dir):
+    g = np.load(os.path.join(golden_dir, "patchify.npz"))
+    for h, w, eh, ew in g["smart_resize"].tolist():
+        assert hostops.smart_resize(h, w) == (eh, ew)
+
+
+def test_parsers_match_reference(golden_dir):
+    for case in json.load(open(os.path.join(golden_dir, "parsers.json"))):
+        assert hostops.parse_points_text_from_content(case["content"]) == case["points_text"]
+        assert hostops.parse_visual_prompt_from_json_s2(case["content"]) == case["prompts"], case["content"]
+
+
+def test_postprocess_generate_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "postprocess.npz"))
+    seq, eos, pad = g["seq"].tolist()
+    ids, outs = torch.from_numpy(g["in_ids"]), torch.from_numpy(g["outs"])
+    cat = hostops.concatenate_input_and_output(ids, outs, 1)
+    assert (cat.numpy() == g["cat"]).all()
+    res = hostops.postprocess_generate({"input_ids": ids, "attention_mask": torch.from_numpy(g["in_mask"]),
+                                        "position_ids": torch.from_numpy(g["in_pos"])}, cat, 1, seq, eos, pad)
+    for k, v in res.items():
+        assert (v.numpy().astype(np.int64) == g["out_" + k].astype(np.int64)).all(), k
+    assert hostops.gather_outputs_to_pad_tensor([[1, 2, 3], [4]], 0).tolist() == [[1, 2, 3], [4, 0, 0]]
+    assert hostops.gather_unpadded_input_ids(torch.tensor([[0, 5, 6]]), torch.tensor([[0, 1, 1]])) == [[5, 6]]
+
+
+def test_dp_split_is_array_split():
+    for n in [0, 1, 7, 8, 250, 256, 257]:
+        for w in [1, 2, 4, 8]:
+            want = [len(c) for c in np.array_split(np.arange(n), w)]
+            assert dp.split_sizes(n, w) == want
+            spans = [dp.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, {root!r})
+from socioreasoner_amd import dp
+rank, world, _ = dp.init_distributed("gloo")
+n = 7
+a, b = dp.shard_range(n, rank, world)
+local = torch.arange(a, b, dtype=torch.int64).unsqueeze(1) * 10 + torch.arange(3)
+full = dp.all_gather_rows(local, n)
+want = torch.arange(n).unsqueeze(1) * 10 + torch.arange(3)
+assert full.shape == (n, 3) and (full == want).all(), (rank, full)
+dp.barrier()
+print("ok", rank)
+"""
+
+
+def test_dp_all_gather_two_ranks_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2
