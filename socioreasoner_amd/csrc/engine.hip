@@ -103,6 +103,7 @@ struct sr_engine {
     bool copy_pending = false;
     // ---- decode graph cache
     hipGraphExec_t graph = nullptr;
+    hipStream_t cap_stream = nullptr;   // used only to CAPTURE the decode step (the caller's stream may be the null stream)
     int graph_B = -1, graph_neos = -1, graph_pad = 0;
     // ---- bookkeeping
     std::map<std::string, bool> loaded;
@@ -492,6 +493,8 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
     if (r != hipSuccess) { delete e; return fail(nullptr, (int)r, "hipHostMalloc: %s", hipGetErrorString(r)); }
     r = hipEventCreateWithFlags(&e->ev_copy, hipEventDisableTiming);
     if (r != hipSuccess) { (void)hipHostFree(e->h_stage); delete e; return fail(nullptr, (int)r, "hipEventCreate"); }
+    r = hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking);
+    if (r != hipSuccess) { (void)hipEventDestroy(e->ev_copy); (void)hipHostFree(e->h_stage); delete e; return fail(nullptr, (int)r, "hipStreamCreate"); }
     // zero weights (padding must be 0), KV cache (0 * stale must stay finite) and decode state
     r = hipMemset(e->ar.base + e->weights_begin, 0, e->weights_end - e->weights_begin);
     if (r == hipSuccess) r = hipMemset(e->kcache, 0, e->kv_layer_elems * e->c.t_layers * sizeof(bf16_t));
@@ -523,6 +526,7 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
 int sr_engine_destroy(sr_engine* e) {
     if (!e) return 0;
     if (e->graph) (void)hipGraphExecDestroy(e->graph);
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     if (e->ev_copy) (void)hipEventDestroy(e->ev_copy);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     delete e;
@@ -786,10 +790,10 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
     if (graph_ok && (e->graph == nullptr || e->graph_B != B || e->graph_neos != n_eos || e->graph_pad != pad_id)) {
         if (e->graph) { (void)hipGraphExecDestroy(e->graph); e->graph = nullptr; }
         hipGraph_t g = nullptr;
-        SR_TRY((int)hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-        int rc = enqueue_step_advance(e, B, n_eos, pad_id, nullptr, s);
-        if (!rc) rc = enqueue_decode_forward(e, B, s);
-        hipError_t er = hipStreamEndCapture(s, &g);
+        SR_TRY((int)hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
+        int rc = enqueue_step_advance(e, B, n_eos, pad_id, nullptr, e->cap_stream);
+        if (!rc) rc = enqueue_decode_forward(e, B, e->cap_stream);
+        hipError_t er = hipStreamEndCapture(e->cap_stream, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         SR_TRY((int)er);
         er = hipGraphInstantiate(&e->graph, g, nullptr, nullptr, 0);

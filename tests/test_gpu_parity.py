@@ -38,6 +38,20 @@ def P(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_KEEP = []
+
+
+def D(t):
+    """host tensor -> device tensor that stays alive until the test module ends (the launches are asynchronous and
+    a temporary freed before the next allocation could be reused by it)."""
+    d = t.cuda()
+    _KEEP.append(d)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return d
+
+
 def rnd(shape, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16)
@@ -73,7 +87,7 @@ def test_gemm_store_bias_rowmap(L, M, N, K):
     a, w, b = rnd((M, K), 1), rnd((N, K), 2, 0.05), rnd((N,), 3, 0.1)
     perm = torch.randperm(M, generator=torch.Generator().manual_seed(4)).int()
     out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
-    rc = L.sr_op_gemm(P(a.cuda()), K, P(w.cuda()), M, N, K, P(out), N, P(b.cuda()), None, P(perm.cuda()), EPI_STORE, sp())
+    rc = L.sr_op_gemm(P(D(a)), K, P(D(w)), M, N, K, P(out), N, P(D(b)), None, P(D(perm)), EPI_STORE, sp())
     assert rc == 0
     want = torch.empty(M, N)
     want[perm.long()] = MR.linear(a.float(), w.float(), b.float())
@@ -85,14 +99,14 @@ def test_gemm_resid_inplace_and_gelu_and_f32(L):
     M, N, K = 300, 1280, 3456
     a, w, b, x = rnd((M, K), 5), rnd((N, K), 6, 0.03), rnd((N,), 7, 0.1), rnd((M, N), 8)
     xd = x.cuda().clone()
-    assert L.sr_op_gemm(P(a.cuda()), K, P(w.cuda()), M, N, K, P(xd), N, P(b.cuda()), P(xd), None, EPI_RESID, sp()) == 0
+    assert L.sr_op_gemm(P(D(a)), K, P(D(w)), M, N, K, P(xd), N, P(D(b)), P(xd), None, EPI_RESID, sp()) == 0
     want = MR.r(x.float() + MR.linear(a.float(), w.float(), b.float()))
     assert_bf16_close(xd.float().cpu(), want, 1, 0.01, "gemm resid")
     out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
-    assert L.sr_op_gemm(P(a.cuda()), K, P(w.cuda()), M, N, K, P(out), N, P(b.cuda()), None, None, EPI_GELU, sp()) == 0
+    assert L.sr_op_gemm(P(D(a)), K, P(D(w)), M, N, K, P(out), N, P(D(b)), None, None, EPI_GELU, sp()) == 0
     assert_bf16_close(out.float().cpu(), MR.gelu_bf16(MR.linear(a.float(), w.float(), b.float())), 1, 0.01, "gemm gelu")
     o32 = torch.zeros(M, N, dtype=torch.float32, device="cuda")
-    assert L.sr_op_gemm(P(a.cuda()), K, P(w.cuda()), M, N, K, P(o32), N, None, None, None, EPI_F32, sp()) == 0
+    assert L.sr_op_gemm(P(D(a)), K, P(D(w)), M, N, K, P(o32), N, None, None, None, EPI_F32, sp()) == 0
     ref = a.double() @ w.double().t()
     assert float((o32.cpu().double() - ref).abs().max()) <= 1e-3   # float32 accumulate vs float64
 
@@ -102,10 +116,10 @@ def test_gemm_swiglu(L, M, I, K, bias):
     from oracle import model_ref as MR
     a, wg, wu = rnd((M, K), 9), rnd((I, K), 10, 0.03), rnd((I, K), 11, 0.03)
     bg, bu = (rnd((I,), 12, 0.1), rnd((I,), 13, 0.1)) if bias else (None, None)
-    w = interleave16(wg, wu).cuda()
-    b = interleave16(bg[:, None], bu[:, None]).reshape(-1).cuda() if bias else None
+    w = D(interleave16(wg, wu))
+    b = D(interleave16(bg[:, None], bu[:, None]).reshape(-1)) if bias else None
     out = torch.zeros(M, I, dtype=torch.bfloat16, device="cuda")
-    assert L.sr_op_gemm(P(a.cuda()), K, P(w), M, 2 * I, K, P(out), I, P(b), None, None, EPI_SWIGLU, sp()) == 0
+    assert L.sr_op_gemm(P(D(a)), K, P(w), M, 2 * I, K, P(out), I, P(b), None, None, EPI_SWIGLU, sp()) == 0
     g = MR.linear(a.float(), wg.float(), bg.float() if bias else None)
     u = MR.linear(a.float(), wu.float(), bu.float() if bias else None)
     assert_bf16_close(out.float().cpu(), MR.r(MR.silu_bf16(g) * u), 1, 0.01, "gemm swiglu")
@@ -119,25 +133,25 @@ def test_gemv_modes(L, M):
     x, w = rnd((M, K), 20), rnd((N, K), 21, 0.03)
     for ks in (1, 2, 4):
         part = torch.zeros(ks, M, N, dtype=torch.float32, device="cuda")
-        assert L.sr_op_gemv(P(x.cuda()), K, P(w.cuda()), M, N, K, P(part), ks, GV_PARTIAL, sp()) == 0
+        assert L.sr_op_gemv(P(D(x)), K, P(D(w)), M, N, K, P(part), ks, GV_PARTIAL, sp()) == 0
         got = part.sum(0).cpu()
         ref = (x.double() @ w.double().t())
         assert float((got.double() - ref).abs().max()) <= 1e-3, ("partial", M, ks)
     V = 4096
     wv = rnd((V, K), 22, 0.03)
     lg = torch.zeros(M, V, dtype=torch.float32, device="cuda")
-    assert L.sr_op_gemv(P(x.cuda()), K, P(wv.cuda()), M, V, K, P(lg), 1, GV_F32, sp()) == 0
+    assert L.sr_op_gemv(P(D(x)), K, P(D(wv)), M, V, K, P(lg), 1, GV_F32, sp()) == 0
     assert float((lg.cpu().double() - x.double() @ wv.double().t()).abs().max()) <= 1e-3
     I, K2 = 11008, 2048
     wg, wu = rnd((I, K2), 23, 0.03), rnd((I, K2), 24, 0.03)
     act = torch.zeros(M, I, dtype=torch.bfloat16, device="cuda")
-    assert L.sr_op_gemv(P(x.cuda()), K2, P(interleave16(wg, wu).cuda()), M, 2 * I, K2, P(act), 1, GV_SWIGLU, sp()) == 0
+    assert L.sr_op_gemv(P(D(x)), K2, P(D(interleave16(wg, wu))), M, 2 * I, K2, P(act), 1, GV_SWIGLU, sp()) == 0
     want = MR.r(MR.silu_bf16(MR.linear(x.float(), wg.float())) * MR.linear(x.float(), wu.float()))
     assert_bf16_close(act.float().cpu(), want, 1, 0.01, f"gemv swiglu M={M}")
     # K = 11008 down projection, split 4
     xd, wd = rnd((M, I), 25), rnd((2048, I), 26, 0.02)
     part = torch.zeros(4, M, 2048, dtype=torch.float32, device="cuda")
-    assert L.sr_op_gemv(P(xd.cuda()), I, P(wd.cuda()), M, 2048, I, P(part), 4, GV_PARTIAL, sp()) == 0
+    assert L.sr_op_gemv(P(D(xd)), I, P(D(wd)), M, 2048, I, P(part), 4, GV_PARTIAL, sp()) == 0
     assert float((part.sum(0).cpu().double() - xd.double() @ wd.double().t()).abs().max()) <= 2e-3
 
 
@@ -147,12 +161,12 @@ def test_rmsnorm_and_resid(L, rows, H):
     from oracle import model_ref as MR
     x, w = rnd((rows, H), 30, 2.0), (1 + rnd((H,), 31, 0.05).float()).to(torch.bfloat16)
     out = torch.zeros(rows, H, dtype=torch.bfloat16, device="cuda")
-    assert L.sr_op_rmsnorm(P(x.cuda()), P(w.cuda()), P(out), rows, H, C.c_float(1e-6), sp()) == 0
+    assert L.sr_op_rmsnorm(P(D(x)), P(D(w)), P(out), rows, H, C.c_float(1e-6), sp()) == 0
     assert_bf16_close(out.float().cpu(), MR.rmsnorm(x.float(), w.float(), 1e-6), 1, 0.002, "rmsnorm")
     if rows <= 32 and H <= 2048:
         part = torch.randn(3, rows, H, generator=torch.Generator().manual_seed(32))
         xd = x.cuda().clone()
-        assert L.sr_op_resid_rmsnorm(P(xd), P(part.cuda()), 3, P(w.cuda()), P(out), rows, H, C.c_float(1e-6), sp()) == 0
+        assert L.sr_op_resid_rmsnorm(P(xd), P(D(part)), 3, P(D(w)), P(out), rows, H, C.c_float(1e-6), sp()) == 0
         h = MR.r(x.float() + MR.r(part[0] + part[1] + part[2]))
         assert_bf16_close(xd.float().cpu(), h, 1, 0.002, "resid")
         assert_bf16_close(out.float().cpu(), MR.rmsnorm(h, w.float(), 1e-6), 1, 0.01, "resid norm")
@@ -165,7 +179,7 @@ def test_argmax_lowest_index_on_ties(L):
     lg[2, V - 1] = 11.0
     lg[3, 0] = 12.0
     out = torch.zeros(4, dtype=torch.int32, device="cuda")
-    assert L.sr_op_argmax(P(lg.cuda()), 4, V, P(out), sp()) == 0
+    assert L.sr_op_argmax(P(D(lg)), 4, V, P(out), sp()) == 0
     assert out.cpu().tolist() == [int(lg[0].argmax()), 77, V - 1, 0]
 
 
