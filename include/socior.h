@@ -122,6 +122,13 @@ int sr_render_overlay(uint8_t* dev_img_rgb, int h, int w, const uint8_t* dev_mas
 int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void* out, int ldo, const void* bias,
                const void* resid, const int32_t* rowmap, int epilogue, void* stream);
 int sr_op_gemv(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ksplit, int mode, void* stream);
+/* decode GEMV with its fusions (mode 3 = bias epilogue, 4 = residual epilogue in place; norm_w != NULL = RMSNorm
+ * prologue, optionally after adding n_slabs float32 slabs [n_slabs][M][K]; amax_* = per-block argmax partials of the
+ * float32 mode, row length sr_op_gemv_f32_blocks(N)) */
+int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ldo, int mode, const void* bias,
+                     const void* norm_w, float eps, const float* slabs, int n_slabs, void* x_out, float* amax_val,
+                     int32_t* amax_idx, void* stream);
+int sr_op_gemv_f32_blocks(int N);
 int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, float eps, void* stream);
 int sr_op_resid_rmsnorm(void* x, const float* partials, int ksplit, const void* w, void* out, int rows, int H, float eps,
                         void* stream);

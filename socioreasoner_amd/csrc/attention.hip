@@ -173,78 +173,137 @@ __global__ __launch_bounds__(256) void k_attn_prefill(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------- decode (q_len = 1)
-// One block per (sequence, kv head): the `group` query heads that share the kv head are the MFMA N dimension.
-constexpr int DEC_HD = 128;
+// One block of 16 waves per (sequence, kv head); the `group` query heads that share the kv head are the MFMA N
+// dimension.  Fused in front of the attention: mRoPE of the new q/k (bf16 ops, hf:557-599) and the KV-cache append
+// (K row, V^T column), so a decode layer needs one launch here instead of three.  The block reads its own cache
+// writes back after a workgroup-scope fence + barrier.  Latency-bound at batch 1 (2 blocks per layer): all key tiles
+// of a wave are prefetched one tile ahead, and 16 waves keep ~150 KB of K / V^T loads in flight.
+constexpr int DEC_HD = 128, DEC_WAVES = 16;
 
-__global__ __launch_bounds__(256) void k_attn_decode(DecodeAttnArgs p, int s_stride) {
+__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2) {
+    o1 = rbf(rbf(x1 * c) + rbf((-x2) * s));
+    o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
+}
+
+__global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p, int s_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    bf16_t* sb = reinterpret_cast<bf16_t*>(dsm);            // [group][s_stride] scores, then probabilities
+    // LDS: q_s[16][136] bf16 | cs[64] sn[64] float | ored[8][64] f32x4 | sb[group][s_stride] bf16
+    bf16_t* q_s = reinterpret_cast<bf16_t*>(dsm);
+    float* cs = reinterpret_cast<float*>(dsm + 16 * 136 * 2);
+    float* sn = cs + 64;
+    f32x4* ored = reinterpret_cast<f32x4*>(sn + 64);
+    bf16_t* sb = reinterpret_cast<bf16_t*>(ored + 8 * 64);
     const int b = blockIdx.x, kvh = blockIdx.y;
     const int slot = p.slots ? p.slots[b] : b;
     const int nkeys = p.ctx_len[b];
+    const int idx = nkeys - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int G = p.group;
-    const bf16_t* kc = p.kcache + (size_t)(slot * p.n_kv_heads + kvh) * p.ctx_max * DEC_HD;
-    const bf16_t* vc = p.vtcache + (size_t)(slot * p.n_kv_heads + kvh) * DEC_HD * p.ctx_max;
+    const int G = p.group, HQ = p.n_q_heads, HK = p.n_kv_heads;
+    bf16_t* kc = p.kcache + (size_t)(slot * HK + kvh) * p.ctx_max * DEC_HD;
+    bf16_t* vc = p.vtcache + (size_t)(slot * HK + kvh) * DEC_HD * p.ctx_max;
+    const bf16_t* row = p.qkv + (size_t)b * p.qkv_stride;
     const uint4 z4 = uint4{0, 0, 0, 0};
+
+    if (tid < 64) {
+        const float ang = (float)p.pos[b] * p.inv_freq[tid];
+        cs[tid] = rbf(cosf(ang));
+        sn[tid] = rbf(sinf(ang));
+    }
+    __syncthreads();
+    // ---- rope + cache append
+    for (int i = tid; i < 16 * 64; i += DEC_WAVES * 64) {
+        const int h = i >> 6, d = i & 63;
+        float o1 = 0.f, o2 = 0.f;
+        if (h < G) {
+            const bf16_t* q = row + (kvh * G + h) * DEC_HD + d;
+            rope_pair(bf2f(q[0]), bf2f(q[64]), cs[d], sn[d], o1, o2);
+        }
+        q_s[h * 136 + d] = f2bf(o1);
+        q_s[h * 136 + d + 64] = f2bf(o2);
+    }
+    if (tid < 64) {
+        const bf16_t* k = row + (HQ + kvh) * DEC_HD + tid;
+        float o1, o2;
+        rope_pair(bf2f(k[0]), bf2f(k[64]), cs[tid], sn[tid], o1, o2);
+        kc[(size_t)idx * DEC_HD + tid] = f2bf(o1);
+        kc[(size_t)idx * DEC_HD + tid + 64] = f2bf(o2);
+    } else if (tid < 64 + DEC_HD) {
+        const int d = tid - 64;
+        vc[(size_t)d * p.ctx_max + idx] = row[(HQ + HK + kvh) * DEC_HD + d];
+    }
+    __threadfence_block();
+    __syncthreads();
 
     // ---- phase A: scores S^T[key][head]
     bf16x8 qf[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        uint4 v = z4;
-        if (fr < G) v = *reinterpret_cast<const uint4*>(p.q + (size_t)b * p.q_stride + (kvh * G + fr) * DEC_HD + kk * 32 + fg * 8);
-        qf[kk] = __builtin_bit_cast(bf16x8, v);
-    }
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(q_s + fr * 136 + kk * 32 + fg * 8);
     const int ntiles = (nkeys + 15) / 16;
-    for (int t = wave; t < ntiles; t += 4) {
+    auto load_k = [&](int t, bf16x8 (&kf)[4]) {
         const int key = min(t * 16 + fr, nkeys - 1);
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 kf = *reinterpret_cast<const bf16x8*>(kc + (size_t)key * DEC_HD + kk * 32 + fg * 8);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
-        }
-        if (fr < G) {
-            uint2 v = {pack2(rbf(acc[0]) * p.scale, rbf(acc[1]) * p.scale), pack2(rbf(acc[2]) * p.scale, rbf(acc[3]) * p.scale)};
-            *reinterpret_cast<uint2*>(sb + fr * s_stride + t * 16 + fg * 4) = v;
+        for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(kc + (size_t)key * DEC_HD + kk * 32 + fg * 8);
+    };
+    {
+        bf16x8 kcur[4], knxt[4];
+        int t = wave;
+        if (t < ntiles) load_k(t, kcur);
+        while (t < ntiles) {
+            const int tn = t + DEC_WAVES;
+            if (tn < ntiles) load_k(tn, knxt);
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kcur[kk], qf[kk], acc, 0, 0, 0);
+            if (fr < G) {
+                uint2 v = {pack2(rbf(acc[0]) * p.scale, rbf(acc[1]) * p.scale), pack2(rbf(acc[2]) * p.scale, rbf(acc[3]) * p.scale)};
+                *reinterpret_cast<uint2*>(sb + fr * s_stride + t * 16 + fg * 4) = v;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) kcur[kk] = knxt[kk];
+            t = tn;
         }
     }
     __syncthreads();
     // ---- phase B: softmax per head (float32), probabilities rounded to bf16 in place; tail zero-filled
     const int npad = (nkeys + 31) / 32 * 32;
-    for (int hh = wave; hh < G; hh += 4) {
-        bf16_t* row = sb + hh * s_stride;
+    for (int hh = wave; hh < G; hh += DEC_WAVES) {
+        bf16_t* srow = sb + hh * s_stride;
         float mx = -INFINITY;
-        for (int j = lane; j < nkeys; j += 64) mx = fmaxf(mx, bf2f(row[j]));
+        for (int j = lane; j < nkeys; j += 64) mx = fmaxf(mx, bf2f(srow[j]));
         mx = wave_max(mx);
         float sum = 0.f;
-        for (int j = lane; j < nkeys; j += 64) sum += __expf(bf2f(row[j]) - mx);
+        for (int j = lane; j < nkeys; j += 64) sum += __expf(bf2f(srow[j]) - mx);
         sum = wave_sum(sum);
         const float inv = 1.0f / sum;
-        for (int j = lane; j < npad; j += 64) row[j] = (j < nkeys) ? f2bf(__expf(bf2f(row[j]) - mx) * inv) : (bf16_t)0;
+        for (int j = lane; j < npad; j += 64) srow[j] = (j < nkeys) ? f2bf(__expf(bf2f(srow[j]) - mx) * inv) : (bf16_t)0;
     }
     __syncthreads();
-    // ---- phase C: O^T[d][head] = V^T[d][:] . P^T
-    f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    for (int kb = 0; kb < npad / 32; ++kb) {
-        uint4 pv = z4;
-        if (fr < G) pv = *reinterpret_cast<const uint4*>(sb + fr * s_stride + kb * 32 + fg * 8);
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, pv);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int d = (wave * 2 + i) * 16 + fr;
-            bf16x8 vf = *reinterpret_cast<const bf16x8*>(vc + (size_t)d * p.ctx_max + kb * 32 + fg * 8);
-            oacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[i], 0, 0, 0);
+    // ---- phase C: O^T[d][head] = V^T[d][:] . P^T ; wave -> (d-tile = wave & 7, key-block parity = wave >> 3)
+    const int dt = wave & 7, par = wave >> 3;
+    const int nkb = npad / 32;
+    f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const bf16_t* vrow = vc + (size_t)(dt * 16 + fr) * p.ctx_max + fg * 8;
+        int kb = par;
+        bf16x8 vcur, vnxt;
+        if (kb < nkb) vcur = *reinterpret_cast<const bf16x8*>(vrow + kb * 32);
+        while (kb < nkb) {
+            const int kn = kb + 2;
+            if (kn < nkb) vnxt = *reinterpret_cast<const bf16x8*>(vrow + kn * 32);
+            uint4 pv = z4;
+            if (fr < G) pv = *reinterpret_cast<const uint4*>(sb + fr * s_stride + kb * 32 + fg * 8);
+            oacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcur, __builtin_bit_cast(bf16x8, pv), oacc, 0, 0, 0);
+            vcur = vnxt;
+            kb = kn;
         }
     }
-    if (fr < G) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            uint2 v = {pack2(oacc[i][0], oacc[i][1]), pack2(oacc[i][2], oacc[i][3])};
-            *reinterpret_cast<uint2*>(p.out + (size_t)b * p.out_stride + (kvh * G + fr) * DEC_HD + (wave * 2 + i) * 16 + fg * 4) = v;
-        }
+    if (par == 1) ored[dt * 64 + lane] = oacc;
+    __syncthreads();
+    if (par == 0 && fr < G) {
+        const f32x4 o2 = ored[dt * 64 + lane];
+        uint2 v = {pack2(oacc[0] + o2[0], oacc[1] + o2[1]), pack2(oacc[2] + o2[2], oacc[3] + o2[3])};
+        *reinterpret_cast<uint2*>(p.out + (size_t)b * p.out_stride + (kvh * G + fr) * DEC_HD + dt * 16 + fg * 4) = v;
     }
 }
 
@@ -261,9 +320,13 @@ int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim) {
     return 0;
 }
 
+static size_t dec_smem(int ctx_max, int group) {
+    return 16 * 136 * 2 + 128 * 4 + 8 * 64 * 16 + (size_t)group * (ctx_max + 8) * sizeof(bf16_t);
+}
+
 // raises the dynamic-LDS limit once, outside of any stream capture
 int attn_decode_prepare(int ctx_max, int group) {
-    const size_t smem = (size_t)group * (ctx_max + 8) * sizeof(bf16_t);
+    const size_t smem = dec_smem(ctx_max, group);
     if (smem > 160 * 1024) return -22;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_decode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 }
@@ -272,8 +335,7 @@ int launch_attn_decode(hipStream_t s, const DecodeAttnArgs& a) {
     if (a.B <= 0) return 0;
     if (a.group > 16 || a.ctx_max % 64 != 0) return -22;
     const int s_stride = a.ctx_max + 8;
-    const size_t smem = (size_t)a.group * s_stride * sizeof(bf16_t);
-    hipLaunchKernelGGL(k_attn_decode, dim3(a.B, a.n_kv_heads), dim3(256), smem, s, a, s_stride);
+    hipLaunchKernelGGL(k_attn_decode, dim3(a.B, a.n_kv_heads), dim3(DEC_WAVES * 64), dec_smem(a.ctx_max, a.group), s, a, s_stride);
     SR_CHECK_LAUNCH();
     return 0;
 }

@@ -132,46 +132,6 @@ __global__ __launch_bounds__(256) void k_lm_rope_prefill(LmRopeArgs p) {
     }
 }
 
-// decode: qkv row = bf16(sum_ks part + bias) (the q/k/v Linear outputs, hf:626-629), then rope, then cache append
-__global__ __launch_bounds__(256) void k_lm_decode_qkv(LmDecodeQkvArgs p) {
-    extern __shared__ float dq[];   // [(HQ+2HK)*128] + cos[64] + sin[64]
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int HQ = p.n_q_heads, HK = p.n_kv_heads, N = (HQ + 2 * HK) * 128;
-    float* cs = dq + N;
-    float* sn = cs + 64;
-    if (tid < 64) {
-        const float ang = (float)p.pos[b] * p.inv_freq[tid];
-        cs[tid] = rbf(cosf(ang));
-        sn[tid] = rbf(sinf(ang));
-    }
-    for (int n = tid; n < N; n += 256) {
-        float a = 0.f;
-        for (int ks = 0; ks < p.ksplit; ++ks) a += p.part[((size_t)ks * p.B + b) * N + n];
-        dq[n] = rbf(a + bf2f(p.bias[n]));
-    }
-    __syncthreads();
-    const int slot = p.slots ? p.slots[b] : b;
-    const int idx = p.ctx_len[b] - 1;
-    for (int i = tid; i < (HQ + HK) * 64; i += 256) {
-        const int h = i >> 6, d = i & 63;
-        float o1, o2;
-        rope_pair_bf16(dq[h * 128 + d], dq[h * 128 + d + 64], cs[d], sn[d], o1, o2);
-        if (h < HQ) {
-            bf16_t* q = p.qout + (size_t)b * HQ * 128 + h * 128 + d;
-            q[0] = f2bf(o1);
-            q[64] = f2bf(o2);
-        } else {
-            bf16_t* kc = p.kcache + ((size_t)(slot * HK + (h - HQ)) * p.ctx_max + idx) * 128 + d;
-            kc[0] = f2bf(o1);
-            kc[64] = f2bf(o2);
-        }
-    }
-    for (int i = tid; i < HK * 128; i += 256) {
-        const int h = i >> 7, d = i & 127;
-        p.vtcache[((size_t)(slot * HK + h) * 128 + d) * p.ctx_max + idx] = f2bf(dq[(HQ + HK) * 128 + i]);
-    }
-}
-
 // ----------------------------------------------------------------------------------------------- gathers
 // src >= 0: token id -> embedding row; src < 0: image feature row -(src+1)  (hf:1210-1216 masked_scatter)
 __global__ __launch_bounds__(256) void k_embed(const int* src, const bf16_t* table, const bf16_t* img, bf16_t* out, int H) {
@@ -238,12 +198,34 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* logits, int V, int
     }
 }
 
-// per-step bookkeeping on the device so that one captured graph replays for every step
-__global__ void k_step_advance(StepArgs a) {
-    const int b = threadIdx.x;
-    const int step = *a.step;
-    if (b < a.B) {
-        int tok = a.argmax[b];
+// per-step bookkeeping on the device so that one captured graph replays for every step.  One block per sequence:
+// finish the greedy argmax from the LM-head partials (lowest index among maxima), log the token, eos / teacher
+// forcing, advance (ctx_len, pos, step) and gather the embedding row of the token that is fed back.
+__global__ __launch_bounds__(256) void k_step(StepArgs a) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ int s_feed;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < a.n_part; i += 256) {
+        const float v = a.amax_val[(size_t)b * a.n_part + i];
+        const int ix = a.amax_idx[(size_t)b * a.n_part + i];
+        if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { sv[tid >> 6] = bv; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < 4; ++k)
+            if (sv[k] > bv || (sv[k] == bv && si[k] < bi)) { bv = sv[k]; bi = si[k]; }
+        const int step = a.step[b];
+        int tok = bi;
         const int fin = a.finished[b];
         if (fin) tok = a.pad_id;
         if (step < a.max_new) a.tokens_out[(size_t)b * a.max_new + step] = tok;
@@ -253,11 +235,15 @@ __global__ void k_step_advance(StepArgs a) {
         a.cur_tok[b] = tok;
         int feed = tok;
         if (a.forced && step < a.max_new) feed = a.forced[(size_t)b * a.max_new + step];
-        a.embed_src[b] = fin ? 0 : feed;
+        if (fin) feed = 0;
         if (!fin && !is_eos) { a.ctx_len[b] += 1; a.pos[b] += 1; }
+        a.step[b] = step + 1;
+        s_feed = feed;
     }
     __syncthreads();
-    if (b == 0) *a.step = step + 1;
+    const bf16_t* from = a.table + (size_t)s_feed * a.H;
+    for (int c = tid; c < a.H / 8; c += 256)
+        reinterpret_cast<uint4*>(a.x + (size_t)b * a.H)[c] = reinterpret_cast<const uint4*>(from)[c];
 }
 
 // counter-based synthetic weights; definition shared with oracle/weights.py (independent implementations)
@@ -332,13 +318,6 @@ int launch_lm_rope_prefill(hipStream_t s, const LmRopeArgs& a) {
     SR_CHECK_LAUNCH();
     return 0;
 }
-int launch_lm_decode_qkv(hipStream_t s, const LmDecodeQkvArgs& a) {
-    if (a.B <= 0) return 0;
-    const size_t smem = ((size_t)(a.n_q_heads + 2 * a.n_kv_heads) * 128 + 128) * sizeof(float);
-    hipLaunchKernelGGL(k_lm_decode_qkv, dim3(a.B), dim3(256), smem, s, a);
-    SR_CHECK_LAUNCH();
-    return 0;
-}
 int launch_embed(hipStream_t s, const int* src, const bf16_t* table, const bf16_t* image_embeds, bf16_t* out, int n_tok, int H) {
     if (n_tok <= 0) return 0;
     hipLaunchKernelGGL(k_embed, dim3(n_tok), dim3(256), 0, s, src, table, image_embeds, out, H);
@@ -371,8 +350,9 @@ int launch_argmax(hipStream_t s, const float* logits, int rows, int V, int* out_
     SR_CHECK_LAUNCH();
     return 0;
 }
-int launch_step_advance(hipStream_t s, const StepArgs& a) {
-    hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(64), 0, s, a);
+int launch_step(hipStream_t s, const StepArgs& a) {
+    if (a.B <= 0) return 0;
+    hipLaunchKernelGGL(k_step, dim3(a.B), dim3(256), 0, s, a);
     SR_CHECK_LAUNCH();
     return 0;
 }

@@ -65,7 +65,7 @@ struct sr_engine {
     sr_config c;
     // derived geometry
     int v_hd, v_pd, v_pd_pad, v_inter_pad, v_mh, t_inter_pad, t_qn, t_group;
-    int ks_h, ks_q, ks_down;     // split-K factors of the decode GEMVs
+    int ks_down;                 // cross-block split-K (float32 slabs) of the decode down-projection
     Arena ar;
     size_t weights_begin = 0, weights_end = 0;
     // ---- weights
@@ -89,10 +89,10 @@ struct sr_engine {
     int *t_src, *t_pos3, *t_slot, *t_idx, *t_lastrow;
     AttnWork* t_work;
     // ---- decode state (device)
-    bf16_t *d_x, *d_xn, *d_q, *d_attn, *d_act;
-    float *d_logits, *d_part_qkv, *d_part_o, *d_part_down;
-    int *d_argmax, *d_cur_tok, *d_embed_src, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
-    int* d_state_init;   // staging copy of [ctx_len | pos | slots] uploaded by prefill
+    bf16_t *d_xa, *d_xb, *d_xn, *d_qkv, *d_attn, *d_act;    // d_xa / d_xb: residual stream ping-pong
+    float *d_logits, *d_slabs, *d_amax_val;
+    int *d_amax_idx, *d_cur_tok, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
+    int n_part = 0;      // LM-head blocks = partial argmax entries per row
     bf16_t *kcache, *vtcache;
     size_t kv_layer_elems;
     // ---- host staging (pinned) + its device mirror
@@ -147,12 +147,6 @@ const char* validate(const sr_config& c) {
     return nullptr;
 }
 
-int pick_ks(int K) {
-    const int ch = K / 64;
-    for (int ks : {4, 2}) if (ch % ks == 0 && ch / ks >= 2) return ks;
-    return 1;
-}
-
 // Carves every buffer.  With ar.base == nullptr this is a dry run that only measures.
 void carve(sr_engine* e) {
     const sr_config& c = e->c;
@@ -165,9 +159,8 @@ void carve(sr_engine* e) {
     e->t_inter_pad = rup(c.t_inter, 64);
     e->t_qn = (c.t_heads + 2 * c.t_kv_heads) * 128;
     e->t_group = c.t_heads / c.t_kv_heads;
-    e->ks_h = pick_ks(c.t_hidden);
-    e->ks_q = pick_ks(c.t_heads * 128);
-    e->ks_down = pick_ks(e->t_inter_pad);
+    e->ks_down = (e->t_inter_pad / 64 >= 16) ? 2 : 1;
+    e->n_part = gemv_f32_blocks(c.t_vocab);
     const int C = c.v_hidden, H = c.t_hidden;
 
     e->weights_begin = (ar.off + 255) & ~(size_t)255;
@@ -240,25 +233,23 @@ void carve(sr_engine* e) {
 
     // decode
     const size_t B = c.max_batch;
-    e->d_x = ar.take<bf16_t>(B * H);
+    e->d_xa = ar.take<bf16_t>(B * H);
+    e->d_xb = ar.take<bf16_t>(B * H);
     e->d_xn = ar.take<bf16_t>(B * H);
-    e->d_q = ar.take<bf16_t>(B * c.t_heads * 128);
+    e->d_qkv = ar.take<bf16_t>(B * e->t_qn);
     e->d_attn = ar.take<bf16_t>(B * c.t_heads * 128);
     e->d_act = ar.take<bf16_t>(B * e->t_inter_pad);
     e->d_logits = ar.take<float>(B * c.t_vocab);
-    e->d_part_qkv = ar.take<float>(4 * B * e->t_qn);
-    e->d_part_o = ar.take<float>(4 * B * H);
-    e->d_part_down = ar.take<float>(4 * B * H);
-    e->d_argmax = ar.take<int>(32);
+    e->d_slabs = ar.take<float>(2 * B * H);
+    e->d_amax_val = ar.take<float>(B * e->n_part);
+    e->d_amax_idx = ar.take<int>(B * e->n_part);
     e->d_cur_tok = ar.take<int>(32);
-    e->d_embed_src = ar.take<int>(32);
     e->d_ctx_len = ar.take<int>(32);
     e->d_pos = ar.take<int>(32);
     e->d_finished = ar.take<int>(32);
     e->d_step = ar.take<int>(32);
     e->d_slots = ar.take<int>(32);
     e->d_eos = ar.take<int>(32);
-    e->d_state_init = ar.take<int>(3 * 32);
     e->d_tokens = ar.take<int>(B * c.max_new_tokens);
     e->kv_layer_elems = B * c.t_kv_heads * (size_t)c.max_ctx * 128;
     e->kcache = ar.take<bf16_t>(e->kv_layer_elems * c.t_layers);
@@ -415,44 +406,79 @@ int gemm(sr_engine* e, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W,
     return 0;
 }
 
-// one decode forward pass for rows 0..B-1 (device state decides tokens / positions / context lengths)
-int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
+GemvArgs gv(const bf16_t* x, int ldx, const bf16_t* W, int M, int N, int K, void* out, int ldo) {
+    GemvArgs a{};
+    a.x = x; a.ldx = ldx; a.W = W; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo; a.ksplit = 1;
+    return a;
+}
+
+// LM head on B rows of `x` (+ optional pending slabs): float32 logits + per-block argmax partials.
+// Small batches fuse the final RMSNorm (and the pending residual) into the GEMV prologue.
+int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending, hipStream_t s) {
     const sr_config& c = e->c;
-    const int H = c.t_hidden, QD = c.t_heads * 128;
-    SR_TRY(launch_embed(s, e->d_embed_src, e->embed, nullptr, e->d_x, B, H));
-    for (int l = 0; l < c.t_layers; ++l) {
-        const LmLayerW& w = e->ll[l];
-        if (l == 0) SR_TRY(launch_rmsnorm(s, e->d_x, w.ln1, e->d_xn, B, H, c.t_rms_eps));
-        else SR_TRY(launch_resid_rmsnorm(s, e->d_x, e->d_part_down, e->ks_down, w.ln1, e->d_xn, B, H, c.t_rms_eps));
-        GemvArgs gq{e->d_xn, H, w.qkv_w, B, e->t_qn, H, e->d_part_qkv, e->ks_h};
-        SR_TRY(launch_gemv(s, gq, GV_PARTIAL));
-        bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
-        bf16_t* vc = e->vtcache + (size_t)l * e->kv_layer_elems;
-        LmDecodeQkvArgs qa{e->d_part_qkv, e->ks_h, w.qkv_b, B, c.t_heads, c.t_kv_heads, e->d_pos, e->d_ctx_len, e->d_slots,
-                           e->inv_freq, e->d_q, kc, vc, c.max_ctx};
-        SR_TRY(launch_lm_decode_qkv(s, qa));
-        DecodeAttnArgs da{e->d_q, QD, kc, vc, e->d_ctx_len, e->d_slots, e->d_attn, QD, B, c.t_kv_heads, e->t_group, c.max_ctx,
-                          (float)(1.0 / sqrt(128.0))};
-        SR_TRY(launch_attn_decode(s, da));
-        GemvArgs go{e->d_attn, QD, w.o_w, B, H, QD, e->d_part_o, e->ks_q};
-        SR_TRY(launch_gemv(s, go, GV_PARTIAL));
-        SR_TRY(launch_resid_rmsnorm(s, e->d_x, e->d_part_o, e->ks_q, w.ln2, e->d_xn, B, H, c.t_rms_eps));
-        GemvArgs gg{e->d_xn, H, w.gu_w, B, 2 * e->t_inter_pad, H, e->d_act, 1};
-        SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
-        GemvArgs gd{e->d_act, e->t_inter_pad, w.down_w, B, H, e->t_inter_pad, e->d_part_down, e->ks_down};
-        SR_TRY(launch_gemv(s, gd, GV_PARTIAL));
+    const int H = c.t_hidden;
+    GemvArgs g = gv(x, H, e->embed, B, c.t_vocab, H, e->d_logits, c.t_vocab);
+    g.amax_val = e->d_amax_val; g.amax_idx = e->d_amax_idx;
+    if (B <= 4) {
+        g.norm_w = e->final_norm; g.eps = c.t_rms_eps;
+        if (pending) { g.slabs = e->d_slabs; g.n_slabs = e->ks_down; g.x_out = x_alt; }
+    } else {
+        if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, e->ks_down, e->final_norm, e->d_xn, B, H, c.t_rms_eps));
+        else SR_TRY(launch_rmsnorm(s, x, e->final_norm, e->d_xn, B, H, c.t_rms_eps));
+        g.x = e->d_xn;
     }
-    SR_TRY(launch_resid_rmsnorm(s, e->d_x, e->d_part_down, e->ks_down, e->final_norm, e->d_xn, B, H, c.t_rms_eps));
-    GemvArgs gl{e->d_xn, H, e->embed, B, c.t_vocab, H, e->d_logits, 1};
-    SR_TRY(launch_gemv(s, gl, GV_F32));
-    SR_TRY(launch_argmax(s, e->d_logits, B, c.t_vocab, e->d_argmax));
+    SR_TRY(launch_gemv(s, g, GV_F32));
     return 0;
 }
 
-int enqueue_step_advance(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, hipStream_t s) {
-    StepArgs a{e->d_argmax, e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished, e->d_tokens,
-               e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, e->d_embed_src, forced};
-    SR_TRY(launch_step_advance(s, a));
+// one decode forward pass for rows 0..B-1 (device state decides tokens / positions / context lengths).
+// B <= 4: 5 launches per layer (norms and residual adds live in GEMV prologues / epilogues); larger batches keep the
+// two RMSNorm launches (the per-block prologue would re-read B rows too often).
+int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
+    const sr_config& c = e->c;
+    const int H = c.t_hidden, QD = c.t_heads * 128;
+    const bool fused = B <= 4;
+    bf16_t *x = e->d_xa, *x_alt = e->d_xb;      // k_step gathered the input embedding into d_xa
+    bool pending = false;                       // down-projection slabs not yet added to the residual stream
+    const float scale = (float)(1.0 / sqrt(128.0));
+    for (int l = 0; l < c.t_layers; ++l) {
+        const LmLayerW& w = e->ll[l];
+        bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
+        bf16_t* vc = e->vtcache + (size_t)l * e->kv_layer_elems;
+        GemvArgs gq = gv(x, H, w.qkv_w, B, e->t_qn, H, e->d_qkv, e->t_qn);
+        gq.bias = w.qkv_b;
+        if (fused) {
+            gq.norm_w = w.ln1; gq.eps = c.t_rms_eps;
+            if (pending) { gq.slabs = e->d_slabs; gq.n_slabs = e->ks_down; gq.x_out = x_alt; }
+        } else {
+            if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, e->ks_down, w.ln1, e->d_xn, B, H, c.t_rms_eps));
+            else SR_TRY(launch_rmsnorm(s, x, w.ln1, e->d_xn, B, H, c.t_rms_eps));
+            gq.x = e->d_xn;
+        }
+        SR_TRY(launch_gemv(s, gq, GV_BIAS));
+        if (fused && pending) { bf16_t* t = x; x = x_alt; x_alt = t; }     // block 0 wrote the updated stream there
+        pending = false;
+        DecodeAttnArgs da{e->d_qkv, e->t_qn, e->d_pos, e->d_ctx_len, e->d_slots, e->inv_freq, kc, vc, e->d_attn, QD,
+                          B, c.t_heads, c.t_kv_heads, e->t_group, c.max_ctx, scale};
+        SR_TRY(launch_attn_decode(s, da));
+        GemvArgs go = gv(e->d_attn, QD, w.o_w, B, H, QD, x, H);
+        SR_TRY(launch_gemv(s, go, GV_RESID));
+        GemvArgs gg = gv(x, H, w.gu_w, B, 2 * e->t_inter_pad, H, e->d_act, e->t_inter_pad);
+        if (fused) { gg.norm_w = w.ln2; gg.eps = c.t_rms_eps; }
+        else { SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps)); gg.x = e->d_xn; }
+        SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
+        GemvArgs gd = gv(e->d_act, e->t_inter_pad, w.down_w, B, H, e->t_inter_pad, e->d_slabs, H);
+        gd.ksplit = e->ks_down;
+        SR_TRY(launch_gemv(s, gd, GV_PARTIAL));
+        pending = true;
+    }
+    return enqueue_lm_head(e, B, x, x_alt, pending, s);
+}
+
+int enqueue_step(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, hipStream_t s) {
+    StepArgs a{e->d_amax_val, e->d_amax_idx, e->n_part, e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished,
+               e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden};
+    SR_TRY(launch_step(s, a));
     return 0;
 }
 
@@ -499,7 +525,7 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
     r = hipMemset(e->ar.base + e->weights_begin, 0, e->weights_end - e->weights_begin);
     if (r == hipSuccess) r = hipMemset(e->kcache, 0, e->kv_layer_elems * e->c.t_layers * sizeof(bf16_t));
     if (r == hipSuccess) r = hipMemset(e->vtcache, 0, e->kv_layer_elems * e->c.t_layers * sizeof(bf16_t));
-    if (r == hipSuccess) r = hipMemset(e->d_argmax, 0, (char*)e->d_tokens - (char*)e->d_argmax);
+    if (r == hipSuccess) r = hipMemset(e->d_cur_tok, 0, (char*)e->d_tokens - (char*)e->d_cur_tok);
     if (r == hipSuccess) r = hipMemset(e->v_vt, 0, (size_t)e->c.v_hidden * e->v_vt_stride * sizeof(bf16_t));
     // normalise LUT (hf image_transforms.py:89-124, 384-440) and rotary inverse frequencies (hf:506-523)
     std::vector<bf16_t> lut(768);
@@ -736,7 +762,7 @@ int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int3
     SR_TRY((int)hipMemcpyAsync(e->d_pos, dmirror(h_state + 32), 32 * 4, hipMemcpyDeviceToDevice, s));
     SR_TRY((int)hipMemcpyAsync(e->d_slots, dmirror(h_state + 64), 32 * 4, hipMemcpyDeviceToDevice, s));
     SR_TRY((int)hipMemsetAsync(e->d_finished, 0, 32 * 4, s));
-    SR_TRY((int)hipMemsetAsync(e->d_step, 0, 4, s));
+    SR_TRY((int)hipMemsetAsync(e->d_step, 0, 32 * 4, s));
 
     // ---- forward over the packed tokens
     const int H = c.t_hidden, QD = c.t_heads * 128;
@@ -760,11 +786,8 @@ int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int3
         if (int rc = gemm(e, s, e->t_act, e->t_inter_pad, w.down_w, n_tok, H, e->t_inter_pad, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID)) return rc;
     }
     // last position of every sequence -> final norm -> tied LM head (hf:1386-1387) -> greedy token
-    SR_TRY(launch_gather_rows(s, e->t_x, e->t_lastrow, e->d_x, B, H));
-    SR_TRY(launch_rmsnorm(s, e->d_x, e->final_norm, e->d_xn, B, H, c.t_rms_eps));
-    GemvArgs gl{e->d_xn, H, e->embed, B, c.t_vocab, H, e->d_logits, 1};
-    SR_TRY(launch_gemv(s, gl, GV_F32));
-    SR_TRY(launch_argmax(s, e->d_logits, B, c.t_vocab, e->d_argmax));
+    SR_TRY(launch_gather_rows(s, e->t_x, e->t_lastrow, e->d_xa, B, H));
+    if (int rc = enqueue_lm_head(e, B, e->d_xa, e->d_xb, false, s)) return rc;
     if (logits_out) SR_TRY((int)hipMemcpyAsync(logits_out, e->d_logits, (size_t)B * c.t_vocab * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
@@ -791,7 +814,7 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
         if (e->graph) { (void)hipGraphExecDestroy(e->graph); e->graph = nullptr; }
         hipGraph_t g = nullptr;
         SR_TRY((int)hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
-        int rc = enqueue_step_advance(e, B, n_eos, pad_id, nullptr, e->cap_stream);
+        int rc = enqueue_step(e, B, n_eos, pad_id, nullptr, e->cap_stream);
         if (!rc) rc = enqueue_decode_forward(e, B, e->cap_stream);
         hipError_t er = hipStreamEndCapture(e->cap_stream, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -805,13 +828,13 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
     std::vector<int> fin(B);
     for (int i = 0; i < max_new; ++i) {
         if (i == max_new - 1) {   // the last token only needs to be recorded
-            if (int rc = enqueue_step_advance(e, B, n_eos, pad_id, forced_dev, s)) return rc;
+            if (int rc = enqueue_step(e, B, n_eos, pad_id, forced_dev, s)) return rc;
             done = max_new;
             break;
         }
         if (graph_ok) SR_TRY((int)hipGraphLaunch(e->graph, s));
         else {
-            if (int rc = enqueue_step_advance(e, B, n_eos, pad_id, forced_dev, s)) return rc;
+            if (int rc = enqueue_step(e, B, n_eos, pad_id, forced_dev, s)) return rc;
             if (int rc = enqueue_decode_forward(e, B, s)) return rc;
             if (logits_trace)
                 SR_TRY((int)hipMemcpyAsync(logits_trace + (size_t)(i + 1) * B * V, e->d_logits, B * V * 4, hipMemcpyDeviceToDevice, s));
@@ -859,9 +882,19 @@ int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void*
     SR_WRAP(launch_gemm((hipStream_t)stream, a, epilogue));
 }
 int sr_op_gemv(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ksplit, int mode, void* stream) {
-    GemvArgs a{(const bf16_t*)x, ldx, (const bf16_t*)W, M, N, K, out, ksplit};
+    GemvArgs a = gv((const bf16_t*)x, ldx, (const bf16_t*)W, M, N, K, out, mode == GV_SWIGLU ? N / 2 : N);
+    a.ksplit = ksplit;
     SR_WRAP(launch_gemv((hipStream_t)stream, a, mode));
 }
+int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ldo, int mode, const void* bias,
+                     const void* norm_w, float eps, const float* slabs, int n_slabs, void* x_out, float* amax_val,
+                     int32_t* amax_idx, void* stream) {
+    GemvArgs a = gv((const bf16_t*)x, ldx, (const bf16_t*)W, M, N, K, out, ldo);
+    a.bias = (const bf16_t*)bias; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.slabs = slabs; a.n_slabs = n_slabs;
+    a.x_out = (bf16_t*)x_out; a.amax_val = amax_val; a.amax_idx = amax_idx;
+    SR_WRAP(launch_gemv((hipStream_t)stream, a, mode));
+}
+int sr_op_gemv_f32_blocks(int N) { return gemv_f32_blocks(N); }
 int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, float eps, void* stream) {
     SR_WRAP(launch_rmsnorm((hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out, rows, H, eps));
 }

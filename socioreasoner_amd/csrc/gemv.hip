@@ -1,17 +1,27 @@
-// Weight-streaming skinny GEMM for autoregressive decode (SURVEY.md 2.3 K13/K16/K17 at M = batch <= 32):
-//   out[M,N] = x[M,K] . W[N,K]^T.   HBM-bound: every weight byte is read exactly once per step, straight from
+// Weight-streaming skinny GEMM for autoregressive decode (SURVEY.md 2.3 K12/K13/K16/K17 at M = batch <= 32):
+//   out[M,N] = f(x)[M,K] . W[N,K]^T.   HBM-bound: every weight byte is read exactly once per step, straight from
 //   HBM into VGPRs (no LDS round trip: the operand is not shared between waves), 16 B per lane, 128 B per row
 //   per k-chunk, non-temporal (each CU reads its slice once), deep unroll so that >= 8 KB per wave is in flight.
-// Each wave owns one 16-row tile of W (two tiles -- gate and up -- for the SwiGLU epilogue) over its K slice and
-// feeds it to the 16x16x32 MFMA as the A operand; x (tiny, L2 resident) is the B operand, rows >= M read as zero.
-// The k-slot -> k mapping is permuted (lane group g covers k = g*16 .. g*16+15 of each 64-chunk as two MFMA steps)
-// so that a lane's two 16-byte loads are contiguous; both operands use the same permutation, so the sum is unchanged.
+// A wave owns one 16-row tile of W (two tiles -- gate and up -- for the SwiGLU epilogue) over a K slice and feeds it
+// to the 16x16x32 MFMA as the A operand; x (tiny) is the B operand, rows >= M read as zero.  The k-slot -> k mapping
+// is permuted (lane group g covers k = g*16 .. g*16+15 of each 64-chunk as two MFMA steps) so that a lane's two
+// 16-byte loads are contiguous; both operands use the same permutation, so the sum is unchanged.
+// K is split over the KP waves of a block (deterministic LDS reduction, fixed order) so that even N = 2048 outputs
+// give every CU work, and optionally over gridDim.y blocks (PARTIAL mode: float32 slabs summed by the consumer).
+// Fusions (each removes a launch from the 36-layer decode chain):
+//   NORM prologue : h = bf16(x + bf16(sum slabs)) (pending residual of the previous down-projection), RMSNorm
+//                   (hf:65-79) of h into LDS as the B operand; block 0 writes h back for the later residual add;
+//   BIAS epilogue : bf16(acc + bias)            (q/k/v Linear, hf:626-629)
+//   RESID epilogue: x = bf16(x + bf16(acc))      (o_proj + residual, hf:744-748) in place
+//   SWIGLU        : bf16(bf16(silu(bf16 g)) * bf16 u)   (hf:541-554)
+//   F32 + argmax  : float32 logits and a per-block (max, lowest index) pair for the greedy token (hf:1386-1387).
 #include "kernels.h"
+#include <math.h>
 #include <type_traits>
 
 namespace {
 
-constexpr int WAVES = 4, UNROLL = 4;
+constexpr int WAVES = 4;
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 __device__ __forceinline__ u32x4 ldg_nt(const bf16_t* p) {
@@ -19,27 +29,72 @@ __device__ __forceinline__ u32x4 ldg_nt(const bf16_t* p) {
 }
 __device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <int MODE, int MT>
+template <int MODE, int MT, int KP, bool NORM>
 __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
-    constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;     // 16-row W tiles per wave
+    constexpr int TPB = WAVES / KP;                    // wave-tiles per block
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int tile = blockIdx.x * WAVES + wave;   // in units of T 16-row tiles
-    if (tile >= ntiles) return;
+    const int tp = wave / KP, kp = wave % KP;
+    const int tile = blockIdx.x * TPB + tp;            // in units of T tiles
+    const bool active = tile < ntiles;
     const int nchunks = p.K / 64;
-    const int per = nchunks / (MODE == GV_PARTIAL ? p.ksplit : 1);
-    const int c0 = (MODE == GV_PARTIAL ? blockIdx.y : 0) * per;
+    const int ks = (MODE == GV_PARTIAL) ? p.ksplit : 1;
+    const int per = (nchunks + ks * KP - 1) / (ks * KP);          // uneven split allowed (K/64 = 172 for the 3B MLP)
+    const int c0 = min(((MODE == GV_PARTIAL ? blockIdx.y : 0) * KP + kp) * per, nchunks);
 
-    const bf16_t* wrow[T];
+    // ---------------------------------------------------------------- NORM prologue: normalised x -> LDS
+    // layout: xn[m][K + 8] bf16 (row pad 16 B: conflict-free ds_read_b128 across rows), then rs[32] float
+    const int xs = p.K + 8;
+    bf16_t* xn = reinterpret_cast<bf16_t*>(smem);
+    float* red = reinterpret_cast<float*>(smem + (NORM ? ((size_t)p.M * xs * 2 + 15) / 16 * 16 : 0));   // [4][32] + reduce area
+    if constexpr (NORM) {
+        const int nch = p.K / 8;
+        // pass 1: h = x (+ pending residual) -> LDS (bf16), per-row sum of squares
+        for (int m = 0; m < p.M; ++m) {
+            float ss = 0.f;
+            for (int c = tid; c < nch; c += WAVES * 64) {
+                uint4 u = *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + c * 8);
+                float v[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
+                if (p.n_slabs > 0) {
+                    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    for (int s = 0; s < p.n_slabs; ++s) {
+                        const float4* pp = reinterpret_cast<const float4*>(p.slabs + ((size_t)s * p.M + m) * p.K + c * 8);
+                        float4 p0 = pp[0], p1 = pp[1];
+                        a[0] += p0.x; a[1] += p0.y; a[2] += p0.z; a[3] += p0.w;
+                        a[4] += p1.x; a[5] += p1.y; a[6] += p1.z; a[7] += p1.w;
+                    }
 #pragma unroll
-    for (int t = 0; t < T; ++t) wrow[t] = p.W + (size_t)(tile * T * 16 + t * 16 + fr) * p.K + fg * 16;
-    const bf16_t* xrow[MT];
-    bool xok[MT];
+                    for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + rbf(a[e]));
+                    u = uint4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                    if (blockIdx.x == 0 && blockIdx.y == 0) *reinterpret_cast<uint4*>(p.x_out + (size_t)m * p.ldx + c * 8) = u;
+                }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int m = mt * 16 + fr;
-        xok[mt] = m < p.M;
-        xrow[mt] = p.x + (size_t)(xok[mt] ? m : 0) * p.ldx + fg * 16;
+                for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+                *reinterpret_cast<uint4*>(xn + (size_t)m * xs + c * 8) = u;
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) red[wave * 32 + m] = ss;
+        }
+        __syncthreads();
+        // pass 2: xn = bf16(w * bf16(h * rs)) in place
+        for (int m = 0; m < p.M; ++m) {
+            const float tot = red[m] + red[32 + m] + red[64 + m] + red[96 + m];
+            const float rs = 1.0f / sqrtf(tot / (float)p.K + p.eps);
+            for (int c = tid; c < nch; c += WAVES * 64) {
+                uint4 u = *reinterpret_cast<const uint4*>(xn + (size_t)m * xs + c * 8);
+                uint4 wu = *reinterpret_cast<const uint4*>(p.norm_w + c * 8);
+                float v[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
+                float wv[8] = {lo16(wu.x), hi16(wu.x), lo16(wu.y), hi16(wu.y), lo16(wu.z), hi16(wu.z), lo16(wu.w), hi16(wu.w)};
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = wv[e] * rbf(v[e] * rs);
+                *reinterpret_cast<uint4*>(xn + (size_t)m * xs + c * 8) =
+                    uint4{pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+            }
+        }
+        __syncthreads();
     }
 
     f32x4 acc[T][MT];
@@ -48,89 +103,224 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto body = [&](int c, auto UN) {
-        constexpr int U = decltype(UN)::value;
-        u32x4 w[U][T][2], xv[U][MT][2];
+    if (active) {
+        const bf16_t* wrow[T];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int t = 0; t < T; ++t) wrow[t] = p.W + (size_t)(tile * T * 16 + t * 16 + fr) * p.K + fg * 16;
+        const bf16_t* xrow[MT];
+        bool xok[MT];
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                w[u][t][0] = ldg_nt(wrow[t] + (size_t)(c + u) * 64);
-                w[u][t][1] = ldg_nt(wrow[t] + (size_t)(c + u) * 64 + 8);
-            }
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mt * 16 + fr;
+            xok[mt] = m < p.M;
+            const int mm = xok[mt] ? m : 0;
+            xrow[mt] = (NORM ? xn + (size_t)mm * xs : p.x + (size_t)mm * p.ldx) + fg * 16;
+        }
+        auto body = [&](int c, auto UN) {
+            constexpr int U = decltype(UN)::value;
+            u32x4 w[U][T][2], xv[U][MT][2];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (xok[mt]) {
-                    xv[u][mt][0] = *reinterpret_cast<const u32x4*>(xrow[mt] + (size_t)(c + u) * 64);
-                    xv[u][mt][1] = *reinterpret_cast<const u32x4*>(xrow[mt] + (size_t)(c + u) * 64 + 8);
-                } else {
-                    xv[u][mt][0] = u32x4{0, 0, 0, 0};
-                    xv[u][mt][1] = u32x4{0, 0, 0, 0};
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    w[u][t][0] = ldg_nt(wrow[t] + (size_t)(c + u) * 64);
+                    w[u][t][1] = ldg_nt(wrow[t] + (size_t)(c + u) * 64 + 8);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (xok[mt]) {
+                        xv[u][mt][0] = *reinterpret_cast<const u32x4*>(xrow[mt] + (size_t)(c + u) * 64);
+                        xv[u][mt][1] = *reinterpret_cast<const u32x4*>(xrow[mt] + (size_t)(c + u) * 64 + 8);
+                    } else {
+                        xv[u][mt][0] = u32x4{0, 0, 0, 0};
+                        xv[u][mt][1] = u32x4{0, 0, 0, 0};
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][0]), as_frag(xv[u][mt][0]), acc[t][mt], 0, 0, 0);
+                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][1]), as_frag(xv[u][mt][1]), acc[t][mt], 0, 0, 0);
+                    }
+        };
+        constexpr int UNROLL = 8 / T;                                // 16 weight loads (16 KB) in flight per wave
+        int c = c0;
+        const int cend = min(c0 + per, nchunks);
+        for (; c + UNROLL <= cend; c += UNROLL) body(c, std::integral_constant<int, UNROLL>{});
+        for (; c < cend; ++c) body(c, std::integral_constant<int, 1>{});
+    }
+
+    // ---------------------------------------------------------------- in-block K reduction (fixed order kp = 1, 2, 3)
+    if constexpr (KP > 1) {
+        f32x4* rbuf = reinterpret_cast<f32x4*>(red + 128);      // [TPB][KP-1][T*MT][64]
+        if (kp > 0) {
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][0]), as_frag(xv[u][mt][0]),
-                                                                          acc[t][mt], 0, 0, 0);
-                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][1]), as_frag(xv[u][mt][1]),
-                                                                          acc[t][mt], 0, 0, 0);
-                }
-    };
-    int c = c0;
-    const int cend = c0 + per;
-    for (; c + UNROLL <= cend; c += UNROLL) body(c, std::integral_constant<int, UNROLL>{});
-    for (; c < cend; ++c) body(c, std::integral_constant<int, 1>{});
+                for (int mt = 0; mt < MT; ++mt)
+                    rbuf[((tp * (KP - 1) + (kp - 1)) * (T * MT) + t * MT + mt) * 64 + lane] = acc[t][mt];
+        }
+        __syncthreads();
+        if (kp == 0) {
+#pragma unroll
+            for (int k = 1; k < KP; ++k)
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        f32x4 o = rbuf[((tp * (KP - 1) + (k - 1)) * (T * MT) + t * MT + mt) * 64 + lane];
+                        acc[t][mt][0] += o[0]; acc[t][mt][1] += o[1]; acc[t][mt][2] += o[2]; acc[t][mt][3] += o[3];
+                    }
+        }
+    }
 
+    // ---------------------------------------------------------------- epilogue (wave kp == 0 of each tile)
     // lane owns batch row m = mt*16 + fr and output columns tile*16 + fg*4 + {0..3}
+    float bestv[MT];
+    int besti[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = mt * 16 + fr;
-        if (m >= p.M) continue;
-        if constexpr (MODE == GV_SWIGLU) {
-            float o[4];
+    for (int mt = 0; mt < MT; ++mt) { bestv[mt] = -INFINITY; besti[mt] = 0x7fffffff; }
+    if (active && kp == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float g = rbf(acc[0][mt][r]), u = rbf(acc[1][mt][r]);
-                o[r] = rbf(silu_f(g)) * u;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mt * 16 + fr;
+            if (m >= p.M) continue;
+            if constexpr (MODE == GV_SWIGLU) {
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float g = rbf(acc[0][mt][r]), u = rbf(acc[1][mt][r]);
+                    o[r] = rbf(silu_f(g)) * u;
+                }
+                uint2 v = {pack2(o[0], o[1]), pack2(o[2], o[3])};
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * (p.N / 2) + tile * 16 + fg * 4) = v;
+            } else if constexpr (MODE == GV_BIAS || MODE == GV_RESID) {
+                const int n = tile * 16 + fg * 4;
+                bf16_t* optr = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n;
+                float o[4] = {acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3]};
+                if (MODE == GV_BIAS && p.bias) {
+                    uint2 b = *reinterpret_cast<const uint2*>(p.bias + n);
+                    o[0] += lo16(b.x); o[1] += hi16(b.x); o[2] += lo16(b.y); o[3] += hi16(b.y);
+                }
+                if constexpr (MODE == GV_RESID) {
+                    uint2 rv = *reinterpret_cast<const uint2*>(optr);
+                    o[0] = lo16(rv.x) + rbf(o[0]); o[1] = hi16(rv.x) + rbf(o[1]);
+                    o[2] = lo16(rv.y) + rbf(o[2]); o[3] = hi16(rv.y) + rbf(o[3]);
+                }
+                *reinterpret_cast<uint2*>(optr) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+            } else {
+                const int n = tile * 16 + fg * 4;
+                float* o = reinterpret_cast<float*>(p.out) + ((size_t)(MODE == GV_PARTIAL ? blockIdx.y : 0) * p.M + m) * p.N + n;
+                *reinterpret_cast<float4*>(o) = float4{acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3]};
+                if constexpr (MODE == GV_F32) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (acc[0][mt][r] > bestv[mt]) { bestv[mt] = acc[0][mt][r]; besti[mt] = n + r; }
+                }
             }
-            uint2 v = {pack2(o[0], o[1]), pack2(o[2], o[3])};
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * (p.N / 2) + tile * 16 + fg * 4) = v;
-        } else {
-            const int n = tile * 16 + fg * 4;
-            float* o = reinterpret_cast<float*>(p.out) +
-                       ((size_t)(MODE == GV_PARTIAL ? blockIdx.y : 0) * p.M + m) * p.N + n;
-            *reinterpret_cast<float4*>(o) = float4{acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3]};
+        }
+    }
+    if constexpr (MODE == GV_F32) {
+        // fused greedy argmax: (max, lowest index) of this block's logits per batch row -> amax[m][blockIdx.x]
+        if (p.amax_val) {
+            float* av = red + 128 + 0;                 // KP == 1 here: reduce area is free.  [WAVES][32]
+            int* ai = reinterpret_cast<int*>(av + WAVES * 32);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float bv = bestv[mt];
+                int bi = besti[mt];
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {     // combine the 4 lane groups that hold the same batch row
+                    const float ov = __shfl_xor(bv, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if (fg == 0) { av[wave * 32 + mt * 16 + fr] = bv; ai[wave * 32 + mt * 16 + fr] = bi; }
+            }
+            __syncthreads();
+            if (tid < p.M) {
+                float bv = av[tid];
+                int bi = ai[tid];
+                for (int w = 1; w < WAVES; ++w) {
+                    const float ov = av[w * 32 + tid];
+                    const int oi = ai[w * 32 + tid];
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                p.amax_val[(size_t)tid * gridDim.x + blockIdx.x] = bv;
+                p.amax_idx[(size_t)tid * gridDim.x + blockIdx.x] = bi;
+            }
         }
     }
 }
 
-template <int MODE>
-int launch_m(hipStream_t s, const GemvArgs& a) {
-    const int T = (MODE == GV_SWIGLU) ? 2 : 1;
+template <int MODE, int MT, int KP, bool NORM>
+int launch_k(hipStream_t s, const GemvArgs& a) {
+    constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;
+    constexpr int TPB = WAVES / KP;
     const int ntiles = a.N / (16 * T);
-    dim3 grid(cdiv(ntiles, WAVES), MODE == GV_PARTIAL ? a.ksplit : 1);
-    if (a.M <= 16) hipLaunchKernelGGL((k_gemv<MODE, 1>), grid, dim3(WAVES * 64), 0, s, a, ntiles);
-    else hipLaunchKernelGGL((k_gemv<MODE, 2>), grid, dim3(WAVES * 64), 0, s, a, ntiles);
+    dim3 grid(cdiv(ntiles, TPB), MODE == GV_PARTIAL ? a.ksplit : 1);
+    size_t smem = NORM ? ((size_t)a.M * (a.K + 8) * 2 + 15) / 16 * 16 : 0;
+    smem += 128 * sizeof(float);                                                  // per-wave row sums
+    size_t red = (size_t)TPB * (KP > 1 ? KP - 1 : 0) * T * MT * 64 * sizeof(f32x4);
+    if (MODE == GV_F32) red = red > (size_t)WAVES * 32 * 8 ? red : (size_t)WAVES * 32 * 8;
+    smem += red;
+    if (smem > 160 * 1024) return -12;
+    static size_t attr = 0;
+    if (smem > 64 * 1024 && smem > attr) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemv<MODE, MT, KP, NORM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (r != hipSuccess) return (int)r;
+        attr = smem;
+    }
+    hipLaunchKernelGGL((k_gemv<MODE, MT, KP, NORM>), grid, dim3(WAVES * 64), smem, s, a, ntiles);
     SR_CHECK_LAUNCH();
     return 0;
 }
 
+template <int MODE, int KP, bool NORM>
+int launch_mt(hipStream_t s, const GemvArgs& a) {
+    return a.M <= 16 ? launch_k<MODE, 1, KP, NORM>(s, a) : launch_k<MODE, 2, KP, NORM>(s, a);
+}
+
+template <int MODE, int KP>
+int launch_n(hipStream_t s, const GemvArgs& a) {
+    if constexpr (MODE == GV_BIAS || MODE == GV_SWIGLU || MODE == GV_F32) {
+        if (a.norm_w) return launch_mt<MODE, KP, true>(s, a);
+    }
+    return launch_mt<MODE, KP, false>(s, a);
+}
+
 }  // namespace
+
+int gemv_f32_blocks(int N) { return cdiv(N / 16, WAVES); }
+
+// largest in-block K split that leaves >= 2 chunks per wave
+int gemv_pick_kp(int K, int ksplit, int want) {
+    const int ch = K / 64 / (ksplit > 0 ? ksplit : 1);
+    for (int kp = want; kp > 1; kp >>= 1)
+        if (ch / kp >= 2) return kp;
+    return 1;
+}
 
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     if (a.M <= 0) return 0;
     if (a.M > 32 || a.K % 64 != 0 || a.N % 16 != 0) return -22;
     if (mode == GV_SWIGLU && a.N % 32 != 0) return -22;
-    if (mode == GV_PARTIAL && (a.ksplit < 1 || (a.K / 64) % a.ksplit != 0)) return -22;
+    if (mode == GV_PARTIAL && (a.ksplit < 1 || a.ksplit > a.K / 64)) return -22;
+    if (a.norm_w && !(mode == GV_BIAS || mode == GV_SWIGLU || mode == GV_F32)) return -22;
+    if (a.n_slabs > 0 && (!a.norm_w || !a.slabs || !a.x_out)) return -22;
+    const int want = mode == GV_F32 ? 1 : (mode == GV_SWIGLU ? 2 : 4);
+    const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
     switch (mode) {
-        case GV_PARTIAL: return launch_m<GV_PARTIAL>(s, a);
-        case GV_SWIGLU: return launch_m<GV_SWIGLU>(s, a);
-        case GV_F32: return launch_m<GV_F32>(s, a);
+        case GV_PARTIAL: return kp == 4 ? launch_n<GV_PARTIAL, 4>(s, a) : kp == 2 ? launch_n<GV_PARTIAL, 2>(s, a) : launch_n<GV_PARTIAL, 1>(s, a);
+        case GV_SWIGLU: return kp == 2 ? launch_n<GV_SWIGLU, 2>(s, a) : launch_n<GV_SWIGLU, 1>(s, a);
+        case GV_F32: return launch_n<GV_F32, 1>(s, a);
+        case GV_BIAS: return kp == 4 ? launch_n<GV_BIAS, 4>(s, a) : kp == 2 ? launch_n<GV_BIAS, 2>(s, a) : launch_n<GV_BIAS, 1>(s, a);
+        case GV_RESID: return kp == 4 ? launch_n<GV_RESID, 4>(s, a) : kp == 2 ? launch_n<GV_RESID, 2>(s, a) : launch_n<GV_RESID, 1>(s, a);
     }
     return -22;
 }

@@ -18,15 +18,22 @@ struct GemmArgs {
 int launch_gemm(hipStream_t s, const GemmArgs& a, int epi);
 
 // ------------------------------------------------------------------ gemv.hip (weight streaming, M <= 32)
-enum { GV_PARTIAL = 0, GV_SWIGLU = 1, GV_F32 = 2 };
+enum { GV_PARTIAL = 0, GV_SWIGLU = 1, GV_F32 = 2, GV_BIAS = 3, GV_RESID = 4 };
 struct GemvArgs {
-    const bf16_t* x; int ldx;   // [M, K]
+    const bf16_t* x; int ldx;   // [M, K] B operand; with norm_w: the residual stream the RMSNorm prologue reads
     const bf16_t* W;            // [N, K]
     int M, N, K;
-    void* out;                  // PARTIAL: float [ksplit][M][N]; SWIGLU: bf16 [M][N/2]; F32: float [M][N]
-    int ksplit;                 // PARTIAL only; (K/64) % ksplit == 0
+    void* out; int ldo;         // PARTIAL: float [ksplit][M][N]; SWIGLU: bf16 [M][N/2]; F32: float [M][N];
+                                // BIAS: bf16 [M][ldo]; RESID: bf16 [M][ldo] updated in place
+    int ksplit;                 // PARTIAL only (gridDim.y)
+    const bf16_t* bias;         // BIAS
+    const bf16_t* norm_w; float eps;        // non-null: fused RMSNorm prologue (BIAS / SWIGLU / F32)
+    const float* slabs; int n_slabs;        // pending residual [n_slabs][M][K] added before the norm
+    bf16_t* x_out;                          // with slabs: block 0 stores h = bf16(x + bf16(sum slabs)) here (ld = ldx)
+    float* amax_val; int* amax_idx;         // F32: per-block (max, lowest index) [M][gridDim.x] (null: skip)
 };
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode);
+int gemv_f32_blocks(int N);    // gridDim.x of the F32 launch (length of the amax rows)
 
 // ------------------------------------------------------------------ attention.hip
 // one 64-query tile of one sequence.  K element (kvh, key j, d) = k[(k_row0 + j)*k_stride + kvh*k_head_stride + d];
@@ -44,14 +51,17 @@ struct AttnArgs {
 };
 int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim);
 
+// decode: q/k/v rows (after the Linear bias, before rope) -> mRoPE -> KV-cache append -> attention, one launch
 struct DecodeAttnArgs {
-    const bf16_t* q; int q_stride;        // [B, Hq*128] after rope
-    const bf16_t* kcache;                 // [slot][kvh][ctx_max][128]
-    const bf16_t* vtcache;                // [slot][kvh][128][ctx_max]
-    const int* ctx_len;                   // [B] keys already in the cache INCLUDING the new token
+    const bf16_t* qkv; int qkv_stride;    // [B, (Hq + 2 Hkv)*128] bf16
+    const int* pos;                       // [B] rotary position of the new token (all three mRoPE axes equal)
+    const int* ctx_len;                   // [B] keys in the cache INCLUDING the new token
     const int* slots;                     // [B] cache slot of each row (null: identity)
-    bf16_t* out; int out_stride;
-    int B, n_kv_heads, group, ctx_max;
+    const float* inv_freq;                // [64]
+    bf16_t* kcache;                       // [slot][kvh][ctx_max][128]
+    bf16_t* vtcache;                      // [slot][kvh][128][ctx_max]
+    bf16_t* out; int out_stride;          // [B, Hq*128]
+    int B, n_q_heads, n_kv_heads, group, ctx_max;
     float scale;
 };
 int launch_attn_decode(hipStream_t s, const DecodeAttnArgs& a);
@@ -75,14 +85,6 @@ struct LmRopeArgs {
     bf16_t* kcache; bf16_t* vtcache; int ctx_max;
 };
 int launch_lm_rope_prefill(hipStream_t s, const LmRopeArgs& a);
-// decode: qkv = r(sum partials + bias); rope at pos[b]; q -> qout [B, Hq*128]; K/V -> cache row ctx_len[b]-1
-struct LmDecodeQkvArgs {
-    const float* part; int ksplit; const bf16_t* bias;
-    int B, n_q_heads, n_kv_heads;
-    const int* pos; const int* ctx_len; const int* slots; const float* inv_freq;
-    bf16_t* qout; bf16_t* kcache; bf16_t* vtcache; int ctx_max;
-};
-int launch_lm_decode_qkv(hipStream_t s, const LmDecodeQkvArgs& a);
 int launch_embed(hipStream_t s, const int* src, const bf16_t* table, const bf16_t* image_embeds, bf16_t* out,
                  int n_tok, int H);
 int launch_gather_rows(hipStream_t s, const bf16_t* in, const int* rows, bf16_t* out, int n, int H);
@@ -90,12 +92,16 @@ int launch_patchify(hipStream_t s, const uint8_t* img, int h, int w, const bf16_
                     int patch, int merge, int temporal);
 int launch_f32_to_bf16_pad(hipStream_t s, const float* in, int rows, int cols, bf16_t* out, int ld_out);
 int launch_argmax(hipStream_t s, const float* logits, int rows, int V, int* out_idx);
+// per-step bookkeeping on the device (one captured graph replays for every step): finishes the greedy argmax from the
+// LM-head partials, logs the token, handles eos / teacher forcing, gathers the next input embedding, advances state
 struct StepArgs {
-    const int* argmax; int* cur_tok; int* ctx_len; int* pos; int* step; int* finished; int* tokens_out;
-    int max_new; const int* eos; int n_eos; int pad_id; int B; int* embed_src;
+    const float* amax_val; const int* amax_idx; int n_part;     // [B][n_part]
+    int* cur_tok; int* ctx_len; int* pos; int* step; int* finished; int* tokens_out;
+    int max_new; const int* eos; int n_eos; int pad_id; int B;
     const int* forced;          // optional [B][max_new]: token fed back instead of the greedy one (teacher forcing)
+    const bf16_t* table; bf16_t* x; int H;                      // embedding gather of the token fed back
 };
-int launch_step_advance(hipStream_t s, const StepArgs& a);
+int launch_step(hipStream_t s, const StepArgs& a);
 int launch_synth_fill(hipStream_t s, bf16_t* out, long long n, uint32_t key, float base, float scale);
 int launch_fill_zero(hipStream_t s, void* p, size_t bytes);
 int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, long long cols, bf16_t* dst, long long dst_ld,
