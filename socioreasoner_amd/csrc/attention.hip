@@ -187,16 +187,18 @@ __device__ __forceinline__ void rope_pair(float x1, float x2, float c, float s, 
 
 __global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p, int s_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    // LDS: q_s[16][136] bf16 | cs[64] sn[64] float | ored[8][64] f32x4 | sb[group][s_stride] bf16
+    // LDS: q_s[16][136] bf16 | k_s[128] v_s[128] bf16 | cs[64] sn[64] float | ored[8][64] f32x4 | sb[group][s_stride] bf16
     bf16_t* q_s = reinterpret_cast<bf16_t*>(dsm);
-    float* cs = reinterpret_cast<float*>(dsm + 16 * 136 * 2);
+    bf16_t* k_s = q_s + 16 * 136;
+    bf16_t* v_s = k_s + 128;
+    float* cs = reinterpret_cast<float*>(v_s + 128);
     float* sn = cs + 64;
     f32x4* ored = reinterpret_cast<f32x4*>(sn + 64);
     bf16_t* sb = reinterpret_cast<bf16_t*>(ored + 8 * 64);
     const int b = blockIdx.x, kvh = blockIdx.y;
     const int slot = p.slots ? p.slots[b] : b;
     const int nkeys = p.ctx_len[b];
-    const int idx = nkeys - 1;
+    const int idx = nkeys - 1;                    // cache row of the new token
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int G = p.group, HQ = p.n_q_heads, HK = p.n_kv_heads;
@@ -204,6 +206,27 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p
     bf16_t* vc = p.vtcache + (size_t)(slot * HK + kvh) * DEC_HD * p.ctx_max;
     const bf16_t* row = p.qkv + (size_t)b * p.qkv_stride;
     const uint4 z4 = uint4{0, 0, 0, 0};
+    const int ntiles = (nkeys + 15) / 16;
+    const int npad = (nkeys + 31) / 32 * 32;
+    const int nkb = npad / 32;
+    const int dt = wave & 7, par = wave >> 3;     // phase C role: d-tile, key-block parity
+
+    // ---- early prefetch of everything that does not depend on the new token: this wave's first 3 key tiles (K rows)
+    // and first 8 key blocks (V^T segments).  The entries that belong to the new token are patched from LDS below,
+    // so the block never has to read back its own cache writes.
+    auto load_k = [&](int t, bf16x8 (&kf)[4]) {
+        const int key = min(t * 16 + fr, nkeys - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(kc + (size_t)key * DEC_HD + kk * 32 + fg * 8);
+    };
+    const bf16_t* vrow = vc + (size_t)(dt * 16 + fr) * p.ctx_max + fg * 8;
+    bf16x8 kf0[3][4], vf0[8];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (wave + i * DEC_WAVES < ntiles) load_k(wave + i * DEC_WAVES, kf0[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (par + 2 * i < nkb) vf0[i] = *reinterpret_cast<const bf16x8*>(vrow + (par + 2 * i) * 32);
 
     if (tid < 64) {
         const float ang = (float)p.pos[b] * p.inv_freq[tid];
@@ -211,7 +234,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p
         sn[tid] = rbf(sinf(ang));
     }
     __syncthreads();
-    // ---- rope + cache append
+    // ---- rope + cache append (fire and forget) + LDS copies of the new q / k / v
     for (int i = tid; i < 16 * 64; i += DEC_WAVES * 64) {
         const int h = i >> 6, d = i & 63;
         float o1 = 0.f, o2 = 0.f;
@@ -226,47 +249,50 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p
         const bf16_t* k = row + (HQ + kvh) * DEC_HD + tid;
         float o1, o2;
         rope_pair(bf2f(k[0]), bf2f(k[64]), cs[tid], sn[tid], o1, o2);
-        kc[(size_t)idx * DEC_HD + tid] = f2bf(o1);
-        kc[(size_t)idx * DEC_HD + tid + 64] = f2bf(o2);
+        const bf16_t b1 = f2bf(o1), b2 = f2bf(o2);
+        kc[(size_t)idx * DEC_HD + tid] = b1;
+        kc[(size_t)idx * DEC_HD + tid + 64] = b2;
+        k_s[tid] = b1;
+        k_s[tid + 64] = b2;
     } else if (tid < 64 + DEC_HD) {
         const int d = tid - 64;
-        vc[(size_t)d * p.ctx_max + idx] = row[(HQ + HK + kvh) * DEC_HD + d];
+        const bf16_t v = row[(HQ + HK + kvh) * DEC_HD + d];
+        vc[(size_t)d * p.ctx_max + idx] = v;
+        v_s[d] = v;
     }
-    __threadfence_block();
     __syncthreads();
 
     // ---- phase A: scores S^T[key][head]
     bf16x8 qf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(q_s + fr * 136 + kk * 32 + fg * 8);
-    const int ntiles = (nkeys + 15) / 16;
-    auto load_k = [&](int t, bf16x8 (&kf)[4]) {
-        const int key = min(t * 16 + fr, nkeys - 1);
+    auto score_tile = [&](int t, bf16x8 (&kf)[4]) {
+        if (min(t * 16 + fr, nkeys - 1) == idx) {           // rows of (or clamped to) the new token come from LDS
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(kc + (size_t)key * DEC_HD + kk * 32 + fg * 8);
-    };
-    {
-        bf16x8 kcur[4], knxt[4];
-        int t = wave;
-        if (t < ntiles) load_k(t, kcur);
-        while (t < ntiles) {
-            const int tn = t + DEC_WAVES;
-            if (tn < ntiles) load_k(tn, knxt);
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kcur[kk], qf[kk], acc, 0, 0, 0);
-            if (fr < G) {
-                uint2 v = {pack2(rbf(acc[0]) * p.scale, rbf(acc[1]) * p.scale), pack2(rbf(acc[2]) * p.scale, rbf(acc[3]) * p.scale)};
-                *reinterpret_cast<uint2*>(sb + fr * s_stride + t * 16 + fg * 4) = v;
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) kcur[kk] = knxt[kk];
-            t = tn;
+            for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(k_s + kk * 32 + fg * 8);
         }
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kk], qf[kk], acc, 0, 0, 0);
+        if (fr < G) {
+            uint2 v = {pack2(rbf(acc[0]) * p.scale, rbf(acc[1]) * p.scale), pack2(rbf(acc[2]) * p.scale, rbf(acc[3]) * p.scale)};
+            *reinterpret_cast<uint2*>(sb + fr * s_stride + t * 16 + fg * 4) = v;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (wave + i * DEC_WAVES < ntiles) score_tile(wave + i * DEC_WAVES, kf0[i]);
+    for (int t0 = wave + 3 * DEC_WAVES; t0 < ntiles; t0 += 3 * DEC_WAVES) {      // contexts beyond 768 keys
+        bf16x8 kf[3][4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (t0 + i * DEC_WAVES < ntiles) load_k(t0 + i * DEC_WAVES, kf[i]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (t0 + i * DEC_WAVES < ntiles) score_tile(t0 + i * DEC_WAVES, kf[i]);
     }
     __syncthreads();
     // ---- phase B: softmax per head (float32), probabilities rounded to bf16 in place; tail zero-filled
-    const int npad = (nkeys + 31) / 32 * 32;
     for (int hh = wave; hh < G; hh += DEC_WAVES) {
         bf16_t* srow = sb + hh * s_stride;
         float mx = -INFINITY;
@@ -280,23 +306,32 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p
     }
     __syncthreads();
     // ---- phase C: O^T[d][head] = V^T[d][:] . P^T ; wave -> (d-tile = wave & 7, key-block parity = wave >> 3)
-    const int dt = wave & 7, par = wave >> 3;
-    const int nkb = npad / 32;
     f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
-        const bf16_t* vrow = vc + (size_t)(dt * 16 + fr) * p.ctx_max + fg * 8;
-        int kb = par;
-        bf16x8 vcur, vnxt;
-        if (kb < nkb) vcur = *reinterpret_cast<const bf16x8*>(vrow + kb * 32);
-        while (kb < nkb) {
-            const int kn = kb + 2;
-            if (kn < nkb) vnxt = *reinterpret_cast<const bf16x8*>(vrow + kn * 32);
-            uint4 pv = z4;
-            if (fr < G) pv = *reinterpret_cast<const uint4*>(sb + fr * s_stride + kb * 32 + fg * 8);
-            oacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcur, __builtin_bit_cast(bf16x8, pv), oacc, 0, 0, 0);
-            vcur = vnxt;
-            kb = kn;
+    const int kb_new = idx >> 5, g_new = (idx & 31) >> 3, e_new = idx & 7;
+    const bf16_t v_new = v_s[dt * 16 + fr];
+    auto pv_block = [&](int kb, bf16x8 vf) {
+        if (kb == kb_new && fg == g_new) {                    // the new token's V^T element comes from LDS
+            typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+            u16x8 t = __builtin_bit_cast(u16x8, vf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (e == e_new) ? v_new : t[e];
+            vf = __builtin_bit_cast(bf16x8, t);
         }
+        uint4 pv = z4;
+        if (fr < G) pv = *reinterpret_cast<const uint4*>(sb + fr * s_stride + kb * 32 + fg * 8);
+        oacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pv), oacc, 0, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (par + 2 * i < nkb) pv_block(par + 2 * i, vf0[i]);
+    for (int kb0 = par + 16; kb0 < nkb; kb0 += 16) {          // contexts beyond 512 keys
+        bf16x8 vf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (kb0 + 2 * i < nkb) vf[i] = *reinterpret_cast<const bf16x8*>(vrow + (kb0 + 2 * i) * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (kb0 + 2 * i < nkb) pv_block(kb0 + 2 * i, vf[i]);
     }
     if (par == 1) ored[dt * 64 + lane] = oacc;
     __syncthreads();
@@ -321,7 +356,7 @@ int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim) {
 }
 
 static size_t dec_smem(int ctx_max, int group) {
-    return 16 * 136 * 2 + 128 * 4 + 8 * 64 * 16 + (size_t)group * (ctx_max + 8) * sizeof(bf16_t);
+    return 16 * 136 * 2 + 256 * 2 + 128 * 4 + 8 * 64 * 16 + (size_t)group * (ctx_max + 8) * sizeof(bf16_t);
 }
 
 // raises the dynamic-LDS limit once, outside of any stream capture

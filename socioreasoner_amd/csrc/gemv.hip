@@ -44,6 +44,34 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     const int per = (nchunks + ks * KP - 1) / (ks * KP);          // uneven split allowed (K/64 = 172 for the 3B MLP)
     const int c0 = min(((MODE == GV_PARTIAL ? blockIdx.y : 0) * KP + kp) * per, nchunks);
 
+    // ---------------------------------------------------------------- weight ring: the first fills do not depend on x, so
+    // they are issued ahead of the norm prologue's second pass and its latency hides behind the first 16 KB per wave.
+    // U chunk slots stay in flight; a slot is refilled right after its MFMAs issue, so the compiler's counted vmcnt
+    // only ever waits for the oldest slot.
+    constexpr int U = 8 / T;
+    u32x4 w[U][T][2];
+    const int cend = min(c0 + per, nchunks);
+    const bf16_t* wrow[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) wrow[t] = p.W + (size_t)((active ? tile : 0) * T * 16 + t * 16 + fr) * p.K + fg * 16;
+    auto fill_w = [&](int u, int c) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            w[u][t][0] = ldg_nt(wrow[t] + (size_t)c * 64);
+            w[u][t][1] = ldg_nt(wrow[t] + (size_t)c * 64 + 8);
+        }
+    };
+    auto first_fills = [&]() {
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (c0 + u < cend) fill_w(u, c0 + u);
+        }
+    };
+    // vmcnt retires in order: with the norm prologue the fills go out right after the prologue's own global loads have
+    // been consumed (end of pass 1), and fly during the barrier + pass 2; without it they go out immediately.
+    if constexpr (!NORM) first_fills();
+
     // ---------------------------------------------------------------- NORM prologue: normalised x -> LDS
     // layout: xn[m][K + 8] bf16 (row pad 16 B: conflict-free ds_read_b128 across rows), then rs[32] float
     const int xs = p.K + 8;
@@ -77,6 +105,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
             ss = wave_sum(ss);
             if (lane == 0) red[wave * 32 + m] = ss;
         }
+        first_fills();
         __syncthreads();
         // pass 2: xn = bf16(w * bf16(h * rs)) in place
         for (int m = 0; m < p.M; ++m) {
@@ -104,9 +133,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
         for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (active) {
-        const bf16_t* wrow[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) wrow[t] = p.W + (size_t)(tile * T * 16 + t * 16 + fr) * p.K + fg * 16;
         const bf16_t* xrow[MT];
         bool xok[MT];
 #pragma unroll
@@ -116,42 +142,44 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
             const int mm = xok[mt] ? m : 0;
             xrow[mt] = (NORM ? xn + (size_t)mm * xs : p.x + (size_t)mm * p.ldx) + fg * 16;
         }
-        auto body = [&](int c, auto UN) {
-            constexpr int U = decltype(UN)::value;
-            u32x4 w[U][T][2], xv[U][MT][2];
+        // x fragments: from LDS (NORM) they are read at consume time; from global they ride the ring with the weights
+        u32x4 xv[U][MT][2];
+        auto fill_x = [&](int u, int c) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (xok[mt]) {
+                    xv[u][mt][0] = *reinterpret_cast<const u32x4*>(xrow[mt] + (size_t)c * 64);
+                    xv[u][mt][1] = *reinterpret_cast<const u32x4*>(xrow[mt] + (size_t)c * 64 + 8);
+                } else {
+                    xv[u][mt][0] = u32x4{0, 0, 0, 0};
+                    xv[u][mt][1] = u32x4{0, 0, 0, 0};
+                }
+            }
+        };
+        if constexpr (!NORM) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (c0 + u < cend) fill_x(u, c0 + u);
+        }
+        for (int c = c0; c < cend; c += U) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                if (c + u < cend) {
+                    if constexpr (NORM) fill_x(u, c + u);
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    w[u][t][0] = ldg_nt(wrow[t] + (size_t)(c + u) * 64);
-                    w[u][t][1] = ldg_nt(wrow[t] + (size_t)(c + u) * 64 + 8);
-                }
+                    for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    if (xok[mt]) {
-                        xv[u][mt][0] = *reinterpret_cast<const u32x4*>(xrow[mt] + (size_t)(c + u) * 64);
-                        xv[u][mt][1] = *reinterpret_cast<const u32x4*>(xrow[mt] + (size_t)(c + u) * 64 + 8);
-                    } else {
-                        xv[u][mt][0] = u32x4{0, 0, 0, 0};
-                        xv[u][mt][1] = u32x4{0, 0, 0, 0};
+                        for (int mt = 0; mt < MT; ++mt) {
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][0]), as_frag(xv[u][mt][0]), acc[t][mt], 0, 0, 0);
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][1]), as_frag(xv[u][mt][1]), acc[t][mt], 0, 0, 0);
+                        }
+                    if (c + U + u < cend) {
+                        fill_w(u, c + U + u);
+                        if constexpr (!NORM) fill_x(u, c + U + u);
                     }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int t = 0; t < T; ++t)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][0]), as_frag(xv[u][mt][0]), acc[t][mt], 0, 0, 0);
-                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][1]), as_frag(xv[u][mt][1]), acc[t][mt], 0, 0, 0);
-                    }
-        };
-        constexpr int UNROLL = 8 / T;                                // 16 weight loads (16 KB) in flight per wave
-        int c = c0;
-        const int cend = min(c0 + per, nchunks);
-        for (; c + UNROLL <= cend; c += UNROLL) body(c, std::integral_constant<int, UNROLL>{});
-        for (; c < cend; ++c) body(c, std::integral_constant<int, 1>{});
+        }
     }
 
     // ---------------------------------------------------------------- in-block K reduction (fixed order kp = 1, 2, 3)
@@ -313,11 +341,11 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     if (mode == GV_PARTIAL && (a.ksplit < 1 || a.ksplit > a.K / 64)) return -22;
     if (a.norm_w && !(mode == GV_BIAS || mode == GV_SWIGLU || mode == GV_F32)) return -22;
     if (a.n_slabs > 0 && (!a.norm_w || !a.slabs || !a.x_out)) return -22;
-    const int want = mode == GV_F32 ? 1 : (mode == GV_SWIGLU ? 2 : 4);
+    const int want = mode == GV_F32 ? 1 : 4;
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
     switch (mode) {
         case GV_PARTIAL: return kp == 4 ? launch_n<GV_PARTIAL, 4>(s, a) : kp == 2 ? launch_n<GV_PARTIAL, 2>(s, a) : launch_n<GV_PARTIAL, 1>(s, a);
-        case GV_SWIGLU: return kp == 2 ? launch_n<GV_SWIGLU, 2>(s, a) : launch_n<GV_SWIGLU, 1>(s, a);
+        case GV_SWIGLU: return kp == 4 ? launch_n<GV_SWIGLU, 4>(s, a) : kp == 2 ? launch_n<GV_SWIGLU, 2>(s, a) : launch_n<GV_SWIGLU, 1>(s, a);
         case GV_F32: return launch_n<GV_F32, 1>(s, a);
         case GV_BIAS: return kp == 4 ? launch_n<GV_BIAS, 4>(s, a) : kp == 2 ? launch_n<GV_BIAS, 2>(s, a) : launch_n<GV_BIAS, 1>(s, a);
         case GV_RESID: return kp == 4 ? launch_n<GV_RESID, 4>(s, a) : kp == 2 ? launch_n<GV_RESID, 2>(s, a) : launch_n<GV_RESID, 1>(s, a);
