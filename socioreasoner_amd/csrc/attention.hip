@@ -210,6 +210,8 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p
     const int npad = (nkeys + 31) / 32 * 32;
     const int nkb = npad / 32;
     const int dt = wave & 7, par = wave >> 3;     // phase C role: d-tile, key-block parity
+    const bool stamp = p.dbg && tid == 0 && b == 0 && kvh == 0;
+    if (stamp) p.dbg[0] = wall_clock64();
 
     // ---- early prefetch of everything that does not depend on the new token: this wave's first 3 key tiles (K rows)
     // and first 8 key blocks (V^T segments).  The entries that belong to the new token are patched from LDS below,
@@ -229,11 +231,12 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p
         if (par + 2 * i < nkb) vf0[i] = *reinterpret_cast<const bf16x8*>(vrow + (par + 2 * i) * 32);
 
     if (tid < 64) {
-        const float ang = (float)p.pos[b] * p.inv_freq[tid];
-        cs[tid] = rbf(cosf(ang));
-        sn[tid] = rbf(sinf(ang));
+        const int pos = p.pos[b];
+        cs[tid] = bf2f(p.rope_cos[(size_t)pos * 64 + tid]);
+        sn[tid] = bf2f(p.rope_sin[(size_t)pos * 64 + tid]);
     }
     __syncthreads();
+    if (stamp) p.dbg[1] = wall_clock64();
     // ---- rope + cache append (fire and forget) + LDS copies of the new q / k / v
     for (int i = tid; i < 16 * 64; i += DEC_WAVES * 64) {
         const int h = i >> 6, d = i & 63;
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p
         v_s[d] = v;
     }
     __syncthreads();
+    if (stamp) p.dbg[2] = wall_clock64();
 
     // ---- phase A: scores S^T[key][head]
     bf16x8 qf[4];
@@ -292,19 +296,57 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p
             if (t0 + i * DEC_WAVES < ntiles) score_tile(t0 + i * DEC_WAVES, kf[i]);
     }
     __syncthreads();
+    if (stamp) p.dbg[3] = wall_clock64();
     // ---- phase B: softmax per head (float32), probabilities rounded to bf16 in place; tail zero-filled
     for (int hh = wave; hh < G; hh += DEC_WAVES) {
         bf16_t* srow = sb + hh * s_stride;
-        float mx = -INFINITY;
-        for (int j = lane; j < nkeys; j += 64) mx = fmaxf(mx, bf2f(srow[j]));
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int j = lane; j < nkeys; j += 64) sum += __expf(bf2f(srow[j]) - mx);
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-        for (int j = lane; j < npad; j += 64) srow[j] = (j < nkeys) ? f2bf(__expf(bf2f(srow[j]) - mx) * inv) : (bf16_t)0;
+        const int nvec = npad / 8;                               // 16-byte vectors of 8 scores
+        if (nvec <= 4 * 64) {
+            float v[4][8];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int vi = lane + i * 64;
+                if (vi < nvec) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(srow + vi * 8);
+                    const float t[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[i][e] = (vi * 8 + e < nkeys) ? t[e] : -INFINITY;
+                        mx = fmaxf(mx, v[i][e]);
+                    }
+                }
+            }
+            mx = wave_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (lane + i * 64 < nvec) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v[i][e] = __expf(v[i][e] - mx); sum += v[i][e]; }
+                }
+            sum = wave_sum(sum);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int vi = lane + i * 64;
+                if (vi < nvec)
+                    *reinterpret_cast<uint4*>(srow + vi * 8) = uint4{pack2(v[i][0] * inv, v[i][1] * inv), pack2(v[i][2] * inv, v[i][3] * inv),
+                                                                      pack2(v[i][4] * inv, v[i][5] * inv), pack2(v[i][6] * inv, v[i][7] * inv)};
+            }
+        } else {                                                 // long contexts: three scalar passes
+            float mx = -INFINITY;
+            for (int j = lane; j < nkeys; j += 64) mx = fmaxf(mx, bf2f(srow[j]));
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int j = lane; j < nkeys; j += 64) sum += __expf(bf2f(srow[j]) - mx);
+            sum = wave_sum(sum);
+            const float inv = 1.0f / sum;
+            for (int j = lane; j < npad; j += 64) srow[j] = (j < nkeys) ? f2bf(__expf(bf2f(srow[j]) - mx) * inv) : (bf16_t)0;
+        }
     }
     __syncthreads();
+    if (stamp) p.dbg[4] = wall_clock64();
     // ---- phase C: O^T[d][head] = V^T[d][:] . P^T ; wave -> (d-tile = wave & 7, key-block parity = wave >> 3)
     f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
     const int kb_new = idx >> 5, g_new = (idx & 31) >> 3, e_new = idx & 7;
@@ -335,6 +377,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p
     }
     if (par == 1) ored[dt * 64 + lane] = oacc;
     __syncthreads();
+    if (stamp) p.dbg[5] = wall_clock64();
     if (par == 0 && fr < G) {
         const f32x4 o2 = ored[dt * 64 + lane];
         uint2 v = {pack2(oacc[0] + o2[0], oacc[1] + o2[1]), pack2(oacc[2] + o2[2], oacc[3] + o2[3])};

@@ -99,14 +99,24 @@ __device__ __forceinline__ void rope_pair_bf16(float x1, float x2, float c, floa
     o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
 }
 
+// The precise cosf/sinf of the device library cost ~7 us per call chain at these argument sizes (measured), so the
+// LM tables are built once per engine and the rope kernels only look them up.
+__global__ __launch_bounds__(256) void k_rope_table(const float* inv_freq, int n_pos, bf16_t* cos_t, bf16_t* sin_t) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pos * 64) return;
+    const float ang = (float)(i >> 6) * inv_freq[i & 63];
+    cos_t[i] = f2bf(cosf(ang));
+    sin_t[i] = f2bf(sinf(ang));
+}
+
 __global__ __launch_bounds__(256) void k_lm_rope_prefill(LmRopeArgs p) {
     __shared__ float cs[64], sn[64];
     const int t = blockIdx.x, tid = threadIdx.x;
     if (tid < 64) {
         const int axis = tid < p.sec0 ? 0 : (tid < p.sec1 ? 1 : 2);
-        const float ang = (float)p.pos3[(size_t)axis * p.n_tok + t] * p.inv_freq[tid];
-        cs[tid] = rbf(cosf(ang));
-        sn[tid] = rbf(sinf(ang));
+        const int pos = p.pos3[(size_t)axis * p.n_tok + t];
+        cs[tid] = bf2f(p.rope_cos[(size_t)pos * 64 + tid]);
+        sn[tid] = bf2f(p.rope_sin[(size_t)pos * 64 + tid]);
     }
     __syncthreads();
     const int HQ = p.n_q_heads, HK = p.n_kv_heads;
@@ -315,6 +325,11 @@ int launch_vit_rope(hipStream_t s, bf16_t* qkv, int n_rows, int n_heads, int hea
 int launch_lm_rope_prefill(hipStream_t s, const LmRopeArgs& a) {
     if (a.n_tok <= 0) return 0;
     hipLaunchKernelGGL(k_lm_rope_prefill, dim3(a.n_tok), dim3(256), 0, s, a);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_rope_table(hipStream_t s, const float* inv_freq, int n_pos, bf16_t* cos_t, bf16_t* sin_t) {
+    hipLaunchKernelGGL(k_rope_table, dim3(cdiv(n_pos * 64, 256)), dim3(256), 0, s, inv_freq, n_pos, cos_t, sin_t);
     SR_CHECK_LAUNCH();
     return 0;
 }

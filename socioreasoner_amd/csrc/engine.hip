@@ -76,6 +76,7 @@ struct sr_engine {
     std::vector<LmLayerW> ll;
     bf16_t* lut;       // [3*256] normalise LUT
     float* inv_freq;   // [64]
+    bf16_t *rope_cos, *rope_sin;   // [max_ctx + 1][64]
     // ---- ViT activations
     bf16_t *v_pix, *v_x, *v_xn, *v_qkv, *v_attn, *v_act, *v_vt, *v_m1;
     int v_vt_stride;
@@ -197,6 +198,8 @@ void carve(sr_engine* e) {
     }
     e->lut = ar.take<bf16_t>(3 * 256);
     e->inv_freq = ar.take<float>(64);
+    e->rope_cos = ar.take<bf16_t>((size_t)(c.max_ctx + 1) * 64);
+    e->rope_sin = ar.take<bf16_t>((size_t)(c.max_ctx + 1) * 64);
     e->weights_end = ar.off;
 
     // ViT activations
@@ -458,8 +461,8 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         SR_TRY(launch_gemv(s, gq, GV_BIAS));
         if (fused && pending) { bf16_t* t = x; x = x_alt; x_alt = t; }     // block 0 wrote the updated stream there
         pending = false;
-        DecodeAttnArgs da{e->d_qkv, e->t_qn, e->d_pos, e->d_ctx_len, e->d_slots, e->inv_freq, kc, vc, e->d_attn, QD,
-                          B, c.t_heads, c.t_kv_heads, e->t_group, c.max_ctx, scale};
+        DecodeAttnArgs da{e->d_qkv, e->t_qn, e->d_pos, e->d_ctx_len, e->d_slots, e->rope_cos, e->rope_sin, kc, vc, e->d_attn, QD,
+                          B, c.t_heads, c.t_kv_heads, e->t_group, c.max_ctx, scale, nullptr};
         SR_TRY(launch_attn_decode(s, da));
         GemvArgs go = gv(e->d_attn, QD, w.o_w, B, H, QD, x, H);
         SR_TRY(launch_gemv(s, go, GV_RESID));
@@ -539,6 +542,8 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
     for (int i = 0; i < 64; ++i) inv[i] = (float)(1.0 / pow((double)e->c.t_rope_theta, (double)(2 * i) / 128.0));
     if (r == hipSuccess) r = hipMemcpy(e->lut, lut.data(), 768 * sizeof(bf16_t), hipMemcpyHostToDevice);
     if (r == hipSuccess) r = hipMemcpy(e->inv_freq, inv.data(), 64 * sizeof(float), hipMemcpyHostToDevice);
+    if (r == hipSuccess) r = (hipError_t)launch_rope_table(nullptr, e->inv_freq, e->c.max_ctx + 1, e->rope_cos, e->rope_sin);
+    if (r == hipSuccess) r = hipDeviceSynchronize();
     if (r == hipSuccess) r = (hipError_t)attn_decode_prepare(e->c.max_ctx, e->t_group);
     if (r != hipSuccess) {
         int rc = fail(nullptr, (int)r, "engine init: %s", hipGetErrorString(r));
@@ -732,6 +737,7 @@ int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int3
             for (int a = 0; a < 3; ++a) {
                 const int64_t p = pos3[(size_t)a * n_tok + t];
                 h_pos[(size_t)a * n_tok + t] = (int)p;
+                if (p < 0 || p > c.max_ctx) return fail(e, -22, "position id %lld outside 0..max_ctx (%d)", (long long)p, c.max_ctx);
                 if (p > maxpos) maxpos = p;
             }
             h_slot[t] = slots[b];
@@ -774,7 +780,7 @@ int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int3
         bf16_t* vc = e->vtcache + (size_t)l * e->kv_layer_elems;
         SR_TRY(launch_rmsnorm(s, e->t_x, w.ln1, e->t_xn, n_tok, H, c.t_rms_eps));
         if (int rc = gemm(e, s, e->t_xn, H, w.qkv_w, n_tok, e->t_qn, H, e->t_qkv, e->t_qn, w.qkv_b, nullptr, nullptr, EPI_STORE)) return rc;
-        LmRopeArgs ra{e->t_qkv, n_tok, c.t_heads, c.t_kv_heads, e->t_pos3, e->t_slot, e->t_idx, e->inv_freq,
+        LmRopeArgs ra{e->t_qkv, n_tok, c.t_heads, c.t_kv_heads, e->t_pos3, e->t_slot, e->t_idx, e->rope_cos, e->rope_sin,
                       c.mrope_section[0], c.mrope_section[0] + c.mrope_section[1], kc, vc, c.max_ctx};
         SR_TRY(launch_lm_rope_prefill(s, ra));
         AttnArgs a{e->t_qkv, e->t_qn, kc, 128, (long long)c.max_ctx * 128, vc, c.max_ctx, (long long)128 * c.max_ctx,
@@ -895,6 +901,15 @@ int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K,
     SR_WRAP(launch_gemv((hipStream_t)stream, a, mode));
 }
 int sr_op_gemv_f32_blocks(int N) { return gemv_f32_blocks(N); }
+int sr_op_attn_decode(const void* qkv, int qkv_stride, const int32_t* pos, const int32_t* ctx_len, const void* rope_cos,
+                      const void* rope_sin, void* kcache, void* vtcache, void* out, int out_stride, int B, int n_q_heads, int n_kv_heads, int ctx_max,
+                      float scale, int64_t* dbg, void* stream) {
+    int rc = attn_decode_prepare(ctx_max, n_q_heads / n_kv_heads);
+    if (rc) return fail(nullptr, rc, "attn_decode_prepare failed with %d", rc);
+    DecodeAttnArgs a{(const bf16_t*)qkv, qkv_stride, pos, ctx_len, nullptr, (const bf16_t*)rope_cos, (const bf16_t*)rope_sin, (bf16_t*)kcache, (bf16_t*)vtcache, (bf16_t*)out,
+                     out_stride, B, n_q_heads, n_kv_heads, n_q_heads / n_kv_heads, ctx_max, scale, (long long*)dbg};
+    SR_WRAP(launch_attn_decode((hipStream_t)stream, a));
+}
 int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, float eps, void* stream) {
     SR_WRAP(launch_rmsnorm((hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out, rows, H, eps));
 }

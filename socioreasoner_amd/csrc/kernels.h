@@ -57,12 +57,14 @@ struct DecodeAttnArgs {
     const int* pos;                       // [B] rotary position of the new token (all three mRoPE axes equal)
     const int* ctx_len;                   // [B] keys in the cache INCLUDING the new token
     const int* slots;                     // [B] cache slot of each row (null: identity)
-    const float* inv_freq;                // [64]
+    const bf16_t* rope_cos;               // [max_pos+1][64] bf16 cos(pos * inv_freq) (hf:486-539), sin likewise
+    const bf16_t* rope_sin;
     bf16_t* kcache;                       // [slot][kvh][ctx_max][128]
     bf16_t* vtcache;                      // [slot][kvh][128][ctx_max]
     bf16_t* out; int out_stride;          // [B, Hq*128]
     int B, n_q_heads, n_kv_heads, group, ctx_max;
     float scale;
+    long long* dbg;                       // optional: phase timestamps (s_memrealtime, 100 MHz) of block (0,0)
 };
 int launch_attn_decode(hipStream_t s, const DecodeAttnArgs& a);
 int attn_decode_prepare(int ctx_max, int group);
@@ -80,11 +82,14 @@ struct LmRopeArgs {
     const int* pos3;            // [3][n_tok] mRoPE position ids
     const int* tok_slot;        // [n_tok] cache slot
     const int* tok_idx;         // [n_tok] index of the token inside its sequence (cache row)
-    const float* inv_freq;      // [64]
+    const bf16_t* rope_cos;     // [max_pos+1][64] bf16 tables
+    const bf16_t* rope_sin;
     int sec0, sec1;             // mrope_section boundaries in rotary pairs (16, 40)
     bf16_t* kcache; bf16_t* vtcache; int ctx_max;
 };
 int launch_lm_rope_prefill(hipStream_t s, const LmRopeArgs& a);
+// cos/sin tables of the LM rotary embedding: [n_pos][64] bf16, angle = float(pos) * inv_freq[f] in float32 (hf:526-539)
+int launch_rope_table(hipStream_t s, const float* inv_freq, int n_pos, bf16_t* cos_t, bf16_t* sin_t);
 int launch_embed(hipStream_t s, const int* src, const bf16_t* table, const bf16_t* image_embeds, bf16_t* out,
                  int n_tok, int H);
 int launch_gather_rows(hipStream_t s, const bf16_t* in, const int* rows, bf16_t* out, int n, int H);
