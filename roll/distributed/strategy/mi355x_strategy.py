@@ -1,0 +1,258 @@
+"""MI355X-native replacement of the reference's ``actor_infer`` strategy (roll/distributed/strategy/vllm_strategy.py)
+and of the raster half of ``seg_infer`` (roll/distributed/strategy/seg_strategy.py), behind the same plugin boundary.
+
+``Mi355xStrategy.generate`` keeps the reference contract (vllm_strategy.py:114-141):
+  in : batch.batch["input_ids" | "attention_mask"] left-padded [B, P]; optionally
+       batch.non_tensor_batch["multi_modal_data"][i] = {"prompt_token_ids": [...], "multi_modal_data": {"image": [PIL, ...]}}
+       generation_config keys of roll/configs/generating_args.py (max_new_tokens, eos_token_id (list), pad_token_id, ...)
+  out: LongTensor [B * n, P + max_response_len_in_batch]: the prompt columns verbatim, responses right-padded with pad.
+Delta to the reference default (BASELINE.json configs): decoding is greedy; the
+temperature / top_p / top_k of the shipped YAML are accepted and ignored with a warning.
+"""
+from __future__ import annotations
+
+import logging
+import queue
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from roll.distributed.scheduler.protocol import DataProto
+from roll.distributed.strategy.strategy import InferenceStrategy
+from socioreasoner_amd import hostops, raster
+from socioreasoner_amd.config import ModelGeometry, geometry_3b, geometry_tiny
+from socioreasoner_amd.engine import Engine
+
+logger = logging.getLogger("roll.mi355x")
+
+
+class _StubTokenizer:
+    """No tokenizer files are available offline: ids in, ids out.  A real run passes an HF tokenizer instead."""
+
+    def __init__(self, geom: ModelGeometry):
+        self.eos_token_id, self.pad_token_id = geom.eos_token_id, geom.pad_token_id
+        self.additional_special_tokens, self.padding_side = [], "left"
+
+    def batch_decode(self, ids, skip_special_tokens=False):
+        return [" ".join(str(int(t)) for t in row if not (skip_special_tokens and int(t) == self.pad_token_id)) for row in ids]
+
+
+def _get(obj, name, default=None):
+    if obj is None:
+        return default
+    if isinstance(obj, dict):
+        return obj.get(name, default)
+    return getattr(obj, name, default)
+
+
+class Mi355xStrategy(InferenceStrategy):
+    strategy_name = "mi355x"
+
+    def __init__(self, worker):
+        super().__init__(worker)
+        self.engine: Engine | None = None
+        self.command_queue: queue.Queue | None = None
+        self.request_metas: Dict = {}
+        self.running = False
+
+    # ------------------------------------------------------------------ lifecycle
+    def initialize(self, model_provider=None):
+        sa = _get(self.worker_config, "strategy_args")
+        sc = dict(_get(sa, "strategy_config", None) or {})
+        margs = _get(self.worker_config, "model_args")
+        path = str(_get(margs, "model_name_or_path", "") or sc.get("model", "synthetic:3b"))
+        self.geom = geometry_tiny() if path.endswith("synthetic:tiny") else geometry_3b()
+        pc = getattr(self.worker, "pipeline_config", None)
+        prompt_len = int(_get(pc, "prompt_length", 4096))
+        resp_len = int(_get(pc, "response_length", 2048))
+        self.max_batch = int(sc.get("max_batch", 32))
+        max_ctx = int(sc.get("max_ctx", min(prompt_len + resp_len, 2048)))
+        max_ctx = (max_ctx + 63) // 64 * 64
+        self.engine = Engine(self.geom, max_patches=int(sc.get("max_patches", 2048 * 2 * 4)),
+                             max_prefill_tokens=int(sc.get("max_prefill_tokens", min(prompt_len, 1024) * 8)),
+                             max_batch=self.max_batch, max_ctx=max_ctx, max_new_tokens=min(resp_len, max_ctx - 1),
+                             device=f"cuda:{int(_get(getattr(self.worker, 'rank_info', None), 'local_rank', 0) or 0)}")
+        import os
+        if os.path.isdir(path):
+            self.engine.load_safetensors_dir(path)
+            try:
+                from transformers import AutoTokenizer
+                self.tokenizer = AutoTokenizer.from_pretrained(path)
+            except Exception:  # noqa: BLE001
+                self.tokenizer = _StubTokenizer(self.geom)
+        else:
+            logger.warning("no checkpoint directory at %r: using synthetic weights (seed 0)", path)
+            self.engine.load_synthetic_weights(seed=int(sc.get("seed", 0)))
+            self.tokenizer = _StubTokenizer(self.geom)
+        self.command_queue = queue.Queue()
+        ri = getattr(self.worker, "rank_info", None)
+        if ri is not None:
+            ri.dp_rank, ri.dp_size = getattr(self.worker, "rank", 0), getattr(self.worker, "world_size", 1)
+
+    def load_states(self, *args, **kwargs):
+        return None          # 7.5 GB of weights stay resident in 288 GB of HBM: nothing to reload
+
+    def offload_states(self, include=None, non_blocking=False):
+        return None
+
+    def setup_collective_group(self, *args, **kwargs):
+        return None          # weights are loaded directly; no trainer -> engine broadcast on the infer path
+
+    # ------------------------------------------------------------------ generate
+    def _prepare(self, ids: List[int], images) -> tuple:
+        """-> (expanded ids np.int64, pos3 [3,S], list of uint8 HWC cuda images, grids)"""
+        g = self.geom
+        f = g.vision.patch_size * g.vision.spatial_merge_size
+        ims, grids = [], []
+        for im in images or []:
+            arr = np.asarray(im.convert("RGB")) if hasattr(im, "convert") else np.asarray(im)
+            h, w = arr.shape[:2]
+            rh, rw = hostops.smart_resize(h, w, factor=f)
+            if (rh, rw) != (h, w):
+                from PIL import Image
+                arr = np.asarray(Image.fromarray(arr).resize((rw, rh), resample=Image.BICUBIC))
+            ims.append(torch.from_numpy(np.ascontiguousarray(arr)).cuda())
+            grids.append((1, rh // g.vision.patch_size, rw // g.vision.patch_size))
+        ids = np.asarray(ids, dtype=np.int64)
+        n_pad = int((ids == g.image_token_id).sum())
+        toks = [t * h * w // g.vision.spatial_merge_size ** 2 for t, h, w in grids]
+        if grids and n_pad == len(grids):          # one placeholder per image (vLLM-style prompt): expand
+            out, k = [], 0
+            for t in ids.tolist():
+                if t == g.image_token_id:
+                    out += [t] * toks[k]
+                    k += 1
+                else:
+                    out.append(t)
+            ids = np.asarray(out, dtype=np.int64)
+        elif grids and n_pad != sum(toks):
+            raise ValueError(f"Image features and image tokens do not match: tokens: {n_pad}, features {sum(toks)}")
+        pos3, _ = hostops.get_rope_index(torch.from_numpy(ids)[None], grids or None, None,
+                                         spatial_merge_size=g.vision.spatial_merge_size, image_token_id=g.image_token_id,
+                                         vision_start_token_id=g.vision_start_token_id)
+        return ids, pos3[:, 0].numpy(), ims, grids
+
+    @torch.no_grad()
+    def generate(self, batch: DataProto, generation_config) -> torch.Tensor:
+        gc = dict(generation_config)
+        if gc.get("num_beams", 1) > 1:
+            raise NotImplementedError("beam search is not part of the inference hot path")
+        if float(gc.get("temperature", 0) or 0) > 0 and int(gc.get("top_k", 1) or 1) != 1:
+            logger.warning("sampling parameters (temperature/top_p/top_k) are ignored: greedy decode")
+        input_ids = batch.batch["input_ids"]
+        attention_mask = batch.batch["attention_mask"]
+        mm = batch.non_tensor_batch.get("multi_modal_data") if batch.non_tensor_batch else None
+        prompts = hostops.gather_unpadded_input_ids(input_ids.cpu(), attention_mask.cpu())
+        eos = gc.get("eos_token_id") or [self.tokenizer.eos_token_id]
+        eos = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos])]
+        pad = int(gc.get("pad_token_id", self.tokenizer.pad_token_id))
+        max_new = min(int(gc["max_new_tokens"]), self.engine.cfg.max_new_tokens)
+        B = len(prompts)
+        results: List[List[int]] = [None] * B
+        prepared = []
+        for i in range(B):
+            ids_i = mm[i]["prompt_token_ids"] if mm is not None and mm[i].get("prompt_token_ids") else prompts[i]
+            imgs = (mm[i].get("multi_modal_data") or {}).get("image") if mm is not None else None
+            prepared.append(self._prepare(ids_i, imgs))
+        i = 0
+        while i < B:                                  # groups bounded by the engine capacities
+            grp, ntok, npatch = [], 0, 0
+            while i < B and len(grp) < self.max_batch:
+                ids_i, _, _, grids = prepared[i]
+                np_i = sum(t * h * w for t, h, w in grids)
+                if grp and (ntok + len(ids_i) > self.engine.cfg.max_prefill_tokens or npatch + np_i > self.engine.cfg.max_patches):
+                    break
+                grp.append(i)
+                ntok += len(ids_i)
+                npatch += np_i
+                i += 1
+            ims = [im for k in grp for im in prepared[k][2]]
+            grids = [g_ for k in grp for g_ in prepared[k][3]]
+            emb = None
+            if ims:
+                pix = torch.cat([self.engine.patchify(im) for im in ims], dim=0)
+                emb = self.engine.vit_forward(pix, grids)
+            self.engine.prefill([prepared[k][0] for k in grp], [prepared[k][1] for k in grp], emb)
+            toks = self.engine.decode(max_new, eos=eos, pad_id=pad).cpu().tolist()
+            for row, k in zip(toks, grp):
+                cut = next((j + 1 for j, t in enumerate(row) if t in eos), len(row))
+                results[k] = row[:cut]
+        n = int(gc.get("num_return_sequences", 1) or 1)
+        results = [r for r in results for _ in range(n)]          # greedy: the n sequences of a prompt are identical
+        output_ids = hostops.gather_outputs_to_pad_tensor(results, pad, device=input_ids.device)
+        return hostops.concatenate_input_and_output(input_ids, output_ids, n)
+
+    # ------------------------------------------------------------------ request-level serving (generate_opt_level 1)
+    def add_request(self, command, data: DataProto):
+        self.command_queue.put((command, data))
+
+    def start_server(self, data: DataProto, request_complete_callback):
+        """Continuous batching in the sense of the reference's level-1 scheduler (vllm_strategy.py:156-205): drain
+        ADD / ABORT / STOP commands, run the queued requests in engine-sized batches, report each as it completes."""
+        self.running = True
+        pending: List[DataProto] = []
+        while True:
+            try:
+                command, req = self.command_queue.get(timeout=0.01)
+            except queue.Empty:
+                command, req = None, None
+            name = getattr(command, "name", command)
+            if name == "ADD":
+                pending.append(req)
+            elif name == "ABORT":
+                rid = req.meta_info["request_id"]
+                pending = [p for p in pending if p.meta_info.get("request_id") != rid]
+            elif name == "STOP":
+                self.running = False
+                return
+            if pending and (len(pending) >= self.max_batch or self.command_queue.empty()):
+                todo, pending = pending[: self.max_batch], pending[self.max_batch:]
+                merged = DataProto.concat(todo)
+                gc = todo[0].meta_info.get("generation_config")
+                out = self.generate(merged, gc)
+                P = merged.batch["input_ids"].shape[1]
+                for row, r in zip(out, todo):
+                    res = DataProto(meta_info=dict(r.meta_info))
+                    res.meta_info["output_token_ids"] = [[int(t) for t in row[P:].tolist() if int(t) != int(gc.get("pad_token_id", -1))]]
+                    request_complete_callback(data=res)
+
+
+class SegRasterStrategy(InferenceStrategy):
+    """Raster half of SegInferStrategy.segment (seg_strategy.py:26-72) on the device: per-object mask union ->
+    nearest 756 -> 768.  The SAM2 forward itself is third-party and not available offline (SURVEY.md "next" row N1):
+    ``model_provider`` must return an object with set_image(image) / predict(**prompt) -> (masks, scores, _)."""
+    strategy_name = "seg_infer"
+
+    def initialize(self, model_provider=None):
+        self.model = model_provider(model_args=_get(self.worker_config, "model_args"), is_trainable=False) if model_provider else None
+
+    def load_states(self, *args, **kwargs):
+        return None
+
+    def offload_states(self, *args, **kwargs):
+        return None
+
+    def segment(self, batch: DataProto) -> dict:
+        masks = []
+        for image, visual_prompt in zip(batch.non_tensor_batch["seg_image"], batch.non_tensor_batch["visual_prompt"]):
+            if len(visual_prompt) == 0:
+                masks.append(np.zeros((768, 768), dtype=np.uint8))
+                continue
+            if self.model is None:
+                raise RuntimeError("seg_infer needs a SAM2-compatible predictor (not available offline)")
+            self.model.set_image(image.resize((756, 756)))
+            acc = torch.zeros(756, 756, dtype=torch.uint8, device="cuda")
+            for vp in visual_prompt:
+                try:
+                    prompt = {k: vp[k] for k in ("point_coords", "point_labels", "box") if k in vp}
+                    pred_masks, scores, _ = self.model.predict(**prompt)
+                    best = np.ascontiguousarray(np.asarray(pred_masks[int(np.argmax(scores))]).astype(np.uint8))
+                    raster.mask_union_(acc, torch.from_numpy(best).cuda())
+                except Exception:  # noqa: BLE001  (the reference swallows per-object failures, seg_strategy.py:61-62)
+                    continue
+            masks.append(raster.resize_nearest(acc, 768, 768).cpu().numpy())
+        out = np.empty(len(masks), dtype=object)
+        for i, m in enumerate(masks):
+            out[i] = m
+        return {"mask": out}

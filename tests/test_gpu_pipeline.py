@@ -1,0 +1,93 @@
+"""GPU: the drop-in surface -- InferenceStrategy.generate contract and the two-stage pipeline in synthetic mode."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(tmp, resp=8, prompt=600):
+    from roll.pipeline.rlvr.rlvr_config import SocioSegConfig
+    return SocioSegConfig.from_dict({
+        "output_dir": str(tmp), "prompt_length": prompt, "response_length": resp, "rollout_batch_size": 5, "pretrain": "synthetic:tiny",
+        "actor_infer": {"model_args": {"model_name_or_path": "synthetic:tiny"},
+                        "generating_args": {"max_new_tokens": resp, "temperature": 1, "top_k": 100, "top_p": 0.8, "num_beams": 1},
+                        "strategy_args": {"strategy_name": "vllm", "strategy_config": {"max_batch": 4, "max_patches": 4096}}},
+        "seg_infer": {"model_args": {}, "strategy_args": {"strategy_name": "seg_infer"}},
+    })
+
+
+def test_strategy_generate_contract(tmp_path):
+    from roll.distributed.scheduler.protocol import DataProto
+    from roll.distributed.strategy.factory import create_strategy
+    from roll.pipeline.rlvr.rlvr_socioseg_vlm_pipeline_infer import _Worker
+    from socioreasoner_amd import synthetic
+    cfg = _cfg(tmp_path)
+    st = create_strategy(_Worker(cfg.actor_infer, cfg, 0, 1, 0))
+    st.initialize(None)
+    g = st.geom
+    P, pad = 600, g.pad_token_id
+    prompts, payload = [], np.empty(5, dtype=object)
+    for i in range(5):
+        if i == 3:   # text-only row, short
+            ids = np.arange(5, 25, dtype=np.int64)
+            payload[i] = {"prompt_token_ids": ids.tolist()}
+        else:
+            ids = synthetic.tile_prompt(g, i, (1, 32, 32), n_pre=10 + i, n_post=7)
+            payload[i] = {"prompt_token_ids": ids.tolist(), "multi_modal_data": {"image": [synthetic.tile_pixels(i)]}}
+        row = np.full(P, pad, dtype=np.int64)
+        row[P - len(ids):] = ids
+        prompts.append(row)
+    input_ids = torch.from_numpy(np.stack(prompts))
+    batch = DataProto(batch={"input_ids": input_ids, "attention_mask": (input_ids != pad).long()},
+                      non_tensor_batch={"multi_modal_data": payload})
+    gc = {"max_new_tokens": 8, "temperature": 0, "top_p": 1.0, "top_k": 1, "num_beams": 1, "repetition_penalty": 1.0,
+          "num_return_sequences": 1, "eos_token_id": [g.eos_token_id], "pad_token_id": pad}
+    out = st.generate(batch, gc)
+    assert out.shape[0] == 5 and P < out.shape[1] <= P + 8 and out.dtype == torch.long
+    assert torch.equal(out[:, :P], input_ids)                       # prompt part verbatim (left padded)
+    # batch composition must not change a sequence: row 2 alone gives the same response
+    single = DataProto(batch={"input_ids": input_ids[2:3], "attention_mask": (input_ids[2:3] != pad).long()},
+                       non_tensor_batch={"multi_modal_data": payload[2:3]})
+    out1 = st.generate(single, gc)
+    L = min(out.shape[1], out1.shape[1])
+    assert torch.equal(out1[0, P:L], out[2, P:L])
+    # one placeholder per image (vLLM-style prompt) expands to the same ids
+    ids = np.asarray(payload[0]["prompt_token_ids"])
+    keep = np.ones(len(ids), dtype=bool)
+    first = int(np.argmax(ids == g.image_token_id))
+    keep[first + 1: first + 256] = False
+    payload2 = np.empty(1, dtype=object)
+    payload2[0] = {"prompt_token_ids": ids[keep].tolist(), "multi_modal_data": payload[0]["multi_modal_data"]}
+    out2 = st.generate(DataProto(batch={"input_ids": input_ids[0:1], "attention_mask": (input_ids[0:1] != pad).long()},
+                                 non_tensor_batch={"multi_modal_data": payload2}), gc)
+    L = min(out.shape[1], out2.shape[1])
+    assert torch.equal(out2[0, P:L], out[0, P:L])
+    # eos stops a sequence and the tail is pad
+    first_tok = int(out[1, P])
+    gc2 = dict(gc, eos_token_id=[first_tok])
+    out3 = st.generate(batch, gc2)
+    assert int(out3[1, P]) == first_tok and (out3[1, P + 1:] == pad).all()
+    st.engine.close()
+
+
+def test_pipeline_runs_two_stages_in_synthetic_mode(tmp_path, monkeypatch):
+    from roll.pipeline.rlvr.rlvr_socioseg_vlm_pipeline_infer import SocioSegInferPipeline, compute_giou
+    monkeypatch.setenv("SOCIOSEG_NUM_SAMPLES", "3")
+    cfg = _cfg(tmp_path, resp=4)
+    pipe = SocioSegInferPipeline(cfg)
+    acc = pipe.run()
+    res = os.path.join(str(tmp_path), "result")
+    assert os.path.exists(os.path.join(res, "iou_acc.txt")) and float(open(os.path.join(res, "iou_acc.txt")).read()) == acc
+    assert len(os.listdir(os.path.join(res, "stage1"))) == 3 and len([f for f in os.listdir(os.path.join(res, "stage2")) if f.endswith(".txt")]) == 3
+    from oracle import host_ref as H
+    from socioreasoner_amd import synthetic
+    want = []
+    for i in range(3):
+        masks, gt = synthetic.tile_masks(i)
+        want.append(H.compute_giou(H.resize_nearest(H.mask_union(list(masks)), 768, 768), gt))
+    assert abs(acc - float(np.mean(want))) < 1e-12
+    assert compute_giou(np.zeros((8, 8), np.uint8), np.zeros((8, 8), np.uint8)) == 1.0
+    pipe.actor_infer.engine.close()

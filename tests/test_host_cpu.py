@@ -118,3 +118,29 @@ def test_dp_all_gather_two_ranks_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def test_roll_api_surface_and_config_loader():
+    """The names examples/infer/infer.sh reaches exist under the reference's module paths; the YAML loads."""
+    from roll.configs import load_yaml_config, parse_device_mapping
+    from roll.distributed.scheduler.initialize import init  # noqa: F401
+    from roll.distributed.scheduler.protocol import DataProto
+    from roll.distributed.strategy.factory import create_strategy  # noqa: F401
+    from roll.distributed.strategy.strategy import InferenceStrategy
+    from roll.pipeline.rlvr.rlvr_socioseg_vlm_pipeline_infer import SocioSegConfig, SocioSegInferPipeline, compute_giou  # noqa: F401
+    from roll.distributed.strategy.mi355x_strategy import Mi355xStrategy
+    assert issubclass(Mi355xStrategy, InferenceStrategy)
+    for m in ("initialize", "generate", "start_server", "add_request", "load_states", "offload_states", "forward_step",
+              "setup_collective_group", "broadcast_bucket", "broadcast_parameter", "update_parameter", "update_parameter_in_bucket"):
+        assert hasattr(InferenceStrategy, m), m
+    cfg = SocioSegConfig.from_dict(load_yaml_config("infer", "rlvr_megatron"))
+    assert cfg.actor_infer.strategy_args.strategy_name == "vllm"
+    assert cfg.actor_infer.generating_args.max_new_tokens == 2048 and cfg.sequence_length == 6144
+    assert cfg.actor_infer.device_mapping == list(range(8)) and cfg.actor_infer.model_args.model_name_or_path == cfg.pretrain
+    assert parse_device_mapping("list(range(0,4))") == [0, 1, 2, 3]
+    # DataProto chunk / concat = np.array_split order (reference protocol.py:550-617)
+    d = DataProto(batch={"x": torch.arange(7).unsqueeze(1)}, non_tensor_batch={"o": np.arange(7).astype(object)})
+    parts = d.chunk(3)
+    assert [len(p) for p in parts] == [3, 2, 2]
+    back = DataProto.concat(parts)
+    assert (back.batch["x"] == d.batch["x"]).all() and list(back.non_tensor_batch["o"]) == list(range(7))
