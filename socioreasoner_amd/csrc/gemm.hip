@@ -3,8 +3,9 @@
 //   reproduce HF's bf16 rounding points (hf: transformers/models/qwen2_5_vl/modeling_qwen2_5_vl.py:85-96, 137-150,
 //   211-322, 541-554, 602-758).
 // Tile: BM x 128 x 64 (BM = 128 or 64), 256 threads = 4 waves in 2x2, each wave (BM/2) x 64 as 16x16x32 MFMA tiles.
-// LDS: double-buffered, rows of 64 bf16 (128 B) with the 16-byte chunk index XOR-ed with (row & 7) so that the
-// ds_read_b128 fragment reads (lane = row, 4 lane-groups = 4 k-chunks) are bank-conflict free.
+// LDS: double-buffered, filled by LDS-DMA (global_load_lds), rows of 64 bf16 (128 B) with the 16-byte chunk index
+// XOR-ed with (row & 7) so that the ds_read_b128 fragment reads (lane = row, 4 lane-groups = 4 k-chunks) are
+// bank-conflict free.
 // The MFMA is issued as D = Wfrag x Afrag, i.e. D[i = n][j = m]: a lane then owns 4 CONSECUTIVE output columns of
 // one output row, which makes the epilogue an 8-byte store per lane and keeps gate/up pairs in the same lane.
 #include "kernels.h"
@@ -26,8 +27,6 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem<BM>& sm = *reinterpret_cast<Smem<BM>*>(smem_raw);
     constexpr int MI = BM / 32;       // 16-row m-tiles per wave
-    constexpr int A_LOADS = BM * 8 / NTHREADS;
-    constexpr int W_LOADS = BN * 8 / NTHREADS;
 
     // ---- block -> tile: XCD-aware (block b runs on XCD b % 8: give each XCD a contiguous run of tiles), then
     // grouped ordering (8 m-tiles share their W panels while walking n)
@@ -49,38 +48,28 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fg = lane >> 4;
 
-    // ---- global -> register staging (16 B per load), rows clamped so edge tiles stay in bounds
-    uint4 ra[A_LOADS], rw[W_LOADS];
-    const bf16_t* aptr[A_LOADS];
-    const bf16_t* wptr[W_LOADS];
-    int a_dst[A_LOADS], w_dst[W_LOADS];
+    // ---- global -> LDS staging by LDS-DMA (global_load_lds, 16 B per lane): no VGPR round trip and no ds_write
+    // (a register-staged ds_write_b128 costs ~13 LDS cycles per wave-instruction on CDNA4 and made the loop LDS-bound).
+    // One wave instruction fills 1 KB of LDS linearly = 8 tile rows x 128 B; the XOR swizzle is applied on the SOURCE
+    // side: lane l fetches logical chunk (l & 7) ^ (row & 7) of row (l >> 3), so that LDS holds physical chunk l & 7.
+    // Rows are clamped so edge tiles stay in bounds (their results are never stored).
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int A_G = BM / 32, W_G = BN / 32;          // 8-row groups per wave
+    const int lr = lane >> 3, lc = ((lane & 7) ^ lr) * 8;
+    const bf16_t* asrc[A_G];
+    const bf16_t* wsrc[W_G];
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-        int c = tid + i * NTHREADS, row = c >> 3, ch = c & 7;
-        int gm = min(m0 + row, p.M - 1);
-        aptr[i] = p.A + (size_t)gm * p.lda + ch * 8;
-        a_dst[i] = swz(row, ch);
-    }
+    for (int i = 0; i < A_G; ++i) asrc[i] = p.A + (size_t)min(m0 + (wave * A_G + i) * 8 + lr, p.M - 1) * p.lda + lc;
 #pragma unroll
-    for (int i = 0; i < W_LOADS; ++i) {
-        int c = tid + i * NTHREADS, row = c >> 3, ch = c & 7;
-        int gn = min(n0 + row, p.N - 1);
-        wptr[i] = p.W + (size_t)gn * p.K + ch * 8;
-        w_dst[i] = swz(row, ch);
-    }
-    auto gload = [&](int kt) {
+    for (int i = 0; i < W_G; ++i) wsrc[i] = p.W + (size_t)min(n0 + (wave * W_G + i) * 8 + lr, p.N - 1) * p.K + lc;
+    auto stage = [&](int buf, int kt) {
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) ra[i] = *reinterpret_cast<const uint4*>(aptr[i] + kt * BK);
+        for (int i = 0; i < A_G; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(sm.a[buf] + (wave * A_G + i) * 512), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < W_LOADS; ++i) rw[i] = *reinterpret_cast<const uint4*>(wptr[i] + kt * BK);
-    };
-    auto lstore = [&](int buf) {
-        unsigned char* ab = reinterpret_cast<unsigned char*>(sm.a[buf]);
-        unsigned char* wb = reinterpret_cast<unsigned char*>(sm.w[buf]);
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<uint4*>(ab + a_dst[i]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < W_LOADS; ++i) *reinterpret_cast<uint4*>(wb + w_dst[i]) = rw[i];
+        for (int i = 0; i < W_G; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK), (lptr_t)(sm.w[buf] + (wave * W_G + i) * 512), 16, 0, 0);
     };
 
     f32x4 acc[MI][4];
@@ -90,12 +79,11 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    stage(0, 0);
+    __syncthreads();               // the compiler drains the LDS-DMA (vmcnt(0)) in front of the barrier
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const unsigned char* ab = reinterpret_cast<const unsigned char*>(sm.a[cur]);
         const unsigned char* wb = reinterpret_cast<const unsigned char*>(sm.w[cur]);
 #pragma unroll
@@ -117,7 +105,6 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
     }
 
