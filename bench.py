@@ -168,9 +168,17 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         decode_step_ms = phase_ms["decode"] / args.steps / (N_NEW - 1)
         kv_bytes = 36864.0 * (448 + N_NEW / 2) * B
+        # HBM traffic per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950 note):
+        # measured ratio traffic / algorithmic bytes of this kernel family x the algorithmic bytes of one launch
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemv_traffic.json")))
+            traffic = round(pmc["traffic_over_algorithmic_weighted"] * bytes_per_launch)
+        except Exception:  # noqa: BLE001
+            pass
         roof = {"bound": "hbm", "kernel": "k_gemv (decode weight stream, all LM linears + LM head)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_ms * 1e3, 2),
+                "traffic": traffic, "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_ms * 1e3, 2),
                 "launches_per_decode_step": n_launch,
                 "decode_step_ms": round(decode_step_ms, 4),
                 "decode_step_achieved_GBs": round((wl + wh + kv_bytes) / (decode_step_ms * 1e-3) / 1e9, 1)}
