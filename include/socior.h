@@ -130,10 +130,10 @@ int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K,
                      int32_t* amax_idx, void* stream);
 int sr_op_gemv_f32_blocks(int N);
 /* fused decode attention: qkv rows (bias applied, pre-rope) -> mRoPE -> KV-cache append -> attention; slots = identity.
- * kcache [B][kvh][ctx_max][128], vtcache [B][kvh][128][ctx_max]; ctx_len counts the new token; rope_cos/sin: bf16 [max_pos+1][64] tables; dbg: optional 6 stamps */
+ * kcache [B][kvh][ctx_max][128], vtcache [B][kvh][128][ctx_max]; ctx_len counts the new token; rope_cos/sin: bf16 [max_pos+1][64] tables; scores_scratch: bf16 [B][heads][ctx_max] */
 int sr_op_attn_decode(const void* qkv, int qkv_stride, const int32_t* pos, const int32_t* ctx_len, const void* rope_cos,
                       const void* rope_sin, void* kcache, void* vtcache, void* out, int out_stride, int B, int n_q_heads, int n_kv_heads, int ctx_max,
-                      float scale, int64_t* dbg, void* stream);
+                      float scale, void* scores_scratch, void* stream);
 int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, float eps, void* stream);
 int sr_op_resid_rmsnorm(void* x, const float* partials, int ksplit, const void* w, void* out, int rows, int H, float eps,
                         void* stream);

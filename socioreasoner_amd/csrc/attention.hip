@@ -173,31 +173,29 @@ __global__ __launch_bounds__(256) void k_attn_prefill(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------- decode (q_len = 1)
-// One block of 16 waves per (sequence, kv head); the `group` query heads that share the kv head are the MFMA N
-// dimension.  Fused in front of the attention: mRoPE of the new q/k (bf16 ops, hf:557-599) and the KV-cache append
-// (K row, V^T column), so a decode layer needs one launch here instead of three.  The block reads its own cache
-// writes back after a workgroup-scope fence + barrier.  Latency-bound at batch 1 (2 blocks per layer): all key tiles
-// of a wave are prefetched one tile ahead, and 16 waves keep ~150 KB of K / V^T loads in flight.
-constexpr int DEC_HD = 128, DEC_WAVES = 16;
+// Two launches per layer.  A single CU sustains only ~50 GB/s, so the 295 KB of K / V^T of one (sequence, kv head)
+// must be spread over many CUs (one block per (sequence, kv head) measured 13 us, 7 us of it waiting for 2 CUs to pull
+// the cache).  Exact HF softmax needs the row max / sum over ALL keys before P is rounded, hence the split:
+//   k_attn_dec_scores : grid (B, kvh, ctx/64)  mRoPE of the new q/k (bf16 ops, hf:557-599), KV-cache append, and the
+//                       scaled + rounded scores of 64 keys -> scratch S[b][kvh][head][key] (bf16)
+//   k_attn_dec_pv     : grid (B, kvh, 8)       softmax over all keys (float32, rounded to bf16), then one 16-wide d-tile
+//                       of O^T = V^T . P^T
+// The `group` query heads that share a kv head are the MFMA N dimension in both.
+constexpr int DEC_HD = 128;
 
 __device__ __forceinline__ void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2) {
     o1 = rbf(rbf(x1 * c) + rbf((-x2) * s));
     o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
 }
 
-__global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p, int s_stride) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    // LDS: q_s[16][136] bf16 | k_s[128] v_s[128] bf16 | cs[64] sn[64] float | ored[8][64] f32x4 | sb[group][s_stride] bf16
-    bf16_t* q_s = reinterpret_cast<bf16_t*>(dsm);
-    bf16_t* k_s = q_s + 16 * 136;
-    bf16_t* v_s = k_s + 128;
-    float* cs = reinterpret_cast<float*>(v_s + 128);
-    float* sn = cs + 64;
-    f32x4* ored = reinterpret_cast<f32x4*>(sn + 64);
-    bf16_t* sb = reinterpret_cast<bf16_t*>(ored + 8 * 64);
-    const int b = blockIdx.x, kvh = blockIdx.y;
-    const int slot = p.slots ? p.slots[b] : b;
+__global__ __launch_bounds__(256) void k_attn_dec_scores(DecodeAttnArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16_t q_s[16 * 136];
+    __shared__ __attribute__((aligned(16))) bf16_t k_s[128];
+    __shared__ float cs[64], sn[64];
+    const int b = blockIdx.x, kvh = blockIdx.y, z = blockIdx.z;
     const int nkeys = p.ctx_len[b];
+    if (z * 64 >= nkeys) return;
+    const int slot = p.slots ? p.slots[b] : b;
     const int idx = nkeys - 1;                    // cache row of the new token
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -205,40 +203,22 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p
     bf16_t* kc = p.kcache + (size_t)(slot * HK + kvh) * p.ctx_max * DEC_HD;
     bf16_t* vc = p.vtcache + (size_t)(slot * HK + kvh) * DEC_HD * p.ctx_max;
     const bf16_t* row = p.qkv + (size_t)b * p.qkv_stride;
-    const uint4 z4 = uint4{0, 0, 0, 0};
     const int ntiles = (nkeys + 15) / 16;
-    const int npad = (nkeys + 31) / 32 * 32;
-    const int nkb = npad / 32;
-    const int dt = wave & 7, par = wave >> 3;     // phase C role: d-tile, key-block parity
-    const bool stamp = p.dbg && tid == 0 && b == 0 && kvh == 0;
-    if (stamp) p.dbg[0] = wall_clock64();
-
-    // ---- early prefetch of everything that does not depend on the new token: this wave's first 3 key tiles (K rows)
-    // and first 8 key blocks (V^T segments).  The entries that belong to the new token are patched from LDS below,
-    // so the block never has to read back its own cache writes.
-    auto load_k = [&](int t, bf16x8 (&kf)[4]) {
-        const int key = min(t * 16 + fr, nkeys - 1);
+    const int t = z * 4 + wave;
+    // early K prefetch (independent of the new token; its row is patched from LDS below)
+    bf16x8 kf[4];
+    const int key = min(t * 16 + fr, nkeys - 1);
+    if (t < ntiles) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(kc + (size_t)key * DEC_HD + kk * 32 + fg * 8);
-    };
-    const bf16_t* vrow = vc + (size_t)(dt * 16 + fr) * p.ctx_max + fg * 8;
-    bf16x8 kf0[3][4], vf0[8];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-        if (wave + i * DEC_WAVES < ntiles) load_k(wave + i * DEC_WAVES, kf0[i]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (par + 2 * i < nkb) vf0[i] = *reinterpret_cast<const bf16x8*>(vrow + (par + 2 * i) * 32);
-
+    }
     if (tid < 64) {
         const int pos = p.pos[b];
         cs[tid] = bf2f(p.rope_cos[(size_t)pos * 64 + tid]);
         sn[tid] = bf2f(p.rope_sin[(size_t)pos * 64 + tid]);
     }
     __syncthreads();
-    if (stamp) p.dbg[1] = wall_clock64();
-    // ---- rope + cache append (fire and forget) + LDS copies of the new q / k / v
-    for (int i = tid; i < 16 * 64; i += DEC_WAVES * 64) {
+    for (int i = tid; i < 16 * 64; i += 256) {
         const int h = i >> 6, d = i & 63;
         float o1 = 0.f, o2 = 0.f;
         if (h < G) {
@@ -248,59 +228,69 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p
         q_s[h * 136 + d] = f2bf(o1);
         q_s[h * 136 + d + 64] = f2bf(o2);
     }
-    if (tid < 64) {
-        const bf16_t* k = row + (HQ + kvh) * DEC_HD + tid;
-        float o1, o2;
-        rope_pair(bf2f(k[0]), bf2f(k[64]), cs[tid], sn[tid], o1, o2);
-        const bf16_t b1 = f2bf(o1), b2 = f2bf(o2);
-        kc[(size_t)idx * DEC_HD + tid] = b1;
-        kc[(size_t)idx * DEC_HD + tid + 64] = b2;
-        k_s[tid] = b1;
-        k_s[tid + 64] = b2;
-    } else if (tid < 64 + DEC_HD) {
-        const int d = tid - 64;
-        const bf16_t v = row[(HQ + HK + kvh) * DEC_HD + d];
-        vc[(size_t)d * p.ctx_max + idx] = v;
-        v_s[d] = v;
+    if (z == (idx >> 6)) {                        // the block that owns the new token's key appends K and V^T
+        if (tid < 64) {
+            const bf16_t* k = row + (HQ + kvh) * DEC_HD + tid;
+            float o1, o2;
+            rope_pair(bf2f(k[0]), bf2f(k[64]), cs[tid], sn[tid], o1, o2);
+            const bf16_t b1 = f2bf(o1), b2 = f2bf(o2);
+            kc[(size_t)idx * DEC_HD + tid] = b1;
+            kc[(size_t)idx * DEC_HD + tid + 64] = b2;
+            k_s[tid] = b1;
+            k_s[tid + 64] = b2;
+        } else if (tid < 64 + DEC_HD) {
+            const int d = tid - 64;
+            vc[(size_t)d * p.ctx_max + idx] = row[(HQ + HK + kvh) * DEC_HD + d];
+        }
     }
     __syncthreads();
-    if (stamp) p.dbg[2] = wall_clock64();
+    if (t >= ntiles) return;
+    if (key == idx) {                             // rows of (or clamped to) the new token come from LDS
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(k_s + kk * 32 + fg * 8);
+    }
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(q_s + fr * 136 + kk * 32 + fg * 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kk], qf, acc, 0, 0, 0);
+    }
+    if (fr < G) {
+        uint2 v = {pack2(rbf(acc[0]) * p.scale, rbf(acc[1]) * p.scale), pack2(rbf(acc[2]) * p.scale, rbf(acc[3]) * p.scale)};
+        *reinterpret_cast<uint2*>(p.scores + ((size_t)(b * HK + kvh) * G + fr) * p.ctx_max + t * 16 + fg * 4) = v;
+    }
+}
 
-    // ---- phase A: scores S^T[key][head]
-    bf16x8 qf[4];
+__global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    // LDS: ored[3][64] f32x4 | sb[group][s_stride] bf16
+    f32x4* ored = reinterpret_cast<f32x4*>(dsm);
+    bf16_t* sb = reinterpret_cast<bf16_t*>(ored + 3 * 64);
+    const int b = blockIdx.x, kvh = blockIdx.y, dt = blockIdx.z;
+    const int slot = p.slots ? p.slots[b] : b;
+    const int nkeys = p.ctx_len[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int G = p.group, HK = p.n_kv_heads;
+    const bf16_t* vc = p.vtcache + (size_t)(slot * HK + kvh) * DEC_HD * p.ctx_max;
+    const int npad = (nkeys + 31) / 32 * 32, nkb = npad / 32, nvec = npad / 8;
+    const uint4 z4 = uint4{0, 0, 0, 0};
+    // early V^T prefetch: this wave's key blocks kb = wave, wave+4, ... of d-tile dt
+    const bf16_t* vrow = vc + (size_t)(dt * 16 + fr) * p.ctx_max + fg * 8;
+    bf16x8 vf0[8];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(q_s + fr * 136 + kk * 32 + fg * 8);
-    auto score_tile = [&](int t, bf16x8 (&kf)[4]) {
-        if (min(t * 16 + fr, nkeys - 1) == idx) {           // rows of (or clamped to) the new token come from LDS
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(k_s + kk * 32 + fg * 8);
-        }
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kk], qf[kk], acc, 0, 0, 0);
-        if (fr < G) {
-            uint2 v = {pack2(rbf(acc[0]) * p.scale, rbf(acc[1]) * p.scale), pack2(rbf(acc[2]) * p.scale, rbf(acc[3]) * p.scale)};
-            *reinterpret_cast<uint2*>(sb + fr * s_stride + t * 16 + fg * 4) = v;
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-        if (wave + i * DEC_WAVES < ntiles) score_tile(wave + i * DEC_WAVES, kf0[i]);
-    for (int t0 = wave + 3 * DEC_WAVES; t0 < ntiles; t0 += 3 * DEC_WAVES) {      // contexts beyond 768 keys
-        bf16x8 kf[3][4];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (t0 + i * DEC_WAVES < ntiles) load_k(t0 + i * DEC_WAVES, kf[i]);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (t0 + i * DEC_WAVES < ntiles) score_tile(t0 + i * DEC_WAVES, kf[i]);
+    for (int i = 0; i < 8; ++i)
+        if (wave + 4 * i < nkb) vf0[i] = *reinterpret_cast<const bf16x8*>(vrow + (wave + 4 * i) * 32);
+    // scores of all heads of this kv head -> LDS
+    const bf16_t* sg = p.scores + (size_t)(b * HK + kvh) * G * p.ctx_max;
+    for (int i = tid; i < G * nvec; i += 256) {
+        const int h = i / nvec, v = i % nvec;
+        *reinterpret_cast<uint4*>(sb + h * s_stride + v * 8) = *reinterpret_cast<const uint4*>(sg + (size_t)h * p.ctx_max + v * 8);
     }
     __syncthreads();
-    if (stamp) p.dbg[3] = wall_clock64();
-    // ---- phase B: softmax per head (float32), probabilities rounded to bf16 in place; tail zero-filled
-    for (int hh = wave; hh < G; hh += DEC_WAVES) {
+    // softmax per head (float32), probabilities rounded to bf16 in place; tail zero-filled
+    for (int hh = wave; hh < G; hh += 4) {
         bf16_t* srow = sb + hh * s_stride;
-        const int nvec = npad / 8;                               // 16-byte vectors of 8 scores
         if (nvec <= 4 * 64) {
             float v[4][8];
             float mx = -INFINITY;
@@ -346,41 +336,34 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void k_attn_decode(DecodeAttnArgs p
         }
     }
     __syncthreads();
-    if (stamp) p.dbg[4] = wall_clock64();
-    // ---- phase C: O^T[d][head] = V^T[d][:] . P^T ; wave -> (d-tile = wave & 7, key-block parity = wave >> 3)
+    // O^T[d][head] for d-tile dt; the 4 waves split the key blocks and reduce through LDS in fixed order
     f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kb_new = idx >> 5, g_new = (idx & 31) >> 3, e_new = idx & 7;
-    const bf16_t v_new = v_s[dt * 16 + fr];
     auto pv_block = [&](int kb, bf16x8 vf) {
-        if (kb == kb_new && fg == g_new) {                    // the new token's V^T element comes from LDS
-            typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
-            u16x8 t = __builtin_bit_cast(u16x8, vf);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = (e == e_new) ? v_new : t[e];
-            vf = __builtin_bit_cast(bf16x8, t);
-        }
         uint4 pv = z4;
         if (fr < G) pv = *reinterpret_cast<const uint4*>(sb + fr * s_stride + kb * 32 + fg * 8);
         oacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pv), oacc, 0, 0, 0);
     };
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-        if (par + 2 * i < nkb) pv_block(par + 2 * i, vf0[i]);
-    for (int kb0 = par + 16; kb0 < nkb; kb0 += 16) {          // contexts beyond 512 keys
+        if (wave + 4 * i < nkb) pv_block(wave + 4 * i, vf0[i]);
+    for (int kb0 = wave + 32; kb0 < nkb; kb0 += 32) {          // contexts beyond 1024 keys
         bf16x8 vf[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (kb0 + 2 * i < nkb) vf[i] = *reinterpret_cast<const bf16x8*>(vrow + (kb0 + 2 * i) * 32);
+            if (kb0 + 4 * i < nkb) vf[i] = *reinterpret_cast<const bf16x8*>(vrow + (kb0 + 4 * i) * 32);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (kb0 + 2 * i < nkb) pv_block(kb0 + 2 * i, vf[i]);
+            if (kb0 + 4 * i < nkb) pv_block(kb0 + 4 * i, vf[i]);
     }
-    if (par == 1) ored[dt * 64 + lane] = oacc;
+    if (wave > 0) ored[(wave - 1) * 64 + lane] = oacc;
     __syncthreads();
-    if (stamp) p.dbg[5] = wall_clock64();
-    if (par == 0 && fr < G) {
-        const f32x4 o2 = ored[dt * 64 + lane];
-        uint2 v = {pack2(oacc[0] + o2[0], oacc[1] + o2[1]), pack2(oacc[2] + o2[2], oacc[3] + o2[3])};
+    if (wave == 0 && fr < G) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const f32x4 o2 = ored[w * 64 + lane];
+            oacc[0] += o2[0]; oacc[1] += o2[1]; oacc[2] += o2[2]; oacc[3] += o2[3];
+        }
+        uint2 v = {pack2(oacc[0], oacc[1]), pack2(oacc[2], oacc[3])};
         *reinterpret_cast<uint2*>(p.out + (size_t)b * p.out_stride + (kvh * G + fr) * DEC_HD + dt * 16 + fg * 4) = v;
     }
 }
@@ -398,22 +381,20 @@ int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim) {
     return 0;
 }
 
-static size_t dec_smem(int ctx_max, int group) {
-    return 16 * 136 * 2 + 256 * 2 + 128 * 4 + 8 * 64 * 16 + (size_t)group * (ctx_max + 8) * sizeof(bf16_t);
-}
+static size_t dec_smem(int ctx_max, int group) { return 3 * 64 * 16 + (size_t)group * (ctx_max + 8) * sizeof(bf16_t); }
 
 // raises the dynamic-LDS limit once, outside of any stream capture
 int attn_decode_prepare(int ctx_max, int group) {
     const size_t smem = dec_smem(ctx_max, group);
     if (smem > 160 * 1024) return -22;
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_decode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_dec_pv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 }
 
 int launch_attn_decode(hipStream_t s, const DecodeAttnArgs& a) {
     if (a.B <= 0) return 0;
-    if (a.group > 16 || a.ctx_max % 64 != 0) return -22;
-    const int s_stride = a.ctx_max + 8;
-    hipLaunchKernelGGL(k_attn_decode, dim3(a.B, a.n_kv_heads), dim3(DEC_WAVES * 64), dec_smem(a.ctx_max, a.group), s, a, s_stride);
+    if (a.group > 16 || a.ctx_max % 64 != 0 || !a.scores) return -22;
+    hipLaunchKernelGGL(k_attn_dec_scores, dim3(a.B, a.n_kv_heads, a.ctx_max / 64), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_attn_dec_pv, dim3(a.B, a.n_kv_heads, DEC_HD / 16), dim3(256), dec_smem(a.ctx_max, a.group), s, a, a.ctx_max + 8);
     SR_CHECK_LAUNCH();
     return 0;
 }

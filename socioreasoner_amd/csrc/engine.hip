@@ -90,7 +90,7 @@ struct sr_engine {
     int *t_src, *t_pos3, *t_slot, *t_idx, *t_lastrow;
     AttnWork* t_work;
     // ---- decode state (device)
-    bf16_t *d_xa, *d_xb, *d_xn, *d_qkv, *d_attn, *d_act;    // d_xa / d_xb: residual stream ping-pong
+    bf16_t *d_xa, *d_xb, *d_xn, *d_qkv, *d_attn, *d_act, *d_scores;    // d_xa / d_xb: residual stream ping-pong
     float *d_logits, *d_slabs, *d_amax_val;
     int *d_amax_idx, *d_cur_tok, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
     int n_part = 0;      // LM-head blocks = partial argmax entries per row
@@ -242,6 +242,7 @@ void carve(sr_engine* e) {
     e->d_qkv = ar.take<bf16_t>(B * e->t_qn);
     e->d_attn = ar.take<bf16_t>(B * c.t_heads * 128);
     e->d_act = ar.take<bf16_t>(B * e->t_inter_pad);
+    e->d_scores = ar.take<bf16_t>(B * c.t_heads * (size_t)c.max_ctx);
     e->d_logits = ar.take<float>(B * c.t_vocab);
     e->d_slabs = ar.take<float>(2 * B * H);
     e->d_amax_val = ar.take<float>(B * e->n_part);
@@ -462,7 +463,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         if (fused && pending) { bf16_t* t = x; x = x_alt; x_alt = t; }     // block 0 wrote the updated stream there
         pending = false;
         DecodeAttnArgs da{e->d_qkv, e->t_qn, e->d_pos, e->d_ctx_len, e->d_slots, e->rope_cos, e->rope_sin, kc, vc, e->d_attn, QD,
-                          B, c.t_heads, c.t_kv_heads, e->t_group, c.max_ctx, scale, nullptr};
+                          B, c.t_heads, c.t_kv_heads, e->t_group, c.max_ctx, scale, e->d_scores};
         SR_TRY(launch_attn_decode(s, da));
         GemvArgs go = gv(e->d_attn, QD, w.o_w, B, H, QD, x, H);
         SR_TRY(launch_gemv(s, go, GV_RESID));
@@ -903,11 +904,11 @@ int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K,
 int sr_op_gemv_f32_blocks(int N) { return gemv_f32_blocks(N); }
 int sr_op_attn_decode(const void* qkv, int qkv_stride, const int32_t* pos, const int32_t* ctx_len, const void* rope_cos,
                       const void* rope_sin, void* kcache, void* vtcache, void* out, int out_stride, int B, int n_q_heads, int n_kv_heads, int ctx_max,
-                      float scale, int64_t* dbg, void* stream) {
+                      float scale, void* scores_scratch, void* stream) {
     int rc = attn_decode_prepare(ctx_max, n_q_heads / n_kv_heads);
     if (rc) return fail(nullptr, rc, "attn_decode_prepare failed with %d", rc);
     DecodeAttnArgs a{(const bf16_t*)qkv, qkv_stride, pos, ctx_len, nullptr, (const bf16_t*)rope_cos, (const bf16_t*)rope_sin, (bf16_t*)kcache, (bf16_t*)vtcache, (bf16_t*)out,
-                     out_stride, B, n_q_heads, n_kv_heads, n_q_heads / n_kv_heads, ctx_max, scale, (long long*)dbg};
+                     out_stride, B, n_q_heads, n_kv_heads, n_q_heads / n_kv_heads, ctx_max, scale, (bf16_t*)scores_scratch};
     SR_WRAP(launch_attn_decode((hipStream_t)stream, a));
 }
 int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, float eps, void* stream) {

@@ -17,6 +17,7 @@
 //   F32 + argmax  : float32 logits and a per-block (max, lowest index) pair for the greedy token (hf:1386-1387).
 #include "kernels.h"
 #include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -341,7 +342,9 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     if (mode == GV_PARTIAL && (a.ksplit < 1 || a.ksplit > a.K / 64)) return -22;
     if (a.norm_w && !(mode == GV_BIAS || mode == GV_SWIGLU || mode == GV_F32)) return -22;
     if (a.n_slabs > 0 && (!a.norm_w || !a.slabs || !a.x_out)) return -22;
-    const int want = mode == GV_F32 ? 1 : 4;
+    int want = mode == GV_F32 ? 1 : 4;
+    static const char* kp_env = getenv("SR_GEMV_KP");          // tuning hook for tools/bench_gemv.py
+    if (kp_env && mode != GV_F32) want = atoi(kp_env);
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
     switch (mode) {
         case GV_PARTIAL: return kp == 4 ? launch_n<GV_PARTIAL, 4>(s, a) : kp == 2 ? launch_n<GV_PARTIAL, 2>(s, a) : launch_n<GV_PARTIAL, 1>(s, a);

@@ -51,7 +51,7 @@ struct AttnArgs {
 };
 int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim);
 
-// decode: q/k/v rows (after the Linear bias, before rope) -> mRoPE -> KV-cache append -> attention, one launch
+// decode: q/k/v rows (after the Linear bias, before rope) -> mRoPE -> KV-cache append -> attention (two launches)
 struct DecodeAttnArgs {
     const bf16_t* qkv; int qkv_stride;    // [B, (Hq + 2 Hkv)*128] bf16
     const int* pos;                       // [B] rotary position of the new token (all three mRoPE axes equal)
@@ -64,7 +64,7 @@ struct DecodeAttnArgs {
     bf16_t* out; int out_stride;          // [B, Hq*128]
     int B, n_q_heads, n_kv_heads, group, ctx_max;
     float scale;
-    long long* dbg;                       // optional: phase timestamps (s_memrealtime, 100 MHz) of block (0,0)
+    bf16_t* scores;                       // scratch [B][kvh][group][ctx_max] bf16 between the two decode launches
 };
 int launch_attn_decode(hipStream_t s, const DecodeAttnArgs& a);
 int attn_decode_prepare(int ctx_max, int group);
