@@ -146,13 +146,28 @@ def main():
         act = torch.empty(B, I, dtype=torch.bfloat16, device=dev)
         lg = torch.empty(B, t_.vocab_size, dtype=torch.float32, device=dev)
 
+        nw = torch.ones(H, dtype=torch.bfloat16, device=dev)
+        bq = torch.zeros(QN, dtype=torch.bfloat16, device=dev)
+        slabs = torch.zeros(2, B, H, dtype=torch.float32, device=dev)
+        xo = torch.zeros(B, H, dtype=torch.bfloat16, device=dev)
+        qkv_o = torch.empty(B, QN, dtype=torch.bfloat16, device=dev)
+        xr = torch.zeros(B, H, dtype=torch.bfloat16, device=dev)
+        nb = lib.sr_op_gemv_f32_blocks(t_.vocab_size)
+        av = torch.empty(B, nb, dtype=torch.float32, device=dev)
+        ai = torch.empty(B, nb, dtype=torch.int32, device=dev)
+        fused = B <= 4          # same launch configuration as the engine's decode layer (engine.hip enqueue_decode_forward)
+        TL = 0x100              # weights are fragment-ordered in the engine; the timing does not depend on the values
+        eps = C.c_float(1e-6)
+
         def gemv_sequence():
             for l in range(nl):
-                lib.sr_op_gemv(P(x), I, P(wq[l]), B, QN, H, P(part), 4, 0, s)
-                lib.sr_op_gemv(P(x), I, P(wo[l]), B, H, H, P(part), 4, 0, s)
-                lib.sr_op_gemv(P(x), I, P(wg[l]), B, 2 * I, H, P(act), 1, 1, s)
-                lib.sr_op_gemv(P(act), I, P(wd[l]), B, H, I, P(part), 4, 0, s)
-            lib.sr_op_gemv(P(x), I, P(wv), B, t_.vocab_size, H, P(lg), 1, 2, s)
+                lib.sr_op_gemv_fused(P(x), I, P(wq[l]), B, QN, H, P(qkv_o), QN, 3 | TL, P(bq), P(nw) if fused else None, eps,
+                                     P(slabs) if fused else None, 2 if fused else 0, P(xo) if fused else None, None, None, s)
+                lib.sr_op_gemv_fused(P(x), I, P(wo[l]), B, H, H, P(xr), H, 4 | TL, None, None, eps, None, 0, None, None, None, s)
+                lib.sr_op_gemv_fused(P(x), I, P(wg[l]), B, 2 * I, H, P(act), I, 1 | TL, None, P(nw) if fused else None, eps, None, 0, None, None, None, s)
+                lib.sr_op_gemv(P(act), I, P(wd[l]), B, H, I, P(part), 2, 0 | TL, s)
+            lib.sr_op_gemv_fused(P(x), I, P(wv), B, t_.vocab_size, H, P(lg), t_.vocab_size, 2 | TL, None, P(nw) if fused else None, eps,
+                                 P(slabs) if fused else None, 2 if fused else 0, P(xo) if fused else None, P(av), P(ai), s)
         gemv_sequence()
         a, b_ = ev(), ev()
         reps = 5

@@ -32,5 +32,15 @@ __device__ __forceinline__ float silu_f(float x) { return x * (1.0f / (1.0f + __
 // nn.GELU() (erf form), float32 internally
 __device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Fragment-ordered ("tiled16x64") weight layout of a [N, K] matrix (N % 16 == 0, K % 64 == 0): every 16-row x 64-k
+// block is 2 KB contiguous, stored in the order the decode GEMV's MFMA A-operand wants it --
+//   [n / 16][k / 64][kstep = (k % 16) / 8][lane = ((k % 64) / 16) * 16 + n % 16][k % 8]
+// so one wave instruction of the weight stream reads 1 KB fully contiguous (measured +22..28 % HBM throughput over
+// 16 rows x 64 B fragments of a row-major matrix).  Any 8 consecutive k of one row stay contiguous (16 B), which is all
+// the GEMM's LDS-DMA staging and the embedding gather need.
+__host__ __device__ __forceinline__ size_t tiled_offset(size_t n, size_t k, size_t K) {
+    return (((n >> 4) * (K >> 6) + (k >> 6)) * 2 + ((k >> 3) & 1)) * 512 + ((((k >> 4) & 3) << 4) + (n & 15)) * 8 + (k & 7);
+}
+
 #define SR_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

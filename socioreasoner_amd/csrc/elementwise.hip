@@ -144,11 +144,13 @@ __global__ __launch_bounds__(256) void k_lm_rope_prefill(LmRopeArgs p) {
 
 // ----------------------------------------------------------------------------------------------- gathers
 // src >= 0: token id -> embedding row; src < 0: image feature row -(src+1)  (hf:1210-1216 masked_scatter)
-__global__ __launch_bounds__(256) void k_embed(const int* src, const bf16_t* table, const bf16_t* img, bf16_t* out, int H) {
+__global__ __launch_bounds__(256) void k_embed(const int* src, const bf16_t* table, const bf16_t* img, bf16_t* out, int H, int tiled) {
     const int t = blockIdx.x, s = src[t];
-    const bf16_t* from = s >= 0 ? table + (size_t)s * H : img + (size_t)(-s - 1) * H;
-    for (int c = threadIdx.x; c < H / 8; c += blockDim.x)
-        reinterpret_cast<uint4*>(out + (size_t)t * H)[c] = reinterpret_cast<const uint4*>(from)[c];
+    for (int c = threadIdx.x; c < H / 8; c += blockDim.x) {
+        const bf16_t* from = s < 0 ? img + (size_t)(-s - 1) * H + c * 8
+                                   : table + (tiled ? tiled_offset(s, (size_t)c * 8, H) : (size_t)s * H + c * 8);
+        reinterpret_cast<uint4*>(out + (size_t)t * H)[c] = *reinterpret_cast<const uint4*>(from);
+    }
 }
 __global__ __launch_bounds__(256) void k_gather_rows(const bf16_t* in, const int* rows, bf16_t* out, int H) {
     const int t = blockIdx.x;
@@ -251,9 +253,10 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
         s_feed = feed;
     }
     __syncthreads();
-    const bf16_t* from = a.table + (size_t)s_feed * a.H;
-    for (int c = tid; c < a.H / 8; c += 256)
-        reinterpret_cast<uint4*>(a.x + (size_t)b * a.H)[c] = reinterpret_cast<const uint4*>(from)[c];
+    for (int c = tid; c < a.H / 8; c += 256) {
+        const bf16_t* from = a.table + (a.table_tiled ? tiled_offset(s_feed, (size_t)c * 8, a.H) : (size_t)s_feed * a.H + c * 8);
+        reinterpret_cast<uint4*>(a.x + (size_t)b * a.H)[c] = *reinterpret_cast<const uint4*>(from);
+    }
 }
 
 // counter-based synthetic weights; definition shared with oracle/weights.py (independent implementations)
@@ -272,25 +275,25 @@ __global__ __launch_bounds__(256) void k_synth_fill(bf16_t* out, long long n, ui
 // weight loader: HF tensor [rows, cols] (bf16 or f32) -> engine layout.  mode 0: dst row = r + row_off;
 // mode 1 / 2: gate / up rows interleaved in blocks of 16 (dst row = (r/16)*32 + r%16 (+16 for up))
 __global__ __launch_bounds__(256) void k_load2d(const void* src, int dtype, long long rows, long long cols, bf16_t* dst,
-                                                long long dst_ld, int mode, long long row_off) {
+                                                long long dst_ld, int mode, long long row_off, int tiled) {
     const long long n = rows * cols;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const long long r = i / cols, c = i % cols;
         const long long dr = mode == 0 ? r + row_off : (r / 16) * 32 + (r % 16) + (mode == 2 ? 16 : 0);
         const bf16_t v = dtype == 0 ? reinterpret_cast<const bf16_t*>(src)[i] : f2bf(reinterpret_cast<const float*>(src)[i]);
-        dst[dr * dst_ld + c] = v;
+        dst[tiled ? (long long)tiled_offset(dr, c, dst_ld) : dr * dst_ld + c] = v;
     }
 }
 
 }  // namespace
 
 int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, long long cols, bf16_t* dst, long long dst_ld,
-                  int mode, long long row_off) {
+                  int mode, long long row_off, int tiled) {
     const long long n = rows * cols;
     if (n <= 0) return 0;
     long long blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_load2d, dim3((unsigned)blocks), dim3(256), 0, s, src, dtype, rows, cols, dst, dst_ld, mode, row_off);
+    hipLaunchKernelGGL(k_load2d, dim3((unsigned)blocks), dim3(256), 0, s, src, dtype, rows, cols, dst, dst_ld, mode, row_off, tiled);
     SR_CHECK_LAUNCH();
     return 0;
 }
@@ -333,9 +336,10 @@ int launch_rope_table(hipStream_t s, const float* inv_freq, int n_pos, bf16_t* c
     SR_CHECK_LAUNCH();
     return 0;
 }
-int launch_embed(hipStream_t s, const int* src, const bf16_t* table, const bf16_t* image_embeds, bf16_t* out, int n_tok, int H) {
+int launch_embed(hipStream_t s, const int* src, const bf16_t* table, const bf16_t* image_embeds, bf16_t* out, int n_tok, int H,
+                 int table_tiled) {
     if (n_tok <= 0) return 0;
-    hipLaunchKernelGGL(k_embed, dim3(n_tok), dim3(256), 0, s, src, table, image_embeds, out, H);
+    hipLaunchKernelGGL(k_embed, dim3(n_tok), dim3(256), 0, s, src, table, image_embeds, out, H, table_tiled);
     SR_CHECK_LAUNCH();
     return 0;
 }

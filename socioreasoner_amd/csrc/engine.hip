@@ -404,8 +404,8 @@ bool is_fullatt(const sr_config& c, int blk) {
 }
 
 int gemm(sr_engine* e, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, void* out, int ldo,
-         const bf16_t* bias, const bf16_t* resid, const int* rowmap, int epi) {
-    GemmArgs a{A, lda, W, M, N, K, out, ldo, bias, resid, rowmap};
+         const bf16_t* bias, const bf16_t* resid, const int* rowmap, int epi, int w_tiled = 0) {
+    GemmArgs a{A, lda, W, M, N, K, out, ldo, bias, resid, rowmap, w_tiled};
     SR_TRY(launch_gemm(s, a, epi));
     return 0;
 }
@@ -413,6 +413,7 @@ int gemm(sr_engine* e, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W,
 GemvArgs gv(const bf16_t* x, int ldx, const bf16_t* W, int M, int N, int K, void* out, int ldo) {
     GemvArgs a{};
     a.x = x; a.ldx = ldx; a.W = W; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo; a.ksplit = 1;
+    a.w_tiled = 1;      // every LM matrix of the engine is stored fragment-ordered
     return a;
 }
 
@@ -481,7 +482,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
 
 int enqueue_step(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, hipStream_t s) {
     StepArgs a{e->d_amax_val, e->d_amax_idx, e->n_part, e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished,
-               e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden};
+               e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden, 1};
     SR_TRY(launch_step(s, a));
     return 0;
 }
@@ -596,7 +597,7 @@ int sr_load_weight(sr_engine* e, const char* hf_name, const void* p, int dtype, 
     const int C = c.v_hidden, H = c.t_hidden;
     bf16_t* dst = nullptr;
     long long ld = cols, exp_rows = -1, exp_cols = -1, row_off = 0;
-    int mode = 0;
+    int mode = 0, tiled = 0;
     int idx = -1;
     char sub[96] = "";
     if (name == "visual.patch_embed.proj.weight") { dst = e->patch_w; ld = e->v_pd_pad; exp_rows = C; exp_cols = e->v_pd; }
@@ -621,7 +622,7 @@ int sr_load_weight(sr_engine* e, const char* hf_name, const void* p, int dtype, 
     else if (name == "visual.merger.mlp.0.bias") { dst = e->fc1_b; exp_rows = e->v_mh; exp_cols = 1; }
     else if (name == "visual.merger.mlp.2.weight") { dst = e->fc2_w; exp_rows = c.v_out_hidden; exp_cols = e->v_mh; }
     else if (name == "visual.merger.mlp.2.bias") { dst = e->fc2_b; exp_rows = c.v_out_hidden; exp_cols = 1; }
-    else if (name == "model.embed_tokens.weight") { dst = e->embed; exp_rows = c.t_vocab; exp_cols = H; }
+    else if (name == "model.embed_tokens.weight") { dst = e->embed; exp_rows = c.t_vocab; exp_cols = H; tiled = 1; }
     else if (name == "model.norm.weight") { dst = e->final_norm; exp_rows = H; exp_cols = 1; }
     else if (sscanf(name.c_str(), "model.layers.%d.%95s", &idx, sub) == 2 && idx >= 0 && idx < c.t_layers) {
         LmLayerW& l = e->ll[idx];
@@ -629,21 +630,21 @@ int sr_load_weight(sr_engine* e, const char* hf_name, const void* p, int dtype, 
         const int QD = c.t_heads * 128, KD = c.t_kv_heads * 128;
         if (t == "input_layernorm.weight") { dst = l.ln1; exp_rows = H; exp_cols = 1; }
         else if (t == "post_attention_layernorm.weight") { dst = l.ln2; exp_rows = H; exp_cols = 1; }
-        else if (t == "self_attn.q_proj.weight") { dst = l.qkv_w; exp_rows = QD; exp_cols = H; }
+        else if (t == "self_attn.q_proj.weight") { tiled = 1; dst = l.qkv_w; exp_rows = QD; exp_cols = H; }
         else if (t == "self_attn.q_proj.bias") { dst = l.qkv_b; exp_rows = QD; exp_cols = 1; }
-        else if (t == "self_attn.k_proj.weight") { dst = l.qkv_w; exp_rows = KD; exp_cols = H; row_off = QD; }
+        else if (t == "self_attn.k_proj.weight") { tiled = 1; dst = l.qkv_w; exp_rows = KD; exp_cols = H; row_off = QD; }
         else if (t == "self_attn.k_proj.bias") { dst = l.qkv_b; exp_rows = KD; exp_cols = 1; row_off = QD; }
-        else if (t == "self_attn.v_proj.weight") { dst = l.qkv_w; exp_rows = KD; exp_cols = H; row_off = QD + KD; }
+        else if (t == "self_attn.v_proj.weight") { tiled = 1; dst = l.qkv_w; exp_rows = KD; exp_cols = H; row_off = QD + KD; }
         else if (t == "self_attn.v_proj.bias") { dst = l.qkv_b; exp_rows = KD; exp_cols = 1; row_off = QD + KD; }
-        else if (t == "self_attn.o_proj.weight") { dst = l.o_w; exp_rows = H; exp_cols = QD; }
-        else if (t == "mlp.gate_proj.weight") { dst = l.gu_w; exp_rows = c.t_inter; exp_cols = H; mode = 1; }
-        else if (t == "mlp.up_proj.weight") { dst = l.gu_w; exp_rows = c.t_inter; exp_cols = H; mode = 2; }
-        else if (t == "mlp.down_proj.weight") { dst = l.down_w; exp_rows = H; exp_cols = c.t_inter; ld = e->t_inter_pad; }
+        else if (t == "self_attn.o_proj.weight") { tiled = 1; dst = l.o_w; exp_rows = H; exp_cols = QD; }
+        else if (t == "mlp.gate_proj.weight") { tiled = 1; dst = l.gu_w; exp_rows = c.t_inter; exp_cols = H; mode = 1; }
+        else if (t == "mlp.up_proj.weight") { tiled = 1; dst = l.gu_w; exp_rows = c.t_inter; exp_cols = H; mode = 2; }
+        else if (t == "mlp.down_proj.weight") { tiled = 1; dst = l.down_w; exp_rows = H; exp_cols = c.t_inter; ld = e->t_inter_pad; }
     }
     if (!dst) return fail(e, -2, "sr_load_weight: unknown parameter '%s'", hf_name);
     if (rows != exp_rows || cols != exp_cols)
         return fail(e, -22, "sr_load_weight: '%s' has shape [%lld, %lld], expected [%lld, %lld]", hf_name, rows, cols, exp_rows, exp_cols);
-    SR_TRY(launch_load2d(s, p, dtype, rows, cols, dst, ld, mode, row_off));
+    SR_TRY(launch_load2d(s, p, dtype, rows, cols, dst, ld, mode, row_off, tiled));
     e->loaded[name] = true;
     return 0;
 }
@@ -773,24 +774,24 @@ int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int3
 
     // ---- forward over the packed tokens
     const int H = c.t_hidden, QD = c.t_heads * 128;
-    SR_TRY(launch_embed(s, e->t_src, e->embed, static_cast<const bf16_t*>(image_embeds), e->t_x, n_tok, H));
+    SR_TRY(launch_embed(s, e->t_src, e->embed, static_cast<const bf16_t*>(image_embeds), e->t_x, n_tok, H, 1));
     const float scale = (float)(1.0 / sqrt(128.0));
     for (int l = 0; l < c.t_layers; ++l) {
         const LmLayerW& w = e->ll[l];
         bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
         bf16_t* vc = e->vtcache + (size_t)l * e->kv_layer_elems;
         SR_TRY(launch_rmsnorm(s, e->t_x, w.ln1, e->t_xn, n_tok, H, c.t_rms_eps));
-        if (int rc = gemm(e, s, e->t_xn, H, w.qkv_w, n_tok, e->t_qn, H, e->t_qkv, e->t_qn, w.qkv_b, nullptr, nullptr, EPI_STORE)) return rc;
+        if (int rc = gemm(e, s, e->t_xn, H, w.qkv_w, n_tok, e->t_qn, H, e->t_qkv, e->t_qn, w.qkv_b, nullptr, nullptr, EPI_STORE, 1)) return rc;
         LmRopeArgs ra{e->t_qkv, n_tok, c.t_heads, c.t_kv_heads, e->t_pos3, e->t_slot, e->t_idx, e->rope_cos, e->rope_sin,
                       c.mrope_section[0], c.mrope_section[0] + c.mrope_section[1], kc, vc, c.max_ctx};
         SR_TRY(launch_lm_rope_prefill(s, ra));
         AttnArgs a{e->t_qkv, e->t_qn, kc, 128, (long long)c.max_ctx * 128, vc, c.max_ctx, (long long)128 * c.max_ctx,
                    e->t_attn, QD, e->t_work, n_work, c.t_heads, e->t_group, scale, 1};
         SR_TRY(launch_attn_prefill(s, a, 128));
-        if (int rc = gemm(e, s, e->t_attn, QD, w.o_w, n_tok, H, QD, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID)) return rc;
+        if (int rc = gemm(e, s, e->t_attn, QD, w.o_w, n_tok, H, QD, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID, 1)) return rc;
         SR_TRY(launch_rmsnorm(s, e->t_x, w.ln2, e->t_xn, n_tok, H, c.t_rms_eps));
-        if (int rc = gemm(e, s, e->t_xn, H, w.gu_w, n_tok, 2 * e->t_inter_pad, H, e->t_act, e->t_inter_pad, nullptr, nullptr, nullptr, EPI_SWIGLU)) return rc;
-        if (int rc = gemm(e, s, e->t_act, e->t_inter_pad, w.down_w, n_tok, H, e->t_inter_pad, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID)) return rc;
+        if (int rc = gemm(e, s, e->t_xn, H, w.gu_w, n_tok, 2 * e->t_inter_pad, H, e->t_act, e->t_inter_pad, nullptr, nullptr, nullptr, EPI_SWIGLU, 1)) return rc;
+        if (int rc = gemm(e, s, e->t_act, e->t_inter_pad, w.down_w, n_tok, H, e->t_inter_pad, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID, 1)) return rc;
     }
     // last position of every sequence -> final norm -> tied LM head (hf:1386-1387) -> greedy token
     SR_TRY(launch_gather_rows(s, e->t_x, e->t_lastrow, e->d_xa, B, H));
@@ -885,13 +886,15 @@ int sr_render_overlay(uint8_t* img, int h, int w, const uint8_t* mask, int mh, i
 }
 int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void* out, int ldo, const void* bias, const void* resid,
                const int32_t* rowmap, int epilogue, void* stream) {
-    GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, M, N, K, out, ldo, (const bf16_t*)bias, (const bf16_t*)resid, rowmap};
-    SR_WRAP(launch_gemm((hipStream_t)stream, a, epilogue));
+    GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, M, N, K, out, ldo, (const bf16_t*)bias, (const bf16_t*)resid, rowmap,
+               (epilogue & 0x100) ? 1 : 0};      // bit 8 of `epilogue`: W is fragment-ordered (tiled16x64)
+    SR_WRAP(launch_gemm((hipStream_t)stream, a, epilogue & 0xff));
 }
 int sr_op_gemv(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ksplit, int mode, void* stream) {
-    GemvArgs a = gv((const bf16_t*)x, ldx, (const bf16_t*)W, M, N, K, out, mode == GV_SWIGLU ? N / 2 : N);
+    GemvArgs a = gv((const bf16_t*)x, ldx, (const bf16_t*)W, M, N, K, out, (mode & 0xff) == GV_SWIGLU ? N / 2 : N);
     a.ksplit = ksplit;
-    SR_WRAP(launch_gemv((hipStream_t)stream, a, mode));
+    a.w_tiled = (mode & 0x100) ? 1 : 0;          // bit 8 of `mode`: W is fragment-ordered (tiled16x64)
+    SR_WRAP(launch_gemv((hipStream_t)stream, a, mode & 0xff));
 }
 int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ldo, int mode, const void* bias,
                      const void* norm_w, float eps, const float* slabs, int n_slabs, void* x_out, float* amax_val,
@@ -899,7 +902,8 @@ int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K,
     GemvArgs a = gv((const bf16_t*)x, ldx, (const bf16_t*)W, M, N, K, out, ldo);
     a.bias = (const bf16_t*)bias; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.slabs = slabs; a.n_slabs = n_slabs;
     a.x_out = (bf16_t*)x_out; a.amax_val = amax_val; a.amax_idx = amax_idx;
-    SR_WRAP(launch_gemv((hipStream_t)stream, a, mode));
+    a.w_tiled = (mode & 0x100) ? 1 : 0;
+    SR_WRAP(launch_gemv((hipStream_t)stream, a, mode & 0xff));
 }
 int sr_op_gemv_f32_blocks(int N) { return gemv_f32_blocks(N); }
 int sr_op_attn_decode(const void* qkv, int qkv_stride, const int32_t* pos, const int32_t* ctx_len, const void* rope_cos,

@@ -61,15 +61,19 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
     const bf16_t* wsrc[W_G];
 #pragma unroll
     for (int i = 0; i < A_G; ++i) asrc[i] = p.A + (size_t)min(m0 + (wave * A_G + i) * 8 + lr, p.M - 1) * p.lda + lc;
+    const int w_kt_stride = p.w_tiled ? 1024 : BK;      // elements between consecutive 64-wide k tiles of one row
 #pragma unroll
-    for (int i = 0; i < W_G; ++i) wsrc[i] = p.W + (size_t)min(n0 + (wave * W_G + i) * 8 + lr, p.N - 1) * p.K + lc;
+    for (int i = 0; i < W_G; ++i) {
+        const size_t r = min(n0 + (wave * W_G + i) * 8 + lr, p.N - 1);
+        wsrc[i] = p.W + (p.w_tiled ? tiled_offset(r, lc, p.K) : r * p.K + lc);
+    }
     auto stage = [&](int buf, int kt) {
 #pragma unroll
         for (int i = 0; i < A_G; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(sm.a[buf] + (wave * A_G + i) * 512), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < W_G; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK), (lptr_t)(sm.w[buf] + (wave * W_G + i) * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)kt * w_kt_stride), (lptr_t)(sm.w[buf] + (wave * W_G + i) * 512), 16, 0, 0);
     };
 
     f32x4 acc[MI][4];

@@ -2,6 +2,8 @@
 //   out[M,N] = f(x)[M,K] . W[N,K]^T.   HBM-bound: every weight byte is read exactly once per step, straight from
 //   HBM into VGPRs (no LDS round trip: the operand is not shared between waves), 16 B per lane, 128 B per row
 //   per k-chunk, non-temporal (each CU reads its slice once), deep unroll so that >= 8 KB per wave is in flight.
+// Weights are normally stored fragment-ordered (tiled16x64, common.h): one wave instruction then reads 1 KB contiguous
+// (+22..28 % throughput over row-major 16 x 64 B fragments); row-major is kept for the op-level tests.
 // A wave owns one 16-row tile of W (two tiles -- gate and up -- for the SwiGLU epilogue) over a K slice and feeds it
 // to the 16x16x32 MFMA as the A operand; x (tiny) is the B operand, rows >= M read as zero.  The k-slot -> k mapping
 // is permuted (lane group g covers k = g*16 .. g*16+15 of each 64-chunk as two MFMA steps) so that a lane's two
@@ -53,13 +55,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     u32x4 w[U][T][2];
     const int cend = min(c0 + per, nchunks);
     const bf16_t* wrow[T];
+    const bool tiled = p.w_tiled != 0;    // fragment-ordered weights [n_tile][chunk][kstep][lane][8] (common.h)
 #pragma unroll
-    for (int t = 0; t < T; ++t) wrow[t] = p.W + (size_t)((active ? tile : 0) * T * 16 + t * 16 + fr) * p.K + fg * 16;
+    for (int t = 0; t < T; ++t)
+        wrow[t] = tiled ? p.W + (size_t)((active ? tile : 0) * T + t) * 16 * p.K + lane * 8
+                        : p.W + (size_t)((active ? tile : 0) * T * 16 + t * 16 + fr) * p.K + fg * 16;
     auto fill_w = [&](int u, int c) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            w[u][t][0] = ldg_nt(wrow[t] + (size_t)c * 64);
-            w[u][t][1] = ldg_nt(wrow[t] + (size_t)c * 64 + 8);
+            if (tiled) {
+                w[u][t][0] = ldg_nt(wrow[t] + (size_t)c * 1024);
+                w[u][t][1] = ldg_nt(wrow[t] + (size_t)c * 1024 + 512);
+            } else {
+                w[u][t][0] = ldg_nt(wrow[t] + (size_t)c * 64);
+                w[u][t][1] = ldg_nt(wrow[t] + (size_t)c * 64 + 8);
+            }
         }
     };
     auto first_fills = [&]() {

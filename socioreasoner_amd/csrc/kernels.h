@@ -14,6 +14,7 @@ struct GemmArgs {
     const bf16_t* bias;         // [N] or null
     const bf16_t* resid;        // EPI_RESID: [M, ldo] (may alias out)
     const int* rowmap;          // optional destination row per source row
+    int w_tiled;                // W stored fragment-ordered (tiled16x64, see common.h) instead of row-major
 };
 int launch_gemm(hipStream_t s, const GemmArgs& a, int epi);
 
@@ -31,6 +32,7 @@ struct GemvArgs {
     const float* slabs; int n_slabs;        // pending residual [n_slabs][M][K] added before the norm
     bf16_t* x_out;                          // with slabs: block 0 stores h = bf16(x + bf16(sum slabs)) here (ld = ldx)
     float* amax_val; int* amax_idx;         // F32: per-block (max, lowest index) [M][gridDim.x] (null: skip)
+    int w_tiled;                            // W stored fragment-ordered (tiled16x64) instead of row-major
 };
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode);
 int gemv_f32_blocks(int N);    // gridDim.x of the F32 launch (length of the amax rows)
@@ -91,7 +93,7 @@ int launch_lm_rope_prefill(hipStream_t s, const LmRopeArgs& a);
 // cos/sin tables of the LM rotary embedding: [n_pos][64] bf16, angle = float(pos) * inv_freq[f] in float32 (hf:526-539)
 int launch_rope_table(hipStream_t s, const float* inv_freq, int n_pos, bf16_t* cos_t, bf16_t* sin_t);
 int launch_embed(hipStream_t s, const int* src, const bf16_t* table, const bf16_t* image_embeds, bf16_t* out,
-                 int n_tok, int H);
+                 int n_tok, int H, int table_tiled);
 int launch_gather_rows(hipStream_t s, const bf16_t* in, const int* rows, bf16_t* out, int n, int H);
 int launch_patchify(hipStream_t s, const uint8_t* img, int h, int w, const bf16_t* lut, bf16_t* out, int ld_out,
                     int patch, int merge, int temporal);
@@ -104,13 +106,13 @@ struct StepArgs {
     int* cur_tok; int* ctx_len; int* pos; int* step; int* finished; int* tokens_out;
     int max_new; const int* eos; int n_eos; int pad_id; int B;
     const int* forced;          // optional [B][max_new]: token fed back instead of the greedy one (teacher forcing)
-    const bf16_t* table; bf16_t* x; int H;                      // embedding gather of the token fed back
+    const bf16_t* table; bf16_t* x; int H; int table_tiled;     // embedding gather of the token fed back
 };
 int launch_step(hipStream_t s, const StepArgs& a);
 int launch_synth_fill(hipStream_t s, bf16_t* out, long long n, uint32_t key, float base, float scale);
 int launch_fill_zero(hipStream_t s, void* p, size_t bytes);
 int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, long long cols, bf16_t* dst, long long dst_ld,
-                  int mode, long long row_off);
+                  int mode, long long row_off, int tiled);
 
 // ------------------------------------------------------------------ raster.hip
 int launch_mask_union(hipStream_t s, uint8_t* acc, const uint8_t* m, size_t n);

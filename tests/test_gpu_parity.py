@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_bf16_close, bf16_compare, bits_to_f32
+from tests.util import assert_bf16_close, bf16_compare, bits_to_f32, tile16x64
 
 pytestmark = pytest.mark.gpu
 
@@ -155,6 +155,32 @@ def test_gemv_modes(L, M):
     part = torch.zeros(4, M, 2048, dtype=torch.float32, device="cuda")
     assert L.sr_op_gemv(P(D(xd)), I, P(D(wd)), M, 2048, I, P(part), 4, GV_PARTIAL, sp()) == 0
     assert float((part.sum(0).cpu().double() - xd.double() @ wd.double().t()).abs().max()) <= 2e-3
+
+
+def test_tiled_weight_layout_matches_row_major(L):
+    """The fragment-ordered weight layout (what the engine stores) gives bit-identical results to row-major."""
+    M, N, K = 200, 2560, 2048
+    a, w = rnd((M, K), 60), rnd((N, K), 61, 0.03)
+    o1 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    o2 = torch.zeros_like(o1)
+    assert L.sr_op_gemm(P(D(a)), K, P(D(w)), M, N, K, P(o1), N, None, None, None, EPI_STORE, sp()) == 0
+    assert L.sr_op_gemm(P(D(a)), K, P(D(tile16x64(w))), M, N, K, P(o2), N, None, None, None, EPI_STORE | 0x100, sp()) == 0
+    assert torch.equal(o1, o2)
+    for m in (1, 20):
+        x = rnd((m, K), 62)
+        l1 = torch.zeros(m, N, dtype=torch.float32, device="cuda")
+        l2 = torch.zeros_like(l1)
+        assert L.sr_op_gemv(P(D(x)), K, P(D(w)), m, N, K, P(l1), 1, GV_F32, sp()) == 0
+        assert L.sr_op_gemv(P(D(x)), K, P(D(tile16x64(w))), m, N, K, P(l2), 1, GV_F32 | 0x100, sp()) == 0
+        assert torch.equal(l1, l2)
+    # K = 11008 (uneven split-K), SwiGLU interleave on top of the tiling
+    I = 11008
+    xd, wd = rnd((3, I), 63), rnd((2048, I), 64, 0.02)
+    p1 = torch.zeros(2, 3, 2048, dtype=torch.float32, device="cuda")
+    p2 = torch.zeros_like(p1)
+    assert L.sr_op_gemv(P(D(xd)), I, P(D(wd)), 3, 2048, I, P(p1), 2, GV_PARTIAL, sp()) == 0
+    assert L.sr_op_gemv(P(D(xd)), I, P(D(tile16x64(wd))), 3, 2048, I, P(p2), 2, GV_PARTIAL | 0x100, sp()) == 0
+    assert torch.equal(p1, p2)
 
 
 @pytest.mark.parametrize("M", [1, 3, 4])

@@ -29,3 +29,11 @@ def assert_bf16_close(got, want, max_ulp=1.0, max_frac=0.01, what=""):
     mu, frac, mad = bf16_compare(got, want)
     assert mu <= max_ulp + 1e-6 and frac <= max_frac, f"{what}: max {mu:.2f} ulp, {frac:.4%} differ, max abs {mad:.3e}"
     return mu, frac, mad
+
+
+def tile16x64(w: torch.Tensor) -> torch.Tensor:
+    """Row-major [N, K] -> the engine's fragment-ordered layout (socioreasoner_amd/csrc/common.h tiled_offset):
+    [n/16][k/64][kstep=(k%16)/8][lane=((k%64)/16)*16 + n%16][k%8], returned flat with the same number of elements."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 64 == 0
+    return w.reshape(N // 16, 16, K // 64, 4, 2, 8).permute(0, 2, 4, 3, 1, 5).contiguous().reshape(N, K)

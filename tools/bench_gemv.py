@@ -16,12 +16,12 @@ xo = torch.zeros(B, H, dtype=torch.bfloat16, device="cuda")
 fused = B <= 4
 def mk(n, k): return (torch.randn(R, n, k, device="cuda") * 0.02).to(torch.bfloat16)
 cases = [
-  ("qkv  bias" + ("+norm+slabs" if fused else ""), mk(QN, H), lambda w, o: L.sr_op_gemv_fused(P(x), I, P(w), B, QN, H, P(o), QN, 3, P(bias), P(nw) if fused else None, C.c_float(1e-6), P(slabs) if fused else None, 2 if fused else 0, P(xo) if fused else None, None, None, s), torch.zeros(B, QN, dtype=torch.bfloat16, device="cuda"), QN * H * 2),
-  ("o    resid", mk(H, H), lambda w, o: L.sr_op_gemv_fused(P(x), I, P(w), B, H, H, P(o), H, 4, None, None, C.c_float(0), None, 0, None, None, None, s), torch.zeros(B, H, dtype=torch.bfloat16, device="cuda"), H * H * 2),
-  ("gate/up swiglu" + ("+norm" if fused else ""), mk(2 * I, H), lambda w, o: L.sr_op_gemv_fused(P(x), I, P(w), B, 2 * I, H, P(o), I, 1, None, P(nw) if fused else None, C.c_float(1e-6), None, 0, None, None, None, s), torch.zeros(B, I, dtype=torch.bfloat16, device="cuda"), 2 * I * H * 2),
+  ("qkv  bias" + ("+norm+slabs" if fused else ""), mk(QN, H), lambda w, o: L.sr_op_gemv_fused(P(x), I, P(w), B, QN, H, P(o), QN, 3 | 0x100, P(bias), P(nw) if fused else None, C.c_float(1e-6), P(slabs) if fused else None, 2 if fused else 0, P(xo) if fused else None, None, None, s), torch.zeros(B, QN, dtype=torch.bfloat16, device="cuda"), QN * H * 2),
+  ("o    resid", mk(H, H), lambda w, o: L.sr_op_gemv_fused(P(x), I, P(w), B, H, H, P(o), H, 4 | 0x100, None, None, C.c_float(0), None, 0, None, None, None, s), torch.zeros(B, H, dtype=torch.bfloat16, device="cuda"), H * H * 2),
+  ("gate/up swiglu" + ("+norm" if fused else ""), mk(2 * I, H), lambda w, o: L.sr_op_gemv_fused(P(x), I, P(w), B, 2 * I, H, P(o), I, 1 | 0x100, None, P(nw) if fused else None, C.c_float(1e-6), None, 0, None, None, None, s), torch.zeros(B, I, dtype=torch.bfloat16, device="cuda"), 2 * I * H * 2),
 ]
 for ks in (2, 4):
-    cases.append((f"down partial ks={ks}", mk(H, I), (lambda ks: lambda w, o: L.sr_op_gemv(P(x), I, P(w), B, H, I, P(o), ks, 0, s))(ks), torch.zeros(4, B, H, device="cuda"), H * I * 2))
+    cases.append((f"down partial ks={ks}", mk(H, I), (lambda ks: lambda w, o: L.sr_op_gemv(P(x), I, P(w), B, H, I, P(o), ks, 0 | 0x100, s))(ks), torch.zeros(4, B, H, device="cuda"), H * I * 2))
 for name, W, fn, out, nbytes in cases:
     for r in range(R): assert fn(W[r], out) == 0
     torch.cuda.synchronize()
