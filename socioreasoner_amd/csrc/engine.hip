@@ -161,7 +161,7 @@ void carve(sr_engine* e) {
     e->t_qn = (c.t_heads + 2 * c.t_kv_heads) * 128;
     e->t_group = c.t_heads / c.t_kv_heads;
     e->ks_down = (e->t_inter_pad / 64 >= 16) ? 2 : 1;
-    e->n_part = gemv_f32_blocks(c.t_vocab);
+    e->n_part = gemv_f32_blocks(c.t_vocab, 1, c.t_hidden);      // upper bound (4-wave blocks); per-launch count below
     const int C = c.v_hidden, H = c.t_hidden;
 
     e->weights_begin = (ar.off + 255) & ~(size_t)255;
@@ -417,6 +417,13 @@ GemvArgs gv(const bf16_t* x, int ldx, const bf16_t* W, int M, int N, int K, void
     return a;
 }
 
+// RMSNorms (and the pending residual add) live in the prologue of the consuming GEMV when the B rows of the residual
+// stream fit in LDS (always for the 3B geometry: 32 x 2056 x 2 B = 132 KB); otherwise they are separate launches
+bool fused_norms(const sr_engine* e, int B) {
+    const int H = e->c.t_hidden;
+    return H % 512 == 0 && (size_t)B * (H + 8) * 2 + 2048 <= 150 * 1024;
+}
+
 // LM head on B rows of `x` (+ optional pending slabs): float32 logits + per-block argmax partials.
 // Small batches fuse the final RMSNorm (and the pending residual) into the GEMV prologue.
 int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending, hipStream_t s) {
@@ -424,7 +431,7 @@ int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending,
     const int H = c.t_hidden;
     GemvArgs g = gv(x, H, e->embed, B, c.t_vocab, H, e->d_logits, c.t_vocab);
     g.amax_val = e->d_amax_val; g.amax_idx = e->d_amax_idx;
-    if (B <= 4) {
+    if (fused_norms(e, B)) {
         g.norm_w = e->final_norm; g.eps = c.t_rms_eps;
         if (pending) { g.slabs = e->d_slabs; g.n_slabs = e->ks_down; g.x_out = x_alt; }
     } else {
@@ -437,12 +444,12 @@ int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending,
 }
 
 // one decode forward pass for rows 0..B-1 (device state decides tokens / positions / context lengths).
-// B <= 4: 5 launches per layer (norms and residual adds live in GEMV prologues / epilogues); larger batches keep the
-// two RMSNorm launches (the per-block prologue would re-read B rows too often).
+// 6 launches per layer (qkv, attention scores, attention softmax+PV, o_proj, gate/up, down): norms and residual adds
+// live in GEMV prologues / epilogues.  Batches above 4 use 16-wave blocks that stage x once per block in LDS.
 int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
     const sr_config& c = e->c;
     const int H = c.t_hidden, QD = c.t_heads * 128;
-    const bool fused = B <= 4;
+    const bool fused = fused_norms(e, B);
     bf16_t *x = e->d_xa, *x_alt = e->d_xb;      // k_step gathered the input embedding into d_xa
     bool pending = false;                       // down-projection slabs not yet added to the residual stream
     const float scale = (float)(1.0 / sqrt(128.0));
@@ -481,7 +488,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
 }
 
 int enqueue_step(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, hipStream_t s) {
-    StepArgs a{e->d_amax_val, e->d_amax_idx, e->n_part, e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished,
+    StepArgs a{e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(e->c.t_vocab, B, e->c.t_hidden), e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished,
                e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden, 1};
     SR_TRY(launch_step(s, a));
     return 0;
@@ -905,7 +912,7 @@ int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K,
     a.w_tiled = (mode & 0x100) ? 1 : 0;
     SR_WRAP(launch_gemv((hipStream_t)stream, a, mode & 0xff));
 }
-int sr_op_gemv_f32_blocks(int N) { return gemv_f32_blocks(N); }
+int sr_op_gemv_f32_blocks(int N, int M, int K) { return gemv_f32_blocks(N, M, K); }
 int sr_op_attn_decode(const void* qkv, int qkv_stride, const int32_t* pos, const int32_t* ctx_len, const void* rope_cos,
                       const void* rope_sin, void* kcache, void* vtcache, void* out, int out_stride, int B, int n_q_heads, int n_kv_heads, int ctx_max,
                       float scale, void* scores_scratch, void* stream) {

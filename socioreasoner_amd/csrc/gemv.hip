@@ -24,18 +24,21 @@
 
 namespace {
 
-constexpr int WAVES = 4;
-
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 __device__ __forceinline__ u32x4 ldg_nt(const bf16_t* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
 }
 __device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <int MODE, int MT, int KP, bool NORM>
+// WAVES = 4 : small batches (M <= 4) and the launches whose x cannot be staged -- many small blocks.
+// WAVES = 16: batches 5..32 with x staged ONCE per block in LDS and shared by TPB = 16/KP weight tiles: at M = 32
+//             every weight tile otherwise re-reads as many x bytes as weight bytes through the CU's load path.
+// STAGE     : x (optionally + pending residual slabs, optionally RMS-normalised) is prepared in LDS by the prologue.
+template <int MODE, int MT, int KP, bool STAGE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;     // 16-row W tiles per wave
     constexpr int TPB = WAVES / KP;                    // wave-tiles per block
+    constexpr int NT = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -47,10 +50,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     const int per = (nchunks + ks * KP - 1) / (ks * KP);          // uneven split allowed (K/64 = 172 for the 3B MLP)
     const int c0 = min(((MODE == GV_PARTIAL ? blockIdx.y : 0) * KP + kp) * per, nchunks);
 
-    // ---------------------------------------------------------------- weight ring: the first fills do not depend on x, so
-    // they are issued ahead of the norm prologue's second pass and its latency hides behind the first 16 KB per wave.
-    // U chunk slots stay in flight; a slot is refilled right after its MFMAs issue, so the compiler's counted vmcnt
-    // only ever waits for the oldest slot.
+    // ---------------------------------------------------------------- weight ring: U chunk slots (16 loads = 16 KB per
+    // wave) stay in flight; a slot is refilled right after its MFMAs issue, so the compiler's counted vmcnt only ever
+    // waits for the oldest slot.  The first fills do not depend on x: they go out before the prologue's second pass.
     constexpr int U = 8 / T;
     u32x4 w[U][T][2];
     const int cend = min(c0 + per, nchunks);
@@ -79,50 +81,55 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                 if (c0 + u < cend) fill_w(u, c0 + u);
         }
     };
-    // vmcnt retires in order: with the norm prologue the fills go out right after the prologue's own global loads have
-    // been consumed (end of pass 1), and fly during the barrier + pass 2; without it they go out immediately.
-    if constexpr (!NORM) first_fills();
+    if constexpr (!STAGE) first_fills();
 
-    // ---------------------------------------------------------------- NORM prologue: normalised x -> LDS
-    // layout: xn[m][K + 8] bf16 (row pad 16 B: conflict-free ds_read_b128 across rows), then rs[32] float
+    // ---------------------------------------------------------------- STAGE prologue: x -> LDS
+    // layout: xn[m][K + 8] bf16 (row pad 16 B: conflict-free ds_read_b128 across rows); red[(K/512)][32] float after it.
+    // The in-block K reduction later reuses the xn region.
     const int xs = p.K + 8;
     bf16_t* xn = reinterpret_cast<bf16_t*>(smem);
-    float* red = reinterpret_cast<float*>(smem + (NORM ? ((size_t)p.M * xs * 2 + 15) / 16 * 16 : 0));   // [4][32] + reduce area
-    if constexpr (NORM) {
-        const int nch = p.K / 8;
-        // pass 1: h = x (+ pending residual) -> LDS (bf16), per-row sum of squares
-        for (int m = 0; m < p.M; ++m) {
-            float ss = 0.f;
-            for (int c = tid; c < nch; c += WAVES * 64) {
-                uint4 u = *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + c * 8);
-                float v[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
-                if (p.n_slabs > 0) {
-                    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    for (int s = 0; s < p.n_slabs; ++s) {
-                        const float4* pp = reinterpret_cast<const float4*>(p.slabs + ((size_t)s * p.M + m) * p.K + c * 8);
-                        float4 p0 = pp[0], p1 = pp[1];
-                        a[0] += p0.x; a[1] += p0.y; a[2] += p0.z; a[3] += p0.w;
-                        a[4] += p1.x; a[5] += p1.y; a[6] += p1.z; a[7] += p1.w;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + rbf(a[e]));
-                    u = uint4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-                    if (blockIdx.x == 0 && blockIdx.y == 0) *reinterpret_cast<uint4*>(p.x_out + (size_t)m * p.ldx + c * 8) = u;
+    const size_t xn_bytes = STAGE ? ((size_t)p.M * xs * 2 + 15) / 16 * 16 : 0;
+    float* red = reinterpret_cast<float*>(smem + xn_bytes);
+    if constexpr (STAGE) {
+        const int nch = p.K / 8;                      // 16-byte chunks per row; nch % 64 == 0 (K % 512 == 0)
+        const int nseg = nch / 64;                    // 64-chunk segments per row: one wave-iteration each
+        const bool norm = p.norm_w != nullptr;
+        // pass 1: h = x (+ pending residual) -> LDS (bf16); per-(row, segment) sum of squares
+        for (int task = tid; task < p.M * nch; task += NT) {
+            const int m = task / nch, c = task % nch;
+            uint4 u = *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + c * 8);
+            float v[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
+            if (p.n_slabs > 0) {
+                float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int s = 0; s < p.n_slabs; ++s) {
+                    const float4* pp = reinterpret_cast<const float4*>(p.slabs + ((size_t)s * p.M + m) * p.K + c * 8);
+                    float4 p0 = pp[0], p1 = pp[1];
+                    a[0] += p0.x; a[1] += p0.y; a[2] += p0.z; a[3] += p0.w;
+                    a[4] += p1.x; a[5] += p1.y; a[6] += p1.z; a[7] += p1.w;
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
-                *reinterpret_cast<uint4*>(xn + (size_t)m * xs + c * 8) = u;
+                for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + rbf(a[e]));
+                u = uint4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                if (blockIdx.x == 0 && blockIdx.y == 0) *reinterpret_cast<uint4*>(p.x_out + (size_t)m * p.ldx + c * 8) = u;
             }
-            ss = wave_sum(ss);
-            if (lane == 0) red[wave * 32 + m] = ss;
+            *reinterpret_cast<uint4*>(xn + (size_t)m * xs + c * 8) = u;
+            if (norm) {
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+                ss = wave_sum(ss);                    // the 64 tasks of a wave-iteration share (m, segment)
+                if (lane == 0) red[(c >> 6) * 32 + m] = ss;
+            }
         }
         first_fills();
         __syncthreads();
-        // pass 2: xn = bf16(w * bf16(h * rs)) in place
-        for (int m = 0; m < p.M; ++m) {
-            const float tot = red[m] + red[32 + m] + red[64 + m] + red[96 + m];
-            const float rs = 1.0f / sqrtf(tot / (float)p.K + p.eps);
-            for (int c = tid; c < nch; c += WAVES * 64) {
+        if (norm) {
+            // pass 2: xn = bf16(w * bf16(h * rs)) in place  (hf:65-79)
+            for (int task = tid; task < p.M * nch; task += NT) {
+                const int m = task / nch, c = task % nch;
+                float tot = 0.f;
+                for (int sg = 0; sg < nseg; ++sg) tot += red[sg * 32 + m];
+                const float rs = 1.0f / sqrtf(tot / (float)p.K + p.eps);
                 uint4 u = *reinterpret_cast<const uint4*>(xn + (size_t)m * xs + c * 8);
                 uint4 wu = *reinterpret_cast<const uint4*>(p.norm_w + c * 8);
                 float v[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
@@ -133,8 +140,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                 *reinterpret_cast<uint4*>(xn + (size_t)m * xs + c * 8) =
                     uint4{pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     f32x4 acc[T][MT];
@@ -151,10 +158,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
             const int m = mt * 16 + fr;
             xok[mt] = m < p.M;
             const int mm = xok[mt] ? m : 0;
-            xrow[mt] = (NORM ? xn + (size_t)mm * xs : p.x + (size_t)mm * p.ldx) + fg * 16;
+            xrow[mt] = (STAGE ? xn + (size_t)mm * xs : p.x + (size_t)mm * p.ldx) + fg * 16;
         }
-        // x fragments: from LDS (NORM) they are read at consume time; from global they ride the ring with the weights
-        u32x4 xv[U][MT][2];
+        // x fragments: from LDS (STAGE) they are read at consume time; from global they ride the ring with the weights
+        constexpr int XU = STAGE ? 1 : U;
+        u32x4 xv[XU][MT][2];
         auto fill_x = [&](int u, int c) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                 }
             }
         };
-        if constexpr (!NORM) {
+        if constexpr (!STAGE) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (c0 + u < cend) fill_x(u, c0 + u);
@@ -176,17 +184,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (c + u < cend) {
-                    if constexpr (NORM) fill_x(u, c + u);
+                    constexpr int xu_static = 0;
+                    const int xu = STAGE ? xu_static : u;
+                    if constexpr (STAGE) fill_x(0, c + u);
 #pragma unroll
                     for (int t = 0; t < T; ++t)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][0]), as_frag(xv[u][mt][0]), acc[t][mt], 0, 0, 0);
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][1]), as_frag(xv[u][mt][1]), acc[t][mt], 0, 0, 0);
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][0]), as_frag(xv[STAGE ? 0 : u][mt][0]), acc[t][mt], 0, 0, 0);
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][1]), as_frag(xv[STAGE ? 0 : u][mt][1]), acc[t][mt], 0, 0, 0);
                         }
+                    (void)xu;
                     if (c + U + u < cend) {
                         fill_w(u, c + U + u);
-                        if constexpr (!NORM) fill_x(u, c + U + u);
+                        if constexpr (!STAGE) fill_x(u, c + U + u);
                     }
                 }
             }
@@ -194,8 +205,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     }
 
     // ---------------------------------------------------------------- in-block K reduction (fixed order kp = 1, 2, 3)
+    // reuses the staged-x region once every wave is done reading it
+    f32x4* rbuf = reinterpret_cast<f32x4*>(STAGE ? smem : reinterpret_cast<unsigned char*>(red + 128));   // [TPB][KP-1][T*MT][64]
     if constexpr (KP > 1) {
-        f32x4* rbuf = reinterpret_cast<f32x4*>(red + 128);      // [TPB][KP-1][T*MT][64]
+        if constexpr (STAGE) __syncthreads();
         if (kp > 0) {
 #pragma unroll
             for (int t = 0; t < T; ++t)
@@ -266,7 +279,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     if constexpr (MODE == GV_F32) {
         // fused greedy argmax: (max, lowest index) of this block's logits per batch row -> amax[m][blockIdx.x]
         if (p.amax_val) {
-            float* av = red + 128 + 0;                 // KP == 1 here: reduce area is free.  [WAVES][32]
+            if constexpr (STAGE) __syncthreads();      // KP == 1 here; the staged x is dead, reuse its region
+            float* av = reinterpret_cast<float*>(rbuf);                 // [WAVES][32]
             int* ai = reinterpret_cast<int*>(av + WAVES * 32);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -296,46 +310,62 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     }
 }
 
-template <int MODE, int MT, int KP, bool NORM>
+size_t stage_bytes(const GemvArgs& a) { return ((size_t)a.M * (a.K + 8) * 2 + 15) / 16 * 16; }
+
+template <int MODE, int MT, int KP, bool STAGE, int WAVES>
 int launch_k(hipStream_t s, const GemvArgs& a) {
     constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;
     constexpr int TPB = WAVES / KP;
     const int ntiles = a.N / (16 * T);
     dim3 grid(cdiv(ntiles, TPB), MODE == GV_PARTIAL ? a.ksplit : 1);
-    size_t smem = NORM ? ((size_t)a.M * (a.K + 8) * 2 + 15) / 16 * 16 : 0;
-    smem += 128 * sizeof(float);                                                  // per-wave row sums
     size_t red = (size_t)TPB * (KP > 1 ? KP - 1 : 0) * T * MT * 64 * sizeof(f32x4);
     if (MODE == GV_F32) red = red > (size_t)WAVES * 32 * 8 ? red : (size_t)WAVES * 32 * 8;
-    smem += red;
+    size_t smem;
+    if (STAGE) {                                       // [xn | row sums]; the reduction reuses the xn region
+        smem = stage_bytes(a);
+        if (red > smem) smem = red;
+        smem += 128 * sizeof(float);
+    } else smem = 128 * sizeof(float) + red;
     if (smem > 160 * 1024) return -12;
     static size_t attr = 0;
     if (smem > 64 * 1024 && smem > attr) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemv<MODE, MT, KP, NORM>),
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemv<MODE, MT, KP, STAGE, WAVES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (r != hipSuccess) return (int)r;
         attr = smem;
     }
-    hipLaunchKernelGGL((k_gemv<MODE, MT, KP, NORM>), grid, dim3(WAVES * 64), smem, s, a, ntiles);
+    hipLaunchKernelGGL((k_gemv<MODE, MT, KP, STAGE, WAVES>), grid, dim3(WAVES * 64), smem, s, a, ntiles);
     SR_CHECK_LAUNCH();
     return 0;
 }
 
-template <int MODE, int KP, bool NORM>
-int launch_mt(hipStream_t s, const GemvArgs& a) {
-    return a.M <= 16 ? launch_k<MODE, 1, KP, NORM>(s, a) : launch_k<MODE, 2, KP, NORM>(s, a);
+// x can be staged in LDS when a whole padded copy fits and the prologue's row segmentation works
+bool can_stage(const GemvArgs& a) { return a.K % 512 == 0 && stage_bytes(a) + 1024 <= 150 * 1024; }
+// big-block configuration: batches above 4 whose x is staged (shared by the block's tiles)
+bool use_big(const GemvArgs& a, int mode) {
+    return a.M > 4 && can_stage(a) && (mode == GV_BIAS || mode == GV_SWIGLU || mode == GV_F32 || mode == GV_RESID);
 }
 
 template <int MODE, int KP>
-int launch_n(hipStream_t s, const GemvArgs& a) {
+int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
+    const bool stage = a.norm_w != nullptr;
     if constexpr (MODE == GV_BIAS || MODE == GV_SWIGLU || MODE == GV_F32) {
-        if (a.norm_w) return launch_mt<MODE, KP, true>(s, a);
+        if (stage) return a.M <= 16 ? launch_k<MODE, 1, KP, true, 4>(s, a) : launch_k<MODE, 2, KP, true, 4>(s, a);
     }
-    return launch_mt<MODE, KP, false>(s, a);
+    return a.M <= 16 ? launch_k<MODE, 1, KP, false, 4>(s, a) : launch_k<MODE, 2, KP, false, 4>(s, a);
+}
+template <int MODE, int KP>
+int launch_big(hipStream_t s, const GemvArgs& a) {        // 16-wave blocks, x staged
+    return a.M <= 16 ? launch_k<MODE, 1, KP, true, 16>(s, a) : launch_k<MODE, 2, KP, true, 16>(s, a);
 }
 
 }  // namespace
 
-int gemv_f32_blocks(int N) { return cdiv(N / 16, WAVES); }
+int gemv_f32_blocks(int N, int M, int K) {
+    GemvArgs a{};
+    a.M = M; a.K = K; a.N = N;
+    return cdiv(N / 16, use_big(a, GV_F32) ? 16 : 4);
+}
 
 // largest in-block K split that leaves >= 2 chunks per wave
 int gemv_pick_kp(int K, int ksplit, int want) {
@@ -351,17 +381,26 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     if (mode == GV_SWIGLU && a.N % 32 != 0) return -22;
     if (mode == GV_PARTIAL && (a.ksplit < 1 || a.ksplit > a.K / 64)) return -22;
     if (a.norm_w && !(mode == GV_BIAS || mode == GV_SWIGLU || mode == GV_F32)) return -22;
+    if (a.norm_w && !can_stage(a)) return -22;
     if (a.n_slabs > 0 && (!a.norm_w || !a.slabs || !a.x_out)) return -22;
     int want = mode == GV_F32 ? 1 : 4;
     static const char* kp_env = getenv("SR_GEMV_KP");          // tuning hook for tools/bench_gemv.py
     if (kp_env && mode != GV_F32) want = atoi(kp_env);
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
+    if (use_big(a, mode)) {
+        switch (mode) {
+            case GV_SWIGLU: return kp == 4 ? launch_big<GV_SWIGLU, 4>(s, a) : launch_big<GV_SWIGLU, 1>(s, a);
+            case GV_F32: return launch_big<GV_F32, 1>(s, a);
+            case GV_BIAS: return kp == 4 ? launch_big<GV_BIAS, 4>(s, a) : launch_big<GV_BIAS, 1>(s, a);
+            case GV_RESID: return kp == 4 ? launch_big<GV_RESID, 4>(s, a) : launch_big<GV_RESID, 1>(s, a);
+        }
+    }
     switch (mode) {
-        case GV_PARTIAL: return kp == 4 ? launch_n<GV_PARTIAL, 4>(s, a) : kp == 2 ? launch_n<GV_PARTIAL, 2>(s, a) : launch_n<GV_PARTIAL, 1>(s, a);
-        case GV_SWIGLU: return kp == 4 ? launch_n<GV_SWIGLU, 4>(s, a) : kp == 2 ? launch_n<GV_SWIGLU, 2>(s, a) : launch_n<GV_SWIGLU, 1>(s, a);
-        case GV_F32: return launch_n<GV_F32, 1>(s, a);
-        case GV_BIAS: return kp == 4 ? launch_n<GV_BIAS, 4>(s, a) : kp == 2 ? launch_n<GV_BIAS, 2>(s, a) : launch_n<GV_BIAS, 1>(s, a);
-        case GV_RESID: return kp == 4 ? launch_n<GV_RESID, 4>(s, a) : kp == 2 ? launch_n<GV_RESID, 2>(s, a) : launch_n<GV_RESID, 1>(s, a);
+        case GV_PARTIAL: return kp == 4 ? launch_small<GV_PARTIAL, 4>(s, a) : kp == 2 ? launch_small<GV_PARTIAL, 2>(s, a) : launch_small<GV_PARTIAL, 1>(s, a);
+        case GV_SWIGLU: return kp == 4 ? launch_small<GV_SWIGLU, 4>(s, a) : kp == 2 ? launch_small<GV_SWIGLU, 2>(s, a) : launch_small<GV_SWIGLU, 1>(s, a);
+        case GV_F32: return launch_small<GV_F32, 1>(s, a);
+        case GV_BIAS: return kp == 4 ? launch_small<GV_BIAS, 4>(s, a) : kp == 2 ? launch_small<GV_BIAS, 2>(s, a) : launch_small<GV_BIAS, 1>(s, a);
+        case GV_RESID: return kp == 4 ? launch_small<GV_RESID, 4>(s, a) : kp == 2 ? launch_small<GV_RESID, 2>(s, a) : launch_small<GV_RESID, 1>(s, a);
     }
     return -22;
 }

@@ -183,7 +183,7 @@ def test_tiled_weight_layout_matches_row_major(L):
     assert torch.equal(p1, p2)
 
 
-@pytest.mark.parametrize("M", [1, 3, 4])
+@pytest.mark.parametrize("M", [1, 3, 4, 5, 16, 17, 32])
 def test_gemv_fused_prologue_and_epilogues(L, M):
     """decode GEMV with the RMSNorm(+pending residual) prologue, bias / residual epilogues and the fused argmax."""
     from oracle import model_ref as MR
@@ -214,7 +214,7 @@ def test_gemv_fused_prologue_and_epilogues(L, M):
     V = 151936
     wv = rnd((V, K), 57, 0.03)
     wv[100] = wv[140000]                      # identical rows -> identical logits -> lowest index must win if it is the max
-    nb = L.sr_op_gemv_f32_blocks(V)
+    nb = L.sr_op_gemv_f32_blocks(V, M, K)
     lg = torch.zeros(M, V, dtype=torch.float32, device="cuda")
     av = torch.zeros(M, nb, dtype=torch.float32, device="cuda")
     ai = torch.zeros(M, nb, dtype=torch.int32, device="cuda")
@@ -430,3 +430,50 @@ def test_truedim_single_block_and_layer():
         d = (trace[1, 0].cpu() - ref_step).abs()
         assert float(d.max()) <= 0.02, ("decode step logits", float(d.max()))
         e.close()
+
+
+# ------------------------------------------------------------------------------------------------ full size (3B), properties
+def test_full_size_3b_properties():
+    """BASELINE.json's full geometry (SocioReasoner-3B, 448x448 tile, 448-token prompt): size-independent properties.
+    (The CPU oracle needs minutes for 36+32 layers; layer-level parity at these dimensions is test_truedim_*.)
+      * decode through the captured hipGraph == eager launches, bit for bit, and run-to-run deterministic;
+      * batch invariance: the same tile in two slots of a batch (next to a different tile) decodes to the same tokens;
+      * KV-cache consistency: the logits of decode step k equal (within the bf16 noise floor) the prefill logits of
+        the prompt extended by the k forced tokens -- two different kernel paths (GEMV + decode attention vs GEMM +
+        prefill attention) computing the same function."""
+    from socioreasoner_amd import hostops, synthetic
+    from socioreasoner_amd.config import geometry_3b
+    from socioreasoner_amd.engine import Engine
+    geom = geometry_3b()
+    e = Engine(geom, max_patches=3072, max_prefill_tokens=1536, max_batch=3, max_ctx=640, max_new_tokens=16)
+    e.load_synthetic_weights(seed=0)
+    grid = (1, 32, 32)
+
+    def prep(i, extra=()):
+        ids = np.concatenate([synthetic.tile_prompt(geom, i, grid), np.asarray(extra, dtype=np.int64)])
+        p, _ = hostops.get_rope_index(torch.from_numpy(ids)[None], [grid], None)
+        return ids, p[:, 0].numpy()
+    pix = [e.patchify(torch.from_numpy(synthetic.tile_pixels(i)).cuda()) for i in (0, 1)]
+    emb0 = e.vit_forward(pix[0], [grid])
+    emb01 = e.vit_forward(torch.cat([pix[0], pix[1], pix[0]]), [grid] * 3)
+    assert torch.equal(emb01[:256], emb0) and torch.equal(emb01[512:], emb0)      # ViT batch invariance, bit exact
+    ids0, pos0 = prep(0)
+    ids1, pos1 = prep(1)
+    e.prefill([ids0], [pos0], emb0)
+    eager, trace = e.decode(16, trace=True, use_graph=False)
+    e.prefill([ids0], [pos0], emb0)
+    graph = e.decode(16, use_graph=True)
+    e.prefill([ids0], [pos0], emb0)
+    graph2 = e.decode(16, use_graph=True)
+    assert torch.equal(eager, graph) and torch.equal(graph, graph2)
+    e.prefill([ids0, ids1, ids0], [pos0, pos1, pos0], emb01)
+    bt = e.decode(16, use_graph=True)
+    assert torch.equal(bt[0], eager[0]) and torch.equal(bt[2], eager[0]) and not torch.equal(bt[1], eager[0])
+    toks = eager[0].tolist()
+    for k in (1, 5):
+        idk, posk = prep(0, toks[:k])
+        lg = e.prefill([idk], [posk], emb0, return_logits=True)
+        d = (lg[0] - trace[k, 0]).abs()
+        scale = float(trace[k, 0].abs().max())
+        assert float(d.max()) <= 0.03 * max(scale, 1.0), (k, float(d.max()), scale)
+    e.close()
