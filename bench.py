@@ -155,7 +155,7 @@ def main():
         nb = lib.sr_op_gemv_f32_blocks(t_.vocab_size, B, H)
         av = torch.empty(B, nb, dtype=torch.float32, device=dev)
         ai = torch.empty(B, nb, dtype=torch.int32, device=dev)
-        fused = True            # same launch configuration as the engine's decode layer (engine.hip enqueue_decode_forward)
+        fused = B <= 4          # same launch configuration as the engine's decode layer (engine.hip enqueue_decode_forward)
         TL = 0x100              # weights are fragment-ordered in the engine; the timing does not depend on the values
         eps = C.c_float(1e-6)
 

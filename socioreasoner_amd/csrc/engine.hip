@@ -417,12 +417,10 @@ GemvArgs gv(const bf16_t* x, int ldx, const bf16_t* W, int M, int N, int K, void
     return a;
 }
 
-// RMSNorms (and the pending residual add) live in the prologue of the consuming GEMV when the B rows of the residual
-// stream fit in LDS (always for the 3B geometry: 32 x 2056 x 2 B = 132 KB); otherwise they are separate launches
-bool fused_norms(const sr_engine* e, int B) {
-    const int H = e->c.t_hidden;
-    return H % 512 == 0 && (size_t)B * (H + 8) * 2 + 2048 <= 150 * 1024;
-}
+// RMSNorms (and the pending residual add) live in the prologue of the consuming GEMV for batches <= 4 (a few KB per
+// block); for larger batches every block would have to ingest B rows (+ float32 slabs) before it can start, which was
+// measured slower than two small RMSNorm launches spread over the chip
+bool fused_norms(const sr_engine* e, int B) { return B <= 4 && e->c.t_hidden % 512 == 0; }
 
 // LM head on B rows of `x` (+ optional pending slabs): float32 logits + per-block argmax partials.
 // Small batches fuse the final RMSNorm (and the pending residual) into the GEMV prologue.
@@ -444,8 +442,8 @@ int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending,
 }
 
 // one decode forward pass for rows 0..B-1 (device state decides tokens / positions / context lengths).
-// 6 launches per layer (qkv, attention scores, attention softmax+PV, o_proj, gate/up, down): norms and residual adds
-// live in GEMV prologues / epilogues.  Batches above 4 use 16-wave blocks that stage x once per block in LDS.
+// 6 launches per layer at batch <= 4 (qkv, attention scores, attention softmax+PV, o_proj, gate/up, down): norms and
+// residual adds live in GEMV prologues / epilogues; larger batches add the two RMSNorm launches.
 int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
     const sr_config& c = e->c;
     const int H = c.t_hidden, QD = c.t_heads * 128;

@@ -30,10 +30,9 @@ __device__ __forceinline__ u32x4 ldg_nt(const bf16_t* p) {
 }
 __device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-// WAVES = 4 : small batches (M <= 4) and the launches whose x cannot be staged -- many small blocks.
-// WAVES = 16: batches 5..32 with x staged ONCE per block in LDS and shared by TPB = 16/KP weight tiles: at M = 32
-//             every weight tile otherwise re-reads as many x bytes as weight bytes through the CU's load path.
-// STAGE     : x (optionally + pending residual slabs, optionally RMS-normalised) is prepared in LDS by the prologue.
+// WAVES = 4 : the dispatched configuration -- many small blocks, K split over the 4 waves.
+// STAGE     : x (optionally + pending residual slabs, optionally RMS-normalised) is prepared in LDS by the prologue
+//             (used for batches <= 4, where the prologue is a few KB per block).
 template <int MODE, int MT, int KP, bool STAGE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;     // 16-row W tiles per wave
@@ -341,10 +340,10 @@ int launch_k(hipStream_t s, const GemvArgs& a) {
 
 // x can be staged in LDS when a whole padded copy fits and the prologue's row segmentation works
 bool can_stage(const GemvArgs& a) { return a.K % 512 == 0 && stage_bytes(a) + 1024 <= 150 * 1024; }
-// big-block configuration: batches above 4 whose x is staged (shared by the block's tiles)
-bool use_big(const GemvArgs& a, int mode) {
-    return a.M > 4 && can_stage(a) && (mode == GV_BIAS || mode == GV_SWIGLU || mode == GV_F32 || mode == GV_RESID);
-}
+// 16-wave blocks that stage x once for 4 weight tiles were measured SLOWER at M = 32 (qkv 30 vs 11 us, gate/up 34 vs
+// 29 us): a CU ingests only ~50-100 GB/s, so a serial 128-640 KB prologue per block costs more than the x re-reads it
+// saves, and only 172 of 256 CUs get a block.  Kept as a template parameter for experiments; not dispatched.
+bool use_big(const GemvArgs&, int) { return false; }
 
 template <int MODE, int KP>
 int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
@@ -354,11 +353,6 @@ int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
     }
     return a.M <= 16 ? launch_k<MODE, 1, KP, false, 4>(s, a) : launch_k<MODE, 2, KP, false, 4>(s, a);
 }
-template <int MODE, int KP>
-int launch_big(hipStream_t s, const GemvArgs& a) {        // 16-wave blocks, x staged
-    return a.M <= 16 ? launch_k<MODE, 1, KP, true, 16>(s, a) : launch_k<MODE, 2, KP, true, 16>(s, a);
-}
-
 }  // namespace
 
 int gemv_f32_blocks(int N, int M, int K) {
@@ -387,14 +381,6 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     static const char* kp_env = getenv("SR_GEMV_KP");          // tuning hook for tools/bench_gemv.py
     if (kp_env && mode != GV_F32) want = atoi(kp_env);
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
-    if (use_big(a, mode)) {
-        switch (mode) {
-            case GV_SWIGLU: return kp == 4 ? launch_big<GV_SWIGLU, 4>(s, a) : launch_big<GV_SWIGLU, 1>(s, a);
-            case GV_F32: return launch_big<GV_F32, 1>(s, a);
-            case GV_BIAS: return kp == 4 ? launch_big<GV_BIAS, 4>(s, a) : launch_big<GV_BIAS, 1>(s, a);
-            case GV_RESID: return kp == 4 ? launch_big<GV_RESID, 4>(s, a) : launch_big<GV_RESID, 1>(s, a);
-        }
-    }
     switch (mode) {
         case GV_PARTIAL: return kp == 4 ? launch_small<GV_PARTIAL, 4>(s, a) : kp == 2 ? launch_small<GV_PARTIAL, 2>(s, a) : launch_small<GV_PARTIAL, 1>(s, a);
         case GV_SWIGLU: return kp == 4 ? launch_small<GV_SWIGLU, 4>(s, a) : kp == 2 ? launch_small<GV_SWIGLU, 2>(s, a) : launch_small<GV_SWIGLU, 1>(s, a);

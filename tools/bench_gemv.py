@@ -13,7 +13,7 @@ nw = torch.ones(H, device="cuda").to(torch.bfloat16)
 bias = torch.zeros(QN, device="cuda").to(torch.bfloat16)
 slabs = torch.zeros(2, B, H, device="cuda")
 xo = torch.zeros(B, H, dtype=torch.bfloat16, device="cuda")
-fused = True
+fused = B <= 4
 def mk(n, k): return (torch.randn(R, n, k, device="cuda") * 0.02).to(torch.bfloat16)
 cases = [
   ("qkv  bias" + ("+norm+slabs" if fused else ""), mk(QN, H), lambda w, o: L.sr_op_gemv_fused(P(x), I, P(w), B, QN, H, P(o), QN, 3 | 0x100, P(bias), P(nw) if fused else None, C.c_float(1e-6), P(slabs) if fused else None, 2 if fused else 0, P(xo) if fused else None, None, None, s), torch.zeros(B, QN, dtype=torch.bfloat16, device="cuda"), QN * H * 2),
