@@ -131,9 +131,9 @@ class SocioSegInferPipeline(BasePipeline):
     # ------------------------------------------------------------------ synthetic batch (no dataset / tokenizer offline)
     def _synthetic_sample(self, i: int) -> Dict:
         grid = (1, 32, 32)
-        one = synthetic.tile_prompt(self.geom, i, grid)
+        ids = synthetic.tile_prompt(self.geom, i, grid, n_images=2)      # (map, satellite) like the reference
         return {"id": f"synthetic_{i:06d}", "tile": synthetic.tile_pixels(i), "map": synthetic.tile_pixels(10_000 + i),
-                "ids": one, "masks": synthetic.tile_masks(i)}
+                "ids": ids, "masks": synthetic.tile_masks(i)}
 
     def _generate(self, samples: List[Dict], images_key: str) -> torch.Tensor:
         P = int(self.pipeline_config.prompt_length)
@@ -163,7 +163,7 @@ class SocioSegInferPipeline(BasePipeline):
         for b0 in range(lo, hi, bs):
             samples = [self._synthetic_sample(i) for i in range(b0, min(b0 + bs, hi))]
             for s in samples:
-                s["images1"] = [s["tile"]]
+                s["images1"] = [s["map"], s["tile"]]
             resp1 = self._generate(samples, "images1")                       # STAGE 1
             text1 = self.tokenizer.batch_decode(resp1, skip_special_tokens=False)
             for s, r, txt in zip(samples, resp1, text1):
@@ -173,7 +173,7 @@ class SocioSegInferPipeline(BasePipeline):
                     raster.mask_union_(acc, torch.from_numpy(m).cuda())
                 s["mask1"] = raster.resize_nearest(acc, 768, 768)
                 boxes = parse_points_text_from_content(txt) or "[]"
-                s["render"] = render_image(boxes, [s["tile"]], s["mask1"].cpu().numpy())
+                s["render"] = render_image(boxes, [s["map"], s["tile"]], s["mask1"].cpu().numpy())
                 open(os.path.join(res_dir, "stage1", s["id"] + ".txt"), "w").write(txt)
             resp2 = self._generate(samples, "render")                        # STAGE 2 (re-encodes the rendered tile)
             text2 = self.tokenizer.batch_decode(resp2, skip_special_tokens=False)
@@ -189,6 +189,7 @@ class SocioSegInferPipeline(BasePipeline):
                     from PIL import Image
                     Image.fromarray(pred.cpu().numpy() * 255).save(os.path.join(res_dir, "stage2", s["id"] + ".png"))
                     Image.fromarray(s["render"][0]).save(os.path.join(res_dir, "render1", s["id"] + ".png"))
+                    Image.fromarray(s["render"][1]).save(os.path.join(res_dir, "render2", s["id"] + ".png"))
                 except Exception:  # noqa: BLE001
                     pass
         local = torch.tensor(ious, dtype=torch.float64).reshape(-1, 1)

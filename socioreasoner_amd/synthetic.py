@@ -12,13 +12,16 @@ def tile_pixels(i: int, h: int = 448, w: int = 448) -> np.ndarray:
     return np.random.default_rng(1000 + i).integers(0, 256, (h, w, 3), dtype=np.uint8)
 
 
-def tile_prompt(g: ModelGeometry, i: int, grid_thw, n_pre: int = 96, n_post: int = 94) -> np.ndarray:
+def tile_prompt(g: ModelGeometry, i: int, grid_thw, n_pre: int = 96, n_post: int = 94, n_images: int = 1) -> np.ndarray:
+    """n_images = 1: the bench tile (448 tokens).  n_images = 2: the reference-faithful (map, satellite) pair the
+    pipeline feeds in both stages (/root/reference/roll/pipeline/rlvr/rlvr_socioseg_vlm_pipeline_infer.py:61-124)."""
     t, h, w = grid_thw
     T = t * h * w // (g.vision.spatial_merge_size ** 2)
     rng = np.random.default_rng(2000 + i)
     hi = min(g.image_token_id, g.text.vocab_size) - 13    # text ids stay below the special-token block
     pre, post = rng.integers(0, hi, n_pre), rng.integers(0, hi, n_post)
-    return np.concatenate([pre, [g.vision_start_token_id], np.full(T, g.image_token_id), [g.vision_end_token_id], post]).astype(np.int64)
+    img = np.concatenate([[g.vision_start_token_id], np.full(T, g.image_token_id), [g.vision_end_token_id]])
+    return np.concatenate([pre] + [img] * n_images + [post]).astype(np.int64)
 
 
 def tile_masks(i: int, n_obj: int = 4, size: int = 756, gt_size: int = 768):

@@ -432,6 +432,31 @@ def test_truedim_single_block_and_layer():
         e.close()
 
 
+def test_truedim_ragged_windows_756_and_896():
+    """BASELINE.json configs[4] geometry: an 896x896 tile is 756x756 under the reference's default max_pixels (ragged
+    36..64-patch windows, 2916 patches, not a multiple of 64) and 896x896 when max_pixels is honoured (4096 patches).
+    One ViT block (window, then full attention) + merger at the true dimensions against the oracle."""
+    from oracle import host_ref as H
+    from oracle import model_ref as MR
+    from oracle import weights as WG
+    from socioreasoner_amd import hostops, synthetic
+    from socioreasoner_amd.engine import Engine
+    assert hostops.smart_resize(896, 896) == (756, 756) and hostops.smart_resize(896, 896, max_pixels=1344 * 1344) == (896, 896)
+    for side, full in ((756, False), (756, True), (896, False)):
+        geom, cfg = _truedim(full)
+        W = WG.LazyWeights(cfg, seed=0)
+        e = Engine(geom, max_patches=4096, max_prefill_tokens=64, max_batch=1, max_ctx=64, max_new_tokens=4)
+        e.load_synthetic_weights(seed=0)
+        img = synthetic.tile_pixels(7, side, side)
+        pv, grid = H.patchify(img)
+        assert grid == (1, side // 14, side // 14)
+        ref = MR.vit_forward(W, cfg, torch.from_numpy(pv), [grid])
+        got = e.vit_forward(e.patchify(torch.from_numpy(img).cuda()), [grid])
+        mu, frac, mad = bf16_compare(got.float().cpu(), ref)
+        assert mad <= 2 * float(ref.abs().max()) * 2 ** -8, (side, full, mu, frac, mad)
+        e.close()
+
+
 # ------------------------------------------------------------------------------------------------ full size (3B), properties
 def test_full_size_3b_properties():
     """BASELINE.json's full geometry (SocioReasoner-3B, 448x448 tile, 448-token prompt): size-independent properties.

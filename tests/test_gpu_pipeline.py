@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _cfg(tmp, resp=8, prompt=600):
+def _cfg(tmp, resp=8, prompt=800):
     from roll.pipeline.rlvr.rlvr_config import SocioSegConfig
     return SocioSegConfig.from_dict({
         "output_dir": str(tmp), "prompt_length": prompt, "response_length": resp, "rollout_batch_size": 5, "pretrain": "synthetic:tiny",
@@ -28,7 +28,7 @@ def test_strategy_generate_contract(tmp_path):
     st = create_strategy(_Worker(cfg.actor_infer, cfg, 0, 1, 0))
     st.initialize(None)
     g = st.geom
-    P, pad = 600, g.pad_token_id
+    P, pad = 800, g.pad_token_id
     prompts, payload = [], np.empty(5, dtype=object)
     for i in range(5):
         if i == 3:   # text-only row, short
