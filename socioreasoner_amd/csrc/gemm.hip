@@ -61,11 +61,20 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
     const bf16_t* wsrc[W_G];
 #pragma unroll
     for (int i = 0; i < A_G; ++i) asrc[i] = p.A + (size_t)min(m0 + (wave * A_G + i) * 8 + lr, p.M - 1) * p.lda + lc;
-    const int w_kt_stride = p.w_tiled ? 1024 : BK;      // elements between consecutive 64-wide k tiles of one row
+    // W source.  Row-major: like A (XOR swizzle on the source side).  Fragment-ordered (tiled16x64, common.h): every
+    // (16-row tile, 64-k chunk) block is 2 KB contiguous, so one wave instruction copies 1 KB *contiguous* global memory
+    // (one kstep half of a tile) linearly into LDS and the LDS image simply keeps the fragment order.
+    const size_t w_kt_stride = p.w_tiled ? 1024 : BK;   // elements between consecutive 64-wide k tiles
 #pragma unroll
     for (int i = 0; i < W_G; ++i) {
-        const size_t r = min(n0 + (wave * W_G + i) * 8 + lr, p.N - 1);
-        wsrc[i] = p.W + (p.w_tiled ? tiled_offset(r, lc, p.K) : r * p.K + lc);
+        if (p.w_tiled) {
+            const int q = wave * W_G + i;                // 0..15: (n_tile_local = q >> 1, kstep = q & 1)
+            const size_t nt = min(n0 / 16 + (q >> 1), p.N / 16 - 1);
+            wsrc[i] = p.W + nt * (size_t)(p.K / 64) * 1024 + (q & 1) * 512 + lane * 8;
+        } else {
+            const size_t r = min(n0 + (wave * W_G + i) * 8 + lr, p.N - 1);
+            wsrc[i] = p.W + r * p.K + lc;
+        }
     }
     auto stage = [&](int buf, int kt) {
 #pragma unroll
@@ -100,8 +109,12 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int row = wn * 64 + j * 16 + fr;
-                wf[j] = *reinterpret_cast<const bf16x8*>(wb + swz(row, kk * 4 + fg));
+                if (p.w_tiled) {     // LDS keeps the fragment order: [tile][kstep = fg & 1][lane' = (kk*2 + fg/2)*16 + fr][16 B]
+                    wf[j] = *reinterpret_cast<const bf16x8*>(wb + (wn * 4 + j) * 2048 + (fg & 1) * 1024 + (((kk * 2 + (fg >> 1)) * 16 + fr) << 4));
+                } else {
+                    int row = wn * 64 + j * 16 + fr;
+                    wf[j] = *reinterpret_cast<const bf16x8*>(wb + swz(row, kk * 4 + fg));
+                }
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)

@@ -26,4 +26,14 @@ for name, M, N, K, epi in shapes:
         L.sr_op_gemm(P(a), K, P(w), M, N, K, P(out), ldo, None, P(res), None, epi, s)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    print(f"{name:16s} M={M:6d} N={N:6d} K={K:6d} epi={epi}: {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s")
+    line = f"{name:16s} M={M:6d} N={N:6d} K={K:6d} epi={epi}: {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s"
+    if name.startswith("lm"):      # the engine stores LM weights fragment-ordered: time that source layout too
+        for _ in range(2):
+            L.sr_op_gemm(P(a), K, P(w), M, N, K, P(out), ldo, None, P(res), None, epi | 0x100, s)
+        e0.record()
+        for _ in range(reps):
+            L.sr_op_gemm(P(a), K, P(w), M, N, K, P(out), ldo, None, P(res), None, epi | 0x100, s)
+        e1.record(); torch.cuda.synchronize()
+        ms2 = e0.elapsed_time(e1) / reps
+        line += f"   | tiled W: {ms2*1e3:9.1f} us  {2*M*N*K/ms2/1e9:8.1f} TF/s"
+    print(line)
