@@ -58,6 +58,57 @@ __global__ __launch_bounds__(256) void k_rmsnorm(bf16_t* x, const bf16_t* xin, c
     }
 }
 
+// Decode-sized variant (rows <= 64): one block of 256 threads per row, every load issued up front, so the launch is
+// one memory latency deep instead of a wave-serial chain (6.5 -> ~3.5 us at 32 rows).  H <= 2048, H % 8 == 0.
+__global__ __launch_bounds__(256) void k_rmsnorm_row(bf16_t* x, const bf16_t* xin, const float* part, int ksplit,
+                                                     const bf16_t* w, bf16_t* out, int rows, int H, float eps) {
+    __shared__ float wsum[4];
+    const int row = blockIdx.x, c = threadIdx.x, nch = H / 8;
+    const bool on = c < nch;
+    uint4 u = uint4{0, 0, 0, 0}, wu = uint4{0, 0, 0, 0};
+    float4 p0[4], p1[4];
+    if (on) {
+        u = *reinterpret_cast<const uint4*>(xin + (size_t)row * H + c * 8);
+        wu = *reinterpret_cast<const uint4*>(w + c * 8);
+        if (part) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                if (ks < ksplit) {
+                    const float4* pp = reinterpret_cast<const float4*>(part + ((size_t)ks * rows + row) * H + c * 8);
+                    p0[ks] = pp[0];
+                    p1[ks] = pp[1];
+                }
+        }
+    }
+    float v[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
+    if (on && part) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            if (ks < ksplit) {
+                a[0] += p0[ks].x; a[1] += p0[ks].y; a[2] += p0[ks].z; a[3] += p0[ks].w;
+                a[4] += p1[ks].x; a[5] += p1[ks].y; a[6] += p1[ks].z; a[7] += p1[ks].w;
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + rbf(a[e]));
+        *reinterpret_cast<uint4*>(x + (size_t)row * H + c * 8) = uint4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float rs = 1.0f / sqrtf((wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)H + eps);
+    if (on) {
+        const float wv[8] = {lo16(wu.x), hi16(wu.x), lo16(wu.y), hi16(wu.y), lo16(wu.z), hi16(wu.z), lo16(wu.w), hi16(wu.w)};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = wv[e] * rbf(v[e] * rs);
+        *reinterpret_cast<uint4*>(out + (size_t)row * H + c * 8) = uint4{pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+    }
+}
+
 // ----------------------------------------------------------------------------------------------- ViT 2-D RoPE (hf:160-171)
 // float32 math, one rounding.  cos/sin tables [n_rows][hd/2] (the two halves of HF's emb are identical).
 __global__ __launch_bounds__(256) void k_vit_rope(bf16_t* qkv, int n_rows, int n_heads, int hd, const float* cos_t,
@@ -302,7 +353,8 @@ int launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* out,
     if (rows <= 0) return 0;
     if (H % 8 != 0 || H > 64 * 8 * 12) return -22;
     dim3 g(cdiv(rows, 4)), b(256);
-    if (H <= 2048) hipLaunchKernelGGL((k_rmsnorm<4>), g, b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps);
+    if (rows <= 64 && H <= 2048) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps);
+    else if (H <= 2048) hipLaunchKernelGGL((k_rmsnorm<4>), g, b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps);
     else hipLaunchKernelGGL((k_rmsnorm<12>), g, b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps);
     SR_CHECK_LAUNCH();
     return 0;
@@ -311,7 +363,8 @@ int launch_resid_rmsnorm(hipStream_t s, bf16_t* x, const float* part, int ksplit
                          int H, float eps) {
     if (rows <= 0) return 0;
     if (H % 8 != 0 || H > 2048) return -22;
-    hipLaunchKernelGGL((k_rmsnorm<4>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, (const bf16_t*)x, part, ksplit, w, out, rows, H, eps);
+    if (rows <= 64 && ksplit <= 4) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), dim3(256), 0, s, x, (const bf16_t*)x, part, ksplit, w, out, rows, H, eps);
+    else hipLaunchKernelGGL((k_rmsnorm<4>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, (const bf16_t*)x, part, ksplit, w, out, rows, H, eps);
     SR_CHECK_LAUNCH();
     return 0;
 }
