@@ -309,6 +309,154 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- batches 17..32
+// 32x32x16 MFMA variant: a wave owns a 32-row weight tile (two 16-row tiles of the fragment-ordered layout) and all
+// 32 batch rows are ONE B operand, so x is read once per 32 weight rows instead of once per 16 (at M = 32 the x
+// fragments otherwise cost twice the weight bytes on the CU's load path).  D[i = weight row][j = batch row]:
+// lane holds batch row l & 31 and weight rows (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5) -> 4 consecutive outputs per
+// register quad, and with the gate/up interleave rows r and r + 16 (gate / up of one column) sit in the same lane.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int MODE, int KP>
+__global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
+    constexpr int WAVES = 4, TPB = WAVES / KP, U = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, half = (lane >> 4) & 1, kg = lane >> 5, m = lane & 31;
+    const int tp = wave / KP, kp = wave % KP;
+    const int tile = blockIdx.x * TPB + tp;
+    const bool active = tile < ntiles32;
+    const int nchunks = p.K / 64;
+    const int ks = (MODE == GV_PARTIAL) ? p.ksplit : 1;
+    const int per = (nchunks + ks * KP - 1) / (ks * KP);
+    const int c0 = min(((MODE == GV_PARTIAL ? blockIdx.y : 0) * KP + kp) * per, nchunks);
+    const int cend = min(c0 + per, nchunks);
+    const int t16 = (active ? tile : 0) * 2 + half;             // 16-row tile index of this lane's weight row
+    const bf16_t* wbase = p.w_tiled ? p.W + (size_t)t16 * nchunks * 1024 + kg * 512 + fr * 8
+                                    : p.W + (size_t)(t16 * 16 + fr) * p.K + kg * 8;
+    const size_t w_c = p.w_tiled ? 1024 : 64, w_s = p.w_tiled ? 128 : 16;   // element strides per chunk / per k16 step
+    const bool xok = m < p.M;
+    const bf16_t* xbase = p.x + (size_t)(xok ? m : 0) * p.ldx + kg * 8;
+
+    u32x4 w[U][4], xv[U][4];
+    auto fill = [&](int u, int c) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) w[u][st] = ldg_nt(wbase + (size_t)c * w_c + st * w_s);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            xv[u][st] = xok ? *reinterpret_cast<const u32x4*>(xbase + (size_t)c * 64 + st * 16) : u32x4{0, 0, 0, 0};
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c0 + u < cend) fill(u, c0 + u);
+        for (int c = c0; c < cend; c += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (c + u < cend) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(w[u][st]), as_frag(xv[u][st]), acc, 0, 0, 0);
+                    if (c + U + u < cend) fill(u, c + U + u);
+                }
+            }
+        }
+    }
+    if constexpr (KP > 1) {
+        f32x16* rbuf = reinterpret_cast<f32x16*>(smem);          // [TPB][KP-1][64]
+        if (kp > 0) rbuf[(tp * (KP - 1) + (kp - 1)) * 64 + lane] = acc;
+        __syncthreads();
+        if (kp == 0) {
+#pragma unroll
+            for (int k = 1; k < KP; ++k) {
+                const f32x16 o = rbuf[(tp * (KP - 1) + (k - 1)) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += o[i];
+            }
+        }
+    }
+    float bestv = -INFINITY;
+    int besti = 0x7fffffff;
+    if (active && kp == 0 && xok) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int nl = 8 * g4 + 4 * kg;                      // first of this quad's 4 consecutive weight rows
+            if constexpr (MODE == GV_SWIGLU) {
+                if (g4 < 2) {
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float g = rbf(acc[g4 * 4 + r]), u = rbf(acc[(g4 + 2) * 4 + r]);
+                        o[r] = rbf(silu_f(g)) * u;
+                    }
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * (p.N / 2) + tile * 16 + nl) =
+                        uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                }
+            } else if constexpr (MODE == GV_BIAS || MODE == GV_RESID) {
+                const int n = tile * 32 + nl;
+                bf16_t* optr = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n;
+                float o[4] = {acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
+                if (MODE == GV_BIAS && p.bias) {
+                    const uint2 b = *reinterpret_cast<const uint2*>(p.bias + n);
+                    o[0] += lo16(b.x); o[1] += hi16(b.x); o[2] += lo16(b.y); o[3] += hi16(b.y);
+                }
+                if constexpr (MODE == GV_RESID) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(optr);
+                    o[0] = lo16(rv.x) + rbf(o[0]); o[1] = hi16(rv.x) + rbf(o[1]);
+                    o[2] = lo16(rv.y) + rbf(o[2]); o[3] = hi16(rv.y) + rbf(o[3]);
+                }
+                *reinterpret_cast<uint2*>(optr) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+            } else {
+                const int n = tile * 32 + nl;
+                float* o = reinterpret_cast<float*>(p.out) + ((size_t)(MODE == GV_PARTIAL ? blockIdx.y : 0) * p.M + m) * p.N + n;
+                *reinterpret_cast<float4*>(o) = float4{acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
+                if constexpr (MODE == GV_F32) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (acc[g4 * 4 + r] > bestv || (acc[g4 * 4 + r] == bestv && n + r < besti)) { bestv = acc[g4 * 4 + r]; besti = n + r; }
+                }
+            }
+        }
+    }
+    if constexpr (MODE == GV_F32) {
+        if (p.amax_val) {                                          // KP == 1: smem is free
+            float* av = reinterpret_cast<float*>(smem);            // [WAVES][32]
+            int* ai = reinterpret_cast<int*>(av + WAVES * 32);
+            const float ov = __shfl_xor(bestv, 32, 64);
+            const int oi = __shfl_xor(besti, 32, 64);
+            if (ov > bestv || (ov == bestv && oi < besti)) { bestv = ov; besti = oi; }
+            if (kg == 0) { av[wave * 32 + m] = bestv; ai[wave * 32 + m] = besti; }
+            __syncthreads();
+            if (tid < p.M) {
+                float bv = av[tid];
+                int bi = ai[tid];
+                for (int w2 = 1; w2 < WAVES; ++w2) {
+                    const float v2 = av[w2 * 32 + tid];
+                    const int i2 = ai[w2 * 32 + tid];
+                    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+                }
+                p.amax_val[(size_t)tid * gridDim.x + blockIdx.x] = bv;
+                p.amax_idx[(size_t)tid * gridDim.x + blockIdx.x] = bi;
+            }
+        }
+    }
+}
+
+template <int MODE, int KP>
+int launch_32(hipStream_t s, const GemvArgs& a) {
+    constexpr int TPB = 4 / KP;
+    const int ntiles = a.N / 32;
+    dim3 grid(cdiv(ntiles, TPB), MODE == GV_PARTIAL ? a.ksplit : 1);
+    size_t smem = (size_t)TPB * (KP > 1 ? KP - 1 : 0) * 64 * sizeof(f32x16);
+    if (smem < 4 * 32 * 8) smem = 4 * 32 * 8;
+    hipLaunchKernelGGL((k_gemv32<MODE, KP>), grid, dim3(256), smem, s, a, ntiles);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+
 size_t stage_bytes(const GemvArgs& a) { return ((size_t)a.M * (a.K + 8) * 2 + 15) / 16 * 16; }
 
 template <int MODE, int MT, int KP, bool STAGE, int WAVES>
@@ -355,10 +503,12 @@ int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
 }
 }  // namespace
 
+bool use_32(const GemvArgs& a) { return a.M > 16 && a.N % 32 == 0 && !a.norm_w; }
+
 int gemv_f32_blocks(int N, int M, int K) {
     GemvArgs a{};
     a.M = M; a.K = K; a.N = N;
-    return cdiv(N / 16, use_big(a, GV_F32) ? 16 : 4);
+    return use_32(a) ? cdiv(N / 32, 4) : cdiv(N / 16, 4);
 }
 
 // largest in-block K split that leaves >= 2 chunks per wave
@@ -381,6 +531,15 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     static const char* kp_env = getenv("SR_GEMV_KP");          // tuning hook for tools/bench_gemv.py
     if (kp_env && mode != GV_F32) want = atoi(kp_env);
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
+    if (use_32(a)) {
+        switch (mode) {
+            case GV_PARTIAL: return kp == 4 ? launch_32<GV_PARTIAL, 4>(s, a) : kp == 2 ? launch_32<GV_PARTIAL, 2>(s, a) : launch_32<GV_PARTIAL, 1>(s, a);
+            case GV_SWIGLU: return kp == 4 ? launch_32<GV_SWIGLU, 4>(s, a) : kp == 2 ? launch_32<GV_SWIGLU, 2>(s, a) : launch_32<GV_SWIGLU, 1>(s, a);
+            case GV_F32: return launch_32<GV_F32, 1>(s, a);
+            case GV_BIAS: return kp == 4 ? launch_32<GV_BIAS, 4>(s, a) : kp == 2 ? launch_32<GV_BIAS, 2>(s, a) : launch_32<GV_BIAS, 1>(s, a);
+            case GV_RESID: return kp == 4 ? launch_32<GV_RESID, 4>(s, a) : kp == 2 ? launch_32<GV_RESID, 2>(s, a) : launch_32<GV_RESID, 1>(s, a);
+        }
+    }
     switch (mode) {
         case GV_PARTIAL: return kp == 4 ? launch_small<GV_PARTIAL, 4>(s, a) : kp == 2 ? launch_small<GV_PARTIAL, 2>(s, a) : launch_small<GV_PARTIAL, 1>(s, a);
         case GV_SWIGLU: return kp == 4 ? launch_small<GV_SWIGLU, 4>(s, a) : kp == 2 ? launch_small<GV_SWIGLU, 2>(s, a) : launch_small<GV_SWIGLU, 1>(s, a);
