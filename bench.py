@@ -152,7 +152,7 @@ def main():
         xo = torch.zeros(B, H, dtype=torch.bfloat16, device=dev)
         qkv_o = torch.empty(B, QN, dtype=torch.bfloat16, device=dev)
         xr = torch.zeros(B, H, dtype=torch.bfloat16, device=dev)
-        nb = lib.sr_op_gemv_f32_blocks(t_.vocab_size, B, H)
+        nb = lib.sr_op_gemv_f32_blocks(t_.vocab_size, B, H, 1 if B <= 4 else 0)
         av = torch.empty(B, nb, dtype=torch.float32, device=dev)
         ai = torch.empty(B, nb, dtype=torch.int32, device=dev)
         fused = B <= 4          # same launch configuration as the engine's decode layer (engine.hip enqueue_decode_forward)

@@ -124,11 +124,11 @@ int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void*
 int sr_op_gemv(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ksplit, int mode, void* stream);
 /* decode GEMV with its fusions (mode 3 = bias epilogue, 4 = residual epilogue in place; norm_w != NULL = RMSNorm
  * prologue, optionally after adding n_slabs float32 slabs [n_slabs][M][K]; amax_* = per-block argmax partials of the
- * float32 mode, row length sr_op_gemv_f32_blocks(N, M, K)) */
+ * float32 mode, row length sr_op_gemv_f32_blocks(N, M, K, norm_w != NULL)) */
 int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ldo, int mode, const void* bias,
                      const void* norm_w, float eps, const float* slabs, int n_slabs, void* x_out, float* amax_val,
                      int32_t* amax_idx, void* stream);
-int sr_op_gemv_f32_blocks(int N, int M, int K);
+int sr_op_gemv_f32_blocks(int N, int M, int K, int has_norm);
 /* fused decode attention: qkv rows (bias applied, pre-rope) -> mRoPE -> KV-cache append -> attention; slots = identity.
  * kcache [B][kvh][ctx_max][128], vtcache [B][kvh][128][ctx_max]; ctx_len counts the new token; rope_cos/sin: bf16 [max_pos+1][64] tables; scores_scratch: bf16 [B][heads][ctx_max] */
 int sr_op_attn_decode(const void* qkv, int qkv_stride, const int32_t* pos, const int32_t* ctx_len, const void* rope_cos,

@@ -160,8 +160,8 @@ void carve(sr_engine* e) {
     e->t_inter_pad = rup(c.t_inter, 64);
     e->t_qn = (c.t_heads + 2 * c.t_kv_heads) * 128;
     e->t_group = c.t_heads / c.t_kv_heads;
-    e->ks_down = (e->t_inter_pad / 64 >= 16) ? 2 : 1;
-    e->n_part = gemv_f32_blocks(c.t_vocab, 1, c.t_hidden);      // upper bound (4-wave blocks); per-launch count below
+    e->ks_down = (e->t_inter_pad / 64 >= 16) ? 2 : 1;          // batches above 16 use 4 slabs (32-row GEMV variant)
+    e->n_part = gemv_f32_blocks(c.t_vocab, 1, c.t_hidden, 1);   // upper bound (16-row tiles); per-launch count below
     const int C = c.v_hidden, H = c.t_hidden;
 
     e->weights_begin = (ar.off + 255) & ~(size_t)255;
@@ -244,7 +244,7 @@ void carve(sr_engine* e) {
     e->d_act = ar.take<bf16_t>(B * e->t_inter_pad);
     e->d_scores = ar.take<bf16_t>(B * c.t_heads * (size_t)c.max_ctx);
     e->d_logits = ar.take<float>(B * c.t_vocab);
-    e->d_slabs = ar.take<float>(2 * B * H);
+    e->d_slabs = ar.take<float>(4 * B * H);
     e->d_amax_val = ar.take<float>(B * e->n_part);
     e->d_amax_idx = ar.take<int>(B * e->n_part);
     e->d_cur_tok = ar.take<int>(32);
@@ -421,6 +421,7 @@ GemvArgs gv(const bf16_t* x, int ldx, const bf16_t* W, int M, int N, int K, void
 // block); for larger batches every block would have to ingest B rows (+ float32 slabs) before it can start, which was
 // measured slower than two small RMSNorm launches spread over the chip
 bool fused_norms(const sr_engine* e, int B) { return B <= 4 && e->c.t_hidden % 512 == 0; }
+int ks_down(const sr_engine* e, int B) { return (B > 16 && e->t_inter_pad / 64 >= 32) ? 4 : e->ks_down; }
 
 // LM head on B rows of `x` (+ optional pending slabs): float32 logits + per-block argmax partials.
 // Small batches fuse the final RMSNorm (and the pending residual) into the GEMV prologue.
@@ -431,9 +432,9 @@ int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending,
     g.amax_val = e->d_amax_val; g.amax_idx = e->d_amax_idx;
     if (fused_norms(e, B)) {
         g.norm_w = e->final_norm; g.eps = c.t_rms_eps;
-        if (pending) { g.slabs = e->d_slabs; g.n_slabs = e->ks_down; g.x_out = x_alt; }
+        if (pending) { g.slabs = e->d_slabs; g.n_slabs = ks_down(e, B); g.x_out = x_alt; }
     } else {
-        if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, e->ks_down, e->final_norm, e->d_xn, B, H, c.t_rms_eps));
+        if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, ks_down(e, B), e->final_norm, e->d_xn, B, H, c.t_rms_eps));
         else SR_TRY(launch_rmsnorm(s, x, e->final_norm, e->d_xn, B, H, c.t_rms_eps));
         g.x = e->d_xn;
     }
@@ -459,9 +460,9 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         gq.bias = w.qkv_b;
         if (fused) {
             gq.norm_w = w.ln1; gq.eps = c.t_rms_eps;
-            if (pending) { gq.slabs = e->d_slabs; gq.n_slabs = e->ks_down; gq.x_out = x_alt; }
+            if (pending) { gq.slabs = e->d_slabs; gq.n_slabs = ks_down(e, B); gq.x_out = x_alt; }
         } else {
-            if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, e->ks_down, w.ln1, e->d_xn, B, H, c.t_rms_eps));
+            if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, ks_down(e, B), w.ln1, e->d_xn, B, H, c.t_rms_eps));
             else SR_TRY(launch_rmsnorm(s, x, w.ln1, e->d_xn, B, H, c.t_rms_eps));
             gq.x = e->d_xn;
         }
@@ -478,7 +479,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         else { SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps)); gg.x = e->d_xn; }
         SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
         GemvArgs gd = gv(e->d_act, e->t_inter_pad, w.down_w, B, H, e->t_inter_pad, e->d_slabs, H);
-        gd.ksplit = e->ks_down;
+        gd.ksplit = ks_down(e, B);
         SR_TRY(launch_gemv(s, gd, GV_PARTIAL));
         pending = true;
     }
@@ -486,7 +487,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
 }
 
 int enqueue_step(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, hipStream_t s) {
-    StepArgs a{e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(e->c.t_vocab, B, e->c.t_hidden), e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished,
+    StepArgs a{e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(e->c.t_vocab, B, e->c.t_hidden, fused_norms(e, B) ? 1 : 0), e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished,
                e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden, 1};
     SR_TRY(launch_step(s, a));
     return 0;
@@ -910,7 +911,7 @@ int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K,
     a.w_tiled = (mode & 0x100) ? 1 : 0;
     SR_WRAP(launch_gemv((hipStream_t)stream, a, mode & 0xff));
 }
-int sr_op_gemv_f32_blocks(int N, int M, int K) { return gemv_f32_blocks(N, M, K); }
+int sr_op_gemv_f32_blocks(int N, int M, int K, int has_norm) { return gemv_f32_blocks(N, M, K, has_norm); }
 int sr_op_attn_decode(const void* qkv, int qkv_stride, const int32_t* pos, const int32_t* ctx_len, const void* rope_cos,
                       const void* rope_sin, void* kcache, void* vtcache, void* out, int out_stride, int B, int n_q_heads, int n_kv_heads, int ctx_max,
                       float scale, void* scores_scratch, void* stream) {

@@ -503,12 +503,20 @@ int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
 }
 }  // namespace
 
-bool use_32(const GemvArgs& a) { return a.M > 16 && a.N % 32 == 0 && !a.norm_w; }
+// measured at M = 32 (us, 16-row / 32-row variant): LM head 187 / 140, down-projection with 4 slabs 17.4 / 13.4;
+// qkv 9.6 / 11.5, o_proj 9.2 / 9.9, gate/up 22.9 / 25.4 (the 32-row tiles halve the wave count of the small launches)
+bool use_32(const GemvArgs& a, int mode) {
+    static const char* env = getenv("SR_GEMV32");               // tuning hook (tools/bench_gemv.py): 0 = never, 2 = always
+    const int force = env ? atoi(env) : 1;
+    if (force == 0 || a.M <= 16 || a.N % 32 != 0 || a.norm_w) return false;
+    return force == 2 || mode == GV_F32 || (mode == GV_PARTIAL && a.ksplit >= 4);
+}
 
-int gemv_f32_blocks(int N, int M, int K) {
+int gemv_f32_blocks(int N, int M, int K, int has_norm) {
     GemvArgs a{};
     a.M = M; a.K = K; a.N = N;
-    return use_32(a) ? cdiv(N / 32, 4) : cdiv(N / 16, 4);
+    a.norm_w = has_norm ? reinterpret_cast<const bf16_t*>(&a) : nullptr;     // only its null-ness matters here
+    return use_32(a, GV_F32) ? cdiv(N / 32, 4) : cdiv(N / 16, 4);
 }
 
 // largest in-block K split that leaves >= 2 chunks per wave
@@ -531,7 +539,7 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     static const char* kp_env = getenv("SR_GEMV_KP");          // tuning hook for tools/bench_gemv.py
     if (kp_env && mode != GV_F32) want = atoi(kp_env);
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
-    if (use_32(a)) {
+    if (use_32(a, mode)) {
         switch (mode) {
             case GV_PARTIAL: return kp == 4 ? launch_32<GV_PARTIAL, 4>(s, a) : kp == 2 ? launch_32<GV_PARTIAL, 2>(s, a) : launch_32<GV_PARTIAL, 1>(s, a);
             case GV_SWIGLU: return kp == 4 ? launch_32<GV_SWIGLU, 4>(s, a) : kp == 2 ? launch_32<GV_SWIGLU, 2>(s, a) : launch_32<GV_SWIGLU, 1>(s, a);

@@ -35,7 +35,7 @@ struct GemvArgs {
     int w_tiled;                            // W stored fragment-ordered (tiled16x64) instead of row-major
 };
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode);
-int gemv_f32_blocks(int N, int M, int K);    // gridDim.x of the F32 launch (length of the amax rows)
+int gemv_f32_blocks(int N, int M, int K, int has_norm);    // gridDim.x of the F32 launch (length of the amax rows)
 
 // ------------------------------------------------------------------ attention.hip
 // one 64-query tile of one sequence.  K element (kvh, key j, d) = k[(k_row0 + j)*k_stride + kvh*k_head_stride + d];

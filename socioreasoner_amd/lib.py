@@ -52,7 +52,7 @@ SIGNATURES = {
     "sr_op_gemm": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "sr_op_gemv": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "sr_op_gemv_fused": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, C.c_float, _vp, _i, _vp, _vp, _vp, _vp]),
-    "sr_op_gemv_f32_blocks": (C.c_int, [_i, _i, _i]),
+    "sr_op_gemv_f32_blocks": (C.c_int, [_i, _i, _i, _i]),
     "sr_op_attn_decode": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _vp, _vp]),
     "sr_op_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i, _i, C.c_float, _vp]),
     "sr_op_resid_rmsnorm": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, C.c_float, _vp]),

@@ -214,7 +214,7 @@ def test_gemv_fused_prologue_and_epilogues(L, M):
     V = 151936
     wv = rnd((V, K), 57, 0.03)
     wv[100] = wv[140000]                      # identical rows -> identical logits -> lowest index must win if it is the max
-    nb = L.sr_op_gemv_f32_blocks(V, M, K)
+    nb = L.sr_op_gemv_f32_blocks(V, M, K, 1)
     lg = torch.zeros(M, V, dtype=torch.float32, device="cuda")
     av = torch.zeros(M, nb, dtype=torch.float32, device="cuda")
     ai = torch.zeros(M, nb, dtype=torch.int32, device="cuda")

@@ -20,15 +20,20 @@ cases = [
   ("o    resid", mk(H, H), lambda w, o: L.sr_op_gemv_fused(P(x), I, P(w), B, H, H, P(o), H, 4 | 0x100, None, None, C.c_float(0), None, 0, None, None, None, s), torch.zeros(B, H, dtype=torch.bfloat16, device="cuda"), H * H * 2),
   ("gate/up swiglu" + ("+norm" if fused else ""), mk(2 * I, H), lambda w, o: L.sr_op_gemv_fused(P(x), I, P(w), B, 2 * I, H, P(o), I, 1 | 0x100, None, P(nw) if fused else None, C.c_float(1e-6), None, 0, None, None, None, s), torch.zeros(B, I, dtype=torch.bfloat16, device="cuda"), 2 * I * H * 2),
 ]
+nb = L.sr_op_gemv_f32_blocks(V, B, H, 1 if fused else 0)
+av = torch.zeros(B, 2400, device="cuda"); ai = torch.zeros(B, 2400, dtype=torch.int32, device="cuda")
+WV = (torch.randn(2, V, H, device="cuda") * 0.02).to(torch.bfloat16)
+cases.append(("lm_head f32+argmax", WV, lambda w, o: L.sr_op_gemv_fused(P(x), I, P(w), B, V, H, P(o), V, 2 | 0x100, None, P(nw) if fused else None, C.c_float(1e-6), None, 0, None, P(av), P(ai), s), torch.zeros(B, V, device="cuda"), V * H * 2))
 for ks in (2, 4):
     cases.append((f"down partial ks={ks}", mk(H, I), (lambda ks: lambda w, o: L.sr_op_gemv(P(x), I, P(w), B, H, I, P(o), ks, 0 | 0x100, s))(ks), torch.zeros(4, B, H, device="cuda"), H * I * 2))
 for name, W, fn, out, nbytes in cases:
-    for r in range(R): assert fn(W[r], out) == 0
+    RR = W.shape[0]
+    for r in range(RR): assert fn(W[r], out) == 0
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for it in range(5):
-        for r in range(R): fn(W[r], out)
+        for r in range(RR): fn(W[r], out)
     e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (5 * R)
-    print(f"B={B} KP={os.environ.get('SR_GEMV_KP','dflt')} {name:28s}: {us:7.2f} us  {nbytes/us/1e6:6.2f} TB/s")
+    us = e0.elapsed_time(e1) * 1e3 / (5 * RR)
+    print(f"B={B} G32={os.environ.get('SR_GEMV32','1')} KP={os.environ.get('SR_GEMV_KP','dflt')} {name:28s}: {us:7.2f} us  {nbytes/us/1e6:6.2f} TB/s")
