@@ -91,3 +91,48 @@ def test_pipeline_runs_two_stages_in_synthetic_mode(tmp_path, monkeypatch):
     assert abs(acc - float(np.mean(want))) < 1e-12
     assert compute_giou(np.zeros((8, 8), np.uint8), np.zeros((8, 8), np.uint8)) == 1.0
     pipe.actor_infer.engine.close()
+
+
+def test_checkpoint_loader_safetensors_both_namings(tmp_path):
+    """sr_load_weight through an HF-style *.safetensors directory (reference-era AND transformers-5 parameter names,
+    bf16 and fp32 tensors, lm_head.weight present) gives the same engine as the device-side synthetic generator."""
+    from safetensors.torch import save_file
+    from oracle import weights as WG
+    from oracle import model_ref as MR
+    from socioreasoner_amd import synthetic
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.engine import Engine
+    geom, cfg = geometry_tiny(), MR.config_tiny()
+    W = WG.LazyWeights(cfg, seed=0)
+    shard1, shard2 = {}, {}
+    for i, (name, shape, base) in enumerate(WG.param_specs(cfg)):
+        t = W[name].clone()
+        new = name
+        if i % 2 == 0:      # transformers-5 naming for every other tensor
+            new = name.replace("visual.", "model.visual.", 1) if name.startswith("visual.") else name.replace("model.", "model.language_model.", 1)
+        t = t.to(torch.bfloat16) if i % 3 else t.float()
+        (shard1 if i % 2 else shard2)[new] = t.contiguous()
+    shard2["lm_head.weight"] = W["model.embed_tokens.weight"].to(torch.bfloat16).contiguous()
+    save_file(shard1, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file(shard2, str(tmp_path / "model-00002-of-00002.safetensors"))
+    kw = dict(max_patches=256, max_prefill_tokens=128, max_batch=1, max_ctx=128, max_new_tokens=8)
+    a, b = Engine(geom, **kw), Engine(geom, **kw)
+    a.load_synthetic_weights(seed=0)
+    b.load_safetensors_dir(str(tmp_path))
+    img = torch.from_numpy(synthetic.tile_pixels(3, 112, 84)).cuda()
+    grid = [(1, 8, 6)]
+    ea, eb = a.vit_forward(a.patchify(img), grid), b.vit_forward(b.patchify(img), grid)
+    assert torch.equal(ea, eb)
+    ids = synthetic.tile_prompt(geom, 3, grid[0], n_pre=5, n_post=6)
+    from socioreasoner_amd import hostops
+    pos3, _ = hostops.get_rope_index(torch.from_numpy(ids)[None], grid, None, image_token_id=geom.image_token_id,
+                                     vision_start_token_id=geom.vision_start_token_id)
+    la = a.prefill([ids], [pos3[:, 0].numpy()], ea, return_logits=True)
+    lb = b.prefill([ids], [pos3[:, 0].numpy()], eb, return_logits=True)
+    assert torch.equal(la, lb) and torch.equal(a.decode(8), b.decode(8))
+    # a missing tensor is reported, not silently zero
+    c = Engine(geom, **kw)
+    with pytest.raises(Exception, match="missing"):
+        c.load_state_dict({k: v for k, v in shard1.items()})
+    for e in (a, b, c):
+        e.close()
