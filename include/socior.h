@@ -109,6 +109,13 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
               int32_t pad_id, int32_t* dev_tokens_out, float* dev_logits_trace, const int32_t* dev_forced, int use_graph,
               void* stream, int* steps_done);
 
+/* One decode step with the token choice left to the caller -- the `sr_decode_step` of SURVEY section 8(B); this is what a
+ * sampling caller (temperature / top-k / top-p of vllm_strategy.py:289-309) or the logits-gathering verification
+ * mode of the multi-GPU path drives.  Feeds dev_last_ids[b] (int64, device; NULL = the greedy token of the logits the
+ * engine holds) to sequence b of the last sr_prefill, runs one forward pass and returns (each optional) the float32
+ * logits [B, vocab] and their greedy ids int64 [B].  Asynchronous on `stream`; eos handling is the caller's. */
+int sr_decode_step(sr_engine* e, const int64_t* dev_last_ids, int B, float* dev_logits_out, int64_t* dev_next_ids, void* stream);
+
 /* K19-K22 raster tail -- replaces seg_strategy.py:58-65 (union, cv2.INTER_NEAREST resize),
  * rlvr_socioseg_vlm_pipeline_infer.py:45-58 (IoU counts) and :383-452 (render).  No engine needed. */
 int sr_mask_union(uint8_t* dev_acc, const uint8_t* dev_mask, size_t n, void* stream);
@@ -138,6 +145,8 @@ int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, floa
 int sr_op_resid_rmsnorm(void* x, const float* partials, int ksplit, const void* w, void* out, int rows, int H, float eps,
                         void* stream);
 int sr_op_argmax(const float* logits, int rows, int V, int32_t* out_idx, void* stream);
+/* cache warm-up of a weight region a later launch streams (tile_bytes > 0: XCD-matched, see k_prefetch) */
+int sr_op_prefetch(const void* base, long long bytes, long long tile_bytes, int blocks, void* stream);
 int sr_version(void);
 
 #ifdef __cplusplus

@@ -6,8 +6,10 @@ and of the raster half of ``seg_infer`` (roll/distributed/strategy/seg_strategy.
        batch.non_tensor_batch["multi_modal_data"][i] = {"prompt_token_ids": [...], "multi_modal_data": {"image": [PIL, ...]}}
        generation_config keys of roll/configs/generating_args.py (max_new_tokens, eos_token_id (list), pad_token_id, ...)
   out: LongTensor [B * n, P + max_response_len_in_batch]: the prompt columns verbatim, responses right-padded with pad.
-Delta to the reference default (BASELINE.json configs): decoding is greedy; the
-temperature / top_p / top_k of the shipped YAML are accepted and ignored with a warning.
+Greedy requests (temperature 0 or top_k 1 -- BASELINE.json's configurations) run the whole decode loop on the device
+(sr_decode, one hipGraph replay per token).  Sampling requests (the shipped YAML's temperature / top_p / top_k /
+repetition_penalty, vllm_strategy.py:289-309) run token by token through sr_decode_step with the draw made by
+socioreasoner_amd.sampling on the device-resident logits.
 """
 from __future__ import annotations
 
@@ -20,7 +22,7 @@ import torch
 
 from roll.distributed.scheduler.protocol import DataProto
 from roll.distributed.strategy.strategy import InferenceStrategy
-from socioreasoner_amd import hostops, raster
+from socioreasoner_amd import hostops, raster, sampling
 from socioreasoner_amd.config import ModelGeometry, geometry_3b, geometry_tiny
 from socioreasoner_amd.engine import Engine
 
@@ -138,8 +140,8 @@ class Mi355xStrategy(InferenceStrategy):
         gc = dict(generation_config)
         if gc.get("num_beams", 1) > 1:
             raise NotImplementedError("beam search is not part of the inference hot path")
-        if float(gc.get("temperature", 0) or 0) > 0 and int(gc.get("top_k", 1) or 1) != 1:
-            logger.warning("sampling parameters (temperature/top_p/top_k) are ignored: greedy decode")
+        greedy = sampling.is_greedy(gc) and float(gc.get("repetition_penalty", 1.0) or 1.0) == 1.0
+        n = int(gc.get("num_return_sequences", 1) or 1)
         input_ids = batch.batch["input_ids"]
         attention_mask = batch.batch["attention_mask"]
         mm = batch.non_tensor_batch.get("multi_modal_data") if batch.non_tensor_batch else None
@@ -149,7 +151,7 @@ class Mi355xStrategy(InferenceStrategy):
         pad = int(gc.get("pad_token_id", self.tokenizer.pad_token_id))
         max_new = min(int(gc["max_new_tokens"]), self.engine.cfg.max_new_tokens)
         B = len(prompts)
-        results: List[List[int]] = [None] * B
+        results: List[List[List[int]]] = [None] * B          # per prompt: n responses
         prepared = []
         for i in range(B):
             ids_i = mm[i]["prompt_token_ids"] if mm is not None and mm[i].get("prompt_token_ids") else prompts[i]
@@ -173,15 +175,52 @@ class Mi355xStrategy(InferenceStrategy):
             if ims:
                 pix = torch.cat([self.engine.patchify(im) for im in ims], dim=0)
                 emb = self.engine.vit_forward(pix, grids)
-            self.engine.prefill([prepared[k][0] for k in grp], [prepared[k][1] for k in grp], emb)
-            toks = self.engine.decode(max_new, eos=eos, pad_id=pad).cpu().tolist()
-            for row, k in zip(toks, grp):
-                cut = next((j + 1 for j, t in enumerate(row) if t in eos), len(row))
-                results[k] = row[:cut]
-        n = int(gc.get("num_return_sequences", 1) or 1)
-        results = [r for r in results for _ in range(n)]          # greedy: the n sequences of a prompt are identical
+            for k in grp:
+                results[k] = []
+            for _ in range(1 if greedy else n):
+                logits = self.engine.prefill([prepared[k][0] for k in grp], [prepared[k][1] for k in grp], emb,
+                                             return_logits=not greedy)
+                if greedy:
+                    toks = self.engine.decode(max_new, eos=eos, pad_id=pad).cpu().tolist()
+                else:
+                    toks = self._sample_loop(logits, [prepared[k][0] for k in grp], max_new, eos, pad, gc).cpu().tolist()
+                for row, k in zip(toks, grp):
+                    cut = next((j + 1 for j, t in enumerate(row) if t in eos), len(row))
+                    results[k].append(row[:cut])
+            if greedy:                                           # the n sequences of a prompt are identical
+                for k in grp:
+                    results[k] = results[k] * n
+        results = [r for rs in results for r in rs]
         output_ids = hostops.gather_outputs_to_pad_tensor(results, pad, device=input_ids.device)
         return hostops.concatenate_input_and_output(input_ids, output_ids, n)
+
+    def _sample_loop(self, logits: torch.Tensor, prompt_ids, max_new: int, eos, pad: int, gc: dict) -> torch.Tensor:
+        """Token-by-token decode with the draw on the host side of the C ABI (sr_decode_step).  -> int64 [B, max_new]"""
+        B, V = logits.shape
+        rp = float(gc.get("repetition_penalty", 1.0) or 1.0)
+        seen = None
+        if rp != 1.0:
+            seen = torch.zeros(B, V, dtype=torch.bool, device=logits.device)
+            for b, ids in enumerate(prompt_ids):
+                seen[b, torch.as_tensor(np.asarray(ids), device=logits.device)] = True
+        gen = getattr(self, "_generator", None)
+        if gen is None:
+            gen = self._generator = torch.Generator(device=logits.device)
+            gen.manual_seed(int(gc.get("seed", 0) or 0) + 7919 * int(getattr(self.worker, "rank", 0) or 0))
+        eos_t = torch.as_tensor(eos, device=logits.device)
+        out = torch.full((B, max_new), pad, dtype=torch.int64, device=logits.device)
+        done = torch.zeros(B, dtype=torch.bool, device=logits.device)
+        for i in range(max_new):
+            tok = sampling.sample(logits, float(gc.get("temperature", 1.0)), gc.get("top_k", -1), gc.get("top_p", 1.0), rp, seen, gen)
+            tok = torch.where(done, torch.full_like(tok, pad), tok)
+            out[:, i] = tok
+            if seen is not None:
+                seen[torch.arange(B, device=tok.device), tok] = True
+            done |= torch.isin(tok, eos_t)
+            if i + 1 == max_new or (i % 8 == 7 and bool(done.all())):
+                break
+            logits, _ = self.engine.decode_step(tok)
+        return out
 
     # ------------------------------------------------------------------ request-level serving (generate_opt_level 1)
     def add_request(self, command, data: DataProto):

@@ -212,36 +212,55 @@ __global__ __launch_bounds__(256) void k_attn_dec_scores(DecodeAttnArgs p) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(kc + (size_t)key * DEC_HD + kk * 32 + fg * 8);
     }
+    // raw q / k / v of the new token go out before anything waits (they do not depend on the rotary table):
+    //   threads 0..127  : query head tid >> 3, 16-byte chunks (tid & 7) of both rotary halves
+    //   threads 128..191: key element pair (d, d + 64) when this block owns the new token's cache row
+    //   threads 192..255: V^T append (no rotary) -- done right here
+    const bool owner = z == (idx >> 6);
+    const int qh = tid >> 3, qc = tid & 7;
+    uint4 q1 = uint4{0, 0, 0, 0}, q2 = q1;
+    float kx1 = 0.f, kx2 = 0.f;
+    if (tid < 128) {
+        if (qh < G) {
+            const bf16_t* q = row + (kvh * G + qh) * DEC_HD + qc * 8;
+            q1 = *reinterpret_cast<const uint4*>(q);
+            q2 = *reinterpret_cast<const uint4*>(q + 64);
+        }
+    } else if (owner) {
+        if (tid < 192) {
+            const bf16_t* k = row + (HQ + kvh) * DEC_HD + (tid - 128);
+            kx1 = bf2f(k[0]);
+            kx2 = bf2f(k[64]);
+        } else {
+            const int d = tid - 192;
+            const bf16_t* v = row + (HQ + HK + kvh) * DEC_HD + d;
+            vc[(size_t)d * p.ctx_max + idx] = v[0];
+            vc[(size_t)(d + 64) * p.ctx_max + idx] = v[64];
+        }
+    }
     if (tid < 64) {
         const int pos = p.pos[b];
         cs[tid] = bf2f(p.rope_cos[(size_t)pos * 64 + tid]);
         sn[tid] = bf2f(p.rope_sin[(size_t)pos * 64 + tid]);
     }
     __syncthreads();
-    for (int i = tid; i < 16 * 64; i += 256) {
-        const int h = i >> 6, d = i & 63;
-        float o1 = 0.f, o2 = 0.f;
-        if (h < G) {
-            const bf16_t* q = row + (kvh * G + h) * DEC_HD + d;
-            rope_pair(bf2f(q[0]), bf2f(q[64]), cs[d], sn[d], o1, o2);
-        }
-        q_s[h * 136 + d] = f2bf(o1);
-        q_s[h * 136 + d + 64] = f2bf(o2);
-    }
-    if (z == (idx >> 6)) {                        // the block that owns the new token's key appends K and V^T
-        if (tid < 64) {
-            const bf16_t* k = row + (HQ + kvh) * DEC_HD + tid;
-            float o1, o2;
-            rope_pair(bf2f(k[0]), bf2f(k[64]), cs[tid], sn[tid], o1, o2);
-            const bf16_t b1 = f2bf(o1), b2 = f2bf(o2);
-            kc[(size_t)idx * DEC_HD + tid] = b1;
-            kc[(size_t)idx * DEC_HD + tid + 64] = b2;
-            k_s[tid] = b1;
-            k_s[tid + 64] = b2;
-        } else if (tid < 64 + DEC_HD) {
-            const int d = tid - 64;
-            vc[(size_t)d * p.ctx_max + idx] = row[(HQ + HK + kvh) * DEC_HD + d];
-        }
+    if (tid < 128) {
+        const float x1[8] = {lo16(q1.x), hi16(q1.x), lo16(q1.y), hi16(q1.y), lo16(q1.z), hi16(q1.z), lo16(q1.w), hi16(q1.w)};
+        const float x2[8] = {lo16(q2.x), hi16(q2.x), lo16(q2.y), hi16(q2.y), lo16(q2.z), hi16(q2.z), lo16(q2.w), hi16(q2.w)};
+        float o1[8], o2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rope_pair(x1[e], x2[e], cs[qc * 8 + e], sn[qc * 8 + e], o1[e], o2[e]);
+        *reinterpret_cast<uint4*>(q_s + qh * 136 + qc * 8) = uint4{pack2(o1[0], o1[1]), pack2(o1[2], o1[3]), pack2(o1[4], o1[5]), pack2(o1[6], o1[7])};
+        *reinterpret_cast<uint4*>(q_s + qh * 136 + 64 + qc * 8) = uint4{pack2(o2[0], o2[1]), pack2(o2[2], o2[3]), pack2(o2[4], o2[5]), pack2(o2[6], o2[7])};
+    } else if (owner && tid < 192) {              // the block that owns the new token's key appends K
+        const int d = tid - 128;
+        float o1, o2;
+        rope_pair(kx1, kx2, cs[d], sn[d], o1, o2);
+        const bf16_t b1 = f2bf(o1), b2 = f2bf(o2);
+        kc[(size_t)idx * DEC_HD + d] = b1;
+        kc[(size_t)idx * DEC_HD + d + 64] = b2;
+        k_s[d] = b1;
+        k_s[d + 64] = b2;
     }
     __syncthreads();
     if (t >= ntiles) return;

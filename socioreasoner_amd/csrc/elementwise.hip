@@ -261,19 +261,14 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* logits, int V, int
     }
 }
 
-// per-step bookkeeping on the device so that one captured graph replays for every step.  One block per sequence:
-// finish the greedy argmax from the LM-head partials (lowest index among maxima), log the token, eos / teacher
-// forcing, advance (ctx_len, pos, step) and gather the embedding row of the token that is fed back.
-__global__ __launch_bounds__(256) void k_step(StepArgs a) {
-    __shared__ float sv[4];
-    __shared__ int si[4];
-    __shared__ int s_feed;
-    const int b = blockIdx.x, tid = threadIdx.x;
+// lowest index among the float32 maxima of row b's LM-head partials; valid in thread 0
+__device__ __forceinline__ int reduce_amax_partials(const float* amax_val, const int* amax_idx, int n_part, int b, float* sv, int* si) {
+    const int tid = threadIdx.x;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < a.n_part; i += 256) {
-        const float v = a.amax_val[(size_t)b * a.n_part + i];
-        const int ix = a.amax_idx[(size_t)b * a.n_part + i];
+    for (int i = tid; i < n_part; i += 256) {
+        const float v = amax_val[(size_t)b * n_part + i];
+        const int ix = amax_idx[(size_t)b * n_part + i];
         if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
     }
 #pragma unroll
@@ -284,9 +279,31 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
     }
     if ((tid & 63) == 0) { sv[tid >> 6] = bv; si[tid >> 6] = bi; }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0)
         for (int k = 1; k < 4; ++k)
             if (sv[k] > bv || (sv[k] == bv && si[k] < bi)) { bv = sv[k]; bi = si[k]; }
+    return bi;
+}
+
+// greedy ids of the current logits as int64 (sr_decode_step's next_ids)
+__global__ __launch_bounds__(256) void k_next_ids(const float* amax_val, const int* amax_idx, int n_part, long long* out) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int bi = reduce_amax_partials(amax_val, amax_idx, n_part, blockIdx.x, sv, si);
+    if (threadIdx.x == 0) out[blockIdx.x] = bi;
+}
+
+// per-step bookkeeping on the device so that one captured graph replays for every step.  One block per sequence:
+// finish the greedy argmax from the LM-head partials (lowest index among maxima), log the token, eos / teacher
+// forcing, advance (ctx_len, pos, step) and gather the embedding row of the token that is fed back.
+__global__ __launch_bounds__(256) void k_step(StepArgs a) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ int s_feed;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int bi = reduce_amax_partials(a.amax_val, a.amax_idx, a.n_part, b, sv, si);
+    if (tid == 0) {
+        if (a.chosen) bi = (int)a.chosen[b];        // the caller sampled this step's token itself
         const int step = a.step[b];
         int tok = bi;
         const int fin = a.finished[b];
@@ -336,6 +353,31 @@ __global__ __launch_bounds__(256) void k_load2d(const void* src, int dtype, long
     }
 }
 
+
+// L2 / Infinity-Cache warm-up of a weight region that a LATER launch streams: plain (temporal) 16-byte loads whose
+// values are discarded.  `tile_bytes` > 0: the consumer's block c reads bytes [c*tile_bytes, (c+1)*tile_bytes) and runs
+// on XCD c % 8 (round-robin workgroup dispatch), so prefetch block j touches only tiles c == j (mod 8) and the lines
+// land in the L2 of the XCD that will want them.
+__global__ __launch_bounds__(256) void k_prefetch(const uint4* base, long long bytes, long long tile_bytes, unsigned* sink) {
+    const long long nseg = bytes / 4096;              // 4 KB = one block-wide 16-byte load
+    unsigned acc = 0;
+    if (tile_bytes > 0) {
+        const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3, nrank = (gridDim.x + 7 - xcd) >> 3;
+        const long long spt = tile_bytes / 4096, ntile = bytes / tile_bytes;
+        const long long mine = ((ntile + 7 - xcd) >> 3) * spt;          // segments of this XCD's tiles
+        for (long long q = rank; q < mine; q += nrank) {
+            const long long tile = (q / spt) * 8 + xcd, seg = tile * spt + q % spt;
+            const uint4 v = base[seg * 256 + threadIdx.x];
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    } else {
+        for (long long seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+            const uint4 v = base[seg * 256 + threadIdx.x];
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    }
+    if (acc == 0x9E3779B9u && sink) *sink = acc;      // never true in practice; keeps the loads alive
+}
 }  // namespace
 
 int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, long long cols, bf16_t* dst, long long dst_ld,
@@ -416,9 +458,21 @@ int launch_f32_to_bf16_pad(hipStream_t s, const float* in, int rows, int cols, b
     SR_CHECK_LAUNCH();
     return 0;
 }
+int launch_prefetch(hipStream_t s, const void* base, long long bytes, long long tile_bytes, int blocks, unsigned* sink) {
+    if (bytes < 4096 || blocks <= 0) return 0;
+    hipLaunchKernelGGL(k_prefetch, dim3(blocks), dim3(256), 0, s, static_cast<const uint4*>(base), bytes, tile_bytes, sink);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
 int launch_argmax(hipStream_t s, const float* logits, int rows, int V, int* out_idx) {
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(k_argmax, dim3(rows), dim3(1024), 0, s, logits, V, out_idx);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_next_ids(hipStream_t s, const float* amax_val, const int* amax_idx, int n_part, int B, long long* out) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_next_ids, dim3(B), dim3(256), 0, s, amax_val, amax_idx, n_part, out);
     SR_CHECK_LAUNCH();
     return 0;
 }

@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -106,6 +107,11 @@ struct sr_engine {
     hipGraphExec_t graph = nullptr;
     hipStream_t cap_stream = nullptr;   // used only to CAPTURE the decode step (the caller's stream may be the null stream)
     int graph_B = -1, graph_neos = -1, graph_pad = 0;
+    hipGraphExec_t step_graph[2] = {nullptr, nullptr};   // sr_decode_step: [0] engine-greedy token, [1] caller-chosen token
+    int step_graph_B[2] = {-1, -1};
+    long long *d_chosen = nullptr, *d_next = nullptr;
+    int prefilled_B = 0;
+    int h_ctx_hi = 0;              // longest context any slot can have reached (prefill length + decode steps issued)
     // ---- bookkeeping
     std::map<std::string, bool> loaded;
     char err[512];
@@ -247,6 +253,8 @@ void carve(sr_engine* e) {
     e->d_slabs = ar.take<float>(4 * B * H);
     e->d_amax_val = ar.take<float>(B * e->n_part);
     e->d_amax_idx = ar.take<int>(B * e->n_part);
+    e->d_chosen = ar.take<long long>(32);
+    e->d_next = ar.take<long long>(32);
     e->d_cur_tok = ar.take<int>(32);
     e->d_ctx_len = ar.take<int>(32);
     e->d_pos = ar.take<int>(32);
@@ -486,9 +494,9 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
     return enqueue_lm_head(e, B, x, x_alt, pending, s);
 }
 
-int enqueue_step(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, hipStream_t s) {
+int enqueue_step(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, hipStream_t s, const long long* chosen = nullptr) {
     StepArgs a{e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(e->c.t_vocab, B, e->c.t_hidden, fused_norms(e, B) ? 1 : 0), e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished,
-               e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden, 1};
+               e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden, 1, chosen};
     SR_TRY(launch_step(s, a));
     return 0;
 }
@@ -565,6 +573,7 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
 int sr_engine_destroy(sr_engine* e) {
     if (!e) return 0;
     if (e->graph) (void)hipGraphExecDestroy(e->graph);
+    for (auto g : e->step_graph) if (g) (void)hipGraphExecDestroy(g);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     if (e->ev_copy) (void)hipEventDestroy(e->ev_copy);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -803,6 +812,9 @@ int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int3
     SR_TRY(launch_gather_rows(s, e->t_x, e->t_lastrow, e->d_xa, B, H));
     if (int rc = enqueue_lm_head(e, B, e->d_xa, e->d_xb, false, s)) return rc;
     if (logits_out) SR_TRY((int)hipMemcpyAsync(logits_out, e->d_logits, (size_t)B * c.t_vocab * 4, hipMemcpyDeviceToDevice, s));
+    e->h_ctx_hi = 0;
+    for (int b = 0; b < B; ++b) e->h_ctx_hi = std::max(e->h_ctx_hi, (int)seq_lens[b]);
+    e->prefilled_B = B;
     return 0;
 }
 
@@ -813,6 +825,10 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
     if (B < 1 || B > c.max_batch || max_new < 1 || max_new > c.max_new_tokens || n_eos < 0 || n_eos > 32)
         return fail(e, -22, "sr_decode: B=%d max_new=%d n_eos=%d out of range", B, max_new, n_eos);
     (void)host_slots;   // slots were fixed by sr_prefill (kept in the signature for the continuous-batching scheduler)
+    if (B != e->prefilled_B) return fail(e, -22, "sr_decode: B=%d but %d sequences were prefilled", B, e->prefilled_B);
+    if (e->h_ctx_hi + max_new > c.max_ctx)
+        return fail(e, -22, "sr_decode: context %d + %d new tokens exceeds max_ctx %d", e->h_ctx_hi, max_new, c.max_ctx);
+    e->h_ctx_hi += max_new;
     hipStream_t s = (hipStream_t)stream;
     if (n_eos) SR_TRY((int)hipMemcpyAsync(e->d_eos, host_eos, n_eos * 4, hipMemcpyHostToDevice, s));
     const size_t V = c.t_vocab;
@@ -877,6 +893,39 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
     return 0;
 }
 
+int sr_decode_step(sr_engine* e, const int64_t* dev_last_ids, int B, float* dev_logits_out, int64_t* dev_next_ids, void* stream) {
+    if (!e) return fail(e, -22, "sr_decode_step: null engine");
+    const sr_config& c = e->c;
+    if (B < 1 || B != e->prefilled_B) return fail(e, -22, "sr_decode_step: B=%d but %d sequences were prefilled", B, e->prefilled_B);
+    if (e->h_ctx_hi + 1 > c.max_ctx) return fail(e, -22, "sr_decode_step: context %d would exceed max_ctx %d", e->h_ctx_hi + 1, c.max_ctx);
+    e->h_ctx_hi += 1;
+    hipStream_t s = (hipStream_t)stream;
+    // eos handling stays with the caller (n_eos = 0): a finished row is simply ignored by whoever samples.
+    // One captured graph per (token source, B): step bookkeeping + forward + greedy ids, replayed from engine-owned buffers.
+    const int kind = dev_last_ids ? 1 : 0;
+    const int n_part = gemv_f32_blocks(c.t_vocab, B, c.t_hidden, fused_norms(e, B) ? 1 : 0);
+    if (e->step_graph[kind] == nullptr || e->step_graph_B[kind] != B) {
+        if (e->step_graph[kind]) { (void)hipGraphExecDestroy(e->step_graph[kind]); e->step_graph[kind] = nullptr; }
+        hipGraph_t g = nullptr;
+        SR_TRY((int)hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
+        int rc = enqueue_step(e, B, 0, 0, nullptr, e->cap_stream, kind ? e->d_chosen : nullptr);
+        if (!rc) rc = enqueue_decode_forward(e, B, e->cap_stream);
+        if (!rc) rc = launch_next_ids(e->cap_stream, e->d_amax_val, e->d_amax_idx, n_part, B, e->d_next);
+        hipError_t er = hipStreamEndCapture(e->cap_stream, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        SR_TRY((int)er);
+        er = hipGraphInstantiate(&e->step_graph[kind], g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        SR_TRY((int)er);
+        e->step_graph_B[kind] = B;
+    }
+    if (kind) SR_TRY((int)hipMemcpyAsync(e->d_chosen, dev_last_ids, (size_t)B * 8, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipGraphLaunch(e->step_graph[kind], s));
+    if (dev_logits_out) SR_TRY((int)hipMemcpyAsync(dev_logits_out, e->d_logits, (size_t)B * c.t_vocab * 4, hipMemcpyDeviceToDevice, s));
+    if (dev_next_ids) SR_TRY((int)hipMemcpyAsync(dev_next_ids, e->d_next, (size_t)B * 8, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------- raster + ops
 #define SR_WRAP(call) do { int rc_ = (call); if (rc_) return fail(nullptr, rc_, #call " failed with %d", rc_); return 0; } while (0)
 
@@ -926,6 +975,9 @@ int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, floa
 }
 int sr_op_resid_rmsnorm(void* x, const float* partials, int ksplit, const void* w, void* out, int rows, int H, float eps, void* stream) {
     SR_WRAP(launch_resid_rmsnorm((hipStream_t)stream, (bf16_t*)x, partials, ksplit, (const bf16_t*)w, (bf16_t*)out, rows, H, eps));
+}
+int sr_op_prefetch(const void* base, long long bytes, long long tile_bytes, int blocks, void* stream) {
+    SR_WRAP(launch_prefetch((hipStream_t)stream, base, bytes, tile_bytes, blocks, nullptr));
 }
 int sr_op_argmax(const float* logits, int rows, int V, int32_t* out_idx, void* stream) {
     SR_WRAP(launch_argmax((hipStream_t)stream, logits, rows, V, out_idx));

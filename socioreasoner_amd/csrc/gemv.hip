@@ -80,6 +80,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                 if (c0 + u < cend) fill_w(u, c0 + u);
         }
     };
+    // epilogue operands (bias / residual) are fetched first: they are the oldest loads in flight, so the epilogue never
+    // waits a memory round trip for them
+    uint2 ep_bias[MT], ep_res[MT];
+    if constexpr (MODE == GV_BIAS || MODE == GV_RESID) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            ep_bias[mt] = uint2{0, 0};
+            ep_res[mt] = uint2{0, 0};
+            const int m = mt * 16 + fr, n = tile * 16 + fg * 4;
+            if (active && kp == 0 && m < p.M) {
+                if (MODE == GV_BIAS && p.bias) ep_bias[mt] = *reinterpret_cast<const uint2*>(p.bias + n);
+                if (MODE == GV_RESID) ep_res[mt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.out) + (size_t)m * p.ldo + n);
+            }
+        }
+    }
     if constexpr (!STAGE) first_fills();
 
     // ---------------------------------------------------------------- STAGE prologue: x -> LDS
@@ -94,18 +109,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
         const int nseg = nch / 64;                    // 64-chunk segments per row: one wave-iteration each
         const bool norm = p.norm_w != nullptr;
         // pass 1: h = x (+ pending residual) -> LDS (bf16); per-(row, segment) sum of squares
-        for (int task = tid; task < p.M * nch; task += NT) {
-            const int m = task / nch, c = task % nch;
-            uint4 u = *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + c * 8);
+        auto finish = [&](int m, int c, uint4 u, const float (&a)[8]) {
             float v[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
             if (p.n_slabs > 0) {
-                float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int s = 0; s < p.n_slabs; ++s) {
-                    const float4* pp = reinterpret_cast<const float4*>(p.slabs + ((size_t)s * p.M + m) * p.K + c * 8);
-                    float4 p0 = pp[0], p1 = pp[1];
-                    a[0] += p0.x; a[1] += p0.y; a[2] += p0.z; a[3] += p0.w;
-                    a[4] += p1.x; a[5] += p1.y; a[6] += p1.z; a[7] += p1.w;
-                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + rbf(a[e]));
                 u = uint4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
@@ -119,8 +125,55 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                 ss = wave_sum(ss);                    // the 64 tasks of a wave-iteration share (m, segment)
                 if (lane == 0) red[(c >> 6) * 32 + m] = ss;
             }
+        };
+        const int total = p.M * nch;
+        const bool pre = total <= NT && p.n_slabs <= 2;
+        uint4 wu_pre = uint4{0, 0, 0, 0};
+        if (pre) {
+            // one task per thread (batch 1 at K = 2048): its loads go out BEFORE the first weight fills -- memory
+            // returns in order, so x issued behind 16 KB of weights would wait for them, and weights issued behind the
+            // consumption of x would start a DRAM round trip late
+            const int m = tid / nch, c = tid % nch;
+            const bool on = tid < total;
+            uint4 u = uint4{0, 0, 0, 0};
+            float4 s0[2] = {float4{0.f, 0.f, 0.f, 0.f}, float4{0.f, 0.f, 0.f, 0.f}}, s1[2] = {s0[0], s0[0]};
+            if (on) {
+                u = *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + c * 8);
+                if (norm) wu_pre = *reinterpret_cast<const uint4*>(p.norm_w + c * 8);
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl)
+                    if (sl < p.n_slabs) {
+                        const float4* pp = reinterpret_cast<const float4*>(p.slabs + ((size_t)sl * p.M + m) * p.K + c * 8);
+                        s0[sl] = pp[0];
+                        s1[sl] = pp[1];
+                    }
+            }
+            first_fills();
+            if (on) {
+                float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl)      // slab order 0, 1: same sums as the general path
+                    if (sl < p.n_slabs) {
+                        a[0] += s0[sl].x; a[1] += s0[sl].y; a[2] += s0[sl].z; a[3] += s0[sl].w;
+                        a[4] += s1[sl].x; a[5] += s1[sl].y; a[6] += s1[sl].z; a[7] += s1[sl].w;
+                    }
+                finish(m, c, u, a);
+            }
+        } else {
+            for (int task = tid; task < total; task += NT) {
+                const int m = task / nch, c = task % nch;
+                const uint4 u = *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + c * 8);
+                float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int sl = 0; sl < p.n_slabs; ++sl) {
+                    const float4* pp = reinterpret_cast<const float4*>(p.slabs + ((size_t)sl * p.M + m) * p.K + c * 8);
+                    float4 p0 = pp[0], p1 = pp[1];
+                    a[0] += p0.x; a[1] += p0.y; a[2] += p0.z; a[3] += p0.w;
+                    a[4] += p1.x; a[5] += p1.y; a[6] += p1.z; a[7] += p1.w;
+                }
+                finish(m, c, u, a);
+            }
+            first_fills();
         }
-        first_fills();
         __syncthreads();
         if (norm) {
             // pass 2: xn = bf16(w * bf16(h * rs)) in place  (hf:65-79)
@@ -130,7 +183,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                 for (int sg = 0; sg < nseg; ++sg) tot += red[sg * 32 + m];
                 const float rs = 1.0f / sqrtf(tot / (float)p.K + p.eps);
                 uint4 u = *reinterpret_cast<const uint4*>(xn + (size_t)m * xs + c * 8);
-                uint4 wu = *reinterpret_cast<const uint4*>(p.norm_w + c * 8);
+                const uint4 wu = pre ? wu_pre : *reinterpret_cast<const uint4*>(p.norm_w + c * 8);
                 float v[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
                 float wv[8] = {lo16(wu.x), hi16(wu.x), lo16(wu.y), hi16(wu.y), lo16(wu.z), hi16(wu.z), lo16(wu.w), hi16(wu.w)};
                 float o[8];
@@ -254,11 +307,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                 bf16_t* optr = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n;
                 float o[4] = {acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3]};
                 if (MODE == GV_BIAS && p.bias) {
-                    uint2 b = *reinterpret_cast<const uint2*>(p.bias + n);
+                    const uint2 b = ep_bias[mt];
                     o[0] += lo16(b.x); o[1] += hi16(b.x); o[2] += lo16(b.y); o[3] += hi16(b.y);
                 }
                 if constexpr (MODE == GV_RESID) {
-                    uint2 rv = *reinterpret_cast<const uint2*>(optr);
+                    const uint2 rv = ep_res[mt];
                     o[0] = lo16(rv.x) + rbf(o[0]); o[1] = hi16(rv.x) + rbf(o[1]);
                     o[2] = lo16(rv.y) + rbf(o[2]); o[3] = hi16(rv.y) + rbf(o[3]);
                 }

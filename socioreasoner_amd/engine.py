@@ -189,3 +189,17 @@ class Engine:
                                    self._s(), C.byref(done)), self._h, "sr_decode")
         self.steps_done = done.value
         return (toks, tr) if trace else toks
+
+    def decode_step(self, last_ids: torch.Tensor | None = None, return_logits: bool = True):
+        """One forward pass with the token choice left to the caller (sampling, logits verification): feeds
+        last_ids [B] int64 (None = the engine's greedy token) and returns (float32 logits [B, V] or None, greedy ids [B] int64)."""
+        B = self._last_B
+        if last_ids is not None:
+            last_ids = last_ids.to(device=self.device, dtype=torch.int64).contiguous()
+            assert last_ids.shape == (B,)
+        logits = torch.empty(B, self.geom.text.vocab_size, dtype=torch.float32, device=self.device) if return_logits else None
+        nxt = torch.empty(B, dtype=torch.int64, device=self.device)
+        L.check(self.lib.sr_decode_step(self._h, C.c_void_p(last_ids.data_ptr()) if last_ids is not None else None, B,
+                                        C.c_void_p(logits.data_ptr()) if logits is not None else None, C.c_void_p(nxt.data_ptr()),
+                                        self._s()), self._h, "sr_decode_step")
+        return logits, nxt

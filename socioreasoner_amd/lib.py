@@ -45,6 +45,7 @@ SIGNATURES = {
     "sr_vit_forward": (C.c_int, [_vp, _vp, _i, _i64p, _i, _vp, _vp]),
     "sr_prefill": (C.c_int, [_vp, _i64p, _i64p, _i32p, _i32p, _i, _vp, _i, _vp, _vp]),
     "sr_decode": (C.c_int, [_vp, _i32p, _i, _i, _i32p, _i, C.c_int32, _vp, _vp, _vp, _i, _vp, C.POINTER(C.c_int)]),
+    "sr_decode_step": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp]),
     "sr_mask_union": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "sr_resize_nearest_u8": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp]),
     "sr_iou_counts": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     "sr_op_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i, _i, C.c_float, _vp]),
     "sr_op_resid_rmsnorm": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, C.c_float, _vp]),
     "sr_op_argmax": (C.c_int, [_vp, _i, _i, _vp, _vp]),
+    "sr_op_prefetch": (C.c_int, [_vp, C.c_longlong, C.c_longlong, _i, _vp]),
 }
 
 

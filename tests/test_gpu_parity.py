@@ -374,6 +374,44 @@ def test_decode_graph_equals_eager_and_batch_invariance(tiny_engine, golden_dir)
     assert st[0].tolist() == [first] + [2045] * 15
 
 
+def test_decode_step_matches_decode_and_accepts_caller_tokens(tiny_engine, golden_dir):
+    """sr_decode_step: greedy chaining reproduces sr_decode bit for bit (tokens and logits); a token
+    chosen by the caller takes the place of the argmax exactly as teacher forcing does; context overflow is refused."""
+    g = np.load(os.path.join(golden_dir, "hf_tiny.npz"))
+    grids = [tuple(x) for x in g["grids"].tolist()]
+    emb = tiny_engine.vit_forward(bits_to_f32(g["pix"]).cuda(), grids)
+    ids, pos3 = g["ids"], g["pos3"]
+    other = ids[:9].copy()
+    other[other >= 2040] = 5
+    pos_o = np.tile(np.arange(9), (3, 1))
+    tiny_engine.prefill([ids, other], [pos3, pos_o], emb)
+    toks, trace = tiny_engine.decode(16, trace=True, use_graph=False)
+    lg0 = tiny_engine.prefill([ids, other], [pos3, pos_o], emb, return_logits=True)
+    assert torch.equal(lg0, trace[0])
+    got = [lg0.argmax(-1)]
+    lgs = [lg0]
+    for i in range(6):
+        lg, nxt = tiny_engine.decode_step(None if i % 2 else got[-1])      # engine's own greedy token / caller's (same) token
+        assert torch.equal(nxt, lg.argmax(-1))
+        got.append(nxt)
+        lgs.append(lg)
+    assert torch.equal(torch.stack(got, 1).int(), toks[:, :7])
+    for i in range(7):
+        assert torch.equal(lgs[i], trace[i]), i
+    # caller-chosen tokens == teacher forcing
+    forced = torch.randint(0, 2000, (2, 16), dtype=torch.int32)
+    tiny_engine.prefill([ids, other], [pos3, pos_o], emb)
+    _, tr_f = tiny_engine.decode(16, trace=True, forced=forced, use_graph=False)
+    tiny_engine.prefill([ids, other], [pos3, pos_o], emb)
+    for i in range(5):
+        lg, _ = tiny_engine.decode_step(forced[:, i].long().cuda())
+        assert torch.equal(lg, tr_f[i + 1]), i
+    # capacity: max_ctx 192, the long prompt has len(ids) tokens
+    with pytest.raises(Exception, match="max_ctx"):
+        for _ in range(200):
+            tiny_engine.decode_step(None, return_logits=False)
+
+
 # ------------------------------------------------------------------------------------------------ true dimensions
 def _truedim(full: bool):
     from oracle import model_ref as MR

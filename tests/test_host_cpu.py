@@ -144,3 +144,31 @@ def test_roll_api_surface_and_config_loader():
     assert [len(p) for p in parts] == [3, 2, 2]
     back = DataProto.concat(parts)
     assert (back.batch["x"] == d.batch["x"]).all() and list(back.non_tensor_batch["o"]) == list(range(7))
+
+
+def test_sampling_policy_cpu():
+    """Host-side token choice used with sr_decode_step: greedy limits, top-k / top-p support, repetition penalty."""
+    import torch
+    from socioreasoner_amd import sampling
+    assert sampling.is_greedy({"temperature": 0.0}) and sampling.is_greedy({"temperature": 0.9, "top_k": 1})
+    assert not sampling.is_greedy({"temperature": 0.99, "top_k": 100, "top_p": 0.99})
+    g = torch.Generator().manual_seed(0)
+    logits = torch.tensor([[2.0, 1.0, 0.5, -1.0, 0.0], [0.0, 0.1, 3.0, 2.9, -2.0]])
+    assert sampling.sample(logits, temperature=0.0).tolist() == [0, 2]
+    draws = torch.stack([sampling.sample(logits, 1.0, top_k=2, generator=g) for _ in range(200)])
+    assert set(draws[:, 0].tolist()) <= {0, 1} and set(draws[:, 1].tolist()) <= {2, 3} and len(set(draws[:, 1].tolist())) == 2
+    # top_p keeps the smallest prefix of the sorted distribution whose mass reaches p
+    p = torch.softmax(logits[0], -1)
+    draws = torch.stack([sampling.sample(logits[:1], 1.0, top_p=float(p[0]) - 1e-3, generator=g) for _ in range(100)])
+    assert set(draws[:, 0].tolist()) == {0}
+    draws = torch.stack([sampling.sample(logits[:1], 1.0, top_p=float(p[0] + p[1]) - 1e-3, generator=g) for _ in range(200)])
+    assert set(draws[:, 0].tolist()) == {0, 1}
+    # repetition penalty: positive logits divided, negative multiplied, only where seen
+    seen = torch.tensor([[True, False, False, True, False]])
+    assert sampling.sample(torch.tensor([[2.0, 1.5, 0.5, -1.0, 0.0]]), 0.0, repetition_penalty=2.0, seen=seen).tolist() == [1]
+    # empirical frequencies follow softmax(logits / T)
+    T = 0.7
+    want = torch.softmax(logits[0] / T, -1)
+    draws = sampling.sample(logits[:1].repeat(20000, 1), T, generator=g)
+    freq = torch.bincount(draws, minlength=5).float() / 20000
+    assert float((freq - want).abs().max()) < 0.015
