@@ -69,7 +69,9 @@ class Mi355xStrategy(InferenceStrategy):
         prompt_len = int(_get(pc, "prompt_length", 4096))
         resp_len = int(_get(pc, "response_length", 2048))
         self.max_batch = int(sc.get("max_batch", 32))
-        max_ctx = int(sc.get("max_ctx", min(prompt_len + resp_len, 2048)))
+        # KV cache sized for prompt + response like the reference's sequence_length (36 KB per token per slot: 32 slots x
+        # 6144 tokens = 7 GB of the 288 GB)
+        max_ctx = int(sc.get("max_ctx", min(prompt_len + resp_len, 8192)))
         max_ctx = (max_ctx + 63) // 64 * 64
         self.engine = Engine(self.geom, max_patches=int(sc.get("max_patches", 2048 * 2 * 4)),
                              max_prefill_tokens=int(sc.get("max_prefill_tokens", min(prompt_len, 1024) * 8)),
@@ -114,7 +116,7 @@ class Mi355xStrategy(InferenceStrategy):
             if (rh, rw) != (h, w):
                 from PIL import Image
                 arr = np.asarray(Image.fromarray(arr).resize((rw, rh), resample=Image.BICUBIC))
-            ims.append(torch.from_numpy(np.ascontiguousarray(arr)).cuda())
+            ims.append(torch.from_numpy(np.array(arr, dtype=np.uint8, order="C")).cuda())
             grids.append((1, rh // g.vision.patch_size, rw // g.vision.patch_size))
         ids = np.asarray(ids, dtype=np.int64)
         n_pad = int((ids == g.image_token_id).sum())
@@ -177,13 +179,17 @@ class Mi355xStrategy(InferenceStrategy):
                 emb = self.engine.vit_forward(pix, grids)
             for k in grp:
                 results[k] = []
+            room = self.engine.cfg.max_ctx - max(len(prepared[k][0]) for k in grp)
+            if room < 1:
+                raise ValueError(f"prompt of {self.engine.cfg.max_ctx - room} tokens leaves no room in max_ctx {self.engine.cfg.max_ctx}")
+            max_new_g = min(max_new, room)
             for _ in range(1 if greedy else n):
                 logits = self.engine.prefill([prepared[k][0] for k in grp], [prepared[k][1] for k in grp], emb,
                                              return_logits=not greedy)
                 if greedy:
-                    toks = self.engine.decode(max_new, eos=eos, pad_id=pad).cpu().tolist()
+                    toks = self.engine.decode(max_new_g, eos=eos, pad_id=pad).cpu().tolist()
                 else:
-                    toks = self._sample_loop(logits, [prepared[k][0] for k in grp], max_new, eos, pad, gc).cpu().tolist()
+                    toks = self._sample_loop(logits, [prepared[k][0] for k in grp], max_new_g, eos, pad, gc).cpu().tolist()
                 for row, k in zip(toks, grp):
                     cut = next((j + 1 for j, t in enumerate(row) if t in eos), len(row))
                     results[k].append(row[:cut])

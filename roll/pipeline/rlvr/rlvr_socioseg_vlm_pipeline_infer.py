@@ -5,28 +5,37 @@ files as the reference (roll/pipeline/rlvr/rlvr_socioseg_vlm_pipeline_infer.py:5
                -> stage-2 generate -> mask -> IoU;  files under ./output/infer/result/{stage1,stage2,render1,render2}
                and the mean in iou_acc.txt.
 
-What is different, and why: there is no Ray (workers = the torchrun ranks, tiles sharded like the reference's
-DP dispatch and gathered with one RCCL all-gather), and nothing that needs the network exists offline -- SocioSeg data,
-the tokenizer and SAM2.  Without them the pipeline runs its *synthetic mode* (SURVEY.md section 8(D)): synthetic tiles
-and token ids, and synthetic per-object masks standing in for SAM2's output, so that every raster step after SAM2 runs
-for real on the device.  With a checkpoint directory + dataset + a SAM2-compatible predictor passed in, the same code
-path runs on real data.
+What is different, and why: there is no Ray (workers = the torchrun ranks; samples are sharded like the reference's DP
+dispatch and the per-sample IoUs gathered with one RCCL all-gather), and nothing that needs the network exists offline
+-- SocioSeg data, the tokenizer and SAM2.  Each has a stand-in behind the SAME interface, so one code path serves both:
+  data      : a SocioSeg folder (roll/datasets/dataset.py layout) via data_args.dataset_dir, else synthetic tiles;
+  processor : the checkpoint's HF processor when `pretrain` is a directory, else textproc.SyntheticProcessor
+              (byte-level tokenizer with the Qwen special-token ids);
+  SAM2      : `sam_predictor_provider` (anything with set_image / predict), else SyntheticSamPredictor, which turns the
+              parsed boxes / points into masks so that every raster step after SAM2 runs for real on the device.
+The batch keys, the order of operations and the files written follow the reference's `run()` step by step.
 """
 from __future__ import annotations
 
 import json
 import os
-from typing import Any, Dict, List, Union
+from collections import defaultdict
+from typing import Any, Dict, List, Optional, Union
 
 import numpy as np
 import torch
 
+from roll.datasets.collator import DataCollatorWithPaddingForMultiSeg
+from roll.distributed.scheduler.generate_scheduler import GenerateScheduler
 from roll.distributed.scheduler.protocol import DataProto
-from roll.distributed.strategy.factory import create_strategy
 from roll.pipeline.base_pipeline import BasePipeline
+from roll.pipeline.base_worker import ActorWorker, Worker
 from roll.pipeline.rlvr.rlvr_config import SocioSegConfig  # noqa: F401  (re-exported like the reference)
-from socioreasoner_amd import dp, hostops, raster, synthetic
+from roll.pipeline.rlvr.seg_worker import SegWorker
+from socioreasoner_amd import dp, hostops, raster, socioseg_data
 from socioreasoner_amd.hostops import parse_points_text_from_content, parse_visual_prompt_from_json_s2  # noqa: F401
+
+_Worker = Worker      # earlier name, kept for callers that build a bare worker
 
 
 def compute_giou(pred_mask: np.ndarray, gt_mask: np.ndarray) -> float:
@@ -98,106 +107,267 @@ def render_image(bboxes_json: str, images: List[Any], mask: Union[np.ndarray, An
     return out
 
 
-class _Worker:
-    """What a strategy sees of its worker (reference: roll/distributed/executor/worker.py:41-204)."""
+def process_image(images: List[Any], processor) -> List[Any]:
+    """Resize to multiples of patch * merge within [min_pixels, max_pixels] with the processor's resampling
+    (reference :126-144; same rule as HF's Qwen2-VL image processor)."""
+    ip = processor.image_processor
+    factor = ip.patch_size * ip.merge_size if "Qwen" in getattr(ip, "image_processor_type", "Qwen") else 28
+    out = []
+    for im in images:
+        rh, rw = hostops.smart_resize(im.height, im.width, factor=factor, min_pixels=ip.min_pixels, max_pixels=ip.max_pixels)
+        out.append(im.resize((rw, rh), resample=ip.resample))
+    return out
 
-    def __init__(self, worker_config, pipeline_config, rank, world_size, local_rank):
-        self.worker_config, self.pipeline_config = worker_config, pipeline_config
-        self.rank, self.world_size = rank, world_size
-        self.rank_info = type("RankInfo", (), {"dp_rank": rank, "dp_size": world_size, "local_rank": local_rank})()
+
+def encode_function(data_i: Dict[str, List], processor, id_key="id", prompt_key="problem", label_key="mask_label",
+                    image_map_key="map_image", image_sat_key="sat_image") -> Dict[str, List]:
+    """Raw SocioSeg columns -> the regularised fields of the reference (:186-268): resized [map, sat] pair, stage-1 prompt
+    text, ground-truth mask / boxes / object count.  An image that fails to load is replaced by a black one and the
+    sample is flagged text-only, as in the reference."""
+    from PIL import Image
+    n = len(data_i[prompt_key])
+    enc = defaultdict(list)
+    for i in range(n):
+        pair, ok = [], True
+        for key in (image_map_key, image_sat_key):
+            try:
+                pair.append(process_image([socioseg_data.load_image(data_i[key][i]).convert("RGB")], processor)[0])
+            except Exception:  # noqa: BLE001
+                pair.append(Image.new("RGB", (224, 224)))
+                ok = False
+        try:
+            gt = socioseg_data.load_image(data_i[label_key][i])
+            seg = socioseg_data.load_image(data_i[image_sat_key][i]).convert("RGB")
+        except Exception:  # noqa: BLE001
+            gt, seg = Image.new("RGB", (756, 756)), Image.new("RGB", (756, 756))
+        enc["id"].append(data_i[id_key][i] if id_key in data_i else f"id_{i}")
+        enc["prompt_map"].append(format_prompt_1(data_i[prompt_key][i], processor, use_image=ok))
+        enc["question"].append(data_i[prompt_key][i])
+        enc["gt_mask"].append(gt)
+        enc["gt_bbox"].append(socioseg_data.get_bboxes([gt])[0])
+        enc["gt_object"].append(socioseg_data.count_components([gt])[0])
+        enc["image_sat"].append([pair[1]])
+        enc["image_map"].append([pair[0]])
+        enc["seg_image"].append(seg)
+        enc["image"].append(pair)
+        enc["image_flag"].append(ok)
+        enc["tag"].append("")
+    return dict(enc)
+
+
+def get_extra_data_provider(model_name_or_path: str = "", processor=None):
+    """-> callable(input_ids, image_grid_thw, video_grid_thw, attention_mask) -> {"position_ids": (B, 3, S)}: mRoPE ids of
+    Qwen2-VL in the (bsz, 3, seqlen) layout DataProto wants (reference :330-381)."""
+    tok = processor.tokenizer
+    merge = processor.image_processor.merge_size
+    ids = {k: tok.convert_tokens_to_ids(v) for k, v in (("image", "<|image_pad|>"), ("start", "<|vision_start|>"))}
+
+    def extra_data_provider(input_ids, image_grid_thw=None, video_grid_thw=None, attention_mask=None):
+        grids = None if image_grid_thw is None else [tuple(int(v) for v in g) for g in image_grid_thw.tolist()]
+        pos, _ = hostops.get_rope_index(input_ids, grids, attention_mask, spatial_merge_size=merge, image_token_id=ids["image"],
+                                        vision_start_token_id=ids["start"])
+        return {"position_ids": pos.transpose(0, 1)}
+
+    return extra_data_provider
+
+
+def get_dataloader(dataset: Dict[str, List], batch_size: int, data_collator, shuffle: bool = False, seed: int = 42):
+    """Batches of collated samples (the reference shuffles with torch's DataLoader; the default here is in-order so that
+    runs are reproducible across rank counts)."""
+    n = len(dataset["id"])
+    order = np.random.default_rng(seed).permutation(n) if shuffle else np.arange(n)
+    for b0 in range(0, n, batch_size):
+        yield data_collator([{k: v[i] for k, v in dataset.items()} for i in order[b0:b0 + batch_size]])
+
+
+def draw_visual_prompt(image, mask, visual_prompt):
+    """Mask overlay (device kernel) + the prompt's box (2-px blue) and points (radius-5 discs: green positive, red
+    negative) for the render1 / render2 outputs (reference :454-509)."""
+    from PIL import Image, ImageDraw
+    arr = torch.from_numpy(np.ascontiguousarray(np.asarray(image.convert("RGB")))).cuda()
+    try:
+        m = np.asarray(mask.convert("L")) if hasattr(mask, "convert") else np.asarray(mask)
+        raster.render_overlay_(arr, torch.from_numpy(np.ascontiguousarray((m > 0).astype(np.uint8))).cuda(), [])
+    except Exception:  # noqa: BLE001
+        pass
+    out = Image.fromarray(arr.cpu().numpy())
+    draw = ImageDraw.Draw(out)
+    vp = visual_prompt or {}
+    if "box" in vp and len(np.asarray(vp["box"]).reshape(-1)) == 4:
+        b = [float(v) for v in np.asarray(vp["box"]).reshape(-1)]
+        draw.rectangle([(b[0], b[1]), (b[2], b[3])], outline="blue", width=2)
+    for pt, lab in zip(vp.get("point_coords", []), vp.get("point_labels", [])):
+        x, y = [float(v) for v in np.asarray(pt).reshape(-1)[:2]]
+        draw.ellipse([x - 5, y - 5, x + 5, y + 5], fill="green" if int(lab) == 1 else "red", outline=None)
+    return out
+
+
+def _obj(values) -> np.ndarray:
+    a = np.empty(len(values), dtype=object)
+    a[:] = list(values)
+    return a
 
 
 class SocioSegInferPipeline(BasePipeline):
-    def __init__(self, pipeline_config, sam_predictor_provider=None, dataset=None):
+    def __init__(self, pipeline_config, sam_predictor_provider=None, dataset: Optional[List[Dict]] = None, processor=None,
+                 actor_worker=None):
         super().__init__(pipeline_config)
+        cfg = pipeline_config
         self.rank, self.world, local = dp.init_distributed()
-        self.actor_infer = create_strategy(_Worker(pipeline_config.actor_infer, pipeline_config, self.rank, self.world, local))
-        self.actor_infer.initialize(None)
-        self.seg_infer = create_strategy(_Worker(pipeline_config.seg_infer, pipeline_config, self.rank, self.world, local))
-        self.seg_infer.initialize(sam_predictor_provider)
-        self.tokenizer = self.actor_infer.tokenizer
-        self.geom = self.actor_infer.geom
-        self.dataset = dataset            # None -> synthetic tiles
-        ga = pipeline_config.actor_infer.generating_args or {}
-        eos = [self.tokenizer.eos_token_id] + list(getattr(self.tokenizer, "additional_special_tokens_ids", []) or [])
-        self.generation_config = {
-            "max_new_tokens": int(ga.get("max_new_tokens") or pipeline_config.response_length),
-            "temperature": ga.get("temperature", 0), "top_p": ga.get("top_p", 1.0), "top_k": ga.get("top_k", 1),
-            "num_beams": ga.get("num_beams", 1), "repetition_penalty": ga.get("repetition_penalty", 1.0),
-            "num_return_sequences": 1, "eos_token_id": eos, "pad_token_id": self.tokenizer.pad_token_id,
-        }
-        self.n_samples = int(os.environ.get("SOCIOSEG_NUM_SAMPLES", pipeline_config.rollout_batch_size))
+        # ---- workers (reference: Ray clusters actor_infer / seg_infer; here the local rank's two workers)
+        self.actor_infer = actor_worker or ActorWorker(cfg.actor_infer, cfg, self.rank, self.world, local, "actor_infer")
+        if actor_worker is None:
+            self.actor_infer.initialize(cfg)
+        self.geom = getattr(self.actor_infer.strategy, "geom", None)
+        # ---- processor / tokenizer: the checkpoint's when there is one, else the offline stand-in
+        if processor is None:
+            path = str((cfg.actor_infer.model_args or {}).get("model_name_or_path") or cfg.get("pretrain") or "")
+            if os.path.isdir(path):
+                from transformers import AutoProcessor
+                processor = AutoProcessor.from_pretrained(path)
+            else:
+                from socioreasoner_amd.textproc import SyntheticProcessor
+                processor = SyntheticProcessor(self.geom)
+        self.processor = processor
+        margs = (cfg.actor_train or {}).get("model_args") or cfg.actor_infer.model_args or {}
+        self.processor.image_processor.max_pixels = int(margs.get("max_pixels") or 768 * 768)
+        self.processor.image_processor.min_pixels = int(margs.get("min_pixels") or 56 * 56)
+        self.tokenizer = self.processor.tokenizer
+        self.tokenizer.padding_side = "left"
+        self.actor_infer.tokenizer = self.tokenizer
+        if hasattr(self.actor_infer.strategy, "tokenizer"):
+            self.actor_infer.strategy.tokenizer = self.tokenizer
+        self.seg_infer = SegWorker(cfg.seg_infer, cfg, self.rank, self.world, local, "seg_infer")
+        self.seg_infer.initialize(cfg, model_provider=sam_predictor_provider or (lambda **_: socioseg_data.SyntheticSamPredictor()),
+                                  tokenizer=self.tokenizer)
+        # ---- data: this rank's contiguous shard (np.array_split sizes, like the reference's DP dispatch)
+        if dataset is None:
+            dargs = (cfg.actor_train or {}).get("data_args") or {}
+            ddir = dargs.get("dataset_dir") and os.path.join(dargs.get("dataset_dir"), dargs.get("file_name") or "")
+            if ddir and os.path.isdir(os.path.join(ddir, "test")):
+                dataset = socioseg_data.load_socioseg_folder(ddir, "test")
+            else:
+                dataset = socioseg_data.synthetic_socioseg(int(os.environ.get("SOCIOSEG_NUM_SAMPLES", cfg.rollout_batch_size)))
+        self.n_samples = len(dataset)
+        lo, hi = dp.shard_range(self.n_samples, self.rank, self.world)
+        raw = {k: [s[k] for s in dataset[lo:hi]] for k in ("id", "problem", "map_image", "sat_image", "mask_label")}
+        self.dataset = encode_function(raw, self.processor)
+        self.extra_data_provider = get_extra_data_provider(processor=self.processor)
+        self.data_collator = DataCollatorWithPaddingForMultiSeg(
+            tokenizer=self.tokenizer, processor=self.processor, extra_data_provider=self.extra_data_provider,
+            max_length=int(cfg.prompt_length), image_key="image", padding="max_length", gt_object_key="gt_object", gt_bbox_key="gt_bbox")
+        self.batch_size = int(os.environ.get("SOCIOSEG_BATCH", cfg.rollout_batch_size))
+        self.generate_scheduler = GenerateScheduler()
 
-    # ------------------------------------------------------------------ synthetic batch (no dataset / tokenizer offline)
-    def _synthetic_sample(self, i: int) -> Dict:
-        grid = (1, 32, 32)
-        ids = synthetic.tile_prompt(self.geom, i, grid, n_images=2)      # (map, satellite) like the reference
-        return {"id": f"synthetic_{i:06d}", "tile": synthetic.tile_pixels(i), "map": synthetic.tile_pixels(10_000 + i),
-                "ids": ids, "masks": synthetic.tile_masks(i)}
+    # one generation round through the scheduler -> the reference's 7 output tensors
+    def _generate(self, gen_batch: DataProto, global_step: int) -> DataProto:
+        gen_batch.meta_info = {"global_step": global_step, "response_callback_fn": self.generate_scheduler.report_response}
+        return self.generate_scheduler.generate(data=gen_batch, actor_cluster=self.actor_infer, pipeline_config=self.pipeline_config)
 
-    def _generate(self, samples: List[Dict], images_key: str) -> torch.Tensor:
-        P = int(self.pipeline_config.prompt_length)
-        pad = self.tokenizer.pad_token_id
-        rows, payload = [], np.empty(len(samples), dtype=object)
-        for k, s in enumerate(samples):
-            ids = np.asarray(s["ids"], dtype=np.int64)
-            row = np.full(P, pad, dtype=np.int64)
-            row[P - len(ids):] = ids                                     # left padding (reference collator.py:444-564)
-            rows.append(row)
-            payload[k] = {"prompt_token_ids": ids.tolist(), "multi_modal_data": {"image": s[images_key]}}
-        input_ids = torch.from_numpy(np.stack(rows))
-        batch = DataProto(batch={"input_ids": input_ids, "attention_mask": (input_ids != pad).long()},
-                          non_tensor_batch={"multi_modal_data": payload})
-        out = self.actor_infer.generate(batch, self.generation_config)
-        return out[:, P:]
+    def _stage2_batch(self, batch: DataProto, bboxs_text_list: List[str]) -> DataProto:
+        """Render stage 1 onto both images and build the stage-2 prompts (reference :714-825)."""
+        cfg = self.pipeline_config
+        padded, loose, grids = defaultdict(list), defaultdict(list), []
+        for question, bboxs_text, images, mask in zip(batch.non_tensor_batch["question"], bboxs_text_list,
+                                                      batch.non_tensor_batch["image"], batch.non_tensor_batch["map_mask"]):
+            text = format_prompt_2(question, bboxs_text, self.processor)
+            rd_image = render_image(bboxs_text, images, mask)
+            enc = self.processor(images=rd_image, text=text)
+            for k in ("input_ids", "attention_mask", "labels"):
+                if k in enc:
+                    padded[k].append(enc.pop(k)[0])
+            enc.convert_to_tensors(tensor_type="pt")
+            grids.append(enc["image_grid_thw"])
+            loose["multi_modal_sat_inputs"].append(dict(enc))
+            loose["multi_modal_sat_data"].append({"prompt_token_ids": self.tokenizer.encode(text, add_special_tokens=False),
+                                                  "multi_modal_data": {"image": rd_image if isinstance(rd_image, list) else [rd_image]}})
+        sat = self.tokenizer.pad(padded, padding="max_length", max_length=int(cfg.prompt_length), pad_to_multiple_of=None, return_tensors="pt")
+        sat = {"input_ids": sat["input_ids"], "attention_mask": sat["attention_mask"]}
+        extra = self.extra_data_provider(input_ids=sat["input_ids"], attention_mask=sat["attention_mask"], image_grid_thw=torch.cat(grids, dim=0))
+        sat["position_ids"] = extra["position_ids"]
+        sat.update({k: _obj(v) for k, v in loose.items()})
+        sat["bboxs_text"] = _obj(bboxs_text_list)
+        return DataProto.from_single_dict(sat)
 
     @torch.no_grad()
     def run(self):
         cfg = self.pipeline_config
         res_dir = os.path.join(cfg.output_dir, "result")
-        for sub in ("stage1", "stage2", "render1", "render2"):
-            os.makedirs(os.path.join(res_dir, sub), exist_ok=True)
-        lo, hi = dp.shard_range(self.n_samples, self.rank, self.world)
-        ious = []
-        bs = int(os.environ.get("SOCIOSEG_BATCH", 32))
-        for b0 in range(lo, hi, bs):
-            samples = [self._synthetic_sample(i) for i in range(b0, min(b0 + bs, hi))]
-            for s in samples:
-                s["images1"] = [s["map"], s["tile"]]
-            resp1 = self._generate(samples, "images1")                       # STAGE 1
-            text1 = self.tokenizer.batch_decode(resp1, skip_special_tokens=False)
-            for s, r, txt in zip(samples, resp1, text1):
-                masks, gt = s["masks"]
-                acc = torch.zeros(756, 756, dtype=torch.uint8, device="cuda")
-                for m in masks[:2]:                                           # synthetic stand-in for SAM2's per-object masks
-                    raster.mask_union_(acc, torch.from_numpy(m).cuda())
-                s["mask1"] = raster.resize_nearest(acc, 768, 768)
-                boxes = parse_points_text_from_content(txt) or "[]"
-                s["render"] = render_image(boxes, [s["map"], s["tile"]], s["mask1"].cpu().numpy())
-                open(os.path.join(res_dir, "stage1", s["id"] + ".txt"), "w").write(txt)
-            resp2 = self._generate(samples, "render")                        # STAGE 2 (re-encodes the rendered tile)
-            text2 = self.tokenizer.batch_decode(resp2, skip_special_tokens=False)
-            for s, txt in zip(samples, text2):
-                masks, gt = s["masks"]
-                acc = torch.zeros(756, 756, dtype=torch.uint8, device="cuda")
-                for m in masks:
-                    raster.mask_union_(acc, torch.from_numpy(m).cuda())
-                pred = raster.resize_nearest(acc, 768, 768)
-                ious.append(raster.compute_giou(pred, torch.from_numpy(gt).cuda()))
-                open(os.path.join(res_dir, "stage2", s["id"] + ".txt"), "w").write(txt)
-                try:
-                    from PIL import Image
-                    Image.fromarray(pred.cpu().numpy() * 255).save(os.path.join(res_dir, "stage2", s["id"] + ".png"))
-                    Image.fromarray(s["render"][0]).save(os.path.join(res_dir, "render1", s["id"] + ".png"))
-                    Image.fromarray(s["render"][1]).save(os.path.join(res_dir, "render2", s["id"] + ".png"))
-                except Exception:  # noqa: BLE001
-                    pass
-        local = torch.tensor(ious, dtype=torch.float64).reshape(-1, 1)
+        dirs = {k: os.path.join(res_dir, k) for k in ("stage1", "stage2", "render1", "render2")}
+        for d in dirs.values():
+            os.makedirs(d, exist_ok=True)
+        n_ret = int((cfg.actor_infer.generating_args or {}).get("num_return_sequences", 1) or 1)
+        all_giou: List[float] = []
+        global_step = 0
+        for batch_dict in get_dataloader(self.dataset, self.batch_size, self.data_collator):
+            self.model_update(global_step)
+            batch = DataProto.from_single_dict(batch_dict)
+            batch.meta_info = {"global_step": global_step}
+            # ---- stage 1: generate on the (map, satellite) pair
+            gen_batch = batch.pop(batch_keys=["map_input_ids", "map_attention_mask", "map_position_ids"], non_tensor_batch_keys=["multi_modal_map_data"])
+            gen_batch.rename(["map_input_ids", "map_attention_mask", "map_position_ids"], ["input_ids", "attention_mask", "position_ids"])
+            gen_batch.non_tensor_batch["multi_modal_data"] = gen_batch.non_tensor_batch.pop("multi_modal_map_data")
+            out = self._generate(gen_batch, global_step)
+            out.rename(["input_ids", "attention_mask", "position_ids", "responses", "response_mask", "prompts", "prompt_mask"],
+                       ["map_input_ids", "map_attention_mask", "map_position_ids", "map_responses", "map_response_mask", "map_prompts", "map_prompt_mask"])
+            out.batch.pop("prompt_id", None)
+            for k, v in batch.non_tensor_batch.items():
+                batch.non_tensor_batch[k] = np.repeat(v, n_ret)
+            batch.batch = out.batch
+            # ---- stage-1 masks: responses -> SAM prompts -> union / nearest resize on the device
+            seg_batch = batch.pop(batch_keys=["map_responses", "map_prompts"], non_tensor_batch_keys=["seg_image"])
+            seg_out = self.seg_infer.segment_v4_map(seg_batch)
+            batch = batch.union(seg_out)
+            batch.non_tensor_batch["map_mask"] = batch.non_tensor_batch.pop("mask")
+            batch.non_tensor_batch["map_visual_prompt"] = batch.non_tensor_batch.pop("visual_prompt")
+            batch.non_tensor_batch.pop("response_text")
+            # ---- stage 2: render stage 1 onto both images, re-prompt with the boxes found
+            map_response_list = self.tokenizer.batch_decode(batch.batch["map_responses"], skip_special_tokens=False)
+            bboxs_text_list = [parse_points_text_from_content(r) for r in map_response_list]
+            batch = batch.union(self._stage2_batch(batch, bboxs_text_list))
+            gen_batch = batch.pop(batch_keys=["input_ids", "attention_mask", "position_ids"], non_tensor_batch_keys=["multi_modal_sat_data"])
+            gen_batch.non_tensor_batch["multi_modal_data"] = gen_batch.non_tensor_batch.pop("multi_modal_sat_data")
+            ga = cfg.actor_infer.generating_args or {}
+            keep = ga.get("num_return_sequences", 1)
+            ga["num_return_sequences"] = 1                      # stage 2 never fans out (reference :838-852)
+            out = self._generate(gen_batch, global_step)
+            ga["num_return_sequences"] = keep
+            out.batch.pop("prompt_id", None)
+            batch = batch.union(out)
+            seg_batch = batch.pop(batch_keys=["responses", "prompts"], non_tensor_batch_keys=["seg_image"])
+            seg_out = self.seg_infer.segment_v4_sat(seg_batch)
+            seg_out.meta_info.pop("metrics", None)
+            batch = batch.union(seg_out)
+            batch.non_tensor_batch["sat_mask"] = batch.non_tensor_batch.pop("mask")
+            batch.non_tensor_batch["sat_visual_prompt"] = batch.non_tensor_batch.pop("visual_prompt")
+            # ---- score and write
+            sat_response_list = self.tokenizer.batch_decode(batch.batch["responses"], skip_special_tokens=False)
+            nt = batch.non_tensor_batch
+            giou_list = []
+            for i in range(len(batch)):
+                gt_mask = np.array(nt["gt_mask"][i].convert("L"))
+                giou_list.append(compute_giou(nt["sat_mask"][i], gt_mask))
+                vp1 = nt["map_visual_prompt"][i][0] if len(nt["map_visual_prompt"][i]) else {}
+                vp2 = nt["sat_visual_prompt"][i][0] if len(nt["sat_visual_prompt"][i]) else {}
+                sid = nt["id"][i]
+                from PIL import Image
+                Image.fromarray(nt["map_mask"][i].astype(np.uint8) * 255).save(os.path.join(dirs["stage1"], f"{sid}.png"))
+                Image.fromarray(nt["sat_mask"][i].astype(np.uint8) * 255).save(os.path.join(dirs["stage2"], f"{sid}.png"))
+                draw_visual_prompt(nt["seg_image"][i], nt["map_mask"][i], vp1).save(os.path.join(dirs["render1"], f"{sid}.png"))
+                draw_visual_prompt(nt["seg_image"][i], nt["sat_mask"][i], vp2).save(os.path.join(dirs["render2"], f"{sid}.png"))
+                with open(os.path.join(dirs["stage1"], f"{sid}.txt"), "w") as f:
+                    f.write(map_response_list[i])
+                with open(os.path.join(dirs["stage2"], f"{sid}.txt"), "w") as f:
+                    f.write(sat_response_list[i])
+            print(f"giou_acc: {np.mean(giou_list)}")
+            all_giou.extend(giou_list)
+            global_step += 1
+        local = torch.tensor(all_giou, dtype=torch.float64).reshape(-1, 1)
         if self.world > 1:
-            local = dp.all_gather_rows(local.cuda() if torch.cuda.is_available() else local, self.n_samples).cpu()
+            local = dp.all_gather_rows(local.cuda() if torch.cuda.is_available() else local, self.n_samples * n_ret).cpu()
         giou_acc = float(local.mean()) if local.numel() else 0.0
         if self.rank == 0:
             print(f"giou_acc: {giou_acc}")
             with open(os.path.join(res_dir, "iou_acc.txt"), "w") as f:
-                f.write(str(giou_acc))
+                f.write(f"giou_acc: {giou_acc}")
         return giou_acc

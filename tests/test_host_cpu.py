@@ -172,3 +172,178 @@ def test_sampling_policy_cpu():
     draws = sampling.sample(logits[:1].repeat(20000, 1), T, generator=g)
     freq = torch.bincount(draws, minlength=5).float() / 20000
     assert float((freq - want).abs().max()) < 0.015
+
+
+# ------------------------------------------------------------------------------------------------ pipeline host side (A2, A3, A7, A10, A14, A15)
+def _tiny_cfg(tmp, **over):
+    from roll.pipeline.rlvr.rlvr_config import SocioSegConfig
+    d = {"output_dir": str(tmp), "prompt_length": 640, "response_length": 160, "rollout_batch_size": 3, "pretrain": "synthetic:tiny",
+         "actor_infer": {"model_args": {"model_name_or_path": "synthetic:tiny"},
+                         "generating_args": {"max_new_tokens": 160, "temperature": 0, "top_k": 1, "top_p": 1.0, "num_beams": 1, "num_return_sequences": 1},
+                         "strategy_args": {"strategy_name": "vllm", "strategy_config": {"max_batch": 4, "max_patches": 4096, "max_ctx": 832}}},
+         "seg_infer": {"model_args": {}, "strategy_args": {"strategy_name": "seg_infer"}}}
+    d.update(over)
+    return SocioSegConfig.from_dict(d)
+
+
+def test_byte_tokenizer_and_processor_contract():
+    from socioreasoner_amd.config import geometry_3b, geometry_tiny
+    from socioreasoner_amd.textproc import ByteTokenizer, SyntheticProcessor
+    from PIL import Image
+    for geom in (geometry_tiny(), geometry_3b()):
+        tok = ByteTokenizer(geom)
+        s = "<|im_start|>user\nFind 'école' <|vision_start|><|image_pad|><|vision_end|> ok<|im_end|>\n"
+        ids = tok.encode(s)
+        assert tok.decode(ids) == s and max(ids) < geom.text.vocab_size
+        assert ids.count(geom.image_token_id) == 1 and tok.convert_tokens_to_ids("<|vision_start|>") == geom.vision_start_token_id
+        assert tok.decode(ids, skip_special_tokens=True) == "user\nFind 'école'  ok\n"
+        padded = tok.pad({"input_ids": [ids, ids[:5]]}, padding="max_length", max_length=len(ids) + 3)
+        assert padded["input_ids"].shape == (2, len(ids) + 3) and padded["attention_mask"][1].tolist() == [0] * (len(ids) - 2) + [1] * 5
+        assert padded["input_ids"][1, 0] == geom.pad_token_id
+        with pytest.raises(ValueError):
+            tok.pad({"input_ids": [ids]}, padding="max_length", max_length=4)
+    proc = SyntheticProcessor(geometry_tiny())
+    text = proc.apply_chat_template([{"role": "user", "content": [{"type": "image"}, {"type": "image"}, {"type": "text", "text": "hi"}]}])
+    assert text.count("<|image_pad|>") == 2 and text.endswith("<|im_start|>assistant\n")
+    f = proc(images=[Image.new("RGB", (448, 448)), Image.new("RGB", (300, 200))], text=text)
+    g = f["image_grid_thw"].tolist()
+    assert g[0] == [1, 32, 32] and g[1] == [1, 196 // 14, 308 // 14]
+    n_img = sum(1 for t in f["input_ids"][0] if t == proc.geom.image_token_id)
+    assert n_img == 256 + (196 // 14) * (308 // 14) // 4
+    with pytest.raises(ValueError):
+        proc(images=[Image.new("RGB", (56, 56))], text=text)
+
+
+def test_collator_and_encode_function_layout(tmp_path):
+    """A2/A3/A5/A14: encode_function + DataCollatorWithPaddingForMultiSeg give the reference's keys, left padding, the
+    engine payload and mRoPE ids equal to the oracle's get_rope_index on the un-padded prompt; a SocioSeg folder written
+    to disk reads back to the same batch."""
+    import torch
+    from oracle import host_ref as H
+    from roll.datasets.collator import DataCollatorWithPaddingForMultiSeg
+    from roll.pipeline.rlvr import rlvr_socioseg_vlm_pipeline_infer as P
+    from socioreasoner_amd import socioseg_data
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.textproc import SyntheticProcessor
+    geom = geometry_tiny()
+    proc = SyntheticProcessor(geom)
+    proc.image_processor.max_pixels, proc.image_processor.min_pixels = 768 * 768, 56 * 56
+    samples = socioseg_data.synthetic_socioseg(3, size=112)
+    samples[1]["sat_image"] = samples[1]["sat_image"].resize((150, 100))        # ragged: different grid per image
+    raw = {k: [s[k] for s in samples] for k in samples[0]}
+    enc = P.encode_function(raw, proc)
+    assert set(enc) == {"id", "prompt_map", "question", "gt_mask", "gt_bbox", "gt_object", "image_sat", "image_map", "seg_image", "image", "image_flag", "tag"}
+    assert enc["image"][1][1].size == (140, 112) and enc["seg_image"][1].size == (150, 100) and all(enc["image_flag"])
+    assert "Please find 'the commercial district near the river' with bboxs." in enc["prompt_map"][1]
+    coll = DataCollatorWithPaddingForMultiSeg(tokenizer=proc.tokenizer, processor=proc, extra_data_provider=P.get_extra_data_provider(processor=proc),
+                                              max_length=900, image_key="image", padding="max_length", gt_object_key="gt_object", gt_bbox_key="gt_bbox")
+    batch = coll([{k: v[i] for k, v in enc.items()} for i in range(3)])
+    assert batch["map_input_ids"].shape == (3, 900) and batch["map_position_ids"].shape == (3, 3, 900)
+    for k in ("multi_modal_map_data", "multi_modal_map_inputs", "question", "gt_mask", "gt_object", "seg_image", "image_map", "gt_bbox", "image", "id"):
+        assert isinstance(batch[k], np.ndarray) and batch[k].dtype == object and len(batch[k]) == 3, k
+    for i in range(3):
+        mask = batch["map_attention_mask"][i].bool()
+        n = int(mask.sum())
+        assert not mask[: 900 - n].any() and mask[900 - n:].all()                              # left padded
+        ids = batch["map_input_ids"][i][mask]
+        payload = batch["multi_modal_map_data"][i]
+        assert payload["prompt_token_ids"].count(geom.image_token_id) == 2 and len(payload["multi_modal_data"]["image"]) == 2
+        grids = batch["multi_modal_map_inputs"][i]["image_grid_thw"]
+        assert int((ids == geom.image_token_id).sum()) == int((grids.prod(-1) // 4).sum())
+        want, _ = H.get_rope_index(ids[None].numpy(), grids.numpy(), None, image_token_id=geom.image_token_id,
+                                   vision_start_token_id=geom.vision_start_token_id)
+        assert np.array_equal(batch["map_position_ids"][i][:, mask].numpy(), np.asarray(want)[:, 0])
+    # folder round trip
+    socioseg_data.write_socioseg_folder(samples, str(tmp_path), "test")
+    back = socioseg_data.load_socioseg_folder(str(tmp_path), "test")
+    assert [s["id"] for s in back] == [s["id"] for s in samples] and back[2]["problem"] == samples[2]["problem"]
+    enc2 = P.encode_function({k: [s[k] for s in back] for k in back[0]}, proc)
+    batch2 = coll([{k: v[i] for k, v in enc2.items()} for i in range(3)])
+    assert torch.equal(batch2["map_input_ids"], batch["map_input_ids"]) and enc2["gt_bbox"] == enc["gt_bbox"]
+    # a broken image -> text-only sample with a black stand-in (reference behaviour)
+    raw["map_image"][0] = "/nonexistent/map.png"
+    enc3 = P.encode_function(raw, proc)
+    assert enc3["image_flag"] == [False, True, True] and "<|image_pad|>" not in enc3["prompt_map"][0]
+    b3 = coll([{k: v[0] for k, v in enc3.items()}])
+    assert "multi_modal_data" not in b3["multi_modal_map_data"][0]
+
+
+def test_gt_components_and_boxes():
+    from socioreasoner_amd import socioseg_data as D
+    m = np.zeros((64, 64), np.uint8)
+    m[2:10, 3:20] = 255
+    m[10:12, 20:22] = 255          # touches the first blob diagonally: 8-connectivity joins them
+    m[40:50, 40:60] = 255
+    m[30, 5] = 255                 # 1 px: counted as a component, too small for a box
+    from PIL import Image
+    im = Image.fromarray(m, mode="L")
+    assert D.count_components([im, im.convert("RGB")]) == [3, 3]
+    assert json.loads(D.get_bboxes([im])[0]) == [{"bbox_2d": [3, 2, 22, 12]}, {"bbox_2d": [40, 40, 60, 50]}]
+
+
+def test_actor_worker_and_scheduler_with_fake_strategy(tmp_path):
+    """A7/A8/A15: ActorWorker.generate injects eos/pad and lays the strategy output out with postprocess_generate (checked
+    against the oracle restatement); the scheduler's request-level mode returns the same tensors as the batch mode."""
+    import torch
+    from oracle import host_ref as H
+    from roll.distributed.scheduler.generate_scheduler import GenerateScheduler
+    from roll.distributed.scheduler.protocol import DataProto
+    from roll.distributed.strategy.mi355x_strategy import Mi355xStrategy
+    from roll.pipeline.base_worker import ActorWorker
+    from socioreasoner_amd import hostops
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.textproc import ByteTokenizer
+    cfg = _tiny_cfg(tmp_path, prompt_length=12, response_length=6)
+    tok = ByteTokenizer(geometry_tiny())
+    seen = {}
+
+    class Fake(Mi355xStrategy):          # keeps the real request loop (start_server / add_request), fakes the engine
+        max_batch = 2
+
+        def initialize(self, model_provider=None):
+            import queue
+            self.command_queue, self.tokenizer = queue.Queue(), tok
+
+        def generate(self, batch, generation_config):
+            seen["gc"] = dict(generation_config)
+            ids, mask = batch.batch["input_ids"], batch.batch["attention_mask"]
+            rows = []
+            for r, m in zip(ids, mask):               # response = reversed prompt tail + eos, length depends on the prompt
+                p = r[m.bool()].tolist()
+                rows.append(list(reversed(p))[: 1 + len(p) % 4] + [tok.eos_token_id])
+            n = int(generation_config["num_return_sequences"])
+            rows = [x for x in rows for _ in range(n)]
+            out = hostops.gather_outputs_to_pad_tensor(rows, generation_config["pad_token_id"], device=ids.device)
+            return hostops.concatenate_input_and_output(ids, out, n)
+
+    w = ActorWorker(cfg.actor_infer, cfg, 0, 1, 0, "actor_infer")
+    w.strategy = Fake(w)
+    w.strategy.initialize()
+    w.tokenizer = tok
+    rng = np.random.default_rng(0)
+    ids = torch.full((5, 12), tok.pad_token_id, dtype=torch.long)
+    mask = torch.zeros(5, 12, dtype=torch.long)
+    for i, n in enumerate([12, 7, 9, 3, 10]):
+        ids[i, 12 - n:] = torch.from_numpy(rng.integers(0, 250, n))
+        mask[i, 12 - n:] = 1
+    pos = (mask.cumsum(-1) - 1).clamp(min=0)[:, None, :].repeat(1, 3, 1)
+    def fresh():
+        return DataProto(batch={"input_ids": ids.clone(), "attention_mask": mask.clone(), "position_ids": pos.clone()}, non_tensor_batch={})
+    sched = GenerateScheduler()
+    out0 = sched.generate(fresh(), w, cfg)
+    assert seen["gc"]["eos_token_id"] == [tok.eos_token_id] and seen["gc"]["pad_token_id"] == tok.pad_token_id
+    assert set(out0.batch) == {"prompts", "responses", "input_ids", "attention_mask", "position_ids", "prompt_mask", "response_mask"}
+    assert out0.batch["input_ids"].shape == (5, 18) and out0.batch["position_ids"].shape == (5, 3, 18)
+    raw = w.strategy.generate(fresh(), dict(seen["gc"]))
+    want = H.postprocess_generate(ids.numpy(), mask.numpy(), pos.numpy(), raw.numpy(), 1, 18, tok.eos_token_id, tok.pad_token_id)
+    for k, v in want.items():
+        assert torch.equal(out0.batch[k], torch.as_tensor(v)), k
+    cfg["generate_opt_level"] = 1                     # request-level dispatch through start_server / add_request
+    out1 = sched.generate(fresh(), w, cfg)
+    for k in want:
+        assert torch.equal(out1.batch[k], out0.batch[k]), k
+    # n = 2 expands neighbours-adjacent
+    cfg["generate_opt_level"] = 0
+    cfg.actor_infer.generating_args["num_return_sequences"] = 2
+    out2 = sched.generate(fresh(), w, cfg)
+    assert out2.batch["responses"].shape[0] == 10 and torch.equal(out2.batch["responses"][0::2], out0.batch["responses"])
