@@ -145,8 +145,6 @@ int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, floa
 int sr_op_resid_rmsnorm(void* x, const float* partials, int ksplit, const void* w, void* out, int rows, int H, float eps,
                         void* stream);
 int sr_op_argmax(const float* logits, int rows, int V, int32_t* out_idx, void* stream);
-/* cache warm-up of a weight region a later launch streams (tile_bytes > 0: XCD-matched, see k_prefetch) */
-int sr_op_prefetch(const void* base, long long bytes, long long tile_bytes, int blocks, void* stream);
 int sr_version(void);
 
 #ifdef __cplusplus

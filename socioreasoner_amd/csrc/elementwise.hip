@@ -354,30 +354,6 @@ __global__ __launch_bounds__(256) void k_load2d(const void* src, int dtype, long
 }
 
 
-// L2 / Infinity-Cache warm-up of a weight region that a LATER launch streams: plain (temporal) 16-byte loads whose
-// values are discarded.  `tile_bytes` > 0: the consumer's block c reads bytes [c*tile_bytes, (c+1)*tile_bytes) and runs
-// on XCD c % 8 (round-robin workgroup dispatch), so prefetch block j touches only tiles c == j (mod 8) and the lines
-// land in the L2 of the XCD that will want them.
-__global__ __launch_bounds__(256) void k_prefetch(const uint4* base, long long bytes, long long tile_bytes, unsigned* sink) {
-    const long long nseg = bytes / 4096;              // 4 KB = one block-wide 16-byte load
-    unsigned acc = 0;
-    if (tile_bytes > 0) {
-        const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3, nrank = (gridDim.x + 7 - xcd) >> 3;
-        const long long spt = tile_bytes / 4096, ntile = bytes / tile_bytes;
-        const long long mine = ((ntile + 7 - xcd) >> 3) * spt;          // segments of this XCD's tiles
-        for (long long q = rank; q < mine; q += nrank) {
-            const long long tile = (q / spt) * 8 + xcd, seg = tile * spt + q % spt;
-            const uint4 v = base[seg * 256 + threadIdx.x];
-            acc ^= v.x ^ v.y ^ v.z ^ v.w;
-        }
-    } else {
-        for (long long seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-            const uint4 v = base[seg * 256 + threadIdx.x];
-            acc ^= v.x ^ v.y ^ v.z ^ v.w;
-        }
-    }
-    if (acc == 0x9E3779B9u && sink) *sink = acc;      // never true in practice; keeps the loads alive
-}
 }  // namespace
 
 int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, long long cols, bf16_t* dst, long long dst_ld,
@@ -455,12 +431,6 @@ int launch_patchify(hipStream_t s, const uint8_t* img, int h, int w, const bf16_
 int launch_f32_to_bf16_pad(hipStream_t s, const float* in, int rows, int cols, bf16_t* out, int ld_out) {
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(k_f32_to_bf16_pad, dim3(rows), dim3(256), 0, s, in, cols, out, ld_out);
-    SR_CHECK_LAUNCH();
-    return 0;
-}
-int launch_prefetch(hipStream_t s, const void* base, long long bytes, long long tile_bytes, int blocks, unsigned* sink) {
-    if (bytes < 4096 || blocks <= 0) return 0;
-    hipLaunchKernelGGL(k_prefetch, dim3(blocks), dim3(256), 0, s, static_cast<const uint4*>(base), bytes, tile_bytes, sink);
     SR_CHECK_LAUNCH();
     return 0;
 }

@@ -976,9 +976,6 @@ int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, floa
 int sr_op_resid_rmsnorm(void* x, const float* partials, int ksplit, const void* w, void* out, int rows, int H, float eps, void* stream) {
     SR_WRAP(launch_resid_rmsnorm((hipStream_t)stream, (bf16_t*)x, partials, ksplit, (const bf16_t*)w, (bf16_t*)out, rows, H, eps));
 }
-int sr_op_prefetch(const void* base, long long bytes, long long tile_bytes, int blocks, void* stream) {
-    SR_WRAP(launch_prefetch((hipStream_t)stream, base, bytes, tile_bytes, blocks, nullptr));
-}
 int sr_op_argmax(const float* logits, int rows, int V, int32_t* out_idx, void* stream) {
     SR_WRAP(launch_argmax((hipStream_t)stream, logits, rows, V, out_idx));
 }

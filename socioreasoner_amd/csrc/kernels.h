@@ -109,7 +109,6 @@ struct StepArgs {
     const bf16_t* table; bf16_t* x; int H; int table_tiled;     // embedding gather of the token fed back
     const long long* chosen;    // optional [B]: this step's token picked by the caller (replaces the greedy argmax)
 };
-int launch_prefetch(hipStream_t s, const void* base, long long bytes, long long tile_bytes, int blocks, unsigned* sink);
 int launch_step(hipStream_t s, const StepArgs& a);
 int launch_next_ids(hipStream_t s, const float* amax_val, const int* amax_idx, int n_part, int B, long long* out);
 int launch_synth_fill(hipStream_t s, bf16_t* out, long long n, uint32_t key, float base, float scale);

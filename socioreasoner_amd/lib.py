@@ -58,7 +58,6 @@ SIGNATURES = {
     "sr_op_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i, _i, C.c_float, _vp]),
     "sr_op_resid_rmsnorm": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, C.c_float, _vp]),
     "sr_op_argmax": (C.c_int, [_vp, _i, _i, _vp, _vp]),
-    "sr_op_prefetch": (C.c_int, [_vp, C.c_longlong, C.c_longlong, _i, _vp]),
 }
 
 
