@@ -46,6 +46,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="tiles per GPU per step (1 = configs[1], 32 = configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--continuous", action="store_true",
+                    help="serve the tiles through the continuous-batching scheduler (configs[2]: admit on finish, 2x batch requests)")
+    ap.add_argument("--gather-logits", action="store_true",
+                    help="verification mode: all-gather the float32 logits of every decode step (north_star's literal exchange)")
     args = ap.parse_args()
 
     from socioreasoner_amd import dp, hostops, raster, synthetic
@@ -83,15 +87,40 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     phase_ms = {"vit": 0.0, "prefill": 0.0, "decode": 0.0, "raster": 0.0}
 
+    def step_continuous():
+        """2*B requests through B rows: the second half is admitted as rows free up (EOS is ignored by the metric, so all
+        rows of a wave finish together; the point is the measured cost of the request-level path)."""
+        from socioreasoner_amd.serving import ContinuousBatcher, Request
+        cb = ContinuousBatcher(eng, eos=[], pad_id=0, steps_per_poll=16)
+        reqs = [Request(ids=ids[k % B], pos3=pos3[k % B], max_new=N_NEW, images=[imgs[k % B]], grids=[grid]) for k in range(2 * B)]
+        toks = cb.run(reqs)
+        counts = torch.empty(2 * B, 2, dtype=torch.int64, device=dev)
+        for k in range(2 * B):
+            acc = torch.zeros(756, 756, dtype=torch.uint8, device=dev)
+            for m in masks[k % B]:
+                raster.mask_union_(acc, m)
+            counts[k] = raster.iou_counts(raster.resize_nearest(acc, 768, 768), gts[k % B])
+        res = torch.cat([torch.tensor(toks, dtype=torch.int64, device=dev), counts], dim=1)
+        if world > 1:
+            res = dp.all_gather_rows(res, 2 * B * world)
+        return res
+
     def step(record=False):
+        if args.continuous:
+            return step_continuous()
         e0, e1, e2, e3, e4 = ev(), ev(), ev(), ev(), ev()
         e0.record()
         pix = torch.cat([eng.patchify(im) for im in imgs], dim=0)
         emb = eng.vit_forward(pix, grids)
         e1.record()
-        eng.prefill(ids, pos3, emb)
+        first = eng.prefill(ids, pos3, emb, return_logits=args.gather_logits)
         e2.record()
-        toks = eng.decode(N_NEW, use_graph=not args.no_graph)
+        if args.gather_logits:
+            alltoks, bad = dp.decode_with_logits_gather(lambda t: eng.decode_step(t), first, N_NEW, B * world)
+            assert bad == 0, f"{bad} on-device argmax results differ from the argmax of the gathered logits"
+            toks = alltoks[rank * B:(rank + 1) * B]
+        else:
+            toks = eng.decode(N_NEW, use_graph=not args.no_graph)
         e3.record()
         counts = torch.empty(B, 2, dtype=torch.int64, device=dev)
         for b in range(B):
@@ -123,7 +152,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    tiles_per_s = world * B * args.steps / dt
+    tiles_per_s = world * B * (2 if args.continuous else 1) * args.steps / dt
 
     # ---- roofline of the dominant kernel (k_gemv, the decode weight stream): HIP events on the launch stream around
     # the exact per-step launch sequence of that kernel (145 launches: 4 per layer + LM head) on weight-sized operands
@@ -195,14 +224,15 @@ def main():
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_ms * 1e3, 2),
                 "launches_per_decode_step": n_launch,
-                "decode_step_ms": round(decode_step_ms, 4),
-                "decode_step_achieved_GBs": round((wl + wh + kv_bytes) / (decode_step_ms * 1e-3) / 1e9, 1)}
+                "decode_step_ms": round(decode_step_ms, 4) if decode_step_ms > 0 else None,
+                "decode_step_achieved_GBs": round((wl + wh + kv_bytes) / (decode_step_ms * 1e-3) / 1e9, 1) if decode_step_ms > 0 else None}
         del wq, wo, wg, wd, wv
         vit_ms = phase_ms["vit"] / args.steps
         pre_ms = phase_ms["prefill"] / args.steps
         phases = {k: round(v / args.steps, 3) for k, v in phase_ms.items()}
-        phases["vit_mfma_frac"] = round(VIT_GFLOP * B / (vit_ms * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)
-        phases["prefill_mfma_frac"] = round(PREFILL_GFLOP * B / (pre_ms * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)
+        if not args.continuous:      # the request-level path interleaves the phases: no per-phase split
+            phases["vit_mfma_frac"] = round(VIT_GFLOP * B / (vit_ms * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)
+            phases["prefill_mfma_frac"] = round(PREFILL_GFLOP * B / (pre_ms * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
@@ -213,7 +243,11 @@ def main():
             "config": {"workload": f"SocioReasoner-3B bf16, batch={B} tile(s)/GPU, 448x448 synthetic tiles, 448-token prompt, "
                                    f"greedy decode of {N_NEW} tokens (EOS ignored), raster tail; random-init weights "
                                    f"(counter-based generator, seed 0)" + (" [BASELINE.json configs[1]]" if B == 1 else ""),
-                       "tiles_per_gpu_per_step": B, "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager"},
+                       "tiles_per_gpu_per_step": B * (2 if args.continuous else 1),
+                       "scheduling": "continuous batching (admit on finish) through B rows" if args.continuous else "static batch",
+                       "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",
+                       "exchange": "float32 logits all-gather per decode step (verification mode)" if args.gather_logits
+                       else "one all-gather of 1 KB result rows per tile"},
             "roofline": roof, "cpu_baseline": cpu, "phase_ms_per_step": phases,
             "weights_load_s": round(load_s, 1), "workspace_GB": round(eng.workspace_bytes / 1e9, 2),
             "result_checksum": int(res.sum().item()),

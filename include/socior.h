@@ -116,6 +116,23 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
  * logits [B, vocab] and their greedy ids int64 [B].  Asynchronous on `stream`; eos handling is the caller's. */
 int sr_decode_step(sr_engine* e, const int64_t* dev_last_ids, int B, float* dev_logits_out, int64_t* dev_next_ids, void* stream);
 
+/* Continuous batching (BASELINE.json configs[2]; replaces vLLM's request-level scheduling behind
+ * vllm_strategy.py:156-205): the max_batch batch rows have independent lifecycles, row index = KV-cache slot.
+ *   sr_rows_begin : all rows free.
+ *   sr_admit      : prefill n sequences into the free rows host_rows[0..n) WITHOUT disturbing running rows; sequence i may
+ *                   generate at most host_max_new[i] tokens (its row then reports finished).  Arguments as sr_prefill.
+ *   sr_rows_step  : n_steps decode steps for all rows (one hipGraph replay each); a row stops at its first eos token or
+ *                   at its limit, later positions are not written.  Asynchronous.
+ *   sr_rows_poll  : host copies of the per-row finished flags and generated-token counts (synchronises the stream).
+ *   sr_rows_read  : the first n generated tokens of a row (int32, device to device). */
+int sr_rows_begin(sr_engine* e, void* stream);
+int sr_admit(sr_engine* e, const int64_t* host_ids, const int64_t* host_pos3, const int32_t* host_seq_lens,
+             const int32_t* host_rows, const int32_t* host_max_new, int n, const void* dev_image_embeds, int n_image_rows,
+             float* dev_logits_out, void* stream);
+int sr_rows_step(sr_engine* e, int n_steps, const int32_t* host_eos, int n_eos, int32_t pad_id, void* stream);
+int sr_rows_poll(sr_engine* e, int32_t* host_finished, int32_t* host_steps, void* stream);
+int sr_rows_read(sr_engine* e, int row, int32_t* dev_tokens_out, int n, void* stream);
+
 /* K19-K22 raster tail -- replaces seg_strategy.py:58-65 (union, cv2.INTER_NEAREST resize),
  * rlvr_socioseg_vlm_pipeline_infer.py:45-58 (IoU counts) and :383-452 (render).  No engine needed. */
 int sr_mask_union(uint8_t* dev_acc, const uint8_t* dev_mask, size_t n, void* stream);

@@ -233,34 +233,83 @@ class Mi355xStrategy(InferenceStrategy):
         self.command_queue.put((command, data))
 
     def start_server(self, data: DataProto, request_complete_callback):
-        """Continuous batching in the sense of the reference's level-1 scheduler (vllm_strategy.py:156-205): drain
-        ADD / ABORT / STOP commands, run the queued requests in engine-sized batches, report each as it completes."""
+        """Request-level serving (reference vllm_strategy.py:156-205): ADD / ABORT / STOP commands arrive through the queue
+        while the loop runs; greedy requests are served by CONTINUOUS batching (socioreasoner_amd.serving: admit on finish,
+        one graph replay per token for all rows), sampling requests in engine-sized static batches.  Each request is
+        reported through the callback the moment its sequence ends."""
+        from socioreasoner_amd.serving import ContinuousBatcher, Request
         self.running = True
-        pending: List[DataProto] = []
+        batcher, bkey = None, None
+        sampled: List[DataProto] = []
+        stop = False
         while True:
+            busy = batcher is not None and not batcher.idle()
             try:
-                command, req = self.command_queue.get(timeout=0.01)
+                command, req = self.command_queue.get(timeout=0.0005 if busy or sampled else 0.01)
             except queue.Empty:
                 command, req = None, None
             name = getattr(command, "name", command)
             if name == "ADD":
-                pending.append(req)
+                gc = dict(req.meta_info.get("generation_config") or {})
+                greedy = sampling.is_greedy(gc) and float(gc.get("repetition_penalty", 1.0) or 1.0) == 1.0 and hasattr(self.engine, "rows_begin")
+                if not greedy or int(gc.get("num_return_sequences", 1) or 1) != 1:
+                    sampled.append(req)
+                else:
+                    eos = gc.get("eos_token_id") or [self.tokenizer.eos_token_id]
+                    eos = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos])]
+                    pad = int(gc.get("pad_token_id", self.tokenizer.pad_token_id))
+                    key = (tuple(eos), pad)
+                    if batcher is None or (key != bkey and batcher.idle()):
+                        batcher, bkey = ContinuousBatcher(self.engine, eos, pad), key
+                    if key != bkey:
+                        sampled.append(req)          # different stop set while rows are running: static path
+                    else:
+                        mm = req.non_tensor_batch.get("multi_modal_data") if req.non_tensor_batch else None
+                        ids_in = hostops.gather_unpadded_input_ids(req.batch["input_ids"].cpu(), req.batch["attention_mask"].cpu())[0]
+                        if mm is not None and mm[0].get("prompt_token_ids"):
+                            ids_in = mm[0]["prompt_token_ids"]
+                        imgs = (mm[0].get("multi_modal_data") or {}).get("image") if mm is not None else None
+                        ids, pos3, ims, grids = self._prepare(ids_in, imgs)
+                        room = self.engine.cfg.max_ctx - len(ids)
+                        if room < 1:
+                            raise ValueError(f"prompt of {len(ids)} tokens leaves no room in max_ctx {self.engine.cfg.max_ctx}")
+                        max_new = max(1, min(int(gc["max_new_tokens"]), self.engine.cfg.max_new_tokens, room))
+                        batcher.submit(Request(ids=ids, pos3=pos3, max_new=max_new, images=ims, grids=grids, tag=req))
             elif name == "ABORT":
                 rid = req.meta_info["request_id"]
-                pending = [p for p in pending if p.meta_info.get("request_id") != rid]
+                sampled = [p for p in sampled if p.meta_info.get("request_id") != rid]
+                if batcher is not None:      # queued requests can be dropped; a running row finishes and is discarded
+                    batcher.pending = type(batcher.pending)(r for r in batcher.pending if r.tag.meta_info.get("request_id") != rid)
+                    for r in batcher.active.values():
+                        if r.tag.meta_info.get("request_id") == rid:
+                            r.tag = None
             elif name == "STOP":
+                stop = True
+            if batcher is not None and not batcher.idle() and (self.command_queue.empty() or len(batcher.active) > 0):
+                def done(r, toks):
+                    if r.tag is None:
+                        return
+                    res = DataProto(meta_info=dict(r.tag.meta_info))
+                    res.meta_info["output_token_ids"] = [[int(t) for t in toks]]
+                    request_complete_callback(data=res)
+                batcher.pump(done)
+            if sampled and (len(sampled) >= self.max_batch or self.command_queue.empty()):
+                todo, sampled = sampled[: self.max_batch], sampled[self.max_batch:]
+                gc = todo[0].meta_info.get("generation_config")
+                if batcher is not None and not batcher.idle():
+                    sampled = todo + sampled      # rows are running: the static path needs the whole engine, wait
+                else:
+                    merged = DataProto.concat(todo)
+                    out = self.generate(merged, gc)
+                    batcher = None                # generate() re-initialises the batch rows
+                    P = merged.batch["input_ids"].shape[1]
+                    for row, r in zip(out, todo):
+                        res = DataProto(meta_info=dict(r.meta_info))
+                        res.meta_info["output_token_ids"] = [[int(t) for t in row[P:].tolist() if int(t) != int(gc.get("pad_token_id", -1))]]
+                        request_complete_callback(data=res)
+            if stop and (batcher is None or batcher.idle()) and not sampled:
                 self.running = False
                 return
-            if pending and (len(pending) >= self.max_batch or self.command_queue.empty()):
-                todo, pending = pending[: self.max_batch], pending[self.max_batch:]
-                merged = DataProto.concat(todo)
-                gc = todo[0].meta_info.get("generation_config")
-                out = self.generate(merged, gc)
-                P = merged.batch["input_ids"].shape[1]
-                for row, r in zip(out, todo):
-                    res = DataProto(meta_info=dict(r.meta_info))
-                    res.meta_info["output_token_ids"] = [[int(t) for t in row[P:].tolist() if int(t) != int(gc.get("pad_token_id", -1))]]
-                    request_complete_callback(data=res)
 
 
 class SegRasterStrategy(InferenceStrategy):

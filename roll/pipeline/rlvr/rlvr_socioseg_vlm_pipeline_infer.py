@@ -97,7 +97,7 @@ def render_image(bboxes_json: str, images: List[Any], mask: Union[np.ndarray, An
     for im in images:
         is_pil = hasattr(im, "convert")
         arr = np.asarray(im.convert("RGB")) if is_pil else np.asarray(im)
-        t = torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+        t = torch.from_numpy(np.array(arr, dtype=np.uint8, order="C")).cuda()
         raster.render_overlay_(t, m, boxes)
         res = t.cpu().numpy()
         if is_pil:

@@ -309,9 +309,10 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
         const int fin = a.finished[b];
         if (fin) tok = a.pad_id;
         if (step < a.max_new) a.tokens_out[(size_t)b * a.max_new + step] = tok;
+        if (!fin) a.n_gen[b] = step + 1;
         bool is_eos = false;
         for (int k = 0; k < a.n_eos; ++k) is_eos |= (tok == a.eos[k]);
-        if (!fin && is_eos) a.finished[b] = 1;
+        if (!fin && (is_eos || (a.row_limit && step + 1 >= a.row_limit[b]))) a.finished[b] = 1;
         a.cur_tok[b] = tok;
         int feed = tok;
         if (a.forced && step < a.max_new) feed = a.forced[(size_t)b * a.max_new + step];
@@ -354,6 +355,27 @@ __global__ __launch_bounds__(256) void k_load2d(const void* src, int dtype, long
 }
 
 
+
+// continuous batching: one thread per admitted sequence installs its row state; the pending first token goes into the
+// row's LM-head partials as a single (0, token) entry among -inf, which is what k_step reduces
+__global__ void k_admit_rows(AdmitArgs a) {
+    const int i = blockIdx.x;
+    if (i >= a.n) return;
+    const int r = a.rows[i];
+    if (threadIdx.x == 0) {
+        a.ctx_len[r] = a.ctx[i];
+        a.d_pos[r] = a.pos[i];
+        a.slots[r] = r;
+        a.finished[r] = 0;
+        a.step[r] = 0;
+        a.n_gen[r] = 0;
+        a.row_limit[r] = a.limit[i];
+    }
+    for (int k = threadIdx.x; k < a.n_part; k += blockDim.x) {
+        a.amax_val[(size_t)r * a.n_part + k] = k == 0 ? 0.0f : -INFINITY;
+        a.amax_idx[(size_t)r * a.n_part + k] = k == 0 ? a.first_tok[i] : 0x7fffffff;
+    }
+}
 }  // namespace
 
 int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, long long cols, bf16_t* dst, long long dst_ld,
@@ -443,6 +465,12 @@ int launch_argmax(hipStream_t s, const float* logits, int rows, int V, int* out_
 int launch_next_ids(hipStream_t s, const float* amax_val, const int* amax_idx, int n_part, int B, long long* out) {
     if (B <= 0) return 0;
     hipLaunchKernelGGL(k_next_ids, dim3(B), dim3(256), 0, s, amax_val, amax_idx, n_part, out);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_admit_rows(hipStream_t s, const AdmitArgs& a) {
+    if (a.n <= 0) return 0;
+    hipLaunchKernelGGL(k_admit_rows, dim3(a.n), dim3(256), 0, s, a);
     SR_CHECK_LAUNCH();
     return 0;
 }

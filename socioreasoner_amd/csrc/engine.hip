@@ -95,6 +95,10 @@ struct sr_engine {
     float *d_logits, *d_slabs, *d_amax_val;
     int *d_amax_idx, *d_cur_tok, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
     int n_part = 0;      // LM-head blocks = partial argmax entries per row
+    // continuous batching (sr_rows_*): admission scratch so that a prefill never touches the pending tokens of running rows
+    float *d_logits_adm = nullptr, *d_amax_val_adm = nullptr;
+    int *d_amax_idx_adm = nullptr, *d_row_limit = nullptr, *d_ngen = nullptr, *d_adm = nullptr;   // d_adm: [rows | ctx | pos | limit | first_tok] x 32
+    bool rows_mode = false;
     bf16_t *kcache, *vtcache;
     size_t kv_layer_elems;
     // ---- host staging (pinned) + its device mirror
@@ -253,6 +257,12 @@ void carve(sr_engine* e) {
     e->d_slabs = ar.take<float>(4 * B * H);
     e->d_amax_val = ar.take<float>(B * e->n_part);
     e->d_amax_idx = ar.take<int>(B * e->n_part);
+    e->d_logits_adm = ar.take<float>(B * c.t_vocab);
+    e->d_amax_val_adm = ar.take<float>(B * e->n_part);
+    e->d_amax_idx_adm = ar.take<int>(B * e->n_part);
+    e->d_row_limit = ar.take<int>(32);
+    e->d_ngen = ar.take<int>(32);
+    e->d_adm = ar.take<int>(5 * 32);
     e->d_chosen = ar.take<long long>(32);
     e->d_next = ar.take<long long>(32);
     e->d_cur_tok = ar.take<int>(32);
@@ -433,11 +443,11 @@ int ks_down(const sr_engine* e, int B) { return (B > 16 && e->t_inter_pad / 64 >
 
 // LM head on B rows of `x` (+ optional pending slabs): float32 logits + per-block argmax partials.
 // Small batches fuse the final RMSNorm (and the pending residual) into the GEMV prologue.
-int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending, hipStream_t s) {
+int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending, hipStream_t s, bool admission = false) {
     const sr_config& c = e->c;
     const int H = c.t_hidden;
-    GemvArgs g = gv(x, H, e->embed, B, c.t_vocab, H, e->d_logits, c.t_vocab);
-    g.amax_val = e->d_amax_val; g.amax_idx = e->d_amax_idx;
+    GemvArgs g = gv(x, H, e->embed, B, c.t_vocab, H, admission ? e->d_logits_adm : e->d_logits, c.t_vocab);
+    g.amax_val = admission ? e->d_amax_val_adm : e->d_amax_val; g.amax_idx = admission ? e->d_amax_idx_adm : e->d_amax_idx;
     if (fused_norms(e, B)) {
         g.norm_w = e->final_norm; g.eps = c.t_rms_eps;
         if (pending) { g.slabs = e->d_slabs; g.n_slabs = ks_down(e, B); g.x_out = x_alt; }
@@ -496,7 +506,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
 
 int enqueue_step(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, hipStream_t s, const long long* chosen = nullptr) {
     StepArgs a{e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(e->c.t_vocab, B, e->c.t_hidden, fused_norms(e, B) ? 1 : 0), e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished,
-               e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden, 1, chosen};
+               e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden, 1, chosen, e->d_row_limit, e->d_ngen};
     SR_TRY(launch_step(s, a));
     return 0;
 }
@@ -714,8 +724,8 @@ int sr_vit_forward(sr_engine* e, const void* pixels, int pixels_dtype, const int
     return 0;
 }
 
-int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_t* seq_lens, const int32_t* slots, int B,
-               const void* image_embeds, int n_image_rows, float* logits_out, void* stream) {
+static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_t* seq_lens, const int32_t* slots, int B,
+                        const void* image_embeds, int n_image_rows, float* logits_out, void* stream, const int32_t* limits) {
     if (!e || !ids || !pos3 || !seq_lens || !slots) return fail(e, -22, "sr_prefill: null argument");
     char miss[160];
     if (sr_weights_missing(e, miss, sizeof miss)) return fail(e, -61, "weights missing, e.g. '%s'", miss);
@@ -738,8 +748,8 @@ int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int3
     int* h_slot = h_pos + 3 * n_tok;
     int* h_idx = h_slot + n_tok;
     int* h_last = h_idx + n_tok;
-    int* h_state = h_last + 32;             // [ctx_len(32) | pos(32) | slots(32)]
-    AttnWork* h_work = reinterpret_cast<AttnWork*>(((uintptr_t)(h_state + 96) + 15) & ~(uintptr_t)15);
+    int* h_state = h_last + 32;             // [ctx_len(32) | pos(32) | slots(32) | limit(32)]
+    AttnWork* h_work = reinterpret_cast<AttnWork*>(((uintptr_t)(h_state + 128) + 15) & ~(uintptr_t)15);
     int n_work = 0, img_row = 0, t0 = 0;
     const int KVH = c.t_kv_heads;
     for (int b = 0; b < B; ++b) {
@@ -767,6 +777,7 @@ int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int3
         h_state[32 + b] = (int)maxpos;      // decode positions continue at max+1 on all three axes
                                             // (reference rule: roll/utils/functionals.py:816-818)
         h_state[64 + b] = slots[b];
+        h_state[96 + b] = limits ? limits[b] : 0x7f7f7f7f;
         t0 += S;
     }
     if (image_embeds && img_row != n_image_rows)
@@ -781,11 +792,20 @@ int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int3
     SR_TRY((int)hipMemcpyAsync(e->t_idx, dmirror(h_idx), (size_t)n_tok * 4, hipMemcpyDeviceToDevice, s));
     SR_TRY((int)hipMemcpyAsync(e->t_lastrow, dmirror(h_last), 32 * 4, hipMemcpyDeviceToDevice, s));
     SR_TRY((int)hipMemcpyAsync(e->t_work, dmirror(h_work), n_work * sizeof(AttnWork), hipMemcpyDeviceToDevice, s));
-    SR_TRY((int)hipMemcpyAsync(e->d_ctx_len, dmirror(h_state), 32 * 4, hipMemcpyDeviceToDevice, s));
-    SR_TRY((int)hipMemcpyAsync(e->d_pos, dmirror(h_state + 32), 32 * 4, hipMemcpyDeviceToDevice, s));
-    SR_TRY((int)hipMemcpyAsync(e->d_slots, dmirror(h_state + 64), 32 * 4, hipMemcpyDeviceToDevice, s));
-    SR_TRY((int)hipMemsetAsync(e->d_finished, 0, 32 * 4, s));
-    SR_TRY((int)hipMemsetAsync(e->d_step, 0, 32 * 4, s));
+    if (!limits) {       // static batch: rows 0..B-1 are (re)initialised, all other rows are dropped
+        SR_TRY((int)hipMemcpyAsync(e->d_ctx_len, dmirror(h_state), 32 * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemcpyAsync(e->d_pos, dmirror(h_state + 32), 32 * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemcpyAsync(e->d_slots, dmirror(h_state + 64), 32 * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemsetAsync(e->d_finished, 0, 32 * 4, s));
+        SR_TRY((int)hipMemsetAsync(e->d_step, 0, 32 * 4, s));
+        SR_TRY((int)hipMemsetAsync(e->d_row_limit, 0x7f, 32 * 4, s));
+        SR_TRY((int)hipMemsetAsync(e->d_ngen, 0, 32 * 4, s));
+    } else {             // admission: [rows | ctx | pos | limit] for the new rows only; installed after the LM head below
+        SR_TRY((int)hipMemcpyAsync(e->d_adm, dmirror(h_state + 64), 32 * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemcpyAsync(e->d_adm + 32, dmirror(h_state), 32 * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemcpyAsync(e->d_adm + 64, dmirror(h_state + 32), 32 * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemcpyAsync(e->d_adm + 96, dmirror(h_state + 96), 32 * 4, hipMemcpyDeviceToDevice, s));
+    }
 
     // ---- forward over the packed tokens
     const int H = c.t_hidden, QD = c.t_heads * 128;
@@ -809,12 +829,92 @@ int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int3
         if (int rc = gemm(e, s, e->t_act, e->t_inter_pad, w.down_w, n_tok, H, e->t_inter_pad, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID, 1)) return rc;
     }
     // last position of every sequence -> final norm -> tied LM head (hf:1386-1387) -> greedy token
-    SR_TRY(launch_gather_rows(s, e->t_x, e->t_lastrow, e->d_xa, B, H));
-    if (int rc = enqueue_lm_head(e, B, e->d_xa, e->d_xb, false, s)) return rc;
-    if (logits_out) SR_TRY((int)hipMemcpyAsync(logits_out, e->d_logits, (size_t)B * c.t_vocab * 4, hipMemcpyDeviceToDevice, s));
+    // (d_xn is decode scratch: rows in flight do not keep anything in it between steps)
+    bf16_t* xl = limits ? e->d_xn : e->d_xa;
+    SR_TRY(launch_gather_rows(s, e->t_x, e->t_lastrow, xl, B, H));
+    if (!limits) {
+        if (int rc = enqueue_lm_head(e, B, xl, e->d_xb, false, s)) return rc;
+        if (logits_out) SR_TRY((int)hipMemcpyAsync(logits_out, e->d_logits, (size_t)B * c.t_vocab * 4, hipMemcpyDeviceToDevice, s));
+        e->h_ctx_hi = 0;
+        for (int b = 0; b < B; ++b) e->h_ctx_hi = std::max(e->h_ctx_hi, (int)seq_lens[b]);
+        e->prefilled_B = B;
+        e->rows_mode = false;
+        return 0;
+    }
+    // admission: final norm + LM head into the admission scratch (B <= 4 fuses the norm; otherwise d_xa is free to hold it:
+    // k_step rewrites every row of d_xa before the next forward), greedy first token, then install the rows
+    {
+        GemvArgs g = gv(xl, H, e->embed, B, c.t_vocab, H, e->d_logits_adm, c.t_vocab);
+        g.amax_val = e->d_amax_val_adm; g.amax_idx = e->d_amax_idx_adm;
+        if (fused_norms(e, B)) { g.norm_w = e->final_norm; g.eps = c.t_rms_eps; }
+        else { SR_TRY(launch_rmsnorm(s, xl, e->final_norm, e->d_xa, B, H, c.t_rms_eps)); g.x = e->d_xa; }
+        SR_TRY(launch_gemv(s, g, GV_F32));
+    }
+    if (logits_out) SR_TRY((int)hipMemcpyAsync(logits_out, e->d_logits_adm, (size_t)B * c.t_vocab * 4, hipMemcpyDeviceToDevice, s));
+    SR_TRY(launch_argmax(s, e->d_logits_adm, B, c.t_vocab, e->d_adm + 128));
+    const int MB = c.max_batch;
+    AdmitArgs aa{e->d_adm, e->d_adm + 32, e->d_adm + 64, e->d_adm + 96, e->d_adm + 128, B,
+                 e->d_ctx_len, e->d_pos, e->d_slots, e->d_finished, e->d_step, e->d_row_limit, e->d_ngen,
+                 e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(c.t_vocab, MB, H, fused_norms(e, MB) ? 1 : 0)};
+    SR_TRY(launch_admit_rows(s, aa));
+    return 0;
+}
+
+int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_t* seq_lens, const int32_t* slots, int B,
+               const void* image_embeds, int n_image_rows, float* logits_out, void* stream) {
+    return prefill_impl(e, ids, pos3, seq_lens, slots, B, image_embeds, n_image_rows, logits_out, stream, nullptr);
+}
+
+// ---- continuous batching: batch rows with independent lifecycles (row index = KV slot); a decode step always runs all
+// max_batch rows, rows that are free or finished are masked by their `finished` flag
+int sr_rows_begin(sr_engine* e, void* stream) {
+    if (!e) return fail(e, -22, "sr_rows_begin: null engine");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<int> st(5 * 32, 0);
+    for (int i = 0; i < 32; ++i) { st[i] = 1; st[64 + i] = 1; st[96 + i] = 0; st[128 + i] = i; }   // ctx 1 | pos 0 | finished 1 | step 0 | slots
+    SR_TRY((int)hipMemcpyAsync(e->d_ctx_len, st.data(), 128, hipMemcpyHostToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->d_pos, st.data() + 32, 128, hipMemcpyHostToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->d_finished, st.data() + 64, 128, hipMemcpyHostToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->d_step, st.data() + 96, 128, hipMemcpyHostToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->d_slots, st.data() + 128, 128, hipMemcpyHostToDevice, s));
+    SR_TRY((int)hipMemsetAsync(e->d_row_limit, 0, 128, s));
+    SR_TRY((int)hipMemsetAsync(e->d_ngen, 0, 128, s));
+    SR_TRY((int)hipStreamSynchronize(s));
+    e->rows_mode = true;
+    e->prefilled_B = e->c.max_batch;
     e->h_ctx_hi = 0;
-    for (int b = 0; b < B; ++b) e->h_ctx_hi = std::max(e->h_ctx_hi, (int)seq_lens[b]);
-    e->prefilled_B = B;
+    return 0;
+}
+
+int sr_admit(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_t* seq_lens, const int32_t* rows, const int32_t* max_new,
+             int n, const void* image_embeds, int n_image_rows, float* logits_out, void* stream) {
+    if (!e || !rows || !max_new) return fail(e, -22, "sr_admit: null argument");
+    if (!e->rows_mode) return fail(e, -22, "sr_admit: call sr_rows_begin first");
+    for (int i = 0; i < n; ++i) {
+        if (max_new[i] < 1 || max_new[i] > e->c.max_new_tokens || seq_lens[i] + max_new[i] > e->c.max_ctx)
+            return fail(e, -22, "sr_admit: sequence %d (len %d, max_new %d) does not fit max_new_tokens %d / max_ctx %d", i, seq_lens[i],
+                        max_new[i], e->c.max_new_tokens, e->c.max_ctx);
+        for (int j = 0; j < i; ++j)
+            if (rows[i] == rows[j]) return fail(e, -22, "sr_admit: row %d given twice", rows[i]);
+    }
+    return prefill_impl(e, ids, pos3, seq_lens, rows, n, image_embeds, n_image_rows, logits_out, stream, max_new);
+}
+
+// one decode step (bookkeeping kernel + forward) captured once per (B, eos count, pad) and replayed
+static int ensure_decode_graph(sr_engine* e, int B, int n_eos, int pad_id) {
+    if (e->graph != nullptr && e->graph_B == B && e->graph_neos == n_eos && e->graph_pad == pad_id) return 0;
+    if (e->graph) { (void)hipGraphExecDestroy(e->graph); e->graph = nullptr; }
+    hipGraph_t g = nullptr;
+    SR_TRY((int)hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
+    int rc = enqueue_step(e, B, n_eos, pad_id, nullptr, e->cap_stream);
+    if (!rc) rc = enqueue_decode_forward(e, B, e->cap_stream);
+    hipError_t er = hipStreamEndCapture(e->cap_stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    SR_TRY((int)er);
+    er = hipGraphInstantiate(&e->graph, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    SR_TRY((int)er);
+    e->graph_B = B; e->graph_neos = n_eos; e->graph_pad = pad_id;
     return 0;
 }
 
@@ -825,6 +925,7 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
     if (B < 1 || B > c.max_batch || max_new < 1 || max_new > c.max_new_tokens || n_eos < 0 || n_eos > 32)
         return fail(e, -22, "sr_decode: B=%d max_new=%d n_eos=%d out of range", B, max_new, n_eos);
     (void)host_slots;   // slots were fixed by sr_prefill (kept in the signature for the continuous-batching scheduler)
+    if (e->rows_mode) return fail(e, -22, "sr_decode: the engine is in continuous-batching mode (use sr_rows_step)");
     if (B != e->prefilled_B) return fail(e, -22, "sr_decode: B=%d but %d sequences were prefilled", B, e->prefilled_B);
     if (e->h_ctx_hi + max_new > c.max_ctx)
         return fail(e, -22, "sr_decode: context %d + %d new tokens exceeds max_ctx %d", e->h_ctx_hi, max_new, c.max_ctx);
@@ -840,20 +941,7 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
         forced_dev = forced;
     }
     const bool graph_ok = use_graph && !logits_trace && !forced;
-    if (graph_ok && (e->graph == nullptr || e->graph_B != B || e->graph_neos != n_eos || e->graph_pad != pad_id)) {
-        if (e->graph) { (void)hipGraphExecDestroy(e->graph); e->graph = nullptr; }
-        hipGraph_t g = nullptr;
-        SR_TRY((int)hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
-        int rc = enqueue_step(e, B, n_eos, pad_id, nullptr, e->cap_stream);
-        if (!rc) rc = enqueue_decode_forward(e, B, e->cap_stream);
-        hipError_t er = hipStreamEndCapture(e->cap_stream, &g);
-        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-        SR_TRY((int)er);
-        er = hipGraphInstantiate(&e->graph, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        SR_TRY((int)er);
-        e->graph_B = B; e->graph_neos = n_eos; e->graph_pad = pad_id;
-    }
+    if (graph_ok) if (int rc = ensure_decode_graph(e, B, n_eos, pad_id)) return rc;
     int done = 0;
     std::vector<int> fin(B);
     for (int i = 0; i < max_new; ++i) {
@@ -893,9 +981,37 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
     return 0;
 }
 
+int sr_rows_step(sr_engine* e, int n_steps, const int32_t* host_eos, int n_eos, int32_t pad_id, void* stream) {
+    if (!e || !e->rows_mode) return fail(e, -22, "sr_rows_step: call sr_rows_begin first");
+    if (n_steps < 1 || n_eos < 0 || n_eos > 32) return fail(e, -22, "sr_rows_step: n_steps=%d n_eos=%d out of range", n_steps, n_eos);
+    hipStream_t s = (hipStream_t)stream;
+    if (n_eos) SR_TRY((int)hipMemcpyAsync(e->d_eos, host_eos, n_eos * 4, hipMemcpyHostToDevice, s));
+    const int B = e->c.max_batch;
+    if (int rc = ensure_decode_graph(e, B, n_eos, pad_id)) return rc;
+    for (int i = 0; i < n_steps; ++i) SR_TRY((int)hipGraphLaunch(e->graph, s));
+    return 0;
+}
+
+int sr_rows_poll(sr_engine* e, int32_t* host_finished, int32_t* host_steps, void* stream) {
+    if (!e || !e->rows_mode || !host_finished || !host_steps) return fail(e, -22, "sr_rows_poll: bad argument / not in rows mode");
+    hipStream_t s = (hipStream_t)stream;
+    SR_TRY((int)hipMemcpyAsync(host_finished, e->d_finished, e->c.max_batch * 4, hipMemcpyDeviceToHost, s));
+    SR_TRY((int)hipMemcpyAsync(host_steps, e->d_ngen, e->c.max_batch * 4, hipMemcpyDeviceToHost, s));
+    SR_TRY((int)hipStreamSynchronize(s));
+    return 0;
+}
+
+int sr_rows_read(sr_engine* e, int row, int32_t* dev_tokens_out, int n, void* stream) {
+    if (!e || !e->rows_mode || row < 0 || row >= e->c.max_batch || n < 0 || n > e->c.max_new_tokens)
+        return fail(e, -22, "sr_rows_read: bad argument / not in rows mode");
+    SR_TRY((int)hipMemcpyAsync(dev_tokens_out, e->d_tokens + (size_t)row * e->c.max_new_tokens, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
 int sr_decode_step(sr_engine* e, const int64_t* dev_last_ids, int B, float* dev_logits_out, int64_t* dev_next_ids, void* stream) {
     if (!e) return fail(e, -22, "sr_decode_step: null engine");
     const sr_config& c = e->c;
+    if (e->rows_mode) return fail(e, -22, "sr_decode_step: the engine is in continuous-batching mode");
     if (B < 1 || B != e->prefilled_B) return fail(e, -22, "sr_decode_step: B=%d but %d sequences were prefilled", B, e->prefilled_B);
     if (e->h_ctx_hi + 1 > c.max_ctx) return fail(e, -22, "sr_decode_step: context %d would exceed max_ctx %d", e->h_ctx_hi + 1, c.max_ctx);
     e->h_ctx_hi += 1;

@@ -108,8 +108,17 @@ struct StepArgs {
     const int* forced;          // optional [B][max_new]: token fed back instead of the greedy one (teacher forcing)
     const bf16_t* table; bf16_t* x; int H; int table_tiled;     // embedding gather of the token fed back
     const long long* chosen;    // optional [B]: this step's token picked by the caller (replaces the greedy argmax)
+    const int* row_limit;       // optional [B]: a row finishes after this many generated tokens (continuous batching)
+    int* n_gen;                 // [B]: tokens generated while the row was live (pads written after eos are not counted)
 };
 int launch_step(hipStream_t s, const StepArgs& a);
+// continuous batching: install n freshly prefilled sequences into batch rows (state + pending first token)
+struct AdmitArgs {
+    const int* rows; const int* ctx; const int* pos; const int* limit; const int* first_tok; int n;
+    int* ctx_len; int* d_pos; int* slots; int* finished; int* step; int* row_limit; int* n_gen;
+    float* amax_val; int* amax_idx; int n_part;
+};
+int launch_admit_rows(hipStream_t s, const AdmitArgs& a);
 int launch_next_ids(hipStream_t s, const float* amax_val, const int* amax_idx, int n_part, int B, long long* out);
 int launch_synth_fill(hipStream_t s, bf16_t* out, long long n, uint32_t key, float base, float scale);
 int launch_fill_zero(hipStream_t s, void* p, size_t bytes);

@@ -55,6 +55,30 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
 
 
+def decode_with_logits_gather(step_fn, first_logits: torch.Tensor, n_new: int, n_total: int, group=None):
+    """BASELINE.json north_star's literal exchange ("RCCL all-gather of logits over xGMI only"), kept as a verification
+    mode: every decode step all-gathers the float32 last-position logits [B_local, V] of all ranks, every rank takes the
+    greedy token of ALL tiles from the gathered rows and feeds its own rows back through ``step_fn(ids) -> (logits,
+    engine_greedy_ids)`` (Engine.decode_step).  Returns (tokens int64 [n_total, n_new], number of positions where the
+    engine's own on-device argmax disagreed with the argmax of the gathered logits -- must be 0).
+    Costs 608 KB per tile per step on the wire; the default path gathers 1 KB of results per tile once."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    lo = sum(split_sizes(n_total, world)[:rank])
+    b_local = first_logits.shape[0]
+    toks, mismatches = [], 0
+    logits, own = first_logits, None
+    for i in range(n_new):
+        allv = all_gather_rows(logits, n_total, group)                # [n_total, V]
+        pick = allv.argmax(dim=-1)
+        if own is not None:
+            mismatches += int((pick[lo:lo + b_local] != own).sum())
+        toks.append(pick)
+        if i + 1 < n_new:
+            logits, own = step_fn(pick[lo:lo + b_local].contiguous())
+    return torch.stack(toks, dim=1), mismatches
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

@@ -190,6 +190,48 @@ class Engine:
         self.steps_done = done.value
         return (toks, tr) if trace else toks
 
+    # ------------------------------------------------------------------ continuous batching (rows with independent lifecycles)
+    def rows_begin(self):
+        L.check(self.lib.sr_rows_begin(self._h, self._s()), self._h, "sr_rows_begin")
+        self._last_B = self.cfg.max_batch
+
+    def admit(self, rows: Sequence[int], ids: Sequence[np.ndarray], pos3: Sequence[np.ndarray], max_new: Sequence[int],
+              image_embeds: torch.Tensor | None = None, return_logits: bool = False):
+        """Prefill sequences into free batch rows without disturbing running ones; row i stops after max_new[i] tokens."""
+        n = len(ids)
+        lens = np.array([len(x) for x in ids], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.int64) for x in ids]))
+        p3 = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.int64).reshape(3, -1) for p in pos3], axis=1))
+        rw = np.asarray(list(rows), dtype=np.int32)
+        mn = np.asarray(list(max_new), dtype=np.int32)
+        logits = torch.empty(n, self.geom.text.vocab_size, dtype=torch.float32, device=self.device) if return_logits else None
+        n_img = 0 if image_embeds is None else int(image_embeds.shape[0])
+        if image_embeds is not None:
+            image_embeds = image_embeds.contiguous()
+            assert image_embeds.dtype == torch.bfloat16
+        L.check(self.lib.sr_admit(self._h, flat.ctypes.data_as(L._i64p), p3.ctypes.data_as(L._i64p), lens.ctypes.data_as(L._i32p),
+                                  rw.ctypes.data_as(L._i32p), mn.ctypes.data_as(L._i32p), n,
+                                  C.c_void_p(image_embeds.data_ptr()) if image_embeds is not None else None, n_img,
+                                  C.c_void_p(logits.data_ptr()) if logits is not None else None, self._s()), self._h, "sr_admit")
+        return logits
+
+    def rows_step(self, n_steps: int, eos: Sequence[int] = (), pad_id: int = 0):
+        eos_a = np.asarray(list(eos), dtype=np.int32)
+        L.check(self.lib.sr_rows_step(self._h, n_steps, eos_a.ctypes.data_as(L._i32p) if len(eos_a) else None, len(eos_a), pad_id, self._s()),
+                self._h, "sr_rows_step")
+
+    def rows_poll(self):
+        """-> (finished flags, generated-token counts), numpy int32 [max_batch]; synchronises."""
+        fin = np.zeros(self.cfg.max_batch, dtype=np.int32)
+        cnt = np.zeros(self.cfg.max_batch, dtype=np.int32)
+        L.check(self.lib.sr_rows_poll(self._h, fin.ctypes.data_as(L._i32p), cnt.ctypes.data_as(L._i32p), self._s()), self._h, "sr_rows_poll")
+        return fin, cnt
+
+    def row_tokens(self, row: int, n: int) -> torch.Tensor:
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        L.check(self.lib.sr_rows_read(self._h, row, C.c_void_p(out.data_ptr()), n, self._s()), self._h, "sr_rows_read")
+        return out
+
     def decode_step(self, last_ids: torch.Tensor | None = None, return_logits: bool = True):
         """One forward pass with the token choice left to the caller (sampling, logits verification): feeds
         last_ids [B] int64 (None = the engine's greedy token) and returns (float32 logits [B, V] or None, greedy ids [B] int64)."""

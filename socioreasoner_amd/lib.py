@@ -46,6 +46,11 @@ SIGNATURES = {
     "sr_prefill": (C.c_int, [_vp, _i64p, _i64p, _i32p, _i32p, _i, _vp, _i, _vp, _vp]),
     "sr_decode": (C.c_int, [_vp, _i32p, _i, _i, _i32p, _i, C.c_int32, _vp, _vp, _vp, _i, _vp, C.POINTER(C.c_int)]),
     "sr_decode_step": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "sr_rows_begin": (C.c_int, [_vp, _vp]),
+    "sr_admit": (C.c_int, [_vp, _i64p, _i64p, _i32p, _i32p, _i32p, _i, _vp, _i, _vp, _vp]),
+    "sr_rows_step": (C.c_int, [_vp, _i, _i32p, _i, C.c_int32, _vp]),
+    "sr_rows_poll": (C.c_int, [_vp, _i32p, _i32p, _vp]),
+    "sr_rows_read": (C.c_int, [_vp, _i, _vp, _i, _vp]),
     "sr_mask_union": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "sr_resize_nearest_u8": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp]),
     "sr_iou_counts": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),

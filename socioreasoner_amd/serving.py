@@ -1,0 +1,91 @@
+"""Continuous batching over the engine's batch rows (BASELINE.json configs[2]: "batch=32 continuous batching"; the
+reference gets this from vLLM's scheduler behind roll/distributed/strategy/vllm_strategy.py:156-205).
+
+A request is admitted into a free row as soon as one exists (its prompt is prefilled without disturbing running rows),
+all rows decode together -- one hipGraph replay per token for the whole batch -- and a row is released the moment its
+sequence hits an eos token or its own max_new_tokens.  Greedy decoding; a request's tokens do not depend on what shares
+the batch with it (per-row arithmetic is independent of the other rows).
+"""
+from __future__ import annotations
+
+from collections import deque
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+@dataclass
+class Request:
+    ids: np.ndarray                       # int64 [S], image placeholders already expanded
+    pos3: np.ndarray                      # int64 [3, S]
+    max_new: int
+    images: list = field(default_factory=list)     # uint8 HWC device tensors
+    grids: list = field(default_factory=list)      # (t, h, w) per image
+    tag: object = None
+
+
+class ContinuousBatcher:
+    def __init__(self, engine, eos: Sequence[int], pad_id: int, steps_per_poll: int = 8):
+        self.engine, self.eos, self.pad_id, self.steps_per_poll = engine, [int(e) for e in eos], int(pad_id), steps_per_poll
+        self.free = deque(range(engine.cfg.max_batch))
+        self.active: Dict[int, Request] = {}
+        self.pending: deque = deque()
+        self.stats = {"admitted": 0, "steps": 0, "admissions": 0}
+        engine.rows_begin()
+
+    def submit(self, req: Request):
+        self.pending.append(req)
+
+    def idle(self) -> bool:
+        return not self.pending and not self.active
+
+    def _admit(self):
+        cfg = self.engine.cfg
+        grp, ntok, npatch = [], 0, 0
+        while self.pending and len(grp) < len(self.free):
+            r = self.pending[0]
+            np_r = sum(t * h * w for t, h, w in r.grids)
+            if grp and (ntok + len(r.ids) > cfg.max_prefill_tokens or npatch + np_r > cfg.max_patches):
+                break
+            grp.append(self.pending.popleft())
+            ntok += len(r.ids)
+            npatch += np_r
+        if not grp:
+            return
+        rows = [self.free.popleft() for _ in grp]
+        emb = None
+        ims = [im for r in grp for im in r.images]
+        if ims:
+            pix = torch.cat([self.engine.patchify(im) for im in ims], dim=0)
+            emb = self.engine.vit_forward(pix, [g for r in grp for g in r.grids])
+        self.engine.admit(rows, [r.ids for r in grp], [r.pos3 for r in grp], [r.max_new for r in grp], emb)
+        for row, r in zip(rows, grp):
+            self.active[row] = r
+        self.stats["admitted"] += len(grp)
+        self.stats["admissions"] += 1
+
+    def pump(self, on_complete: Callable[[Request, List[int]], None]):
+        """One scheduling round: admit what fits, decode `steps_per_poll` tokens, release finished rows."""
+        self._admit()
+        if not self.active:
+            return
+        self.engine.rows_step(self.steps_per_poll, self.eos, self.pad_id)
+        self.stats["steps"] += self.steps_per_poll
+        fin, cnt = self.engine.rows_poll()
+        for row in [r for r in self.active if fin[r]]:
+            req = self.active.pop(row)
+            toks = self.engine.row_tokens(row, int(cnt[row])).cpu().tolist()
+            self.free.append(row)
+            on_complete(req, toks)
+
+    def run(self, requests: Sequence[Request]) -> List[List[int]]:
+        """Serve a fixed list of requests; returns their token lists in request order."""
+        order = {id(r): i for i, r in enumerate(requests)}
+        out: List[Optional[List[int]]] = [None] * len(requests)
+        for r in requests:
+            self.submit(r)
+        while not self.idle():
+            self.pump(lambda req, toks: out.__setitem__(order[id(req)], toks))
+        return out

@@ -412,6 +412,60 @@ def test_decode_step_matches_decode_and_accepts_caller_tokens(tiny_engine, golde
             tiny_engine.decode_step(None, return_logits=False)
 
 
+def test_continuous_batching_matches_one_at_a_time(tiny_engine, golden_dir):
+    """configs[2]: requests admitted into free rows while others are mid-decode (admit on finish), each with its own length
+    limit / eos, produce exactly the tokens of the same request served alone."""
+    from socioreasoner_amd.serving import ContinuousBatcher, Request
+    g = np.load(os.path.join(golden_dir, "hf_tiny.npz"))
+    grids = [tuple(x) for x in g["grids"].tolist()]
+    pix = bits_to_f32(g["pix"]).cuda()
+    ids_img, pos_img = g["ids"], g["pos3"]
+    emb = tiny_engine.vit_forward(pix, grids)
+    rng = np.random.default_rng(3)
+    reqs = []
+    for k, (n, mx) in enumerate([(9, 16), (30, 5), (17, 11), (None, 16), (4, 7), (25, 16), (None, 3), (12, 9), (40, 1)]):
+        if n is None:
+            reqs.append((ids_img, pos_img, mx, True))
+        else:
+            ids = rng.integers(0, 2000, n).astype(np.int64)
+            reqs.append((ids, np.tile(np.arange(n), (3, 1)), mx, False))
+    # reference: every request alone through the static path
+    alone = []
+    for ids, pos, mx, has_img in reqs:
+        tiny_engine.prefill([ids], [pos], emb if has_img else None)
+        alone.append(tiny_engine.decode(16, use_graph=False)[0, :mx].tolist())
+    eos = [alone[0][6], alone[5][9]]                       # tokens that occur mid-sequence somewhere -> early stops
+
+    def cut(row):
+        for j, t in enumerate(row):
+            if t in eos:
+                return row[: j + 1]
+        return row
+    want = [cut(a) for a in alone]
+    assert any(len(w) < len(a) for w, a in zip(want, alone))
+
+    class PixEngine:                                        # the batcher patchifies uint8 images; here features are ready-made
+        def __init__(self, e):
+            self.e = e
+        def __getattr__(self, k):
+            return getattr(self.e, k)
+        def patchify(self, im):
+            return im
+        def vit_forward(self, pixrows, gr):
+            return self.e.vit_forward(pixrows, gr)
+    for steps_per_poll in (1, 4):
+        cb = ContinuousBatcher(PixEngine(tiny_engine), eos, pad_id=2045, steps_per_poll=steps_per_poll)
+        rl = [Request(ids=i, pos3=p, max_new=mx, images=[pix] if has_img else [], grids=grids if has_img else []) for i, p, mx, has_img in reqs]
+        got = cb.run(rl)
+        assert got == want, (steps_per_poll, got, want)
+        assert cb.stats["admissions"] >= 3                  # 9 requests through 4 rows: rows were re-used mid-flight
+    # static calls work again afterwards
+    tiny_engine.prefill([reqs[0][0]], [reqs[0][1]], None)
+    assert tiny_engine.decode(16, use_graph=True)[0].tolist() == alone[0]
+    with pytest.raises(Exception, match="rows"):
+        tiny_engine.rows_step(1)
+
+
 # ------------------------------------------------------------------------------------------------ true dimensions
 def _truedim(full: bool):
     from oracle import model_ref as MR

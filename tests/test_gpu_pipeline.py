@@ -301,3 +301,44 @@ def test_strategy_sampling_path():
         top2 = lg.topk(2, dim=-1).indices
         assert bool(((tok[:, None] == top2).any(-1)).all()), i
         lg, _ = eng.decode_step(tok)
+
+
+def test_request_level_serving_on_the_engine():
+    """generate_opt_level 1 on the real engine: single-prompt requests through add_request / start_server (continuous
+    batching) return the tensors of the batch call (level 0)."""
+    from roll.distributed.scheduler.generate_scheduler import GenerateScheduler
+    from roll.distributed.scheduler.protocol import DataProto
+    from roll.pipeline.base_worker import ActorWorker
+    from socioreasoner_amd import synthetic
+    cfg = _cfg("/tmp/unused", resp=12, prompt=400)
+    cfg.actor_infer.generating_args.update({"temperature": 0, "top_k": 1, "max_new_tokens": 12})
+    cfg.actor_infer.strategy_args.strategy_config["max_batch"] = 3
+    w = ActorWorker(cfg.actor_infer, cfg, 0, 1, 0, "actor_infer").initialize(cfg)
+    g = w.strategy.geom
+    P, pad = 400, g.pad_token_id
+    rows, payload = [], np.empty(7, dtype=object)
+    for i in range(7):
+        if i % 3 == 1:
+            ids = np.arange(5, 25 + i, dtype=np.int64)
+            payload[i] = {"prompt_token_ids": ids.tolist()}
+        else:
+            ids = synthetic.tile_prompt(g, i, (1, 16, 16), n_pre=6 + i, n_post=5)
+            payload[i] = {"prompt_token_ids": ids.tolist(), "multi_modal_data": {"image": [synthetic.tile_pixels(i, 224, 224)]}}
+        row = np.full(P, pad, dtype=np.int64)
+        row[P - len(ids):] = ids
+        rows.append(row)
+    input_ids = torch.from_numpy(np.stack(rows))
+    mask = (input_ids != pad).long()
+    pos = (mask.cumsum(-1) - 1).clamp(min=0)[:, None, :].repeat(1, 3, 1)
+
+    def fresh():
+        return DataProto(batch={"input_ids": input_ids.clone(), "attention_mask": mask.clone(), "position_ids": pos.clone()},
+                         non_tensor_batch={"multi_modal_data": payload.copy()})
+    sched = GenerateScheduler()
+    out0 = sched.generate(fresh(), w, cfg)
+    cfg["generate_opt_level"] = 1
+    out1 = sched.generate(fresh(), w, cfg)
+    for k in ("responses", "input_ids", "attention_mask", "response_mask", "position_ids"):
+        assert torch.equal(out0.batch[k], out1.batch[k]), k
+    assert int(out0.batch["response_mask"].sum()) > 0
+    w.strategy.engine.close()

@@ -104,6 +104,26 @@ local = torch.arange(a, b, dtype=torch.int64).unsqueeze(1) * 10 + torch.arange(3
 full = dp.all_gather_rows(local, n)
 want = torch.arange(n).unsqueeze(1) * 10 + torch.arange(3)
 assert full.shape == (n, 3) and (full == want).all(), (rank, full)
+# logits all-gather verification mode with a scripted "model": logits of row r after feeding token t peak at (7 * t + r + 3) % V
+V = 50
+def logits_for(tok, rows):
+    l = torch.zeros(len(rows), V)
+    for k, (t, r) in enumerate(zip(tok.tolist(), rows)):
+        l[k, (7 * t + r + 3) % V] = 1.0
+    return l
+rows = list(range(a, b))
+first = logits_for(torch.zeros(len(rows), dtype=torch.long), rows)
+def step_fn(ids):
+    l = logits_for(ids, rows)
+    return l, l.argmax(-1)
+toks, bad = dp.decode_with_logits_gather(step_fn, first, 5, n)
+assert bad == 0 and toks.shape == (n, 5)
+for r in range(n):
+    t, exp = 0, []
+    for _ in range(5):
+        t = (7 * t + r + 3) % V
+        exp.append(t)
+    assert toks[r].tolist() == exp, (rank, r, toks[r].tolist(), exp)
 dp.barrier()
 print("ok", rank)
 """

@@ -1,5 +1,2 @@
 cd /root/repo
-for v in 0 256 128; do echo "== SR_GEMM3=$v"; SR_GEMM3=$v timeout 300 python tools/bench_gemm.py 2>&1 | grep -E "B32|square"; done
-echo "== correctness"; timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "gemm" -p no:cacheprovider 2>&1 | tail -3
-SR_GEMM3=256 timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "gemm" -p no:cacheprovider 2>&1 | tail -3
-SR_GEMM3=128 timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "gemm" -p no:cacheprovider 2>&1 | tail -3
+timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 32 --continuous > gpurun_out/b32c.log 2>&1; grep -o '"value": [0-9.]*, "unit": "tiles/s"' gpurun_out/b32c.log || tail -20 gpurun_out/b32c.log
