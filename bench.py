@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="tiles per GPU per step (1 = configs[1], 32 = configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE.json configs[4] weights: LM decoder linears fp8 e4m3, per-channel scale")
     ap.add_argument("--continuous", action="store_true",
                     help="serve the tiles through the continuous-batching scheduler (configs[2]: admit on finish, 2x batch requests)")
     ap.add_argument("--gather-logits", action="store_true",
@@ -63,7 +64,7 @@ def main():
     torch.cuda.set_device(dev)
     B = args.batch
     geom = geometry_3b()
-    eng = Engine(geom, max_patches=1024 * B, max_prefill_tokens=448 * B, max_batch=B, max_ctx=640, max_new_tokens=N_NEW, device=str(dev))
+    eng = Engine(geom, max_patches=1024 * B, max_prefill_tokens=448 * B, max_batch=B, max_ctx=640, max_new_tokens=N_NEW, device=str(dev), lm_fp8=args.fp8)
     t0 = time.time()
     eng.load_synthetic_weights(seed=0)
     load_s = time.time() - t0
@@ -188,7 +189,20 @@ def main():
         TL = 0x100              # weights are fragment-ordered in the engine; the timing does not depend on the values
         eps = C.c_float(1e-6)
 
+        if args.fp8:            # fp8 images + scales of the four layer linears (values do not matter for the timing)
+            w8 = [torch.empty(nl, n_ * k_, dtype=torch.uint8, device=dev).random_(0, 120) for n_, k_ in ((QN, H), (H, H), (2 * I, H), (H, I))]
+            sc8 = torch.ones(2 * I, dtype=torch.float32, device=dev)
+
         def gemv_sequence():
+            if args.fp8:
+                for l in range(nl):
+                    lib.sr_op_gemv_f8(P(x), I, P(w8[0][l]), P(sc8), B, QN, H, P(qkv_o), QN, 3, P(bq), P(nw) if fused else None, eps, 1, s)
+                    lib.sr_op_gemv_f8(P(x), I, P(w8[1][l]), P(sc8), B, H, H, P(xr), H, 4, None, None, eps, 1, s)
+                    lib.sr_op_gemv_f8(P(x), I, P(w8[2][l]), P(sc8), B, 2 * I, H, P(act), I, 1, None, P(nw) if fused else None, eps, 1, s)
+                    lib.sr_op_gemv_f8(P(act), I, P(w8[3][l]), P(sc8), B, H, I, P(part), H, 0, None, None, eps, 2, s)
+                lib.sr_op_gemv_fused(P(x), I, P(wv), B, t_.vocab_size, H, P(lg), t_.vocab_size, 2 | TL, None, P(nw) if fused else None, eps,
+                                     P(slabs) if fused else None, 2 if fused else 0, P(xo) if fused else None, P(av), P(ai), s)
+                return
             for l in range(nl):
                 lib.sr_op_gemv_fused(P(x), I, P(wq[l]), B, QN, H, P(qkv_o), QN, 3 | TL, P(bq), P(nw) if fused else None, eps,
                                      P(slabs) if fused else None, 2 if fused else 0, P(xo) if fused else None, None, None, s)
@@ -208,6 +222,8 @@ def main():
         n_launch = 4 * nl + 1
         avg_ms = a.elapsed_time(b_) / reps / n_launch
         wl, wh = lm_weight_bytes(geom)
+        if args.fp8:
+            wl = wl / 2          # the layer linears stream 1 byte per weight (+ 4 bytes per output channel, < 0.1 %)
         bytes_per_launch = (wl + wh) / n_launch
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         decode_step_ms = phase_ms["decode"] / args.steps / (N_NEW - 1)
@@ -220,7 +236,9 @@ def main():
             traffic = round(pmc["traffic_over_algorithmic_weighted"] * bytes_per_launch)
         except Exception:  # noqa: BLE001
             pass
-        roof = {"bound": "hbm", "kernel": "k_gemv (decode weight stream, all LM linears + LM head)",
+        if args.fp8:
+            traffic = None       # the PMC calibration under profiles/ was taken on the bf16 stream
+        roof = {"bound": "hbm", "kernel": "k_gemv (decode weight stream, all LM linears + LM head)" + (" [fp8 layer linears]" if args.fp8 else ""),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_ms * 1e3, 2),
                 "launches_per_decode_step": n_launch,
@@ -239,10 +257,10 @@ def main():
         out = {
             "metric": "satellite tiles/sec (448x448, SocioReasoner-3B)", "value": round(tiles_per_s, 4), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"SocioReasoner-3B bf16, batch={B} tile(s)/GPU, 448x448 synthetic tiles, 448-token prompt, "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not args.fp8 else "bf16 (fp8-e4m3 LM linear weights, bf16 activations / MFMA)", "data": "synthetic",
+            "config": {"workload": f"SocioReasoner-3B {'fp8-weight' if args.fp8 else 'bf16'}, batch={B} tile(s)/GPU, 448x448 synthetic tiles, 448-token prompt, "
                                    f"greedy decode of {N_NEW} tokens (EOS ignored), raster tail; random-init weights "
-                                   f"(counter-based generator, seed 0)" + (" [BASELINE.json configs[1]]" if B == 1 else ""),
+                                   f"(counter-based generator, seed 0)" + (" [BASELINE.json configs[1]]" if B == 1 and not args.fp8 else ""),
                        "tiles_per_gpu_per_step": B * (2 if args.continuous else 1),
                        "scheduling": "continuous batching (admit on finish) through B rows" if args.continuous else "static batch",
                        "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",

@@ -45,6 +45,11 @@ typedef struct sr_config {
     int32_t max_batch;           /* KV-cache slots = concurrent sequences (<= 32) */
     int32_t max_ctx;             /* KV rows per slot, multiple of 64 (prompt + generated) */
     int32_t max_new_tokens;      /* rows of the device token log */
+    /* storage of the LM decoder linears (q/k/v, o, gate/up, down) -- BASELINE.json configs[4]:
+     *   0 = bf16;  1 = fp8 e4m3 with one float32 scale per output channel, W[n,k] = q[n,k] * scale[n], scale[n] = amax_n / 448.
+     * Embedding / LM head and the ViT stay bf16.  The decode GEMV streams the fp8 image (half the HBM bytes) and widens it to
+     * bf16 in registers (exact); prefill multiplies a bf16 image of the same q; both apply scale[n] to the float32 accumulator. */
+    int32_t lm_weight_dtype;
 } sr_config;
 
 /* Bytes of device workspace sr_engine_create needs for this configuration (0 on invalid config). */
@@ -109,6 +114,10 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
               int32_t pad_id, int32_t* dev_tokens_out, float* dev_logits_trace, const int32_t* dev_forced, int use_graph,
               void* stream, int* steps_done);
 
+/* Call once after the last sr_load_weight / sr_synth_fill and before the first forward: checks that every tensor arrived and,
+ * with lm_weight_dtype = 1, quantises the LM decoder linears in place (see sr_config).  Idempotent. */
+int sr_finalize_weights(sr_engine* e, void* stream);
+
 /* One decode step with the token choice left to the caller -- the `sr_decode_step` of SURVEY section 8(B); this is what a
  * sampling caller (temperature / top-k / top-p of vllm_strategy.py:289-309) or the logits-gathering verification
  * mode of the multi-GPU path drives.  Feeds dev_last_ids[b] (int64, device; NULL = the greedy token of the logits the
@@ -162,6 +171,12 @@ int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, floa
 int sr_op_resid_rmsnorm(void* x, const float* partials, int ksplit, const void* w, void* out, int rows, int H, float eps,
                         void* stream);
 int sr_op_argmax(const float* logits, int rows, int V, int32_t* out_idx, void* stream);
+/* fp8 quantisation of a fragment-ordered bf16 matrix (the kernel sr_finalize_weights runs): dev_w8 [N*K] bytes (tiled8),
+ * dev_scale float32 [N]; W itself becomes the bf16 image of q */
+int sr_op_quant_f8(void* dev_w_tiled, int N, int K, void* dev_w8, float* dev_scale, void* stream);
+/* decode GEMV on an fp8 weight image: mode 0 PARTIAL / 1 SWIGLU / 3 BIAS / 4 RESID as sr_op_gemv_fused */
+int sr_op_gemv_f8(const void* x, int ldx, const void* w8, const float* w_scale, int M, int N, int K, void* out, int ldo, int mode,
+                  const void* bias, const void* norm_w, float eps, int ksplit, void* stream);
 int sr_version(void);
 
 #ifdef __cplusplus

@@ -90,12 +90,44 @@ def r(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+class QuantW:
+    """fp8 (OCP e4m3fn) per-output-channel quantised Linear weight -- BASELINE.json configs[4], the repo's definition
+    (include/socior.h sr_config.lm_weight_dtype): scale[n] = amax_n / 448 (1 for an all-zero row), q = fp8(W / scale),
+    y = bf16((x . q^T) * scale + bias).  No reference implementation exists for this mode (the reference ships bf16)."""
+
+    def __init__(self, w: torch.Tensor):
+        amax = w.abs().amax(dim=1, keepdim=True)
+        scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+        self.q8 = (w / scale).to(torch.float8_e4m3fn)
+        self.q = self.q8.float()
+        self.scale = scale[:, 0].contiguous()
+
+
 def linear(x, w, b=None):
     """bf16 nn.Linear: float32 accumulate, bias added in float32, one rounding (hf:88-96, 218, 626-629)."""
-    y = x @ w.t()
+    if isinstance(w, QuantW):
+        y = (x @ w.q.t()) * w.scale
+    else:
+        y = x @ w.t()
     if b is not None:
         y = y + b
     return r(y)
+
+
+class Fp8LmWeights:
+    """View of a weight dict in which the LM decoder linears (q/k/v/o, gate/up/down) are fp8-quantised."""
+    import re as _re
+    _LM = _re.compile(r"model\.layers\.\d+\.(self_attn\.[qkvo]_proj|mlp\.(gate|up|down)_proj)\.weight$")
+
+    def __init__(self, base):
+        self.base, self._cache = base, {}
+
+    def __getitem__(self, name):
+        if self._LM.match(name):
+            if name not in self._cache:
+                self._cache[name] = QuantW(self.base[name])
+            return self._cache[name]
+        return self.base[name]
 
 
 def rmsnorm(x, w, eps):

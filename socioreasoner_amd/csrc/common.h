@@ -42,5 +42,20 @@ __host__ __device__ __forceinline__ size_t tiled_offset(size_t n, size_t k, size
     return (((n >> 4) * (K >> 6) + (k >> 6)) * 2 + ((k >> 3) & 1)) * 512 + ((((k >> 4) & 3) << 4) + (n & 15)) * 8 + (k & 7);
 }
 
+// fp8 (OCP e4m3fn) weights of the decode stream (BASELINE.json configs[4]): W[n, k] = q[n, k] * scale[n], q in fp8.
+// Fragment-ordered layout of q: every 16-row x 64-k block is 1 KB contiguous,
+//   [n / 16][k / 64][lane = ((k % 64) / 16) * 16 + n % 16][k % 16]
+// i.e. a lane's 16 bytes are the two 8-k MFMA steps (k % 16 < 8, >= 8) of its (row, k-group) -- the same k permutation
+// the bf16 stream uses, so the x operand addressing is unchanged.
+__host__ __device__ __forceinline__ size_t tiled8_offset(size_t n, size_t k, size_t K) {
+    return (((n >> 4) * (K >> 6) + (k >> 6)) * 64 + (((k >> 4) & 3) << 4) + (n & 15)) * 16 + (k & 15);
+}
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// 4 fp8 in one dword -> 4 bf16 (exact: every e4m3 value is a bf16 value); v_cvt_scalef32_pk_bf16_fp8 with scale 1
+__device__ __forceinline__ void f8x4_to_bf16(uint32_t v, uint32_t& lo, uint32_t& hi) {
+    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, false));
+    hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, true));
+}
+
 #define SR_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

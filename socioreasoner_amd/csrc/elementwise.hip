@@ -376,6 +376,52 @@ __global__ void k_admit_rows(AdmitArgs a) {
         a.amax_idx[(size_t)r * a.n_part + k] = k == 0 ? a.first_tok[i] : 0x7fffffff;
     }
 }
+
+// fp8 weight quantisation, one block per 16-row tile of a fragment-ordered bf16 matrix (see kernels.h)
+__global__ __launch_bounds__(256) void k_quant_f8(bf16_t* W, int K, unsigned char* W8, float* scale) {
+    __shared__ float amax_s[16][17];
+    __shared__ float sc_s[16];
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    bf16_t* wt = W + (size_t)tile * 16 * K;                 // the tile's 16 x K elements are contiguous in tiled16x64
+    // vector v of the tile: chunk = v >> 7, kstep = (v >> 6) & 1, lane = v & 63, row = lane & 15 = v & 15.  A thread's
+    // vectors (v = tid + 256 j) all belong to row tid & 15.
+    const int nvec = 16 * K / 8;                              // 16-byte vectors
+    float mx = 0.f;
+    for (int v = tid; v < nvec; v += 256) {
+        const uint4 u = *reinterpret_cast<const uint4*>(wt + (size_t)v * 8);
+        const float f[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(f[e]));
+    }
+    // thread tid owns row tid & 15; 16 threads per row
+    amax_s[tid & 15][tid >> 4] = mx;
+    __syncthreads();
+    if (tid < 16) {
+        float m = 0.f;
+        for (int j = 0; j < 16; ++j) m = fmaxf(m, amax_s[tid][j]);
+        const float sc = m > 0.f ? __fdiv_rn(m, 448.0f) : 1.0f;
+        sc_s[tid] = sc;
+        scale[tile * 16 + tid] = sc;
+    }
+    __syncthreads();
+    const float sc = sc_s[tid & 15];
+    unsigned char* w8t = W8 + (size_t)tile * 16 * K;          // tiled8: the tile's 16 x K bytes are contiguous
+    for (int v = tid; v < nvec; v += 256) {
+        const int chunk = v >> 7, kstep = (v >> 6) & 1, lane = v & 63;
+        uint4 u = *reinterpret_cast<const uint4*>(wt + (size_t)v * 8);
+        const float f[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
+        int p0 = 0, p1 = 0;
+        p0 = __builtin_amdgcn_cvt_pk_fp8_f32(__fdiv_rn(f[0], sc), __fdiv_rn(f[1], sc), p0, false);
+        p0 = __builtin_amdgcn_cvt_pk_fp8_f32(__fdiv_rn(f[2], sc), __fdiv_rn(f[3], sc), p0, true);
+        p1 = __builtin_amdgcn_cvt_pk_fp8_f32(__fdiv_rn(f[4], sc), __fdiv_rn(f[5], sc), p1, false);
+        p1 = __builtin_amdgcn_cvt_pk_fp8_f32(__fdiv_rn(f[6], sc), __fdiv_rn(f[7], sc), p1, true);
+        *reinterpret_cast<uint2*>(w8t + ((size_t)chunk * 64 + lane) * 16 + kstep * 8) = uint2{(uint32_t)p0, (uint32_t)p1};
+        uint32_t a0, a1, b0, b1;
+        f8x4_to_bf16((uint32_t)p0, a0, a1);
+        f8x4_to_bf16((uint32_t)p1, b0, b1);
+        *reinterpret_cast<uint4*>(wt + (size_t)v * 8) = uint4{a0, a1, b0, b1};
+    }
+}
 }  // namespace
 
 int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, long long cols, bf16_t* dst, long long dst_ld,
@@ -465,6 +511,12 @@ int launch_argmax(hipStream_t s, const float* logits, int rows, int V, int* out_
 int launch_next_ids(hipStream_t s, const float* amax_val, const int* amax_idx, int n_part, int B, long long* out) {
     if (B <= 0) return 0;
     hipLaunchKernelGGL(k_next_ids, dim3(B), dim3(256), 0, s, amax_val, amax_idx, n_part, out);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_quant_f8(hipStream_t s, bf16_t* W_tiled, int N, int K, unsigned char* W8, float* scale) {
+    if (N % 16 || K % 64) return -22;
+    hipLaunchKernelGGL(k_quant_f8, dim3(N / 16), dim3(256), 0, s, W_tiled, K, W8, scale);
     SR_CHECK_LAUNCH();
     return 0;
 }

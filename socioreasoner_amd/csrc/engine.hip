@@ -28,7 +28,12 @@ namespace {
 thread_local char g_err[512] = "ok";
 
 struct VitBlockW { bf16_t *norm1, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2, *gu_w, *gu_b, *down_w, *down_b; };
-struct LmLayerW { bf16_t *ln1, *qkv_w, *qkv_b, *o_w, *ln2, *gu_w, *down_w; };
+struct LmLayerW {
+    bf16_t *ln1, *qkv_w, *qkv_b, *o_w, *ln2, *gu_w, *down_w;
+    // lm_weight_dtype = 1: fp8 images (tiled8) + per-output-channel scales of the four linears (null in bf16 mode)
+    unsigned char *qkv_w8 = nullptr, *o_w8 = nullptr, *gu_w8 = nullptr, *down_w8 = nullptr;
+    float *qkv_s = nullptr, *o_s = nullptr, *gu_s = nullptr, *down_s = nullptr;
+};
 
 struct Arena {
     char* base = nullptr;
@@ -99,6 +104,7 @@ struct sr_engine {
     float *d_logits_adm = nullptr, *d_amax_val_adm = nullptr;
     int *d_amax_idx_adm = nullptr, *d_row_limit = nullptr, *d_ngen = nullptr, *d_adm = nullptr;   // d_adm: [rows | ctx | pos | limit | first_tok] x 32
     bool rows_mode = false;
+    bool finalized = false;        // sr_finalize_weights ran (fp8 mode: the LM linears are quantised)
     bf16_t *kcache, *vtcache;
     size_t kv_layer_elems;
     // ---- host staging (pinned) + its device mirror
@@ -153,6 +159,7 @@ const char* validate(const sr_config& c) {
     if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] != 64) return "mrope_section must sum to 64";
     if (c.max_batch < 1 || c.max_batch > 32) return "max_batch in 1..32";
     if (c.max_ctx < 64 || c.max_ctx % 64) return "max_ctx multiple of 64";
+    if (c.lm_weight_dtype != 0 && c.lm_weight_dtype != 1) return "lm_weight_dtype 0 (bf16) or 1 (fp8 e4m3, per-channel scale)";
     if (c.max_patches < 4 || c.max_patches % 4 || c.max_prefill_tokens < 1 || c.max_new_tokens < 1) return "capacities";
     if (c.v_n_fullatt < 0 || c.v_n_fullatt > 16 || c.v_depth < 1 || c.t_layers < 1) return "depths";
     return nullptr;
@@ -205,6 +212,16 @@ void carve(sr_engine* e) {
         l.ln2 = ar.take<bf16_t>(H);
         l.gu_w = ar.take<bf16_t>((size_t)2 * e->t_inter_pad * H);
         l.down_w = ar.take<bf16_t>((size_t)H * e->t_inter_pad);
+        if (c.lm_weight_dtype == 1) {
+            l.qkv_w8 = ar.take<unsigned char>((size_t)e->t_qn * H);
+            l.o_w8 = ar.take<unsigned char>((size_t)H * c.t_heads * 128);
+            l.gu_w8 = ar.take<unsigned char>((size_t)2 * e->t_inter_pad * H);
+            l.down_w8 = ar.take<unsigned char>((size_t)H * e->t_inter_pad);
+            l.qkv_s = ar.take<float>(e->t_qn);
+            l.o_s = ar.take<float>(H);
+            l.gu_s = ar.take<float>(2 * e->t_inter_pad);
+            l.down_s = ar.take<float>(H);
+        }
     }
     e->lut = ar.take<bf16_t>(3 * 256);
     e->inv_freq = ar.take<float>(64);
@@ -422,8 +439,8 @@ bool is_fullatt(const sr_config& c, int blk) {
 }
 
 int gemm(sr_engine* e, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, void* out, int ldo,
-         const bf16_t* bias, const bf16_t* resid, const int* rowmap, int epi, int w_tiled = 0) {
-    GemmArgs a{A, lda, W, M, N, K, out, ldo, bias, resid, rowmap, w_tiled};
+         const bf16_t* bias, const bf16_t* resid, const int* rowmap, int epi, int w_tiled = 0, const float* w_scale = nullptr) {
+    GemmArgs a{A, lda, W, M, N, K, out, ldo, bias, resid, rowmap, w_tiled, w_scale};
     SR_TRY(launch_gemm(s, a, epi));
     return 0;
 }
@@ -475,7 +492,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
         bf16_t* vc = e->vtcache + (size_t)l * e->kv_layer_elems;
         GemvArgs gq = gv(x, H, w.qkv_w, B, e->t_qn, H, e->d_qkv, e->t_qn);
-        gq.bias = w.qkv_b;
+        gq.bias = w.qkv_b; gq.W8 = w.qkv_w8; gq.w_scale = w.qkv_s;
         if (fused) {
             gq.norm_w = w.ln1; gq.eps = c.t_rms_eps;
             if (pending) { gq.slabs = e->d_slabs; gq.n_slabs = ks_down(e, B); gq.x_out = x_alt; }
@@ -491,13 +508,16 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
                           B, c.t_heads, c.t_kv_heads, e->t_group, c.max_ctx, scale, e->d_scores};
         SR_TRY(launch_attn_decode(s, da));
         GemvArgs go = gv(e->d_attn, QD, w.o_w, B, H, QD, x, H);
+        go.W8 = w.o_w8; go.w_scale = w.o_s;
         SR_TRY(launch_gemv(s, go, GV_RESID));
         GemvArgs gg = gv(x, H, w.gu_w, B, 2 * e->t_inter_pad, H, e->d_act, e->t_inter_pad);
+        gg.W8 = w.gu_w8; gg.w_scale = w.gu_s;
         if (fused) { gg.norm_w = w.ln2; gg.eps = c.t_rms_eps; }
         else { SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps)); gg.x = e->d_xn; }
         SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
         GemvArgs gd = gv(e->d_act, e->t_inter_pad, w.down_w, B, H, e->t_inter_pad, e->d_slabs, H);
         gd.ksplit = ks_down(e, B);
+        gd.W8 = w.down_w8; gd.w_scale = w.down_s;
         SR_TRY(launch_gemv(s, gd, GV_PARTIAL));
         pending = true;
     }
@@ -724,12 +744,36 @@ int sr_vit_forward(sr_engine* e, const void* pixels, int pixels_dtype, const int
     return 0;
 }
 
+int sr_finalize_weights(sr_engine* e, void* stream) {
+    if (!e) return fail(e, -22, "sr_finalize_weights: null engine");
+    if (e->finalized) return 0;
+    {
+        char first[160] = "";
+        const int missing = sr_weights_missing(e, first, sizeof first);
+        if (missing) return fail(e, -22, "sr_finalize_weights: %d parameters missing, e.g. %s", missing, first);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (e->c.lm_weight_dtype == 1) {
+        const int H = e->c.t_hidden, QD = e->c.t_heads * 128;
+        for (auto& l : e->ll) {
+            SR_TRY(launch_quant_f8(s, l.qkv_w, e->t_qn, H, l.qkv_w8, l.qkv_s));
+            SR_TRY(launch_quant_f8(s, l.o_w, H, QD, l.o_w8, l.o_s));
+            SR_TRY(launch_quant_f8(s, l.gu_w, 2 * e->t_inter_pad, H, l.gu_w8, l.gu_s));
+            SR_TRY(launch_quant_f8(s, l.down_w, H, e->t_inter_pad, l.down_w8, l.down_s));
+        }
+        SR_TRY((int)hipStreamSynchronize(s));
+    }
+    e->finalized = true;
+    return 0;
+}
+
 static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_t* seq_lens, const int32_t* slots, int B,
                         const void* image_embeds, int n_image_rows, float* logits_out, void* stream, const int32_t* limits) {
     if (!e || !ids || !pos3 || !seq_lens || !slots) return fail(e, -22, "sr_prefill: null argument");
     char miss[160];
     if (sr_weights_missing(e, miss, sizeof miss)) return fail(e, -61, "weights missing, e.g. '%s'", miss);
     const sr_config& c = e->c;
+    if (c.lm_weight_dtype == 1 && !e->finalized) return fail(e, -22, "fp8 weights: call sr_finalize_weights after loading");
     if (B < 1 || B > c.max_batch) return fail(e, -22, "sr_prefill: B=%d outside 1..%d", B, c.max_batch);
     hipStream_t s = (hipStream_t)stream;
     int n_tok = 0;
@@ -816,17 +860,17 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
         bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
         bf16_t* vc = e->vtcache + (size_t)l * e->kv_layer_elems;
         SR_TRY(launch_rmsnorm(s, e->t_x, w.ln1, e->t_xn, n_tok, H, c.t_rms_eps));
-        if (int rc = gemm(e, s, e->t_xn, H, w.qkv_w, n_tok, e->t_qn, H, e->t_qkv, e->t_qn, w.qkv_b, nullptr, nullptr, EPI_STORE, 1)) return rc;
+        if (int rc = gemm(e, s, e->t_xn, H, w.qkv_w, n_tok, e->t_qn, H, e->t_qkv, e->t_qn, w.qkv_b, nullptr, nullptr, EPI_STORE, 1, w.qkv_s)) return rc;
         LmRopeArgs ra{e->t_qkv, n_tok, c.t_heads, c.t_kv_heads, e->t_pos3, e->t_slot, e->t_idx, e->rope_cos, e->rope_sin,
                       c.mrope_section[0], c.mrope_section[0] + c.mrope_section[1], kc, vc, c.max_ctx};
         SR_TRY(launch_lm_rope_prefill(s, ra));
         AttnArgs a{e->t_qkv, e->t_qn, kc, 128, (long long)c.max_ctx * 128, vc, c.max_ctx, (long long)128 * c.max_ctx,
                    e->t_attn, QD, e->t_work, n_work, c.t_heads, e->t_group, scale, 1};
         SR_TRY(launch_attn_prefill(s, a, 128));
-        if (int rc = gemm(e, s, e->t_attn, QD, w.o_w, n_tok, H, QD, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID, 1)) return rc;
+        if (int rc = gemm(e, s, e->t_attn, QD, w.o_w, n_tok, H, QD, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID, 1, w.o_s)) return rc;
         SR_TRY(launch_rmsnorm(s, e->t_x, w.ln2, e->t_xn, n_tok, H, c.t_rms_eps));
-        if (int rc = gemm(e, s, e->t_xn, H, w.gu_w, n_tok, 2 * e->t_inter_pad, H, e->t_act, e->t_inter_pad, nullptr, nullptr, nullptr, EPI_SWIGLU, 1)) return rc;
-        if (int rc = gemm(e, s, e->t_act, e->t_inter_pad, w.down_w, n_tok, H, e->t_inter_pad, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID, 1)) return rc;
+        if (int rc = gemm(e, s, e->t_xn, H, w.gu_w, n_tok, 2 * e->t_inter_pad, H, e->t_act, e->t_inter_pad, nullptr, nullptr, nullptr, EPI_SWIGLU, 1, w.gu_s)) return rc;
+        if (int rc = gemm(e, s, e->t_act, e->t_inter_pad, w.down_w, n_tok, H, e->t_inter_pad, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID, 1, w.down_s)) return rc;
     }
     // last position of every sequence -> final norm -> tied LM head (hf:1386-1387) -> greedy token
     // (d_xn is decode scratch: rows in flight do not keep anything in it between steps)
@@ -1091,6 +1135,17 @@ int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, floa
 }
 int sr_op_resid_rmsnorm(void* x, const float* partials, int ksplit, const void* w, void* out, int rows, int H, float eps, void* stream) {
     SR_WRAP(launch_resid_rmsnorm((hipStream_t)stream, (bf16_t*)x, partials, ksplit, (const bf16_t*)w, (bf16_t*)out, rows, H, eps));
+}
+int sr_op_quant_f8(void* w_tiled, int N, int K, void* w8, float* scale, void* stream) {
+    SR_WRAP(launch_quant_f8((hipStream_t)stream, (bf16_t*)w_tiled, N, K, (unsigned char*)w8, scale));
+}
+int sr_op_gemv_f8(const void* x, int ldx, const void* w8, const float* w_scale, int M, int N, int K, void* out, int ldo, int mode,
+                  const void* bias, const void* norm_w, float eps, int ksplit, void* stream) {
+    GemvArgs a{};
+    a.x = (const bf16_t*)x; a.ldx = ldx; a.W = nullptr; a.W8 = (const unsigned char*)w8; a.w_scale = w_scale; a.w_tiled = 1;
+    a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo; a.ksplit = ksplit > 0 ? ksplit : 1;
+    a.bias = (const bf16_t*)bias; a.norm_w = (const bf16_t*)norm_w; a.eps = eps;
+    SR_WRAP(launch_gemv((hipStream_t)stream, a, mode));
 }
 int sr_op_argmax(const float* logits, int rows, int V, int32_t* out_idx, void* stream) {
     SR_WRAP(launch_argmax((hipStream_t)stream, logits, rows, V, out_idx));

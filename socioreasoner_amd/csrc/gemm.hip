@@ -146,6 +146,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float g = acc[i][2 * jp][r], u = acc[i][2 * jp + 1][r];
+                    if (p.w_scale) { g *= p.w_scale[ng + r]; u *= p.w_scale[nu + r]; }
                     if (p.bias) { g += bf2f(p.bias[ng + r]); u += bf2f(p.bias[nu + r]); }
                     g = rbf(g); u = rbf(u);
                     o[r] = rbf(silu_f(g)) * u;
@@ -162,6 +163,10 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = acc[i][j][r];
+                if (p.w_scale) {
+                    const float4 sc = *reinterpret_cast<const float4*>(p.w_scale + n);
+                    o[0] *= sc.x; o[1] *= sc.y; o[2] *= sc.z; o[3] *= sc.w;
+                }
                 if constexpr (EPI == EPI_F32) {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow * p.ldo + n) =
                         float4{o[0], o[1], o[2], o[3]};

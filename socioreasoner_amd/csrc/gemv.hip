@@ -33,7 +33,7 @@ __device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(b
 // WAVES = 4 : the dispatched configuration -- many small blocks, K split over the 4 waves.
 // STAGE     : x (optionally + pending residual slabs, optionally RMS-normalised) is prepared in LDS by the prologue
 //             (used for batches <= 4, where the prologue is a few KB per block).
-template <int MODE, int MT, int KP, bool STAGE, int WAVES>
+template <int MODE, int MT, int KP, bool STAGE, int WAVES, bool F8 = false>
 __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;     // 16-row W tiles per wave
     constexpr int TPB = WAVES / KP;                    // wave-tiles per block
@@ -52,8 +52,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     // ---------------------------------------------------------------- weight ring: U chunk slots (16 loads = 16 KB per
     // wave) stay in flight; a slot is refilled right after its MFMAs issue, so the compiler's counted vmcnt only ever
     // waits for the oldest slot.  The first fills do not depend on x: they go out before the prologue's second pass.
-    constexpr int U = 8 / T;
-    u32x4 w[U][T][2];
+    // F8: the stream is the fp8 image (1 KB per 16 x 64 block): ONE 16-byte load per lane and chunk, widened to the two
+    // bf16 MFMA operands at consume time (exact), the per-channel scale multiplies the float32 accumulator.
+    constexpr int U = ((F8 && STAGE) ? 16 : 8) / T;      // x rides the ring in registers when it is not staged: keep it short there
+    constexpr int WL = F8 ? 1 : 2;
+    u32x4 w[U][T][WL];
     const int cend = min(c0 + per, nchunks);
     const bf16_t* wrow[T];
     const bool tiled = p.w_tiled != 0;    // fragment-ordered weights [n_tile][chunk][kstep][lane][8] (common.h)
@@ -61,10 +64,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     for (int t = 0; t < T; ++t)
         wrow[t] = tiled ? p.W + (size_t)((active ? tile : 0) * T + t) * 16 * p.K + lane * 8
                         : p.W + (size_t)((active ? tile : 0) * T * 16 + t * 16 + fr) * p.K + fg * 16;
+    const unsigned char* w8row[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) w8row[t] = F8 ? p.W8 + (size_t)((active ? tile : 0) * T + t) * 16 * p.K + lane * 16 : nullptr;
     auto fill_w = [&](int u, int c) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            if (tiled) {
+            if constexpr (F8) {
+                w[u][t][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(w8row[t] + (size_t)c * 1024));
+            } else if (tiled) {
                 w[u][t][0] = ldg_nt(wrow[t] + (size_t)c * 1024);
                 w[u][t][1] = ldg_nt(wrow[t] + (size_t)c * 1024 + 512);
             } else {
@@ -240,12 +248,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                     const int xu = STAGE ? xu_static : u;
                     if constexpr (STAGE) fill_x(0, c + u);
 #pragma unroll
-                    for (int t = 0; t < T; ++t)
+                    for (int t = 0; t < T; ++t) {
+                        u32x4 w0, w1;
+                        if constexpr (F8) {
+                            const u32x4 q = w[u][t][0];
+                            uint32_t d[8];
+                            f8x4_to_bf16(q[0], d[0], d[1]); f8x4_to_bf16(q[1], d[2], d[3]);
+                            f8x4_to_bf16(q[2], d[4], d[5]); f8x4_to_bf16(q[3], d[6], d[7]);
+                            w0 = u32x4{d[0], d[1], d[2], d[3]};
+                            w1 = u32x4{d[4], d[5], d[6], d[7]};
+                        } else {
+                            w0 = w[u][t][0];
+                            w1 = w[u][t][WL - 1];
+                        }
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][0]), as_frag(xv[STAGE ? 0 : u][mt][0]), acc[t][mt], 0, 0, 0);
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][1]), as_frag(xv[STAGE ? 0 : u][mt][1]), acc[t][mt], 0, 0, 0);
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w0), as_frag(xv[STAGE ? 0 : u][mt][0]), acc[t][mt], 0, 0, 0);
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w1), as_frag(xv[STAGE ? 0 : u][mt][1]), acc[t][mt], 0, 0, 0);
                         }
+                    }
                     (void)xu;
                     if (c + U + u < cend) {
                         fill_w(u, c + U + u);
@@ -284,6 +305,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
 
     // ---------------------------------------------------------------- epilogue (wave kp == 0 of each tile)
     // lane owns batch row m = mt*16 + fr and output columns tile*16 + fg*4 + {0..3}
+    if constexpr (F8) {
+        if (active && kp == 0) {        // per-output-channel scale of the fp8 weights (engine row order, gate / up interleaved)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float4 sc = *reinterpret_cast<const float4*>(p.w_scale + (size_t)(tile * T + t) * 16 + fg * 4);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[t][mt][0] *= sc.x; acc[t][mt][1] *= sc.y; acc[t][mt][2] *= sc.z; acc[t][mt][3] *= sc.w;
+                }
+            }
+        }
+    }
     float bestv[MT];
     int besti[MT];
 #pragma unroll
@@ -512,7 +545,7 @@ int launch_32(hipStream_t s, const GemvArgs& a) {
 
 size_t stage_bytes(const GemvArgs& a) { return ((size_t)a.M * (a.K + 8) * 2 + 15) / 16 * 16; }
 
-template <int MODE, int MT, int KP, bool STAGE, int WAVES>
+template <int MODE, int MT, int KP, bool STAGE, int WAVES, bool F8 = false>
 int launch_k(hipStream_t s, const GemvArgs& a) {
     constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;
     constexpr int TPB = WAVES / KP;
@@ -529,12 +562,12 @@ int launch_k(hipStream_t s, const GemvArgs& a) {
     if (smem > 160 * 1024) return -12;
     static size_t attr = 0;
     if (smem > 64 * 1024 && smem > attr) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemv<MODE, MT, KP, STAGE, WAVES>),
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemv<MODE, MT, KP, STAGE, WAVES, F8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (r != hipSuccess) return (int)r;
         attr = smem;
     }
-    hipLaunchKernelGGL((k_gemv<MODE, MT, KP, STAGE, WAVES>), grid, dim3(WAVES * 64), smem, s, a, ntiles);
+    hipLaunchKernelGGL((k_gemv<MODE, MT, KP, STAGE, WAVES, F8>), grid, dim3(WAVES * 64), smem, s, a, ntiles);
     SR_CHECK_LAUNCH();
     return 0;
 }
@@ -546,13 +579,13 @@ bool can_stage(const GemvArgs& a) { return a.K % 512 == 0 && stage_bytes(a) + 10
 // saves, and only 172 of 256 CUs get a block.  Kept as a template parameter for experiments; not dispatched.
 bool use_big(const GemvArgs&, int) { return false; }
 
-template <int MODE, int KP>
+template <int MODE, int KP, bool F8 = false>
 int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
     const bool stage = a.norm_w != nullptr;
     if constexpr (MODE == GV_BIAS || MODE == GV_SWIGLU || MODE == GV_F32) {
-        if (stage) return a.M <= 16 ? launch_k<MODE, 1, KP, true, 4>(s, a) : launch_k<MODE, 2, KP, true, 4>(s, a);
+        if (stage) return a.M <= 16 ? launch_k<MODE, 1, KP, true, 4, F8>(s, a) : launch_k<MODE, 2, KP, true, 4, F8>(s, a);
     }
-    return a.M <= 16 ? launch_k<MODE, 1, KP, false, 4>(s, a) : launch_k<MODE, 2, KP, false, 4>(s, a);
+    return a.M <= 16 ? launch_k<MODE, 1, KP, false, 4, F8>(s, a) : launch_k<MODE, 2, KP, false, 4, F8>(s, a);
 }
 }  // namespace
 
@@ -592,6 +625,17 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     static const char* kp_env = getenv("SR_GEMV_KP");          // tuning hook for tools/bench_gemv.py
     if (kp_env && mode != GV_F32) want = atoi(kp_env);
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
+    if (a.W8) {          // fp8 weight stream (decode of the quantised LM linears); the in-block K split is always 4 there
+        if (!a.w_scale || mode == GV_F32) return -22;
+        if (kp != 4) return -22;
+        switch (mode) {
+            case GV_PARTIAL: return launch_small<GV_PARTIAL, 4, true>(s, a);
+            case GV_SWIGLU: return launch_small<GV_SWIGLU, 4, true>(s, a);
+            case GV_BIAS: return launch_small<GV_BIAS, 4, true>(s, a);
+            case GV_RESID: return launch_small<GV_RESID, 4, true>(s, a);
+        }
+        return -22;
+    }
     if (use_32(a, mode)) {
         switch (mode) {
             case GV_PARTIAL: return kp == 4 ? launch_32<GV_PARTIAL, 4>(s, a) : kp == 2 ? launch_32<GV_PARTIAL, 2>(s, a) : launch_32<GV_PARTIAL, 1>(s, a);

@@ -15,6 +15,7 @@ struct GemmArgs {
     const bf16_t* resid;        // EPI_RESID: [M, ldo] (may alias out)
     const int* rowmap;          // optional destination row per source row
     int w_tiled;                // W stored fragment-ordered (tiled16x64, see common.h) instead of row-major
+    const float* w_scale;       // optional [N]: per-output-channel scale applied to the accumulator (fp8-quantised W)
 };
 int launch_gemm(hipStream_t s, const GemmArgs& a, int epi);
 
@@ -33,6 +34,8 @@ struct GemvArgs {
     bf16_t* x_out;                          // with slabs: block 0 stores h = bf16(x + bf16(sum slabs)) here (ld = ldx)
     float* amax_val; int* amax_idx;         // F32: per-block (max, lowest index) [M][gridDim.x] (null: skip)
     int w_tiled;                            // W stored fragment-ordered (tiled16x64) instead of row-major
+    const unsigned char* W8;                // non-null: stream THIS fp8 image (tiled8, common.h) instead of W ...
+    const float* w_scale;                   // ... and scale output channel n by w_scale[n]
 };
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode);
 int gemv_f32_blocks(int N, int M, int K, int has_norm);    // gridDim.x of the F32 launch (length of the amax rows)
@@ -111,6 +114,9 @@ struct StepArgs {
     const int* row_limit;       // optional [B]: a row finishes after this many generated tokens (continuous batching)
     int* n_gen;                 // [B]: tokens generated while the row was live (pads written after eos are not counted)
 };
+// fp8 quantisation of a fragment-ordered bf16 matrix [N, K]: scale[n] = amax_n / 448 (1 if the row is zero),
+// q = fp8(W / scale) -> W8 (tiled8); W itself is overwritten with q as bf16 (what the prefill GEMM multiplies, scaled in its epilogue)
+int launch_quant_f8(hipStream_t s, bf16_t* W_tiled, int N, int K, unsigned char* W8, float* scale);
 int launch_step(hipStream_t s, const StepArgs& a);
 // continuous batching: install n freshly prefilled sequences into batch rows (state + pending first token)
 struct AdmitArgs {

@@ -11,7 +11,7 @@ from . import lib as L
 from .config import ModelGeometry
 
 
-def _sr_config(g: ModelGeometry, max_patches, max_prefill_tokens, max_batch, max_ctx, max_new_tokens) -> L.SrConfig:
+def _sr_config(g: ModelGeometry, max_patches, max_prefill_tokens, max_batch, max_ctx, max_new_tokens, lm_fp8=False) -> L.SrConfig:
     v, t = g.vision, g.text
     c = L.SrConfig()
     c.v_depth, c.v_hidden, c.v_heads, c.v_inter = v.depth, v.hidden_size, v.num_heads, v.intermediate_size
@@ -28,19 +28,20 @@ def _sr_config(g: ModelGeometry, max_patches, max_prefill_tokens, max_batch, max
     c.image_token_id = g.image_token_id
     c.max_patches, c.max_prefill_tokens, c.max_batch = max_patches, max_prefill_tokens, max_batch
     c.max_ctx, c.max_new_tokens = max_ctx, max_new_tokens
+    c.lm_weight_dtype = 1 if lm_fp8 else 0
     return c
 
 
 class Engine:
     def __init__(self, geometry: ModelGeometry, *, max_patches=1024, max_prefill_tokens=512, max_batch=1, max_ctx=640,
-                 max_new_tokens=128, device="cuda:0"):
+                 max_new_tokens=128, device="cuda:0", lm_fp8: bool = False):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.SocioRError("no GPU visible: the product path has no CPU fallback")
         self.geom = geometry
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        self.cfg = _sr_config(geometry, max_patches, max_prefill_tokens, max_batch, max_ctx, max_new_tokens)
+        self.cfg = _sr_config(geometry, max_patches, max_prefill_tokens, max_batch, max_ctx, max_new_tokens, lm_fp8)
         nbytes = self.lib.sr_workspace_bytes(C.byref(self.cfg))
         if nbytes == 0:
             raise L.SocioRError("invalid engine configuration: " + self.lib.sr_last_error(None).decode())
@@ -119,6 +120,7 @@ class Engine:
         n = self.lib.sr_weights_missing(self._h, buf, 200)
         if n:
             raise L.SocioRError(f"{n} parameters missing, e.g. {buf.value.decode()}")
+        L.check(self.lib.sr_finalize_weights(self._h, self._s()), self._h, "sr_finalize_weights")   # fp8 mode: quantise
 
     # ------------------------------------------------------------------ ViT
     def patchify(self, img_u8: torch.Tensor) -> torch.Tensor:

@@ -231,6 +231,74 @@ def test_gemv_fused_prologue_and_epilogues(L, M):
         assert float(av[m].max()) == float(mx) and int(cand) == first, (m, k)
 
 
+# ------------------------------------------------------------------------------------------------ fp8 weight stream
+@pytest.mark.parametrize("N,K", [(2560, 2048), (2048, 11008), (64, 512)])
+def test_quant_f8_bit_exact(L, N, K):
+    """configs[4]: the device quantiser (scale = amax/448 per output channel, q = fp8 e4m3 RNE) equals the oracle's
+    definition bit for bit: scales, fp8 bytes in the tiled8 order, and the bf16 image of q left in place of W."""
+    from oracle import model_ref as MR
+    from tests.util import tile8
+    w = rnd((N, K), 70 + N % 7, 0.03)
+    w[3] = 0                                         # an all-zero row: scale 1, q 0
+    w[5, 7] = 3.0                                    # an outlier sets its row's scale
+    ref = MR.QuantW(w.float())
+    wt = tile16x64(w).cuda().contiguous()
+    w8 = torch.zeros(N * K, dtype=torch.uint8, device="cuda")
+    sc = torch.zeros(N, dtype=torch.float32, device="cuda")
+    assert L.sr_op_quant_f8(P(wt), N, K, P(w8), P(sc), sp()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(sc.cpu(), ref.scale)
+    assert torch.equal(w8.cpu().view(N, K), tile8(ref.q8.view(torch.uint8)))
+    assert torch.equal(wt.cpu().view(torch.int16), tile16x64(ref.q.to(torch.bfloat16)).view(torch.int16))
+
+
+@pytest.mark.parametrize("M", [1, 4, 5, 17, 32])
+def test_gemv_f8_modes(L, M):
+    """decode GEMV on the fp8 image (widened to bf16 in registers, scale on the accumulator) against the oracle's
+    quantised Linear: bias (+ fused RMSNorm at M <= 4), residual, SwiGLU, float32 K-split partials."""
+    from oracle import model_ref as MR
+    from tests.util import tile8
+    K, N, I = 2048, 2560, 11008
+    x = rnd((M, K), 80, 1.5)
+    def quant(w):
+        q = MR.QuantW(w.float())
+        return q, tile8(q.q8.view(torch.uint8)).cuda().contiguous(), q.scale.cuda()
+    # BIAS (qkv), with the norm prologue where the engine uses it
+    w, b = rnd((N, K), 81, 0.03), rnd((N,), 82, 0.1)
+    nw = (1 + rnd((K,), 83, 0.05).float()).to(torch.bfloat16)
+    qw, w8, sc = quant(w)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    fused = M <= 4
+    assert L.sr_op_gemv_f8(P(D(x)), K, P(w8), P(sc), M, N, K, P(out), N, 3, P(D(b)), P(D(nw)) if fused else None, C.c_float(1e-6), 1, sp()) == 0
+    xin = MR.rmsnorm(x.float(), nw.float(), 1e-6) if fused else x.float()
+    assert_bf16_close(out.float().cpu(), MR.linear(xin, qw, b.float()), 1, 0.02, "f8 gemv bias")
+    # RESID (o_proj)
+    wo = rnd((2048, K), 84, 0.03)
+    qo, o8, so = quant(wo)
+    res = rnd((M, 2048), 85)
+    rd = res.cuda().clone()
+    assert L.sr_op_gemv_f8(P(D(x)), K, P(o8), P(so), M, 2048, K, P(rd), 2048, 4, None, None, C.c_float(0), 1, sp()) == 0
+    assert_bf16_close(rd.float().cpu(), MR.r(res.float() + MR.linear(x.float(), qo)), 1, 0.01, "f8 gemv resid")
+    # SWIGLU (gate / up interleaved in blocks of 16 rows)
+    g, u = rnd((I, K), 86, 0.03), rnd((I, K), 87, 0.03)
+    qg, qu = MR.QuantW(g.float()), MR.QuantW(u.float())
+    gu8 = tile8(interleave16(qg.q8.view(torch.uint8), qu.q8.view(torch.uint8))).cuda().contiguous()
+    gus = interleave16(qg.scale[:, None], qu.scale[:, None])[:, 0].cuda().contiguous()
+    act = torch.zeros(M, I, dtype=torch.bfloat16, device="cuda")
+    assert L.sr_op_gemv_f8(P(D(x)), K, P(gu8), P(gus), M, 2 * I, K, P(act), I, 1, None, P(D(nw)) if fused else None, C.c_float(1e-6), 1, sp()) == 0
+    want = MR.r(MR.silu_bf16(MR.linear(xin, qg)) * MR.linear(xin, qu))
+    assert_bf16_close(act.float().cpu(), want, 3, 0.005, "f8 gemv swiglu")
+    # PARTIAL (down-projection slabs)
+    xa = rnd((M, I), 88, 0.5)
+    wd = rnd((2048, I), 89, 0.03)
+    qd, d8, sd = quant(wd)
+    for ks in (2, 4):
+        slabs = torch.zeros(ks, M, 2048, dtype=torch.float32, device="cuda")
+        assert L.sr_op_gemv_f8(P(D(xa)), I, P(d8), P(sd), M, 2048, I, P(slabs), 2048, 0, None, None, C.c_float(0), ks, sp()) == 0
+        ref = (xa.double() @ qd.q.double().t()) * qd.scale.double()
+        assert float((slabs.sum(0).cpu().double() - ref).abs().max()) <= 2e-3, ks
+
+
 # ------------------------------------------------------------------------------------------------ norms / argmax
 @pytest.mark.parametrize("rows,H", [(1024, 1280), (448, 2048), (3, 512), (1, 2048), (9, 320)])
 def test_rmsnorm_and_resid(L, rows, H):
@@ -347,6 +415,47 @@ def test_tiny_vit_and_prefill_and_decode(tiny_engine, golden_dir):
         top2 = lg_ref[i].topk(2).values
         if float(top2[0] - top2[1]) > 0.08:
             assert int(toks[0, i]) == toks_ref[i], i
+
+
+def test_tiny_fp8_weights_prefill_and_decode(golden_dir):
+    """configs[4] (fp8 LM linears): engine with lm_fp8 against the oracle with the same quantisation definition --
+    prefill logits, teacher-forced decode logits (the decode GEMV streams the fp8 image, the prefill GEMM the bf16 image
+    of the same q), graph == eager."""
+    from oracle import model_ref as MR
+    from oracle import weights as WG
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.engine import Engine
+    g = np.load(os.path.join(golden_dir, "hf_tiny.npz"))
+    cfg = MR.config_tiny()
+    W = MR.Fp8LmWeights(WG.LazyWeights(cfg, seed=0))
+    eng = Engine(geometry_tiny(), max_patches=512, max_prefill_tokens=256, max_batch=2, max_ctx=192, max_new_tokens=16, lm_fp8=True)
+    eng.load_synthetic_weights(seed=0)
+    grids = [tuple(x) for x in g["grids"].tolist()]
+    img_ref = MR.vit_forward(W, cfg, bits_to_f32(g["pix"]), grids)
+    ids, pos3 = g["ids"], g["pos3"]
+    emb = img_ref.to(torch.bfloat16).cuda()
+    logits = eng.prefill([ids], [pos3], emb, return_logits=True)
+    x = MR.embed_with_images(W, cfg, torch.from_numpy(ids), img_ref)
+    ref_logits = MR.lm_forward(W, cfg, x, torch.from_numpy(pos3), MR.new_caches(cfg))[0]
+    d = (logits[0].cpu() - ref_logits).abs()
+    assert float(d.max()) <= 0.03, ("fp8 prefill logits", float(d.max()))
+    # the quantisation is visible: logits differ from the bf16 model's by more than the parity bound
+    Wb = WG.LazyWeights(cfg, seed=0)
+    bf = MR.lm_forward(Wb, cfg, MR.embed_with_images(Wb, cfg, torch.from_numpy(ids), img_ref), torch.from_numpy(pos3), MR.new_caches(cfg))[0]
+    assert float((bf - ref_logits).abs().max()) > 0.03
+    n_new = 10
+    toks_ref, lg_ref = MR.generate_greedy(W, cfg, torch.from_numpy(ids), torch.from_numpy(pos3), img_ref, n_new)
+    forced = torch.tensor([toks_ref + [0] * (16 - len(toks_ref))], dtype=torch.int32)
+    eng.prefill([ids], [pos3], emb)
+    toks, trace = eng.decode(16, trace=True, forced=forced, use_graph=False)
+    for i in range(n_new):
+        dd = (trace[i, 0].cpu() - lg_ref[i]).abs()
+        assert float(dd.max()) <= 0.04, (i, float(dd.max()))
+    eng.prefill([ids], [pos3], emb)
+    a = eng.decode(16, use_graph=False)
+    eng.prefill([ids], [pos3], emb)
+    assert torch.equal(a, eng.decode(16, use_graph=True))
+    eng.close()
 
 
 def test_decode_graph_equals_eager_and_batch_invariance(tiny_engine, golden_dir):

@@ -37,3 +37,11 @@ def tile16x64(w: torch.Tensor) -> torch.Tensor:
     N, K = w.shape
     assert N % 16 == 0 and K % 64 == 0
     return w.reshape(N // 16, 16, K // 64, 4, 2, 8).permute(0, 2, 4, 3, 1, 5).contiguous().reshape(N, K)
+
+
+def tile8(q: torch.Tensor) -> torch.Tensor:
+    """Row-major [N, K] bytes -> the fp8 fragment order (socioreasoner_amd/csrc/common.h tiled8_offset):
+    [n/16][k/64][lane=((k%64)/16)*16 + n%16][k%16]."""
+    N, K = q.shape
+    assert N % 16 == 0 and K % 64 == 0
+    return q.reshape(N // 16, 16, K // 64, 4, 16).permute(0, 2, 3, 1, 4).contiguous().reshape(N, K)
