@@ -707,3 +707,42 @@ def test_full_size_3b_properties():
         if float(top2[0] - top2[1]) > 0.16 * scale:
             assert int(lg[0].argmax()) == int(trace[k, 0].argmax())
     e.close()
+
+
+def test_full_size_config5_fp8_896_tile():
+    """BASELINE.json configs[4] at full size on one GPU: fp8 LM linears, one 896 x 896 tile (4096 patches -> 1024 image
+    tokens, full-attention blocks over 4096 keys, S = 1216 prompt).  Size-independent properties: graph == eager and
+    deterministic; ViT batch invariance; KV-cache consistency between the fp8 decode GEMV path and the prefill GEMM path
+    (bf16 image of the same quantised weights) within the bf16 noise floor."""
+    from socioreasoner_amd import hostops, synthetic
+    from socioreasoner_amd.config import geometry_3b
+    from socioreasoner_amd.engine import Engine
+    geom = geometry_3b()
+    e = Engine(geom, max_patches=8192, max_prefill_tokens=1280, max_batch=2, max_ctx=1280, max_new_tokens=8, lm_fp8=True)
+    e.load_synthetic_weights(seed=0)
+    grid = (1, 64, 64)
+
+    def prep(i, extra=()):
+        ids = np.concatenate([synthetic.tile_prompt(geom, i, grid), np.asarray(extra, dtype=np.int64)])
+        p, _ = hostops.get_rope_index(torch.from_numpy(ids)[None], [grid], None)
+        return ids, p[:, 0].numpy()
+    pix0 = e.patchify(torch.from_numpy(synthetic.tile_pixels(0, 896, 896)).cuda())
+    pix1 = e.patchify(torch.from_numpy(synthetic.tile_pixels(1, 896, 896)).cuda())
+    assert pix0.shape[0] == 4096
+    emb0 = e.vit_forward(pix0, [grid])
+    emb10 = e.vit_forward(torch.cat([pix1, pix0]), [grid] * 2)
+    assert emb0.shape == (1024, 2048) and torch.equal(emb10[1024:], emb0) and bool(torch.isfinite(emb0.float()).all())
+    ids0, pos0 = prep(0)
+    assert len(ids0) == 1216
+    e.prefill([ids0], [pos0], emb0)
+    eager, trace = e.decode(8, trace=True, use_graph=False)
+    e.prefill([ids0], [pos0], emb0)
+    graph = e.decode(8, use_graph=True)
+    assert torch.equal(eager, graph) and bool(torch.isfinite(trace).all())
+    toks = eager[0].tolist()
+    idk, posk = prep(0, toks[:3])
+    lg = e.prefill([idk], [posk], emb0, return_logits=True)
+    d = (lg[0] - trace[3, 0]).abs()
+    scale = float(trace[3, 0].abs().max())
+    assert float(d.max()) <= 0.08 * max(scale, 1.0), (float(d.max()), scale)
+    e.close()

@@ -7,8 +7,7 @@ stage() { name=$1; shift; echo "=== $name"; timeout "$T" "$@" > gpurun_out/$name
 : > gpurun_out/summary.txt
 rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit" | head -4 >> gpurun_out/summary.txt
 nproc >> gpurun_out/summary.txt
-T=600 stage ops python -m pytest tests/test_gpu_parity.py -q -m gpu -k "synth or gemm or gemv or rmsnorm or argmax or raster or tiled" -p no:cacheprovider
-T=600 stage tiny python -m pytest tests/test_gpu_parity.py -q -m gpu -k "patchify or tiny or decode_graph" -p no:cacheprovider
+T=900 stage ops_tiny python -m pytest tests/test_gpu_parity.py -q -m gpu -k "not (truedim or full_size or ragged)" -p no:cacheprovider
 T=900 stage truedim python -m pytest tests/test_gpu_parity.py -q -m gpu -k "truedim or full_size or ragged" -p no:cacheprovider
 T=600 stage pipeline python -m pytest tests/test_gpu_pipeline.py -q -m gpu -p no:cacheprovider
 T=300 stage smoke python -c "import __graft_entry__ as g; g.smoke()"
