@@ -149,10 +149,7 @@ def main():
     torch.cuda.synchronize(dev)
     dp.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = dp.all_reduce_max(dt, dev)
     tiles_per_s = world * B * (2 if args.continuous else 1) * args.steps / dt
 
     # ---- roofline of the dominant kernel (k_gemv, the decode weight stream): HIP events on the launch stream around

@@ -76,6 +76,7 @@ class Mi355xStrategy(InferenceStrategy):
         self.engine = Engine(self.geom, max_patches=int(sc.get("max_patches", 2048 * 2 * 4)),
                              max_prefill_tokens=int(sc.get("max_prefill_tokens", min(prompt_len, 1024) * 8)),
                              max_batch=self.max_batch, max_ctx=max_ctx, max_new_tokens=min(resp_len, max_ctx - 1),
+                             lm_fp8=str(sc.get("quantization", "") or "").lower() in ("fp8", "fp8_e4m3"),   # vLLM's knob name
                              device=f"cuda:{int(_get(getattr(self.worker, 'rank_info', None), 'local_rank', 0) or 0)}")
         import os
         if os.path.isdir(path):

@@ -32,11 +32,14 @@ def init_distributed(backend: str | None = None):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SR_DIST_BACKEND") or \
+                ("nccl" if torch.cuda.is_available() and torch.cuda.device_count() >= world else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
             torch.cuda.set_device(local)
+        elif torch.cuda.is_available():      # more ranks than GPUs (development box): share the devices, exchange over gloo
+            local = local % torch.cuda.device_count()
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -48,11 +51,13 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
     world = dist.get_world_size(group)
     sizes = split_sizes(n_total, world)
     mx = max(sizes)
-    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
+    dev = local.device
+    xdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev     # gloo exchanges host tensors
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=xdev)
+    pad[: local.shape[0]] = local.to(xdev)
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0).to(dev)
 
 
 def decode_with_logits_gather(step_fn, first_logits: torch.Tensor, n_new: int, n_total: int, group=None):
@@ -77,6 +82,16 @@ def decode_with_logits_gather(step_fn, first_logits: torch.Tensor, n_new: int, n
         if i + 1 < n_new:
             logits, own = step_fn(pick[lo:lo + b_local].contiguous())
     return torch.stack(toks, dim=1), mismatches
+
+
+def all_reduce_max(value: float, device=None) -> float:
+    """max over ranks of a host scalar (the bench's timing rule)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    dev = torch.device("cpu") if dist.get_backend() == "gloo" or device is None else device
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def barrier():

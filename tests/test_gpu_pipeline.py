@@ -342,3 +342,28 @@ def test_request_level_serving_on_the_engine():
         assert torch.equal(out0.batch[k], out1.batch[k]), k
     assert int(out0.batch["response_mask"].sum()) > 0
     w.strategy.engine.close()
+
+
+def test_two_rank_data_parallel_bench_equals_single_process():
+    """Section 8(E): two torchrun ranks (RCCL when there are two GPUs, gloo + shared GPU on a one-GPU box), one tile each,
+    give the result rows of one process running both tiles; the logits all-gather verification mode agrees as well."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(cmd, port=None):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    tr = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    one = run([sys.executable, "bench.py", "--batch", "2"] + common)
+    two = run(tr + ["--master-port", "29551", "bench.py", "--gpus", "2"] + common)
+    ver = run(tr + ["--master-port", "29552", "bench.py", "--gpus", "2", "--gather-logits"] + common)
+    assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "dp2" and two["scaling"] == "weak"
+    assert one["result_checksum"] == two["result_checksum"] == ver["result_checksum"]
+    for j in (one, two):
+        assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1 and j["unit"] == "tiles/s"
