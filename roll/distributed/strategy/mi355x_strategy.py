@@ -111,6 +111,14 @@ class Mi355xStrategy(InferenceStrategy):
         f = g.vision.patch_size * g.vision.spatial_merge_size
         ims, grids = [], []
         for im in images or []:
+            if isinstance(im, torch.Tensor) and im.is_cuda:      # device-resident uint8 HWC (stage 2: the render kernel's output)
+                h, w = int(im.shape[0]), int(im.shape[1])
+                rh, rw = hostops.smart_resize(h, w, factor=f)
+                if (rh, rw) == (h, w):
+                    ims.append(im.contiguous())
+                    grids.append((1, rh // g.vision.patch_size, rw // g.vision.patch_size))
+                    continue
+                im = im.cpu().numpy()                            # a size the ViT cannot take: bicubic resize on the host
             arr = np.asarray(im.convert("RGB")) if hasattr(im, "convert") else np.asarray(im)
             h, w = arr.shape[:2]
             rh, rw = hostops.smart_resize(h, w, factor=f)

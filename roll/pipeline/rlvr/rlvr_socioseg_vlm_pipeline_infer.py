@@ -80,9 +80,11 @@ def format_prompt_2(prompt, bboxs, processor, use_image=True, prompt_image_token
     return _chat(processor, _Q2.format(prompt=prompt, bboxs=bboxs, answer=_A2), use_image, prompt_image_token)
 
 
-def render_image(bboxes_json: str, images: List[Any], mask: Union[np.ndarray, Any]) -> List[Any]:
+def render_image(bboxes_json: str, images: List[Any], mask: Union[np.ndarray, Any], keep_on_device: bool = False) -> List[Any]:
     """Reference :383-452 on the device: nearest-resize of the mask to the image, 2-px blue box outlines, 40 % red
-    overlay (PIL alpha_composite arithmetic).  Accepts PIL images or uint8 HWC arrays, returns the same kind."""
+    overlay (PIL alpha_composite arithmetic).  Accepts PIL images, uint8 HWC arrays or CUDA tensors; returns the same kind,
+    or -- with keep_on_device -- uint8 HWC CUDA tensors that the strategy patchifies without a host round trip (SURVEY
+    "next" row N3)."""
     try:
         data = json.loads(bboxes_json)
         boxes = [it["bbox_2d"] for it in data if isinstance(it, dict) and "bbox_2d" in it and len(it["bbox_2d"]) == 4] \
@@ -91,14 +93,23 @@ def render_image(bboxes_json: str, images: List[Any], mask: Union[np.ndarray, An
         boxes = []
     m = None
     if mask is not None:
-        m = np.asarray(mask.convert("L")) if hasattr(mask, "convert") else np.asarray(mask)
-        m = torch.from_numpy(np.ascontiguousarray((m > 0).astype(np.uint8))).cuda()
+        if isinstance(mask, torch.Tensor):
+            m = (mask > 0).to(torch.uint8).cuda().contiguous()
+        else:
+            mm = np.asarray(mask.convert("L")) if hasattr(mask, "convert") else np.asarray(mask)
+            m = torch.from_numpy(np.ascontiguousarray((mm > 0).astype(np.uint8))).cuda()
     out = []
     for im in images:
         is_pil = hasattr(im, "convert")
-        arr = np.asarray(im.convert("RGB")) if is_pil else np.asarray(im)
-        t = torch.from_numpy(np.array(arr, dtype=np.uint8, order="C")).cuda()
+        if isinstance(im, torch.Tensor):
+            t = im.cuda().clone()
+        else:
+            arr = np.asarray(im.convert("RGB")) if is_pil else np.asarray(im)
+            t = torch.from_numpy(np.array(arr, dtype=np.uint8, order="C")).cuda()
         raster.render_overlay_(t, m, boxes)
+        if keep_on_device or isinstance(im, torch.Tensor):
+            out.append(t)
+            continue
         res = t.cpu().numpy()
         if is_pil:
             from PIL import Image
@@ -184,7 +195,7 @@ def draw_visual_prompt(image, mask, visual_prompt):
     """Mask overlay (device kernel) + the prompt's box (2-px blue) and points (radius-5 discs: green positive, red
     negative) for the render1 / render2 outputs (reference :454-509)."""
     from PIL import Image, ImageDraw
-    arr = torch.from_numpy(np.ascontiguousarray(np.asarray(image.convert("RGB")))).cuda()
+    arr = torch.from_numpy(np.array(image.convert("RGB"), dtype=np.uint8, order="C")).cuda()
     try:
         m = np.asarray(mask.convert("L")) if hasattr(mask, "convert") else np.asarray(mask)
         raster.render_overlay_(arr, torch.from_numpy(np.ascontiguousarray((m > 0).astype(np.uint8))).cuda(), [])
@@ -268,19 +279,29 @@ class SocioSegInferPipeline(BasePipeline):
         """Render stage 1 onto both images and build the stage-2 prompts (reference :714-825)."""
         cfg = self.pipeline_config
         padded, loose, grids = defaultdict(list), defaultdict(list), []
+        ip = self.processor.image_processor
+        m2 = ip.merge_size ** 2
+        img_tok = "<|image_pad|>"
         for question, bboxs_text, images, mask in zip(batch.non_tensor_batch["question"], bboxs_text_list,
                                                       batch.non_tensor_batch["image"], batch.non_tensor_batch["map_mask"]):
             text = format_prompt_2(question, bboxs_text, self.processor)
-            rd_image = render_image(bboxs_text, images, mask)
-            enc = self.processor(images=rd_image, text=text)
-            for k in ("input_ids", "attention_mask", "labels"):
-                if k in enc:
-                    padded[k].append(enc.pop(k)[0])
-            enc.convert_to_tensors(tensor_type="pt")
-            grids.append(enc["image_grid_thw"])
-            loose["multi_modal_sat_inputs"].append(dict(enc))
+            # the rendered pair stays in HBM (uint8 HWC): render kernel -> patchify kernel, no PIL / host copy in between;
+            # what the processor would have contributed -- the grid and the expanded placeholders -- is computed here
+            rd_image = render_image(bboxs_text, images, mask, keep_on_device=True)
+            grid = torch.tensor([[1, int(t.shape[0]) // ip.patch_size, int(t.shape[1]) // ip.patch_size] for t in rd_image], dtype=torch.long)
+            pieces = text.split(img_tok)
+            if len(pieces) - 1 != len(rd_image):
+                raise ValueError(f"text has {len(pieces) - 1} image placeholders for {len(rd_image)} images")
+            full = pieces[0]
+            for g_, rest in zip(grid.tolist(), pieces[1:]):
+                full += img_tok * (g_[0] * g_[1] * g_[2] // m2) + rest
+            ids = self.tokenizer.encode(full, add_special_tokens=False)
+            padded["input_ids"].append(ids)
+            padded["attention_mask"].append([1] * len(ids))
+            grids.append(grid)
+            loose["multi_modal_sat_inputs"].append({"image_grid_thw": grid})
             loose["multi_modal_sat_data"].append({"prompt_token_ids": self.tokenizer.encode(text, add_special_tokens=False),
-                                                  "multi_modal_data": {"image": rd_image if isinstance(rd_image, list) else [rd_image]}})
+                                                  "multi_modal_data": {"image": rd_image}})
         sat = self.tokenizer.pad(padded, padding="max_length", max_length=int(cfg.prompt_length), pad_to_multiple_of=None, return_tensors="pt")
         sat = {"input_ids": sat["input_ids"], "attention_mask": sat["attention_mask"]}
         extra = self.extra_data_provider(input_ids=sat["input_ids"], attention_mask=sat["attention_mask"], image_grid_thw=torch.cat(grids, dim=0))

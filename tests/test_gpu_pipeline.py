@@ -137,7 +137,8 @@ def test_pipeline_two_stage_flow_against_oracle(tmp_path):
                 if "have been rendered" in text:                       # stage 2: add points to the boxes that were found
                     q = re.search(r'segmentation for "(.*?)" have been rendered', text).group(1)
                     found = re.search(r"The found bbox\(s\) are: (.*?)\.Please add some points", text, re.DOTALL).group(1)
-                    seen["stage2_images"][q] = [np.asarray(im) for im in payload["multi_modal_data"]["image"]]
+                    assert all(isinstance(im, torch.Tensor) and im.is_cuda for im in payload["multi_modal_data"]["image"])   # N3: no host round trip
+                    seen["stage2_images"][q] = [im.cpu().numpy() for im in payload["multi_modal_data"]["image"]]
                     seen["stage2_text"][q] = found
                     try:
                         objs = [{"bbox_2d": o["bbox_2d"], "points": [[(o["bbox_2d"][0] + o["bbox_2d"][2]) // 2, (o["bbox_2d"][1] + o["bbox_2d"][3]) // 2],
