@@ -96,13 +96,52 @@ class Mi355xStrategy(InferenceStrategy):
             ri.dp_rank, ri.dp_size = getattr(self.worker, "rank", 0), getattr(self.worker, "world_size", 1)
 
     def load_states(self, *args, **kwargs):
+        self._finish_weight_update()
         return None          # 7.5 GB of weights stay resident in 288 GB of HBM: nothing to reload
 
     def offload_states(self, include=None, non_blocking=False):
         return None
 
-    def setup_collective_group(self, *args, **kwargs):
-        return None          # weights are loaded directly; no trainer -> engine broadcast on the infer path
+    # ------------------------------------------------------------------ trainer -> engine weight sync (reference
+    # vllm_strategy.py:258-271 -> worker_helper.py:64-115).  The sender is rank `src_rank` of a torch.distributed group
+    # (RCCL over xGMI on the node); with no group the update_* entry points can still be fed directly.
+    def setup_collective_group(self, comm_plan=None, backend=None, rank_in_cluster=None, group=None, src_rank: int = 0):
+        self._sync_group, self._sync_src = group, int(src_rank)
+        return None
+
+    def _bcast(self, t: torch.Tensor):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("broadcast_* needs torch.distributed (torchrun); use update_parameter* to feed tensors directly")
+        grp = getattr(self, "_sync_group", None)
+        xt = t.cpu() if dist.get_backend(grp) == "gloo" else t
+        dist.broadcast(xt, src=getattr(self, "_sync_src", 0), group=grp)
+        return xt.to(t.device)
+
+    def broadcast_bucket(self, src_pp_rank, meta_infos, bucket_size):
+        buf = torch.empty(int(bucket_size), dtype=torch.int8, device="cuda")
+        self.update_parameter_in_bucket(meta_infos, self._bcast(buf), None)
+
+    def broadcast_parameter(self, src_pp_rank, dtype, shape, parameter_name):
+        self.update_parameter(parameter_name, self._bcast(torch.empty(tuple(shape), dtype=dtype, device="cuda")), None)
+
+    def update_parameter(self, parameter_name, weight, ranks_in_worker=None):
+        self.engine.load_weight(parameter_name, weight)
+        self._weights_dirty = True            # re-finalised (fp8: re-quantised) before the next generate
+
+    def update_parameter_in_bucket(self, meta_infos, buffer, ranks_in_worker=None):
+        from socioreasoner_amd.weight_sync import BucketReceiver
+        if not hasattr(self, "_recv"):
+            self._recv = BucketReceiver()
+        for name, t in self._recv.process_bucket(meta_infos, buffer).items():
+            self.update_parameter(name, t)
+
+    def _finish_weight_update(self):
+        if getattr(self, "_weights_dirty", False):
+            if hasattr(self, "_recv"):
+                self._recv.clear()
+            self.engine.assert_ready()
+            self._weights_dirty = False
 
     # ------------------------------------------------------------------ generate
     def _prepare(self, ids: List[int], images) -> tuple:
@@ -148,6 +187,7 @@ class Mi355xStrategy(InferenceStrategy):
 
     @torch.no_grad()
     def generate(self, batch: DataProto, generation_config) -> torch.Tensor:
+        self._finish_weight_update()
         gc = dict(generation_config)
         if gc.get("num_beams", 1) > 1:
             raise NotImplementedError("beam search is not part of the inference hot path")

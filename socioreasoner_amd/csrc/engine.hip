@@ -33,6 +33,8 @@ struct LmLayerW {
     // lm_weight_dtype = 1: fp8 images (tiled8) + per-output-channel scales of the four linears (null in bf16 mode)
     unsigned char *qkv_w8 = nullptr, *o_w8 = nullptr, *gu_w8 = nullptr, *down_w8 = nullptr;
     float *qkv_s = nullptr, *o_s = nullptr, *gu_s = nullptr, *down_s = nullptr;
+    // HF tensors (re)loaded into each fused matrix since its last quantisation: qkv {q,k,v} = 7, o = 1, gate/up = 3, down = 1
+    unsigned char dirty[4] = {0, 0, 0, 0};
 };
 
 struct Arena {
@@ -673,24 +675,27 @@ int sr_load_weight(sr_engine* e, const char* hf_name, const void* p, int dtype, 
         LmLayerW& l = e->ll[idx];
         const std::string t = sub;
         const int QD = c.t_heads * 128, KD = c.t_kv_heads * 128;
+        int dm = -1, dbit = 0;          // fused matrix + constituent bit of an LM linear weight (fp8 re-quantisation bookkeeping)
         if (t == "input_layernorm.weight") { dst = l.ln1; exp_rows = H; exp_cols = 1; }
         else if (t == "post_attention_layernorm.weight") { dst = l.ln2; exp_rows = H; exp_cols = 1; }
-        else if (t == "self_attn.q_proj.weight") { tiled = 1; dst = l.qkv_w; exp_rows = QD; exp_cols = H; }
+        else if (t == "self_attn.q_proj.weight") { tiled = 1; dst = l.qkv_w; exp_rows = QD; exp_cols = H; dm = 0; dbit = 1; }
         else if (t == "self_attn.q_proj.bias") { dst = l.qkv_b; exp_rows = QD; exp_cols = 1; }
-        else if (t == "self_attn.k_proj.weight") { tiled = 1; dst = l.qkv_w; exp_rows = KD; exp_cols = H; row_off = QD; }
+        else if (t == "self_attn.k_proj.weight") { tiled = 1; dst = l.qkv_w; exp_rows = KD; exp_cols = H; row_off = QD; dm = 0; dbit = 2; }
         else if (t == "self_attn.k_proj.bias") { dst = l.qkv_b; exp_rows = KD; exp_cols = 1; row_off = QD; }
-        else if (t == "self_attn.v_proj.weight") { tiled = 1; dst = l.qkv_w; exp_rows = KD; exp_cols = H; row_off = QD + KD; }
+        else if (t == "self_attn.v_proj.weight") { tiled = 1; dst = l.qkv_w; exp_rows = KD; exp_cols = H; row_off = QD + KD; dm = 0; dbit = 4; }
         else if (t == "self_attn.v_proj.bias") { dst = l.qkv_b; exp_rows = KD; exp_cols = 1; row_off = QD + KD; }
-        else if (t == "self_attn.o_proj.weight") { tiled = 1; dst = l.o_w; exp_rows = H; exp_cols = QD; }
-        else if (t == "mlp.gate_proj.weight") { tiled = 1; dst = l.gu_w; exp_rows = c.t_inter; exp_cols = H; mode = 1; }
-        else if (t == "mlp.up_proj.weight") { tiled = 1; dst = l.gu_w; exp_rows = c.t_inter; exp_cols = H; mode = 2; }
-        else if (t == "mlp.down_proj.weight") { tiled = 1; dst = l.down_w; exp_rows = H; exp_cols = c.t_inter; ld = e->t_inter_pad; }
+        else if (t == "self_attn.o_proj.weight") { tiled = 1; dst = l.o_w; exp_rows = H; exp_cols = QD; dm = 1; dbit = 1; }
+        else if (t == "mlp.gate_proj.weight") { tiled = 1; dst = l.gu_w; exp_rows = c.t_inter; exp_cols = H; mode = 1; dm = 2; dbit = 1; }
+        else if (t == "mlp.up_proj.weight") { tiled = 1; dst = l.gu_w; exp_rows = c.t_inter; exp_cols = H; mode = 2; dm = 2; dbit = 2; }
+        else if (t == "mlp.down_proj.weight") { tiled = 1; dst = l.down_w; exp_rows = H; exp_cols = c.t_inter; ld = e->t_inter_pad; dm = 3; dbit = 1; }
+        if (dm >= 0 && rows == exp_rows && cols == exp_cols) l.dirty[dm] |= (unsigned char)dbit;
     }
     if (!dst) return fail(e, -2, "sr_load_weight: unknown parameter '%s'", hf_name);
     if (rows != exp_rows || cols != exp_cols)
         return fail(e, -22, "sr_load_weight: '%s' has shape [%lld, %lld], expected [%lld, %lld]", hf_name, rows, cols, exp_rows, exp_cols);
     SR_TRY(launch_load2d(s, p, dtype, rows, cols, dst, ld, mode, row_off, tiled));
     e->loaded[name] = true;
+    e->finalized = false;     // fp8 mode: the matrix has to be (re)quantised before the next forward
     return 0;
 }
 
@@ -755,11 +760,19 @@ int sr_finalize_weights(sr_engine* e, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (e->c.lm_weight_dtype == 1) {
         const int H = e->c.t_hidden, QD = e->c.t_heads * 128;
-        for (auto& l : e->ll) {
-            SR_TRY(launch_quant_f8(s, l.qkv_w, e->t_qn, H, l.qkv_w8, l.qkv_s));
-            SR_TRY(launch_quant_f8(s, l.o_w, H, QD, l.o_w8, l.o_s));
-            SR_TRY(launch_quant_f8(s, l.gu_w, 2 * e->t_inter_pad, H, l.gu_w8, l.gu_s));
-            SR_TRY(launch_quant_f8(s, l.down_w, H, e->t_inter_pad, l.down_w8, l.down_s));
+        // a fused matrix is re-quantised when ALL of its HF tensors were reloaded (a trainer -> engine weight sync sends every
+        // parameter); a partial reload would mix fresh bf16 rows with rows that already hold quantised values
+        static const unsigned char full[4] = {7, 1, 3, 1};
+        for (size_t i = 0; i < e->ll.size(); ++i) {
+            LmLayerW& l = e->ll[i];
+            for (int m = 0; m < 4; ++m)
+                if (l.dirty[m] != 0 && l.dirty[m] != full[m])
+                    return fail(e, -22, "fp8 weights: layer %zu matrix %d was only partly reloaded (mask %d of %d)", i, m, l.dirty[m], full[m]);
+            if (l.dirty[0]) SR_TRY(launch_quant_f8(s, l.qkv_w, e->t_qn, H, l.qkv_w8, l.qkv_s));
+            if (l.dirty[1]) SR_TRY(launch_quant_f8(s, l.o_w, H, QD, l.o_w8, l.o_s));
+            if (l.dirty[2]) SR_TRY(launch_quant_f8(s, l.gu_w, 2 * e->t_inter_pad, H, l.gu_w8, l.gu_s));
+            if (l.dirty[3]) SR_TRY(launch_quant_f8(s, l.down_w, H, e->t_inter_pad, l.down_w8, l.down_s));
+            l.dirty[0] = l.dirty[1] = l.dirty[2] = l.dirty[3] = 0;
         }
         SR_TRY((int)hipStreamSynchronize(s));
     }

@@ -368,3 +368,60 @@ def test_two_rank_data_parallel_bench_equals_single_process():
     assert one["result_checksum"] == two["result_checksum"] == ver["result_checksum"]
     for j in (one, two):
         assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1 and j["unit"] == "tiles/s"
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_weight_sync_into_the_engine(fp8):
+    """N4: an engine whose weights arrive through the reference's bucket protocol (update_parameter_in_bucket, pieces split
+    across 1 MB buckets, fp32 and bf16 tensors) generates exactly what an engine loaded directly generates -- also with fp8
+    LM linears, where every fused matrix is re-quantised once all of its tensors have arrived; a second sync round with
+    changed weights changes the output, and a partial round is refused in fp8 mode."""
+    from oracle import model_ref as MR
+    from oracle import weights as WG
+    from roll.distributed.scheduler.protocol import DataProto
+    from roll.distributed.strategy.factory import create_strategy
+    from roll.pipeline.base_worker import Worker
+    from socioreasoner_amd.weight_sync import BucketSender
+    cfg = _cfg("/tmp/unused", resp=8, prompt=64)
+    cfg.actor_infer.generating_args.update({"temperature": 0, "top_k": 1})
+    if fp8:
+        cfg.actor_infer.strategy_args.strategy_config["quantization"] = "fp8"
+    rcfg = MR.config_tiny()
+    W = WG.LazyWeights(rcfg, seed=0)
+    specs = WG.param_specs(rcfg)
+
+    def strat():
+        st = create_strategy(Worker(cfg.actor_infer, cfg, 0, 1, 0))
+        st.initialize(None)                       # synthetic weights, seed 0
+        return st
+
+    def sync(st, scale=1.0, only=None):
+        snd = BucketSender(1 << 20, device="cuda")
+        for i, (name, shape, base) in enumerate(specs):
+            if only is not None and name not in only:
+                continue
+            t = (W[name] * scale).to(torch.bfloat16 if i % 2 else torch.float32).cuda()
+            for meta, buf in snd.push(name, t):
+                st.update_parameter_in_bucket({k: dict(v) for k, v in meta.items()}, buf.clone(), [0])
+        meta, buf = snd.flush()
+        if meta:
+            st.update_parameter_in_bucket(meta, buf.clone(), [0])
+    rng = np.random.default_rng(1)
+    ids = torch.from_numpy(rng.integers(0, 2000, size=(2, 20))).long()
+    batch = DataProto(batch={"input_ids": ids, "attention_mask": torch.ones_like(ids)}, non_tensor_batch={})
+    gc = dict(max_new_tokens=8, eos_token_id=[2046], pad_token_id=2045, num_beams=1, num_return_sequences=1, repetition_penalty=1.0, temperature=0.0, top_k=1, top_p=1.0)
+    a, b = strat(), strat()
+    want = a.generate(batch, gc)
+    b.engine.load_weight("model.norm.weight", torch.zeros(512))     # make sure the sync really overwrites
+    sync(b)
+    assert torch.equal(b.generate(batch, gc), want)
+    sync(b, scale=1.5)
+    assert not torch.equal(b.generate(batch, gc), want)
+    sync(b)
+    assert torch.equal(b.generate(batch, gc), want)
+    if fp8:
+        sync(b, only={"model.layers.0.self_attn.q_proj.weight"})
+        with pytest.raises(Exception, match="partly reloaded"):
+            b.generate(batch, gc)
+    a.engine.close()
+    b.engine.close()

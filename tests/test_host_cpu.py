@@ -367,3 +367,40 @@ def test_actor_worker_and_scheduler_with_fake_strategy(tmp_path):
     cfg.actor_infer.generating_args["num_return_sequences"] = 2
     out2 = sched.generate(fresh(), w, cfg)
     assert out2.batch["responses"].shape[0] == 10 and torch.equal(out2.batch["responses"][0::2], out0.batch["responses"])
+
+
+def test_weight_sync_buckets_round_trip():
+    """N4: tensors of mixed dtype / size packed into fixed-size int8 buckets (pieces split across buckets) are reassembled
+    bit for bit, in arrival order, and a missing piece is detected."""
+    import torch
+    from socioreasoner_amd.weight_sync import BucketReceiver, BucketSender
+    g = torch.Generator().manual_seed(0)
+    tensors = {"a.weight": torch.randn(37, 19, generator=g).to(torch.bfloat16), "b.bias": torch.randn(5, generator=g),
+               "c.weight": torch.randn(300, 41, generator=g).to(torch.bfloat16), "d.weight": torch.randn(2, 3, generator=g)}
+    for bucket_size in (64, 1000, 1 << 20):
+        snd, rcv, got, n_buckets = BucketSender(bucket_size), BucketReceiver(), {}, 0
+        def feed(meta, buf):
+            nonlocal n_buckets
+            n_buckets += 1
+            wire = {k: dict(v) for k, v in meta.items()}                  # what an RPC would deliver
+            got.update(rcv.process_bucket(wire, buf.clone()))
+        for name, t in tensors.items():
+            for meta, buf in snd.push(name, t):
+                feed(meta, buf)
+        meta, buf = snd.flush()
+        if meta:
+            feed(meta, buf)
+        rcv.clear()
+        assert set(got) == set(tensors) and all(torch.equal(got[k], tensors[k]) and got[k].dtype == tensors[k].dtype for k in tensors)
+        total = sum(t.numel() * t.element_size() for t in tensors.values())
+        assert n_buckets == -(-total // bucket_size)
+    snd, rcv = BucketSender(64), BucketReceiver()
+    it = snd.push("c.weight", tensors["c.weight"])
+    m1, b1 = next(it)
+    rcv.process_bucket(m1, b1.clone())
+    next(it)                                   # a lost bucket
+    m3, b3 = next(it)
+    with pytest.raises(ValueError, match="expected"):
+        rcv.process_bucket(m3, b3.clone())
+    with pytest.raises(RuntimeError, match="partly received"):
+        rcv.clear()
