@@ -356,6 +356,51 @@ def test_raster_tail_bit_exact(L):
     assert torch.equal(same.cpu(), big)
 
 
+@pytest.mark.parametrize("CTX,lens", [(4608, [4500, 2049, 1]), (1024, [1024, 577, 64]), (192, [191])])
+def test_decode_attention_against_oracle_math(L, CTX, lens):
+    """k_attn_dec_scores + k_attn_dec_pv (mRoPE of the new q/k, KV append, scores, softmax, P.V) against the oracle's
+    attention arithmetic (oracle/model_ref.py lm_attention: hf:602-689 rounding points) on random caches, including the
+    long-context code paths (> 1024 and > 2048 keys) that the end-to-end tests do not reach."""
+    from oracle import model_ref as MR
+    B, HQ, HK, HD = len(lens), 16, 2, 128
+    G = HQ // HK
+    torch.manual_seed(CTX + len(lens))
+    qkv = (torch.randn(B, (HQ + 2 * HK) * HD) * 1.5).to(torch.bfloat16)
+    kc0 = torch.randn(B, HK, CTX, HD).to(torch.bfloat16)
+    vc0 = torch.randn(B, HK, HD, CTX).to(torch.bfloat16)
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    pos = torch.tensor([min(x + 3, CTX) for x in lens], dtype=torch.int32)
+    inv = 1.0 / (1e6 ** (torch.arange(0, HD, 2).float() / HD))
+    ang = torch.arange(CTX + 1).float()[:, None] * inv[None]
+    rc, rs = ang.cos().to(torch.bfloat16), ang.sin().to(torch.bfloat16)
+    kc, vc = kc0.cuda(), vc0.cuda()
+    out = torch.zeros(B, HQ * HD, dtype=torch.bfloat16, device="cuda")
+    scratch = torch.zeros(B * HQ * CTX, dtype=torch.bfloat16, device="cuda")
+    assert L.sr_op_attn_decode(P(D(qkv)), qkv.shape[1], P(D(pos)), P(D(ctx)), P(D(rc)), P(D(rs)), P(kc), P(vc), P(out), HQ * HD, B, HQ, HK, CTX,
+                               C.c_float(HD ** -0.5), P(scratch), sp()) == 0
+    torch.cuda.synchronize()
+    for b, n in enumerate(lens):
+        row = qkv[b].float()
+        q = row[: HQ * HD].reshape(HQ, HD)
+        k = row[HQ * HD: (HQ + HK) * HD].reshape(HK, HD)
+        v = row[(HQ + HK) * HD:].reshape(HK, HD)
+        c = torch.cat([rc[pos[b]], rc[pos[b]]]).float()
+        s_ = torch.cat([rs[pos[b]], rs[pos[b]]]).float()
+        q = MR.r(MR.r(q * c) + MR.r(MR.rotate_half(q) * s_))
+        k = MR.r(MR.r(k * c) + MR.r(MR.rotate_half(k) * s_))
+        # cache append, bit exact
+        assert torch.equal(kc[b, :, n - 1].cpu().float(), k) and torch.equal(vc[b, :, :, n - 1].cpu().float(), v), b
+        assert torch.equal(kc[b, :, : n - 1].cpu(), kc0[b, :, : n - 1]) and torch.equal(vc[b, :, :, : n - 1].cpu(), vc0[b, :, :, : n - 1])
+        keys = torch.cat([kc0[b, :, : n - 1].float(), k[:, None]], dim=1)                   # [HK, n, HD]
+        vals = torch.cat([vc0[b, :, :, : n - 1].float().transpose(1, 2), v[:, None]], dim=1)  # [HK, n, HD]
+        kh, vh = keys.repeat_interleave(G, dim=0), vals.repeat_interleave(G, dim=0)
+        sc = MR.r(torch.einsum("hd,hnd->hn", q, kh))
+        sc = MR.r(sc * torch.tensor(HD ** -0.5))
+        pr = MR.r(torch.softmax(sc, dim=-1))
+        o = MR.r(torch.einsum("hn,hnd->hd", pr, vh)).reshape(-1)
+        assert_bf16_close(out[b].float().cpu(), o, 2, 0.02, f"decode attention row {b} ({n} keys)")
+
+
 # ------------------------------------------------------------------------------------------------ engine, tiny geometry
 @pytest.fixture(scope="module")
 def tiny_engine():
