@@ -404,3 +404,61 @@ def test_weight_sync_buckets_round_trip():
         rcv.process_bucket(m3, b3.clone())
     with pytest.raises(RuntimeError, match="partly received"):
         rcv.clear()
+
+
+def test_host_ops_agree_with_oracle_on_random_inputs():
+    """Product host logic vs the oracle restatements (two independent implementations of the reference's integer rows) on
+    seeded random cases beyond the golden fixtures: mRoPE ids for ragged multi-image left-padded batches, output layout
+    (postprocess_generate) for random prompt / response lengths, smart_resize over a size sweep."""
+    import torch
+    from oracle import host_ref as H
+    from socioreasoner_amd import hostops
+    rng = np.random.default_rng(11)
+    IMG, VS, VE, PAD = 151655, 151652, 151653, 151643
+    for case in range(25):
+        B, S = int(rng.integers(1, 5)), int(rng.integers(40, 400))
+        ids = np.full((B, S), PAD, dtype=np.int64)
+        mask = np.zeros((B, S), dtype=np.int64)
+        grids = []
+        for b in range(B):
+            seq = []
+            for _ in range(int(rng.integers(0, 3))):
+                h, w = 2 * int(rng.integers(1, 5)), 2 * int(rng.integers(1, 5))
+                if len(seq) + h * w // 4 + 12 > S:
+                    break
+                seq += rng.integers(0, 1000, int(rng.integers(0, 6))).tolist() + [VS] + [IMG] * (h * w // 4) + [VE]
+                grids.append((1, h, w))
+            seq += rng.integers(0, 1000, int(rng.integers(1, 8))).tolist()
+            seq = seq[:S]
+            ids[b, S - len(seq):] = seq
+            mask[b, S - len(seq):] = 1
+        got, dg = hostops.get_rope_index(torch.from_numpy(ids), grids or None, torch.from_numpy(mask))
+        want, dw = H.get_rope_index(ids, np.asarray(grids) if grids else None, mask)
+        assert np.array_equal(got.numpy(), np.asarray(want)) and np.array_equal(dg.numpy().reshape(-1), np.asarray(dw).reshape(-1)), case
+    for case in range(25):
+        B, P, R = int(rng.integers(1, 6)), int(rng.integers(4, 30)), int(rng.integers(1, 12))
+        n = int(rng.integers(1, 3))
+        seq_len = P + R + int(rng.integers(0, 5))
+        ids = np.full((B, P), PAD, dtype=np.int64)
+        mask = np.zeros((B, P), dtype=np.int64)
+        for b in range(B):
+            k = int(rng.integers(1, P + 1))
+            ids[b, P - k:] = rng.integers(0, 1000, k)
+            mask[b, P - k:] = 1
+        pos = np.repeat(np.clip(np.cumsum(mask, -1) - 1, 0, None)[:, None, :], 3, axis=1)
+        out = np.full((B * n, P + R), PAD, dtype=np.int64)
+        out[:, :P] = np.repeat(ids, n, axis=0)
+        for r in range(B * n):
+            k = int(rng.integers(1, R + 1))
+            out[r, P:P + k] = rng.integers(0, 1000, k)
+        got = hostops.postprocess_generate({"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "position_ids": torch.from_numpy(pos)},
+                                           torch.from_numpy(out), n, seq_len, 151645, PAD)
+        want = H.postprocess_generate(ids, mask, pos, out, n, seq_len, 151645, PAD)
+        for k, v in want.items():
+            assert np.array_equal(got[k].numpy(), np.asarray(v)), (case, k)
+    for h in range(20, 1400, 37):
+        for w in (28, 301, 448, 1000, 2600):
+            for mx in (768 * 768, 28 * 28 * 1280):
+                if max(h, w) / min(h, w) > 200:
+                    continue
+                assert hostops.smart_resize(h, w, factor=28, min_pixels=56 * 56, max_pixels=mx) == H.smart_resize(h, w, 28, 56 * 56, mx)
