@@ -101,6 +101,13 @@ int sr_prefill(sr_engine* e, const int64_t* host_ids, const int64_t* host_pos3, 
                const int32_t* host_slots, int B, const void* dev_image_embeds, int n_image_rows, float* dev_logits_out,
                void* stream);
 
+/* Teacher-forced forward with logits at EVERY position -- what a logits-consuming caller of
+ * InferenceStrategy.forward_step gets from the HF forward (hf_strategy.py:49-94, use_cache=False): arguments as
+ * sr_prefill (sequences use KV slots 0..B-1), dev_all_logits float32 [n_tok, vocab] for the packed tokens.  Un-rounded
+ * float32 like sr_prefill's last-position logits (HF rounds to bf16). */
+int sr_forward_logits(sr_engine* e, const int64_t* host_ids, const int64_t* host_pos3, const int32_t* host_seq_lens, int B,
+                      const void* dev_image_embeds, int n_image_rows, float* dev_all_logits, void* stream);
+
 /* Decode -- replaces the autoregressive loop of vllm.LLM.generate with SamplingParams built at
  * vllm_strategy.py:289-309 for temperature 0 (greedy): generates up to max_new tokens for the sequences prefilled
  * into slots host_slots[0..B).  Stops a sequence at the first token in host_eos (the token is kept, later positions

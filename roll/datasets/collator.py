@@ -17,6 +17,19 @@ import numpy as np
 import torch
 
 
+def collate_fn_to_dict_list(data_list: List[Dict[str, Any]]) -> Dict[str, Any]:
+    """list of dicts -> dict: tensors concatenated along dim 0, everything else an object array (reference :13-37)."""
+    tensors: Dict[str, List[torch.Tensor]] = {}
+    others: Dict[str, List[Any]] = {}
+    for d in data_list:
+        for k, v in d.items():
+            (tensors if isinstance(v, torch.Tensor) else others).setdefault(k, []).append(v)
+    out: Dict[str, Any] = {k: torch.cat(v, dim=0) for k, v in tensors.items()}
+    for k, v in others.items():
+        out[k] = _object_array(v)
+    return out
+
+
 def _object_array(values: List[Any]) -> np.ndarray:
     arr = np.empty([len(values)], dtype=object)
     arr[:] = values

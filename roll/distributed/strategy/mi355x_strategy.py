@@ -143,6 +143,56 @@ class Mi355xStrategy(InferenceStrategy):
             self.engine.assert_ready()
             self._weights_dirty = False
 
+    # ------------------------------------------------------------------ logits for callers that score sequences
+    @torch.no_grad()
+    def forward_step(self, batch: DataProto, forward_func) -> Dict[str, torch.Tensor]:
+        """Reference contract (hf_strategy.py:49-94): micro-batches of (input_ids, attention_mask, position_ids [B,3,S],
+        optional non_tensor_batch["multi_modal_inputs"] = per-sample {"pixel_values", "image_grid_thw"}); the model's
+        logits [b, S, vocab] (bf16 like the HF forward; zeros at padded positions) go to
+        forward_func(micro_batch, logits) -> (loss, dict), the dicts are collated."""
+        from roll.datasets.collator import collate_fn_to_dict_list
+        self._finish_weight_update()
+        n = len(batch)
+        mbs = int(batch.meta_info.get("micro_batch_size") or n)
+        results = []
+        for data in batch.chunk(max(n // max(mbs, 1), 1)):
+            ids, mask, pos = data.batch["input_ids"], data.batch["attention_mask"].bool(), data.batch["position_ids"]
+            if pos.dim() == 2:
+                pos = pos[:, None, :].expand(-1, 3, -1)
+            mm = data.non_tensor_batch.get("multi_modal_inputs") if data.non_tensor_batch else None
+            b, S = ids.shape
+            V = self.geom.text.vocab_size
+            logits = torch.zeros(b, S, V, dtype=torch.bfloat16, device="cuda")
+            i = 0
+            while i < b:                               # groups bounded by the engine capacities
+                grp, ntok = [], 0
+                while i < b and len(grp) < self.max_batch:
+                    k = int(mask[i].sum())
+                    if grp and ntok + k > self.engine.cfg.max_prefill_tokens:
+                        break
+                    grp.append(i)
+                    ntok += k
+                    i += 1
+                pix, grids = [], []
+                for j in grp:
+                    inp = mm[j] if mm is not None else None
+                    if inp and "pixel_values" in inp:
+                        pix.append(torch.as_tensor(inp["pixel_values"]).to("cuda", torch.float32))
+                        grids += [tuple(int(v) for v in g_) for g_ in torch.as_tensor(inp["image_grid_thw"]).tolist()]
+                emb = None
+                if pix:
+                    emb = self.engine.vit_forward(torch.cat(pix, dim=0).contiguous(), grids)     # HF processor layout [N, 1176] f32
+                flat = self.engine.forward_logits([ids[j][mask[j]].cpu().numpy() for j in grp],
+                                                  [pos[j][:, mask[j]].cpu().numpy() for j in grp], emb)
+                o = 0
+                for j in grp:
+                    k = int(mask[j].sum())
+                    logits[j, mask[j].to(logits.device)] = flat[o:o + k].to(torch.bfloat16)
+                    o += k
+            _, reduced = forward_func(data, logits.to(ids.device) if ids.device.type != "cuda" else logits)
+            results.append(reduced)
+        return collate_fn_to_dict_list(results)
+
     # ------------------------------------------------------------------ generate
     def _prepare(self, ids: List[int], images) -> tuple:
         """-> (expanded ids np.int64, pos3 [3,S], list of uint8 HWC cuda images, grids)"""

@@ -781,7 +781,8 @@ int sr_finalize_weights(sr_engine* e, void* stream) {
 }
 
 static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_t* seq_lens, const int32_t* slots, int B,
-                        const void* image_embeds, int n_image_rows, float* logits_out, void* stream, const int32_t* limits) {
+                        const void* image_embeds, int n_image_rows, float* logits_out, void* stream, const int32_t* limits,
+                        float* all_logits_out = nullptr) {
     if (!e || !ids || !pos3 || !seq_lens || !slots) return fail(e, -22, "sr_prefill: null argument");
     char miss[160];
     if (sr_weights_missing(e, miss, sizeof miss)) return fail(e, -61, "weights missing, e.g. '%s'", miss);
@@ -886,6 +887,10 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
         if (int rc = gemm(e, s, e->t_act, e->t_inter_pad, w.down_w, n_tok, H, e->t_inter_pad, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID, 1, w.down_s)) return rc;
     }
     // last position of every sequence -> final norm -> tied LM head (hf:1386-1387) -> greedy token
+    if (all_logits_out) {       // every position: final norm over all rows, tied LM head as an MFMA GEMM with float32 output
+        SR_TRY(launch_rmsnorm(s, e->t_x, e->final_norm, e->t_xn, n_tok, H, c.t_rms_eps));
+        if (int rc = gemm(e, s, e->t_xn, H, e->embed, n_tok, c.t_vocab, H, all_logits_out, c.t_vocab, nullptr, nullptr, nullptr, EPI_F32, 1)) return rc;
+    }
     // (d_xn is decode scratch: rows in flight do not keep anything in it between steps)
     bf16_t* xl = limits ? e->d_xn : e->d_xa;
     SR_TRY(launch_gather_rows(s, e->t_x, e->t_lastrow, xl, B, H));
@@ -920,6 +925,15 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
 int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_t* seq_lens, const int32_t* slots, int B,
                const void* image_embeds, int n_image_rows, float* logits_out, void* stream) {
     return prefill_impl(e, ids, pos3, seq_lens, slots, B, image_embeds, n_image_rows, logits_out, stream, nullptr);
+}
+
+int sr_forward_logits(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_t* seq_lens, int B, const void* image_embeds,
+                      int n_image_rows, float* all_logits_out, void* stream) {
+    if (!all_logits_out) return fail(e, -22, "sr_forward_logits: null output");
+    if (!e || B < 1 || B > 32) return fail(e, -22, "sr_forward_logits: bad batch");
+    int32_t slots[32];
+    for (int b = 0; b < B; ++b) slots[b] = b;
+    return prefill_impl(e, ids, pos3, seq_lens, slots, B, image_embeds, n_image_rows, nullptr, stream, nullptr, all_logits_out);
 }
 
 // ---- continuous batching: batch rows with independent lifecycles (row index = KV slot); a decode step always runs all

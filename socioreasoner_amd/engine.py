@@ -173,6 +173,22 @@ class Engine:
         self._last_B = B
         return logits
 
+    def forward_logits(self, ids: Sequence[np.ndarray], pos3: Sequence[np.ndarray], image_embeds: torch.Tensor | None = None):
+        """Teacher-forced forward: float32 logits [n_tok, V] for every position of the packed sequences."""
+        B = len(ids)
+        lens = np.array([len(x) for x in ids], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.int64) for x in ids]))
+        p3 = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.int64).reshape(3, -1) for p in pos3], axis=1))
+        out = torch.empty(len(flat), self.geom.text.vocab_size, dtype=torch.float32, device=self.device)
+        n_img = 0 if image_embeds is None else int(image_embeds.shape[0])
+        if image_embeds is not None:
+            image_embeds = image_embeds.contiguous()
+        L.check(self.lib.sr_forward_logits(self._h, flat.ctypes.data_as(L._i64p), p3.ctypes.data_as(L._i64p), lens.ctypes.data_as(L._i32p), B,
+                                           C.c_void_p(image_embeds.data_ptr()) if image_embeds is not None else None, n_img,
+                                           C.c_void_p(out.data_ptr()), self._s()), self._h, "sr_forward_logits")
+        self._last_B = B
+        return out
+
     def decode(self, max_new: int, eos: Sequence[int] = (), pad_id: int = 0, trace: bool = False,
                forced: torch.Tensor | None = None, use_graph: bool = True):
         """Greedy decode for the sequences of the last prefill.  Returns int32 tokens [B, max_new] (and, with

@@ -425,3 +425,60 @@ def test_weight_sync_into_the_engine(fp8):
             b.generate(batch, gc)
     a.engine.close()
     b.engine.close()
+
+
+def test_forward_step_all_position_logits(golden_dir=os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")):
+    """InferenceStrategy.forward_step (hf_strategy.py:49-94): logits at every position for left-padded (image + text,
+    text-only) rows against the oracle's teacher-forced forward, zeros at padded positions, micro-batching + collation."""
+    from oracle import model_ref as MR
+    from oracle import weights as WG
+    from roll.distributed.scheduler.protocol import DataProto
+    from roll.distributed.strategy.factory import create_strategy
+    from roll.pipeline.base_worker import Worker
+    from tests.util import bits_to_f32
+    cfg = _cfg("/tmp/unused", resp=8, prompt=160)
+    st = create_strategy(Worker(cfg.actor_infer, cfg, 0, 1, 0))
+    st.initialize(None)
+    g = np.load(os.path.join(golden_dir, "hf_tiny.npz"))
+    rcfg = MR.config_tiny()
+    W = WG.LazyWeights(rcfg, seed=0)
+    grids = [tuple(x) for x in g["grids"].tolist()]
+    pix = bits_to_f32(g["pix"])
+    ids_img, pos_img = g["ids"], g["pos3"]
+    txt = np.arange(7, 30, dtype=np.int64)
+    S = 160
+    input_ids = torch.zeros(3, S, dtype=torch.long)
+    mask = torch.zeros(3, S, dtype=torch.long)
+    pos = torch.zeros(3, 3, S, dtype=torch.long)
+    rows = [(ids_img, pos_img), (txt, np.tile(np.arange(len(txt)), (3, 1))), (ids_img, pos_img)]
+    for i, (a, p3) in enumerate(rows):
+        input_ids[i, S - len(a):] = torch.from_numpy(a)
+        mask[i, S - len(a):] = 1
+        pos[i, :, S - len(a):] = torch.from_numpy(p3)
+    mm = np.empty(3, dtype=object)
+    mm[0] = {"pixel_values": pix, "image_grid_thw": torch.tensor(grids)}
+    mm[1] = {}
+    mm[2] = {"pixel_values": pix, "image_grid_thw": torch.tensor(grids)}
+    batch = DataProto(batch={"input_ids": input_ids, "attention_mask": mask, "position_ids": pos},
+                      non_tensor_batch={"multi_modal_inputs": mm}, meta_info={"micro_batch_size": 1})
+    seen = []
+
+    def forward_func(data, logits):
+        seen.append(logits.float().cpu())
+        lp = torch.log_softmax(logits.float(), dim=-1)[:, :-1].gather(-1, data.batch["input_ids"][:, 1:, None].to(logits.device))[..., 0]
+        lp = lp * data.batch["attention_mask"][:, 1:].to(logits.device)
+        return lp.sum(), {"log_probs": lp.cpu(), "n": int(data.batch["input_ids"].shape[0])}
+    res = st.forward_step(batch, forward_func)
+    assert res["log_probs"].shape == (3, S - 1) and [int(x) for x in res["n"]] == [1, 1, 1]
+    got = torch.cat(seen, dim=0)
+    assert got.shape == (3, S, 2048)
+    img_ref = MR.vit_forward(W, rcfg, pix, grids)
+    for i, (a, p3) in enumerate(rows):
+        x = MR.embed_with_images(W, rcfg, torch.from_numpy(a), img_ref if len(a) > 40 else None)
+        ref = MR.lm_forward(W, rcfg, x, torch.from_numpy(p3), MR.new_caches(rcfg), all_logits=True)
+        assert float(got[i, : S - len(a)].abs().max()) == 0.0
+        d = (got[i, S - len(a):] - ref).abs()
+        # bf16 noise floor of the 7-layer tiny model (DESIGN.md section 2) + the bf16 rounding of the returned logits
+        assert float(d.max()) <= 0.06 and float(d.mean()) <= 0.01, (i, float(d.max()), float(d.mean()))
+    assert torch.equal(got[0], got[2])
+    st.engine.close()
