@@ -13,6 +13,8 @@
 // every hot-path shape (lm gate/up 911 vs 980 TF/s, ViT qkv 663 vs 723): with two 4-wave blocks per CU the memory round trip is
 // already covered by the other block, and one 8-wave block per CU barriers twice as many waves per k-tile.  Under MFMA load the
 // chip clocks ~2.0 GHz (guide: DVFS), i.e. ~2.1 PF effective peak; this kernel runs 0.9-1.0 PF on random data at large M.
+// Also measured: requesting both k-steps' fragments up front (sched_group_barrier: 16 ds_read, then 32 MFMA) lets the compiler hoist
+// the tile barrier above the MFMAs; +4..6 % on two shapes, -3..20 % on the others (lm qkv 725 vs 910 TF/s).  Not kept.
 #include "kernels.h"
 
 namespace {
