@@ -281,8 +281,8 @@ def cpu_baseline():
     from oracle import weights as WG
     from socioreasoner_amd import hostops, synthetic
     cfg = MR.config_3b()
-    cfg.vision.depth, cfg.text.num_hidden_layers = 2, 2
-    cfg.vision.fullatt_block_indexes = (1,)
+    cfg.vision.depth, cfg.text.num_hidden_layers = 4, 4          # the sample: 4 ViT blocks, 4 LM layers at the true dimensions
+    cfg.vision.fullatt_block_indexes = (1, 3)
     W = WG.LazyWeights(cfg, seed=0)
     for n, _, _ in WG.param_specs(cfg):
         W[n]                                  # materialise outside the timed region
@@ -302,38 +302,41 @@ def cpu_baseline():
     cos, sin = MR.vit_rotary_tables(vc, [grid], widx)
     t1 = time.perf_counter()
     xw = MR.vit_block(W, 0, vc, x, cu_win, cos, sin)
+    xw = MR.vit_block(W, 2, vc, xw, cu_win, cos, sin)
     t2 = time.perf_counter()
     xf = MR.vit_block(W, 1, vc, xw, cu_full, cos, sin)
+    xf = MR.vit_block(W, 3, vc, xf, cu_full, cos, sin)
     t3 = time.perf_counter()
     emb = MR.vit_merger(W, vc, xf)[torch.argsort(widx)]
     t4 = time.perf_counter()
-    vit_s = (t1 - t0) + 28 * (t2 - t1) + 4 * (t3 - t2) + (t4 - t3)
+    vit_s = (t1 - t0) + 28 * (t2 - t1) / 2 + 4 * (t3 - t2) / 2 + (t4 - t3)
     tc = cfg.text
     caches = MR.new_caches(cfg)
+    NL = 4                                      # LM layers in the sample
     t5 = time.perf_counter()
     h = MR.embed_with_images(W, cfg, torch.from_numpy(ids), emb)
     c_, s_ = MR.mrope_tables(tc, p3)
     t6 = time.perf_counter()
-    for i in range(2):
+    for i in range(NL):
         h = MR.lm_layer(W, i, tc, h, c_, s_, caches[i])
     t7 = time.perf_counter()
     lg = MR.rmsnorm(h[-1:], W["model.norm.weight"], tc.rms_norm_eps) @ W["lm_head.weight"].t()
     t8 = time.perf_counter()
-    prefill_s = (t6 - t5) + 18 * (t7 - t6) + (t8 - t7)
-    nd = 3
+    prefill_s = 36 / NL * (t7 - t6) + (t8 - t7)
+    nd = 12
     t9 = time.perf_counter()
     for k in range(nd):
         xx = W["model.embed_tokens.weight"][torch.tensor([int(lg.argmax())])]
         cc, ss = MR.mrope_tables(tc, torch.full((3, 1), int(p3.max()) + 1 + k))
-        for i in range(2):
+        for i in range(NL):
             xx = MR.lm_layer(W, i, tc, xx, cc, ss, caches[i])
     t10 = time.perf_counter()
     head_s = t8 - t7
-    decode_s = (N_NEW - 1) * (18 * (t10 - t9) / nd + head_s)
+    decode_s = (N_NEW - 1) * (36 / NL * (t10 - t9) / nd + head_s)
     total = vit_s + prefill_s + decode_s
     return {"value": round(1.0 / total, 5), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle/model_ref.py (float32 math, HF bf16 rounding points) on one synthetic 448x448 tile: 2/32 ViT "
-                      "blocks (1 window + 1 full) and 2/36 LM layers at true dims, 448-token prefill, 3 decode steps, "
+            "sample": "oracle/model_ref.py (float32 math, HF bf16 rounding points) on one synthetic 448x448 tile: 4/32 ViT "
+                      "blocks (2 window + 2 full) and 4/36 LM layers at true dims, 448-token prefill, 12 decode steps, "
                       "extrapolated linearly in depth and to 127 decode steps",
             "seconds_per_tile_extrapolated": round(total, 2),
             "phases_s": {"vit": round(vit_s, 2), "prefill": round(prefill_s, 2), "decode": round(decode_s, 2)}}
