@@ -503,6 +503,33 @@ def test_tiny_fp8_weights_prefill_and_decode(golden_dir):
     eng.close()
 
 
+def test_vit_random_grids_window_index_math(tiny_engine):
+    """The engine's host-side ViT index math (window permutation, cu_seqlens of windows / images, 2-D rotary tables, merger
+    un-permutation -- engine.hip vit_prepare) on seeded random ragged grids, 1-3 images per call, against the oracle
+    (which is pinned to HF's get_vision_window_index on the golden grids)."""
+    from oracle import model_ref as MR
+    from oracle import weights as WG
+    cfg = MR.config_tiny()
+    W = WG.LazyWeights(cfg, seed=0)
+    rng = np.random.default_rng(21)
+    for case in range(10):
+        grids, n = [], 0
+        for _ in range(int(rng.integers(1, 4))):
+            h, w = 2 * int(rng.integers(1, 12)), 2 * int(rng.integers(1, 12))
+            if n + h * w > 480:
+                continue
+            grids.append((1, h, w))
+            n += h * w
+        if not grids:
+            grids, n = [(1, 6, 10)], 60
+        pix = torch.from_numpy(rng.standard_normal((n, 1176)).astype(np.float32)).to(torch.bfloat16).float()
+        ref = MR.vit_forward(W, cfg, pix, grids)
+        got = tiny_engine.vit_forward(pix.cuda(), grids)
+        assert got.shape == ref.shape, (grids, got.shape, ref.shape)
+        mu, frac, mad = bf16_compare(got.float().cpu(), ref)
+        assert mad <= 3 * float(ref.abs().max()) * 2 ** -8, (case, grids, mu, frac, mad)
+
+
 def test_decode_graph_equals_eager_and_batch_invariance(tiny_engine, golden_dir):
     g = np.load(os.path.join(golden_dir, "hf_tiny.npz"))
     grids = [tuple(x) for x in g["grids"].tolist()]
