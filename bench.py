@@ -139,6 +139,8 @@ def main():
                 phase_ms[k] += a.elapsed_time(b_)
         return res
 
+    if world > 1:      # open the RCCL communicator outside the timed region even with --warmup 0
+        dp.all_gather_rows(torch.zeros(B, 1, dtype=torch.int64, device=dev), B * world)
     for _ in range(args.warmup):
         step()
     dp.barrier()
