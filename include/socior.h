@@ -125,6 +125,16 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
  * with lm_weight_dtype = 1, quantises the LM decoder linears in place (see sr_config).  Idempotent. */
 int sr_finalize_weights(sr_engine* e, void* stream);
 
+/* Sampled decode on the device -- replaces vllm.LLM.generate with the SamplingParams of vllm_strategy.py:289-309
+ * (temperature > 0, 1 <= top_k <= 1024, 0 < top_p <= 1, repetition_penalty): as sr_decode, but every token is drawn by
+ * k_sample (exact top-k, temperature softmax, top-p, one categorical draw with a counter-based RNG keyed by
+ * (seed, sequence, step)); with use_graph one captured graph per step includes the draw.  The stream of random numbers is
+ * this library's own (vLLM's cannot be reproduced): top_k = 1 equals greedy decode exactly, everything else is pinned
+ * distributionally (tests). */
+int sr_decode_sample(sr_engine* e, int B, int max_new, const int32_t* host_eos, int n_eos, int32_t pad_id, float temperature,
+                     int top_k, float top_p, float repetition_penalty, uint32_t seed, int32_t* dev_tokens_out, int use_graph,
+                     void* stream, int* steps_done);
+
 /* One decode step with the token choice left to the caller -- the `sr_decode_step` of SURVEY section 8(B); this is what a
  * sampling caller (temperature / top-k / top-p of vllm_strategy.py:289-309) or the logits-gathering verification
  * mode of the multi-GPU path drives.  Feeds dev_last_ids[b] (int64, device; NULL = the greedy token of the logits the
@@ -178,6 +188,12 @@ int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, floa
 int sr_op_resid_rmsnorm(void* x, const float* partials, int ksplit, const void* w, void* out, int rows, int H, float eps,
                         void* stream);
 int sr_op_argmax(const float* logits, int rows, int V, int32_t* out_idx, void* stream);
+/* the sampling kernel on caller-provided float32 logits [B, V]; dev_seen: optional bitmask [B][(V+31)/32]; dev_step: optional
+ * int32 [B]; dev_blk_max: optional per-block maxima [B][n_blk] of blk_rows consecutive ids each (the LM head's argmax partials):
+ * the exact top-k is then searched only in the blocks that can contain it */
+int sr_op_sample(const float* dev_logits, int B, int V, float temperature, int top_k, float top_p, float repetition_penalty,
+                 const uint32_t* dev_seen, uint32_t seed, const int32_t* dev_step, int64_t* dev_out, const float* dev_blk_max,
+                 int n_blk, int blk_rows, void* stream);
 /* fp8 quantisation of a fragment-ordered bf16 matrix (the kernel sr_finalize_weights runs): dev_w8 [N*K] bytes (tiled8),
  * dev_scale float32 [N]; W itself becomes the bf16 image of q */
 int sr_op_quant_f8(void* dev_w_tiled, int N, int K, void* dev_w8, float* dev_scale, void* stream);

@@ -8,8 +8,9 @@ and of the raster half of ``seg_infer`` (roll/distributed/strategy/seg_strategy.
   out: LongTensor [B * n, P + max_response_len_in_batch]: the prompt columns verbatim, responses right-padded with pad.
 Greedy requests (temperature 0 or top_k 1 -- BASELINE.json's configurations) run the whole decode loop on the device
 (sr_decode, one hipGraph replay per token).  Sampling requests (the shipped YAML's temperature / top_p / top_k /
-repetition_penalty, vllm_strategy.py:289-309) run token by token through sr_decode_step with the draw made by
-socioreasoner_amd.sampling on the device-resident logits.
+repetition_penalty, vllm_strategy.py:289-309) also stay on the device when 1 <= top_k <= 1024 (sr_decode_sample: the draw
+is a kernel inside the captured step); without a top-k bound they run token by token through sr_decode_step with the draw
+made by socioreasoner_amd.sampling on the device-resident logits.
 """
 from __future__ import annotations
 
@@ -282,11 +283,17 @@ class Mi355xStrategy(InferenceStrategy):
             if room < 1:
                 raise ValueError(f"prompt of {self.engine.cfg.max_ctx - room} tokens leaves no room in max_ctx {self.engine.cfg.max_ctx}")
             max_new_g = min(max_new, room)
-            for _ in range(1 if greedy else n):
+            tk = gc.get("top_k", -1)
+            on_device = not greedy and tk is not None and 1 <= int(tk) <= 1024 and float(gc.get("temperature", 1.0)) > 1e-5
+            for rep in range(1 if greedy else n):
                 logits = self.engine.prefill([prepared[k][0] for k in grp], [prepared[k][1] for k in grp], emb,
-                                             return_logits=not greedy)
+                                             return_logits=not greedy and not on_device)
                 if greedy:
                     toks = self.engine.decode(max_new_g, eos=eos, pad_id=pad).cpu().tolist()
+                elif on_device:          # k_sample inside the captured decode step
+                    seed = int(gc.get("seed", 0) or 0) * 1000003 + 7919 * int(getattr(self.worker, "rank", 0) or 0) + 104729 * rep + grp[0]
+                    toks = self.engine.decode_sample(max_new_g, float(gc.get("temperature", 1.0)), int(tk), float(gc.get("top_p", 1.0) or 1.0),
+                                                     float(gc.get("repetition_penalty", 1.0) or 1.0), seed, eos=eos, pad_id=pad).cpu().tolist()
                 else:
                     toks = self._sample_loop(logits, [prepared[k][0] for k in grp], max_new_g, eos, pad, gc).cpu().tolist()
                 for row, k in zip(toks, grp):

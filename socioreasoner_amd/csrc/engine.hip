@@ -121,7 +121,11 @@ struct sr_engine {
     int graph_B = -1, graph_neos = -1, graph_pad = 0;
     hipGraphExec_t step_graph[2] = {nullptr, nullptr};   // sr_decode_step: [0] engine-greedy token, [1] caller-chosen token
     int step_graph_B[2] = {-1, -1};
-    long long *d_chosen = nullptr, *d_next = nullptr;
+    long long *d_chosen = nullptr, *d_next = nullptr, *d_sampled = nullptr;
+    unsigned* d_seen = nullptr;    // [32][seen_words] token bitmask for the repetition penalty
+    int seen_words = 0;
+    hipGraphExec_t sgraph = nullptr;      // sampled decode step: bookkeeping + forward + k_sample
+    int sg_B = -1, sg_neos = -1, sg_pad = 0, sg_topk = 0; float sg_it = 0.f, sg_topp = 0.f, sg_rp = 0.f; unsigned sg_seed = 0;
     int prefilled_B = 0;
     int h_ctx_hi = 0;              // longest context any slot can have reached (prefill length + decode steps issued)
     // ---- bookkeeping
@@ -282,6 +286,9 @@ void carve(sr_engine* e) {
     e->d_row_limit = ar.take<int>(32);
     e->d_ngen = ar.take<int>(32);
     e->d_adm = ar.take<int>(5 * 32);
+    e->d_sampled = ar.take<long long>(32);
+    e->seen_words = (c.t_vocab + 31) / 32;
+    e->d_seen = ar.take<unsigned>((size_t)32 * e->seen_words);
     e->d_chosen = ar.take<long long>(32);
     e->d_next = ar.take<long long>(32);
     e->d_cur_tok = ar.take<int>(32);
@@ -606,6 +613,7 @@ int sr_engine_destroy(sr_engine* e) {
     if (!e) return 0;
     if (e->graph) (void)hipGraphExecDestroy(e->graph);
     for (auto g : e->step_graph) if (g) (void)hipGraphExecDestroy(g);
+    if (e->sgraph) (void)hipGraphExecDestroy(e->sgraph);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     if (e->ev_copy) (void)hipEventDestroy(e->ev_copy);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -1052,6 +1060,81 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
     return 0;
 }
 
+// Sampled decode (temperature / top-k / top-p / repetition penalty of vllm_strategy.py:289-309), entirely on the device:
+// the token of every step is drawn by k_sample from the logits the LM head left in HBM and fed back through k_step.
+int sr_decode_sample(sr_engine* e, int B, int max_new, const int32_t* host_eos, int n_eos, int32_t pad_id, float temperature, int top_k,
+                     float top_p, float rep_penalty, uint32_t seed, int32_t* tokens_out, int use_graph, void* stream, int* steps_done) {
+    if (!e || !tokens_out) return fail(e, -22, "sr_decode_sample: null argument");
+    const sr_config& c = e->c;
+    if (e->rows_mode) return fail(e, -22, "sr_decode_sample: the engine is in continuous-batching mode");
+    if (B < 1 || B != e->prefilled_B || max_new < 1 || max_new > c.max_new_tokens || n_eos < 0 || n_eos > 32)
+        return fail(e, -22, "sr_decode_sample: B=%d (prefilled %d) max_new=%d n_eos=%d out of range", B, e->prefilled_B, max_new, n_eos);
+    if (!(temperature > 0.f) || top_k < 1 || top_k > 1024 || !(top_p > 0.f) || top_p > 1.f || !(rep_penalty > 0.f))
+        return fail(e, -22, "sr_decode_sample: temperature > 0, 1 <= top_k <= 1024, 0 < top_p <= 1, repetition_penalty > 0 required");
+    if (e->h_ctx_hi + max_new > c.max_ctx)
+        return fail(e, -22, "sr_decode_sample: context %d + %d new tokens exceeds max_ctx %d", e->h_ctx_hi, max_new, c.max_ctx);
+    e->h_ctx_hi += max_new;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_eos) SR_TRY((int)hipMemcpyAsync(e->d_eos, host_eos, n_eos * 4, hipMemcpyHostToDevice, s));
+    const bool rp = rep_penalty != 1.0f;
+    const float it = 1.0f / temperature;
+    const int hn = fused_norms(e, B) ? 1 : 0;
+    SampleArgs sa{e->d_logits, c.t_vocab, B, it, top_k, top_p, rep_penalty, rp ? e->d_seen : nullptr, e->seen_words, seed, e->d_step, e->d_sampled,
+                  e->d_amax_val, gemv_f32_blocks(c.t_vocab, B, c.t_hidden, hn), gemv_f32_block_rows(c.t_vocab, B, c.t_hidden, hn)};
+    if (rp) SR_TRY(launch_mark_prompt(s, e->t_src, e->t_lastrow, e->d_seen, e->seen_words, B));
+    SR_TRY(launch_sample(s, sa));                  // first token, from the prefill logits
+    auto enqueue = [&](hipStream_t q) -> int {     // one step: consume the drawn token, forward, draw the next
+        if (int rc = enqueue_step(e, B, n_eos, pad_id, nullptr, q, e->d_sampled)) return rc;
+        if (rp) SR_TRY(launch_mark_chosen(q, e->d_sampled, e->d_seen, e->seen_words, B));
+        if (int rc = enqueue_decode_forward(e, B, q)) return rc;
+        return launch_sample(q, sa);
+    };
+    if (use_graph && (e->sgraph == nullptr || e->sg_B != B || e->sg_neos != n_eos || e->sg_pad != pad_id || e->sg_topk != top_k ||
+                      e->sg_it != it || e->sg_topp != top_p || e->sg_rp != rep_penalty || e->sg_seed != seed)) {
+        if (e->sgraph) { (void)hipGraphExecDestroy(e->sgraph); e->sgraph = nullptr; }
+        hipGraph_t g = nullptr;
+        SR_TRY((int)hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
+        int rc = enqueue(e->cap_stream);
+        hipError_t er = hipStreamEndCapture(e->cap_stream, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        SR_TRY((int)er);
+        er = hipGraphInstantiate(&e->sgraph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        SR_TRY((int)er);
+        e->sg_B = B; e->sg_neos = n_eos; e->sg_pad = pad_id; e->sg_topk = top_k; e->sg_it = it; e->sg_topp = top_p; e->sg_rp = rep_penalty; e->sg_seed = seed;
+    }
+    int done = 0;
+    std::vector<int> fin(B);
+    for (int i = 0; i < max_new; ++i) {
+        if (i == max_new - 1) {                    // the last token only needs to be recorded
+            if (int rc = enqueue_step(e, B, n_eos, pad_id, nullptr, s, e->d_sampled)) return rc;
+            done = max_new;
+            break;
+        }
+        if (use_graph) SR_TRY((int)hipGraphLaunch(e->sgraph, s));
+        else if (int rc = enqueue(s)) return rc;
+        done = i + 1;
+        if (n_eos && (i % 16) == 15) {
+            SR_TRY((int)hipMemcpyAsync(fin.data(), e->d_finished, B * 4, hipMemcpyDeviceToHost, s));
+            SR_TRY((int)hipStreamSynchronize(s));
+            bool all = true;
+            for (int b = 0; b < B; ++b) all &= fin[b] != 0;
+            if (all) break;
+        }
+    }
+    if (done < max_new) {
+        std::vector<int> padrow(max_new, pad_id);
+        for (int b = 0; b < B; ++b)
+            SR_TRY((int)hipMemcpyAsync(e->d_tokens + (size_t)b * c.max_new_tokens + done, padrow.data(), (max_new - done) * 4, hipMemcpyHostToDevice, s));
+        SR_TRY((int)hipStreamSynchronize(s));
+    }
+    SR_TRY((int)hipMemcpy2DAsync(tokens_out, (size_t)max_new * 4, e->d_tokens, (size_t)c.max_new_tokens * 4, (size_t)max_new * 4, B,
+                                 hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipStreamSynchronize(s));
+    if (steps_done) *steps_done = done;
+    return 0;
+}
+
 int sr_rows_step(sr_engine* e, int n_steps, const int32_t* host_eos, int n_eos, int32_t pad_id, void* stream) {
     if (!e || !e->rows_mode) return fail(e, -22, "sr_rows_step: call sr_rows_begin first");
     if (n_steps < 1 || n_eos < 0 || n_eos > 32) return fail(e, -22, "sr_rows_step: n_steps=%d n_eos=%d out of range", n_steps, n_eos);
@@ -1173,6 +1256,13 @@ int sr_op_gemv_f8(const void* x, int ldx, const void* w8, const float* w_scale, 
     a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo; a.ksplit = ksplit > 0 ? ksplit : 1;
     a.bias = (const bf16_t*)bias; a.norm_w = (const bf16_t*)norm_w; a.eps = eps;
     SR_WRAP(launch_gemv((hipStream_t)stream, a, mode));
+}
+int sr_op_sample(const float* logits, int B, int V, float temperature, int top_k, float top_p, float rep_penalty, const uint32_t* seen,
+                 uint32_t seed, const int32_t* step, int64_t* out, const float* blk_max, int n_blk, int blk_rows, void* stream) {
+    if (!(temperature > 0.f)) return fail(nullptr, -22, "sr_op_sample: temperature must be > 0");
+    SampleArgs a{logits, V, B, 1.0f / temperature, top_k, top_p, rep_penalty, seen, (V + 31) / 32, seed, step, reinterpret_cast<long long*>(out),
+                 blk_max, n_blk, blk_rows};
+    SR_WRAP(launch_sample((hipStream_t)stream, a));
 }
 int sr_op_argmax(const float* logits, int rows, int V, int32_t* out_idx, void* stream) {
     SR_WRAP(launch_argmax((hipStream_t)stream, logits, rows, V, out_idx));

@@ -605,6 +605,14 @@ int gemv_f32_blocks(int N, int M, int K, int has_norm) {
     return use_32(a, GV_F32) ? cdiv(N / 32, 4) : cdiv(N / 16, 4);
 }
 
+// vocabulary rows covered by one block of the F32 (LM head) launch = rows per entry of the argmax partials
+int gemv_f32_block_rows(int N, int M, int K, int has_norm) {
+    GemvArgs a{};
+    a.M = M; a.K = K; a.N = N;
+    a.norm_w = has_norm ? reinterpret_cast<const bf16_t*>(&a) : nullptr;
+    return use_32(a, GV_F32) ? 128 : 64;
+}
+
 // largest in-block K split that leaves >= 2 chunks per wave
 int gemv_pick_kp(int K, int ksplit, int want) {
     const int ch = K / 64 / (ksplit > 0 ? ksplit : 1);

@@ -38,7 +38,8 @@ struct GemvArgs {
     const float* w_scale;                   // ... and scale output channel n by w_scale[n]
 };
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode);
-int gemv_f32_blocks(int N, int M, int K, int has_norm);    // gridDim.x of the F32 launch (length of the amax rows)
+int gemv_f32_blocks(int N, int M, int K, int has_norm);
+int gemv_f32_block_rows(int N, int M, int K, int has_norm);   // vocabulary rows per block of that launch    // gridDim.x of the F32 launch (length of the amax rows)
 
 // ------------------------------------------------------------------ attention.hip
 // one 64-query tile of one sequence.  K element (kvh, key j, d) = k[(k_row0 + j)*k_stride + kvh*k_head_stride + d];
@@ -125,6 +126,18 @@ struct AdmitArgs {
     float* amax_val; int* amax_idx; int n_part;
 };
 int launch_admit_rows(hipStream_t s, const AdmitArgs& a);
+// ------------------------------------------------------------------ sample.hip
+struct SampleArgs {
+    const float* logits; int V; int B;      // float32 [B, V]
+    float inv_temp; int top_k; float top_p; float rep_penalty;
+    const unsigned* seen; int seen_words;   // optional bitmask [B][seen_words] of tokens already in prompt / output
+    unsigned seed; const int* step;         // RNG stream: (seed, row, step[row])
+    long long* out;                         // [B] chosen token
+    const float* blk_max; int n_blk, blk_rows;   // optional: the LM head's per-block maxima [B][n_blk], block j = ids [j*blk_rows, (j+1)*blk_rows)
+};
+int launch_sample(hipStream_t s, const SampleArgs& a);
+int launch_mark_prompt(hipStream_t s, const int* src, const int* lastrow, unsigned* seen, int seen_words, int B);
+int launch_mark_chosen(hipStream_t s, const long long* chosen, unsigned* seen, int seen_words, int B);
 int launch_next_ids(hipStream_t s, const float* amax_val, const int* amax_idx, int n_part, int B, long long* out);
 int launch_synth_fill(hipStream_t s, bf16_t* out, long long n, uint32_t key, float base, float scale);
 int launch_fill_zero(hipStream_t s, void* p, size_t bytes);

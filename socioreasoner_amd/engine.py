@@ -173,6 +173,19 @@ class Engine:
         self._last_B = B
         return logits
 
+    def decode_sample(self, max_new: int, temperature: float, top_k: int, top_p: float = 1.0, repetition_penalty: float = 1.0,
+                      seed: int = 0, eos: Sequence[int] = (), pad_id: int = 0, use_graph: bool = True) -> torch.Tensor:
+        """Sampled decode on the device for the sequences of the last prefill -> int32 tokens [B, max_new]."""
+        B = self._last_B
+        toks = torch.empty(B, max_new, dtype=torch.int32, device=self.device)
+        eos_a = np.asarray(list(eos), dtype=np.int32)
+        done = C.c_int(0)
+        L.check(self.lib.sr_decode_sample(self._h, B, max_new, eos_a.ctypes.data_as(L._i32p) if len(eos_a) else None, len(eos_a), pad_id,
+                                          C.c_float(temperature), int(top_k), C.c_float(top_p), C.c_float(repetition_penalty), int(seed) & 0xffffffff,
+                                          C.c_void_p(toks.data_ptr()), 1 if use_graph else 0, self._s(), C.byref(done)), self._h, "sr_decode_sample")
+        self.steps_done = done.value
+        return toks
+
     def forward_logits(self, ids: Sequence[np.ndarray], pos3: Sequence[np.ndarray], image_embeds: torch.Tensor | None = None):
         """Teacher-forced forward: float32 logits [n_tok, V] for every position of the packed sequences."""
         B = len(ids)

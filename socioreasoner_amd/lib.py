@@ -47,6 +47,8 @@ SIGNATURES = {
     "sr_decode": (C.c_int, [_vp, _i32p, _i, _i, _i32p, _i, C.c_int32, _vp, _vp, _vp, _i, _vp, C.POINTER(C.c_int)]),
     "sr_decode_step": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp]),
     "sr_finalize_weights": (C.c_int, [_vp, _vp]),
+    "sr_decode_sample": (C.c_int, [_vp, _i, _i, _i32p, _i, C.c_int32, C.c_float, _i, C.c_float, C.c_float, C.c_uint32, _vp, _i, _vp, C.POINTER(C.c_int)]),
+    "sr_op_sample": (C.c_int, [_vp, _i, _i, C.c_float, _i, C.c_float, C.c_float, _vp, C.c_uint32, _vp, _vp, _vp, _i, _i, _vp]),
     "sr_forward_logits": (C.c_int, [_vp, _i64p, _i64p, _i32p, _i, _vp, _i, _vp, _vp]),
     "sr_op_quant_f8": (C.c_int, [_vp, _i, _i, _vp, _vp, _vp]),
     "sr_op_gemv_f8": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, C.c_float, _i, _vp]),

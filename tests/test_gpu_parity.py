@@ -299,6 +299,117 @@ def test_gemv_f8_modes(L, M):
         assert float((slabs.sum(0).cpu().double() - ref).abs().max()) <= 2e-3, ks
 
 
+# ------------------------------------------------------------------------------------------------ sampling kernel
+def _filtered_probs(logits, temperature, top_k, top_p):
+    """Reference distribution of the sampler (same filtering rule as socioreasoner_amd/sampling.py), float64."""
+    x = logits.double() / temperature
+    kth = torch.topk(x, top_k).values[-1]
+    x = torch.where(x < kth, torch.full_like(x, float("-inf")), x)
+    sx, si = torch.sort(x, descending=False)
+    cp = torch.softmax(sx, -1).cumsum(-1)
+    drop = cp <= (1.0 - top_p)
+    drop[-1] = False
+    sx = sx.masked_fill(drop, float("-inf"))
+    return torch.softmax(torch.empty_like(x).scatter_(-1, si, sx), -1)
+
+
+def test_sample_kernel_limits_and_distribution(L):
+    """k_sample: top_k = 1 is the arg-max with the lowest id on ties; ties AT the top-k threshold resolve to the lowest ids;
+    the repetition penalty moves the choice; and the empirical frequencies over 8192 draws follow softmax(logits / T)
+    restricted by top-k and top-p (support exact, frequencies within sampling error)."""
+    V = 151936
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(V, generator=g) * 2.0
+    def run(logits, B, temperature, top_k, top_p, rp=1.0, seen=None, seed=1, step=None):
+        out = torch.zeros(B, dtype=torch.int64, device="cuda")
+        st = D(step) if step is not None else None
+        assert L.sr_op_sample(P(D(logits)), B, logits.shape[1], C.c_float(temperature), top_k, C.c_float(top_p), C.c_float(rp),
+                              P(D(seen)) if seen is not None else None, seed, P(st), P(out), None, 0, 0, sp()) == 0
+        torch.cuda.synchronize()
+        return out.cpu()
+    # top_k = 1 (any temperature / top_p): arg-max, lowest id among equal maxima
+    lg = base.repeat(3, 1).clone()
+    lg[1, 777] = lg[1, 140001] = lg[1].max() + 1.0
+    lg[2] = 0.0                                                   # all equal
+    got = run(lg, 3, 0.9, 1, 0.5)
+    assert got.tolist() == [int(base.argmax()), 777, 0]
+    # ties at the threshold: rows of identical values -> the top-k set is the k lowest ids
+    got = torch.stack([run(lg[2:3], 1, 1.0, 5, 1.0, seed=s_) for s_ in range(40)])
+    assert set(got.flatten().tolist()) <= {0, 1, 2, 3, 4} and len(set(got.flatten().tolist())) >= 4
+    # repetition penalty on the arg-max token hands the choice to the runner-up
+    top2 = base.topk(2).indices.tolist()
+    seen = torch.zeros(1, (V + 31) // 32, dtype=torch.int32)
+    seen[0, top2[0] // 32] = 1 << (top2[0] % 32) if top2[0] % 32 < 31 else -(1 << 31)
+    assert int(base[top2[0]]) >= 0 or True
+    big = base.clone(); big[top2[0]] = abs(big[top2[0]]) + 1.0; big[top2[1]] = big[top2[0]] - 0.1
+    assert run(big[None], 1, 1.0, 1, 1.0, rp=3.0, seen=seen).tolist() == [top2[1]]
+    assert run(big[None], 1, 1.0, 1, 1.0, rp=1.0, seen=seen).tolist() == [top2[0]]
+    # distribution: 32 rows x 256 steps of the same logits (the RNG is keyed by row and step): 8192 draws
+    T, K, PP = 0.7, 50, 0.9
+    want = _filtered_probs(base, T, K, PP)
+    support = set(torch.nonzero(want > 0).flatten().tolist())
+    rows = base.repeat(32, 1).cuda().contiguous()
+    out = torch.zeros(32, dtype=torch.int64, device="cuda")
+    out2 = torch.zeros(32, dtype=torch.int64, device="cuda")
+    bmax = rows.view(32, V // 64, 64).amax(-1).contiguous()
+    counts = torch.zeros(V, dtype=torch.float64)
+    n_draws = 0
+    for it in range(256):
+        step = (torch.arange(32, dtype=torch.int32) * 256 + it).cuda()
+        # odd iterations go through the block-maxima shortcut (the LM head's argmax partials): it must pick the same tokens
+        if it % 2:
+            assert L.sr_op_sample(P(rows), 32, V, C.c_float(T), K, C.c_float(PP), C.c_float(1.0), None, 99, P(step), P(out2), P(bmax), V // 64, 64, sp()) == 0
+        assert L.sr_op_sample(P(rows), 32, V, C.c_float(T), K, C.c_float(PP), C.c_float(1.0), None, 99, P(step), P(out), None, 0, 0, sp()) == 0
+        got = out.cpu()
+        if it % 2:
+            assert torch.equal(out2.cpu(), got), it
+        assert set(got.tolist()) <= support
+        counts += torch.bincount(got, minlength=V).double()
+        n_draws += 32
+    # chi-square-like bound: per-token |freq - p| <= 5 sigma (binomial) + 1/n
+    freq = counts / n_draws
+    sigma = torch.sqrt(want * (1 - want) / n_draws)
+    assert bool(((freq - want).abs() <= 5 * sigma + 1.0 / n_draws).all()), float(((freq - want).abs() - 5 * sigma).max())
+    assert len(support) < K and float(want.max()) < 0.9            # top-p really cut the top-k set; not degenerate
+
+
+def test_decode_sample_on_device(tiny_engine, golden_dir):
+    """sr_decode_sample: top_k = 1 reproduces the greedy tokens; a seed fixes the sequence (graph == eager); different
+    seeds differ; every sampled token lies in the top-k set of the logits that produced it (checked by replay); eos stops."""
+    g = np.load(os.path.join(golden_dir, "hf_tiny.npz"))
+    grids = [tuple(x) for x in g["grids"].tolist()]
+    emb = tiny_engine.vit_forward(bits_to_f32(g["pix"]).cuda(), grids)
+    ids, pos3 = g["ids"], g["pos3"]
+    other = ids[:9].copy()
+    other[other >= 2040] = 5
+    pos_o = np.tile(np.arange(9), (3, 1))
+    def pre():
+        return tiny_engine.prefill([ids, other], [pos3, pos_o], emb, return_logits=True)
+    pre()
+    greedy = tiny_engine.decode(16)
+    pre()
+    assert torch.equal(tiny_engine.decode_sample(16, 0.8, 1, 0.9, seed=3), greedy)
+    pre()
+    a = tiny_engine.decode_sample(16, 1.3, 4, 0.95, repetition_penalty=1.2, seed=7, use_graph=True)
+    pre()
+    b = tiny_engine.decode_sample(16, 1.3, 4, 0.95, repetition_penalty=1.2, seed=7, use_graph=False)
+    pre()
+    c = tiny_engine.decode_sample(16, 1.3, 4, 0.95, repetition_penalty=1.2, seed=8)
+    assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, greedy)
+    # replay through sr_decode_step: token i must be among the 4 best of the logits before it (penalty 1 for this check)
+    pre()
+    d = tiny_engine.decode_sample(12, 1.5, 4, 1.0, seed=21)
+    lg = pre()
+    for i in range(12):
+        top = lg.topk(4, dim=-1).indices
+        assert bool((d[:, i, None].long() == top).any(-1).all()), i
+        lg, _ = tiny_engine.decode_step(d[:, i].long())
+    # eos: the first sampled token as eos -> stop after one token, pad afterwards
+    pre()
+    e1 = tiny_engine.decode_sample(16, 1.5, 4, 1.0, seed=21, eos=[int(d[0, 0])], pad_id=2045)
+    assert e1[0].tolist() == [int(d[0, 0])] + [2045] * 15
+
+
 # ------------------------------------------------------------------------------------------------ norms / argmax
 @pytest.mark.parametrize("rows,H", [(1024, 1280), (448, 2048), (3, 512), (1, 2048), (9, 320)])
 def test_rmsnorm_and_resid(L, rows, H):
