@@ -150,8 +150,11 @@ int sr_decode_step(sr_engine* e, const int64_t* dev_last_ids, int B, float* dev_
  *   sr_rows_step  : n_steps decode steps for all rows (one hipGraph replay each); a row stops at its first eos token or
  *                   at its limit, later positions are not written.  Asynchronous.
  *   sr_rows_poll  : host copies of the per-row finished flags and generated-token counts (synchronises the stream).
- *   sr_rows_read  : the first n generated tokens of a row (int32, device to device). */
+ *   sr_rows_read  : the first n generated tokens of a row (int32, device to device).
+ *   sr_rows_sampling : (optional, after sr_rows_begin) all rows draw their tokens with k_sample (temperature > 0, 1 <= top_k <= 1024,
+ *                   0 < top_p <= 1) instead of the greedy arg-max; temperature 0 switches back. */
 int sr_rows_begin(sr_engine* e, void* stream);
+int sr_rows_sampling(sr_engine* e, float temperature, int top_k, float top_p, uint32_t seed);
 int sr_admit(sr_engine* e, const int64_t* host_ids, const int64_t* host_pos3, const int32_t* host_seq_lens,
              const int32_t* host_rows, const int32_t* host_max_new, int n, const void* dev_image_embeds, int n_image_rows,
              float* dev_logits_out, void* stream);

@@ -340,9 +340,10 @@ class Mi355xStrategy(InferenceStrategy):
 
     def start_server(self, data: DataProto, request_complete_callback):
         """Request-level serving (reference vllm_strategy.py:156-205): ADD / ABORT / STOP commands arrive through the queue
-        while the loop runs; greedy requests are served by CONTINUOUS batching (socioreasoner_amd.serving: admit on finish,
-        one graph replay per token for all rows), sampling requests in engine-sized static batches.  Each request is
-        reported through the callback the moment its sequence ends."""
+        while the loop runs; greedy requests and sampling requests with a top-k bound are served by CONTINUOUS batching
+        (socioreasoner_amd.serving: admit on finish, one graph replay per token for all rows, the draw inside the graph);
+        anything else (unbounded top-k, repetition penalty, n > 1) in engine-sized static batches.  Each request is reported
+        through the callback the moment its sequence ends."""
         from socioreasoner_amd.serving import ContinuousBatcher, Request
         self.running = True
         batcher, bkey = None, None
@@ -357,18 +358,24 @@ class Mi355xStrategy(InferenceStrategy):
             name = getattr(command, "name", command)
             if name == "ADD":
                 gc = dict(req.meta_info.get("generation_config") or {})
-                greedy = sampling.is_greedy(gc) and float(gc.get("repetition_penalty", 1.0) or 1.0) == 1.0 and hasattr(self.engine, "rows_begin")
-                if not greedy or int(gc.get("num_return_sequences", 1) or 1) != 1:
+                rp1 = float(gc.get("repetition_penalty", 1.0) or 1.0) == 1.0
+                greedy = sampling.is_greedy(gc)
+                tk = gc.get("top_k", -1)
+                dev_sampling = not greedy and tk is not None and 1 <= int(tk) <= 1024 and float(gc.get("temperature", 1.0)) > 1e-5
+                rows_ok = hasattr(self.engine, "rows_begin") and rp1 and (greedy or dev_sampling) and int(gc.get("num_return_sequences", 1) or 1) == 1
+                if not rows_ok:
                     sampled.append(req)
                 else:
                     eos = gc.get("eos_token_id") or [self.tokenizer.eos_token_id]
                     eos = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos])]
                     pad = int(gc.get("pad_token_id", self.tokenizer.pad_token_id))
-                    key = (tuple(eos), pad)
+                    smp = None if greedy else {"temperature": float(gc.get("temperature", 1.0)), "top_k": int(tk),
+                                               "top_p": float(gc.get("top_p", 1.0) or 1.0), "seed": int(gc.get("seed", 0) or 0)}
+                    key = (tuple(eos), pad, None if smp is None else tuple(sorted(smp.items())))
                     if batcher is None or (key != bkey and batcher.idle()):
-                        batcher, bkey = ContinuousBatcher(self.engine, eos, pad), key
+                        batcher, bkey = ContinuousBatcher(self.engine, eos, pad, sampling=smp), key
                     if key != bkey:
-                        sampled.append(req)          # different stop set while rows are running: static path
+                        sampled.append(req)          # different stop set / sampling parameters while rows are running: static path
                     else:
                         mm = req.non_tensor_batch.get("multi_modal_data") if req.non_tensor_batch else None
                         ids_in = hostops.gather_unpadded_input_ids(req.batch["input_ids"].cpu(), req.batch["attention_mask"].cpu())[0]

@@ -124,6 +124,10 @@ struct sr_engine {
     long long *d_chosen = nullptr, *d_next = nullptr, *d_sampled = nullptr;
     unsigned* d_seen = nullptr;    // [32][seen_words] token bitmask for the repetition penalty
     int seen_words = 0;
+    // continuous batching with sampling (sr_rows_sampling): parameters shared by all rows; 0 temperature = greedy
+    float rows_temp = 0.f, rows_topp = 1.f; int rows_topk = 0; unsigned rows_seed = 0, adm_count = 0;
+    long long* d_adm_pick = nullptr;
+    hipGraphExec_t rgraph = nullptr; int rg_neos = -1, rg_pad = 0, rg_topk = 0; float rg_it = 0.f, rg_topp = 0.f; unsigned rg_seed = 0;
     hipGraphExec_t sgraph = nullptr;      // sampled decode step: bookkeeping + forward + k_sample
     int sg_B = -1, sg_neos = -1, sg_pad = 0, sg_topk = 0; float sg_it = 0.f, sg_topp = 0.f, sg_rp = 0.f; unsigned sg_seed = 0;
     int prefilled_B = 0;
@@ -287,6 +291,7 @@ void carve(sr_engine* e) {
     e->d_ngen = ar.take<int>(32);
     e->d_adm = ar.take<int>(5 * 32);
     e->d_sampled = ar.take<long long>(32);
+    e->d_adm_pick = ar.take<long long>(32);
     e->seen_words = (c.t_vocab + 31) / 32;
     e->d_seen = ar.take<unsigned>((size_t)32 * e->seen_words);
     e->d_chosen = ar.take<long long>(32);
@@ -614,6 +619,7 @@ int sr_engine_destroy(sr_engine* e) {
     if (e->graph) (void)hipGraphExecDestroy(e->graph);
     for (auto g : e->step_graph) if (g) (void)hipGraphExecDestroy(g);
     if (e->sgraph) (void)hipGraphExecDestroy(e->sgraph);
+    if (e->rgraph) (void)hipGraphExecDestroy(e->rgraph);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     if (e->ev_copy) (void)hipEventDestroy(e->ev_copy);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -927,6 +933,12 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
                  e->d_ctx_len, e->d_pos, e->d_slots, e->d_finished, e->d_step, e->d_row_limit, e->d_ngen,
                  e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(c.t_vocab, MB, H, fused_norms(e, MB) ? 1 : 0)};
     SR_TRY(launch_admit_rows(s, aa));
+    if (e->rows_temp > 0.f) {      // sampling mode: the first token of the new rows is drawn from the admission logits
+        SampleArgs sa{e->d_logits_adm, c.t_vocab, B, 1.0f / e->rows_temp, e->rows_topk, e->rows_topp, 1.0f, nullptr, e->seen_words,
+                      e->rows_seed ^ (0x9E3779B9u * ++e->adm_count), nullptr, e->d_adm_pick, nullptr, 0, 0};
+        SR_TRY(launch_sample(s, sa));
+        SR_TRY(launch_scatter_rows(s, e->d_adm, e->d_adm_pick, e->d_sampled, B));
+    }
     return 0;
 }
 
@@ -962,6 +974,16 @@ int sr_rows_begin(sr_engine* e, void* stream) {
     e->rows_mode = true;
     e->prefilled_B = e->c.max_batch;
     e->h_ctx_hi = 0;
+    e->rows_temp = 0.f;
+    return 0;
+}
+
+int sr_rows_sampling(sr_engine* e, float temperature, int top_k, float top_p, uint32_t seed) {
+    if (!e || !e->rows_mode) return fail(e, -22, "sr_rows_sampling: call sr_rows_begin first");
+    if (temperature > 0.f && (top_k < 1 || top_k > 1024 || !(top_p > 0.f) || top_p > 1.f))
+        return fail(e, -22, "sr_rows_sampling: 1 <= top_k <= 1024 and 0 < top_p <= 1 required");
+    e->rows_temp = temperature > 0.f ? temperature : 0.f;
+    e->rows_topk = top_k; e->rows_topp = top_p; e->rows_seed = seed; e->adm_count = 0;
     return 0;
 }
 
@@ -1141,6 +1163,31 @@ int sr_rows_step(sr_engine* e, int n_steps, const int32_t* host_eos, int n_eos, 
     hipStream_t s = (hipStream_t)stream;
     if (n_eos) SR_TRY((int)hipMemcpyAsync(e->d_eos, host_eos, n_eos * 4, hipMemcpyHostToDevice, s));
     const int B = e->c.max_batch;
+    if (e->rows_temp > 0.f) {      // sampled step: consume the drawn tokens, forward, draw the next ones for every row
+        const sr_config& c = e->c;
+        const float it = 1.0f / e->rows_temp;
+        if (e->rgraph == nullptr || e->rg_neos != n_eos || e->rg_pad != pad_id || e->rg_topk != e->rows_topk || e->rg_it != it ||
+            e->rg_topp != e->rows_topp || e->rg_seed != e->rows_seed) {
+            if (e->rgraph) { (void)hipGraphExecDestroy(e->rgraph); e->rgraph = nullptr; }
+            const int hn = fused_norms(e, B) ? 1 : 0;
+            SampleArgs sa{e->d_logits, c.t_vocab, B, it, e->rows_topk, e->rows_topp, 1.0f, nullptr, e->seen_words, e->rows_seed, e->d_step, e->d_sampled,
+                          e->d_amax_val, gemv_f32_blocks(c.t_vocab, B, c.t_hidden, hn), gemv_f32_block_rows(c.t_vocab, B, c.t_hidden, hn)};
+            hipGraph_t g = nullptr;
+            SR_TRY((int)hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
+            int rc = enqueue_step(e, B, n_eos, pad_id, nullptr, e->cap_stream, e->d_sampled);
+            if (!rc) rc = enqueue_decode_forward(e, B, e->cap_stream);
+            if (!rc) rc = launch_sample(e->cap_stream, sa);
+            hipError_t er = hipStreamEndCapture(e->cap_stream, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            SR_TRY((int)er);
+            er = hipGraphInstantiate(&e->rgraph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            SR_TRY((int)er);
+            e->rg_neos = n_eos; e->rg_pad = pad_id; e->rg_topk = e->rows_topk; e->rg_it = it; e->rg_topp = e->rows_topp; e->rg_seed = e->rows_seed;
+        }
+        for (int i = 0; i < n_steps; ++i) SR_TRY((int)hipGraphLaunch(e->rgraph, s));
+        return 0;
+    }
     if (int rc = ensure_decode_graph(e, B, n_eos, pad_id)) return rc;
     for (int i = 0; i < n_steps; ++i) SR_TRY((int)hipGraphLaunch(e->graph, s));
     return 0;

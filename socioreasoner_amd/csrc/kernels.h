@@ -136,6 +136,7 @@ struct SampleArgs {
     const float* blk_max; int n_blk, blk_rows;   // optional: the LM head's per-block maxima [B][n_blk], block j = ids [j*blk_rows, (j+1)*blk_rows)
 };
 int launch_sample(hipStream_t s, const SampleArgs& a);
+int launch_scatter_rows(hipStream_t s, const int* rows, const long long* src, long long* dst, int n);   // dst[rows[i]] = src[i]
 int launch_mark_prompt(hipStream_t s, const int* src, const int* lastrow, unsigned* seen, int seen_words, int B);
 int launch_mark_chosen(hipStream_t s, const long long* chosen, unsigned* seen, int seen_words, int B);
 int launch_next_ids(hipStream_t s, const float* amax_val, const int* amax_idx, int n_part, int B, long long* out);

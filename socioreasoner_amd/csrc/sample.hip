@@ -266,8 +266,18 @@ __global__ void k_mark_chosen(const long long* chosen, unsigned* seen, int seen_
     }
 }
 
+__global__ void k_scatter_rows(const int* rows, const long long* src, long long* dst, int n) {
+    const int i = threadIdx.x;
+    if (i < n) dst[rows[i]] = src[i];
+}
+
 }  // namespace
 
+int launch_scatter_rows(hipStream_t s, const int* rows, const long long* src, long long* dst, int n) {
+    hipLaunchKernelGGL(k_scatter_rows, dim3(1), dim3(64), 0, s, rows, src, dst, n);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
 int launch_sample(hipStream_t s, const SampleArgs& a) {
     if (a.B <= 0) return 0;
     if (a.top_k < 1 || a.top_k > KMAX || a.top_k > a.V || !(a.inv_temp > 0.f) || !(a.top_p > 0.f)) return -22;

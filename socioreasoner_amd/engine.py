@@ -226,6 +226,10 @@ class Engine:
         L.check(self.lib.sr_rows_begin(self._h, self._s()), self._h, "sr_rows_begin")
         self._last_B = self.cfg.max_batch
 
+    def rows_sampling(self, temperature: float, top_k: int, top_p: float = 1.0, seed: int = 0):
+        """After rows_begin: all rows sample (k_sample) instead of taking the arg-max; temperature 0 = greedy again."""
+        L.check(self.lib.sr_rows_sampling(self._h, C.c_float(temperature), int(top_k), C.c_float(top_p), int(seed) & 0xffffffff), self._h, "sr_rows_sampling")
+
     def admit(self, rows: Sequence[int], ids: Sequence[np.ndarray], pos3: Sequence[np.ndarray], max_new: Sequence[int],
               image_embeds: torch.Tensor | None = None, return_logits: bool = False):
         """Prefill sequences into free batch rows without disturbing running ones; row i stops after max_new[i] tokens."""

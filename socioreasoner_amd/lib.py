@@ -53,6 +53,7 @@ SIGNATURES = {
     "sr_op_quant_f8": (C.c_int, [_vp, _i, _i, _vp, _vp, _vp]),
     "sr_op_gemv_f8": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, C.c_float, _i, _vp]),
     "sr_rows_begin": (C.c_int, [_vp, _vp]),
+    "sr_rows_sampling": (C.c_int, [_vp, C.c_float, _i, C.c_float, C.c_uint32]),
     "sr_admit": (C.c_int, [_vp, _i64p, _i64p, _i32p, _i32p, _i32p, _i, _vp, _i, _vp, _vp]),
     "sr_rows_step": (C.c_int, [_vp, _i, _i32p, _i, C.c_int32, _vp]),
     "sr_rows_poll": (C.c_int, [_vp, _i32p, _i32p, _vp]),

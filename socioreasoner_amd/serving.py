@@ -27,13 +27,16 @@ class Request:
 
 
 class ContinuousBatcher:
-    def __init__(self, engine, eos: Sequence[int], pad_id: int, steps_per_poll: int = 8):
+    def __init__(self, engine, eos: Sequence[int], pad_id: int, steps_per_poll: int = 8, sampling: Optional[dict] = None):
+        """sampling: None = greedy, else {"temperature", "top_k" (1..1024), "top_p", "seed"} shared by all requests."""
         self.engine, self.eos, self.pad_id, self.steps_per_poll = engine, [int(e) for e in eos], int(pad_id), steps_per_poll
         self.free = deque(range(engine.cfg.max_batch))
         self.active: Dict[int, Request] = {}
         self.pending: deque = deque()
         self.stats = {"admitted": 0, "steps": 0, "admissions": 0}
         engine.rows_begin()
+        if sampling:
+            engine.rows_sampling(float(sampling["temperature"]), int(sampling["top_k"]), float(sampling.get("top_p", 1.0)), int(sampling.get("seed", 0)))
 
     def submit(self, req: Request):
         self.pending.append(req)

@@ -751,6 +751,14 @@ def test_continuous_batching_matches_one_at_a_time(tiny_engine, golden_dir):
         got = cb.run(rl)
         assert got == want, (steps_per_poll, got, want)
         assert cb.stats["admissions"] >= 3                  # 9 requests through 4 rows: rows were re-used mid-flight
+    # sampling rows: top_k = 1 is the greedy result again; a seed fixes the outcome, another seed changes it
+    def run_sampled(**smp):
+        cb = ContinuousBatcher(PixEngine(tiny_engine), eos, pad_id=2045, steps_per_poll=2, sampling=smp)
+        return cb.run([Request(ids=i, pos3=p, max_new=mx, images=[pix] if has_img else [], grids=grids if has_img else []) for i, p, mx, has_img in reqs])
+    assert run_sampled(temperature=0.7, top_k=1, top_p=0.9, seed=1) == want
+    s1 = run_sampled(temperature=1.4, top_k=6, top_p=0.95, seed=5)
+    assert s1 == run_sampled(temperature=1.4, top_k=6, top_p=0.95, seed=5) and s1 != run_sampled(temperature=1.4, top_k=6, top_p=0.95, seed=6)
+    assert s1 != want and all(1 <= len(t) <= mx for t, (_, _, mx, _) in zip(s1, reqs))
     # static calls work again afterwards
     tiny_engine.prefill([reqs[0][0]], [reqs[0][1]], None)
     assert tiny_engine.decode(16, use_graph=True)[0].tolist() == alone[0]
