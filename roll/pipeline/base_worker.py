@@ -8,7 +8,6 @@ There is no load/offload of model state around the call: the weights stay reside
 from __future__ import annotations
 
 import logging
-import queue
 import threading
 
 import torch

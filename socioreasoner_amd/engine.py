@@ -76,7 +76,6 @@ class Engine:
             t = t.float()
         t = t.to(self.device).contiguous()
         shape = (C.c_int64 * t.dim())(*t.shape)
-        dt = L.SrConfig  # noqa: F841 (keeps the import used by linters)
         L.check(self.lib.sr_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), 0 if t.dtype == torch.bfloat16 else 1,
                                         shape, t.dim(), self._s()), self._h, f"sr_load_weight({name})")
 
