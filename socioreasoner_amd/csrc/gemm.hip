@@ -16,10 +16,11 @@
 // Also measured: requesting both k-steps' fragments up front (sched_group_barrier: 16 ds_read, then 32 MFMA) lets the compiler hoist
 // the tile barrier above the MFMAs; +4..6 % on two shapes, -3..20 % on the others (lm qkv 725 vs 910 TF/s).  Not kept.
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BN = 128, BK = 64, NTHREADS = 256;
+constexpr int BN = 128, BK = 64;
 
 template <int BM>
 struct Smem {
@@ -29,11 +30,13 @@ struct Smem {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * (BK * 2) + ((chunk ^ (row & 7)) << 4); }
 
-template <int BM, int EPI>
-__global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn) {
+template <int BM, int EPI, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p, int ntm, int ntn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem<BM>& sm = *reinterpret_cast<Smem<BM>*>(smem_raw);
-    constexpr int MI = BM / 32;       // 16-row m-tiles per wave
+    constexpr int MI = BM / 32;       // 16-row m-tiles per wave (waves are arranged 2 x NW/2)
+    constexpr int WNC = NW / 2;       // wave columns
+    constexpr int NJ = BN / WNC / 16; // 16-col n-tiles per wave: 4 (NW = 4) or 2 (NW = 8)
 
     // ---- block -> tile: XCD-aware (block b runs on XCD b % 8: give each XCD a contiguous run of tiles), then
     // grouped ordering (8 m-tiles share their W panels while walking n)
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNC, wn = wave % WNC;
     const int fr = lane & 15, fg = lane >> 4;
 
     // ---- global -> LDS staging by LDS-DMA (global_load_lds, 16 B per lane): no VGPR round trip and no ds_write
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
     // Rows are clamped so edge tiles stay in bounds (their results are never stored).
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    constexpr int A_G = BM / 32, W_G = BN / 32;          // 8-row groups per wave
+    constexpr int A_G = BM / 8 / NW, W_G = BN / 8 / NW;  // 8-row groups (1-KB LDS-DMA instructions) per wave
     const int lr = lane >> 3, lc = ((lane & 7) ^ lr) * 8;
     const bf16_t* asrc[A_G];
     const bf16_t* wsrc[W_G];
@@ -92,11 +95,11 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
             __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (size_t)kt * w_kt_stride), (lptr_t)(sm.w[buf] + (wave * W_G + i) * 512), 16, 0, 0);
     };
 
-    f32x4 acc[MI][4];
+    f32x4 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
     stage(0, 0);
@@ -108,25 +111,25 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
         const unsigned char* wb = reinterpret_cast<const unsigned char*>(sm.w[cur]);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[MI], wf[4];
+            bf16x8 af[MI], wf[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 int row = wm * (BM / 2) + i * 16 + fr;
                 af[i] = *reinterpret_cast<const bf16x8*>(ab + swz(row, kk * 4 + fg));
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 if (p.w_tiled) {     // LDS keeps the fragment order: [tile][kstep = fg & 1][lane' = (kk*2 + fg/2)*16 + fr][16 B]
-                    wf[j] = *reinterpret_cast<const bf16x8*>(wb + (wn * 4 + j) * 2048 + (fg & 1) * 1024 + (((kk * 2 + (fg >> 1)) * 16 + fr) << 4));
+                    wf[j] = *reinterpret_cast<const bf16x8*>(wb + (wn * NJ + j) * 2048 + (fg & 1) * 1024 + (((kk * 2 + (fg >> 1)) * 16 + fr) << 4));
                 } else {
-                    int row = wn * 64 + j * 16 + fr;
+                    int row = wn * (NJ * 16) + j * 16 + fr;
                     wf[j] = *reinterpret_cast<const bf16x8*>(wb + swz(row, kk * 4 + fg));
                 }
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
         const int orow = p.rowmap ? p.rowmap[m] : m;
         if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                const int ng = n0 + wn * 64 + jp * 32 + fg * 4;       // gate columns (interleaved index)
+            for (int jp = 0; jp < NJ / 2; ++jp) {
+                const int ng = n0 + wn * (NJ * 16) + jp * 32 + fg * 4;       // gate columns (interleaved index)
                 if (ng >= p.N) continue;
                 const int nu = ng + 16;
                 float o[4];
@@ -153,14 +156,14 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
                     g = rbf(g); u = rbf(u);
                     o[r] = rbf(silu_f(g)) * u;
                 }
-                const int no = (n0 + wn * 64) / 2 + jp * 16 + fg * 4;
+                const int no = (n0 + wn * (NJ * 16)) / 2 + jp * 16 + fg * 4;
                 uint2 v = {pack2(o[0], o[1]), pack2(o[2], o[3])};
                 *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + no) = v;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + fg * 4;
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * (NJ * 16) + j * 16 + fg * 4;
                 if (n >= p.N) continue;
                 float o[4];
 #pragma unroll
@@ -194,17 +197,17 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm(GemmArgs p, int ntm, int ntn)
     }
 }
 
-template <int BM, int EPI>
+template <int BM, int EPI, int NW = 4>
 int launch_t(hipStream_t s, const GemmArgs& a) {
     int ntm = cdiv(a.M, BM), ntn = cdiv(a.N, BN);
     size_t smem = sizeof(Smem<BM>);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, EPI, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_gemm<BM, EPI>), dim3(ntm * ntn), dim3(NTHREADS), smem, s, a, ntm, ntn);
+    hipLaunchKernelGGL((k_gemm<BM, EPI, NW>), dim3(ntm * ntn), dim3(NW * 64), smem, s, a, ntm, ntn);
     SR_CHECK_LAUNCH();
     return 0;
 }
@@ -213,7 +216,15 @@ template <int EPI>
 int launch_e(hipStream_t s, const GemmArgs& a) {
     // 128-row tiles only when they still give every CU work; otherwise 64-row tiles double the block count
     long blocks128 = (long)cdiv(a.M, 128) * cdiv(a.N, BN);
-    if (blocks128 >= 512) return launch_t<128, EPI>(s, a);
+    static const char* bm_env = getenv("SR_GEMM_BM");          // tuning hook for tools/bench_gemm.py: 64 forces the 64-row tile
+    if (bm_env && atoi(bm_env) == 64) return launch_t<64, EPI>(s, a);
+    if (bm_env && atoi(bm_env) == 1288) return launch_t<128, EPI, 8>(s, a);      // 128-row tile, 8 waves (2 x 4) of 64 x 32
+    if (blocks128 >= 512) {
+        // 8 waves (2 x 4, 64 x 32 each; four waves per SIMD with two blocks per CU) measured +2..4 % on the SwiGLU / residual shapes
+        // (lm gate/up 984 vs 943 TF/s, ViT gate/up 821 vs 797, ViT down 874 vs 856) and -5 % on the ViT qkv store shape
+        if constexpr (EPI == EPI_SWIGLU || EPI == EPI_RESID) return launch_t<128, EPI, 8>(s, a);
+        return launch_t<128, EPI>(s, a);
+    }
     return launch_t<64, EPI>(s, a);
 }
 
