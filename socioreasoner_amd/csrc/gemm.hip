@@ -13,6 +13,9 @@
 // every hot-path shape (lm gate/up 911 vs 980 TF/s, ViT qkv 663 vs 723): with two 4-wave blocks per CU the memory round trip is
 // already covered by the other block, and one 8-wave block per CU barriers twice as many waves per k-tile.  Under MFMA load the
 // chip clocks ~2.0 GHz (guide: DVFS), i.e. ~2.1 PF effective peak; this kernel runs 0.9-1.0 PF on random data at large M.
+// A two-stage 256 x 128 tile with 8 waves (one block per CU) lost 5-25 %, a 64 x 128 tile (three blocks per CU) 10-18 %: two
+// 128 x 128 blocks per CU, each covering the other's LDS-DMA wait, is the sweet spot of this structure (PMC on lm gate/up: MFMA pipe
+// 46 % busy at ~2.0 GHz; waves 34 % issuing, 37 % issue-stalled, 30 % parked; LDS instructions 3 % of wave time, no bank conflicts).
 // Also measured: requesting both k-steps' fragments up front (sched_group_barrier: 16 ds_read, then 32 MFMA) lets the compiler hoist
 // the tile barrier above the MFMAs; +4..6 % on two shapes, -3..20 % on the others (lm qkv 725 vs 910 TF/s).  Not kept.
 #include "kernels.h"
