@@ -589,6 +589,8 @@ int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
 }
 }  // namespace
 
+// Also measured at M = 32: doubling the weight rows a wave owns per x fragment (half the x load instructions) is slower -- gate/up 25.5 vs
+// 22.7 us, qkv 11.1 vs 10.4 us: the halved wave count costs more than the saved L2 reads.
 // measured at M = 32 (us, 16-row / 32-row variant): LM head 187 / 140, down-projection with 4 slabs 17.4 / 13.4;
 // qkv 9.6 / 11.5, o_proj 9.2 / 9.9, gate/up 22.9 / 25.4 (the 32-row tiles halve the wave count of the small launches)
 bool use_32(const GemvArgs& a, int mode) {
