@@ -888,6 +888,12 @@ def test_full_size_3b_properties():
     e.prefill([ids0, ids1, ids0], [pos0, pos1, pos0], emb01)
     bt = e.decode(16, use_graph=True)
     assert torch.equal(bt[0], eager[0]) and torch.equal(bt[2], eager[0]) and not torch.equal(bt[1], eager[0])
+    # all-position logits (sr_forward_logits: final norm over every row + LM head as an MFMA GEMM, N = 151 936) against the
+    # last-position logits of the prefill (LM head as the decode GEMV): same function, float32 accumulation order apart
+    allp = e.forward_logits([ids0], [pos0], emb0)
+    last = e.prefill([ids0], [pos0], emb0, return_logits=True)
+    assert allp.shape == (len(ids0), geom.text.vocab_size) and bool(torch.isfinite(allp).all())
+    assert float((allp[-1] - last[0]).abs().max()) <= 2e-3
     toks = eager[0].tolist()
     for k in (1, 5):
         idk, posk = prep(0, toks[:k])
