@@ -284,12 +284,15 @@ __global__ __launch_bounds__(256) void k_attn_dec_scores(DecodeAttnArgs p) {
     }
 }
 
+// DT = 16-wide d-tiles per block: 1 at small batch (most blocks), 2 at batch >= 16 (the softmax of a (sequence, kv head) is then
+// recomputed by 4 blocks instead of 8)
+template <int DT>
 __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    // LDS: ored[3][64] f32x4 | sb[group][s_stride] bf16
+    // LDS: ored[DT][3][64] f32x4 | sb[group][s_stride] bf16
     f32x4* ored = reinterpret_cast<f32x4*>(dsm);
-    bf16_t* sb = reinterpret_cast<bf16_t*>(ored + 3 * 64);
-    const int b = blockIdx.x, kvh = blockIdx.y, dt = blockIdx.z;
+    bf16_t* sb = reinterpret_cast<bf16_t*>(ored + DT * 3 * 64);
+    const int b = blockIdx.x, kvh = blockIdx.y, dt0 = blockIdx.z * DT;
     const int slot = p.slots ? p.slots[b] : b;
     const int nkeys = p.ctx_len[b];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -299,11 +302,15 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
     const int npad = (nkeys + 31) / 32 * 32, nkb = npad / 32, nvec = npad / 8;
     const uint4 z4 = uint4{0, 0, 0, 0};
     // early V^T prefetch: this wave's key blocks kb = wave, wave+4, ... of d-tile dt
-    const bf16_t* vrow = vc + (size_t)(dt * 16 + fr) * p.ctx_max + fg * 8;
-    bf16x8 vf0[8];
+    const bf16_t* vrow[DT];
+    bf16x8 vf0[DT][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (wave + 4 * i < nkb) vf0[i] = *reinterpret_cast<const bf16x8*>(vrow + (wave + 4 * i) * 32);
+    for (int d = 0; d < DT; ++d) {
+        vrow[d] = vc + (size_t)((dt0 + d) * 16 + fr) * p.ctx_max + fg * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (wave + 4 * i < nkb) vf0[d][i] = *reinterpret_cast<const bf16x8*>(vrow[d] + (wave + 4 * i) * 32);
+    }
     // scores of all heads of this kv head -> LDS
     const bf16_t* sg = p.scores + (size_t)(b * HK + kvh) * G * p.ctx_max;
     for (int i = tid; i < G * nvec; i += 256) {
@@ -359,35 +366,50 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
         }
     }
     __syncthreads();
-    // O^T[d][head] for d-tile dt; the 4 waves split the key blocks and reduce through LDS in fixed order
-    f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto pv_block = [&](int kb, bf16x8 vf) {
+    // O^T[d][head] for the block's d-tiles; the 4 waves split the key blocks and reduce through LDS in fixed order
+    f32x4 oacc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto pfrag = [&](int kb) {
         uint4 pv = z4;
         if (fr < G) pv = *reinterpret_cast<const uint4*>(sb + fr * s_stride + kb * 32 + fg * 8);
-        oacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pv), oacc, 0, 0, 0);
+        return __builtin_bit_cast(bf16x8, pv);
     };
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-        if (wave + 4 * i < nkb) pv_block(wave + 4 * i, vf0[i]);
+        if (wave + 4 * i < nkb) {
+            const bf16x8 pf = pfrag(wave + 4 * i);
+#pragma unroll
+            for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0[d][i], pf, oacc[d], 0, 0, 0);
+        }
     for (int kb0 = wave + 32; kb0 < nkb; kb0 += 32) {          // contexts beyond 1024 keys
-        bf16x8 vf[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (kb0 + 4 * i < nkb) vf[i] = *reinterpret_cast<const bf16x8*>(vrow + (kb0 + 4 * i) * 32);
+        for (int d = 0; d < DT; ++d) {
+            bf16x8 vf[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (kb0 + 4 * i < nkb) pv_block(kb0 + 4 * i, vf[i]);
+            for (int i = 0; i < 8; ++i)
+                if (kb0 + 4 * i < nkb) vf[i] = *reinterpret_cast<const bf16x8*>(vrow[d] + (kb0 + 4 * i) * 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (kb0 + 4 * i < nkb) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[i], pfrag(kb0 + 4 * i), oacc[d], 0, 0, 0);
+        }
     }
-    if (wave > 0) ored[(wave - 1) * 64 + lane] = oacc;
+    if (wave > 0) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d) ored[(d * 3 + wave - 1) * 64 + lane] = oacc[d];
+    }
     __syncthreads();
     if (wave == 0 && fr < G) {
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
-            const f32x4 o2 = ored[w * 64 + lane];
-            oacc[0] += o2[0]; oacc[1] += o2[1]; oacc[2] += o2[2]; oacc[3] += o2[3];
+        for (int d = 0; d < DT; ++d) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const f32x4 o2 = ored[(d * 3 + w) * 64 + lane];
+                oacc[d][0] += o2[0]; oacc[d][1] += o2[1]; oacc[d][2] += o2[2]; oacc[d][3] += o2[3];
+            }
+            uint2 v = {pack2(oacc[d][0], oacc[d][1]), pack2(oacc[d][2], oacc[d][3])};
+            *reinterpret_cast<uint2*>(p.out + (size_t)b * p.out_stride + (kvh * G + fr) * DEC_HD + (dt0 + d) * 16 + fg * 4) = v;
         }
-        uint2 v = {pack2(oacc[0], oacc[1]), pack2(oacc[2], oacc[3])};
-        *reinterpret_cast<uint2*>(p.out + (size_t)b * p.out_stride + (kvh * G + fr) * DEC_HD + dt * 16 + fg * 4) = v;
     }
 }
 
@@ -404,20 +426,23 @@ int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim) {
     return 0;
 }
 
-static size_t dec_smem(int ctx_max, int group) { return 3 * 64 * 16 + (size_t)group * (ctx_max + 8) * sizeof(bf16_t); }
+static size_t dec_smem(int ctx_max, int group, int dtiles = 2) { return (size_t)dtiles * 3 * 64 * 16 + (size_t)group * (ctx_max + 8) * sizeof(bf16_t); }
 
 // raises the dynamic-LDS limit once, outside of any stream capture
 int attn_decode_prepare(int ctx_max, int group) {
     const size_t smem = dec_smem(ctx_max, group);
     if (smem > 160 * 1024) return -22;
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_dec_pv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_dec_pv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (rc) return rc;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_dec_pv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 }
 
 int launch_attn_decode(hipStream_t s, const DecodeAttnArgs& a) {
     if (a.B <= 0) return 0;
     if (a.group > 16 || a.ctx_max % 64 != 0 || !a.scores) return -22;
     hipLaunchKernelGGL(k_attn_dec_scores, dim3(a.B, a.n_kv_heads, a.ctx_max / 64), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_attn_dec_pv, dim3(a.B, a.n_kv_heads, DEC_HD / 16), dim3(256), dec_smem(a.ctx_max, a.group), s, a, a.ctx_max + 8);
+    if (a.B >= 16) hipLaunchKernelGGL(k_attn_dec_pv<2>, dim3(a.B, a.n_kv_heads, DEC_HD / 32), dim3(256), dec_smem(a.ctx_max, a.group, 2), s, a, a.ctx_max + 8);
+    else hipLaunchKernelGGL(k_attn_dec_pv<1>, dim3(a.B, a.n_kv_heads, DEC_HD / 16), dim3(256), dec_smem(a.ctx_max, a.group, 1), s, a, a.ctx_max + 8);
     SR_CHECK_LAUNCH();
     return 0;
 }

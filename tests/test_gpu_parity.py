@@ -467,7 +467,7 @@ def test_raster_tail_bit_exact(L):
     assert torch.equal(same.cpu(), big)
 
 
-@pytest.mark.parametrize("CTX,lens", [(4608, [4500, 2049, 1]), (1024, [1024, 577, 64]), (192, [191])])
+@pytest.mark.parametrize("CTX,lens", [(4608, [4500, 2049, 1]), (1024, [1024, 577, 64]), (192, [191]), (640, [577, 640, 64, 1] * 4)])
 def test_decode_attention_against_oracle_math(L, CTX, lens):
     """k_attn_dec_scores + k_attn_dec_pv (mRoPE of the new q/k, KV append, scores, softmax, P.V) against the oracle's
     attention arithmetic (oracle/model_ref.py lm_attention: hf:602-689 rounding points) on random caches, including the
