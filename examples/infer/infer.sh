@@ -1,6 +1,8 @@
-#!/bin/bash
-# Drop-in for the reference's examples/infer/infer.sh: same entry point, same flags.
-# Multi-GPU: torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/start_rlvr_socioseg_pipeline_infer.py ...
-set +x
-CONFIG_PATH=$(basename $(dirname $0))
-python examples/start_rlvr_socioseg_pipeline_infer.py --config_path $CONFIG_PATH  --config_name rlvr_megatron
+#!/usr/bin/env bash
+# Entry point with the reference's name and behaviour: runs the two-stage SocioSeg inference pipeline with
+# examples/infer/rlvr_megatron.yaml, served by the MI355X-native engine.  Works from any directory; extra arguments are
+# passed through.  8 GPUs:
+#   torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/start_rlvr_socioseg_pipeline_infer.py \
+#       --config_path infer --config_name rlvr_megatron
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+exec python "$here/../start_rlvr_socioseg_pipeline_infer.py" --config_path "$(basename "$here")" --config_name rlvr_megatron "$@"
