@@ -1,8 +1,8 @@
-#!/usr/bin/env bash
+#!/bin/sh
 # Entry point with the reference's name and behaviour: runs the two-stage SocioSeg inference pipeline with
 # examples/infer/rlvr_megatron.yaml, served by the MI355X-native engine.  Works from any directory; extra arguments are
 # passed through.  8 GPUs:
 #   torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/start_rlvr_socioseg_pipeline_infer.py \
 #       --config_path infer --config_name rlvr_megatron
-here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+here="$(cd "$(dirname "$0")" && pwd)"
 exec python "$here/../start_rlvr_socioseg_pipeline_infer.py" --config_path "$(basename "$here")" --config_name rlvr_megatron "$@"
