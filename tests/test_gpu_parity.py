@@ -976,3 +976,29 @@ def test_full_size_batch_variants_agree():
     assert out[5] == out[16] and out[17] == out[32], out
     assert out[1][0] == out[5][0] == out[17][0]
     e.close()
+
+
+def test_full_size_long_context_decode():
+    """Full 3B geometry with a 2100-token prompt (decode attention beyond 2048 keys: scalar softmax path, second V^T sweep):
+    graph == eager, and the decode logits of step k equal -- within the bf16 noise floor -- the all-position logits of the
+    prompt extended by the k generated tokens (GEMV + decode attention vs GEMM + prefill attention)."""
+    from socioreasoner_amd.config import geometry_3b
+    from socioreasoner_amd.engine import Engine
+    geom = geometry_3b()
+    e = Engine(geom, max_patches=256, max_prefill_tokens=2176, max_batch=1, max_ctx=2304, max_new_tokens=8)
+    e.load_synthetic_weights(seed=0)
+    ids = np.random.default_rng(9).integers(0, 150000, 2100).astype(np.int64)
+    pos = np.tile(np.arange(len(ids)), (3, 1))
+    e.prefill([ids], [pos], None)
+    eager, trace = e.decode(8, trace=True, use_graph=False)
+    e.prefill([ids], [pos], None)
+    assert torch.equal(e.decode(8, use_graph=True), eager) and bool(torch.isfinite(trace).all())
+    toks = eager[0].tolist()
+    k = 4
+    idk = np.concatenate([ids, np.asarray(toks[:k], dtype=np.int64)])
+    allp = e.forward_logits([idk], [np.tile(np.arange(len(idk)), (3, 1))], None)
+    for j in (0, k):                      # position 2099 + j predicts token j: compare with the decode-path logits of step j
+        d = (allp[len(ids) - 1 + j] - trace[j, 0]).abs()
+        scale = float(trace[j, 0].abs().max())
+        assert float(d.max()) <= 0.08 * max(scale, 1.0), (j, float(d.max()), scale)
+    e.close()
