@@ -111,35 +111,51 @@ __global__ __launch_bounds__(256) void k_rmsnorm_row(bf16_t* x, const bf16_t* xi
 
 // ----------------------------------------------------------------------------------------------- ViT 2-D RoPE (hf:160-171)
 // float32 math, one rounding.  cos/sin tables [n_rows][hd/2] (the two halves of HF's emb are identical).
+// one thread = 8 rotary pairs: 16-byte loads of x[d..d+7] and x[d+half..], two float4 each of cos / sin (hd/2 % 8 == 0)
 __global__ __launch_bounds__(256) void k_vit_rope(bf16_t* qkv, int n_rows, int n_heads, int hd, const float* cos_t,
                                                   const float* sin_t) {
-    const int row = blockIdx.x;
-    const int half = hd / 2, C = n_heads * hd;
-    bf16_t* base = qkv + (size_t)row * 3 * C;
-    for (int i = threadIdx.x; i < 2 * n_heads * half; i += blockDim.x) {
-        const int sec = i / (n_heads * half), rem = i % (n_heads * half);
-        const int h = rem / half, d = rem % half;
-        bf16_t* p = base + sec * C + h * hd + d;
-        const float x1 = bf2f(p[0]), x2 = bf2f(p[half]);
-        const float c = cos_t[(size_t)row * half + d], s = sin_t[(size_t)row * half + d];
-        p[0] = f2bf(x1 * c + (-x2) * s);
-        p[half] = f2bf(x2 * c + x1 * s);
+    const int half = hd / 2, C = n_heads * hd, nch = half / 8, per_row = 2 * n_heads * nch;
+    const long long task = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (task >= (long long)n_rows * per_row) return;
+    const int row = (int)(task / per_row), rem = (int)(task % per_row);
+    const int sec = rem / (n_heads * nch), h = (rem / nch) % n_heads, c = rem % nch;
+    bf16_t* p = qkv + (size_t)row * 3 * C + sec * C + h * hd + c * 8;
+    const uint4 u1 = *reinterpret_cast<const uint4*>(p), u2 = *reinterpret_cast<const uint4*>(p + half);
+    const float4* cp = reinterpret_cast<const float4*>(cos_t + (size_t)row * half + c * 8);
+    const float4* sp = reinterpret_cast<const float4*>(sin_t + (size_t)row * half + c * 8);
+    const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+    const float x1[8] = {lo16(u1.x), hi16(u1.x), lo16(u1.y), hi16(u1.y), lo16(u1.z), hi16(u1.z), lo16(u1.w), hi16(u1.w)};
+    const float x2[8] = {lo16(u2.x), hi16(u2.x), lo16(u2.y), hi16(u2.y), lo16(u2.z), hi16(u2.z), lo16(u2.w), hi16(u2.w)};
+    const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    float o1[8], o2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o1[e] = x1[e] * cc[e] + (-x2[e]) * ss[e];
+        o2[e] = x2[e] * cc[e] + x1[e] * ss[e];
     }
+    *reinterpret_cast<uint4*>(p) = uint4{pack2(o1[0], o1[1]), pack2(o1[2], o1[3]), pack2(o1[4], o1[5]), pack2(o1[6], o1[7])};
+    *reinterpret_cast<uint4*>(p + half) = uint4{pack2(o2[0], o2[1]), pack2(o2[2], o2[3]), pack2(o2[4], o2[5]), pack2(o2[6], o2[7])};
 }
 
-// V^T for the attention kernel: vt[h][d][row] = qkv[row][2C + h*hd + d]; 64 rows x one head per block via LDS
+// V^T for the attention kernel: vt[h][d][row] = qkv[row][2C + h*hd + d]; 64 rows x one head per block via LDS, 16-byte
+// global loads and stores (hd % 8 == 0)
 __global__ __launch_bounds__(256) void k_vit_vtranspose(const bf16_t* qkv, int n_rows, int n_heads, int hd, bf16_t* vt,
                                                         int vt_stride) {
-    __shared__ bf16_t tile[64][130];
-    const int r0 = blockIdx.x * 64, h = blockIdx.y, C = n_heads * hd;
-    for (int i = threadIdx.x; i < 64 * hd; i += 256) {
-        const int r = i / hd, d = i % hd;
-        tile[r][d] = (r0 + r < n_rows) ? qkv[(size_t)(r0 + r) * 3 * C + 2 * C + h * hd + d] : (bf16_t)0;
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][136];
+    const int r0 = blockIdx.x * 64, h = blockIdx.y, C = n_heads * hd, nv = hd / 8;
+    for (int i = threadIdx.x; i < 64 * nv; i += 256) {
+        const int r = i / nv, v = i % nv;
+        uint4 u = uint4{0, 0, 0, 0};
+        if (r0 + r < n_rows) u = *reinterpret_cast<const uint4*>(qkv + (size_t)(r0 + r) * 3 * C + 2 * C + h * hd + v * 8);
+        *reinterpret_cast<uint4*>(&tile[r][v * 8]) = u;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < hd * 64; i += 256) {
-        const int d = i / 64, r = i % 64;
-        vt[((size_t)h * hd + d) * vt_stride + r0 + r] = tile[r][d];
+    for (int i = threadIdx.x; i < hd * 8; i += 256) {
+        const int d = i / 8, rv = i % 8;                      // 8 consecutive rows -> one 16-byte store
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[rv * 8 + 2 * e][d] | ((uint32_t)tile[rv * 8 + 2 * e + 1][d] << 16);
+        *reinterpret_cast<uint4*>(vt + ((size_t)h * hd + d) * vt_stride + r0 + rv * 8) = uint4{w[0], w[1], w[2], w[3]};
     }
 }
 
@@ -458,7 +474,9 @@ int launch_vit_rope(hipStream_t s, bf16_t* qkv, int n_rows, int n_heads, int hea
                     const float* sin_t, bf16_t* vt, int vt_stride) {
     if (n_rows <= 0) return 0;
     if (head_dim > 128) return -22;
-    hipLaunchKernelGGL(k_vit_rope, dim3(n_rows), dim3(256), 0, s, qkv, n_rows, n_heads, head_dim, cos_t, sin_t);
+    if (head_dim % 16 != 0 || vt_stride % 8 != 0) return -22;
+    const long long tasks = (long long)n_rows * 2 * n_heads * (head_dim / 16);
+    hipLaunchKernelGGL(k_vit_rope, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, qkv, n_rows, n_heads, head_dim, cos_t, sin_t);
     hipLaunchKernelGGL(k_vit_vtranspose, dim3(cdiv(n_rows, 64), n_heads), dim3(256), 0, s, (const bf16_t*)qkv, n_rows, n_heads,
                        head_dim, vt, vt_stride);
     SR_CHECK_LAUNCH();
