@@ -233,6 +233,32 @@ def compute_giou(pred, gt) -> float:
     return 1.0 if u == 0 else i / u
 
 
+INT_STANDIN = -(1 << 30)     # stands in for the INT_MIN an x86 double->int cast yields for NaN / out-of-range values
+
+
+def pil_box(bb):
+    """What PIL's ImageDraw.rectangle([(b0, b1), (b2, b3)]) does with one model-generated box before it draws
+    (PIL 12.2 _imaging.c _draw_rectangle + path.c PyPath_Flatten; probed by tools/make_golden.py):
+      * every coordinate must be a Python int / float (bool is an int); anything else -> ValueError -> the reference
+        skips the box (rlvr_socioseg_vlm_pipeline_infer.py:427-433);
+      * x1 < x0 or y1 < y0 -- compared as DOUBLES, before any truncation -> ValueError -> skipped;
+      * then each coordinate is cast (int): truncation toward zero.
+    Returns 4 ints or None (skipped).  NaN / |v| >= 2^31 become INT_MIN in the x86 cast; -2^30 draws the same pixels."""
+    if not isinstance(bb, (list, tuple)) or len(bb) != 4:
+        return None
+    f = []
+    for v in bb:
+        if not isinstance(v, (bool, int, float)):
+            return None
+        try:
+            f.append(float(v))
+        except OverflowError:
+            return None
+    if f[2] < f[0] or f[3] < f[1]:
+        return None
+    return [int(v) if (v == v and abs(v) < 2147483648.0) else INT_STANDIN for v in f]
+
+
 def render_overlay(img_rgb: np.ndarray, mask: np.ndarray, bboxes, alpha=102, color=(255, 0, 0)):
     """rlvr_socioseg_vlm_pipeline_infer.py:383-452 for one image, integer-exact restatement of the PIL calls:
     RGB->RGBA(A=255), ImageDraw.rectangle(outline=blue, width=2) per bbox, then
@@ -241,12 +267,10 @@ def render_overlay(img_rgb: np.ndarray, mask: np.ndarray, bboxes, alpha=102, col
     h, w = img_rgb.shape[:2]
     out = img_rgb.astype(np.int64).copy()
     for bb in bboxes:
-        if len(bb) != 4:
-            continue
-        x0, y0, x1, y1 = (int(v) for v in bb)  # PIL truncates float coordinates
-        if x1 < x0 or y1 < y0:
-            continue  # PIL raises ValueError -> the reference swallows it (:431-432)
-        draw_rect_outline(out, x0, y0, x1, y1, 2, (0, 0, 255))
+        ib = pil_box(bb)
+        if ib is None:
+            continue  # PIL raises -> the reference swallows it (:431-432)
+        draw_rect_outline(out, ib[0], ib[1], ib[2], ib[3], 2, (0, 0, 255))
     if mask is None:
         return out.astype(np.uint8)
     m = resize_nearest((mask > 0).astype(np.uint8), h, w) > 0
@@ -260,19 +284,68 @@ def render_overlay(img_rgb: np.ndarray, mask: np.ndarray, bboxes, alpha=102, col
 
 
 def draw_rect_outline(img, x0, y0, x1, y1, width, color):
-    """PIL ImageDraw.rectangle(outline, width): inclusive coordinates, border grows inwards.
-    Exact for boxes at least 3 px in both dimensions (verified against PIL 12.2); thinner boxes are clipped to
-    the box itself here, whereas PIL spills a pixel outside -- documented deviation."""
+    """PIL ImageDraw.rectangle(outline, width) on integer coordinates (libImaging Draw.c, outline branch):
+    per i < width: hline(x0, y0+i, x1), hline(x0, y1-i, x1), vertical lines at x1-i and x0+i from y0+width towards
+    y1-width+1 (|dy| points from the start, end point excluded) -- so boxes thinner than 3 px spill outside themselves
+    exactly as PIL's do.  Clipped to the image."""
     h, w = img.shape[:2]
 
-    def fill(xa, ya, xb, yb):
-        xa, ya = max(xa, 0, x0), max(ya, 0, y0)
-        xb, yb = min(xb, w - 1, x1), min(yb, h - 1, y1)
-        if xb >= xa and yb >= ya:
-            img[ya: yb + 1, xa: xb + 1] = color
+    def span(a, b, n):
+        a, b = (a, b) if a <= b else (b, a)
+        return max(a, 0), min(b, n - 1)
 
+    def hline(xa, y, xb):
+        if 0 <= y < h:
+            lo, hi = span(xa, xb, w)
+            if hi >= lo:
+                img[y, lo: hi + 1] = color
+
+    def vline(x, ya, yb):
+        # libImaging's vertical line loop draws |yb - ya| points starting at ya and stepping toward yb: the end point
+        # itself is not drawn
+        if ya == yb or not 0 <= x < w:
+            return
+        lo, hi = (ya, yb - 1) if yb > ya else (yb + 1, ya)
+        lo, hi = max(lo, 0), min(hi, h - 1)
+        if hi >= lo:
+            img[lo: hi + 1, x] = color
+
+    if y0 > y1:
+        y0, y1 = y1, y0
     for i in range(width):
-        fill(x0, y0 + i, x1, y0 + i)
-        fill(x0, y1 - i, x1, y1 - i)
-        fill(x0 + i, y0, x0 + i, y1)
-        fill(x1 - i, y0, x1 - i, y1)
+        hline(x0, y0 + i, x1)
+        hline(x0, y1 - i, x1)
+        vline(x1 - i, y0 + width, y1 - width + 1)
+        vline(x0 + i, y0 + width, y1 - width + 1)
+
+
+def render_image(bboxes_json: str, images, mask):
+    """rlvr_socioseg_vlm_pipeline_infer.py:383-452 as a whole, on uint8 HWC arrays: the bbox list parsed the way the
+    reference parses it (a non-list JSON value -> no boxes; items must be dicts holding a 4-element ``bbox_2d``; a
+    ``bbox_2d`` without len() raises TypeError inside the same try -> ALL boxes dropped), ONE overlay at the first image's
+    size (mask nearest-resized there), outlines drawn before compositing; an image of another size gets the overlay
+    resampled with PIL's LANCZOS (:436-438) -- that resample is PIL's own (this oracle calls it like the reference does)."""
+    import json
+    try:
+        data = json.loads(bboxes_json)
+        boxes = []
+        if isinstance(data, list):
+            for it in data:
+                if isinstance(it, dict) and "bbox_2d" in it and len(it["bbox_2d"]) == 4:
+                    boxes.append(it["bbox_2d"])
+    except (json.JSONDecodeError, TypeError):
+        boxes = []
+    out = []
+    h0, w0 = images[0].shape[:2] if images else (0, 0)
+    for img in images:
+        if img.shape[:2] == (h0, w0) or mask is None:
+            out.append(render_overlay(img, mask, boxes))
+            continue
+        from PIL import Image
+        m0 = resize_nearest((np.asarray(mask) > 0).astype(np.uint8), h0, w0) > 0
+        ov = np.zeros((h0, w0, 4), dtype=np.uint8)
+        ov[m0] = (255, 0, 0, 102)
+        base = Image.fromarray(render_overlay(img, None, boxes)).convert("RGBA")
+        over = Image.fromarray(ov, "RGBA").resize(base.size, Image.Resampling.LANCZOS)
+        out.append(np.array(Image.alpha_composite(base, over).convert("RGB")))
+    return out

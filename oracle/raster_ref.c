@@ -41,34 +41,46 @@ void ref_iou_counts(const uint8_t *p, const uint8_t *g, size_t n, int64_t out[2]
     out[1] = uni;
 }
 
-/* clipped to the image and to the box itself (PIL spills outside boxes thinner than 3 px: documented deviation) */
-static void fill(uint8_t *img, int h, int w, int bx0, int by0, int bx1, int by1, int xa, int ya, int xb, int yb) {
-    if (xa < bx0) xa = bx0;
-    if (ya < by0) ya = by0;
-    if (xb > bx1) xb = bx1;
-    if (yb > by1) yb = by1;
+/* PIL 12.2 ImageDraw.rectangle(outline, width=2) on integer coordinates (libImaging Draw.c ImagingDrawRectangle, outline
+   branch, probed against PIL itself by tools/make_golden.py -> tests/golden/render_boxes.json):
+     for i in 0..width-1:  hline(x0, y0+i, x1); hline(x0, y1-i, x1); line(x1-i, y0+width, x1-i, y1-width+1);
+                           line(x0+i, y0+width, x0+i, y1-width+1)
+   hline covers [min(xa,xb), max(xa,xb)] of one row; the vertical line loop draws |dy| points from its start towards its
+   end (end point excluded) -- so a box thinner than 3 px spills outside itself exactly as PIL does.  Clipped to the image. */
+static void put(uint8_t *img, int h, int w, int x, int y) {
+    if (x < 0 || y < 0 || x >= w || y >= h) return;
+    uint8_t *px = img + ((size_t)y * w + x) * 3;
+    px[0] = 0; px[1] = 0; px[2] = 255;
+}
+static void hline(uint8_t *img, int h, int w, int xa, int y, int xb) {
+    if (y < 0 || y >= h) return;
+    if (xa > xb) { int t = xa; xa = xb; xb = t; }
     if (xa < 0) xa = 0;
-    if (ya < 0) ya = 0;
     if (xb > w - 1) xb = w - 1;
-    if (yb > h - 1) yb = h - 1;
-    for (int y = ya; y <= yb; ++y)
-        for (int x = xa; x <= xb; ++x) {
-            uint8_t *px = img + ((size_t)y * w + x) * 3;
-            px[0] = 0; px[1] = 0; px[2] = 255;
-        }
+    for (int x = xa; x <= xb; ++x) put(img, h, w, x, y);
+}
+static void vline(uint8_t *img, int h, int w, int x, int ya, int yb) {
+    /* |yb - ya| points from ya towards yb: the end point is not drawn */
+    if (x < 0 || x >= w || ya == yb) return;
+    int lo = yb > ya ? ya : yb + 1, hi = yb > ya ? yb - 1 : ya;
+    if (lo < 0) lo = 0;
+    if (hi > h - 1) hi = h - 1;
+    for (int y = lo; y <= hi; ++y) put(img, h, w, x, y);
 }
 
-/* img: RGB u8 [h,w,3] in place; mask u8 [mh,mw] (nearest-resized to h,w; may be NULL); boxes int32 [nb,4] */
+/* img: RGB u8 [h,w,3] in place; mask u8 [mh,mw] (nearest-resized to h,w; may be NULL); boxes int32 [nb,4]: already
+   validated and truncated the way PIL's _draw_rectangle does it (oracle/host_ref.py pil_box) */
 void ref_render_overlay(uint8_t *img, int h, int w, const uint8_t *mask, int mh, int mw,
                         const int32_t *boxes, int nb) {
+    const int width = 2;
     for (int b = 0; b < nb; ++b) {
         int x0 = boxes[4 * b], y0 = boxes[4 * b + 1], x1 = boxes[4 * b + 2], y1 = boxes[4 * b + 3];
-        if (x1 < x0 || y1 < y0) continue;
-        for (int i = 0; i < 2; ++i) {
-            fill(img, h, w, x0, y0, x1, y1, x0, y0 + i, x1, y0 + i);
-            fill(img, h, w, x0, y0, x1, y1, x0, y1 - i, x1, y1 - i);
-            fill(img, h, w, x0, y0, x1, y1, x0 + i, y0, x0 + i, y1);
-            fill(img, h, w, x0, y0, x1, y1, x1 - i, y0, x1 - i, y1);
+        if (y0 > y1) { int t = y0; y0 = y1; y1 = t; }
+        for (int i = 0; i < width; ++i) {
+            hline(img, h, w, x0, y0 + i, x1);
+            hline(img, h, w, x0, y1 - i, x1);
+            vline(img, h, w, x1 - i, y0 + width, y1 - width + 1);
+            vline(img, h, w, x0 + i, y0 + width, y1 - width + 1);
         }
     }
     if (!mask) return;

@@ -49,7 +49,9 @@ def iou_counts(pred, gt):
 
 
 def render_overlay(img_rgb, mask, boxes):
+    from .host_ref import pil_box
     img = np.ascontiguousarray(img_rgb, dtype=np.uint8).copy()
+    boxes = [ib for ib in (pil_box(b if not isinstance(b, np.ndarray) else b.tolist()) for b in boxes) if ib is not None]
     boxes = np.ascontiguousarray(np.asarray(boxes, dtype=np.int32).reshape(-1, 4))
     if mask is None:
         lib().ref_render_overlay(_p(img), img.shape[0], img.shape[1], None, 0, 0, _p(boxes), len(boxes))

@@ -393,14 +393,14 @@ class Mi355xStrategy(InferenceStrategy):
                 sampled = [p for p in sampled if p.meta_info.get("request_id") != rid]
                 if batcher is not None:      # queued requests can be dropped; a running row finishes and is discarded
                     batcher.pending = type(batcher.pending)(r for r in batcher.pending if r.tag.meta_info.get("request_id") != rid)
-                    for r in batcher.active.values():
+                    for r in batcher.active.values():      # (an ABORT may name a row that was already aborted: keep the tag)
                         if r.tag.meta_info.get("request_id") == rid:
-                            r.tag = None
+                            r.aborted = True
             elif name == "STOP":
                 stop = True
             if batcher is not None and not batcher.idle() and (self.command_queue.empty() or len(batcher.active) > 0):
                 def done(r, toks):
-                    if r.tag is None:
+                    if r.aborted:
                         return
                     res = DataProto(meta_info=dict(r.tag.meta_info))
                     res.meta_info["output_token_ids"] = [[int(t) for t in toks]]

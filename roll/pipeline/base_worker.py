@@ -75,6 +75,12 @@ class ActorWorker(Worker):
 
         def loop():
             try:
+                # the HIP current device is per THREAD and defaults to 0: without this, every launch / copy / graph capture of
+                # a worker with local_rank > 0 would target device 0 against a workspace that lives on device N
+                eng = getattr(self.strategy, "engine", None)
+                if eng is not None and getattr(eng, "device", None) is not None:
+                    import torch
+                    torch.cuda.set_device(eng.device)
                 self.strategy.start_server(data=data, request_complete_callback=cb)
             except BaseException as e:  # noqa: BLE001  (surfaced by ALIVE_CHECK instead of dying silently)
                 self.server_error = e

@@ -99,6 +99,7 @@ def render_image(bboxes_json: str, images: List[Any], mask: Union[np.ndarray, An
             mm = np.asarray(mask.convert("L")) if hasattr(mask, "convert") else np.asarray(mask)
             m = torch.from_numpy(np.ascontiguousarray((mm > 0).astype(np.uint8))).cuda()
     out = []
+    first_hw = None
     for im in images:
         is_pil = hasattr(im, "convert")
         if isinstance(im, torch.Tensor):
@@ -106,7 +107,13 @@ def render_image(bboxes_json: str, images: List[Any], mask: Union[np.ndarray, An
         else:
             arr = np.asarray(im.convert("RGB")) if is_pil else np.asarray(im)
             t = torch.from_numpy(np.array(arr, dtype=np.uint8, order="C")).cuda()
-        raster.render_overlay_(t, m, boxes)
+        hw = (int(t.shape[0]), int(t.shape[1]))
+        if first_hw is None:
+            first_hw = hw
+        if m is None or hw == first_hw:
+            raster.render_overlay_(t, m, boxes)
+        else:
+            t = _render_other_size(t, m, boxes, first_hw)
         if keep_on_device or isinstance(im, torch.Tensor):
             out.append(t)
             continue
@@ -116,6 +123,21 @@ def render_image(bboxes_json: str, images: List[Any], mask: Union[np.ndarray, An
             res = Image.fromarray(res)
         out.append(res)
     return out
+
+
+def _render_other_size(t: torch.Tensor, m: torch.Tensor, boxes, first_hw) -> torch.Tensor:
+    """The reference builds ONE overlay at the FIRST image's size and, for an image of another size, resamples that RGBA
+    overlay with LANCZOS before compositing (reference :436-438).  Rare (map and satellite tiles normally share a size), so
+    this branch keeps the box outlines on the device and lets PIL -- the library the reference itself calls -- do the
+    resample + composite on the host: identical pixels by construction."""
+    from PIL import Image
+    raster.render_overlay_(t, None, boxes)
+    m0 = raster.resize_nearest(m, first_hw[0], first_hw[1]).cpu().numpy() > 0
+    ov = np.zeros((first_hw[0], first_hw[1], 4), dtype=np.uint8)
+    ov[m0] = (255, 0, 0, int(255 * 0.4))
+    base = Image.fromarray(t.cpu().numpy()).convert("RGBA")
+    over = Image.fromarray(ov, "RGBA").resize(base.size, Image.Resampling.LANCZOS)
+    return torch.from_numpy(np.array(Image.alpha_composite(base, over).convert("RGB"), dtype=np.uint8, order="C")).cuda()
 
 
 def process_image(images: List[Any], processor) -> List[Any]:
@@ -385,7 +407,9 @@ class SocioSegInferPipeline(BasePipeline):
             global_step += 1
         local = torch.tensor(all_giou, dtype=torch.float64).reshape(-1, 1)
         if self.world > 1:
-            local = dp.all_gather_rows(local.cuda() if torch.cuda.is_available() else local, self.n_samples * n_ret).cpu()
+            # samples are array_split over the ranks and every sample contributes n_ret rows
+            local = dp.all_gather_rows(local.cuda() if torch.cuda.is_available() else local, self.n_samples * n_ret,
+                                       sizes=[s_ * n_ret for s_ in dp.split_sizes(self.n_samples, self.world)]).cpu()
         giou_acc = float(local.mean()) if local.numel() else 0.0
         if self.rank == 0:
             print(f"giou_acc: {giou_acc}")

@@ -117,6 +117,7 @@ struct sr_engine {
     bool copy_pending = false;
     // ---- decode graph cache
     hipGraphExec_t graph = nullptr;
+    int device = 0;                     // the GPU the workspace lives on: every C-ABI entry makes it current (per-thread HIP state)
     hipStream_t cap_stream = nullptr;   // used only to CAPTURE the decode step (the caller's stream may be the null stream)
     int graph_B = -1, graph_neos = -1, graph_pad = 0;
     hipGraphExec_t step_graph[2] = {nullptr, nullptr};   // sr_decode_step: [0] engine-greedy token, [1] caller-chosen token
@@ -138,6 +139,10 @@ struct sr_engine {
 };
 
 namespace {
+
+// HIP's current device is per-thread state (default 0): make the engine's device current at every entry, so that a
+// caller on a fresh thread (the request-level server loop) launches, copies and captures on the right GPU
+inline void enter(const sr_engine* e) { if (e) (void)hipSetDevice(e->device); }
 
 int fail(sr_engine* e, int code, const char* fmt, ...) {
     char buf[512];
@@ -569,6 +574,14 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
     sr_engine* e = new sr_engine();
     e->c = *cfg;
     snprintf(e->err, sizeof e->err, "ok");
+    {   // the engine belongs to the device that owns the workspace, whatever the calling thread's current device is
+        hipPointerAttribute_t pa{};
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        e->device = (hipPointerGetAttributes(&pa, workspace) == hipSuccess) ? pa.device : cur;
+        (void)hipGetLastError();
+        (void)hipSetDevice(e->device);
+    }
     e->ar.base = static_cast<char*>(workspace);
     e->ar.cap = workspace_bytes;
     carve(e);
@@ -615,6 +628,7 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
 }
 
 int sr_engine_destroy(sr_engine* e) {
+    enter(e);
     if (!e) return 0;
     if (e->graph) (void)hipGraphExecDestroy(e->graph);
     for (auto g : e->step_graph) if (g) (void)hipGraphExecDestroy(g);
@@ -645,6 +659,7 @@ int sr_synth_fill(void* dev_out_bf16, int64_t n, const char* hf_name, uint32_t s
 }
 
 int sr_load_weight(sr_engine* e, const char* hf_name, const void* p, int dtype, const int64_t* shape, int ndim, void* stream) {
+    enter(e);
     if (!e || !hf_name || !p || !shape || ndim < 1) return fail(e, -22, "sr_load_weight: null argument");
     if (dtype != SR_DTYPE_BF16 && dtype != SR_DTYPE_F32) return fail(e, -22, "sr_load_weight: dtype");
     hipStream_t s = (hipStream_t)stream;
@@ -716,6 +731,7 @@ int sr_load_weight(sr_engine* e, const char* hf_name, const void* p, int dtype, 
 int sr_pixel_ld(const sr_engine* e) { return e->v_pd_pad; }
 
 int sr_patchify_u8(sr_engine* e, const uint8_t* img, int h, int w, void* out, void* stream) {
+    enter(e);
     const sr_config& c = e->c;
     const int f = c.v_patch * c.v_merge;
     if (c.v_in_ch != 3 || h % f || w % f || h <= 0 || w <= 0) return fail(e, -22, "sr_patchify_u8: h,w must be multiples of %d", f);
@@ -724,6 +740,7 @@ int sr_patchify_u8(sr_engine* e, const uint8_t* img, int h, int w, void* out, vo
 }
 
 int sr_vit_forward(sr_engine* e, const void* pixels, int pixels_dtype, const int64_t* grid, int n_img, void* out, void* stream) {
+    enter(e);
     if (!e || !pixels || !grid || !out || n_img < 1) return fail(e, -22, "sr_vit_forward: null argument");
     char miss[160];
     if (sr_weights_missing(e, miss, sizeof miss)) return fail(e, -61, "weights missing, e.g. '%s'", miss);
@@ -764,6 +781,7 @@ int sr_vit_forward(sr_engine* e, const void* pixels, int pixels_dtype, const int
 }
 
 int sr_finalize_weights(sr_engine* e, void* stream) {
+    enter(e);
     if (!e) return fail(e, -22, "sr_finalize_weights: null engine");
     if (e->finalized) return 0;
     {
@@ -797,6 +815,7 @@ int sr_finalize_weights(sr_engine* e, void* stream) {
 static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_t* seq_lens, const int32_t* slots, int B,
                         const void* image_embeds, int n_image_rows, float* logits_out, void* stream, const int32_t* limits,
                         float* all_logits_out = nullptr) {
+    enter(e);
     if (!e || !ids || !pos3 || !seq_lens || !slots) return fail(e, -22, "sr_prefill: null argument");
     char miss[160];
     if (sr_weights_missing(e, miss, sizeof miss)) return fail(e, -61, "weights missing, e.g. '%s'", miss);
@@ -959,6 +978,7 @@ int sr_forward_logits(sr_engine* e, const int64_t* ids, const int64_t* pos3, con
 // ---- continuous batching: batch rows with independent lifecycles (row index = KV slot); a decode step always runs all
 // max_batch rows, rows that are free or finished are masked by their `finished` flag
 int sr_rows_begin(sr_engine* e, void* stream) {
+    enter(e);
     if (!e) return fail(e, -22, "sr_rows_begin: null engine");
     hipStream_t s = (hipStream_t)stream;
     std::vector<int> st(5 * 32, 0);
@@ -1021,6 +1041,7 @@ static int ensure_decode_graph(sr_engine* e, int B, int n_eos, int pad_id) {
 
 int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const int32_t* host_eos, int n_eos, int32_t pad_id,
               int32_t* tokens_out, float* logits_trace, const int32_t* forced, int use_graph, void* stream, int* steps_done) {
+    enter(e);
     if (!e || !tokens_out) return fail(e, -22, "sr_decode: null argument");
     const sr_config& c = e->c;
     if (B < 1 || B > c.max_batch || max_new < 1 || max_new > c.max_new_tokens || n_eos < 0 || n_eos > 32)
@@ -1086,6 +1107,7 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
 // the token of every step is drawn by k_sample from the logits the LM head left in HBM and fed back through k_step.
 int sr_decode_sample(sr_engine* e, int B, int max_new, const int32_t* host_eos, int n_eos, int32_t pad_id, float temperature, int top_k,
                      float top_p, float rep_penalty, uint32_t seed, int32_t* tokens_out, int use_graph, void* stream, int* steps_done) {
+    enter(e);
     if (!e || !tokens_out) return fail(e, -22, "sr_decode_sample: null argument");
     const sr_config& c = e->c;
     if (e->rows_mode) return fail(e, -22, "sr_decode_sample: the engine is in continuous-batching mode");
@@ -1158,6 +1180,7 @@ int sr_decode_sample(sr_engine* e, int B, int max_new, const int32_t* host_eos, 
 }
 
 int sr_rows_step(sr_engine* e, int n_steps, const int32_t* host_eos, int n_eos, int32_t pad_id, void* stream) {
+    enter(e);
     if (!e || !e->rows_mode) return fail(e, -22, "sr_rows_step: call sr_rows_begin first");
     if (n_steps < 1 || n_eos < 0 || n_eos > 32) return fail(e, -22, "sr_rows_step: n_steps=%d n_eos=%d out of range", n_steps, n_eos);
     hipStream_t s = (hipStream_t)stream;
@@ -1194,6 +1217,7 @@ int sr_rows_step(sr_engine* e, int n_steps, const int32_t* host_eos, int n_eos, 
 }
 
 int sr_rows_poll(sr_engine* e, int32_t* host_finished, int32_t* host_steps, void* stream) {
+    enter(e);
     if (!e || !e->rows_mode || !host_finished || !host_steps) return fail(e, -22, "sr_rows_poll: bad argument / not in rows mode");
     hipStream_t s = (hipStream_t)stream;
     SR_TRY((int)hipMemcpyAsync(host_finished, e->d_finished, e->c.max_batch * 4, hipMemcpyDeviceToHost, s));
@@ -1203,6 +1227,7 @@ int sr_rows_poll(sr_engine* e, int32_t* host_finished, int32_t* host_steps, void
 }
 
 int sr_rows_read(sr_engine* e, int row, int32_t* dev_tokens_out, int n, void* stream) {
+    enter(e);
     if (!e || !e->rows_mode || row < 0 || row >= e->c.max_batch || n < 0 || n > e->c.max_new_tokens)
         return fail(e, -22, "sr_rows_read: bad argument / not in rows mode");
     SR_TRY((int)hipMemcpyAsync(dev_tokens_out, e->d_tokens + (size_t)row * e->c.max_new_tokens, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -1210,6 +1235,7 @@ int sr_rows_read(sr_engine* e, int row, int32_t* dev_tokens_out, int n, void* st
 }
 
 int sr_decode_step(sr_engine* e, const int64_t* dev_last_ids, int B, float* dev_logits_out, int64_t* dev_next_ids, void* stream) {
+    enter(e);
     if (!e) return fail(e, -22, "sr_decode_step: null engine");
     const sr_config& c = e->c;
     if (e->rows_mode) return fail(e, -22, "sr_decode_step: the engine is in continuous-batching mode");

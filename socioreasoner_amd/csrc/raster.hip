@@ -66,11 +66,17 @@ __global__ __launch_bounds__(256) void k_render(uint8_t* img, int h, int w, cons
     uint8_t* px = img + ((size_t)y * w + x) * 3;
     int c0 = px[0], c1 = px[1], c2 = px[2];
     for (int b = 0; b < nb; ++b) {
-        const int x0 = boxes[4 * b], y0 = boxes[4 * b + 1], x1 = boxes[4 * b + 2], y1 = boxes[4 * b + 3];
-        if (x1 < x0 || y1 < y0) continue;
-        if (x < x0 || x > x1 || y < y0 || y > y1) continue;
-        // PIL width-2 outline: rows y0, y0+1, y1-1, y1 and columns x0, x0+1, x1-1, x1 (inclusive box)
-        if (y <= y0 + 1 || y >= y1 - 1 || x <= x0 + 1 || x >= x1 - 1) { c0 = 0; c1 = 0; c2 = 255; }
+        // PIL ImageDraw.rectangle(outline, width = 2) on already validated / truncated coordinates (raster.py pil_rect):
+        // rows y0, y0+1, y1-1, y1 over [x0, x1]; columns x0, x0+1, x1-1, x1 over the |dy| points that start at y0+2 and step
+        // towards y1-1 (end excluded) -- which is what makes boxes thinner than 3 px spill outside themselves in PIL
+        const int x0 = boxes[4 * b], x1 = boxes[4 * b + 2];
+        const int y0 = min(boxes[4 * b + 1], boxes[4 * b + 3]), y1 = max(boxes[4 * b + 1], boxes[4 * b + 3]);
+        bool hit = x >= min(x0, x1) && x <= max(x0, x1) && (y == y0 || y == y0 + 1 || y == y1 || y == y1 - 1);
+        if (x == x0 || x == x0 + 1 || x == x1 || x == x1 - 1) {
+            const int ya = y0 + 2, yb = y1 - 1;
+            hit |= (yb > ya) ? (y >= ya && y < yb) : (y > yb && y <= ya && yb != ya);
+        }
+        if (hit) { c0 = 0; c1 = 0; c2 = 255; }
     }
     if (mask) {
         const double fy = (double)mh / h, fx = (double)mw / w;

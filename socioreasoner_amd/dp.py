@@ -26,38 +26,101 @@ def shard_range(n: int, rank: int, world: int):
 
 
 def init_distributed(backend: str | None = None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).  Returns (rank, world, local_rank).
+
+    One process per GPU and RCCL (torch backend "nccl") is THE multi-GPU path.  gloo is never chosen silently on a GPU
+    box: it has to be asked for (argument or SR_DIST_BACKEND=gloo -- CPU tests, or a development box with fewer GPUs than
+    ranks, where the ranks share devices and exchange through host memory).  SR_FORCE_DIST=1 opens the process group even
+    for a single rank, so that the RCCL code path can be exercised on a one-GPU box."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("SR_FORCE_DIST", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
+        backend = backend or os.environ.get("SR_DIST_BACKEND")
+        have_gpu = torch.cuda.is_available()
         if backend is None:
-            backend = os.environ.get("SR_DIST_BACKEND") or \
-                ("nccl" if torch.cuda.is_available() and torch.cuda.device_count() >= world else "gloo")
+            if not have_gpu:
+                backend = "gloo"
+            elif torch.cuda.device_count() >= world:
+                backend = "nccl"
+            else:
+                raise RuntimeError(f"{world} ranks but {torch.cuda.device_count()} visible GPU(s): one process per GPU over RCCL is the "
+                                   f"supported layout; set SR_DIST_BACKEND=gloo to share devices on a development box")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
+            if torch.cuda.device_count() < world:
+                raise RuntimeError(f"backend nccl (RCCL) needs one GPU per rank: {world} ranks, {torch.cuda.device_count()} GPU(s)")
             torch.cuda.set_device(local)
-        elif torch.cuda.is_available():      # more ranks than GPUs (development box): share the devices, exchange over gloo
-            local = local % torch.cuda.device_count()
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        else:
+            if have_gpu:      # more ranks than GPUs: share the devices, exchange over gloo
+                local = local % torch.cuda.device_count()
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
-def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
-    """Concatenates the per-rank row blocks (array_split sizes) in rank order; every rank gets the full tensor."""
+_gather_bufs: dict = {}
+
+
+def _gather_equal(pad: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """all-gather of equally sized blocks -> [world, *pad.shape].  RCCL: ONE all_gather_into_tensor into a pre-allocated,
+    reused device buffer (no list of views, no per-call allocation, no host staging); gloo: host tensors."""
+    if dist.get_backend(group) == "gloo":
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
+        return torch.stack(bufs, dim=0)
+    key = (tuple(pad.shape), pad.dtype, pad.device, world, id(group))
+    out = _gather_bufs.get(key)
+    if out is None:
+        out = _gather_bufs[key] = torch.empty((world,) + tuple(pad.shape), dtype=pad.dtype, device=pad.device)
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    return out
+
+
+def exchange_info(group=None) -> dict:
+    """What the data-path exchange actually ran on -- goes into the bench line so that a scaling record can be checked
+    against "RCCL saw N ranks" (and, with NCCL_DEBUG=INFO set by the launcher, which transports its channels use)."""
+    if not dist.is_initialized():
+        return {"backend": "none (single process)", "nranks": 1}
+    info = {"backend": dist.get_backend(group), "nranks": dist.get_world_size(group)}
+    if info["backend"] == "nccl":
+        try:
+            v = torch.cuda.nccl.version()
+            info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+        except Exception:  # noqa: BLE001
+            pass
+        info["collective"] = "all_gather_into_tensor (pre-allocated device buffer)"
+        path = os.environ.get("SR_RCCL_LOG")
+        if path and os.path.exists(path):
+            txt = open(path, errors="replace").read()
+            info["log_nranks"] = sorted({int(t.split()[0]) for t in txt.split("nranks ")[1:] if t.split() and t.split()[0].isdigit()})
+            info["channels_via_p2p"] = txt.count(" via P2P/")
+            info["channels_via_shm"] = txt.count(" via SHM/")
+            info["channels_via_net"] = txt.count(" via NET/")
+    return info
+
+
+def all_gather_rows(local: torch.Tensor, n_total: int, group=None, sizes=None) -> torch.Tensor:
+    """Concatenates the per-rank row blocks in rank order; every rank gets the full tensor.  Per-rank row counts are the
+    array_split sizes of ``n_total`` unless ``sizes`` gives them explicitly (e.g. n_ret rows per sample: the SAMPLES are
+    array_split over ranks, so rank r holds split_sizes(n_samples)[r] * n_ret rows, not split_sizes(n_samples * n_ret)[r])."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
-    sizes = split_sizes(n_total, world)
+    sizes = split_sizes(n_total, world) if sizes is None else [int(v) for v in sizes]
+    if len(sizes) != world or sum(sizes) != n_total or local.shape[0] != sizes[dist.get_rank(group)]:
+        raise ValueError(f"all_gather_rows: rank {dist.get_rank(group)} holds {local.shape[0]} rows, per-rank sizes {sizes}, total {n_total}")
     mx = max(sizes)
     dev = local.device
     xdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev     # gloo exchanges host tensors
+    if all(sz == mx for sz in sizes):
+        return _gather_equal(local.to(xdev).contiguous(), world, group).reshape((n_total,) + tuple(local.shape[1:])).to(dev)
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=xdev)
     pad[: local.shape[0]] = local.to(xdev)
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0).to(dev)
+    full = _gather_equal(pad, world, group)
+    return torch.cat([full[r, :sz] for r, sz in enumerate(sizes)], dim=0).to(dev)
 
 
 def decode_with_logits_gather(step_fn, first_logits: torch.Tensor, n_new: int, n_total: int, group=None):

@@ -46,10 +46,34 @@ def compute_giou(pred: torch.Tensor, gt: torch.Tensor) -> float:
     return 1.0 if u == 0 else i / u
 
 
+def pil_rect(box):
+    """One model-generated ``bbox_2d`` -> the 4 ints PIL's ImageDraw.rectangle([(b0, b1), (b2, b3)]) would draw, or None when
+    PIL would raise (the reference then skips the box, rlvr_socioseg_vlm_pipeline_infer.py:427-433): coordinates must be
+    plain numbers, x1 >= x0 and y1 >= y0 are checked on the float values, then each value is truncated toward zero
+    ((int) cast in PIL's _draw_rectangle).  Non-finite / beyond-int32 values map to -2^30 (PIL's cast yields INT_MIN; both
+    lie off every image and draw the same pixels)."""
+    try:
+        if len(box) != 4:
+            return None
+        vals = []
+        for v in box:
+            if isinstance(v, (bool, int, float)):
+                vals.append(float(v))
+            else:
+                return None
+    except (TypeError, OverflowError):
+        return None
+    if vals[2] < vals[0] or vals[3] < vals[1]:
+        return None
+    return [int(v) if (v == v and -2147483648.0 < v < 2147483648.0) else -(1 << 30) for v in vals]
+
+
 def render_overlay_(img_rgb: torch.Tensor, mask: torch.Tensor | None, boxes) -> torch.Tensor:
-    """In place on a uint8 [H,W,3] CUDA image: 2-px blue outlines for ``boxes`` then the 40 % red overlay where mask>0."""
+    """In place on a uint8 [H,W,3] CUDA image: PIL's width-2 blue outline for every drawable box of ``boxes`` (malformed
+    boxes are skipped like the reference's try/except does), then the 40 % red overlay where mask>0."""
     assert img_rgb.dtype == torch.uint8 and img_rgb.is_cuda and img_rgb.is_contiguous()
-    bx = torch.as_tensor([[int(v) for v in b] for b in boxes if len(b) == 4], dtype=torch.int32).reshape(-1, 4).to(img_rgb.device)
+    rects = [r for r in (pil_rect(b) for b in boxes) if r is not None]
+    bx = torch.as_tensor(rects, dtype=torch.int32).reshape(-1, 4).to(img_rgb.device)
     h, w = img_rgb.shape[:2]
     if mask is not None:
         mask = mask.contiguous()

@@ -24,6 +24,7 @@ class Request:
     images: list = field(default_factory=list)     # uint8 HWC device tensors
     grids: list = field(default_factory=list)      # (t, h, w) per image
     tag: object = None
+    aborted: bool = False                 # set by the serving loop: the row runs to its end, its result is discarded
 
 
 class ContinuousBatcher:

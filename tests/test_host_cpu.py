@@ -104,6 +104,21 @@ local = torch.arange(a, b, dtype=torch.int64).unsqueeze(1) * 10 + torch.arange(3
 full = dp.all_gather_rows(local, n)
 want = torch.arange(n).unsqueeze(1) * 10 + torch.arange(3)
 assert full.shape == (n, 3) and (full == want).all(), (rank, full)
+# n_ret rows per sample with n_samples % world != 0: rank 0 holds 3 * 2 rows, rank 1 holds 2 * 2 (not 5 / 5)
+ns, nr = 5, 2
+sa, sb = dp.shard_range(ns, rank, world)
+loc = torch.arange(sa, sb, dtype=torch.int64).repeat_interleave(nr).unsqueeze(1)
+full2 = dp.all_gather_rows(loc, ns * nr, sizes=[s * nr for s in dp.split_sizes(ns, world)])
+assert full2[:, 0].tolist() == [i for i in range(ns) for _ in range(nr)], (rank, full2)
+try:
+    dp.all_gather_rows(loc, ns * nr)
+    raise SystemExit("row-count mismatch not detected")
+except ValueError:
+    pass
+# equal blocks take the single pre-allocated-buffer path
+eq = dp.all_gather_rows(torch.full((4, 2), rank, dtype=torch.int64), 8)
+assert eq[:, 0].tolist() == [0] * 4 + [1] * 4
+assert dp.exchange_info()["nranks"] == world and dp.exchange_info()["backend"] == "gloo"
 # logits all-gather verification mode with a scripted "model": logits of row r after feeding token t peak at (7 * t + r + 3) % V
 V = 50
 def logits_for(tok, rows):

@@ -171,6 +171,19 @@ def test_raster(golden_dir):
     assert H.compute_giou(np.zeros((4, 4)), np.zeros((4, 4))) == float(g["giou_empty"]) == 1.0
 
 
+def test_render_image_reference_function(golden_dir):
+    """The reference's render_image executed on thin / float / reversed / malformed boxes and on image pairs of unequal
+    size (tools/make_golden.py gen_render_image): the oracle reproduces every output image."""
+    import json
+    cases = json.load(open(os.path.join(golden_dir, "render_image.json")))
+    assert sum(c["sizes"][0] != c["sizes"][1] for c in cases) >= 3
+    for k, c in enumerate(cases):
+        imgs = [np.random.default_rng(sd).integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8) for sd, hw in zip(c["seeds"][:2], c["sizes"])]
+        mask = (np.random.default_rng(c["seeds"][2]).random((48, 48)) > 0.55).astype(np.uint8)
+        got = H.render_image(c["bboxes_json"], imgs, mask)
+        assert [hashlib.sha256(np.ascontiguousarray(g).tobytes()).hexdigest() for g in got] == c["sha256"], (k, c["bboxes_json"])
+
+
 def test_postprocess_generate(golden_dir):
     g = np.load(os.path.join(golden_dir, "postprocess.npz"))
     seq, eos, pad = g["seq"].tolist()

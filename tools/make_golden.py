@@ -368,6 +368,66 @@ def gen_reference_python():
     print("reference python fixtures done")
 
 
+def gen_render_image():
+    """The reference's own ``render_image`` (rlvr_socioseg_vlm_pipeline_infer.py:383-452) executed on model-output-like
+    bbox strings: thin / float / reversed / malformed boxes, and an image pair of unequal size (the LANCZOS branch).
+    cv2 is absent: its one call (INTER_NEAREST resize) is answered by the documented rule, in this process only."""
+    import typing
+    from PIL import Image, ImageDraw
+
+    class _CV2:
+        INTER_NEAREST = 0
+
+        @staticmethod
+        def resize(a, size, interpolation=0):
+            w, h = size
+            ys = np.minimum(np.floor(np.arange(h) * (a.shape[0] / h)).astype(np.int64), a.shape[0] - 1)
+            xs = np.minimum(np.floor(np.arange(w) * (a.shape[1] / w)).astype(np.int64), a.shape[1] - 1)
+            return a[ys][:, xs]
+    ns = {"np": np, "json": json, "Image": Image, "ImageDraw": ImageDraw, "cv2": _CV2, "List": typing.List, "Dict": typing.Dict,
+          "Any": typing.Any, "Union": typing.Union}
+    extract("roll/pipeline/rlvr/rlvr_socioseg_vlm_pipeline_infer.py", ["render_image"], ns)
+    fn = ns["render_image"]
+    rng = np.random.default_rng(4100)
+    texts = [
+        '[{"bbox_2d": [10, 12, 30, 40]}, {"bbox_2d": [5, 5, 5, 5]}, {"bbox_2d": [20, 3, 21, 50]}, {"bbox_2d": [2, 30, 60, 31]}]',
+        '[{"bbox_2d": [1.9, 2.2, 7.5, 3.1]}, {"bbox_2d": [12.7, 9.2, 12.9, 30.8]}, {"bbox_2d": [3.9, 3.9, 3.1, 8]}, {"bbox_2d": [-4.5, -3.5, 6.2, 6.9]}]',
+        '[{"bbox_2d": [1, 2, null, 4]}, {"bbox_2d": [8, 8, 20, 20]}, {"bbox_2d": ["1", 2, 3, 4]}, {"bbox_2d": [[1, 2], 3, 4, 5]}, {"bbox_2d": "abcd"}]',
+        '[{"bbox_2d": [30, 30, 20, 40]}, {"bbox_2d": [30, 30, 40, 20]}, {"bbox_2d": [true, false, 9, 9]}, {"bbox_2d": [50, 60, 500, 600]}, {"bbox_2d": [-50, -60, 3, 2]}]',
+        '[{"bbox_2d": [4, 4, 9, 9]}, {"bbox_2d": 5}]',
+        '[{"bbox_2d": [4, 4, 9, 9]}, 7, {"points": [1, 2]}, {"bbox_2d": [1, 2, 3]}, {"bbox_2d": [14, 4, 14, 7]}, {"bbox_2d": [24, 4, 24, 6]}, {"bbox_2d": [34, 4, 36, 4]}]',
+        'not json at all', '{"bbox_2d": [1, 2, 3, 4]}', '[]',
+        '[{"bbox_2d": [1e10, 1, 2e10, 30]}, {"bbox_2d": [0, 0, 0, 0]}, {"bbox_2d": [63, 79, 63, 79]}, {"bbox_2d": [0.99, 0.99, 1.01, 1.01]}]',
+    ]
+    cases = []
+    for k, txt in enumerate(texts + [None] * 6):
+        h, w = int(rng.integers(40, 90)), int(rng.integers(40, 90))
+        other = (h, w) if k % 3 else (int(rng.integers(30, 100)), int(rng.integers(30, 100)))
+        if txt is None:              # random mixtures
+            bb = []
+            for _ in range(int(rng.integers(2, 9))):
+                x0, y0 = float(rng.integers(-5, w + 3)), float(rng.integers(-5, h + 3))
+                ww, hh = float(rng.integers(0, 4)) if rng.random() < 0.5 else float(rng.integers(0, 50)), \
+                    float(rng.integers(0, 4)) if rng.random() < 0.5 else float(rng.integers(0, 50))
+                if rng.random() < 0.4:
+                    x0, y0, ww, hh = x0 + float(rng.random()), y0 + float(rng.random()), ww + float(rng.random()), hh + float(rng.random())
+                    bb.append({"bbox_2d": [round(x0, 3), round(y0, 3), round(x0 + ww, 3), round(y0 + hh, 3)]})
+                else:
+                    bb.append({"bbox_2d": [int(x0), int(y0), int(x0 + ww), int(y0 + hh)]})
+            txt = json.dumps(bb)
+        seeds = [int(rng.integers(1, 1 << 30)) for _ in range(3)]
+        imgs = [np.random.default_rng(seeds[0]).integers(0, 256, (h, w, 3), dtype=np.uint8),
+                np.random.default_rng(seeds[1]).integers(0, 256, (other[0], other[1], 3), dtype=np.uint8)]
+        mask = (np.random.default_rng(seeds[2]).random((48, 48)) > 0.55).astype(np.uint8)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = fn(txt, [Image.fromarray(a) for a in imgs], mask)
+        cases.append({"bboxes_json": txt, "sizes": [[h, w], list(other)], "seeds": seeds,
+                      "sha256": [hashlib.sha256(np.array(o).tobytes()).hexdigest() for o in out]})
+    json.dump(cases, open(os.path.join(OUT, "render_image.json"), "w"), indent=1)
+    print("render_image done:", len(cases), "cases,", sum(c["sizes"][0] != c["sizes"][1] for c in cases), "with unequal sizes")
+
+
 def make_ref_rope():
     ns = {"torch": torch, "Optional": __import__("typing").Optional, "Tuple": __import__("typing").Tuple}
     extract("mcore_adapter/src/mcore_adapter/models/qwen2_5_vl/modeling_qwen2_5_vl.py", ["get_rope_index"], ns)
@@ -386,6 +446,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     rope = make_ref_rope()
     gen_reference_python()
+    gen_render_image()
     gen_index(rope)
     gen_patchify()
     gen_hf_tiny(rope)
