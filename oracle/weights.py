@@ -59,6 +59,32 @@ def _mix32_np(x: np.ndarray) -> np.ndarray:
     return x
 
 
+def _mix32_t(x: torch.Tensor) -> torch.Tensor:
+    """mix32 on int64 tensors holding uint32 values (multiplications wrap mod 2^64; the low 32 bits are what counts)."""
+    M = 0xFFFFFFFF
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & M
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & M
+    return x ^ (x >> 16)
+
+
+def synth_f32_torch(name: str, shape, seed: int = 0, base: float = 0.0, start: int = 0) -> torch.Tensor:
+    """Same definition as synth_f32, evaluated with multi-threaded torch integer ops (the numpy path is single-threaded and
+    needs minutes for the 3.75 G parameters of the full model); tests/test_oracle_golden.py checks the two bit for bit."""
+    n = int(np.prod(shape))
+    key = tensor_key(name, seed)
+    out = torch.empty(n, dtype=torch.float32)
+    CH = 1 << 24
+    for lo in range(0, n, CH):
+        hi = min(n, lo + CH)
+        idx = torch.arange(start + lo, start + hi, dtype=torch.int64) & 0xFFFFFFFF
+        h = _mix32_t((idx * 0x9E3779B1 + key) & 0xFFFFFFFF)
+        s_ = (h & 255) + ((h >> 8) & 255) + ((h >> 16) & 255) + (h >> 24) - 510
+        out[lo:hi] = np.float32(base) + s_.to(torch.float32) * float(SCALE_F32)
+    return out.to(torch.bfloat16).to(torch.float32).reshape(tuple(shape))
+
+
 def synth_f32(name: str, shape, seed: int = 0, base: float = 0.0, start: int = 0) -> np.ndarray:
     """float32 array holding bf16-representable values."""
     n = int(np.prod(shape))
@@ -134,16 +160,21 @@ def param_specs(cfg) -> list[tuple[str, tuple, float]]:
 class LazyWeights(dict):
     """name -> float32 torch tensor (bf16-representable), generated on first use."""
 
-    def __init__(self, cfg, seed: int = 0, cache: bool = True):
+    def __init__(self, cfg, seed: int = 0, cache: bool = True, fast: bool = False, source=None):
+        """source: optional callable (name, shape, base) -> float32 tensor that materialises a parameter some faster way
+        (bench.py hands in the device generator, which tests/test_gpu_parity.py::test_synth_fill_bit_exact pins to synth_f32)."""
         super().__init__()
-        self.cfg, self.seed, self.cache = cfg, seed, cache
+        self.cfg, self.seed, self.cache, self.fast, self.source = cfg, seed, cache, fast, source
         self.specs = {n: (s, b) for n, s, b in param_specs(cfg)}
 
     def __missing__(self, name):
         if name == "lm_head.weight":  # tied (tie_word_embeddings for the 3B geometry)
             return self["model.embed_tokens.weight"]
         shape, base = self.specs[name]
-        t = torch.from_numpy(synth_f32(name, shape, self.seed, base))
+        if self.source is not None:
+            t = self.source(name, shape, base)
+        else:
+            t = synth_f32_torch(name, shape, self.seed, base) if self.fast else torch.from_numpy(synth_f32(name, shape, self.seed, base))
         if self.cache:
             self[name] = t
         return t

@@ -459,7 +459,7 @@ bool is_fullatt(const sr_config& c, int blk) {
 
 int gemm(sr_engine* e, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, void* out, int ldo,
          const bf16_t* bias, const bf16_t* resid, const int* rowmap, int epi, int w_tiled = 0, const float* w_scale = nullptr) {
-    GemmArgs a{A, lda, W, M, N, K, out, ldo, bias, resid, rowmap, w_tiled, w_scale};
+    GemmArgs a{A, lda, W, M, N, K, out, ldo, bias, resid, rowmap, w_tiled, w_scale, 0};
     SR_TRY(launch_gemm(s, a, epi));
     return 0;
 }
@@ -1285,7 +1285,8 @@ int sr_render_overlay(uint8_t* img, int h, int w, const uint8_t* mask, int mh, i
 int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void* out, int ldo, const void* bias, const void* resid,
                const int32_t* rowmap, int epilogue, void* stream) {
     GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, M, N, K, out, ldo, (const bf16_t*)bias, (const bf16_t*)resid, rowmap,
-               (epilogue & 0x100) ? 1 : 0};      // bit 8 of `epilogue`: W is fragment-ordered (tiled16x64)
+               (epilogue & 0x100) ? 1 : 0, nullptr,      // bit 8 of `epilogue`: W is fragment-ordered (tiled16x64)
+               (epilogue & 0x200) ? 256 : (epilogue & 0x400) ? 128 : 0};      // bits 9 / 10: force the 256- / 128-tile kernel
     SR_WRAP(launch_gemm((hipStream_t)stream, a, epilogue & 0xff));
 }
 int sr_op_gemv(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ksplit, int mode, void* stream) {

@@ -1,0 +1,285 @@
+// 256 x 256 x 64 bf16 MFMA GEMM with an 8-phase, ping-pong schedule for the large-M rows of the hot path (ViT and LM prefill at
+// batch >= 8: SURVEY.md 2.3 K5, K8, K9, K13, K16).  Same contract and epilogues as gemm.hip (out = A[M,K] . W[N,K]^T, float32
+// accumulation, HF's bf16 rounding points); this file only changes HOW the tile is fed.
+//
+// Why: the 128 x 128 kernel of gemm.hip tops out at 0.9-1.0 PF (MFMA pipe 46 % busy): every k-tile ends in a barrier that first
+// drains the LDS-DMA queue (vmcnt(0)), so loads never span a barrier.  Here (MI355X guide, "256^2 8-phase template"):
+//   * 8 waves (2 x 4), each 128 x 64 of the tile = 8 x 4 MFMA tiles of 16 x 16 x 32 -> 64 MFMAs per wave and k-tile, issued
+//     as four "quadrant" phases of 16 (4 m-tiles x 2 n-tiles x 2 k-steps); fragments are (re)loaded per quadrant, so only
+//     32 + 32 VGPRs hold operands next to the 128 accumulator registers;
+//   * LDS: 2 k-tile buffers x (A 32 KB + W 32 KB) = 128 KB, filled by LDS-DMA in four 16 KB UNITS per k-tile, one unit per
+//     phase: a unit is the set of rows ALL waves read in one phase (UA0 = the first 64 rows of both A halves, UA1 = the
+//     second 64, UB0 / UB1 = the first / second 32 columns of every wave's 64), so a unit's buffer is free again as soon as
+//     its phase is over and the next-but-one k-tile's unit can be streamed into it two phases later;
+//   * loads stay in flight across barriers: raw s_barrier (no vmcnt drain) and ONE counted s_waitcnt vmcnt(4) per k-tile
+//     (two units = 4 LDS-DMA instructions per wave may still be flying); a unit is read one phase after the wait + barrier
+//     that retires it, and re-staged >= 2 phases after its last read;
+//   * the two wave rows run half a phase apart (wm = 1 passes one extra barrier up front): on every SIMD one wave is in its
+//     MFMA segment while its partner issues ds_reads / LDS-DMA, s_setprio(1) around the MFMA cluster.
+// Phase plan of k-tile t (reads come from buffer t & 1):
+//     p0: read UB0(t) [4 x b128] + UA0(t) [8]   stage UA1(t+1)        p1: read UB1(t) [4]      stage UB1(t+1)
+//     p2: read UA1(t) [8]                       stage UA0(t+2)        p3: (B0 kept in VGPRs)   stage UB0(t+2); vmcnt(4)
+#include "kernels.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
+constexpr int A_BYTES = BM2 * BK2 * 2, W_BYTES = BN2 * BK2 * 2, BUF_BYTES = A_BYTES + W_BYTES;   // 32 KB + 32 KB
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ int swz2(int row, int chunk) { return row * (BK2 * 2) + ((chunk ^ (row & 7)) << 4); }
+
+template <int EPI>
+__global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // ONE array (a second __shared__ object de-pipelines)
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    {   // XCD-aware: block b runs on XCD b % 8 -> give every XCD a contiguous run of tiles (bijective for any grid size)
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP = 4;                       // m-tiles that share their W panels while walking n
+    const int per_group = GROUP * ntn;
+    const int gid = bid / per_group, first_m = gid * GROUP, gsz = min(ntm - first_m, GROUP);
+    const int tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const bool tiled = p.w_tiled != 0;
+
+    // ---- LDS-DMA sources.  Every unit is 16 pieces of 1 KB (8 tile rows x 128 B, or one k-step half of a fragment-ordered
+    // W tile); wave w issues pieces 2w and 2w + 1.
+    const int lr = lane >> 3, lc = ((lane & 7) ^ lr) * 8;                     // XOR swizzle on the SOURCE side (LDS-DMA writes linearly)
+    const bf16_t* asrc[2][2];                                                 // [unit half][piece]
+    int adst[2][2];
+    const bf16_t* wsrc[2][2];
+    int wdst[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int g = wave * 2 + i;                                       // 8-row group inside the unit: 0..15
+            const int ru = g * 8;                                             // first unit row of the group
+            const int trow = (ru < 64 ? ru : ru + 64) + h * 64;               // tile row: unit h = rows [h*64, +64) of both A halves
+            asrc[h][i] = p.A + (size_t)min(m0 + trow + lr, p.M - 1) * p.lda + lc;
+            adst[h][i] = trow * 128;
+            if (tiled) {      // piece = (n-tile of the unit, k-step): the unit's 8 n-tiles are tiles {wn*4 + h*2 + (0,1)}
+                const int ntu = g >> 1, ks = g & 1;
+                const int ntile = (ntu >> 1) * 4 + h * 2 + (ntu & 1);
+                wsrc[h][i] = p.W + (size_t)(n0 / 16 + ntile) * (size_t)(p.K / 64) * 1024 + ks * 512 + lane * 8;
+                wdst[h][i] = ntile * 2048 + ks * 1024;
+            } else {          // row-major: unit h = n-rows [wn*64 + h*32, +32) of every wave column
+                const int nrow = (ru >> 5) * 64 + h * 32 + (ru & 31);
+                wsrc[h][i] = p.W + (size_t)min(n0 + nrow + lr, p.N - 1) * p.K + lc;
+                wdst[h][i] = nrow * 128;
+            }
+        }
+    const size_t w_kt = tiled ? 1024 : BK2;
+    auto stage_a = [&](int h, int kt) {
+        unsigned char* base = smem + (kt & 1) * BUF_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[h][i] + (size_t)kt * BK2), (lptr_t)(base + adst[h][i]), 16, 0, 0);
+    };
+    auto stage_w = [&](int h, int kt) {
+        unsigned char* base = smem + (kt & 1) * BUF_BYTES + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[h][i] + (size_t)kt * w_kt), (lptr_t)(base + wdst[h][i]), 16, 0, 0);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], wf0[2][2], wf1[2][2];          // [tile in quadrant][k-step]
+
+    // fragment addresses (bytes inside a buffer)
+    int a_off[2][2];                                 // [m-half quadrant base: tile 0][k-step] -> + t * 16 rows * 128 B
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        a_off[0][kk] = swz2(wm * 128 + fr, kk * 4 + fg);          // rows (wm*128 + t*16 + fr): the swizzle only depends on fr & 7
+        a_off[1][kk] = swz2(wm * 128 + 64 + fr, kk * 4 + fg);
+    }
+    int w_off[2][2];                                 // [n-half][k-step] of the half's tile 0 -> + t * (2048 or 16 * 128)
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            w_off[nh][kk] = A_BYTES + (tiled ? (wn * 4 + nh * 2) * 2048 + (fg & 1) * 1024 + (((kk * 2 + (fg >> 1)) * 16 + fr) << 4)
+                                             : swz2(wn * 64 + nh * 32 + fr, kk * 4 + fg));
+    const int w_tile = tiled ? 2048 : 16 * 128;
+
+    auto read_a = [&](const unsigned char* buf, int mh) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) af[t][kk] = *reinterpret_cast<const bf16x8*>(buf + a_off[mh][kk] + t * 2048);
+    };
+    auto read_w = [&](const unsigned char* buf, int nh, bf16x8 (&wf)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) wf[t][kk] = *reinterpret_cast<const bf16x8*>(buf + w_off[nh][kk] + t * w_tile);
+    };
+    auto quad = [&](int mh, int nh, bf16x8 (&wf)[2][2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], af[i][kk], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+    };
+#define PHASE_SYNC_COMPUTE(MH, NH, WF)                       \
+    __builtin_amdgcn_sched_barrier(0);                       \
+    __builtin_amdgcn_s_barrier();                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+    __builtin_amdgcn_sched_barrier(0);                       \
+    __builtin_amdgcn_s_setprio(1);                           \
+    quad(MH, NH, WF);                                        \
+    __builtin_amdgcn_s_setprio(0);                           \
+    __builtin_amdgcn_sched_barrier(0);                       \
+    __builtin_amdgcn_s_barrier();                            \
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int nk = p.K / BK2;
+    // ---- prologue: k-tile 0 completely, plus the two units of k-tile 1 the steady state has already issued by then
+    stage_a(0, 0); stage_w(0, 0); stage_w(1, 0); stage_a(1, 0);
+    if (nk > 1) { stage_a(0, 1); stage_w(0, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();       // the second wave row runs half a phase behind the first
+
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* buf = smem + (t & 1) * BUF_BYTES;
+        // p0
+        read_w(buf, 0, wf0);
+        read_a(buf, 0);
+        if (t + 1 < nk) stage_a(1, t + 1);
+        PHASE_SYNC_COMPUTE(0, 0, wf0)
+        // p1
+        read_w(buf, 1, wf1);
+        if (t + 1 < nk) stage_w(1, t + 1);
+        PHASE_SYNC_COMPUTE(0, 1, wf1)
+        // p2
+        read_a(buf, 1);
+        if (t + 2 < nk) stage_a(0, t + 2);
+        PHASE_SYNC_COMPUTE(1, 1, wf1)
+        // p3
+        if (t + 2 < nk) { stage_w(0, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PHASE_SYNC_COMPUTE(1, 0, wf0)
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();       // balance the extra barrier of the other wave row
+#undef PHASE_SYNC_COMPUTE
+
+    // ---- epilogue (same rounding points as gemm.hip).  lane owns row m = .. + fr and columns n = .. + fg*4 + {0..3}.
+    // Column-only operands (bias, fp8 scale) and the row map are fetched once, up front: no memory wait inside the store loop.
+    int orow[8];
+    bool rok[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + fr;
+        rok[i] = m < p.M;
+        orow[i] = (rok[i] && p.rowmap) ? p.rowmap[m] : m;
+    }
+    uint2 bia[4];
+    float4 scl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + fg * 4;
+        bia[j] = p.bias ? *reinterpret_cast<const uint2*>(p.bias + n) : uint2{0, 0};
+        scl[j] = p.w_scale ? *reinterpret_cast<const float4*>(p.w_scale + n) : float4{1.f, 1.f, 1.f, 1.f};
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (!rok[i]) continue;
+        if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {                                  // tiles (2jp, 2jp+1) = (gate, up) of 16 columns
+                const float gs[4] = {scl[2 * jp].x, scl[2 * jp].y, scl[2 * jp].z, scl[2 * jp].w};
+                const float us[4] = {scl[2 * jp + 1].x, scl[2 * jp + 1].y, scl[2 * jp + 1].z, scl[2 * jp + 1].w};
+                const float gb[4] = {lo16(bia[2 * jp].x), hi16(bia[2 * jp].x), lo16(bia[2 * jp].y), hi16(bia[2 * jp].y)};
+                const float ub[4] = {lo16(bia[2 * jp + 1].x), hi16(bia[2 * jp + 1].x), lo16(bia[2 * jp + 1].y), hi16(bia[2 * jp + 1].y)};
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float g = acc[i][2 * jp][r], u = acc[i][2 * jp + 1][r];
+                    if (p.w_scale) { g *= gs[r]; u *= us[r]; }
+                    if (p.bias) { g += gb[r]; u += ub[r]; }
+                    g = rbf(g); u = rbf(u);
+                    o[r] = rbf(silu_f(g)) * u;
+                }
+                const int no = (n0 + wn * 64) / 2 + jp * 16 + fg * 4;
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow[i] * p.ldo + no) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+            }
+        } else {
+            uint2 rv[4];
+            if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    rv[j] = *reinterpret_cast<const uint2*>(p.resid + (size_t)orow[i] * p.ldo + n0 + wn * 64 + j * 16 + fg * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fg * 4;
+                float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (p.w_scale) { o[0] *= scl[j].x; o[1] *= scl[j].y; o[2] *= scl[j].z; o[3] *= scl[j].w; }
+                if constexpr (EPI == EPI_F32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow[i] * p.ldo + n) = float4{o[0], o[1], o[2], o[3]};
+                } else {
+                    if (p.bias) { o[0] += lo16(bia[j].x); o[1] += hi16(bia[j].x); o[2] += lo16(bia[j].y); o[3] += hi16(bia[j].y); }
+                    if constexpr (EPI == EPI_RESID) {
+                        o[0] = lo16(rv[j].x) + rbf(o[0]); o[1] = hi16(rv[j].x) + rbf(o[1]);
+                        o[2] = lo16(rv[j].y) + rbf(o[2]); o[3] = hi16(rv[j].y) + rbf(o[3]);
+                    } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = gelu_f(rbf(o[r]));
+                    }
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow[i] * p.ldo + n) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch256_t(hipStream_t s, const GemmArgs& a) {
+    const int ntm = cdiv(a.M, BM2), ntn = a.N / BN2;
+    constexpr int smem = 2 * BUF_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm256<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (r != hipSuccess) return (int)r;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_gemm256<EPI>), dim3(ntm * ntn), dim3(512), smem, s, a, ntm, ntn);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+// shapes the 256-tile kernel takes: whole 256-column tiles, at least two 64-wide k-tiles (M is arbitrary: edge rows are clamped
+// on load and masked on store)
+bool gemm256_supports(const GemmArgs& a) { return a.N % BN2 == 0 && a.K % BK2 == 0 && a.K / BK2 >= 2 && a.M >= 1; }
+
+int launch_gemm256(hipStream_t s, const GemmArgs& a, int epi) {
+    if (!gemm256_supports(a)) return -22;
+    switch (epi) {
+        case EPI_STORE: return launch256_t<EPI_STORE>(s, a);
+        case EPI_RESID: return launch256_t<EPI_RESID>(s, a);
+        case EPI_SWIGLU: return launch256_t<EPI_SWIGLU>(s, a);
+        case EPI_GELU: return launch256_t<EPI_GELU>(s, a);
+        case EPI_F32: return launch256_t<EPI_F32>(s, a);
+    }
+    return -22;
+}

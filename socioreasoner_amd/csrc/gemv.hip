@@ -531,6 +531,143 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- batches 5..32, wide N
+// x shared through LDS.  In k_gemv the 4 waves of a block split K, so every wave fetches its own x fragments from L2: at
+// M = 32 that is 4 KB of x per 2 KB weight chunk on the CU's load path.  Here the 4 waves of a block own 4 DIFFERENT weight
+// tiles over the SAME k range: the block stages each 64-wide x chunk (32 rows x 128 B) once, in groups of 4 chunks, double
+// buffered -- ordinary 16-byte loads issued one group ahead, written to LDS (row stride 144 B) after the current group's
+// MFMAs, one barrier per group -- and every wave reads its B fragments from LDS.  Loads per weight chunk drop from 2 + 4 to
+// 2 + 1/4; the weight stream itself is unchanged (fragment-ordered tiles straight from HBM into a register ring, U chunks
+// deep).  No in-block K reduction; K is split over gridDim.y (PARTIAL) or not at all (SWIGLU).
+template <int MODE, int MT, int U>
+__global__ __launch_bounds__(256) void k_gemvx(GemvArgs p, int ntiles) {
+    constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;
+    constexpr int GC = 4, XS = 72;                       // chunks per x group; LDS row stride in elements (64 + 8 pad)
+    static_assert(U % GC == 0, "ring depth must be a multiple of the x group");
+    __shared__ __attribute__((aligned(16))) bf16_t xs[2][GC][32][XS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tile = blockIdx.x * 4 + wave;              // in units of T tiles
+    const bool active = tile < ntiles;
+    const int nchunks = p.K / 64;
+    const int ks = (MODE == GV_PARTIAL) ? p.ksplit : 1;
+    const int per = (nchunks + ks - 1) / ks;
+    const int c0 = min((MODE == GV_PARTIAL ? (int)blockIdx.y : 0) * per, nchunks), cend = min(c0 + per, nchunks);
+
+    // x staging: thread -> (row, 16-byte piece) of every chunk of a group
+    const int xrow = tid >> 3, xpc = tid & 7;
+    const bool xon = xrow < p.M;
+    const bf16_t* xsrc = p.x + (size_t)(xon ? xrow : 0) * p.ldx + xpc * 8;
+    u32x4 xr[GC];
+    auto load_x = [&](int cg) {                          // chunks cg .. cg + GC - 1
+#pragma unroll
+        for (int j = 0; j < GC; ++j)
+            xr[j] = (xon && cg + j < cend) ? *reinterpret_cast<const u32x4*>(xsrc + (size_t)(cg + j) * 64) : u32x4{0, 0, 0, 0};
+    };
+    auto write_x = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < GC; ++j) *reinterpret_cast<u32x4*>(&xs[buf][j][xrow][xpc * 8]) = xr[j];
+    };
+
+    u32x4 w[U][T][2];
+    const bf16_t* wrow[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) wrow[t] = p.W + (size_t)((active ? tile : 0) * T + t) * 16 * p.K + lane * 8;
+    auto fill_w = [&](int u, int c) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            w[u][t][0] = ldg_nt(wrow[t] + (size_t)c * 1024);
+            w[u][t][1] = ldg_nt(wrow[t] + (size_t)c * 1024 + 512);
+        }
+    };
+    load_x(c0);                                          // oldest loads in flight: the first barrier only waits for these
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c0 + u < cend) fill_w(u, c0 + u);
+    }
+    write_x(0);
+    __syncthreads();
+
+    f32x4 acc[T][MT];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int buf = 0;
+    for (int cb = c0; cb < cend; cb += U) {
+#pragma unroll
+        for (int gg = 0; gg < U / GC; ++gg) {
+            const int cg = cb + gg * GC;
+            if (cg < cend) {
+                const bool more = cg + GC < cend;
+                if (more) load_x(cg + GC);
+                if (active) {
+#pragma unroll
+                    for (int j = 0; j < GC; ++j) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int u = gg * GC + j, c = cg + j;
+                        if (c < cend) {
+                            u32x4 xv[MT][2];
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) {
+                                const bf16_t* xp = &xs[buf][j][mt * 16 + fr][fg * 16];
+                                xv[mt][0] = *reinterpret_cast<const u32x4*>(xp);
+                                xv[mt][1] = *reinterpret_cast<const u32x4*>(xp + 8);
+                            }
+#pragma unroll
+                            for (int t = 0; t < T; ++t)
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt) {
+                                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][0]), as_frag(xv[mt][0]), acc[t][mt], 0, 0, 0);
+                                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][1]), as_frag(xv[mt][1]), acc[t][mt], 0, 0, 0);
+                                }
+                            if (c + U < cend) fill_w(u, c + U);
+                        }
+                    }
+                }
+                if (more) {
+                    write_x(buf ^ 1);
+                    __syncthreads();
+                    buf ^= 1;
+                }
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue: lane owns batch row mt*16 + fr, columns tile*16 + fg*4 + {0..3}
+    if (!active) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + fr;
+        if (m >= p.M) continue;
+        if constexpr (MODE == GV_SWIGLU) {
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float g = rbf(acc[0][mt][r]), u = rbf(acc[1][mt][r]);
+                o[r] = rbf(silu_f(g)) * u;
+            }
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * (p.N / 2) + tile * 16 + fg * 4) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+        } else {
+            float* o = reinterpret_cast<float*>(p.out) + ((size_t)blockIdx.y * p.M + m) * p.N + tile * 16 + fg * 4;
+            *reinterpret_cast<float4*>(o) = float4{acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3]};
+        }
+    }
+}
+
+template <int MODE, int U>
+int launch_x(hipStream_t s, const GemvArgs& a) {
+    constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;
+    const int ntiles = a.N / (16 * T);
+    dim3 grid(cdiv(ntiles, 4), MODE == GV_PARTIAL ? a.ksplit : 1);
+    if (a.M <= 16) hipLaunchKernelGGL((k_gemvx<MODE, 1, U>), grid, dim3(256), 0, s, a, ntiles);
+    else hipLaunchKernelGGL((k_gemvx<MODE, 2, U>), grid, dim3(256), 0, s, a, ntiles);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int MODE, int KP>
 int launch_32(hipStream_t s, const GemvArgs& a) {
     constexpr int TPB = 4 / KP;
@@ -645,6 +782,15 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
             case GV_RESID: return launch_small<GV_RESID, 4, true>(s, a);
         }
         return -22;
+    }
+    // batches above 4, wide matrices: x shared through LDS (k_gemvx).  SR_GEMVX: bit 0 = gate/up (SWIGLU), bit 1 = split-K
+    // down-projection (PARTIAL); SR_GEMVX_U: weight ring depth in chunks (4 / 8 / 16)
+    static const char* x_env = getenv("SR_GEMVX");
+    static const char* xu_env = getenv("SR_GEMVX_U");
+    const int xmask = x_env ? atoi(x_env) : 0, xu = xu_env ? atoi(xu_env) : 8;
+    if (a.M > 4 && !a.norm_w && a.w_tiled && a.K % 64 == 0) {
+        if (mode == GV_SWIGLU && (xmask & 1)) return xu == 4 ? launch_x<GV_SWIGLU, 4>(s, a) : launch_x<GV_SWIGLU, 8>(s, a);
+        if (mode == GV_PARTIAL && (xmask & 2)) return xu == 4 ? launch_x<GV_PARTIAL, 4>(s, a) : xu == 16 ? launch_x<GV_PARTIAL, 16>(s, a) : launch_x<GV_PARTIAL, 8>(s, a);
     }
     if (use_32(a, mode)) {
         switch (mode) {

@@ -16,8 +16,12 @@ struct GemmArgs {
     const int* rowmap;          // optional destination row per source row
     int w_tiled;                // W stored fragment-ordered (tiled16x64, see common.h) instead of row-major
     const float* w_scale;       // optional [N]: per-output-channel scale applied to the accumulator (fp8-quantised W)
+    int force_tile;             // 0: launch_gemm picks the kernel; 256 / 128: force gemm256.hip / gemm.hip (tests, tuning)
 };
 int launch_gemm(hipStream_t s, const GemmArgs& a, int epi);
+// gemm256.hip: 256 x 256 x 64 tile, 8-phase ping-pong schedule (large M); launch_gemm dispatches to it
+bool gemm256_supports(const GemmArgs& a);
+int launch_gemm256(hipStream_t s, const GemmArgs& a, int epi);
 
 // ------------------------------------------------------------------ gemv.hip (weight streaming, M <= 32)
 enum { GV_PARTIAL = 0, GV_SWIGLU = 1, GV_F32 = 2, GV_BIAS = 3, GV_RESID = 4 };

@@ -28,9 +28,12 @@ class Request:
 
 
 class ContinuousBatcher:
-    def __init__(self, engine, eos: Sequence[int], pad_id: int, steps_per_poll: int = 8, sampling: Optional[dict] = None):
-        """sampling: None = greedy, else {"temperature", "top_k" (1..1024), "top_p", "seed"} shared by all requests."""
+    def __init__(self, engine, eos: Sequence[int], pad_id: int, steps_per_poll: int = 8, sampling: Optional[dict] = None,
+                 time_phases: bool = False):
+        """sampling: None = greedy, else {"temperature", "top_k" (1..1024), "top_p", "seed"} shared by all requests.
+        time_phases: bracket every ViT / prefill / decode call with events on the launch stream (phase_ms() sums them)."""
         self.engine, self.eos, self.pad_id, self.steps_per_poll = engine, [int(e) for e in eos], int(pad_id), steps_per_poll
+        self._ev = [] if time_phases else None
         self.free = deque(range(engine.cfg.max_batch))
         self.active: Dict[int, Request] = {}
         self.pending: deque = deque()
@@ -38,6 +41,26 @@ class ContinuousBatcher:
         engine.rows_begin()
         if sampling:
             engine.rows_sampling(float(sampling["temperature"]), int(sampling["top_k"]), float(sampling.get("top_p", 1.0)), int(sampling.get("seed", 0)))
+
+    def _mark(self):
+        if self._ev is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(self.engine.device))
+        return e
+
+    def _span(self, name, a, b):
+        if self._ev is not None:
+            self._ev.append((name, a, b))
+
+    def phase_ms(self) -> Dict[str, float]:
+        """Sum of the event-bracketed spans per phase (synchronises)."""
+        out = {"vit": 0.0, "prefill": 0.0, "decode": 0.0}
+        if self._ev:
+            torch.cuda.synchronize(self.engine.device)
+            for name, a, b in self._ev:
+                out[name] += a.elapsed_time(b)
+        return out
 
     def submit(self, req: Request):
         self.pending.append(req)
@@ -61,10 +84,14 @@ class ContinuousBatcher:
         rows = [self.free.popleft() for _ in grp]
         emb = None
         ims = [im for r in grp for im in r.images]
+        t0 = self._mark()
         if ims:
             pix = torch.cat([self.engine.patchify(im) for im in ims], dim=0)
             emb = self.engine.vit_forward(pix, [g for r in grp for g in r.grids])
+        t1 = self._mark()
         self.engine.admit(rows, [r.ids for r in grp], [r.pos3 for r in grp], [r.max_new for r in grp], emb)
+        self._span("vit", t0, t1)
+        self._span("prefill", t1, self._mark())
         for row, r in zip(rows, grp):
             self.active[row] = r
         self.stats["admitted"] += len(grp)
@@ -75,7 +102,9 @@ class ContinuousBatcher:
         self._admit()
         if not self.active:
             return
+        t0 = self._mark()
         self.engine.rows_step(self.steps_per_poll, self.eos, self.pad_id)
+        self._span("decode", t0, self._mark())
         self.stats["steps"] += self.steps_per_poll
         fin, cnt = self.engine.rows_poll()
         for row in [r for r in self.active if fin[r]]:

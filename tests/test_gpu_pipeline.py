@@ -354,16 +354,19 @@ def test_two_rank_data_parallel_bench_equals_single_process():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
     def run(cmd, port=None):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        # two ranks on the ONE GPU of the test box: sharing a device over gloo has to be asked for (dp.init_distributed refuses to
+        # fall back silently; RCCL with one GPU per rank is the driver's scaling tier)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", SR_DIST_BACKEND="gloo")
         out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
         return json.loads(line)
     common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
     tr = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
-    one = run([sys.executable, "bench.py", "--batch", "2"] + common)
-    two = run(tr + ["--master-port", "29551", "bench.py", "--gpus", "2"] + common)
-    ver = run(tr + ["--master-port", "29552", "bench.py", "--gpus", "2", "--gather-logits"] + common)
+    one = run([sys.executable, "bench.py", "--batch", "2", "--static", "--no-latency"] + common)
+    two = run(tr + ["--master-port", "29551", "bench.py", "--gpus", "2", "--batch", "1"] + common)
+    ver = run(tr + ["--master-port", "29552", "bench.py", "--gpus", "2", "--batch", "1", "--gather-logits"] + common)
+    assert two["config"]["exchange"]["backend"] == "gloo" and two["config"]["exchange"]["nranks"] == 2
     assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "dp2" and two["scaling"] == "weak"
     assert one["result_checksum"] == two["result_checksum"] == ver["result_checksum"]
     for j in (one, two):

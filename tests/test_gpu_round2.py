@@ -1,0 +1,198 @@
+"""GPU tests added in round 2: the 256 x 256 8-phase GEMM, the PIL-exact render path on the reference's own fixtures,
+32-row continuous batching at the full 3B geometry (BASELINE.json configs[2]), the RCCL exchange on a one-rank communicator."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_bf16_close, tile16x64
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EPI_STORE, EPI_RESID, EPI_SWIGLU, EPI_GELU, EPI_F32 = range(5)
+TILED, F256, F128 = 0x100, 0x200, 0x400
+
+
+@pytest.fixture(scope="module")
+def L():
+    from socioreasoner_amd import lib
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return lib.load()
+
+
+def sp():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def interleave16(gate, up):
+    n, k = gate.shape
+    out = torch.empty(2 * n, k, dtype=gate.dtype)
+    o = out.view(n // 16, 2, 16, k)
+    o[:, 0] = gate.view(n // 16, 16, k)
+    o[:, 1] = up.view(n // 16, 16, k)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ 256-tile GEMM
+@pytest.mark.parametrize("M,N,K,tiled", [(777, 512, 320, False), (256, 256, 128, True), (1000, 1280, 1216, False), (513, 768, 2048, True)])
+def test_gemm256_store_bias_rowmap_vs_cpu(L, M, N, K, tiled):
+    """gemm256.hip against the float32 CPU reference: ragged M (clamped loads, masked stores), odd and minimal k-tile counts,
+    row map, both weight layouts."""
+    from oracle import model_ref as MR
+    a, w, b = rnd((M, K), 1), rnd((N, K), 2, 0.05), rnd((N,), 3, 0.1)
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(4)).int()
+    wd = (tile16x64(w) if tiled else w).cuda()
+    ad, bd, pd = a.cuda(), b.cuda(), perm.cuda()
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    assert L.sr_op_gemm(P(ad), K, P(wd), M, N, K, P(out), N, P(bd), None, P(pd), EPI_STORE | F256 | (TILED if tiled else 0), sp()) == 0
+    want = torch.empty(M, N)
+    want[perm.long()] = MR.linear(a.float(), w.float(), b.float())
+    assert_bf16_close(out.float().cpu(), want, 1, 0.01, f"gemm256 store {M}x{N}x{K}")
+
+
+def test_gemm256_equals_gemm128_bit_for_bit(L):
+    """Both kernels accumulate every output element over k in the same order (16 x 16 x 32 MFMA steps, ascending k), so the
+    256-tile kernel must reproduce the 128-tile kernel EXACTLY -- on the hot-path shapes, for every epilogue."""
+    torch.manual_seed(0)
+    for (M, N, K, epi, tiled) in [(2048, 2560, 2048, EPI_STORE, True), (1792, 2048, 11008, EPI_RESID, True), (1536, 22016, 2048, EPI_SWIGLU, True),
+                                   (4096, 3840, 1280, EPI_STORE, False), (2048, 1280, 3456, EPI_RESID, False), (2048, 6912, 1280, EPI_SWIGLU, False),
+                                   (1000, 5120, 5120, EPI_GELU, False), (300, 4096, 2048, EPI_F32, True)]:
+        a = (torch.randn(M, K, device="cuda") * 1.0).to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda") * 0.03).to(torch.bfloat16)
+        b = (torch.randn(N, device="cuda") * 0.1).to(torch.bfloat16) if epi != EPI_F32 else None
+        No = N // 2 if epi == EPI_SWIGLU else N
+        res0 = (torch.randn(M, No, device="cuda")).to(torch.bfloat16) if epi == EPI_RESID else None
+        outs = []
+        for force in (F256, F128):
+            out = torch.zeros(M, No, dtype=torch.float32 if epi == EPI_F32 else torch.bfloat16, device="cuda")
+            res = None
+            if epi == EPI_RESID:
+                out.copy_(res0)
+                res = out                                           # in place, like the engine
+            rc = L.sr_op_gemm(P(a), K, P(w), M, N, K, P(out), No, P(b), P(res), None, epi | force | (TILED if tiled else 0), sp())
+            assert rc == 0, (M, N, K, epi)
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), (M, N, K, epi, float((outs[0].float() - outs[1].float()).abs().max()))
+        assert bool(torch.isfinite(outs[0].float()).all()) and float(outs[0].float().abs().max()) > 0
+
+
+def test_gemm256_race_screen(L):
+    """The LDS-DMA pipeline keeps loads in flight across barriers: repeat one launch many times on the same inputs and
+    require identical bits every time (an early read of a buffer still being filled shows up as run-to-run differences)."""
+    M, N, K = 4096, 2048, 2048
+    a = (torch.randn(M, K, device="cuda")).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * 0.03).to(torch.bfloat16)
+    ref = None
+    for it in range(40):
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        assert L.sr_op_gemm(P(a), K, P(w), M, N, K, P(out), N, None, None, None, EPI_STORE | F256, sp()) == 0
+        if ref is None:
+            ref = out
+        else:
+            assert torch.equal(out, ref), it
+
+
+# ------------------------------------------------------------------------------------------------ render_image vs the reference's own function
+def test_render_image_equals_reference_function_outputs(golden_dir):
+    """Product render_image (device outlines + overlay; PIL resample only in the unequal-size branch) on the fixtures made by
+    EXECUTING the reference's render_image: thin / float / reversed / malformed boxes, image pairs of unequal size."""
+    from PIL import Image
+    from roll.pipeline.rlvr.rlvr_socioseg_vlm_pipeline_infer import render_image
+    cases = json.load(open(os.path.join(golden_dir, "render_image.json")))
+    for k, c in enumerate(cases):
+        imgs = [np.random.default_rng(sd).integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8) for sd, hw in zip(c["seeds"][:2], c["sizes"])]
+        mask = (np.random.default_rng(c["seeds"][2]).random((48, 48)) > 0.55).astype(np.uint8)
+        got = render_image(c["bboxes_json"], [Image.fromarray(a) for a in imgs], mask)
+        assert [hashlib.sha256(np.array(g).tobytes()).hexdigest() for g in got] == c["sha256"], (k, c["bboxes_json"])
+        dev = render_image(c["bboxes_json"], [torch.from_numpy(a).cuda() for a in imgs], torch.from_numpy(mask).cuda(), keep_on_device=True)
+        assert [hashlib.sha256(np.ascontiguousarray(g.cpu().numpy()).tobytes()).hexdigest() for g in dev] == c["sha256"], (k, "device tensors")
+
+
+# ------------------------------------------------------------------------------------------------ configs[2] at full size
+def test_continuous_batching_32_rows_full_3b():
+    """BASELINE.json configs[2]: SocioReasoner-3B, 32 rows in flight, continuous batching (admit on finish).  40 tile requests
+    (448-token image prompts, ragged max_new so rows free up at different times) through 32 rows: every request's tokens equal
+    the tokens of the same request decoded in a STATIC batch of 32 (same decode kernels; per-row arithmetic is independent of
+    the neighbours), all 32 rows are really in flight together, and every admission past the first fills freed rows."""
+    from socioreasoner_amd import hostops, synthetic
+    from socioreasoner_amd.config import geometry_3b
+    from socioreasoner_amd.engine import Engine
+    from socioreasoner_amd.serving import ContinuousBatcher, Request
+    geom = geometry_3b()
+    B, NREQ, G = 32, 40, 24
+    e = Engine(geom, max_patches=1024 * B, max_prefill_tokens=448 * B, max_batch=B, max_ctx=512, max_new_tokens=G)
+    e.load_synthetic_weights(seed=0)
+    grid = (1, 32, 32)
+    imgs = [torch.from_numpy(synthetic.tile_pixels(i)).cuda() for i in range(8)]
+    ids, pos = [], []
+    for i in range(NREQ):
+        x = synthetic.tile_prompt(geom, i, grid)
+        p, _ = hostops.get_rope_index(torch.from_numpy(x)[None], [grid], None)
+        ids.append(x)
+        pos.append(p[:, 0].numpy())
+    max_new = [G - (i * 7) % 13 for i in range(NREQ)]
+    # static reference: requests 0..31 as one batch of 32 (greedy, no eos), then 32..39 padded with repeats
+    ref = {}
+    for lo in (0, NREQ - B):
+        sel = list(range(lo, lo + B))
+        pix = torch.cat([e.patchify(imgs[i % 8]) for i in sel], dim=0)
+        emb = e.vit_forward(pix, [grid] * B)
+        e.prefill([ids[i] for i in sel], [pos[i] for i in sel], emb)
+        toks = e.decode(G).cpu().tolist()
+        for r, i in enumerate(sel):
+            ref[i] = toks[r]
+    cb = ContinuousBatcher(e, eos=[], pad_id=0, steps_per_poll=4)
+    reqs = [Request(ids=ids[i], pos3=pos[i], max_new=max_new[i], images=[imgs[i % 8]], grids=[grid]) for i in range(NREQ)]
+    out = cb.run(reqs)
+    for i in range(NREQ):
+        assert out[i] == ref[i][: max_new[i]], (i, out[i][:8], ref[i][:8])
+    assert cb.stats["admitted"] == NREQ and cb.stats["admissions"] >= 2
+    e.close()
+
+
+# ------------------------------------------------------------------------------------------------ RCCL on one rank
+def test_rccl_exchange_path_single_rank(tmp_path):
+    """The test box has one GPU, so the N > 1 RCCL run belongs to the driver's scaling tier; what CAN run here is the same
+    code path on a one-rank communicator: backend "nccl" (RCCL) initialised by dp.init_distributed, the pre-allocated
+    all_gather_into_tensor exchange, the max-over-ranks reduction and the exchange report of the bench line."""
+    script = tmp_path / "w.py"
+    script.write_text(f"""
+import os, sys, json, torch
+sys.path.insert(0, {ROOT!r})
+from socioreasoner_amd import dp
+rank, world, local = dp.init_distributed()
+import torch.distributed as dist
+assert dist.is_initialized() and dist.get_backend() == "nccl", dist.get_backend()
+x = torch.arange(12, dtype=torch.int64, device="cuda").reshape(4, 3)
+y = dp.all_gather_rows(x, 4)
+assert y.data_ptr() == x.data_ptr() or torch.equal(y, x)
+z = dp._gather_equal(x, 1)
+assert z.shape == (1, 4, 3) and torch.equal(z[0], x)
+assert dp.all_reduce_max(3.5, torch.device("cuda")) == 3.5
+info = dp.exchange_info()
+assert info["backend"] == "nccl" and info["nranks"] == 1, info
+dp.barrier()
+print("RCCL_OK", json.dumps(info))
+""")
+    env = dict(os.environ, SR_FORCE_DIST="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547",
+               NCCL_DEBUG="INFO", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env["SR_RCCL_LOG"] = str(tmp_path / "rccl.log")
+    env["NCCL_DEBUG_FILE"] = env["SR_RCCL_LOG"]
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
