@@ -171,7 +171,10 @@ int sr_render_overlay(uint8_t* dev_img_rgb, int h, int w, const uint8_t* dev_mas
                       const int32_t* dev_boxes, int n_boxes, void* stream);
 
 /* Single-kernel entry points used by the parity tests and micro-benchmarks (same kernels the engine launches).
- * All pointers are device pointers; layouts are documented in DESIGN.md "Kernels". */
+ * All pointers are device pointers; layouts are documented in DESIGN.md "Kernels".
+ * Flag bits OR-ed into `epilogue` / `mode`: 0x100 W fragment-ordered (tiled16x64); sr_op_gemm: 0x200 / 0x400 force the 256- /
+ * 128-tile kernel; sr_op_gemv*: 0x800 x fragment-ordered (tiled16x64 of a [ceil16(M), K] matrix), 0x1000 SwiGLU output
+ * fragment-ordered. */
 int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void* out, int ldo, const void* bias,
                const void* resid, const int32_t* rowmap, int epilogue, void* stream);
 int sr_op_gemv(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ksplit, int mode, void* stream);

@@ -408,7 +408,8 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
                 oacc[d][0] += o2[0]; oacc[d][1] += o2[1]; oacc[d][2] += o2[2]; oacc[d][3] += o2[3];
             }
             uint2 v = {pack2(oacc[d][0], oacc[d][1]), pack2(oacc[d][2], oacc[d][3])};
-            *reinterpret_cast<uint2*>(p.out + (size_t)b * p.out_stride + (kvh * G + fr) * DEC_HD + (dt0 + d) * 16 + fg * 4) = v;
+            const int col = (kvh * G + fr) * DEC_HD + (dt0 + d) * 16 + fg * 4;      // 4 consecutive columns stay contiguous in fragment order
+            *reinterpret_cast<uint2*>(p.out + (p.out_tiled ? tiled_offset((size_t)b, (size_t)col, (size_t)p.out_stride) : (size_t)b * p.out_stride + col)) = v;
         }
     }
 }

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm(bf16_t* x, const bf16_t* xin, c
 // Decode-sized variant (rows <= 64): one block of 256 threads per row, every load issued up front, so the launch is
 // one memory latency deep instead of a wave-serial chain (6.5 -> ~3.5 us at 32 rows).  H <= 2048, H % 8 == 0.
 __global__ __launch_bounds__(256) void k_rmsnorm_row(bf16_t* x, const bf16_t* xin, const float* part, int ksplit,
-                                                     const bf16_t* w, bf16_t* out, int rows, int H, float eps) {
+                                                     const bf16_t* w, bf16_t* out, int rows, int H, float eps, int out_tiled) {
     __shared__ float wsum[4];
     const int row = blockIdx.x, c = threadIdx.x, nch = H / 8;
     const bool on = c < nch;
@@ -105,7 +105,9 @@ __global__ __launch_bounds__(256) void k_rmsnorm_row(bf16_t* x, const bf16_t* xi
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = wv[e] * rbf(v[e] * rs);
-        *reinterpret_cast<uint4*>(out + (size_t)row * H + c * 8) = uint4{pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+        // fragment order: the 8 consecutive k of one row stay contiguous (16 B), see tiled_offset in common.h
+        bf16_t* dst = out + (out_tiled ? tiled_offset((size_t)row, (size_t)c * 8, (size_t)H) : (size_t)row * H + c * 8);
+        *reinterpret_cast<uint4*>(dst) = uint4{pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
     }
 }
 
@@ -451,21 +453,23 @@ int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, lon
     return 0;
 }
 
-int launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int H, float eps) {
+int launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int H, float eps, int out_tiled) {
     if (rows <= 0) return 0;
     if (H % 8 != 0 || H > 64 * 8 * 12) return -22;
+    if (out_tiled && !(rows <= 64 && H <= 2048 && H % 64 == 0)) return -22;
     dim3 g(cdiv(rows, 4)), b(256);
-    if (rows <= 64 && H <= 2048) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps);
+    if (rows <= 64 && H <= 2048) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps, out_tiled);
     else if (H <= 2048) hipLaunchKernelGGL((k_rmsnorm<4>), g, b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps);
     else hipLaunchKernelGGL((k_rmsnorm<12>), g, b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps);
     SR_CHECK_LAUNCH();
     return 0;
 }
 int launch_resid_rmsnorm(hipStream_t s, bf16_t* x, const float* part, int ksplit, const bf16_t* w, bf16_t* out, int rows,
-                         int H, float eps) {
+                         int H, float eps, int out_tiled) {
     if (rows <= 0) return 0;
     if (H % 8 != 0 || H > 2048) return -22;
-    if (rows <= 64 && ksplit <= 4) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), dim3(256), 0, s, x, (const bf16_t*)x, part, ksplit, w, out, rows, H, eps);
+    if (out_tiled && !(rows <= 64 && ksplit <= 4 && H % 64 == 0)) return -22;
+    if (rows <= 64 && ksplit <= 4) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), dim3(256), 0, s, x, (const bf16_t*)x, part, ksplit, w, out, rows, H, eps, out_tiled);
     else hipLaunchKernelGGL((k_rmsnorm<4>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, (const bf16_t*)x, part, ksplit, w, out, rows, H, eps);
     SR_CHECK_LAUNCH();
     return 0;

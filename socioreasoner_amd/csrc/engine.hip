@@ -280,10 +280,11 @@ void carve(sr_engine* e) {
     const size_t B = c.max_batch;
     e->d_xa = ar.take<bf16_t>(B * H);
     e->d_xb = ar.take<bf16_t>(B * H);
-    e->d_xn = ar.take<bf16_t>(B * H);
+    const size_t Bp = (B + 15) / 16 * 16;           // the fragment-ordered x buffers of the batch > 4 decode path hold whole 16-row groups
+    e->d_xn = ar.take<bf16_t>(Bp * H);
     e->d_qkv = ar.take<bf16_t>(B * e->t_qn);
-    e->d_attn = ar.take<bf16_t>(B * c.t_heads * 128);
-    e->d_act = ar.take<bf16_t>(B * e->t_inter_pad);
+    e->d_attn = ar.take<bf16_t>(Bp * c.t_heads * 128);
+    e->d_act = ar.take<bf16_t>(Bp * e->t_inter_pad);
     e->d_scores = ar.take<bf16_t>(B * c.t_heads * (size_t)c.max_ctx);
     e->d_logits = ar.take<float>(B * c.t_vocab);
     e->d_slabs = ar.take<float>(4 * B * H);
@@ -475,6 +476,12 @@ GemvArgs gv(const bf16_t* x, int ldx, const bf16_t* W, int M, int N, int K, void
 // block); for larger batches every block would have to ingest B rows (+ float32 slabs) before it can start, which was
 // measured slower than two small RMSNorm launches spread over the chip
 bool fused_norms(const sr_engine* e, int B) { return B <= 4 && e->c.t_hidden % 512 == 0; }
+// fragment-ordered activations between the launches of the batch > 4 decode layer (x_tiled): needs whole 64-wide k chunks
+bool x_tiled_ok(const sr_engine* e) {
+    static const char* env = getenv("SR_XTILED");          // tuning hook: 0 = row-major x as in round 1
+    if (env && atoi(env) == 0) return false;
+    return e->c.t_hidden % 64 == 0 && (e->c.t_heads * 128) % 64 == 0 && e->t_inter_pad % 64 == 0 && e->c.t_hidden <= 2048;
+}
 int ks_down(const sr_engine* e, int B) { return (B > 16 && e->t_inter_pad / 64 >= 32) ? 4 : e->ks_down; }
 
 // LM head on B rows of `x` (+ optional pending slabs): float32 logits + per-block argmax partials.
@@ -488,9 +495,11 @@ int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending,
         g.norm_w = e->final_norm; g.eps = c.t_rms_eps;
         if (pending) { g.slabs = e->d_slabs; g.n_slabs = ks_down(e, B); g.x_out = x_alt; }
     } else {
-        if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, ks_down(e, B), e->final_norm, e->d_xn, B, H, c.t_rms_eps));
-        else SR_TRY(launch_rmsnorm(s, x, e->final_norm, e->d_xn, B, H, c.t_rms_eps));
-        g.x = e->d_xn;
+        // batches > 4: the normalised rows are written fragment-ordered, so the GEMV's x loads are 1 KB contiguous
+        const int xt = x_tiled_ok(e) ? 1 : 0;
+        if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, ks_down(e, B), e->final_norm, e->d_xn, B, H, c.t_rms_eps, xt));
+        else SR_TRY(launch_rmsnorm(s, x, e->final_norm, e->d_xn, B, H, c.t_rms_eps, xt));
+        g.x = e->d_xn; g.x_tiled = xt;
     }
     SR_TRY(launch_gemv(s, g, GV_F32));
     return 0;
@@ -503,6 +512,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
     const sr_config& c = e->c;
     const int H = c.t_hidden, QD = c.t_heads * 128;
     const bool fused = fused_norms(e, B);
+    const int xt = (!fused && x_tiled_ok(e)) ? 1 : 0;      // activations handed from launch to launch in fragment order
     bf16_t *x = e->d_xa, *x_alt = e->d_xb;      // k_step gathered the input embedding into d_xa
     bool pending = false;                       // down-projection slabs not yet added to the residual stream
     const float scale = (float)(1.0 / sqrt(128.0));
@@ -516,27 +526,27 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
             gq.norm_w = w.ln1; gq.eps = c.t_rms_eps;
             if (pending) { gq.slabs = e->d_slabs; gq.n_slabs = ks_down(e, B); gq.x_out = x_alt; }
         } else {
-            if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, ks_down(e, B), w.ln1, e->d_xn, B, H, c.t_rms_eps));
-            else SR_TRY(launch_rmsnorm(s, x, w.ln1, e->d_xn, B, H, c.t_rms_eps));
-            gq.x = e->d_xn;
+            if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, ks_down(e, B), w.ln1, e->d_xn, B, H, c.t_rms_eps, xt));
+            else SR_TRY(launch_rmsnorm(s, x, w.ln1, e->d_xn, B, H, c.t_rms_eps, xt));
+            gq.x = e->d_xn; gq.x_tiled = xt;
         }
         SR_TRY(launch_gemv(s, gq, GV_BIAS));
         if (fused && pending) { bf16_t* t = x; x = x_alt; x_alt = t; }     // block 0 wrote the updated stream there
         pending = false;
         DecodeAttnArgs da{e->d_qkv, e->t_qn, e->d_pos, e->d_ctx_len, e->d_slots, e->rope_cos, e->rope_sin, kc, vc, e->d_attn, QD,
-                          B, c.t_heads, c.t_kv_heads, e->t_group, c.max_ctx, scale, e->d_scores};
+                          B, c.t_heads, c.t_kv_heads, e->t_group, c.max_ctx, scale, e->d_scores, xt};
         SR_TRY(launch_attn_decode(s, da));
         GemvArgs go = gv(e->d_attn, QD, w.o_w, B, H, QD, x, H);
-        go.W8 = w.o_w8; go.w_scale = w.o_s;
+        go.W8 = w.o_w8; go.w_scale = w.o_s; go.x_tiled = xt;
         SR_TRY(launch_gemv(s, go, GV_RESID));
         GemvArgs gg = gv(x, H, w.gu_w, B, 2 * e->t_inter_pad, H, e->d_act, e->t_inter_pad);
         gg.W8 = w.gu_w8; gg.w_scale = w.gu_s;
         if (fused) { gg.norm_w = w.ln2; gg.eps = c.t_rms_eps; }
-        else { SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps)); gg.x = e->d_xn; }
+        else { SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt)); gg.x = e->d_xn; gg.x_tiled = xt; gg.out_tiled = xt; }
         SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
         GemvArgs gd = gv(e->d_act, e->t_inter_pad, w.down_w, B, H, e->t_inter_pad, e->d_slabs, H);
         gd.ksplit = ks_down(e, B);
-        gd.W8 = w.down_w8; gd.w_scale = w.down_s;
+        gd.W8 = w.down_w8; gd.w_scale = w.down_s; gd.x_tiled = xt;
         SR_TRY(launch_gemv(s, gd, GV_PARTIAL));
         pending = true;
     }
@@ -1293,6 +1303,7 @@ int sr_op_gemv(const void* x, int ldx, const void* W, int M, int N, int K, void*
     GemvArgs a = gv((const bf16_t*)x, ldx, (const bf16_t*)W, M, N, K, out, (mode & 0xff) == GV_SWIGLU ? N / 2 : N);
     a.ksplit = ksplit;
     a.w_tiled = (mode & 0x100) ? 1 : 0;          // bit 8 of `mode`: W is fragment-ordered (tiled16x64)
+    a.x_tiled = (mode & 0x800) ? 1 : 0;          // bit 11: x is fragment-ordered (tiled16x64 of [ceil16(M), K])
     SR_WRAP(launch_gemv((hipStream_t)stream, a, mode & 0xff));
 }
 int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ldo, int mode, const void* bias,
@@ -1302,6 +1313,8 @@ int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K,
     a.bias = (const bf16_t*)bias; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.slabs = slabs; a.n_slabs = n_slabs;
     a.x_out = (bf16_t*)x_out; a.amax_val = amax_val; a.amax_idx = amax_idx;
     a.w_tiled = (mode & 0x100) ? 1 : 0;
+    a.x_tiled = (mode & 0x800) ? 1 : 0;          // bit 11: x fragment-ordered; bit 12: SWIGLU output fragment-ordered
+    a.out_tiled = (mode & 0x1000) ? 1 : 0;
     SR_WRAP(launch_gemv((hipStream_t)stream, a, mode & 0xff));
 }
 int sr_op_gemv_f32_blocks(int N, int M, int K, int has_norm) { return gemv_f32_blocks(N, M, K, has_norm); }

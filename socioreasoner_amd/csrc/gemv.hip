@@ -226,7 +226,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
         auto fill_x = [&](int u, int c) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                if (xok[mt]) {
+                if (!STAGE && p.x_tiled) {      // fragment-ordered x: 1 KB contiguous per wave instruction; rows >= M of the 16-row group only
+                                                // feed output columns that are never stored
+                    const bf16_t* xt = p.x + ((size_t)(mt * nchunks + c) * 2) * 512 + lane * 8;
+                    xv[u][mt][0] = *reinterpret_cast<const u32x4*>(xt);
+                    xv[u][mt][1] = *reinterpret_cast<const u32x4*>(xt + 512);
+                } else if (xok[mt]) {
                     xv[u][mt][0] = *reinterpret_cast<const u32x4*>(xrow[mt] + (size_t)c * 64);
                     xv[u][mt][1] = *reinterpret_cast<const u32x4*>(xrow[mt] + (size_t)c * 64 + 8);
                 } else {
@@ -334,7 +339,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                     o[r] = rbf(silu_f(g)) * u;
                 }
                 uint2 v = {pack2(o[0], o[1]), pack2(o[2], o[3])};
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * (p.N / 2) + tile * 16 + fg * 4) = v;
+                bf16_t* ob = reinterpret_cast<bf16_t*>(p.out);
+                *reinterpret_cast<uint2*>(ob + (p.out_tiled ? tiled_offset((size_t)m, (size_t)(tile * 16 + fg * 4), (size_t)(p.N / 2))
+                                                            : (size_t)m * (p.N / 2) + tile * 16 + fg * 4)) = v;
             } else if constexpr (MODE == GV_BIAS || MODE == GV_RESID) {
                 const int n = tile * 16 + fg * 4;
                 bf16_t* optr = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n;
@@ -422,7 +429,10 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
                                     : p.W + (size_t)(t16 * 16 + fr) * p.K + kg * 8;
     const size_t w_c = p.w_tiled ? 1024 : 64, w_s = p.w_tiled ? 128 : 16;   // element strides per chunk / per k16 step
     const bool xok = m < p.M;
-    const bf16_t* xbase = p.x + (size_t)(xok ? m : 0) * p.ldx + kg * 8;
+    // fragment-ordered x (x_tiled): element (row m, k = c*64 + st*16 + kg*8 + e) sits at tile (m / 16, c), k-step half kg, lane st*16 + m % 16
+    const bf16_t* xbase = p.x_tiled ? p.x + ((size_t)(m >> 4) * nchunks * 2 + kg) * 512 + (m & 15) * 8
+                                    : p.x + (size_t)(xok ? m : 0) * p.ldx + kg * 8;
+    const size_t x_c = p.x_tiled ? 1024 : 64, x_s = p.x_tiled ? 128 : 16;
 
     u32x4 w[U][4], xv[U][4];
     auto fill = [&](int u, int c) {
@@ -430,7 +440,7 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
         for (int st = 0; st < 4; ++st) w[u][st] = ldg_nt(wbase + (size_t)c * w_c + st * w_s);
 #pragma unroll
         for (int st = 0; st < 4; ++st)
-            xv[u][st] = xok ? *reinterpret_cast<const u32x4*>(xbase + (size_t)c * 64 + st * 16) : u32x4{0, 0, 0, 0};
+            xv[u][st] = (xok || p.x_tiled) ? *reinterpret_cast<const u32x4*>(xbase + (size_t)c * x_c + st * x_s) : u32x4{0, 0, 0, 0};
     };
     f32x16 acc;
 #pragma unroll
@@ -478,8 +488,9 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
                         const float g = rbf(acc[g4 * 4 + r]), u = rbf(acc[(g4 + 2) * 4 + r]);
                         o[r] = rbf(silu_f(g)) * u;
                     }
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * (p.N / 2) + tile * 16 + nl) =
-                        uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                    bf16_t* ob = reinterpret_cast<bf16_t*>(p.out);
+                    *reinterpret_cast<uint2*>(ob + (p.out_tiled ? tiled_offset((size_t)m, (size_t)(tile * 16 + nl), (size_t)(p.N / 2))
+                                                                : (size_t)m * (p.N / 2) + tile * 16 + nl)) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
                 }
             } else if constexpr (MODE == GV_BIAS || MODE == GV_RESID) {
                 const int n = tile * 32 + nl;
@@ -531,143 +542,11 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------- batches 5..32, wide N
-// x shared through LDS.  In k_gemv the 4 waves of a block split K, so every wave fetches its own x fragments from L2: at
-// M = 32 that is 4 KB of x per 2 KB weight chunk on the CU's load path.  Here the 4 waves of a block own 4 DIFFERENT weight
-// tiles over the SAME k range: the block stages each 64-wide x chunk (32 rows x 128 B) once, in groups of 4 chunks, double
-// buffered -- ordinary 16-byte loads issued one group ahead, written to LDS (row stride 144 B) after the current group's
-// MFMAs, one barrier per group -- and every wave reads its B fragments from LDS.  Loads per weight chunk drop from 2 + 4 to
-// 2 + 1/4; the weight stream itself is unchanged (fragment-ordered tiles straight from HBM into a register ring, U chunks
-// deep).  No in-block K reduction; K is split over gridDim.y (PARTIAL) or not at all (SWIGLU).
-template <int MODE, int MT, int U>
-__global__ __launch_bounds__(256) void k_gemvx(GemvArgs p, int ntiles) {
-    constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;
-    constexpr int GC = 4, XS = 72;                       // chunks per x group; LDS row stride in elements (64 + 8 pad)
-    static_assert(U % GC == 0, "ring depth must be a multiple of the x group");
-    __shared__ __attribute__((aligned(16))) bf16_t xs[2][GC][32][XS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fg = lane >> 4;
-    const int tile = blockIdx.x * 4 + wave;              // in units of T tiles
-    const bool active = tile < ntiles;
-    const int nchunks = p.K / 64;
-    const int ks = (MODE == GV_PARTIAL) ? p.ksplit : 1;
-    const int per = (nchunks + ks - 1) / ks;
-    const int c0 = min((MODE == GV_PARTIAL ? (int)blockIdx.y : 0) * per, nchunks), cend = min(c0 + per, nchunks);
-
-    // x staging: thread -> (row, 16-byte piece) of every chunk of a group
-    const int xrow = tid >> 3, xpc = tid & 7;
-    const bool xon = xrow < p.M;
-    const bf16_t* xsrc = p.x + (size_t)(xon ? xrow : 0) * p.ldx + xpc * 8;
-    u32x4 xr[GC];
-    auto load_x = [&](int cg) {                          // chunks cg .. cg + GC - 1
-#pragma unroll
-        for (int j = 0; j < GC; ++j)
-            xr[j] = (xon && cg + j < cend) ? *reinterpret_cast<const u32x4*>(xsrc + (size_t)(cg + j) * 64) : u32x4{0, 0, 0, 0};
-    };
-    auto write_x = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < GC; ++j) *reinterpret_cast<u32x4*>(&xs[buf][j][xrow][xpc * 8]) = xr[j];
-    };
-
-    u32x4 w[U][T][2];
-    const bf16_t* wrow[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) wrow[t] = p.W + (size_t)((active ? tile : 0) * T + t) * 16 * p.K + lane * 8;
-    auto fill_w = [&](int u, int c) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            w[u][t][0] = ldg_nt(wrow[t] + (size_t)c * 1024);
-            w[u][t][1] = ldg_nt(wrow[t] + (size_t)c * 1024 + 512);
-        }
-    };
-    load_x(c0);                                          // oldest loads in flight: the first barrier only waits for these
-    if (active) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (c0 + u < cend) fill_w(u, c0 + u);
-    }
-    write_x(0);
-    __syncthreads();
-
-    f32x4 acc[T][MT];
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    int buf = 0;
-    for (int cb = c0; cb < cend; cb += U) {
-#pragma unroll
-        for (int gg = 0; gg < U / GC; ++gg) {
-            const int cg = cb + gg * GC;
-            if (cg < cend) {
-                const bool more = cg + GC < cend;
-                if (more) load_x(cg + GC);
-                if (active) {
-#pragma unroll
-                    for (int j = 0; j < GC; ++j) {
-                        constexpr int dummy = 0; (void)dummy;
-                        const int u = gg * GC + j, c = cg + j;
-                        if (c < cend) {
-                            u32x4 xv[MT][2];
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) {
-                                const bf16_t* xp = &xs[buf][j][mt * 16 + fr][fg * 16];
-                                xv[mt][0] = *reinterpret_cast<const u32x4*>(xp);
-                                xv[mt][1] = *reinterpret_cast<const u32x4*>(xp + 8);
-                            }
-#pragma unroll
-                            for (int t = 0; t < T; ++t)
-#pragma unroll
-                                for (int mt = 0; mt < MT; ++mt) {
-                                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][0]), as_frag(xv[mt][0]), acc[t][mt], 0, 0, 0);
-                                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w[u][t][1]), as_frag(xv[mt][1]), acc[t][mt], 0, 0, 0);
-                                }
-                            if (c + U < cend) fill_w(u, c + U);
-                        }
-                    }
-                }
-                if (more) {
-                    write_x(buf ^ 1);
-                    __syncthreads();
-                    buf ^= 1;
-                }
-            }
-        }
-    }
-
-    // ---------------------------------------------------------------- epilogue: lane owns batch row mt*16 + fr, columns tile*16 + fg*4 + {0..3}
-    if (!active) return;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = mt * 16 + fr;
-        if (m >= p.M) continue;
-        if constexpr (MODE == GV_SWIGLU) {
-            float o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float g = rbf(acc[0][mt][r]), u = rbf(acc[1][mt][r]);
-                o[r] = rbf(silu_f(g)) * u;
-            }
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * (p.N / 2) + tile * 16 + fg * 4) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
-        } else {
-            float* o = reinterpret_cast<float*>(p.out) + ((size_t)blockIdx.y * p.M + m) * p.N + tile * 16 + fg * 4;
-            *reinterpret_cast<float4*>(o) = float4{acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3]};
-        }
-    }
-}
-
-template <int MODE, int U>
-int launch_x(hipStream_t s, const GemvArgs& a) {
-    constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;
-    const int ntiles = a.N / (16 * T);
-    dim3 grid(cdiv(ntiles, 4), MODE == GV_PARTIAL ? a.ksplit : 1);
-    if (a.M <= 16) hipLaunchKernelGGL((k_gemvx<MODE, 1, U>), grid, dim3(256), 0, s, a, ntiles);
-    else hipLaunchKernelGGL((k_gemvx<MODE, 2, U>), grid, dim3(256), 0, s, a, ntiles);
-    SR_CHECK_LAUNCH();
-    return 0;
-}
-
+// Measured and dropped (round 2): sharing x through LDS at batches 5..32 -- the 4 waves of a block own 4 DIFFERENT weight tiles
+// over the SAME k range, the block stages each 64-wide x chunk once (double-buffered groups of 4 chunks, one barrier per group), so
+// the loads per weight chunk drop from 2 + 4 to 2 + 1/4.  Correct, but slower everywhere: gate/up 25.3 vs 23.1 us at M = 32 (22.0 vs
+// 18.9 at M = 16) with 172 blocks instead of 688, the split-K down-projection 18.6 vs 13.7 us.  Giving every CU several independent
+// waves matters more than the x re-reads; what does help the x path is the fragment-ordered x below (x_tiled).
 template <int MODE, int KP>
 int launch_32(hipStream_t s, const GemvArgs& a) {
     constexpr int TPB = 4 / KP;
@@ -768,6 +647,8 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     if (a.norm_w && !(mode == GV_BIAS || mode == GV_SWIGLU || mode == GV_F32)) return -22;
     if (a.norm_w && !can_stage(a)) return -22;
     if (a.n_slabs > 0 && (!a.norm_w || !a.slabs || !a.x_out)) return -22;
+    if (a.x_tiled && a.norm_w) return -22;                   // fragment-ordered x: the un-staged paths only
+    if (a.out_tiled && (mode != GV_SWIGLU || (a.N / 2) % 64 != 0)) return -22;
     int want = mode == GV_F32 ? 1 : 4;
     static const char* kp_env = getenv("SR_GEMV_KP");          // tuning hook for tools/bench_gemv.py
     if (kp_env && mode != GV_F32) want = atoi(kp_env);
@@ -782,15 +663,6 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
             case GV_RESID: return launch_small<GV_RESID, 4, true>(s, a);
         }
         return -22;
-    }
-    // batches above 4, wide matrices: x shared through LDS (k_gemvx).  SR_GEMVX: bit 0 = gate/up (SWIGLU), bit 1 = split-K
-    // down-projection (PARTIAL); SR_GEMVX_U: weight ring depth in chunks (4 / 8 / 16)
-    static const char* x_env = getenv("SR_GEMVX");
-    static const char* xu_env = getenv("SR_GEMVX_U");
-    const int xmask = x_env ? atoi(x_env) : 0, xu = xu_env ? atoi(xu_env) : 8;
-    if (a.M > 4 && !a.norm_w && a.w_tiled && a.K % 64 == 0) {
-        if (mode == GV_SWIGLU && (xmask & 1)) return xu == 4 ? launch_x<GV_SWIGLU, 4>(s, a) : launch_x<GV_SWIGLU, 8>(s, a);
-        if (mode == GV_PARTIAL && (xmask & 2)) return xu == 4 ? launch_x<GV_PARTIAL, 4>(s, a) : xu == 16 ? launch_x<GV_PARTIAL, 16>(s, a) : launch_x<GV_PARTIAL, 8>(s, a);
     }
     if (use_32(a, mode)) {
         switch (mode) {

@@ -40,6 +40,9 @@ struct GemvArgs {
     int w_tiled;                            // W stored fragment-ordered (tiled16x64) instead of row-major
     const unsigned char* W8;                // non-null: stream THIS fp8 image (tiled8, common.h) instead of W ...
     const float* w_scale;                   // ... and scale output channel n by w_scale[n]
+    int x_tiled;                            // x is stored fragment-ordered (tiled16x64 of a [ceil16(M), K] matrix, common.h): a wave's
+                                            // x load is 1 KB contiguous instead of 16 rows x 64 B (batches > 4, no fused norm)
+    int out_tiled;                          // SWIGLU: write the activation fragment-ordered (it is the next GEMV's x)
 };
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode);
 int gemv_f32_blocks(int N, int M, int K, int has_norm);
@@ -75,15 +78,17 @@ struct DecodeAttnArgs {
     int B, n_q_heads, n_kv_heads, group, ctx_max;
     float scale;
     bf16_t* scores;                       // scratch [B][kvh][group][ctx_max] bf16 between the two decode launches
+    int out_tiled;                        // write `out` fragment-ordered (tiled16x64, K = out_stride): it is the o_proj GEMV's x
 };
 int launch_attn_decode(hipStream_t s, const DecodeAttnArgs& a);
 int attn_decode_prepare(int ctx_max, int group);
 
 // ------------------------------------------------------------------ elementwise.hip
-int launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int H, float eps);
+// out_tiled (decode rows only): `out` is written fragment-ordered (tiled16x64 of [ceil16(rows), H]) for the consuming GEMV
+int launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int H, float eps, int out_tiled = 0);
 // h = r(x + r(sum_ks part[ks] + bias)) written back to x; out = rmsnorm(h) * w.   part may be null (plain norm).
 int launch_resid_rmsnorm(hipStream_t s, bf16_t* x, const float* part, int ksplit, const bf16_t* w, bf16_t* out,
-                         int rows, int H, float eps);
+                         int rows, int H, float eps, int out_tiled = 0);
 int launch_vit_rope(hipStream_t s, bf16_t* qkv, int n_rows, int n_heads, int head_dim, const float* cos_t,
                     const float* sin_t, bf16_t* vt, int vt_stride);
 // prefill: rope q,k in place in qkv [T, (Hq+2Hkv)*128]; write K / V^T into the cache at (slot, pos_in_seq)

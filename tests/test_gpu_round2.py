@@ -196,3 +196,96 @@ print("RCCL_OK", json.dumps(info))
     env["NCCL_DEBUG_FILE"] = env["SR_RCCL_LOG"]
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ fragment-ordered x (batch > 4 decode)
+def untile16x64(t: torch.Tensor, N: int, K: int) -> torch.Tensor:
+    return t.reshape(N // 16, K // 64, 2, 4, 16, 8).permute(0, 4, 1, 3, 2, 5).reshape(N, K)
+
+
+@pytest.mark.parametrize("M", [5, 16, 17, 32])
+def test_gemv_fragment_ordered_x_equals_row_major(L, M):
+    """The batch > 4 decode layer hands activations from launch to launch in fragment order (x_tiled / out_tiled): same
+    arithmetic, different addresses -> every mode must give exactly the bits of the row-major call."""
+    GV_PARTIAL, GV_SWIGLU, GV_F32, GV_BIAS, GV_RESID = range(5)
+    XT, OT = 0x800, 0x1000
+    Mp = (M + 15) // 16 * 16
+    eps = C.c_float(1e-6)
+    for (mode, N, K, ks) in [(GV_BIAS, 2560, 2048, 1), (GV_RESID, 2048, 2048, 1), (GV_SWIGLU, 22016, 2048, 1), (GV_PARTIAL, 2048, 11008, 2),
+                             (GV_PARTIAL, 2048, 11008, 4), (GV_F32, 8192, 2048, 1)]:
+        x = rnd((M, K), 21 + M)
+        w = tile16x64(rnd((N, K), 22, 0.03)).cuda()
+        xp = torch.zeros(Mp, K, dtype=torch.bfloat16)
+        xp[:M] = x
+        xt = tile16x64(xp).cuda()
+        xd = x.cuda()
+        bias = rnd((N,), 23, 0.1).cuda() if mode == GV_BIAS else None
+        outs = []
+        for tiled in (False, True):
+            No = N // 2 if mode == GV_SWIGLU else N
+            if mode == GV_PARTIAL:
+                out = torch.zeros(ks, M, N, dtype=torch.float32, device="cuda")
+            elif mode == GV_F32:
+                out = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+            elif mode == GV_RESID:
+                out = rnd((M, N), 24).cuda()
+            else:
+                out = torch.zeros(Mp if (tiled and mode == GV_SWIGLU) else M, No, dtype=torch.bfloat16, device="cuda")
+            flags = mode | TILED | ((XT | (OT if mode == GV_SWIGLU else 0)) if tiled else 0)
+            if mode == GV_PARTIAL:
+                rc = L.sr_op_gemv(P(xt if tiled else xd), K, P(w), M, N, K, P(out), ks, flags, sp())
+            else:
+                rc = L.sr_op_gemv_fused(P(xt if tiled else xd), K, P(w), M, N, K, P(out), No, flags, P(bias), None, eps, None, 0, None, None, None, sp())
+            assert rc == 0, (mode, tiled)
+            torch.cuda.synchronize()
+            if tiled and mode == GV_SWIGLU:
+                out = untile16x64(out.reshape(-1), Mp, No)[:M].contiguous()
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), (M, mode, float((outs[0].float() - outs[1].float()).abs().max()))
+        assert float(outs[0].float().abs().max()) > 0
+
+
+def test_full_depth_batch32_decode_vs_hf(golden_dir):
+    """The batch-32 decode kernels (un-staged GEMV family on fragment-ordered activations, 32-row LM head, 2-d-tile attention)
+    at FULL depth against HF: BASELINE.json's tile in rows 0 and 31 of a 32-row batch (other rows: different tiles),
+    teacher-forced on HF's tokens -- same bands as the batch-1 test."""
+    from socioreasoner_amd import hostops, synthetic
+    from socioreasoner_amd.config import geometry_3b
+    from socioreasoner_amd.engine import Engine
+    from tests.test_gpu_hf_parity import stats, record
+    from tests.util import bits_to_f32
+    g = np.load(os.path.join(golden_dir, "hf_full3b.npz"))
+    G = int(g["g_new"][0])
+    geom = geometry_3b()
+    B = 32
+    e = Engine(geom, max_patches=1024 * 4, max_prefill_tokens=448 * B, max_batch=B, max_ctx=512, max_new_tokens=G)
+    e.load_synthetic_weights(seed=0)
+    grid = (1, 32, 32)
+    rows = [0, 1, 2, 3] * 7 + [1, 2, 3, 0]                     # tile of every row; rows 0 and 31 carry the fixture's tile 0
+    embs = e.vit_forward(torch.cat([e.patchify(torch.from_numpy(synthetic.tile_pixels(i)).cuda()) for i in range(4)], dim=0), [grid] * 4)
+    emb = torch.cat([embs[r * 256:(r + 1) * 256] for r in rows], dim=0)
+    ids, pos = [], []
+    for r in rows:
+        x = synthetic.tile_prompt(geom, r, grid)
+        p, _ = hostops.get_rope_index(torch.from_numpy(x)[None], [grid], None)
+        ids.append(x)
+        pos.append(p[:, 0].numpy())
+    assert np.array_equal(ids[0], g["tile448_ids"])
+    logits = e.prefill(ids, pos, emb, return_logits=True)
+    hf_tokens = g["tile448_tokens"].tolist()
+    forced = torch.tensor([hf_tokens] * B, dtype=torch.int32)
+    _, trace = e.decode(G, trace=True, forced=forced, use_graph=False)
+    stride = int(g["stride"][0])
+    oracle_l = g["tile448_oracle_logits_last"]
+    worst = {"rms": 0.0, "max": 0.0, "bias": 0.0}
+    for row in (0, 31):
+        s0 = stats(logits[row], bits_to_f32(g["tile448_logits_last"]))
+        assert s0["rms"] <= 1.5 * oracle_l[1] and abs(s0["bias"]) <= 2e-3, s0
+        for k in range(G - 1):
+            lg = trace[k + 1, row].cpu()
+            st = stats(lg[::stride], bits_to_f32(g["tile448_sample"][k]))
+            assert st["rms"] <= 1.6 * oracle_l[1] and st["max"] <= 2.0 * oracle_l[0] and abs(st["bias"]) <= 3e-3, (row, k, st)
+            worst = {"rms": max(worst["rms"], st["rms"]), "max": max(worst["max"], st["max"]), "bias": max(worst["bias"], abs(st["bias"]))}
+    assert torch.equal(trace[:, 0], trace[:, 31])              # same tile, same tokens -> same bits in both rows
+    record("full3b_tile448_batch32_decode", worst)
+    e.close()
