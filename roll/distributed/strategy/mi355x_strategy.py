@@ -74,8 +74,11 @@ class Mi355xStrategy(InferenceStrategy):
         # 6144 tokens = 7 GB of the 288 GB)
         max_ctx = int(sc.get("max_ctx", min(prompt_len + resp_len, 8192)))
         max_ctx = (max_ctx + 63) // 64 * 64
-        self.engine = Engine(self.geom, max_patches=int(sc.get("max_patches", 2048 * 2 * 4)),
-                             max_prefill_tokens=int(sc.get("max_prefill_tokens", min(prompt_len, 1024) * 8)),
+        # ViT / prefill capacities follow the batch: the shipped workload feeds TWO images of up to 756 x 756 (2916 patches, 729
+        # image tokens each) per sample, so a full batch of max_batch samples must fit one admission (otherwise decode would run
+        # with a fraction of its rows filled)
+        self.engine = Engine(self.geom, max_patches=int(sc.get("max_patches", self.max_batch * 2 * 2916)),
+                             max_prefill_tokens=int(sc.get("max_prefill_tokens", min(prompt_len, 2048) * self.max_batch)),
                              max_batch=self.max_batch, max_ctx=max_ctx, max_new_tokens=min(resp_len, max_ctx - 1),
                              lm_fp8=str(sc.get("quantization", "") or "").lower() in ("fp8", "fp8_e4m3"),   # vLLM's knob name
                              device=f"cuda:{int(_get(getattr(self.worker, 'rank_info', None), 'local_rank', 0) or 0)}")
@@ -106,25 +109,47 @@ class Mi355xStrategy(InferenceStrategy):
     # ------------------------------------------------------------------ trainer -> engine weight sync (reference
     # vllm_strategy.py:258-271 -> worker_helper.py:64-115).  The sender is rank `src_rank` of a torch.distributed group
     # (RCCL over xGMI on the node); with no group the update_* entry points can still be fed directly.
-    def setup_collective_group(self, comm_plan=None, backend=None, rank_in_cluster=None, group=None, src_rank: int = 0):
-        self._sync_group, self._sync_src = group, int(src_rank)
-        return None
-
-    def _bcast(self, t: torch.Tensor):
+    def setup_collective_group(self, comm_plan, backend="nccl", rank_in_cluster=None):
+        """Reference contract (strategy.py:85-113, third_party/vllm/worker_helper.py:68-92): find this worker in the comm plan,
+        join the named group of its broadcast tree (RCCL over xGMI on the node; rank 0 = the trainer rank that owns the
+        weights), warm the group up with one tiny all-reduce, remember the plan under its source pipeline rank."""
         import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError("broadcast_* needs torch.distributed (torchrun); use update_parameter* to feed tensors directly")
-        grp = getattr(self, "_sync_group", None)
-        xt = t.cpu() if dist.get_backend(grp) == "gloo" else t
-        dist.broadcast(xt, src=getattr(self, "_sync_src", 0), group=grp)
-        return xt.to(t.device)
+        from socioreasoner_amd.sync_group import join_named_group
+        self.model_update_comm_plan = getattr(self, "model_update_comm_plan", {})
+        me = int(getattr(self.worker, "rank", 0) or 0) if rank_in_cluster is None else int(rank_in_cluster)
+        rank, args = hostops.get_dist_info_from_comm_plan(comm_plan, rank_in_cluster=me, rank_in_worker=0)
+        if rank is None:
+            logger.info("no comm_plan found for rank %s/0", me)
+            return
+        world = len(args["tgt_devices"]) + 1
+        grp = join_named_group(args["group_name"], backend, world, rank, args["master_addr"], args["master_port"])
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        dist.all_reduce(torch.zeros(1, device=dev), group=grp)                 # warm-up, like the reference
+        self.model_update_comm_plan[args["src_pp_rank"]] = dict(rank=rank, world_size=world, src_pp_rank=args["src_pp_rank"],
+                                                                group_name=args["group_name"], comm_plan=comm_plan, comm_plan_args=args,
+                                                                group=grp, device=dev)
+        logger.info("joined %s as rank %d of %d", args["group_name"], rank, world)
+
+    def _bcast(self, src_pp_rank, t: torch.Tensor):
+        import torch.distributed as dist
+        plan = getattr(self, "model_update_comm_plan", {}).get(src_pp_rank)
+        if plan is None:
+            return None                          # this engine rank is not a receiver of that pipeline stage (reference: silent no-op)
+        xt = t.to(plan["device"])
+        dist.broadcast(xt, src=0, group=plan["group"])
+        return xt
 
     def broadcast_bucket(self, src_pp_rank, meta_infos, bucket_size):
-        buf = torch.empty(int(bucket_size), dtype=torch.int8, device="cuda")
-        self.update_parameter_in_bucket(meta_infos, self._bcast(buf), None)
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        buf = self._bcast(src_pp_rank, torch.empty(int(bucket_size), dtype=torch.int8, device=dev))
+        if buf is not None:
+            self.update_parameter_in_bucket(meta_infos, buf, [0])
 
     def broadcast_parameter(self, src_pp_rank, dtype, shape, parameter_name):
-        self.update_parameter(parameter_name, self._bcast(torch.empty(tuple(shape), dtype=dtype, device="cuda")), None)
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        w = self._bcast(src_pp_rank, torch.empty(tuple(shape), dtype=dtype, device=dev))
+        if w is not None:
+            self.update_parameter(parameter_name, w, [0])
 
     def update_parameter(self, parameter_name, weight, ranks_in_worker=None):
         self.engine.load_weight(parameter_name, weight)
@@ -260,7 +285,30 @@ class Mi355xStrategy(InferenceStrategy):
             imgs = (mm[i].get("multi_modal_data") or {}).get("image") if mm is not None else None
             prepared.append(self._prepare(ids_i, imgs))
         i = 0
-        while i < B:                                  # groups bounded by the engine capacities
+        tk = gc.get("top_k", -1)
+        on_device = not greedy and tk is not None and 1 <= int(tk) <= 1024 and float(gc.get("temperature", 1.0)) > 1e-5
+        rp1 = float(gc.get("repetition_penalty", 1.0) or 1.0) == 1.0
+        if greedy or (on_device and rp1 and n == 1):
+            # the stages are decoupled: the scheduler admits the prompts in capacity-sized groups (ViT + prefill into free KV rows)
+            # and ALL filled rows decode together -- a batch larger than one admission, or than max_batch, still decodes at full
+            # width, and rows freed by short answers are refilled at once (socioreasoner_amd/serving.py)
+            from socioreasoner_amd.serving import ContinuousBatcher, Request
+            smp = None if greedy else {"temperature": float(gc.get("temperature", 1.0)), "top_k": int(tk), "top_p": float(gc.get("top_p", 1.0) or 1.0),
+                                       "seed": int(gc.get("seed", 0) or 0) * 1000003 + 7919 * int(getattr(self.worker, "rank", 0) or 0)}
+            reqs = []
+            for k in range(B):
+                ids_k, pos_k, ims_k, grids_k = prepared[k]
+                room = self.engine.cfg.max_ctx - len(ids_k)
+                if room < 1:
+                    raise ValueError(f"prompt of {len(ids_k)} tokens leaves no room in max_ctx {self.engine.cfg.max_ctx}")
+                reqs.append(Request(ids=ids_k, pos3=pos_k, max_new=max(1, min(max_new, room)), images=ims_k, grids=grids_k))
+            outs = ContinuousBatcher(self.engine, eos, pad, sampling=smp).run(reqs)
+            for k in range(B):
+                row = [int(t) for t in outs[k]]
+                cut = next((j + 1 for j, t in enumerate(row) if t in eos), len(row))
+                results[k] = [row[:cut]] * n
+            i = B
+        while i < B:                                  # static batches (repetition penalty, unbounded top-k, n > 1 sampled sequences)
             grp, ntok, npatch = [], 0, 0
             while i < B and len(grp) < self.max_batch:
                 ids_i, _, _, grids = prepared[i]
@@ -283,14 +331,9 @@ class Mi355xStrategy(InferenceStrategy):
             if room < 1:
                 raise ValueError(f"prompt of {self.engine.cfg.max_ctx - room} tokens leaves no room in max_ctx {self.engine.cfg.max_ctx}")
             max_new_g = min(max_new, room)
-            tk = gc.get("top_k", -1)
-            on_device = not greedy and tk is not None and 1 <= int(tk) <= 1024 and float(gc.get("temperature", 1.0)) > 1e-5
-            for rep in range(1 if greedy else n):
-                logits = self.engine.prefill([prepared[k][0] for k in grp], [prepared[k][1] for k in grp], emb,
-                                             return_logits=not greedy and not on_device)
-                if greedy:
-                    toks = self.engine.decode(max_new_g, eos=eos, pad_id=pad).cpu().tolist()
-                elif on_device:          # k_sample inside the captured decode step
+            for rep in range(n):
+                logits = self.engine.prefill([prepared[k][0] for k in grp], [prepared[k][1] for k in grp], emb, return_logits=not on_device)
+                if on_device:          # k_sample inside the captured decode step
                     seed = int(gc.get("seed", 0) or 0) * 1000003 + 7919 * int(getattr(self.worker, "rank", 0) or 0) + 104729 * rep + grp[0]
                     toks = self.engine.decode_sample(max_new_g, float(gc.get("temperature", 1.0)), int(tk), float(gc.get("top_p", 1.0) or 1.0),
                                                      float(gc.get("repetition_penalty", 1.0) or 1.0), seed, eos=eos, pad_id=pad).cpu().tolist()
@@ -299,9 +342,6 @@ class Mi355xStrategy(InferenceStrategy):
                 for row, k in zip(toks, grp):
                     cut = next((j + 1 for j, t in enumerate(row) if t in eos), len(row))
                     results[k].append(row[:cut])
-            if greedy:                                           # the n sequences of a prompt are identical
-                for k in grp:
-                    results[k] = results[k] * n
         results = [r for rs in results for r in rs]
         output_ids = hostops.gather_outputs_to_pad_tensor(results, pad, device=input_ids.device)
         return hostops.concatenate_input_and_output(input_ids, output_ids, n)

@@ -207,3 +207,15 @@ def compute_giou(pred_mask: np.ndarray, gt_mask: np.ndarray) -> float:
     if union == 0:
         return 1.0
     return np.logical_and(p, g).sum() / union
+
+
+def get_dist_info_from_comm_plan(comm_plan: Dict[Any, Dict[str, Any]], rank_in_cluster: int, rank_in_worker: int):
+    """Which broadcast tree of a model-update comm plan this (engine worker, device) belongs to and at which group rank
+    (reference roll/utils/functionals.py:875-882): group rank 0 is the sending trainer rank, rank i >= 1 is the i-th entry of
+    ``tgt_devices`` = {"rank": worker rank in the target cluster, "device": {"rank": device index inside that worker, ...}}.
+    -> (group rank, that tree's comm_plan_args) or (None, None)."""
+    for args in comm_plan.values():
+        for pos, tgt in enumerate(args["tgt_devices"], start=1):
+            if tgt["rank"] == rank_in_cluster and tgt["device"]["rank"] == rank_in_worker:
+                return pos, args
+    return None, None

@@ -485,3 +485,73 @@ def test_forward_step_all_position_logits(golden_dir=os.path.join(os.path.dirnam
         assert float(d.max()) <= 0.06 and float(d.mean()) <= 0.01, (i, float(d.max()), float(d.mean()))
     assert torch.equal(got[0], got[2])
     st.engine.close()
+
+
+def test_generate_decouples_admission_from_decode_and_server_survives_abort_bursts(tmp_path):
+    """(1) A batch that does not fit ONE ViT / prefill admission (capacity for 2 image prompts, 4 batch rows, 7 prompts) still
+    decodes at full width: generate() hands the prompts to the scheduler, every row equals the single-prompt call.
+    (2) The request-level server keeps running when the same request is ABORTed repeatedly while its row is decoding
+    (ROLL schedulers send ABORTs in bursts); the other requests complete, the aborted one reports nothing."""
+    import queue
+    import threading
+    from roll.distributed.scheduler.protocol import DataProto
+    from roll.distributed.strategy.factory import create_strategy
+    from roll.pipeline.rlvr.rlvr_socioseg_vlm_pipeline_infer import _Worker
+    from roll.utils.functionals import GenerateRequestType
+    from socioreasoner_amd import synthetic
+    cfg = _cfg(tmp_path, resp=12)
+    cfg.actor_infer.strategy_args.strategy_config.update({"max_batch": 4, "max_patches": 2048, "max_prefill_tokens": 1000})
+    st = create_strategy(_Worker(cfg.actor_infer, cfg, 0, 1, 0))
+    st.initialize(None)
+    g = st.geom
+    P, pad = 500, g.pad_token_id
+    rows, payload = [], np.empty(7, dtype=object)
+    for i in range(7):
+        ids = synthetic.tile_prompt(g, i, (1, 32, 32), n_pre=8 + i, n_post=6)
+        payload[i] = {"prompt_token_ids": ids.tolist(), "multi_modal_data": {"image": [synthetic.tile_pixels(i)]}}
+        row = np.full(P, pad, dtype=np.int64)
+        row[P - len(ids):] = ids
+        rows.append(row)
+    input_ids = torch.from_numpy(np.stack(rows))
+    gc = {"max_new_tokens": 12, "temperature": 0, "top_p": 1.0, "top_k": 1, "num_beams": 1, "repetition_penalty": 1.0,
+          "num_return_sequences": 1, "eos_token_id": [g.eos_token_id], "pad_token_id": pad}
+
+    def batch_of(sel):
+        return DataProto(batch={"input_ids": input_ids[sel], "attention_mask": (input_ids[sel] != pad).long()},
+                         non_tensor_batch={"multi_modal_data": payload[sel]})
+    out = st.generate(batch_of(slice(0, 7)), gc)
+    assert out.shape[0] == 7
+    for k in (0, 3, 6):
+        one = st.generate(batch_of(slice(k, k + 1)), gc)
+        L = min(out.shape[1], one.shape[1])
+        assert torch.equal(one[0, P:L], out[k, P:L]), k
+    # ---- (2) abort bursts against running rows
+    done = queue.Queue()
+    err = []
+
+    def loop():
+        try:
+            torch.cuda.set_device(st.engine.device)
+            st.start_server(data=None, request_complete_callback=lambda data: done.put(data.meta_info["request_id"]))
+        except BaseException as e:  # noqa: BLE001
+            err.append(e)
+    th = threading.Thread(target=loop, daemon=True)
+    th.start()
+    long_gc = dict(gc, max_new_tokens=12)
+    for k in range(5):
+        req = batch_of(slice(k, k + 1))
+        req.meta_info = {"request_id": f"r{k}", "generation_config": long_gc}
+        st.add_request(GenerateRequestType.ADD, req)
+    import time
+    time.sleep(0.05)                                  # rows are decoding now
+    for _ in range(4):                                # a burst naming a running row (and once a row that never existed)
+        st.add_request(GenerateRequestType.ABORT, DataProto(meta_info={"request_id": "r1"}))
+    st.add_request(GenerateRequestType.ABORT, DataProto(meta_info={"request_id": "nope"}))
+    st.add_request(GenerateRequestType.STOP, None)
+    th.join(timeout=120)
+    assert not th.is_alive() and not err, err
+    got = set()
+    while not done.empty():
+        got.add(done.get())
+    assert {"r0", "r2", "r3", "r4"} <= got and len(got) in (4, 5)      # r1 is dropped unless it finished before the burst arrived
+    st.engine.close()

@@ -384,6 +384,124 @@ def test_actor_worker_and_scheduler_with_fake_strategy(tmp_path):
     assert out2.batch["responses"].shape[0] == 10 and torch.equal(out2.batch["responses"][0::2], out0.batch["responses"])
 
 
+def test_weight_sync_receiver_on_buckets_packed_by_the_reference(golden_dir):
+    """N4 pinned to the reference: tests/golden/weight_sync.* holds buckets + meta_infos produced by EXECUTING the
+    reference's SendBucketManager / TensorBucket (tools/make_golden.py gen_weight_sync) on a mixed-dtype tensor set whose
+    members straddle bucket boundaries.  The receiver reassembles every tensor bit for bit -- and this repo's own packer
+    emits the very same buckets and metas; the comm-plan lookup equals the reference function's answers."""
+    import json
+    import torch
+    from socioreasoner_amd import hostops
+    from socioreasoner_amd.weight_sync import BucketReceiver, BucketSender
+    j = json.load(open(os.path.join(golden_dir, "weight_sync.json")))
+    z = np.load(os.path.join(golden_dir, "weight_sync.npz"))
+    dt = lambda s_: getattr(torch, s_.split(".")[1])
+    rcv, got = BucketReceiver(), {}
+    for i, meta in enumerate(j["metas"]):
+        wire = {k: dict(v, tensor_meta={"shape": v["tensor_meta"]["shape"], "dtype": dt(v["tensor_meta"]["dtype"])}) for k, v in meta.items()}
+        got.update(rcv.process_bucket(wire, torch.from_numpy(z[f"bucket{i}"].view(np.int8).copy())))
+    rcv.clear()
+    assert list(got) == list(j["tensors"])                             # completion order = the sender's push order
+    for name, spec in j["tensors"].items():
+        assert list(got[name].shape) == spec["shape"] and str(got[name].dtype) == spec["dtype"]
+        assert np.array_equal(got[name].contiguous().view(-1).view(torch.uint8).numpy(), z["tensor_" + name]), name
+    # our packer against the reference's, byte for byte
+    snd, k = BucketSender(j["bucket_size"]), 0
+
+    def check(meta, buf, nbytes):
+        nonlocal k
+        assert np.array_equal(buf[:nbytes].numpy().view(np.uint8), z[f"bucket{k}"]), k
+        assert {n: (m["bucket_start"], m["tensor_start"], m["save_bytes"], list(m["tensor_meta"]["shape"]), str(m["tensor_meta"]["dtype"])) for n, m in meta.items()} == \
+            {n: (m["bucket_start"], m["tensor_start"], m["save_bytes"], m["tensor_meta"]["shape"], m["tensor_meta"]["dtype"]) for n, m in j["metas"][k].items()}, k
+        k += 1
+    for name in j["tensors"]:
+        for meta, buf in snd.push(name, got[name]):
+            check(meta, buf, j["bucket_size"])
+    last_bytes = snd.write
+    meta, buf = snd.flush()
+    if meta:
+        check(meta, buf, last_bytes)
+    assert k == len(j["metas"])
+    for q in j["lookups"]:
+        r, a = hostops.get_dist_info_from_comm_plan(j["comm_plan"], rank_in_cluster=q["rank_in_cluster"], rank_in_worker=q["rank_in_worker"])
+        assert r == q["rank"] and (None if a is None else a["group_name"]) == q["group_name"], q
+
+
+_SYNC_WORKER = r"""
+import os, sys, json, numpy as np, torch
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from socioreasoner_amd.sync_group import join_named_group
+from socioreasoner_amd.weight_sync import BucketSender
+rank = int(os.environ["SYNC_RANK"])
+plan = {{"0": {{"group_name": "model_update_train_0_to_infer_(0,0)-(1,0)", "master_addr": "127.0.0.1", "master_port": {port}, "src_pp_rank": 0, "src_rank": 0,
+               "tgt_devices": [{{"rank": 0, "device": {{"rank": 0}}}}, {{"rank": 1, "device": {{"rank": 0}}}}]}}}}
+g = torch.Generator().manual_seed(5)
+tensors = {{"model.layers.0.mlp.down_proj.weight": torch.randn(64, 33, generator=g).to(torch.bfloat16), "model.norm.weight": torch.randn(700, generator=g)}}
+BS = 2048
+if rank == 0:            # the trainer side: hosts the group, packs, broadcasts every bucket's bytes (metas travel by RPC in the reference)
+    grp = join_named_group(plan["0"]["group_name"], "gloo", 3, 0, "127.0.0.1", {port})
+    dist.all_reduce(torch.zeros(1), group=grp)
+    snd = BucketSender(BS)
+    def send(meta, buf):
+        dist.broadcast(buf.clone(), src=0, group=grp)
+    for n, t in tensors.items():
+        for meta, buf in snd.push(n, t):
+            send(meta, buf)
+    meta, buf = snd.flush()
+    if meta:
+        send(meta, buf)
+    p = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    dist.broadcast(p, src=0, group=grp)
+    print("sync ok 0")
+else:                    # an engine rank: the strategy's hooks with a recording engine (no GPU here)
+    from roll.distributed.strategy.mi355x_strategy import Mi355xStrategy
+    class Eng:
+        def __init__(self): self.got = {{}}
+        def load_weight(self, name, t): self.got[name] = t.clone()
+        def assert_ready(self): pass
+    class W:
+        rank = rank - 1
+        worker_config = None
+    st = Mi355xStrategy(W())
+    st.engine = Eng()
+    st.setup_collective_group(plan, backend="gloo")
+    assert st.model_update_comm_plan[0]["rank"] == rank and st.model_update_comm_plan[0]["world_size"] == 3
+    snd = BucketSender(BS)                       # metas: recomputed here from the same tensors (deterministic packer)
+    metas = []
+    for n, t in tensors.items():
+        for meta, buf in snd.push(n, t):
+            metas.append({{k: dict(v) for k, v in meta.items()}})
+    meta, buf = snd.flush()
+    if meta:
+        metas.append({{k: dict(v) for k, v in meta.items()}})
+    for m in metas:
+        st.broadcast_bucket(0, m, BS)
+    st.broadcast_bucket(7, metas[0], BS)        # a pipeline stage this rank does not receive from: silent no-op
+    st.broadcast_parameter(0, torch.float32, (3, 4), "extra.weight")
+    st._finish_weight_update()
+    assert set(st.engine.got) == set(tensors) | {{"extra.weight"}}
+    for n, t in tensors.items():
+        assert torch.equal(st.engine.got[n], t) and st.engine.got[n].dtype == t.dtype, n
+    assert torch.equal(st.engine.got["extra.weight"], torch.arange(12, dtype=torch.float32).reshape(3, 4))
+    print("sync ok", rank)
+"""
+
+
+def test_weight_sync_over_a_named_group_three_ranks_gloo(tmp_path):
+    """setup_collective_group(comm_plan, backend) -> join the plan's named group (rank 0 = trainer, ranks 1.. = tgt_devices in
+    order), warm-up all-reduce, then broadcast_bucket / broadcast_parameter receive over that group and feed the engine's
+    weight loader.  Three processes, gloo, no default process group anywhere (the trainer and the engines live in different
+    worlds in the reference too)."""
+    script = tmp_path / "s.py"
+    script.write_text(_SYNC_WORKER.format(root=ROOT, port=29571))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, SYNC_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(3)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert sum("sync ok" in o for o in outs) == 3
+
+
 def test_weight_sync_buckets_round_trip():
     """N4: tensors of mixed dtype / size packed into fixed-size int8 buckets (pieces split across buckets) are reassembled
     bit for bit, in arrival order, and a missing piece is detected."""

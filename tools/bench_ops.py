@@ -82,24 +82,34 @@ def bench_gemv(Ms):
     wo = torch.empty(nl, H, H, dtype=torch.bfloat16, device=dev).normal_(0, 0.02)
     wg = torch.empty(nl, 2 * I, H, dtype=torch.bfloat16, device=dev).normal_(0, 0.02)
     wd = torch.empty(nl, H, I, dtype=torch.bfloat16, device=dev).normal_(0, 0.02)
+    wv = torch.empty(2, V, H, dtype=torch.bfloat16, device=dev).normal_(0, 0.02)
     eps = C.c_float(1e-6)
     TL = 0x100
     for M in Ms:
-        x = torch.empty(M, I, dtype=torch.bfloat16, device=dev).normal_(0, 1)
-        part = torch.empty(4, M, QN, dtype=torch.float32, device=dev)
-        act = torch.empty(M, I, dtype=torch.bfloat16, device=dev)
+        part = torch.empty(8, M, QN, dtype=torch.float32, device=dev)
         nw = torch.ones(H, dtype=torch.bfloat16, device=dev)
         bq = torch.zeros(QN, dtype=torch.bfloat16, device=dev)
         qkv_o = torch.empty(M, QN, dtype=torch.bfloat16, device=dev)
         xr = torch.zeros(M, H, dtype=torch.bfloat16, device=dev)
         fused = M <= 4
-        ksd = 4 if M > 16 else 2
+        ksd = int(os.environ.get("SR_BENCH_KSD", "4" if M > 16 else "2"))
         s = stream()
+        # batches > 4: activations travel in fragment order (engine.hip x_tiled); the values are random either way.  x / act are
+        # over-allocated to 32 rows so that the tiled addressing of a 16-row group stays in bounds
+        XT = 0x800 if (M > 4 and os.environ.get("SR_XTILED", "1") != "0") else 0
+        OT = 0x1000 if XT else 0
+        x = torch.empty(32, I, dtype=torch.bfloat16, device=dev).normal_(0, 1)
+        act = torch.empty(32, I, dtype=torch.bfloat16, device=dev).normal_(0, 1)
+        nbv = lib.sr_op_gemv_f32_blocks(V, M, H, 1 if fused else 0)
+        av = torch.empty(M, nbv, dtype=torch.float32, device=dev)
+        ai = torch.empty(M, nbv, dtype=torch.int32, device=dev)
+        lg = torch.empty(M, V, dtype=torch.float32, device=dev)
         ops = {
-            "qkv": (lambda l: lib.sr_op_gemv_fused(P(x), I, P(wq[l]), M, QN, H, P(qkv_o), QN, 3 | TL, P(bq), P(nw) if fused else None, eps, None, 0, None, None, None, s), QN * H * 2),
-            "o": (lambda l: lib.sr_op_gemv_fused(P(x), I, P(wo[l]), M, H, H, P(xr), H, 4 | TL, None, None, eps, None, 0, None, None, None, s), H * H * 2),
-            "gate_up": (lambda l: lib.sr_op_gemv_fused(P(x), I, P(wg[l]), M, 2 * I, H, P(act), I, 1 | TL, None, P(nw) if fused else None, eps, None, 0, None, None, None, s), 2 * I * H * 2),
-            "down": (lambda l: lib.sr_op_gemv(P(act), I, P(wd[l]), M, H, I, P(part), ksd, 0 | TL, s), H * I * 2),
+            "qkv": (lambda l: lib.sr_op_gemv_fused(P(x), H, P(wq[l]), M, QN, H, P(qkv_o), QN, 3 | TL | XT, P(bq), P(nw) if fused else None, eps, None, 0, None, None, None, s), QN * H * 2),
+            "o": (lambda l: lib.sr_op_gemv_fused(P(x), H, P(wo[l]), M, H, H, P(xr), H, 4 | TL | XT, None, None, eps, None, 0, None, None, None, s), H * H * 2),
+            "gate_up": (lambda l: lib.sr_op_gemv_fused(P(x), H, P(wg[l]), M, 2 * I, H, P(act), I, 1 | TL | XT | OT, None, P(nw) if fused else None, eps, None, 0, None, None, None, s), 2 * I * H * 2),
+            "down": (lambda l: lib.sr_op_gemv(P(act), I, P(wd[l]), M, H, I, P(part), ksd, 0 | TL | XT, s), H * I * 2),
+            "head": (lambda l: lib.sr_op_gemv_fused(P(x), H, P(wv[l % 2]), M, V, H, P(lg), V, 2 | TL | XT, None, P(nw) if fused else None, eps, None, 0, None, P(av), P(ai), s), V * H * 2),
         }
         for name, (fn, nbytes) in ops.items():
             # one hipGraph of nl launches of this op (distinct weights each): replayed, so that the host launch cost (ctypes +

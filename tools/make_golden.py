@@ -43,7 +43,7 @@ def extract(path, names, ns):
     tree = ast.parse(src)
     found = {}
     for node in ast.walk(tree):
-        if isinstance(node, ast.FunctionDef) and node.name in names and node.name not in found:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in names and node.name not in found:
             found[node.name] = ast.get_source_segment(src, node)
     for n in names:
         code = found[n]
@@ -428,6 +428,60 @@ def gen_render_image():
     print("render_image done:", len(cases), "cases,", sum(c["sizes"][0] != c["sizes"][1] for c in cases), "with unequal sizes")
 
 
+def gen_weight_sync():
+    """Wire format of the trainer -> engine weight push: the reference's OWN packer (send_recv_utils.py:64-152 TensorBucket /
+    SendBucketManager, executed here on the CPU) fed with a mixed-dtype tensor set whose members straddle bucket boundaries;
+    stored: every bucket's bytes, its meta_infos (after the reference's meta_to_dict, as they cross the RPC boundary) and the
+    comm-plan lookup results of get_dist_info_from_comm_plan (functionals.py:875-882)."""
+    import typing
+    ns = {"torch": torch, "Dict": typing.Dict, "List": typing.List, "Optional": typing.Optional}
+    extract("roll/utils/send_recv_utils.py", ["get_tensor_size", "TensorBucket", "SendBucketManager"], ns)
+    BS = 4096
+    mgr = ns["SendBucketManager"].__new__(ns["SendBucketManager"])       # the constructor hard-wires device="cuda": build by hand
+    mgr.bucket_size = BS
+    mgr.bucket = ns["TensorBucket"](BS, device="cpu")
+    g = torch.Generator().manual_seed(77)
+    tensors = {
+        "model.layers.0.self_attn.q_proj.weight": torch.randn(48, 40, generator=g).to(torch.bfloat16),
+        "model.layers.0.self_attn.q_proj.bias": torch.randn(48, generator=g).to(torch.bfloat16),
+        "model.norm.weight": torch.randn(1000, generator=g),
+        "visual.blocks.0.attn.qkv.weight": torch.randn(7, 3, 5, generator=g).to(torch.float16),
+        "model.embed_tokens.weight": torch.randn(300, 23, generator=g).to(torch.bfloat16),
+        "tiny": torch.randn(1, generator=g),
+        "lm_head.weight": torch.randn(129, 17, generator=g),
+    }
+    buckets, metas = [], []
+
+    def keep(meta_infos, buffer, nbytes):
+        m = {k: dict(v) for k, v in meta_infos.items()}
+        ns["SendBucketManager"].meta_to_dict(m)
+        metas.append({k: {"bucket_start": int(v["bucket_start"]), "tensor_start": int(v["tensor_start"]), "save_bytes": int(v["save_bytes"]),
+                          "tensor_meta": {"shape": v["tensor_meta"]["shape"], "dtype": str(v["tensor_meta"]["dtype"])}} for k, v in m.items()})
+        buckets.append(buffer[:nbytes].clone().numpy().view(np.uint8))
+    for name, t in tensors.items():
+        for meta_infos, buffer in mgr.push_tensor(t, name):
+            keep(meta_infos, buffer, BS)
+    meta_infos, buffer = mgr.pop_last_bucket()
+    if meta_infos is not None:
+        keep(meta_infos, buffer, mgr.bucket.write_index)
+    ns2 = {}
+    extract("roll/utils/functionals.py", ["get_dist_info_from_comm_plan"], ns2)
+    plan = {"0": {"group_name": "model_update_a_0_to_b_(0,0)-(1,0)-(2,1)", "master_addr": "127.0.0.1", "master_port": 29999, "src_pp_rank": 0, "src_rank": 0,
+                  "tgt_devices": [{"rank": 0, "device": {"rank": 0, "node_rank": 0, "gpu_rank": 1}}, {"rank": 1, "device": {"rank": 0, "node_rank": 0, "gpu_rank": 2}},
+                                  {"rank": 2, "device": {"rank": 1, "node_rank": 0, "gpu_rank": 5}}]},
+            "1": {"group_name": "model_update_a_1_to_b_(3,0)", "master_addr": "127.0.0.1", "master_port": 29998, "src_pp_rank": 0, "src_rank": 1,
+                  "tgt_devices": [{"rank": 3, "device": {"rank": 0, "node_rank": 0, "gpu_rank": 7}}]}}
+    lookups = []
+    for rc, rw in [(0, 0), (1, 0), (2, 1), (2, 0), (3, 0), (4, 0)]:
+        r, a = ns2["get_dist_info_from_comm_plan"](plan, rank_in_cluster=rc, rank_in_worker=rw)
+        lookups.append({"rank_in_cluster": rc, "rank_in_worker": rw, "rank": r, "group_name": None if a is None else a["group_name"]})
+    np.savez_compressed(os.path.join(OUT, "weight_sync.npz"), **{f"bucket{i}": b for i, b in enumerate(buckets)},
+                        **{"tensor_" + k: v.contiguous().view(-1).view(torch.uint8).numpy() for k, v in tensors.items()})
+    json.dump({"bucket_size": BS, "metas": metas, "tensors": {k: {"shape": list(v.shape), "dtype": str(v.dtype)} for k, v in tensors.items()},
+               "comm_plan": plan, "lookups": lookups}, open(os.path.join(OUT, "weight_sync.json"), "w"), indent=1)
+    print("weight_sync done:", len(buckets), "buckets")
+
+
 def make_ref_rope():
     ns = {"torch": torch, "Optional": __import__("typing").Optional, "Tuple": __import__("typing").Tuple}
     extract("mcore_adapter/src/mcore_adapter/models/qwen2_5_vl/modeling_qwen2_5_vl.py", ["get_rope_index"], ns)
@@ -447,6 +501,7 @@ if __name__ == "__main__":
     rope = make_ref_rope()
     gen_reference_python()
     gen_render_image()
+    gen_weight_sync()
     gen_index(rope)
     gen_patchify()
     gen_hf_tiny(rope)
