@@ -9,6 +9,10 @@
 //   S^T[key][query] = K[key][:] . Q[query][:]      (A = K rows,  B = Q rows, both d-contiguous)
 //   O^T[d][query]   = V^T[d][:] . P^T[:][query]    (A = V^T rows, key-contiguous; B = P from the S^T registers)
 // V is therefore kept transposed in HBM ([d][key]: the ViT rope kernel and the LM KV-cache writer produce it).
+// Measured and dropped (round 2): register-prefetched tiles (loads of tile t + 1 in flight while tile t is multiplied, issue early /
+// write late) plus a single-tile path that reuses pass 1's scores: bit-identical, but the kernel grows from 44-56 to 116-160 VGPRs
+// and loses to the plain version that lets 4+ blocks per CU cover each other's staging -- LM causal 215 vs 155 us, ViT full 1133 vs
+// 906 us, ViT windows 112 vs 110 us (those read q, k, v exactly once: they sit on the HBM floor of the qkv buffer).
 #include "kernels.h"
 #include <math.h>
 
