@@ -221,9 +221,14 @@ def main():
 
         def gemv_roofline(MB):
             """average launch duration of the decode step's weight-streaming launches at batch MB (events on the launch stream)"""
-            x = torch.empty(MB, I, dtype=torch.bfloat16, device=dev).normal_(0, 1)
+            # batches > 4: activations travel between the launches in fragment order, exactly as in the engine's decode layer
+            # (engine.hip enqueue_decode_forward: x_tiled / out_tiled); buffers hold whole 16-row groups
+            XT = 0x800 if MB > 4 else 0
+            OT = 0x1000 if MB > 4 else 0
+            Mp = (MB + 15) // 16 * 16
+            x = torch.empty(Mp, I, dtype=torch.bfloat16, device=dev).normal_(0, 1)
             part = torch.empty(4, MB, QN, dtype=torch.float32, device=dev)
-            act = torch.empty(MB, I, dtype=torch.bfloat16, device=dev)
+            act = torch.empty(Mp, I, dtype=torch.bfloat16, device=dev).normal_(0, 1)
             lg = torch.empty(MB, t_.vocab_size, dtype=torch.float32, device=dev)
             nw = torch.ones(H, dtype=torch.bfloat16, device=dev)
             bq = torch.zeros(QN, dtype=torch.bfloat16, device=dev)
@@ -247,12 +252,12 @@ def main():
                         lib.sr_op_gemv_f8(P(x), I, P(w8[2][l]), P(sc8), MB, 2 * I, H, P(act), I, 1, None, P(nw) if fused else None, eps, 1, s)
                         lib.sr_op_gemv_f8(P(act), I, P(w8[3][l]), P(sc8), MB, H, I, P(part), H, 0, None, None, eps, ksd, s)
                         continue
-                    lib.sr_op_gemv_fused(P(x), I, P(wq[l]), MB, QN, H, P(qkv_o), QN, 3 | TL, P(bq), P(nw) if fused else None, eps,
+                    lib.sr_op_gemv_fused(P(x), I, P(wq[l]), MB, QN, H, P(qkv_o), QN, 3 | TL | XT, P(bq), P(nw) if fused else None, eps,
                                          P(slabs) if fused else None, 2 if fused else 0, P(xo) if fused else None, None, None, s)
-                    lib.sr_op_gemv_fused(P(x), I, P(wo[l]), MB, H, H, P(xr), H, 4 | TL, None, None, eps, None, 0, None, None, None, s)
-                    lib.sr_op_gemv_fused(P(x), I, P(wg[l]), MB, 2 * I, H, P(act), I, 1 | TL, None, P(nw) if fused else None, eps, None, 0, None, None, None, s)
-                    lib.sr_op_gemv(P(act), I, P(wd[l]), MB, H, I, P(part), ksd, 0 | TL, s)
-                lib.sr_op_gemv_fused(P(x), I, P(wv), MB, t_.vocab_size, H, P(lg), t_.vocab_size, 2 | TL, None, P(nw) if fused else None, eps,
+                    lib.sr_op_gemv_fused(P(x), I, P(wo[l]), MB, H, H, P(xr), H, 4 | TL | XT, None, None, eps, None, 0, None, None, None, s)
+                    lib.sr_op_gemv_fused(P(x), I, P(wg[l]), MB, 2 * I, H, P(act), I, 1 | TL | XT | OT, None, P(nw) if fused else None, eps, None, 0, None, None, None, s)
+                    lib.sr_op_gemv(P(act), I, P(wd[l]), MB, H, I, P(part), ksd, 0 | TL | XT, s)
+                lib.sr_op_gemv_fused(P(x), I, P(wv), MB, t_.vocab_size, H, P(lg), t_.vocab_size, 2 | TL | XT, None, P(nw) if fused else None, eps,
                                      P(slabs) if fused else None, 2 if fused else 0, P(xo) if fused else None, P(av), P(ai), s)
             seq()
             a, b_ = ev(), ev()
