@@ -138,63 +138,103 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p, int ntm, int ntn) 
         __syncthreads();
     }
 
-    // ---- epilogue.  lane owns row m = .. + fr and columns n = .. + fg*4 + {0,1,2,3} of every 16x16 tile
+    // ---- epilogue.  lane owns row m = .. + fr and columns n = .. + fg*4 + {0,1,2,3} of every 16x16 tile.
+    // 16-byte accesses (same scheme as gemm256.hip): v_permlane16_swap trades the packed halves of two neighbouring tiles between
+    // the lane pairs (l, l + 16), after which even 16-lane rows hold 8 consecutive columns of the first tile and odd rows 8 of the
+    // second -- one dwordx4 store (and residual load) per lane and tile pair instead of two dwordx2.
+    auto widen = [&](uint2 ta, uint2 tb) -> uint4 {
+        const auto sx = __builtin_amdgcn_permlane16_swap(ta.x, tb.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(ta.y, tb.y, false, false);
+        return uint4{sx[0], sy[0], sx[1], sy[1]};
+    };
+    const int odd = fg & 1, half8 = (fg >> 1) * 8;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 16 + fr;
-        if (m >= p.M) continue;
-        const int orow = p.rowmap ? p.rowmap[m] : m;
+        const bool rok = m < p.M;                              // (masked rows still take part in the lane exchange)
+        const int orow = (rok && p.rowmap) ? p.rowmap[m] : m;
         if constexpr (EPI == EPI_SWIGLU) {
+            uint2 t2[NJ / 2];
 #pragma unroll
             for (int jp = 0; jp < NJ / 2; ++jp) {
                 const int ng = n0 + wn * (NJ * 16) + jp * 32 + fg * 4;       // gate columns (interleaved index)
-                if (ng >= p.N) continue;
                 const int nu = ng + 16;
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float g = acc[i][2 * jp][r], u = acc[i][2 * jp + 1][r];
-                    if (p.w_scale) { g *= p.w_scale[ng + r]; u *= p.w_scale[nu + r]; }
-                    if (p.bias) { g += bf2f(p.bias[ng + r]); u += bf2f(p.bias[nu + r]); }
+                    if (ng < p.N) {
+                        if (p.w_scale) { g *= p.w_scale[ng + r]; u *= p.w_scale[nu + r]; }
+                        if (p.bias) { g += bf2f(p.bias[ng + r]); u += bf2f(p.bias[nu + r]); }
+                    }
                     g = rbf(g); u = rbf(u);
                     o[r] = rbf(silu_f(g)) * u;
                 }
-                const int no = (n0 + wn * (NJ * 16)) / 2 + jp * 16 + fg * 4;
-                uint2 v = {pack2(o[0], o[1]), pack2(o[2], o[3])};
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + no) = v;
+                t2[jp] = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
             }
-        } else {
+            if constexpr (NJ == 4) {
+                const uint4 v = widen(t2[0], t2[1]);
+                const int ngs = n0 + wn * 64 + odd * 32;                     // gate-column base of the output tile this lane stores
+                const int no = (n0 + wn * 64) / 2 + odd * 16 + half8;
+                if (rok && ngs < p.N) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + no) = v;
+            } else {
+                const int ng = n0 + wn * (NJ * 16) + fg * 4;
+                const int no = (n0 + wn * (NJ * 16)) / 2 + fg * 4;
+                if (rok && ng < p.N) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + no) = t2[0];
+            }
+        } else if constexpr (EPI == EPI_F32) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int n = n0 + wn * (NJ * 16) + j * 16 + fg * 4;
-                if (n >= p.N) continue;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = acc[i][j][r];
+                if (!rok || n >= p.N) continue;
+                float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 if (p.w_scale) {
                     const float4 sc = *reinterpret_cast<const float4*>(p.w_scale + n);
                     o[0] *= sc.x; o[1] *= sc.y; o[2] *= sc.z; o[3] *= sc.w;
                 }
-                if constexpr (EPI == EPI_F32) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow * p.ldo + n) =
-                        float4{o[0], o[1], o[2], o[3]};
-                } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow * p.ldo + n) = float4{o[0], o[1], o[2], o[3]};
+            }
+        } else {
+            uint2 rv[NJ], t4[NJ];
+            if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+                for (int jp = 0; jp < NJ / 2; ++jp) {
+                    const int n = n0 + wn * (NJ * 16) + (2 * jp + odd) * 16 + half8;
+                    const uint4 l4 = (rok && n < p.N) ? *reinterpret_cast<const uint4*>(p.resid + (size_t)orow * p.ldo + n) : uint4{0, 0, 0, 0};
+                    const auto sx = __builtin_amdgcn_permlane16_swap(l4.x, l4.z, false, false);
+                    const auto sy = __builtin_amdgcn_permlane16_swap(l4.y, l4.w, false, false);
+                    rv[2 * jp] = uint2{sx[0], sy[0]};
+                    rv[2 * jp + 1] = uint2{sx[1], sy[1]};
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * (NJ * 16) + j * 16 + fg * 4;
+                float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (n < p.N) {
+                    if (p.w_scale) {
+                        const float4 sc = *reinterpret_cast<const float4*>(p.w_scale + n);
+                        o[0] *= sc.x; o[1] *= sc.y; o[2] *= sc.z; o[3] *= sc.w;
+                    }
                     if (p.bias) {
-                        uint2 b = *reinterpret_cast<const uint2*>(p.bias + n);
+                        const uint2 b = *reinterpret_cast<const uint2*>(p.bias + n);
                         o[0] += lo16(b.x); o[1] += hi16(b.x); o[2] += lo16(b.y); o[3] += hi16(b.y);
                     }
-                    bf16_t* optr = reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + n;
-                    if constexpr (EPI == EPI_RESID) {
-                        uint2 rv = *reinterpret_cast<const uint2*>(p.resid + (size_t)orow * p.ldo + n);
-                        o[0] = lo16(rv.x) + rbf(o[0]); o[1] = hi16(rv.x) + rbf(o[1]);
-                        o[2] = lo16(rv.y) + rbf(o[2]); o[3] = hi16(rv.y) + rbf(o[3]);
-                    } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = gelu_f(rbf(o[r]));
-                    }
-                    uint2 v = {pack2(o[0], o[1]), pack2(o[2], o[3])};
-                    *reinterpret_cast<uint2*>(optr) = v;
                 }
+                if constexpr (EPI == EPI_RESID) {
+                    o[0] = lo16(rv[j].x) + rbf(o[0]); o[1] = hi16(rv[j].x) + rbf(o[1]);
+                    o[2] = lo16(rv[j].y) + rbf(o[2]); o[3] = hi16(rv[j].y) + rbf(o[3]);
+                } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = gelu_f(rbf(o[r]));
+                }
+                t4[j] = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+            }
+#pragma unroll
+            for (int jp = 0; jp < NJ / 2; ++jp) {
+                const uint4 v = widen(t4[2 * jp], t4[2 * jp + 1]);
+                const int n = n0 + wn * (NJ * 16) + (2 * jp + odd) * 16 + half8;
+                if (rok && n < p.N) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + n) = v;
             }
         }
     }

@@ -199,10 +199,22 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn) {
         bia[j] = p.bias ? *reinterpret_cast<const uint2*>(p.bias + n) : uint2{0, 0};
         scl[j] = p.w_scale ? *reinterpret_cast<const float4*>(p.w_scale + n) : float4{1.f, 1.f, 1.f, 1.f};
     }
+    // 16-byte stores: a lane owns 4 consecutive columns (8 B) of a row in every 16-column tile; the lane 16 further on owns the next
+    // 4.  v_permlane16_swap trades the odd 16-lane rows of one register with the even rows of another, so after swapping the packed
+    // halves of two neighbouring tiles (A, B) every even-row lane holds 8 consecutive columns of tile A and every odd-row lane 8
+    // consecutive columns of tile B: one dwordx4 store per lane and tile pair instead of two dwordx2 (16 rows x 64 B per
+    // instruction instead of 16 x 32 B).
+    auto widen = [&](uint2 ta, uint2 tb) -> uint4 {
+        const auto sx = __builtin_amdgcn_permlane16_swap(ta.x, tb.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(ta.y, tb.y, false, false);
+        return uint4{sx[0], sy[0], sx[1], sy[1]};
+    };
+    const int odd = fg & 1, half8 = (fg >> 1) * 8;            // which tile of a pair this lane stores, and its 8-column half
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        if (!rok[i]) continue;
+        // (no early exit on masked rows: the lane exchange needs every lane of the wave)
         if constexpr (EPI == EPI_SWIGLU) {
+            uint2 t2[2];
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {                                  // tiles (2jp, 2jp+1) = (gate, up) of 16 columns
                 const float gs[4] = {scl[2 * jp].x, scl[2 * jp].y, scl[2 * jp].z, scl[2 * jp].w};
@@ -218,34 +230,53 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn) {
                     g = rbf(g); u = rbf(u);
                     o[r] = rbf(silu_f(g)) * u;
                 }
-                const int no = (n0 + wn * 64) / 2 + jp * 16 + fg * 4;
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow[i] * p.ldo + no) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                t2[jp] = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
             }
-        } else {
-            uint2 rv[4];
-            if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    rv[j] = *reinterpret_cast<const uint2*>(p.resid + (size_t)orow[i] * p.ldo + n0 + wn * 64 + j * 16 + fg * 4);
-            }
+            const uint4 v = widen(t2[0], t2[1]);
+            const int no = (n0 + wn * 64) / 2 + odd * 16 + half8;
+            if (rok[i]) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow[i] * p.ldo + no) = v;
+        } else if constexpr (EPI == EPI_F32) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = n0 + wn * 64 + j * 16 + fg * 4;
                 float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 if (p.w_scale) { o[0] *= scl[j].x; o[1] *= scl[j].y; o[2] *= scl[j].z; o[3] *= scl[j].w; }
-                if constexpr (EPI == EPI_F32) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow[i] * p.ldo + n) = float4{o[0], o[1], o[2], o[3]};
-                } else {
-                    if (p.bias) { o[0] += lo16(bia[j].x); o[1] += hi16(bia[j].x); o[2] += lo16(bia[j].y); o[3] += hi16(bia[j].y); }
-                    if constexpr (EPI == EPI_RESID) {
-                        o[0] = lo16(rv[j].x) + rbf(o[0]); o[1] = hi16(rv[j].x) + rbf(o[1]);
-                        o[2] = lo16(rv[j].y) + rbf(o[2]); o[3] = hi16(rv[j].y) + rbf(o[3]);
-                    } else if constexpr (EPI == EPI_GELU) {
+                if (rok[i]) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow[i] * p.ldo + n) = float4{o[0], o[1], o[2], o[3]};
+            }
+        } else {
+            uint2 rv[4], t4[4];
+            if constexpr (EPI == EPI_RESID) {
+                // the residual comes in with the same 16-byte accesses: load the 8 columns this lane will STORE, then the same lane
+                // exchange hands every lane the 4 + 4 columns it accumulates (the swap is its own inverse on this layout)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = gelu_f(rbf(o[r]));
-                    }
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow[i] * p.ldo + n) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                for (int jp = 0; jp < 2; ++jp) {
+                    const uint4 l4 = rok[i] ? *reinterpret_cast<const uint4*>(p.resid + (size_t)orow[i] * p.ldo + n0 + wn * 64 + (2 * jp + odd) * 16 + half8)
+                                            : uint4{0, 0, 0, 0};
+                    const auto sx = __builtin_amdgcn_permlane16_swap(l4.x, l4.z, false, false);
+                    const auto sy = __builtin_amdgcn_permlane16_swap(l4.y, l4.w, false, false);
+                    rv[2 * jp] = uint2{sx[0], sy[0]};
+                    rv[2 * jp + 1] = uint2{sx[1], sy[1]};
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (p.w_scale) { o[0] *= scl[j].x; o[1] *= scl[j].y; o[2] *= scl[j].z; o[3] *= scl[j].w; }
+                if (p.bias) { o[0] += lo16(bia[j].x); o[1] += hi16(bia[j].x); o[2] += lo16(bia[j].y); o[3] += hi16(bia[j].y); }
+                if constexpr (EPI == EPI_RESID) {
+                    o[0] = lo16(rv[j].x) + rbf(o[0]); o[1] = hi16(rv[j].x) + rbf(o[1]);
+                    o[2] = lo16(rv[j].y) + rbf(o[2]); o[3] = hi16(rv[j].y) + rbf(o[3]);
+                } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = gelu_f(rbf(o[r]));
+                }
+                t4[j] = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+            }
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                const uint4 v = widen(t4[2 * jp], t4[2 * jp + 1]);
+                const int n = n0 + wn * 64 + (2 * jp + odd) * 16 + half8;
+                if (rok[i]) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow[i] * p.ldo + n) = v;
             }
         }
     }
