@@ -276,10 +276,10 @@ def main():
         kv_bytes = 36864.0 * (448 + N_NEW / 2) * B
         # HBM traffic per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950 note):
         # measured ratio traffic / algorithmic bytes of this kernel family x the algorithmic bytes of one launch
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemv_traffic.json")))
-            traffic = round(pmc["traffic_over_algorithmic_weighted"] * bytes_per_launch)
+        traffic, pmc = None, None
+        try:     # profiles/r02_pmc_gemv_traffic.json: FETCH_SIZE passes of this kernel family at batch 32 and batch 1 (tools/gpu_pmc_r2.sh)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_gemv_traffic.json")))
+            traffic = round(pmc["traffic_over_algorithmic_weighted_batch32" if B > 4 else "traffic_over_algorithmic_weighted_batch1"] * bytes_per_launch)
         except Exception:  # noqa: BLE001
             pass
         if args.fp8:
@@ -295,6 +295,7 @@ def main():
             latency["roofline"] = {"bound": "hbm", "kernel": "k_gemv family at batch 1", "achieved": round(bytes_per_launch / (a1 * 1e-3) / 1e9, 1),
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_per_launch / (a1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "avg_launch_us": round(a1 * 1e3, 2),
+                                   "traffic": round(pmc["traffic_over_algorithmic_weighted_batch1"] * bytes_per_launch) if pmc else None,
                                    "decode_step_achieved_GBs": round((wl + wh + 36864.0 * (448 + N_NEW / 2)) / (latency["decode_step_ms"] * 1e-3) / 1e9, 1)}
         del wq, wo, wg, wd, wv
         per = args.steps * (2 if continuous else 1)          # batches of B tiles inside the timed region
