@@ -215,10 +215,11 @@ def mask_union(masks):
 def resize_nearest(src: np.ndarray, H: int, W: int) -> np.ndarray:
     """cv2.INTER_NEAREST as called at seg_strategy.py:65 and rlvr_socioseg_vlm_pipeline_infer.py:399.
     cv2 is not installed here (parity of this rule is UNPINNED): documented rule
-    sx = min(floor(dx * sw / dw), sw - 1) evaluated in double like OpenCV's resizeNN."""
+    sx = min(floor(dx * ifx), sw - 1) with ifx = 1 / (dw / sw) formed like cv::resize forms it (inv_scale = dsize / ssize, then
+    its reciprocal) -- NOT floor(dx * sw / dw): the two differ for rare size pairs (e.g. 768 -> 1148)."""
     h, w = src.shape[:2]
-    ys = np.minimum(np.floor(np.arange(H) * (h / H)).astype(np.int64), h - 1)
-    xs = np.minimum(np.floor(np.arange(W) * (w / W)).astype(np.int64), w - 1)
+    ys = np.minimum(np.floor(np.arange(H) * (1.0 / (H / h))).astype(np.int64), h - 1)
+    xs = np.minimum(np.floor(np.arange(W) * (1.0 / (W / w))).astype(np.int64), w - 1)
     return src[ys][:, xs]
 
 

@@ -3,7 +3,9 @@
  *   ref_mask_union        roll/distributed/strategy/seg_strategy.py:58-60  (logical_or -> uint8 {0,1})
  *   ref_resize_nearest_u8 cv2.INTER_NEAREST at seg_strategy.py:65 and
  *                         roll/pipeline/rlvr/rlvr_socioseg_vlm_pipeline_infer.py:399
- *                         (cv2 absent here: documented rule sx = min(floor(dx*sw/dw), sw-1), double arithmetic)
+ *                         (cv2 absent here: OpenCV's resizeNN rule restated -- inverse scale 1 / ((double)dw / sw) formed the way
+ *                         cv::resize forms it, sx = min(floor(dx * that), sw - 1); the reciprocal matters: floor(dx * sw / dw)
+ *                         differs from it for rare size pairs, e.g. 768 -> 1148)
  *   ref_iou_counts        rlvr_socioseg_vlm_pipeline_infer.py:45-58
  *   ref_render_overlay    rlvr_socioseg_vlm_pipeline_infer.py:383-452 (PIL ImageDraw.rectangle + alpha_composite,
  *                         integer formulas verified against PIL 12.2 by tools/make_golden.py)
@@ -18,7 +20,7 @@ void ref_mask_union(uint8_t *acc, const uint8_t *m, size_t n) {
 }
 
 void ref_resize_nearest_u8(const uint8_t *src, int sh, int sw, uint8_t *dst, int dh, int dw) {
-    double fy = (double)sh / dh, fx = (double)sw / dw;
+    double fy = 1.0 / ((double)dh / sh), fx = 1.0 / ((double)dw / sw);
     for (int y = 0; y < dh; ++y) {
         int sy = (int)floor(y * fy);
         if (sy > sh - 1) sy = sh - 1;
@@ -86,7 +88,7 @@ void ref_render_overlay(uint8_t *img, int h, int w, const uint8_t *mask, int mh,
     if (!mask) return;
     const int a = 102;
     const int col[3] = {255, 0, 0};
-    double fy = (double)mh / h, fx = (double)mw / w;
+    double fy = 1.0 / ((double)h / mh), fx = 1.0 / ((double)w / mw);
     for (int y = 0; y < h; ++y) {
         int sy = (int)floor(y * fy);
         if (sy > mh - 1) sy = mh - 1;

@@ -33,7 +33,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __forceinline__ int swz2(int row, int chunk) { return row * (BK2 * 2) + ((chunk ^ (row & 7)) << 4); }
 
 template <int EPI>
-__global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn) {
+__global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, int GROUP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // ONE array (a second __shared__ object de-pipelines)
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn) {
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    constexpr int GROUP = 4;                       // m-tiles that share their W panels while walking n
+    // GROUP m-tiles share their W panels while walking n
     const int per_group = GROUP * ntn;
     const int gid = bid / per_group, first_m = gid * GROUP, gsz = min(ntm - first_m, GROUP);
     const int tm = first_m + (bid % per_group) % gsz, tn = (bid % per_group) / gsz;
@@ -292,7 +292,9 @@ int launch256_t(hipStream_t s, const GemmArgs& a) {
         if (r != hipSuccess) return (int)r;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_gemm256<EPI>), dim3(ntm * ntn), dim3(512), smem, s, a, ntm, ntn);
+    static const char* g_env = getenv("SR_G256_GROUP");        // tuning hook
+    const int group = g_env ? atoi(g_env) : 4;
+    hipLaunchKernelGGL((k_gemm256<EPI>), dim3(ntm * ntn), dim3(512), smem, s, a, ntm, ntn, group);
     SR_CHECK_LAUNCH();
     return 0;
 }

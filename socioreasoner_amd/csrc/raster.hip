@@ -2,7 +2,8 @@
 // Reference behaviour (paths relative to /root/reference):
 //   mask union      roll/distributed/strategy/seg_strategy.py:58-60   np.logical_or(mask, best).astype(uint8)
 //   nearest resize  seg_strategy.py:65, roll/pipeline/rlvr/rlvr_socioseg_vlm_pipeline_infer.py:399 (cv2.INTER_NEAREST:
-//                   sx = min(floor(dx * sw / dw), sw - 1), evaluated in double)
+//                   sx = min(floor(dx * ifx), sw - 1), ifx = 1 / ((double)dw / sw): OpenCV's resizeNN forms the inverse scale as a
+//                   reciprocal; floor(dx * sw / dw) differs from it for rare size pairs)
 //   IoU counts      rlvr_socioseg_vlm_pipeline_infer.py:45-58
 //   render          rlvr_socioseg_vlm_pipeline_infer.py:383-452 (2-px blue ImageDraw.rectangle outlines, then
 //                   Image.alpha_composite of (255,0,0,102) where mask>0; PIL's fixed-point formula)
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void k_mask_union(uint8_t* acc, const uint8_t*
 __global__ __launch_bounds__(256) void k_resize_nearest(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= dw) return;
-    const double fy = (double)sh / dh, fx = (double)sw / dw;
+    const double fy = 1.0 / ((double)dh / sh), fx = 1.0 / ((double)dw / sw);
     int sy = (int)floor(y * fy), sx = (int)floor(x * fx);
     sy = min(sy, sh - 1);
     sx = min(sx, sw - 1);
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void k_render(uint8_t* img, int h, int w, cons
         if (hit) { c0 = 0; c1 = 0; c2 = 255; }
     }
     if (mask) {
-        const double fy = (double)mh / h, fx = (double)mw / w;
+        const double fy = 1.0 / ((double)h / mh), fx = 1.0 / ((double)w / mw);
         const int sy = min((int)floor(y * fy), mh - 1), sx = min((int)floor(x * fx), mw - 1);
         if (mask[(size_t)sy * mw + sx] != 0) {
             const int a = 102, col[3] = {255, 0, 0};

@@ -171,6 +171,21 @@ def test_raster(golden_dir):
     assert H.compute_giou(np.zeros((4, 4)), np.zeros((4, 4))) == float(g["giou_empty"]) == 1.0
 
 
+def test_nearest_rule_is_opencvs_reciprocal_form():
+    """cv::resize forms the inverse scale as 1 / (dsize / ssize) and resizeNN takes floor(dx * that).  For most size pairs this
+    equals floor(dx * ssize / dsize); 768 -> 1148 is one where it does not (2 of 1148 columns) -- both oracles follow OpenCV."""
+    src = np.arange(768, dtype=np.int64)
+    want = np.minimum(np.floor(np.arange(1148) * (1.0 / (1148 / 768))).astype(np.int64), 767)
+    naive = np.minimum(np.floor(np.arange(1148) * (768 / 1148)).astype(np.int64), 767)
+    assert int((want != naive).sum()) == 2
+    img = (src[None, :] % 251).astype(np.uint8).repeat(4, axis=0)
+    for impl in (H, R):
+        assert np.array_equal(impl.resize_nearest(img, 4, 1148)[0], img[0][want]), impl.__name__
+    for s_, d_ in ((756, 768), (768, 448), (768, 756), (768, 896)):        # the sizes on the shipped path: both forms agree
+        a = np.minimum(np.floor(np.arange(d_) * (1.0 / (d_ / s_))).astype(np.int64), s_ - 1)
+        assert np.array_equal(a, np.minimum(np.floor(np.arange(d_) * (s_ / d_)).astype(np.int64), s_ - 1))
+
+
 def test_render_image_reference_function(golden_dir):
     """The reference's render_image executed on thin / float / reversed / malformed boxes and on image pairs of unequal
     size (tools/make_golden.py gen_render_image): the oracle reproduces every output image."""

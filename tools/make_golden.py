@@ -312,7 +312,7 @@ def gen_reference_python():
         ras[f"masks_sha{k}"] = np.frombuffer(hashlib.sha256(masks.tobytes()).digest(), dtype=np.uint8)
         ras[f"gt_sha{k}"] = np.frombuffer(hashlib.sha256(gt.tobytes()).digest(), dtype=np.uint8)
         # nearest 756->768 by the documented rule (cv2 absent) -- stored so the rule itself is frozen
-        ys = np.minimum(np.floor(np.arange(768) * (756 / 768)).astype(np.int64), 755)
+        ys = np.minimum(np.floor(np.arange(768) * (1.0 / (768 / 756))).astype(np.int64), 755)   # OpenCV forms the inverse scale as a reciprocal
         up = acc[ys][:, ys]
         ras[f"resized_sha{k}"] = np.frombuffer(hashlib.sha256(up.tobytes()).digest(), dtype=np.uint8)
         ras[f"giou{k}"] = np.array(ns["compute_giou"](up, gt), dtype=np.float64)
@@ -328,7 +328,7 @@ def gen_reference_python():
                 d.rectangle([(b[0], b[1]), (b[2], b[3])], outline="blue", width=2)
             except Exception:
                 continue
-        ys2 = np.minimum(np.floor(np.arange(448) * (768 / 448)).astype(np.int64), 767)
+        ys2 = np.minimum(np.floor(np.arange(448) * (1.0 / (448 / 768))).astype(np.int64), 767)
         mk = up[ys2][:, ys2] > 0
         ov = np.zeros((448, 448, 4), dtype=np.uint8)
         ov[mk] = [255, 0, 0, int(255 * 0.4)]
@@ -381,8 +381,8 @@ def gen_render_image():
         @staticmethod
         def resize(a, size, interpolation=0):
             w, h = size
-            ys = np.minimum(np.floor(np.arange(h) * (a.shape[0] / h)).astype(np.int64), a.shape[0] - 1)
-            xs = np.minimum(np.floor(np.arange(w) * (a.shape[1] / w)).astype(np.int64), a.shape[1] - 1)
+            ys = np.minimum(np.floor(np.arange(h) * (1.0 / (h / a.shape[0]))).astype(np.int64), a.shape[0] - 1)     # cv::resize: 1 / (dsize / ssize)
+            xs = np.minimum(np.floor(np.arange(w) * (1.0 / (w / a.shape[1]))).astype(np.int64), a.shape[1] - 1)
             return a[ys][:, xs]
     ns = {"np": np, "json": json, "Image": Image, "ImageDraw": ImageDraw, "cv2": _CV2, "List": typing.List, "Dict": typing.Dict,
           "Any": typing.Any, "Union": typing.Union}
