@@ -54,9 +54,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="BASELINE.json configs[4] weights: LM decoder linears fp8 e4m3, per-channel scale")
+    ap.add_argument("--fp8-mx", action="store_true", help="--fp8 plus MX fp8 activations in the prefill linears (fp8 x fp8 block-scaled MFMA, lm_weight_dtype 2)")
     ap.add_argument("--gather-logits", action="store_true",
                     help="verification mode (static batch): all-gather the float32 logits of every decode step (north_star's literal exchange)")
     args = ap.parse_args()
+    if args.fp8_mx:
+        args.fp8 = True
     B = args.batch
     continuous = (B > 1 and not args.static and not args.gather_logits) or args.continuous
     if args.gather_logits or args.no_graph:
@@ -77,7 +80,7 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     geom = geometry_3b()
-    eng = Engine(geom, max_patches=1024 * B, max_prefill_tokens=448 * B, max_batch=B, max_ctx=640, max_new_tokens=N_NEW, device=str(dev), lm_fp8=args.fp8)
+    eng = Engine(geom, max_patches=1024 * B, max_prefill_tokens=448 * B, max_batch=B, max_ctx=640, max_new_tokens=N_NEW, device=str(dev), lm_fp8="mx" if args.fp8_mx else args.fp8)
     t0 = time.time()
     eng.load_synthetic_weights(seed=0)
     load_s = time.time() - t0
@@ -321,7 +324,8 @@ def main():
         out = {
             "metric": "satellite tiles/sec (448x448, SocioReasoner-3B)", "value": round(tiles_per_s, 4), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not args.fp8 else "bf16 (fp8-e4m3 LM linear weights, bf16 activations / MFMA)", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not args.fp8 else ("fp8-e4m3 LM linears: prefill fp8 x fp8 on the block-scaled MFMA (MX activations), decode fp8 weights x bf16 activations"
+                                                      if args.fp8_mx else "bf16 (fp8-e4m3 LM linear weights, bf16 activations / MFMA)"), "data": "synthetic",
             "config": {"workload": f"SocioReasoner-3B {'fp8-weight' if args.fp8 else 'bf16'}, {B} batch row(s)/GPU, "
                                    + (f"continuous batching (admit on finish): {n_req} tile requests per step through {B} rows, " if continuous else "static batch, ")
                                    + f"448x448 synthetic tiles, 448-token prompt, greedy decode of {N_NEW} tokens (EOS ignored), raster tail; random-init "

@@ -48,7 +48,10 @@ typedef struct sr_config {
     /* storage of the LM decoder linears (q/k/v, o, gate/up, down) -- BASELINE.json configs[4]:
      *   0 = bf16;  1 = fp8 e4m3 with one float32 scale per output channel, W[n,k] = q[n,k] * scale[n], scale[n] = amax_n / 448.
      * Embedding / LM head and the ViT stay bf16.  The decode GEMV streams the fp8 image (half the HBM bytes) and widens it to
-     * bf16 in registers (exact); prefill multiplies a bf16 image of the same q; both apply scale[n] to the float32 accumulator. */
+     * bf16 in registers (exact); prefill multiplies a bf16 image of the same q; both apply scale[n] to the float32 accumulator.
+     *   2 = 1, and the PREFILL linears run fp8 x fp8 on the block-scaled K = 128 MFMA (twice the bf16 rate): their inputs are
+     * quantised to OCP-MX e4m3 (32-wide blocks along k, e8m0 shared scales; definition: oracle/model_ref.py mx_quantize), the
+     * weight operand is the same fp8 image; decode is unchanged (bf16 activations). */
     int32_t lm_weight_dtype;
 } sr_config;
 
@@ -177,6 +180,12 @@ int sr_render_overlay(uint8_t* dev_img_rgb, int h, int w, const uint8_t* dev_mas
  * fragment-ordered. */
 int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void* out, int ldo, const void* bias,
                const void* resid, const int32_t* rowmap, int epilogue, void* stream);
+/* fp8 x fp8 prefill GEMM on the block-scaled MFMA (BASELINE.json configs[4]): sr_op_quant_mx quantises bf16 activations [M][ldx] to
+ * OCP-MX e4m3 (q [M][K] bytes + e8m0 scales [K/128][rows_pad][4]); sr_op_gemm_mx multiplies them with an fp8 weight image (tiled8,
+ * per-output-channel float32 scale) -- out = bf16((q_x . q_w^T with block scales) * w_scale + bias), epilogues 0 / 1 / 2 / 4 as sr_op_gemm */
+int sr_op_quant_mx(const void* x, int ldx, int M, int K, void* q, void* scales, int rows_pad, void* stream);
+int sr_op_gemm_mx(const void* A8, int lda, const void* a_scale, int a_rows_pad, const void* W8, const float* w_scale, int M, int N, int K, void* out,
+                  int ldo, const void* bias, const void* resid, int epilogue, void* stream);
 int sr_op_gemv(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ksplit, int mode, void* stream);
 /* decode GEMV with its fusions (mode 3 = bias epilogue, 4 = residual epilogue in place; norm_w != NULL = RMSNorm
  * prologue, optionally after adding n_slabs float32 slabs [n_slabs][M][K]; amax_* = per-block argmax partials of the

@@ -103,9 +103,30 @@ class QuantW:
         self.scale = scale[:, 0].contiguous()
 
 
+def mx_quantize(x: torch.Tensor):
+    """OCP Microscaling (MX) v1.0 quantisation of activations with e4m3 elements, the repo's definition of the fp8 PREFILL path's
+    activation side (BASELINE.json configs[4] "CDNA4 fp8 MFMA"; the block-scaled K = 128 MFMA is the fp8 form that runs at twice
+    the bf16 rate): along the last axis in blocks of 32, shared scale X = 2^(floor(log2(max|v|)) - 8) stored as e8m0 (exponent
+    clamped to -127..127, an all-zero block takes -127), elements = e4m3(v / X), round to nearest even, saturating at +-448.
+    -> (dequantised values x_q = element * X as float32 (exact), exponents int32 [..., K/32])."""
+    K0 = x.shape[-1]
+    if K0 % 32:             # the engine pads every K to a multiple of 64 with zeros; zeros change neither a block's maximum nor its sum
+        x = F.pad(x, (0, 32 - K0 % 32))
+    K = x.shape[-1]
+    xb = x.reshape(*x.shape[:-1], K // 32, 32).float()
+    amax = xb.abs().amax(-1)
+    _, ex = torch.frexp(amax)                                   # amax = m * 2^ex, m in [0.5, 1): floor(log2) = ex - 1
+    e = torch.where(amax > 0, ex - 1 - 8, torch.full_like(ex, -127)).clamp(-127, 127)
+    scale = torch.ldexp(torch.ones_like(amax), e)
+    el = (xb / scale[..., None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+    return (el * scale[..., None]).reshape(x.shape)[..., :K0], e.to(torch.int32)
+
+
 def linear(x, w, b=None):
     """bf16 nn.Linear: float32 accumulate, bias added in float32, one rounding (hf:88-96, 218, 626-629)."""
     if isinstance(w, QuantW):
+        if getattr(w, "mx_act", False):                         # fp8 x fp8: MX-quantised activations against the fp8 weights
+            x = mx_quantize(x)[0]
         y = (x @ w.q.t()) * w.scale
     else:
         y = x @ w.t()
@@ -119,13 +140,21 @@ class Fp8LmWeights:
     import re as _re
     _LM = _re.compile(r"model\.layers\.\d+\.(self_attn\.[qkvo]_proj|mlp\.(gate|up|down)_proj)\.weight$")
 
-    def __init__(self, base):
-        self.base, self._cache = base, {}
+    def __init__(self, base, mx_act: bool = False):
+        """mx_act: the linears quantise their INPUT too (mx_quantize) -- the engine's lm_weight_dtype = 2 does that in the prefill
+        GEMMs (fp8 x fp8 block-scaled MFMA) and not in decode; toggle with set_mx_act around the calls."""
+        self.base, self._cache, self.mx_act = base, {}, mx_act
+
+    def set_mx_act(self, on: bool):
+        self.mx_act = on
+        for q in self._cache.values():
+            q.mx_act = on
 
     def __getitem__(self, name):
         if self._LM.match(name):
             if name not in self._cache:
                 self._cache[name] = QuantW(self.base[name])
+                self._cache[name].mx_act = self.mx_act
             return self._cache[name]
         return self.base[name]
 

@@ -80,7 +80,7 @@ class Mi355xStrategy(InferenceStrategy):
         self.engine = Engine(self.geom, max_patches=int(sc.get("max_patches", self.max_batch * 2 * 2916)),
                              max_prefill_tokens=int(sc.get("max_prefill_tokens", min(prompt_len, 2048) * self.max_batch)),
                              max_batch=self.max_batch, max_ctx=max_ctx, max_new_tokens=min(resp_len, max_ctx - 1),
-                             lm_fp8=str(sc.get("quantization", "") or "").lower() in ("fp8", "fp8_e4m3"),   # vLLM's knob name
+                             lm_fp8={"fp8": True, "fp8_e4m3": True, "fp8_mx": "mx"}.get(str(sc.get("quantization", "") or "").lower(), False),   # vLLM's knob name; fp8_mx: + MX fp8 activations in prefill
                              device=f"cuda:{int(_get(getattr(self.worker, 'rank_info', None), 'local_rank', 0) or 0)}")
         import os
         if os.path.isdir(path):

@@ -440,6 +440,47 @@ __global__ __launch_bounds__(256) void k_quant_f8(bf16_t* W, int K, unsigned cha
         *reinterpret_cast<uint4*>(wt + (size_t)v * 8) = uint4{a0, a1, b0, b1};
     }
 }
+
+// MX activation quantiser of the fp8 prefill path (BASELINE.json configs[4]; definition: oracle/model_ref.py mx_quantize, OCP
+// Microscaling v1.0 with e4m3 elements): per row and 32-wide k-block, shared scale X = 2^(floor(log2(max|v|)) - 8) (e8m0, clamped
+// to 2^-127..2^127; an all-zero block takes 2^-127), elements = fp8_e4m3(v / X) with round-to-nearest-even and saturation to +-448.
+// One thread per block: 64 B in, 32 B out; the 4 scale bytes of a row's 128-wide k-tile are contiguous: scales[k/128][row][4].
+__global__ __launch_bounds__(256) void k_quant_mx_act(const bf16_t* x, int ldx, int M, int K, unsigned char* q, unsigned char* scales, int rows_pad) {
+    const int nb = K / 32;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)M * nb) return;
+    const int m = (int)(t / nb), b = (int)(t % nb);
+    const uint4* src = reinterpret_cast<const uint4*>(x + (size_t)m * ldx + b * 32);
+    uint4 u[4] = {src[0], src[1], src[2], src[3]};
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i * 8 + 0] = lo16(u[i].x); v[i * 8 + 1] = hi16(u[i].x); v[i * 8 + 2] = lo16(u[i].y); v[i * 8 + 3] = hi16(u[i].y);
+        v[i * 8 + 4] = lo16(u[i].z); v[i * 8 + 5] = hi16(u[i].z); v[i * 8 + 6] = lo16(u[i].w); v[i * 8 + 7] = hi16(u[i].w);
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    // floor(log2(amax)) from the exponent field (bf16 inputs widened to float32 are normal or zero)
+    int e = (amax > 0.f) ? (int)((__float_as_uint(amax) >> 23) & 255) - 127 - 8 : -127;
+    e = max(-127, min(127, e));
+    const float inv = __uint_as_float((uint32_t)(127 - e) << 23);          // 2^-e, exact (127 - e in 0..254; e = 127 -> 2^-127 is subnormal:
+    const float inv2 = (e == 127) ? 5.877471754111438e-39f : inv;          //  written out, the shift above would give 0)
+    int p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float a0 = fminf(fmaxf(v[4 * i + 0] * inv2, -448.f), 448.f), a1 = fminf(fmaxf(v[4 * i + 1] * inv2, -448.f), 448.f);
+        float a2 = fminf(fmaxf(v[4 * i + 2] * inv2, -448.f), 448.f), a3 = fminf(fmaxf(v[4 * i + 3] * inv2, -448.f), 448.f);
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, w, true);
+        p[i] = w;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(q + (size_t)m * K + b * 32);
+    dst[0] = uint4{(uint32_t)p[0], (uint32_t)p[1], (uint32_t)p[2], (uint32_t)p[3]};
+    dst[1] = uint4{(uint32_t)p[4], (uint32_t)p[5], (uint32_t)p[6], (uint32_t)p[7]};
+    scales[((size_t)(b >> 2) * rows_pad + m) * 4 + (b & 3)] = (unsigned char)(e + 127);
+}
 }  // namespace
 
 int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, long long cols, bf16_t* dst, long long dst_ld,
@@ -563,3 +604,12 @@ int launch_synth_fill(hipStream_t s, bf16_t* out, long long n, uint32_t key, flo
     return 0;
 }
 int launch_fill_zero(hipStream_t s, void* p, size_t bytes) { return (int)hipMemsetAsync(p, 0, bytes, s); }
+
+int launch_quant_mx_act(hipStream_t s, const bf16_t* x, int ldx, int M, int K, unsigned char* q, unsigned char* scales, int rows_pad) {
+    if (M <= 0) return 0;
+    if (K % 128 != 0 || ldx % 8 != 0 || rows_pad < M) return -22;
+    const long long n = (long long)M * (K / 32);
+    hipLaunchKernelGGL(k_quant_mx_act, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ldx, M, K, q, scales, rows_pad);
+    SR_CHECK_LAUNCH();
+    return 0;
+}

@@ -95,6 +95,7 @@ struct sr_engine {
     std::vector<int64_t> v_grid_cached;
     // ---- LM activations
     bf16_t *t_x, *t_xn, *t_qkv, *t_attn, *t_act;
+    unsigned char *t_q8 = nullptr, *t_qs = nullptr; int t_rows_pad = 0;     // lm_weight_dtype 2: MX-quantised GEMM input of the prefill
     int *t_src, *t_pos3, *t_slot, *t_idx, *t_lastrow;
     AttnWork* t_work;
     // ---- decode state (device)
@@ -174,7 +175,9 @@ const char* validate(const sr_config& c) {
     if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] != 64) return "mrope_section must sum to 64";
     if (c.max_batch < 1 || c.max_batch > 32) return "max_batch in 1..32";
     if (c.max_ctx < 64 || c.max_ctx % 64) return "max_ctx multiple of 64";
-    if (c.lm_weight_dtype != 0 && c.lm_weight_dtype != 1) return "lm_weight_dtype 0 (bf16) or 1 (fp8 e4m3, per-channel scale)";
+    if (c.lm_weight_dtype < 0 || c.lm_weight_dtype > 2) return "lm_weight_dtype 0 (bf16), 1 (fp8 e4m3 weights, per-channel scale) or 2 (1 + MX fp8 activations in prefill)";
+    if (c.lm_weight_dtype == 2 && (c.t_hidden % 256 || ((c.t_heads + 2 * c.t_kv_heads) * 128) % 256 || c.t_hidden / 128 < 2))
+        return "lm_weight_dtype 2: the block-scaled fp8 GEMM needs hidden and q/k/v widths in multiples of 256";
     if (c.max_patches < 4 || c.max_patches % 4 || c.max_prefill_tokens < 1 || c.max_new_tokens < 1) return "capacities";
     if (c.v_n_fullatt < 0 || c.v_n_fullatt > 16 || c.v_depth < 1 || c.t_layers < 1) return "depths";
     return nullptr;
@@ -227,7 +230,7 @@ void carve(sr_engine* e) {
         l.ln2 = ar.take<bf16_t>(H);
         l.gu_w = ar.take<bf16_t>((size_t)2 * e->t_inter_pad * H);
         l.down_w = ar.take<bf16_t>((size_t)H * e->t_inter_pad);
-        if (c.lm_weight_dtype == 1) {
+        if (c.lm_weight_dtype >= 1) {
             l.qkv_w8 = ar.take<unsigned char>((size_t)e->t_qn * H);
             l.o_w8 = ar.take<unsigned char>((size_t)H * c.t_heads * 128);
             l.gu_w8 = ar.take<unsigned char>((size_t)2 * e->t_inter_pad * H);
@@ -269,6 +272,12 @@ void carve(sr_engine* e) {
     e->t_qkv = ar.take<bf16_t>(TP * e->t_qn);
     e->t_attn = ar.take<bf16_t>(TP * c.t_heads * 128);
     e->t_act = ar.take<bf16_t>(TP * e->t_inter_pad);
+    if (c.lm_weight_dtype == 2) {      // MX activations of the fp8 x fp8 prefill GEMMs: element bytes + e8m0 block scales [K/128][rows_pad][4]
+        e->t_rows_pad = (int)((TP + 255) / 256 * 256);
+        const size_t kmax = std::max((size_t)e->t_inter_pad, std::max((size_t)H, (size_t)c.t_heads * 128));
+        e->t_q8 = ar.take<unsigned char>(TP * kmax);
+        e->t_qs = ar.take<unsigned char>((kmax / 128 + 1) * (size_t)e->t_rows_pad * 4);
+    }
     e->t_src = ar.take<int>(TP);
     e->t_pos3 = ar.take<int>(3 * TP);
     e->t_slot = ar.take<int>(TP);
@@ -462,6 +471,20 @@ int gemm(sr_engine* e, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W,
          const bf16_t* bias, const bf16_t* resid, const int* rowmap, int epi, int w_tiled = 0, const float* w_scale = nullptr) {
     GemmArgs a{A, lda, W, M, N, K, out, ldo, bias, resid, rowmap, w_tiled, w_scale, 0};
     SR_TRY(launch_gemm(s, a, epi));
+    return 0;
+}
+
+// one linear of the LM prefill.  lm_weight_dtype 0 / 1: MFMA GEMM on bf16 operands (mode 1 multiplies the bf16 image of the fp8-quantised
+// weights and scales in the epilogue).  Mode 2 (BASELINE.json configs[4] "CDNA4 fp8 MFMA"): the activations are MX-quantised
+// (k_quant_mx_act) and multiplied with the fp8 weight image by the block-scaled K = 128 MFMA -- ALWAYS, whatever the row count, so
+// that a sequence's result does not depend on what else is in the batch.
+int lm_gemm(sr_engine* e, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const unsigned char* W8, const float* w_scale, int M,
+            int N, int K, void* out, int ldo, const bf16_t* bias, const bf16_t* resid, int epi) {
+    if (e->c.lm_weight_dtype != 2) return gemm(e, s, A, lda, W, M, N, K, out, ldo, bias, resid, nullptr, epi, 1, w_scale);
+    SR_TRY(launch_quant_mx_act(s, A, lda, M, K, e->t_q8, e->t_qs, e->t_rows_pad));
+    GemmArgs a{reinterpret_cast<const bf16_t*>(e->t_q8), K, reinterpret_cast<const bf16_t*>(W8), M, N, K, out, ldo, bias, resid, nullptr, 1, w_scale, 256,
+               e->t_qs, e->t_rows_pad};
+    SR_TRY(launch_gemm256_mx(s, a, epi));
     return 0;
 }
 
@@ -800,7 +823,7 @@ int sr_finalize_weights(sr_engine* e, void* stream) {
         if (missing) return fail(e, -22, "sr_finalize_weights: %d parameters missing, e.g. %s", missing, first);
     }
     hipStream_t s = (hipStream_t)stream;
-    if (e->c.lm_weight_dtype == 1) {
+    if (e->c.lm_weight_dtype >= 1) {
         const int H = e->c.t_hidden, QD = e->c.t_heads * 128;
         // a fused matrix is re-quantised when ALL of its HF tensors were reloaded (a trainer -> engine weight sync sends every
         // parameter); a partial reload would mix fresh bf16 rows with rows that already hold quantised values
@@ -830,7 +853,7 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
     char miss[160];
     if (sr_weights_missing(e, miss, sizeof miss)) return fail(e, -61, "weights missing, e.g. '%s'", miss);
     const sr_config& c = e->c;
-    if (c.lm_weight_dtype == 1 && !e->finalized) return fail(e, -22, "fp8 weights: call sr_finalize_weights after loading");
+    if (c.lm_weight_dtype >= 1 && !e->finalized) return fail(e, -22, "fp8 weights: call sr_finalize_weights after loading");
     if (B < 1 || B > c.max_batch) return fail(e, -22, "sr_prefill: B=%d outside 1..%d", B, c.max_batch);
     hipStream_t s = (hipStream_t)stream;
     int n_tok = 0;
@@ -917,17 +940,17 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
         bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
         bf16_t* vc = e->vtcache + (size_t)l * e->kv_layer_elems;
         SR_TRY(launch_rmsnorm(s, e->t_x, w.ln1, e->t_xn, n_tok, H, c.t_rms_eps));
-        if (int rc = gemm(e, s, e->t_xn, H, w.qkv_w, n_tok, e->t_qn, H, e->t_qkv, e->t_qn, w.qkv_b, nullptr, nullptr, EPI_STORE, 1, w.qkv_s)) return rc;
+        if (int rc = lm_gemm(e, s, e->t_xn, H, w.qkv_w, w.qkv_w8, w.qkv_s, n_tok, e->t_qn, H, e->t_qkv, e->t_qn, w.qkv_b, nullptr, EPI_STORE)) return rc;
         LmRopeArgs ra{e->t_qkv, n_tok, c.t_heads, c.t_kv_heads, e->t_pos3, e->t_slot, e->t_idx, e->rope_cos, e->rope_sin,
                       c.mrope_section[0], c.mrope_section[0] + c.mrope_section[1], kc, vc, c.max_ctx};
         SR_TRY(launch_lm_rope_prefill(s, ra));
         AttnArgs a{e->t_qkv, e->t_qn, kc, 128, (long long)c.max_ctx * 128, vc, c.max_ctx, (long long)128 * c.max_ctx,
                    e->t_attn, QD, e->t_work, n_work, c.t_heads, e->t_group, scale, 1};
         SR_TRY(launch_attn_prefill(s, a, 128));
-        if (int rc = gemm(e, s, e->t_attn, QD, w.o_w, n_tok, H, QD, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID, 1, w.o_s)) return rc;
+        if (int rc = lm_gemm(e, s, e->t_attn, QD, w.o_w, w.o_w8, w.o_s, n_tok, H, QD, e->t_x, H, nullptr, e->t_x, EPI_RESID)) return rc;
         SR_TRY(launch_rmsnorm(s, e->t_x, w.ln2, e->t_xn, n_tok, H, c.t_rms_eps));
-        if (int rc = gemm(e, s, e->t_xn, H, w.gu_w, n_tok, 2 * e->t_inter_pad, H, e->t_act, e->t_inter_pad, nullptr, nullptr, nullptr, EPI_SWIGLU, 1, w.gu_s)) return rc;
-        if (int rc = gemm(e, s, e->t_act, e->t_inter_pad, w.down_w, n_tok, H, e->t_inter_pad, e->t_x, H, nullptr, e->t_x, nullptr, EPI_RESID, 1, w.down_s)) return rc;
+        if (int rc = lm_gemm(e, s, e->t_xn, H, w.gu_w, w.gu_w8, w.gu_s, n_tok, 2 * e->t_inter_pad, H, e->t_act, e->t_inter_pad, nullptr, nullptr, EPI_SWIGLU)) return rc;
+        if (int rc = lm_gemm(e, s, e->t_act, e->t_inter_pad, w.down_w, w.down_w8, w.down_s, n_tok, H, e->t_inter_pad, e->t_x, H, nullptr, e->t_x, EPI_RESID)) return rc;
     }
     // last position of every sequence -> final norm -> tied LM head (hf:1386-1387) -> greedy token
     if (all_logits_out) {       // every position: final norm over all rows, tied LM head as an MFMA GEMM with float32 output
@@ -1298,6 +1321,15 @@ int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void*
                (epilogue & 0x100) ? 1 : 0, nullptr,      // bit 8 of `epilogue`: W is fragment-ordered (tiled16x64)
                (epilogue & 0x200) ? 256 : (epilogue & 0x400) ? 128 : 0};      // bits 9 / 10: force the 256- / 128-tile kernel
     SR_WRAP(launch_gemm((hipStream_t)stream, a, epilogue & 0xff));
+}
+int sr_op_quant_mx(const void* x, int ldx, int M, int K, void* q, void* scales, int rows_pad, void* stream) {
+    SR_WRAP(launch_quant_mx_act((hipStream_t)stream, (const bf16_t*)x, ldx, M, K, (unsigned char*)q, (unsigned char*)scales, rows_pad));
+}
+int sr_op_gemm_mx(const void* A8, int lda, const void* a_scale, int a_rows_pad, const void* W8, const float* w_scale, int M, int N, int K, void* out,
+                  int ldo, const void* bias, const void* resid, int epilogue, void* stream) {
+    GemmArgs a{(const bf16_t*)A8, lda, (const bf16_t*)W8, M, N, K, out, ldo, (const bf16_t*)bias, (const bf16_t*)resid, nullptr, 1, w_scale, 256,
+               (const unsigned char*)a_scale, a_rows_pad};
+    SR_WRAP(launch_gemm256_mx((hipStream_t)stream, a, epilogue & 0xff));
 }
 int sr_op_gemv(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ksplit, int mode, void* stream) {
     GemvArgs a = gv((const bf16_t*)x, ldx, (const bf16_t*)W, M, N, K, out, (mode & 0xff) == GV_SWIGLU ? N / 2 : N);

@@ -21,6 +21,7 @@
 //     p2: read UA1(t) [8]                       stage UA0(t+2)        p3: (B0 kept in VGPRs)   stage UB0(t+2); vmcnt(4)
 #include "kernels.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -32,7 +33,17 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ int swz2(int row, int chunk) { return row * (BK2 * 2) + ((chunk ^ (row & 7)) << 4); }
 
-template <int EPI>
+// MX = true: the fp8 path of BASELINE.json configs[4].  Operands are OCP e4m3 bytes, 128 of them (= the same 128 bytes) per tile row
+// and k-tile, multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 -- the block-scaled form, which is the one that runs at twice the bf16
+// rate (plain fp8 MFMA does not).  Everything about the data movement stays: same units, same swizzle, same phase plan; the byte
+// geometry of a k-tile is identical, it just spans 128 k instead of 64.  Operand layout (established on the hardware by
+// tools/mx_probe): lane (g = l >> 4, r = l & 15) supplies row r's bytes k = 16g..16g+15 and 64+16g..64+16g+15 of the 128-chunk --
+// exactly the two 16-byte pieces the bf16 kernel's two k-steps read -- and the e8m0 scale of the row's 32-wide k-block b comes from
+// lane g = b.  Activations: fp8 bytes [M][K] row-major + scales [K/128][ceil256(M)][4] (k_quant_mx_act); the 1 KB of scales of a
+// k-tile rides along with unit UA1 (one more LDS-DMA by wave 0).  Weights: the decode stream's fp8 image (tiled8, common.h), whose
+// 2 KB per (16-row tile, 128 k) already IS two operand fragments; its per-output-channel float32 scale stays in the epilogue, the
+// block scale of the weight operand is 1 (e8m0 127).
+template <int EPI, bool MX>
 __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, int GROUP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // ONE array (a second __shared__ object de-pipelines)
     int bid = blockIdx.x;
@@ -55,10 +66,14 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
 
     // ---- LDS-DMA sources.  Every unit is 16 pieces of 1 KB (8 tile rows x 128 B, or one k-step half of a fragment-ordered
     // W tile); wave w issues pieces 2w and 2w + 1.
-    const int lr = lane >> 3, lc = ((lane & 7) ^ lr) * 8;                     // XOR swizzle on the SOURCE side (LDS-DMA writes linearly)
-    const bf16_t* asrc[2][2];                                                 // [unit half][piece]
+    const int lr = lane >> 3, lc = ((lane & 7) ^ lr) * 16;                    // XOR swizzle on the SOURCE side (LDS-DMA writes linearly); bytes
+    constexpr int ES = MX ? 1 : 2;                                            // bytes per element
+    const unsigned char* Ab = reinterpret_cast<const unsigned char*>(p.A);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
+    const int nk = p.K / (MX ? 128 : BK2);                                    // k-tiles of 128 bytes per row
+    const unsigned char* asrc[2][2];                                          // [unit half][piece]
     int adst[2][2];
-    const bf16_t* wsrc[2][2];
+    const unsigned char* wsrc[2][2];
     int wdst[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -67,25 +82,32 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
             const int g = wave * 2 + i;                                       // 8-row group inside the unit: 0..15
             const int ru = g * 8;                                             // first unit row of the group
             const int trow = (ru < 64 ? ru : ru + 64) + h * 64;               // tile row: unit h = rows [h*64, +64) of both A halves
-            asrc[h][i] = p.A + (size_t)min(m0 + trow + lr, p.M - 1) * p.lda + lc;
+            asrc[h][i] = Ab + (size_t)min(m0 + trow + lr, p.M - 1) * p.lda * ES + lc;
             adst[h][i] = trow * 128;
             if (tiled) {      // piece = (n-tile of the unit, k-step): the unit's 8 n-tiles are tiles {wn*4 + h*2 + (0,1)}
                 const int ntu = g >> 1, ks = g & 1;
                 const int ntile = (ntu >> 1) * 4 + h * 2 + (ntu & 1);
-                wsrc[h][i] = p.W + (size_t)(n0 / 16 + ntile) * (size_t)(p.K / 64) * 1024 + ks * 512 + lane * 8;
+                // bf16 tiled16x64: 2 KB per (tile, 64 k) = two k-step halves; fp8 tiled8: 1 KB per (tile, 64 k), two of them per k-tile
+                wsrc[h][i] = Wb + (size_t)(n0 / 16 + ntile) * (size_t)nk * 2048 + ks * 1024 + lane * 16;
                 wdst[h][i] = ntile * 2048 + ks * 1024;
             } else {          // row-major: unit h = n-rows [wn*64 + h*32, +32) of every wave column
                 const int nrow = (ru >> 5) * 64 + h * 32 + (ru & 31);
-                wsrc[h][i] = p.W + (size_t)min(n0 + nrow + lr, p.N - 1) * p.K + lc;
+                wsrc[h][i] = Wb + (size_t)min(n0 + nrow + lr, p.N - 1) * p.K * ES + lc;
                 wdst[h][i] = nrow * 128;
             }
         }
-    const size_t w_kt = tiled ? 1024 : BK2;
+    const size_t w_kt = tiled ? 2048 : 128;                                   // bytes per k-tile
+    // MX: the k-tile's activation scales, 256 rows x 4 bytes = 1 KB, [k-tile][row][4]; staged by wave 0 together with unit UA1
+    const unsigned char* ssrc = MX ? p.a_scale + (size_t)m0 * 4 + lane * 16 : nullptr;
     auto stage_a = [&](int h, int kt) {
         unsigned char* base = smem + (kt & 1) * BUF_BYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[h][i] + (size_t)kt * BK2), (lptr_t)(base + adst[h][i]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[h][i] + (size_t)kt * 128), (lptr_t)(base + adst[h][i]), 16, 0, 0);
+        if constexpr (MX) {
+            if (h == 1 && wave == 0)
+                __builtin_amdgcn_global_load_lds((gptr_t)(ssrc + (size_t)kt * p.a_rows_pad * 4), (lptr_t)(smem + 2 * BUF_BYTES + (kt & 1) * 1024), 16, 0, 0);
+        }
     };
     auto stage_w = [&](int h, int kt) {
         unsigned char* base = smem + (kt & 1) * BUF_BYTES + A_BYTES;
@@ -99,7 +121,13 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[4][2], wf0[2][2], wf1[2][2];          // [tile in quadrant][k-step]
+    // operand fragments of one quadrant.  bf16: [tile][k-step] 4 VGPRs each; MX: ONE 8-VGPR operand per tile (the two 16-byte pieces
+    // are loaded straight into its halves, so that no register moves are needed to form the 8-register MFMA source)
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    struct Frag { bf16x8 h[2]; };
+    typedef typename std::conditional<MX, i32x8, Frag>::type frag_t;
+    frag_t af[4], wf0[2], wf1[2];
 
     // fragment addresses (bytes inside a buffer)
     int a_off[2][2];                                 // [m-half quadrant base: tile 0][k-step] -> + t * 16 rows * 128 B
@@ -113,47 +141,83 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
-            w_off[nh][kk] = A_BYTES + (tiled ? (wn * 4 + nh * 2) * 2048 + (fg & 1) * 1024 + (((kk * 2 + (fg >> 1)) * 16 + fr) << 4)
-                                             : swz2(wn * 64 + nh * 32 + fr, kk * 4 + fg));
+            w_off[nh][kk] = A_BYTES + (!tiled ? swz2(wn * 64 + nh * 32 + fr, kk * 4 + fg)
+                                       : MX ? (wn * 4 + nh * 2) * 2048 + kk * 1024 + (lane << 4)       // tiled8: [64-k half][lane][16 B]
+                                            : (wn * 4 + nh * 2) * 2048 + (fg & 1) * 1024 + (((kk * 2 + (fg >> 1)) * 16 + fr) << 4));
     const int w_tile = tiled ? 2048 : 16 * 128;
 
+    auto load_frag = [&](const unsigned char* p0, const unsigned char* p1, frag_t& f) {
+        if constexpr (MX) {
+            const i32x4 lo = *reinterpret_cast<const i32x4*>(p0), hi = *reinterpret_cast<const i32x4*>(p1);
+            f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+            f.h[0] = *reinterpret_cast<const bf16x8*>(p0);
+            f.h[1] = *reinterpret_cast<const bf16x8*>(p1);
+        }
+    };
     auto read_a = [&](const unsigned char* buf, int mh) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) af[t][kk] = *reinterpret_cast<const bf16x8*>(buf + a_off[mh][kk] + t * 2048);
+        for (int t = 0; t < 4; ++t) load_frag(buf + a_off[mh][0] + t * 2048, buf + a_off[mh][1] + t * 2048, af[t]);
     };
-    auto read_w = [&](const unsigned char* buf, int nh, bf16x8 (&wf)[2][2]) {
+    auto read_w = [&](const unsigned char* buf, int nh, frag_t (&wf)[2]) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) wf[t][kk] = *reinterpret_cast<const bf16x8*>(buf + w_off[nh][kk] + t * w_tile);
+        for (int t = 0; t < 2; ++t) load_frag(buf + w_off[nh][0] + t * w_tile, buf + w_off[nh][1] + t * w_tile, wf[t]);
     };
-    auto quad = [&](int mh, int nh, bf16x8 (&wf)[2][2]) {
+    int asc[4];                                      // MX: e8m0 scale of (m-tile row, this lane's k-block fg) for the 4 m-tiles of the current half
+    auto read_scales = [&](int t, int mh) {
+        if constexpr (MX) {
+            const unsigned char* sb = smem + 2 * BUF_BYTES + (t & 1) * 1024;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+            for (int i = 0; i < 4; ++i)
+                asc[i] = *reinterpret_cast<const int*>(sb + (wm * 128 + (mh * 4 + i) * 16 + fr) * 4) >> (8 * fg);   // the MFMA reads byte 0
+        }
+    };
+    auto quad = [&](int mh, int nh, frag_t (&wf)[2]) {
+        if constexpr (MX) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], af[i][kk], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+                    acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0, 127, 0, asc[i]);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j].h[kk], af[i].h[kk], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+        }
+    };
+    // MX only: hipcc (ROCm 7.2) does not keep the block-scaled MFMAs inside their phase -- sched_barrier notwithstanding it sinks
+    // the quadrants of three phases into one 24-MFMA run at the end of the k-tile (ping-pong gone, every fragment alive at once,
+    // spills).  An empty volatile asm that "modifies" the quadrant's accumulators before and after the MFMAs ties them to the
+    // barriers (volatile asm keeps its order relative to the barrier builtins and the other asm statements).
+    auto pin = [&](int mh, int nh) {
+        if constexpr (MX) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[mh * 4 + i][nh * 2 + j]));
+        }
     };
 #define PHASE_SYNC_COMPUTE(MH, NH, WF)                       \
     __builtin_amdgcn_sched_barrier(0);                       \
     __builtin_amdgcn_s_barrier();                            \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
     __builtin_amdgcn_sched_barrier(0);                       \
+    pin(MH, NH);                                             \
     __builtin_amdgcn_s_setprio(1);                           \
     quad(MH, NH, WF);                                        \
     __builtin_amdgcn_s_setprio(0);                           \
+    pin(MH, NH);                                             \
     __builtin_amdgcn_sched_barrier(0);                       \
     __builtin_amdgcn_s_barrier();                            \
     __builtin_amdgcn_sched_barrier(0);
 
-    const int nk = p.K / BK2;
     // ---- prologue: k-tile 0 completely, plus the two units of k-tile 1 the steady state has already issued by then
     stage_a(0, 0); stage_w(0, 0); stage_w(1, 0); stage_a(1, 0);
-    if (nk > 1) { stage_a(0, 1); stage_w(0, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    if (nk > 1) { stage_a(0, 1); stage_w(MX ? 1 : 0, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();       // the second wave row runs half a phase behind the first
@@ -163,18 +227,23 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
         // p0
         read_w(buf, 0, wf0);
         read_a(buf, 0);
+        read_scales(t, 0);
         if (t + 1 < nk) stage_a(1, t + 1);
         PHASE_SYNC_COMPUTE(0, 0, wf0)
         // p1
         read_w(buf, 1, wf1);
-        if (t + 1 < nk) stage_w(1, t + 1);
+        if (t + 1 < nk) stage_w(MX ? 0 : 1, t + 1);       // MX re-reads UB0 in p3, so UB0 / UB1 trade places in the staging order
         PHASE_SYNC_COMPUTE(0, 1, wf1)
         // p2
         read_a(buf, 1);
+        read_scales(t, 1);
         if (t + 2 < nk) stage_a(0, t + 2);
         PHASE_SYNC_COMPUTE(1, 1, wf1)
-        // p3
-        if (t + 2 < nk) { stage_w(0, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        // p3 (MX: the 8-register operands leave no room to keep B0 alive through p1 / p2 -- it is re-read here, like the guide's
+        // template does.  UB0 is then busy until p3, so MX stages UA1(t+1) | UB0(t+1) | UA0(t+2) | UB1(t+2) in p0..p3: every unit is
+        // still re-staged >= 2 phases after its last read, and vmcnt(4) at p3 still retires everything k-tile t + 1 needs)
+        if constexpr (MX) read_w(buf, 0, wf0);
+        if (t + 2 < nk) { stage_w(MX ? 1 : 0, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PHASE_SYNC_COMPUTE(1, 0, wf0)
     }
@@ -282,19 +351,19 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
     }
 }
 
-template <int EPI>
+template <int EPI, bool MX = false>
 int launch256_t(hipStream_t s, const GemmArgs& a) {
     const int ntm = cdiv(a.M, BM2), ntn = a.N / BN2;
-    constexpr int smem = 2 * BUF_BYTES;
+    constexpr int smem = 2 * BUF_BYTES + (MX ? 2048 : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm256<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm256<EPI, MX>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (r != hipSuccess) return (int)r;
         attr_done = true;
     }
     static const char* g_env = getenv("SR_G256_GROUP");        // tuning hook
     const int group = g_env ? atoi(g_env) : 4;
-    hipLaunchKernelGGL((k_gemm256<EPI>), dim3(ntm * ntn), dim3(512), smem, s, a, ntm, ntn, group);
+    hipLaunchKernelGGL((k_gemm256<EPI, MX>), dim3(ntm * ntn), dim3(512), smem, s, a, ntm, ntn, group);
     SR_CHECK_LAUNCH();
     return 0;
 }
@@ -304,6 +373,18 @@ int launch256_t(hipStream_t s, const GemmArgs& a) {
 // shapes the 256-tile kernel takes: whole 256-column tiles, at least two 64-wide k-tiles (M is arbitrary: edge rows are clamped
 // on load and masked on store)
 bool gemm256_supports(const GemmArgs& a) { return a.N % BN2 == 0 && a.K % BK2 == 0 && a.K / BK2 >= 2 && a.M >= 1; }
+
+// fp8 x fp8 on the block-scaled MFMA: A = fp8 bytes [M][lda], a_scale = [K/128][a_rows_pad][4] e8m0, W = tiled8 fp8 image, w_scale per channel
+int launch_gemm256_mx(hipStream_t s, const GemmArgs& a, int epi) {
+    if (a.N % BN2 != 0 || a.K % 128 != 0 || a.K / 128 < 2 || a.M < 1 || !a.a_scale || !a.w_tiled || a.a_rows_pad < cdiv(a.M, 256) * 256) return -22;
+    switch (epi) {
+        case EPI_STORE: return launch256_t<EPI_STORE, true>(s, a);
+        case EPI_RESID: return launch256_t<EPI_RESID, true>(s, a);
+        case EPI_SWIGLU: return launch256_t<EPI_SWIGLU, true>(s, a);
+        case EPI_F32: return launch256_t<EPI_F32, true>(s, a);
+    }
+    return -22;
+}
 
 int launch_gemm256(hipStream_t s, const GemmArgs& a, int epi) {
     if (!gemm256_supports(a)) return -22;

@@ -17,11 +17,16 @@ struct GemmArgs {
     int w_tiled;                // W stored fragment-ordered (tiled16x64, see common.h) instead of row-major
     const float* w_scale;       // optional [N]: per-output-channel scale applied to the accumulator (fp8-quantised W)
     int force_tile;             // 0: launch_gemm picks the kernel; 256 / 128: force gemm256.hip / gemm.hip (tests, tuning)
+    const unsigned char* a_scale;   // MX fp8 path (launch_gemm256_mx): e8m0 block scales of A, [K/128][a_rows_pad][4]
+    int a_rows_pad;
 };
 int launch_gemm(hipStream_t s, const GemmArgs& a, int epi);
 // gemm256.hip: 256 x 256 x 64 tile, 8-phase ping-pong schedule (large M); launch_gemm dispatches to it
 bool gemm256_supports(const GemmArgs& a);
 int launch_gemm256(hipStream_t s, const GemmArgs& a, int epi);
+int launch_gemm256_mx(hipStream_t s, const GemmArgs& a, int epi);
+// MX activation quantiser (OCP MX, e4m3 elements, 32-wide blocks): x bf16 [M][ldx] -> q fp8 [M][K] + e8m0 scales [K/128][rows_pad][4]
+int launch_quant_mx_act(hipStream_t s, const bf16_t* x, int ldx, int M, int K, unsigned char* q, unsigned char* scales, int rows_pad);
 
 // ------------------------------------------------------------------ gemv.hip (weight streaming, M <= 32)
 enum { GV_PARTIAL = 0, GV_SWIGLU = 1, GV_F32 = 2, GV_BIAS = 3, GV_RESID = 4 };

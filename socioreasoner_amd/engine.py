@@ -28,13 +28,13 @@ def _sr_config(g: ModelGeometry, max_patches, max_prefill_tokens, max_batch, max
     c.image_token_id = g.image_token_id
     c.max_patches, c.max_prefill_tokens, c.max_batch = max_patches, max_prefill_tokens, max_batch
     c.max_ctx, c.max_new_tokens = max_ctx, max_new_tokens
-    c.lm_weight_dtype = 1 if lm_fp8 else 0
+    c.lm_weight_dtype = 2 if lm_fp8 == "mx" else 1 if lm_fp8 else 0      # "mx": fp8 weights + MX fp8 activations in prefill (fp8 x fp8 MFMA)
     return c
 
 
 class Engine:
     def __init__(self, geometry: ModelGeometry, *, max_patches=1024, max_prefill_tokens=512, max_batch=1, max_ctx=640,
-                 max_new_tokens=128, device="cuda:0", lm_fp8: bool = False):
+                 max_new_tokens=128, device="cuda:0", lm_fp8=False):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.SocioRError("no GPU visible: the product path has no CPU fallback")

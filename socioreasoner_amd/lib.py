@@ -63,6 +63,8 @@ SIGNATURES = {
     "sr_iou_counts": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
     "sr_render_overlay": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "sr_op_gemm": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "sr_op_quant_mx": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "sr_op_gemm_mx": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "sr_op_gemv": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "sr_op_gemv_fused": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, C.c_float, _vp, _i, _vp, _vp, _vp, _vp]),
     "sr_op_gemv_f32_blocks": (C.c_int, [_i, _i, _i, _i]),

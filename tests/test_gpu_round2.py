@@ -289,3 +289,129 @@ def test_full_depth_batch32_decode_vs_hf(golden_dir):
     assert torch.equal(trace[:, 0], trace[:, 31])              # same tile, same tokens -> same bits in both rows
     record("full3b_tile448_batch32_decode", worst)
     e.close()
+
+
+# ------------------------------------------------------------------------------------------------ fp8 x fp8 prefill GEMM (MX-scaled MFMA)
+def _tile8(q: torch.Tensor) -> torch.Tensor:
+    from tests.util import tile8
+    return tile8(q)
+
+
+def test_mx_activation_quantiser_bit_exact(L):
+    """k_quant_mx_act against oracle/model_ref.py mx_quantize (OCP MX, e4m3 elements, 32-wide blocks): element bytes and e8m0
+    scale bytes equal, including all-zero blocks, blocks whose scaled maximum saturates at 448, tiny and huge magnitudes."""
+    from oracle import model_ref as MR
+    M, K = 77, 512
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(M, K, generator=g)
+    x[3, 32:64] = 0.0
+    x[5] *= 1e-20
+    x[6] *= 3e20
+    x[7, 0:32] = torch.linspace(-1.99, 1.99, 32)          # max just under a power of two: v / X reaches 509 -> saturates at 448
+    x[8] = torch.randn(K, generator=g) * torch.logspace(-8, 8, K)
+    xb = x.to(torch.bfloat16)
+    rows_pad = 256
+    q = torch.zeros(M, K, dtype=torch.uint8, device="cuda")
+    sc = torch.zeros(K // 128, rows_pad, 4, dtype=torch.uint8, device="cuda")
+    assert L.sr_op_quant_mx(P(xb.cuda()), K, M, K, P(q), P(sc), rows_pad, sp()) == 0
+    xq, e = MR.mx_quantize(xb.float())
+    want_el = (xq.reshape(M, K // 32, 32) / torch.ldexp(torch.ones(M, K // 32), e)[..., None]).reshape(M, K).to(torch.float8_e4m3fn)
+    assert torch.equal(q.cpu(), want_el.view(torch.uint8))
+    want_sc = (e + 127).to(torch.uint8).reshape(M, K // 128, 4).permute(1, 0, 2)
+    assert torch.equal(sc[:, :M].cpu(), want_sc)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(512, 2560, 2048, EPI_STORE), (300, 2048, 11008, EPI_RESID), (777, 1024, 256, EPI_SWIGLU), (256, 256, 256, EPI_F32)])
+def test_gemm_mx_fp8_vs_oracle_definition(L, M, N, K, epi):
+    """The block-scaled fp8 MFMA GEMM against the stated definition: y = bf16((mx_quantize(x) . q_w^T) * scale_w + bias) with the
+    device quantiser feeding it (operand / scale layout of v_mfma_scale_f32_16x16x128_f8f6f4 as established by tools/mx_probe)."""
+    from oracle import model_ref as MR
+    x, w, b = rnd((M, K), 31), rnd((N, K), 32, 0.04), rnd((N,), 33, 0.1)
+    QW = MR.QuantW(w.float())
+    QW.mx_act = True
+    w8 = _tile8(QW.q8.view(torch.uint8)).cuda()
+    wsc = QW.scale.float().cuda()
+    rows_pad = (M + 255) // 256 * 256
+    q = torch.zeros(M, K, dtype=torch.uint8, device="cuda")
+    sc = torch.zeros(K // 128, rows_pad, 4, dtype=torch.uint8, device="cuda")
+    assert L.sr_op_quant_mx(P(x.cuda()), K, M, K, P(q), P(sc), rows_pad, sp()) == 0
+    No = N // 2 if epi == EPI_SWIGLU else N
+    bias = b.cuda() if epi in (EPI_STORE, EPI_RESID) else None
+    res0 = rnd((M, No), 34)
+    out = res0.cuda().clone() if epi == EPI_RESID else torch.zeros(M, No, dtype=torch.float32 if epi == EPI_F32 else torch.bfloat16, device="cuda")
+    rc = L.sr_op_gemm_mx(P(q), K, P(sc), rows_pad, P(w8), P(wsc), M, N, K, P(out), No, P(bias), P(out) if epi == EPI_RESID else None, epi, sp())
+    assert rc == 0
+    xq = MR.mx_quantize(x.float())[0]
+    acc = (xq.double() @ QW.q.double().t()).float() * QW.scale
+    # the block-scaled MFMA accumulates with ~2^-16 relative precision (tools/mx_accuracy.py: rms error 1.5e-5 of the result's rms,
+    # no bias) -- coarser than the float32 accumulation of the bf16 MFMA, so a few per cent of the bf16 outputs round the other way
+    if epi == EPI_F32:
+        assert float((out.cpu() - acc).abs().max()) <= 2e-4 * float(acc.abs().max())
+        return
+    if epi == EPI_SWIGLU:       # engine row order: blocks of 16 gate rows then 16 up rows
+        a3 = acc.reshape(M, N // 32, 2, 16)
+        gt, up = MR.r(a3[:, :, 0].reshape(M, N // 2)), MR.r(a3[:, :, 1].reshape(M, N // 2))
+        want = MR.r(MR.silu_bf16(gt) * up)
+        assert_bf16_close(out.float().cpu(), want, 3, 0.05, "mx swiglu")
+        return
+    y = MR.r(acc + b.float())
+    if epi == EPI_RESID:
+        y = MR.r(res0.float() + y)
+    assert_bf16_close(out.float().cpu(), y, 2 if epi == EPI_RESID else 1, 0.03, f"mx gemm {M}x{N}x{K}")     # residual add: a second rounding
+
+
+def test_tiny_fp8_mx_prefill_against_oracle_definition(golden_dir):
+    """lm_weight_dtype = 2 end to end on the tiny model: prefill linears = fp8 x fp8 on the block-scaled MFMA with MX-quantised inputs,
+    decode = fp8 weights with bf16 activations; the oracle applies the same definition (Fp8LmWeights(mx_act) for the prompt, off for
+    the decode steps).  Quantising activations to e4m3 makes the forward discontinuous at 3-bit-mantissa granularity, so bf16-level
+    differences upstream occasionally flip an fp8 rounding downstream: the bound is the fp8 noise floor, checked as rms / bias / max."""
+    from oracle import model_ref as MR
+    from oracle import weights as WG
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.engine import Engine
+    from tests.util import bits_to_f32
+    g = np.load(os.path.join(golden_dir, "hf_tiny.npz"))
+    cfg = MR.config_tiny()
+    W = MR.Fp8LmWeights(WG.LazyWeights(cfg, seed=0), mx_act=True)
+    eng = Engine(geometry_tiny(), max_patches=512, max_prefill_tokens=256, max_batch=2, max_ctx=192, max_new_tokens=16, lm_fp8="mx")
+    eng.load_synthetic_weights(seed=0)
+    grids = [tuple(x) for x in g["grids"].tolist()]
+    img_ref = MR.vit_forward(W, cfg, bits_to_f32(g["pix"]), grids)
+    ids, pos3 = g["ids"], g["pos3"]
+    emb = img_ref.to(torch.bfloat16).cuda()
+    logits = eng.prefill([ids], [pos3], emb, return_logits=True)
+    x = MR.embed_with_images(W, cfg, torch.from_numpy(ids), img_ref)
+    caches = MR.new_caches(cfg)
+    ref_logits = MR.lm_forward(W, cfg, x, torch.from_numpy(pos3), caches)[0]
+    d = (logits[0].cpu() - ref_logits)
+    st = {"max": float(d.abs().max()), "rms": float(d.pow(2).mean().sqrt()), "bias": float(d.mean())}
+    # what the activation quantisation itself costs (information, not a bound): MX prefill vs the W8A16 prefill of mode 1
+    W.set_mx_act(False)
+    a16 = MR.lm_forward(W, cfg, MR.embed_with_images(W, cfg, torch.from_numpy(ids), img_ref), torch.from_numpy(pos3), MR.new_caches(cfg))[0]
+    quant_effect = float((a16 - ref_logits).pow(2).mean().sqrt())
+    print("mx prefill vs oracle", st, "| rms effect of the activation quantisation itself", quant_effect)
+    # measured: rms 0.019 between engine and oracle where the quantisation itself moves the logits by rms 0.031 -- an e4m3 rounding
+    # that flips changes its element by 6 %, so two correct implementations of a 3-layer fp8 x fp8 forward agree only to about the
+    # perturbation the mode itself introduces (the GEMM and the quantiser are pinned exactly at op level above)
+    assert st["rms"] <= quant_effect + 0.005 and abs(st["bias"]) <= 2e-3 and st["max"] <= 0.15, (st, quant_effect)
+    assert quant_effect > 0.02                      # the mode is visible: it is not silently the W8A16 path
+    # decode steps (bf16 activations) continue from the MX-prefilled cache: teacher-forced on the oracle's tokens
+    n_new = 8
+    toks_ref, lg_ref = [], []
+    lg = ref_logits
+    for k in range(n_new):
+        t = MR.greedy_argmax(lg)
+        toks_ref.append(t)
+        xx = W["model.embed_tokens.weight"][torch.tensor([t])]
+        lg = MR.lm_forward(W, cfg, xx, torch.full((3, 1), int(pos3.max()) + 1 + k), caches)[0]
+        lg_ref.append(lg)
+    forced = torch.tensor([toks_ref + [0] * (16 - n_new)], dtype=torch.int32)
+    _, trace = eng.decode(16, trace=True, forced=forced, use_graph=False)
+    for k in range(n_new - 1):
+        dd = (trace[k + 1, 0].cpu() - lg_ref[k])
+        assert float(dd.pow(2).mean().sqrt()) <= quant_effect + 0.005 and float(dd.abs().max()) <= 0.15, (k, float(dd.abs().max()))
+    # batch invariance of the MX prefill: the same prompt alone and next to another prompt gives the same logits, bit for bit
+    txt = np.random.default_rng(3).integers(0, 2000, 50).astype(np.int64)
+    two = eng.prefill([txt, ids], [np.tile(np.arange(50), (3, 1)), pos3], emb, return_logits=True)
+    assert torch.equal(two[1], logits[0])
+    eng.close()

@@ -73,6 +73,32 @@ def bench_gemm():
                           "ms_128": round(t128, 4), "ms_256": round(t256, 4), "TF_128": round(fl / t128 / 1e9, 1), "TF_256": round(fl / t256 / 1e9, 1)}), flush=True)
 
 
+def bench_gemm_mx():
+    """LM prefill shapes at batch 32: bf16 256-tile GEMM vs the fp8 x fp8 block-scaled (MX) GEMM, plus the activation quantiser pass"""
+    lib = L.load()
+    for name, M, N, K, epi in [("lm qkv", 14336, 2560, 2048, "store"), ("lm o", 14336, 2048, 2048, "resid"), ("lm gate/up", 14336, 22016, 2048, "swiglu"),
+                               ("lm down", 14336, 2048, 11008, "resid"), ("lm gate/up 896", 38912, 22016, 2048, "swiglu"), ("lm down 896", 38912, 2048, 11008, "resid")]:
+        a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda") * 0.03).to(torch.bfloat16)
+        w8 = torch.randint(0, 120, (N, K), dtype=torch.uint8, device="cuda")
+        wsc = torch.ones(N, dtype=torch.float32, device="cuda")
+        b = (torch.randn(N, device="cuda") * 0.1).to(torch.bfloat16)
+        No = N // 2 if epi == "swiglu" else N
+        out = torch.zeros(M, No, dtype=torch.bfloat16, device="cuda")
+        res = out if epi == "resid" else None
+        rp = (M + 255) // 256 * 256
+        q = torch.zeros(M, K, dtype=torch.uint8, device="cuda")
+        sc = torch.zeros(K // 128, rp, 4, dtype=torch.uint8, device="cuda")
+        f_bf = lambda: lib.sr_op_gemm(P(a), K, P(w), M, N, K, P(out), No, P(b), P(res), None, EPI[epi] | F256 | TILED, stream())
+        f_q = lambda: lib.sr_op_quant_mx(P(a), K, M, K, P(q), P(sc), rp, stream())
+        f_mx = lambda: lib.sr_op_gemm_mx(P(q), K, P(sc), rp, P(w8), P(wsc), M, N, K, P(out), No, P(b), P(res), EPI[epi], stream())
+        f_q()
+        t_bf, t_mx, t_q = time_variants([f_bf, f_mx, f_q])
+        fl = 2.0 * M * N * K
+        print(json.dumps({"op": "gemm_mx", "shape": name, "M": M, "N": N, "K": K, "ms_bf16": round(t_bf, 4), "ms_mx": round(t_mx, 4), "ms_quant": round(t_q, 4),
+                          "TF_bf16": round(fl / t_bf / 1e9, 1), "TF_mx": round(fl / t_mx / 1e9, 1), "TF_mx_incl_quant": round(fl / (t_mx + t_q) / 1e9, 1)}), flush=True)
+
+
 def bench_gemv(Ms):
     lib = L.load()
     H, QN, I, V = 2048, 2560, 11008, 151936
@@ -143,5 +169,7 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     if what == "gemm":
         bench_gemm()
+    elif what == "gemm_mx":
+        bench_gemm_mx()
     else:
         bench_gemv([int(a) for a in sys.argv[2:]] or [1, 32])
