@@ -49,7 +49,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="batch rows per GPU (32 = configs[2], the default; 1 = configs[1])")
     ap.add_argument("--static", action="store_true", help="one static batch of --batch tiles per step instead of continuous batching")
-    ap.add_argument("--continuous", action="store_true", help="(default for --batch > 1) serve 2 x batch requests through the scheduler")
+    ap.add_argument("--continuous", action="store_true", help="(default for --batch > 1) serve --waves x batch requests through the scheduler")
+    ap.add_argument("--waves", type=int, default=4, help="continuous mode: a step serves waves x batch tile requests through the batch rows")
+    ap.add_argument("--no-overlap", action="store_true", help="continuous mode: admit between decode steps on one stream (round-1 behaviour) instead of "
+                    "staging the next admission on a CU-masked stream under the running rows' decode")
     ap.add_argument("--no-latency", action="store_true", help="skip the additional batch-1 (configs[1]) measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -64,6 +67,8 @@ def main():
     continuous = (B > 1 and not args.static and not args.gather_logits) or args.continuous
     if args.gather_logits or args.no_graph:
         continuous = False
+
+    overlap = continuous and not args.no_overlap
 
     from socioreasoner_amd import dp, hostops, raster, synthetic
     from socioreasoner_amd.config import geometry_3b
@@ -80,13 +85,14 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     geom = geometry_3b()
-    eng = Engine(geom, max_patches=1024 * B, max_prefill_tokens=448 * B, max_batch=B, max_ctx=640, max_new_tokens=N_NEW, device=str(dev), lm_fp8="mx" if args.fp8_mx else args.fp8)
+    eng = Engine(geom, max_patches=1024 * B, max_prefill_tokens=448 * B, max_batch=B, max_ctx=640, max_new_tokens=N_NEW, device=str(dev), lm_fp8="mx" if args.fp8_mx else args.fp8,
+                 kv_slots=2 * B if overlap else 0)      # spare KV slots: the next requests are prefilled while the current rows decode
     t0 = time.time()
     eng.load_synthetic_weights(seed=0)
     load_s = time.time() - t0
 
     # ---- synthetic inputs, resident in HBM.  Request k of a step is tile (rank * n_req + k)
-    n_req = 2 * B if continuous else B
+    n_req = args.waves * B if continuous else B
     tiles = [rank * n_req + i for i in range(n_req)]
     imgs = [torch.from_numpy(synthetic.tile_pixels(i)).to(dev) for i in tiles]
     ids = [synthetic.tile_prompt(geom, i, GRID) for i in tiles]
@@ -114,10 +120,10 @@ def main():
         return counts
 
     def step_continuous(phase_ms=None):
-        """2 x B requests through B rows: the second half is admitted as rows free up (EOS is ignored by the metric, so all
+        """waves x B requests through B rows: the later ones are admitted as rows free up (EOS is ignored by the metric, so all
         rows of a wave finish together; the point is the measured cost of the request-level path)."""
         from socioreasoner_amd.serving import ContinuousBatcher, Request
-        cb = ContinuousBatcher(eng, eos=[], pad_id=0, steps_per_poll=16, time_phases=phase_ms is not None)
+        cb = ContinuousBatcher(eng, eos=[], pad_id=0, steps_per_poll=16, time_phases=phase_ms is not None, overlap=overlap)
         reqs = [Request(ids=ids[k], pos3=pos3[k], max_new=N_NEW, images=[imgs[k]], grids=[GRID]) for k in range(n_req)]
         toks = cb.run(reqs)
         e0, e1 = ev(), ev()
@@ -129,7 +135,9 @@ def main():
             res = dp.all_gather_rows(res, n_req * world)
         if phase_ms is not None:
             for k, v in cb.phase_ms().items():
-                phase_ms[k] += v
+                phase_ms[k] = phase_ms.get(k, 0.0) + v
+            for k in ("admitted", "staged_shared", "steps", "steps_shared"):
+                sched[k] = sched.get(k, 0) + cb.stats[k]
             phase_ms["raster"] += e0.elapsed_time(e1)
         return res
 
@@ -160,6 +168,7 @@ def main():
         return res
 
     phase_ms = {"vit": 0.0, "prefill": 0.0, "decode": 0.0, "raster": 0.0}
+    sched = {}          # continuous mode: requests admitted / staged under decode, decode steps alone / sharing the chip
     step = (lambda rec=False: step_continuous(phase_ms if rec else None)) if continuous else \
         (lambda rec=False: step_static(B, phase_ms if rec else None))
 
@@ -274,8 +283,9 @@ def main():
 
         avg_ms = gemv_roofline(B)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        steps_total = args.steps * (2 if continuous else 1) * (N_NEW - 1)
-        decode_step_ms = phase_ms["decode"] / steps_total if not continuous else phase_ms["decode"] / (args.steps * 2 * N_NEW)
+        steps_total = args.steps * (N_NEW - 1)
+        # continuous mode: the decode steps that had the chip to themselves (steps that shared it with an admission are listed apart)
+        decode_step_ms = phase_ms["decode"] / steps_total if not continuous else phase_ms["decode"] / max(sched["steps"] - sched["steps_shared"], 1)
         kv_bytes = 36864.0 * (448 + N_NEW / 2) * B
         # HBM traffic per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950 note):
         # measured ratio traffic / algorithmic bytes of this kernel family x the algorithmic bytes of one launch
@@ -301,8 +311,13 @@ def main():
                                    "traffic": round(pmc["traffic_over_algorithmic_weighted_batch1"] * bytes_per_launch) if pmc else None,
                                    "decode_step_achieved_GBs": round((wl + wh + 36864.0 * (448 + N_NEW / 2)) / (latency["decode_step_ms"] * 1e-3) / 1e9, 1)}
         del wq, wo, wg, wd, wv
-        per = args.steps * (2 if continuous else 1)          # batches of B tiles inside the timed region
+        # batches of B tiles inside the timed region whose admission had the whole chip (the MFMA fractions are quoted on those)
+        per = (sched["admitted"] - sched["staged_shared"]) / B if continuous else args.steps
         phases = {k: round(v / args.steps, 3) for k, v in phase_ms.items()}
+        if continuous:
+            phases["scheduler"] = dict({k: v // args.steps for k, v in sched.items()}, overlap=overlap,
+                                       decode_step_ms_shared=round(phase_ms.get("decode_shared", 0.0) / max(sched["steps_shared"], 1), 4),
+                                       note="spans named *_shared ran concurrently on disjoint CU sets (admission 96 CUs, decode 160): they do not add up to ms_per_step" if overlap else None)
         vit_ms, pre_ms = phase_ms["vit"] / per, phase_ms["prefill"] / per
         phases["vit_mfma_frac"] = round(VIT_GFLOP * B / (vit_ms * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)
         phases["prefill_mfma_frac"] = round(PREFILL_GFLOP * B / (pre_ms * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)
@@ -331,7 +346,8 @@ def main():
                                    + f"448x448 synthetic tiles, 448-token prompt, greedy decode of {N_NEW} tokens (EOS ignored), raster tail; random-init "
                                    f"weights (counter-based generator, seed 0)" + (f" [{cfg_name}]" if cfg_name else ""),
                        "tiles_per_gpu_per_step": n_req,
-                       "scheduling": "continuous batching (admit on finish) through B rows" if continuous else "static batch",
+                       "scheduling": ("continuous batching through B rows; the next requests' ViT + prefill are staged into spare KV slots on a CU-masked stream under the running rows' decode"
+                                      if overlap else "continuous batching (admit on finish) through B rows") if continuous else "static batch",
                        "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",
                        "exchange": dict(exchange, payload="float32 logits all-gather per decode step (verification mode)" if args.gather_logits
                                         else "one all-gather of 1 KB result rows per tile and step")},

@@ -53,6 +53,9 @@ typedef struct sr_config {
      * quantised to OCP-MX e4m3 (32-wide blocks along k, e8m0 shared scales; definition: oracle/model_ref.py mx_quantize), the
      * weight operand is the same fp8 image; decode is unchanged (bf16 activations). */
     int32_t lm_weight_dtype;
+    /* KV-cache slots, 0 = max_batch.  More slots than batch rows let an admission (sr_admit_stage) prefill the NEXT sequences into
+     * spare slots while all max_batch rows are still decoding; sr_admit_commit then maps freed rows onto those slots. */
+    int32_t kv_slots;
 } sr_config;
 
 /* Bytes of device workspace sr_engine_create needs for this configuration (0 on invalid config). */
@@ -161,6 +164,16 @@ int sr_rows_sampling(sr_engine* e, float temperature, int top_k, float top_p, ui
 int sr_admit(sr_engine* e, const int64_t* host_ids, const int64_t* host_pos3, const int32_t* host_seq_lens,
              const int32_t* host_rows, const int32_t* host_max_new, int n, const void* dev_image_embeds, int n_image_rows,
              float* dev_logits_out, void* stream);
+/* The admission in two halves, so that its expensive half can run UNDER the running rows' decode steps on another (CU-masked) stream:
+ *   sr_admit_stage  : prefill n sequences into SPARE KV slots (sr_config.kv_slots > max_batch), LM head, first token -- touches no row
+ *                     state and only admission-owned scratch; at most one staged admission at a time.
+ *   sr_admit_commit : install the NEXT n staged sequences (in staging order; several calls may share one staged admission as rows
+ *                     free up) into free batch rows (row -> KV slot), on the DECODE stream between two steps; the caller orders it
+ *                     after the staging stream's work (event).  sr_admit = stage into slot == row + commit of all. */
+int sr_admit_stage(sr_engine* e, const int64_t* host_ids, const int64_t* host_pos3, const int32_t* host_seq_lens,
+                   const int32_t* host_kv_slots, const int32_t* host_max_new, int n, const void* dev_image_embeds, int n_image_rows,
+                   float* dev_logits_out, void* stream);
+int sr_admit_commit(sr_engine* e, const int32_t* host_rows, int n, void* stream);
 int sr_rows_step(sr_engine* e, int n_steps, const int32_t* host_eos, int n_eos, int32_t pad_id, void* stream);
 int sr_rows_poll(sr_engine* e, int32_t* host_finished, int32_t* host_steps, void* stream);
 int sr_rows_read(sr_engine* e, int row, int32_t* dev_tokens_out, int n, void* stream);

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_attn_dec_scores(DecodeAttnArgs p) {
     //   threads 0..127  : query head tid >> 3, 16-byte chunks (tid & 7) of both rotary halves
     //   threads 128..191: key element pair (d, d + 64) when this block owns the new token's cache row
     //   threads 192..255: V^T append (no rotary) -- done right here
-    const bool owner = z == (idx >> 6);
+    const bool owner = z == (idx >> 6) && !(p.frozen && p.frozen[b]);
     const int qh = tid >> 3, qc = tid & 7;
     uint4 q1 = uint4{0, 0, 0, 0}, q2 = q1;
     float kx1 = 0.f, kx2 = 0.f;

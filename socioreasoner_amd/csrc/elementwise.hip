@@ -383,7 +383,7 @@ __global__ void k_admit_rows(AdmitArgs a) {
     if (threadIdx.x == 0) {
         a.ctx_len[r] = a.ctx[i];
         a.d_pos[r] = a.pos[i];
-        a.slots[r] = r;
+        a.slots[r] = a.kv_slot ? a.kv_slot[i] : r;
         a.finished[r] = 0;
         a.step[r] = 0;
         a.n_gen[r] = 0;

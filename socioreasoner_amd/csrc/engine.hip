@@ -95,6 +95,9 @@ struct sr_engine {
     std::vector<int64_t> v_grid_cached;
     // ---- LM activations
     bf16_t *t_x, *t_xn, *t_qkv, *t_attn, *t_act;
+    int n_slots = 0;                         // KV-cache slots (>= max_batch): spare slots take admissions prefilled UNDER the running rows' decode
+    int staged_n = 0, staged_off = 0;        // sequences of a staged admission that still wait for rows / already installed
+    bf16_t *d_xadm = nullptr, *d_xadm_n = nullptr; int* d_adm_slots = nullptr; int h_rows[32];
     unsigned char *t_q8 = nullptr, *t_qs = nullptr; int t_rows_pad = 0;     // lm_weight_dtype 2: MX-quantised GEMM input of the prefill
     int *t_src, *t_pos3, *t_slot, *t_idx, *t_lastrow;
     AttnWork* t_work;
@@ -174,6 +177,7 @@ const char* validate(const sr_config& c) {
     if (c.t_heads % c.t_kv_heads || c.t_heads / c.t_kv_heads > 16) return "GQA group must divide and be <= 16";
     if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] != 64) return "mrope_section must sum to 64";
     if (c.max_batch < 1 || c.max_batch > 32) return "max_batch in 1..32";
+    if (c.kv_slots != 0 && (c.kv_slots < c.max_batch || c.kv_slots > 64)) return "kv_slots 0 (= max_batch) or max_batch..64";
     if (c.max_ctx < 64 || c.max_ctx % 64) return "max_ctx multiple of 64";
     if (c.lm_weight_dtype < 0 || c.lm_weight_dtype > 2) return "lm_weight_dtype 0 (bf16), 1 (fp8 e4m3 weights, per-channel scale) or 2 (1 + MX fp8 activations in prefill)";
     if (c.lm_weight_dtype == 2 && (c.t_hidden % 256 || ((c.t_heads + 2 * c.t_kv_heads) * 128) % 256 || c.t_hidden / 128 < 2))
@@ -305,6 +309,9 @@ void carve(sr_engine* e) {
     e->d_row_limit = ar.take<int>(32);
     e->d_ngen = ar.take<int>(32);
     e->d_adm = ar.take<int>(5 * 32);
+    e->d_adm_slots = ar.take<int>(32);
+    e->d_xadm = ar.take<bf16_t>(B * H);           // admission scratch of its own: an admission may run on another stream while rows decode
+    e->d_xadm_n = ar.take<bf16_t>(((B + 15) / 16 * 16) * H);
     e->d_sampled = ar.take<long long>(32);
     e->d_adm_pick = ar.take<long long>(32);
     e->seen_words = (c.t_vocab + 31) / 32;
@@ -319,7 +326,8 @@ void carve(sr_engine* e) {
     e->d_slots = ar.take<int>(32);
     e->d_eos = ar.take<int>(32);
     e->d_tokens = ar.take<int>(B * c.max_new_tokens);
-    e->kv_layer_elems = B * c.t_kv_heads * (size_t)c.max_ctx * 128;
+    e->n_slots = c.kv_slots ? c.kv_slots : c.max_batch;
+    e->kv_layer_elems = (size_t)e->n_slots * c.t_kv_heads * (size_t)c.max_ctx * 128;
     e->kcache = ar.take<bf16_t>(e->kv_layer_elems * c.t_layers);
     e->vtcache = ar.take<bf16_t>(e->kv_layer_elems * c.t_layers);
 
@@ -557,7 +565,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         if (fused && pending) { bf16_t* t = x; x = x_alt; x_alt = t; }     // block 0 wrote the updated stream there
         pending = false;
         DecodeAttnArgs da{e->d_qkv, e->t_qn, e->d_pos, e->d_ctx_len, e->d_slots, e->rope_cos, e->rope_sin, kc, vc, e->d_attn, QD,
-                          B, c.t_heads, c.t_kv_heads, e->t_group, c.max_ctx, scale, e->d_scores, xt};
+                          B, c.t_heads, c.t_kv_heads, e->t_group, c.max_ctx, scale, e->d_scores, xt, e->d_finished};
         SR_TRY(launch_attn_decode(s, da));
         GemvArgs go = gv(e->d_attn, QD, w.o_w, B, H, QD, x, H);
         go.W8 = w.o_w8; go.w_scale = w.o_s; go.x_tiled = xt;
@@ -845,9 +853,28 @@ int sr_finalize_weights(sr_engine* e, void* stream) {
     return 0;
 }
 
+// installs the staged admission's sequences into batch rows (row state + pending first token); runs on the DECODE stream, between steps
+static int commit_admission(sr_engine* e, const int32_t* rows, int n, hipStream_t s) {
+    const sr_config& c = e->c;
+    // the staged sequences may be committed in several portions (rows free up one by one): `off` = how many are installed already
+    const int off = e->staged_off;
+    for (int i = 0; i < n; ++i) e->h_rows[off + i] = rows[i];
+    SR_TRY((int)hipMemcpyAsync(e->d_adm + off, e->h_rows + off, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    const int MB = c.max_batch;
+    AdmitArgs aa{e->d_adm + off, e->d_adm + 32 + off, e->d_adm + 64 + off, e->d_adm + 96 + off, e->d_adm + 128 + off, n,
+                 e->d_ctx_len, e->d_pos, e->d_slots, e->d_finished, e->d_step, e->d_row_limit, e->d_ngen,
+                 e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(c.t_vocab, MB, c.t_hidden, fused_norms(e, MB) ? 1 : 0), e->d_adm_slots + off};
+    SR_TRY(launch_admit_rows(s, aa));
+    if (e->rows_temp > 0.f) SR_TRY(launch_scatter_rows(s, e->d_adm + off, e->d_adm_pick + off, e->d_sampled, n));   // the drawn first tokens
+    e->staged_n -= n;
+    e->staged_off = e->staged_n ? off + n : 0;
+    return 0;
+}
+
+// `commit`: admission only -- install the rows right away (rows = slots: the plain sr_admit); false = stage, sr_admit_commit installs later
 static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_t* seq_lens, const int32_t* slots, int B,
                         const void* image_embeds, int n_image_rows, float* logits_out, void* stream, const int32_t* limits,
-                        float* all_logits_out = nullptr) {
+                        float* all_logits_out = nullptr, bool commit = true) {
     enter(e);
     if (!e || !ids || !pos3 || !seq_lens || !slots) return fail(e, -22, "sr_prefill: null argument");
     char miss[160];
@@ -860,7 +887,7 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
     for (int b = 0; b < B; ++b) {
         if (seq_lens[b] < 1 || seq_lens[b] + 1 > c.max_ctx)
             return fail(e, -22, "sequence %d length %d does not fit max_ctx %d", b, seq_lens[b], c.max_ctx);
-        if (slots[b] < 0 || slots[b] >= c.max_batch) return fail(e, -22, "slot %d out of range", slots[b]);
+        if (slots[b] < 0 || slots[b] >= e->n_slots) return fail(e, -22, "KV slot %d out of range 0..%d", slots[b], e->n_slots - 1);
         n_tok += seq_lens[b];
     }
     if (n_tok > c.max_prefill_tokens) return fail(e, -22, "%d prompt tokens exceed max_prefill_tokens %d", n_tok, c.max_prefill_tokens);
@@ -925,7 +952,7 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
         SR_TRY((int)hipMemsetAsync(e->d_row_limit, 0x7f, 32 * 4, s));
         SR_TRY((int)hipMemsetAsync(e->d_ngen, 0, 32 * 4, s));
     } else {             // admission: [rows | ctx | pos | limit] for the new rows only; installed after the LM head below
-        SR_TRY((int)hipMemcpyAsync(e->d_adm, dmirror(h_state + 64), 32 * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemcpyAsync(e->d_adm_slots, dmirror(h_state + 64), 32 * 4, hipMemcpyDeviceToDevice, s));
         SR_TRY((int)hipMemcpyAsync(e->d_adm + 32, dmirror(h_state), 32 * 4, hipMemcpyDeviceToDevice, s));
         SR_TRY((int)hipMemcpyAsync(e->d_adm + 64, dmirror(h_state + 32), 32 * 4, hipMemcpyDeviceToDevice, s));
         SR_TRY((int)hipMemcpyAsync(e->d_adm + 96, dmirror(h_state + 96), 32 * 4, hipMemcpyDeviceToDevice, s));
@@ -957,8 +984,9 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
         SR_TRY(launch_rmsnorm(s, e->t_x, e->final_norm, e->t_xn, n_tok, H, c.t_rms_eps));
         if (int rc = gemm(e, s, e->t_xn, H, e->embed, n_tok, c.t_vocab, H, all_logits_out, c.t_vocab, nullptr, nullptr, nullptr, EPI_F32, 1)) return rc;
     }
-    // (d_xn is decode scratch: rows in flight do not keep anything in it between steps)
-    bf16_t* xl = limits ? e->d_xn : e->d_xa;
+    // (an admission keeps to scratch of its own -- d_xadm / d_xadm_n, the *_adm logits and partials -- because it may run on another
+    // stream while the rows decode)
+    bf16_t* xl = limits ? e->d_xadm : e->d_xa;
     SR_TRY(launch_gather_rows(s, e->t_x, e->t_lastrow, xl, B, H));
     if (!limits) {
         if (int rc = enqueue_lm_head(e, B, xl, e->d_xb, false, s)) return rc;
@@ -969,28 +997,28 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
         e->rows_mode = false;
         return 0;
     }
-    // admission: final norm + LM head into the admission scratch (B <= 4 fuses the norm; otherwise d_xa is free to hold it:
-    // k_step rewrites every row of d_xa before the next forward), greedy first token, then install the rows
+    // admission: final norm + LM head into the admission scratch (B <= 4 fuses the norm), greedy first token, then install the rows
     {
         GemvArgs g = gv(xl, H, e->embed, B, c.t_vocab, H, e->d_logits_adm, c.t_vocab);
         g.amax_val = e->d_amax_val_adm; g.amax_idx = e->d_amax_idx_adm;
         if (fused_norms(e, B)) { g.norm_w = e->final_norm; g.eps = c.t_rms_eps; }
-        else { SR_TRY(launch_rmsnorm(s, xl, e->final_norm, e->d_xa, B, H, c.t_rms_eps)); g.x = e->d_xa; }
+        else {
+            const int xt = x_tiled_ok(e) ? 1 : 0;
+            SR_TRY(launch_rmsnorm(s, xl, e->final_norm, e->d_xadm_n, B, H, c.t_rms_eps, xt));
+            g.x = e->d_xadm_n; g.x_tiled = xt;
+        }
         SR_TRY(launch_gemv(s, g, GV_F32));
     }
     if (logits_out) SR_TRY((int)hipMemcpyAsync(logits_out, e->d_logits_adm, (size_t)B * c.t_vocab * 4, hipMemcpyDeviceToDevice, s));
     SR_TRY(launch_argmax(s, e->d_logits_adm, B, c.t_vocab, e->d_adm + 128));
-    const int MB = c.max_batch;
-    AdmitArgs aa{e->d_adm, e->d_adm + 32, e->d_adm + 64, e->d_adm + 96, e->d_adm + 128, B,
-                 e->d_ctx_len, e->d_pos, e->d_slots, e->d_finished, e->d_step, e->d_row_limit, e->d_ngen,
-                 e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(c.t_vocab, MB, H, fused_norms(e, MB) ? 1 : 0)};
-    SR_TRY(launch_admit_rows(s, aa));
     if (e->rows_temp > 0.f) {      // sampling mode: the first token of the new rows is drawn from the admission logits
         SampleArgs sa{e->d_logits_adm, c.t_vocab, B, 1.0f / e->rows_temp, e->rows_topk, e->rows_topp, 1.0f, nullptr, e->seen_words,
                       e->rows_seed ^ (0x9E3779B9u * ++e->adm_count), nullptr, e->d_adm_pick, nullptr, 0, 0};
         SR_TRY(launch_sample(s, sa));
-        SR_TRY(launch_scatter_rows(s, e->d_adm, e->d_adm_pick, e->d_sampled, B));
     }
+    e->staged_n = B;
+    e->staged_off = 0;
+    if (commit) return commit_admission(e, slots, B, s);
     return 0;
 }
 
@@ -1025,6 +1053,7 @@ int sr_rows_begin(sr_engine* e, void* stream) {
     SR_TRY((int)hipMemsetAsync(e->d_ngen, 0, 128, s));
     SR_TRY((int)hipStreamSynchronize(s));
     e->rows_mode = true;
+    e->staged_n = e->staged_off = 0;
     e->prefilled_B = e->c.max_batch;
     e->h_ctx_hi = 0;
     e->rows_temp = 0.f;
@@ -1048,10 +1077,43 @@ int sr_admit(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_
         if (max_new[i] < 1 || max_new[i] > e->c.max_new_tokens || seq_lens[i] + max_new[i] > e->c.max_ctx)
             return fail(e, -22, "sr_admit: sequence %d (len %d, max_new %d) does not fit max_new_tokens %d / max_ctx %d", i, seq_lens[i],
                         max_new[i], e->c.max_new_tokens, e->c.max_ctx);
+        if (rows[i] < 0 || rows[i] >= e->c.max_batch) return fail(e, -22, "sr_admit: row %d out of range", rows[i]);
         for (int j = 0; j < i; ++j)
             if (rows[i] == rows[j]) return fail(e, -22, "sr_admit: row %d given twice", rows[i]);
     }
-    return prefill_impl(e, ids, pos3, seq_lens, rows, n, image_embeds, n_image_rows, logits_out, stream, max_new);
+    if (e->staged_n) return fail(e, -22, "sr_admit: %d staged sequences are waiting for sr_admit_commit", e->staged_n);
+    return prefill_impl(e, ids, pos3, seq_lens, rows, n, image_embeds, n_image_rows, logits_out, stream, max_new);      // row r uses KV slot r
+}
+
+// Admission in two halves, so that the expensive half can run UNDER the decode steps of the running rows on another (CU-masked)
+// stream: sr_admit_stage = ViT-fed prefill of n sequences into SPARE KV slots + LM head + first-token choice (touches no row state and
+// only admission-owned scratch); sr_admit_commit = install them into free batch rows (row -> KV slot indirection), on the decode
+// stream, between two steps, once the staging stream's work is known to be complete (the caller orders the streams with an event).
+int sr_admit_stage(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_t* seq_lens, const int32_t* kv_slots, const int32_t* max_new,
+                   int n, const void* image_embeds, int n_image_rows, float* logits_out, void* stream) {
+    if (!e || !kv_slots || !max_new) return fail(e, -22, "sr_admit_stage: null argument");
+    if (!e->rows_mode) return fail(e, -22, "sr_admit_stage: call sr_rows_begin first");
+    if (e->staged_n) return fail(e, -22, "sr_admit_stage: %d staged sequences are waiting for sr_admit_commit", e->staged_n);
+    for (int i = 0; i < n; ++i) {
+        if (max_new[i] < 1 || max_new[i] > e->c.max_new_tokens || seq_lens[i] + max_new[i] > e->c.max_ctx)
+            return fail(e, -22, "sr_admit_stage: sequence %d (len %d, max_new %d) does not fit max_new_tokens %d / max_ctx %d", i, seq_lens[i],
+                        max_new[i], e->c.max_new_tokens, e->c.max_ctx);
+        for (int j = 0; j < i; ++j)
+            if (kv_slots[i] == kv_slots[j]) return fail(e, -22, "sr_admit_stage: KV slot %d given twice", kv_slots[i]);
+    }
+    return prefill_impl(e, ids, pos3, seq_lens, kv_slots, n, image_embeds, n_image_rows, logits_out, stream, max_new, nullptr, false);
+}
+
+int sr_admit_commit(sr_engine* e, const int32_t* rows, int n, void* stream) {
+    enter(e);
+    if (!e || !rows) return fail(e, -22, "sr_admit_commit: null argument");
+    if (!e->rows_mode || n > e->staged_n || n < 1) return fail(e, -22, "sr_admit_commit: %d rows given, %d sequences staged", n, e ? e->staged_n : 0);
+    for (int i = 0; i < n; ++i) {
+        if (rows[i] < 0 || rows[i] >= e->c.max_batch) return fail(e, -22, "sr_admit_commit: row %d out of range", rows[i]);
+        for (int j = 0; j < i; ++j)
+            if (rows[i] == rows[j]) return fail(e, -22, "sr_admit_commit: row %d given twice", rows[i]);
+    }
+    return commit_admission(e, rows, n, (hipStream_t)stream);
 }
 
 // one decode step (bookkeeping kernel + forward) captured once per (B, eos count, pad) and replayed
@@ -1356,7 +1418,7 @@ int sr_op_attn_decode(const void* qkv, int qkv_stride, const int32_t* pos, const
     int rc = attn_decode_prepare(ctx_max, n_q_heads / n_kv_heads);
     if (rc) return fail(nullptr, rc, "attn_decode_prepare failed with %d", rc);
     DecodeAttnArgs a{(const bf16_t*)qkv, qkv_stride, pos, ctx_len, nullptr, (const bf16_t*)rope_cos, (const bf16_t*)rope_sin, (bf16_t*)kcache, (bf16_t*)vtcache, (bf16_t*)out,
-                     out_stride, B, n_q_heads, n_kv_heads, n_q_heads / n_kv_heads, ctx_max, scale, (bf16_t*)scores_scratch};
+                     out_stride, B, n_q_heads, n_kv_heads, n_q_heads / n_kv_heads, ctx_max, scale, (bf16_t*)scores_scratch, 0, nullptr};
     SR_WRAP(launch_attn_decode((hipStream_t)stream, a));
 }
 int sr_op_rmsnorm(const void* x, const void* w, void* out, int rows, int H, float eps, void* stream) {

@@ -84,6 +84,8 @@ struct DecodeAttnArgs {
     float scale;
     bf16_t* scores;                       // scratch [B][kvh][group][ctx_max] bf16 between the two decode launches
     int out_tiled;                        // write `out` fragment-ordered (tiled16x64, K = out_stride): it is the o_proj GEMV's x
+    const int* frozen;                    // [B] or null: rows whose flag is set append nothing to the cache (finished rows: their
+                                          // KV slot may already be staged for the next sequence -- sr_admit_stage)
 };
 int launch_attn_decode(hipStream_t s, const DecodeAttnArgs& a);
 int attn_decode_prepare(int ctx_max, int group);
@@ -138,6 +140,7 @@ struct AdmitArgs {
     const int* rows; const int* ctx; const int* pos; const int* limit; const int* first_tok; int n;
     int* ctx_len; int* d_pos; int* slots; int* finished; int* step; int* row_limit; int* n_gen;
     float* amax_val; int* amax_idx; int n_part;
+    const int* kv_slot;         // KV-cache slot of each admitted sequence (null: slot = row)
 };
 int launch_admit_rows(hipStream_t s, const AdmitArgs& a);
 // ------------------------------------------------------------------ sample.hip

@@ -11,7 +11,7 @@ from . import lib as L
 from .config import ModelGeometry
 
 
-def _sr_config(g: ModelGeometry, max_patches, max_prefill_tokens, max_batch, max_ctx, max_new_tokens, lm_fp8=False) -> L.SrConfig:
+def _sr_config(g: ModelGeometry, max_patches, max_prefill_tokens, max_batch, max_ctx, max_new_tokens, lm_fp8=False, kv_slots=0) -> L.SrConfig:
     v, t = g.vision, g.text
     c = L.SrConfig()
     c.v_depth, c.v_hidden, c.v_heads, c.v_inter = v.depth, v.hidden_size, v.num_heads, v.intermediate_size
@@ -28,20 +28,23 @@ def _sr_config(g: ModelGeometry, max_patches, max_prefill_tokens, max_batch, max
     c.image_token_id = g.image_token_id
     c.max_patches, c.max_prefill_tokens, c.max_batch = max_patches, max_prefill_tokens, max_batch
     c.max_ctx, c.max_new_tokens = max_ctx, max_new_tokens
+    c.kv_slots = int(kv_slots)
     c.lm_weight_dtype = 2 if lm_fp8 == "mx" else 1 if lm_fp8 else 0      # "mx": fp8 weights + MX fp8 activations in prefill (fp8 x fp8 MFMA)
     return c
 
 
 class Engine:
     def __init__(self, geometry: ModelGeometry, *, max_patches=1024, max_prefill_tokens=512, max_batch=1, max_ctx=640,
-                 max_new_tokens=128, device="cuda:0", lm_fp8=False):
+                 max_new_tokens=128, device="cuda:0", lm_fp8=False, kv_slots: int = 0):
+        """kv_slots: KV-cache slots (0 = max_batch); spare slots let the scheduler prefill the next requests while all rows decode"""
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.SocioRError("no GPU visible: the product path has no CPU fallback")
         self.geom = geometry
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        self.cfg = _sr_config(geometry, max_patches, max_prefill_tokens, max_batch, max_ctx, max_new_tokens, lm_fp8)
+        self.cfg = _sr_config(geometry, max_patches, max_prefill_tokens, max_batch, max_ctx, max_new_tokens, lm_fp8, kv_slots)
+        self.kv_slots = int(kv_slots) or int(max_batch)
         nbytes = self.lib.sr_workspace_bytes(C.byref(self.cfg))
         if nbytes == 0:
             raise L.SocioRError("invalid engine configuration: " + self.lib.sr_last_error(None).decode())
@@ -248,6 +251,30 @@ class Engine:
                                   C.c_void_p(image_embeds.data_ptr()) if image_embeds is not None else None, n_img,
                                   C.c_void_p(logits.data_ptr()) if logits is not None else None, self._s()), self._h, "sr_admit")
         return logits
+
+    def admit_stage(self, kv_slots: Sequence[int], ids: Sequence[np.ndarray], pos3: Sequence[np.ndarray], max_new: Sequence[int],
+                    image_embeds: torch.Tensor | None = None):
+        """First half of an admission, on the CURRENT torch stream (normally a CU-masked side stream): prefill into spare KV slots, LM
+        head, first token.  No row state is touched; admit_commit installs the sequences into rows later."""
+        n = len(ids)
+        lens = np.array([len(x) for x in ids], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.int64) for x in ids]))
+        p3 = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.int64).reshape(3, -1) for p in pos3], axis=1))
+        sl = np.asarray(list(kv_slots), dtype=np.int32)
+        mn = np.asarray(list(max_new), dtype=np.int32)
+        n_img = 0 if image_embeds is None else int(image_embeds.shape[0])
+        if image_embeds is not None:
+            image_embeds = image_embeds.contiguous()
+            assert image_embeds.dtype == torch.bfloat16
+        L.check(self.lib.sr_admit_stage(self._h, flat.ctypes.data_as(L._i64p), p3.ctypes.data_as(L._i64p), lens.ctypes.data_as(L._i32p),
+                                        sl.ctypes.data_as(L._i32p), mn.ctypes.data_as(L._i32p), n,
+                                        C.c_void_p(image_embeds.data_ptr()) if image_embeds is not None else None, n_img, None, self._s()),
+                self._h, "sr_admit_stage")
+
+    def admit_commit(self, rows: Sequence[int]):
+        """Second half, on the decode stream between two steps: batch row rows[i] takes over the i-th staged sequence (and its KV slot)."""
+        rw = np.asarray(list(rows), dtype=np.int32)
+        L.check(self.lib.sr_admit_commit(self._h, rw.ctypes.data_as(L._i32p), len(rw), self._s()), self._h, "sr_admit_commit")
 
     def rows_step(self, n_steps: int, eos: Sequence[int] = (), pad_id: int = 0):
         eos_a = np.asarray(list(eos), dtype=np.int32)

@@ -19,7 +19,7 @@ class SrConfig(C.Structure):
         ("t_rms_eps", C.c_float), ("t_rope_theta", C.c_float), ("mrope_section", C.c_int32 * 3),
         ("image_token_id", C.c_int32),
         ("max_patches", C.c_int32), ("max_prefill_tokens", C.c_int32), ("max_batch", C.c_int32),
-        ("max_ctx", C.c_int32), ("max_new_tokens", C.c_int32), ("lm_weight_dtype", C.c_int32),
+        ("max_ctx", C.c_int32), ("max_new_tokens", C.c_int32), ("lm_weight_dtype", C.c_int32), ("kv_slots", C.c_int32),
     ]
 
 
@@ -55,6 +55,8 @@ SIGNATURES = {
     "sr_rows_begin": (C.c_int, [_vp, _vp]),
     "sr_rows_sampling": (C.c_int, [_vp, C.c_float, _i, C.c_float, C.c_uint32]),
     "sr_admit": (C.c_int, [_vp, _i64p, _i64p, _i32p, _i32p, _i32p, _i, _vp, _i, _vp, _vp]),
+    "sr_admit_stage": (C.c_int, [_vp, _i64p, _i64p, _i32p, _i32p, _i32p, _i, _vp, _i, _vp, _vp]),
+    "sr_admit_commit": (C.c_int, [_vp, _i32p, _i, _vp]),
     "sr_rows_step": (C.c_int, [_vp, _i, _i32p, _i, C.c_int32, _vp]),
     "sr_rows_poll": (C.c_int, [_vp, _i32p, _i32p, _vp]),
     "sr_rows_read": (C.c_int, [_vp, _i, _vp, _i, _vp]),

@@ -29,15 +29,26 @@ class Request:
 
 class ContinuousBatcher:
     def __init__(self, engine, eos: Sequence[int], pad_id: int, steps_per_poll: int = 8, sampling: Optional[dict] = None,
-                 time_phases: bool = False):
+                 time_phases: bool = False, overlap: bool = False, admit_cus_per_se: int = 3):
         """sampling: None = greedy, else {"temperature", "top_k" (1..1024), "top_p", "seed"} shared by all requests.
-        time_phases: bracket every ViT / prefill / decode call with events on the launch stream (phase_ms() sums them)."""
+        time_phases: bracket every ViT / prefill / decode call with events on the launch stream (phase_ms() sums them).
+        overlap: admissions are STAGED into spare KV slots (engine.kv_slots > max_batch) on a CU-masked side stream while the running
+        rows keep decoding on the rest of the chip, and committed into rows as they free up (socioreasoner_amd/streams.py)."""
         self.engine, self.eos, self.pad_id, self.steps_per_poll = engine, [int(e) for e in eos], int(pad_id), steps_per_poll
         self._ev = [] if time_phases else None
+        self.overlap = bool(overlap) and engine.kv_slots > engine.cfg.max_batch
+        self.staged = None                     # (requests, kv slots, completion event) of the admission in flight
+        self.row_slot: Dict[int, int] = {}
+        self.free_slots = deque(range(engine.kv_slots))
+        self._dec_last = None
+        self._commit_ev = None
+        if self.overlap:
+            from .streams import OverlapStreams
+            self.streams = OverlapStreams(engine.device, admit_cus_per_se)
         self.free = deque(range(engine.cfg.max_batch))
         self.active: Dict[int, Request] = {}
         self.pending: deque = deque()
-        self.stats = {"admitted": 0, "steps": 0, "admissions": 0}
+        self.stats = {"admitted": 0, "steps": 0, "admissions": 0, "staged_shared": 0, "steps_shared": 0}
         engine.rows_begin()
         if sampling:
             engine.rows_sampling(float(sampling["temperature"]), int(sampling["top_k"]), float(sampling.get("top_p", 1.0)), int(sampling.get("seed", 0)))
@@ -56,6 +67,8 @@ class ContinuousBatcher:
     def phase_ms(self) -> Dict[str, float]:
         """Sum of the event-bracketed spans per phase (synchronises)."""
         out = {"vit": 0.0, "prefill": 0.0, "decode": 0.0}
+        if self.overlap:      # spans that shared the chip (admission on its CU set under decode on the rest) are kept apart
+            out.update({"vit_shared": 0.0, "prefill_shared": 0.0, "decode_shared": 0.0})
         if self._ev:
             torch.cuda.synchronize(self.engine.device)
             for name, a, b in self._ev:
@@ -66,7 +79,7 @@ class ContinuousBatcher:
         self.pending.append(req)
 
     def idle(self) -> bool:
-        return not self.pending and not self.active
+        return not self.pending and not self.active and self.staged is None
 
     def _admit(self):
         cfg = self.engine.cfg
@@ -97,8 +110,109 @@ class ContinuousBatcher:
         self.stats["admitted"] += len(grp)
         self.stats["admissions"] += 1
 
+    # ------------------------------------------------------------------ overlapped admission (stage on a side stream, commit into rows)
+    def _take_group(self, limit: int):
+        cfg = self.engine.cfg
+        grp, ntok, npatch = [], 0, 0
+        while self.pending and len(grp) < limit:
+            r = self.pending[0]
+            np_r = sum(t * h * w for t, h, w in r.grids)
+            if grp and (ntok + len(r.ids) > cfg.max_prefill_tokens or npatch + np_r > cfg.max_patches):
+                break
+            grp.append(self.pending.popleft())
+            ntok += len(r.ids)
+            npatch += np_r
+        return grp
+
+    def _use_decode_stream(self, s):
+        """decode moves between the unmasked stream and the masked one; the new stream waits for what the old one has queued"""
+        if self._dec_last is not None and self._dec_last is not s:
+            s.wait_stream(self._dec_last)
+        self._dec_last = s
+        return s
+
+    def _stage(self):
+        grp = self._take_group(min(len(self.free_slots), self.engine.cfg.max_batch))
+        if not grp:
+            return
+        slots = [self.free_slots.popleft() for _ in grp]
+        # with rows running: the admission's half of the chip; with nothing to decode there is nothing to share the chip with
+        shared = "_shared" if self.active else ""
+        if self.active:
+            s = self.streams.admit
+            self.stats["staged_shared"] += len(grp)
+            if self._commit_ev is not None:
+                s.wait_event(self._commit_ev)          # the previous group's last commit reads the engine's admission scratch
+        else:
+            s = self._use_decode_stream(self.streams.decode_full)
+        with torch.cuda.stream(s):
+            t0 = self._mark()
+            emb = None
+            ims = [im for r in grp for im in r.images]
+            if ims:
+                pix = torch.cat([self.engine.patchify(im) for im in ims], dim=0)
+                emb = self.engine.vit_forward(pix, [g for r in grp for g in r.grids])
+            t1 = self._mark()
+            self.engine.admit_stage(slots, [r.ids for r in grp], [r.pos3 for r in grp], [r.max_new for r in grp], emb)
+            self._span("vit" + shared, t0, t1)
+            self._span("prefill" + shared, t1, self._mark())
+            ev = torch.cuda.Event()
+            ev.record(s)
+        self.staged = (grp, slots, ev, emb)            # emb kept alive until the side stream is done with it
+        self.stats["admissions"] += 1
+
+    def _commit(self):
+        """install as many staged sequences as there are free rows (in staging order); the rest waits for the next rows"""
+        grp, slots, ev, _ = self.staged
+        k = min(len(self.free), len(grp))
+        rows = [self.free.popleft() for _ in range(k)]
+        s = self._use_decode_stream(self.streams.decode_full)
+        s.wait_event(ev)
+        with torch.cuda.stream(s):
+            self.engine.admit_commit(rows)
+            self._commit_ev = torch.cuda.Event()
+            self._commit_ev.record(s)
+        for row, slot, r in zip(rows, slots[:k], grp[:k]):
+            self.active[row] = r
+            self.row_slot[row] = slot
+        self.stats["admitted"] += k
+        del grp[:k], slots[:k]
+        if not grp:
+            self.staged = None
+
+    def _pump_overlap(self, on_complete):
+        if self.staged is not None and self.free and (self.staged[2].query() or not self.active):
+            self._commit()                             # (ordered after the staging stream through the event, not on the host)
+        if not self.active and self.staged is None and self.pending:
+            self._stage()                              # nothing to decode meanwhile: whole chip, install at once
+            self._commit()
+        if not self.active:
+            if self.staged is not None:
+                self.staged[2].synchronize()
+            return
+        busy = self.staged is not None and not self.staged[2].query()
+        s = self._use_decode_stream(self.streams.decode if busy else self.streams.decode_full)
+        with torch.cuda.stream(s):
+            t0 = self._mark()
+            self.engine.rows_step(self.steps_per_poll, self.eos, self.pad_id)
+            self._span("decode_shared" if busy else "decode", t0, self._mark())
+        self.stats["steps"] += self.steps_per_poll
+        self.stats["steps_shared"] += self.steps_per_poll if busy else 0
+        if self.staged is None and self.pending and self.free_slots:
+            self._stage()                              # the host side of the next admission is prepared while the chunk above runs
+        with torch.cuda.stream(s):
+            fin, cnt = self.engine.rows_poll()
+            for row in [r for r in self.active if fin[r]]:
+                req = self.active.pop(row)
+                toks = self.engine.row_tokens(row, int(cnt[row])).cpu().tolist()
+                self.free.append(row)
+                self.free_slots.append(self.row_slot.pop(row))
+                on_complete(req, toks)
+
     def pump(self, on_complete: Callable[[Request, List[int]], None]):
         """One scheduling round: admit what fits, decode `steps_per_poll` tokens, release finished rows."""
+        if self.overlap:
+            return self._pump_overlap(on_complete)
         self._admit()
         if not self.active:
             return
@@ -121,4 +235,6 @@ class ContinuousBatcher:
             self.submit(r)
         while not self.idle():
             self.pump(lambda req, toks: out.__setitem__(order[id(req)], toks))
+        if self.overlap and self._dec_last is not None:      # hand back to the caller's stream
+            torch.cuda.current_stream(self.engine.device).wait_stream(self._dec_last)
         return out

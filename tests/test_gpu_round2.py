@@ -166,6 +166,62 @@ def test_continuous_batching_32_rows_full_3b():
     e.close()
 
 
+def test_overlapped_admission_equals_static_batches():
+    """Admission overlapped with decode (socioreasoner_amd/serving.py overlap=True): the next requests' ViT + prefill run on a
+    CU-masked stream into SPARE KV slots (kv_slots 48 > 32 rows) while the running rows keep decoding on the rest of the chip,
+    and are committed into rows as they free up -- possibly in several portions.  56 requests, a third of them short text-only
+    prompts with small budgets (their rows finish early and their slots are re-staged with 448-token image prompts while the
+    finished rows still step: the decode append of a finished row must not touch the re-used slot), ragged max_new.  Every
+    request's tokens equal those of the same request decoded in a static batch."""
+    import numpy as np
+    from socioreasoner_amd import hostops, synthetic
+    from socioreasoner_amd.config import geometry_3b
+    from socioreasoner_amd.engine import Engine
+    from socioreasoner_amd.serving import ContinuousBatcher, Request
+    geom = geometry_3b()
+    B, NREQ, G = 32, 56, 24
+    e = Engine(geom, max_patches=1024 * B, max_prefill_tokens=448 * B, max_batch=B, max_ctx=512, max_new_tokens=G, kv_slots=48)
+    e.load_synthetic_weights(seed=0)
+    grid = (1, 32, 32)
+    imgs = [torch.from_numpy(synthetic.tile_pixels(i)).cuda() for i in range(8)]
+    rng = np.random.default_rng(5)
+    ids, pos, has_img = [], [], []
+    for i in range(NREQ):
+        if i % 3 == 2:
+            x = rng.integers(1000, 60000, size=20 + (i * 5) % 37).astype(np.int64)
+            p, _ = hostops.get_rope_index(torch.from_numpy(x)[None], None, None)
+        else:
+            x = synthetic.tile_prompt(geom, i, grid)
+            p, _ = hostops.get_rope_index(torch.from_numpy(x)[None], [grid], None)
+        ids.append(x)
+        pos.append(p[:, 0].numpy())
+        has_img.append(i % 3 != 2)
+    max_new = [(3 + i % 4) if not has_img[i] else G - (i * 7) % 13 for i in range(NREQ)]
+    ref = {}
+    for lo in (0, NREQ - B):
+        sel = list(range(lo, lo + B))
+        pix = torch.cat([e.patchify(imgs[i % 8]) for i in sel if has_img[i]], dim=0)
+        emb = e.vit_forward(pix, [grid] * sum(has_img[i] for i in sel))
+        e.prefill([ids[i] for i in sel], [pos[i] for i in sel], emb)
+        toks = e.decode(G).cpu().tolist()
+        for r, i in enumerate(sel):
+            ref[i] = toks[r]
+    reqs = lambda: [Request(ids=ids[i], pos3=pos[i], max_new=max_new[i], images=[imgs[i % 8]] if has_img[i] else [],
+                            grids=[grid] if has_img[i] else []) for i in range(NREQ)]
+    cb = ContinuousBatcher(e, eos=[], pad_id=0, steps_per_poll=2, overlap=True)
+    assert cb.overlap
+    out = cb.run(reqs())
+    for i in range(NREQ):
+        assert out[i] == ref[i][: max_new[i]], (i, out[i][:8], ref[i][:8])
+    assert cb.stats["admitted"] == NREQ and cb.stats["staged_shared"] >= NREQ - B and cb.stats["steps_shared"] > 0
+    assert sorted(cb.free_slots) == list(range(48)) and len(cb.free) == B
+    # the same engine afterwards through the one-stream scheduler (sr_admit: slot == row): same tokens
+    cb2 = ContinuousBatcher(e, eos=[], pad_id=0, steps_per_poll=4)
+    out2 = cb2.run(reqs())
+    assert out2 == out
+    e.close()
+
+
 # ------------------------------------------------------------------------------------------------ RCCL on one rank
 def test_rccl_exchange_path_single_rank(tmp_path):
     """The test box has one GPU, so the N > 1 RCCL run belongs to the driver's scaling tier; what CAN run here is the same
