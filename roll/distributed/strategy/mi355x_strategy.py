@@ -77,7 +77,11 @@ class Mi355xStrategy(InferenceStrategy):
         # ViT / prefill capacities follow the batch: the shipped workload feeds TWO images of up to 756 x 756 (2916 patches, 729
         # image tokens each) per sample, so a full batch of max_batch samples must fit one admission (otherwise decode would run
         # with a fraction of its rows filled)
-        self.engine = Engine(self.geom, max_patches=int(sc.get("max_patches", self.max_batch * 2 * 2916)),
+        # spare KV slots (default: as many again as rows) let the scheduler prefill the next requests on a CU-masked stream while the
+        # running rows decode (socioreasoner_amd/serving.py overlap); strategy_config overlap_admission: false = one stream as before
+        self.overlap = bool(sc.get("overlap_admission", True))
+        kv_slots = int(sc.get("kv_slots", 2 * self.max_batch if self.overlap else 0))
+        self.engine = Engine(self.geom, max_patches=int(sc.get("max_patches", self.max_batch * 2 * 2916)), kv_slots=kv_slots,
                              max_prefill_tokens=int(sc.get("max_prefill_tokens", min(prompt_len, 2048) * self.max_batch)),
                              max_batch=self.max_batch, max_ctx=max_ctx, max_new_tokens=min(resp_len, max_ctx - 1),
                              lm_fp8={"fp8": True, "fp8_e4m3": True, "fp8_mx": "mx"}.get(str(sc.get("quantization", "") or "").lower(), False),   # vLLM's knob name; fp8_mx: + MX fp8 activations in prefill
@@ -302,7 +306,7 @@ class Mi355xStrategy(InferenceStrategy):
                 if room < 1:
                     raise ValueError(f"prompt of {len(ids_k)} tokens leaves no room in max_ctx {self.engine.cfg.max_ctx}")
                 reqs.append(Request(ids=ids_k, pos3=pos_k, max_new=max(1, min(max_new, room)), images=ims_k, grids=grids_k))
-            outs = ContinuousBatcher(self.engine, eos, pad, sampling=smp).run(reqs)
+            outs = ContinuousBatcher(self.engine, eos, pad, sampling=smp, overlap=self.overlap).run(reqs)
             for k in range(B):
                 row = [int(t) for t in outs[k]]
                 cut = next((j + 1 for j, t in enumerate(row) if t in eos), len(row))
@@ -413,7 +417,7 @@ class Mi355xStrategy(InferenceStrategy):
                                                "top_p": float(gc.get("top_p", 1.0) or 1.0), "seed": int(gc.get("seed", 0) or 0)}
                     key = (tuple(eos), pad, None if smp is None else tuple(sorted(smp.items())))
                     if batcher is None or (key != bkey and batcher.idle()):
-                        batcher, bkey = ContinuousBatcher(self.engine, eos, pad, sampling=smp), key
+                        batcher, bkey = ContinuousBatcher(self.engine, eos, pad, sampling=smp, overlap=self.overlap), key
                     if key != bkey:
                         sampled.append(req)          # different stop set / sampling parameters while rows are running: static path
                     else:
@@ -433,7 +437,8 @@ class Mi355xStrategy(InferenceStrategy):
                 sampled = [p for p in sampled if p.meta_info.get("request_id") != rid]
                 if batcher is not None:      # queued requests can be dropped; a running row finishes and is discarded
                     batcher.pending = type(batcher.pending)(r for r in batcher.pending if r.tag.meta_info.get("request_id") != rid)
-                    for r in batcher.active.values():      # (an ABORT may name a row that was already aborted: keep the tag)
+                    # (an ABORT may name a row that was already aborted: keep the tag.  Staged requests -- prefilled, waiting for a row -- run too)
+                    for r in list(batcher.active.values()) + (list(batcher.staged[0]) if batcher.staged is not None else []):
                         if r.tag.meta_info.get("request_id") == rid:
                             r.aborted = True
             elif name == "STOP":

@@ -43,8 +43,8 @@ class ContinuousBatcher:
         self._dec_last = None
         self._commit_ev = None
         if self.overlap:
-            from .streams import OverlapStreams
-            self.streams = OverlapStreams(engine.device, admit_cus_per_se)
+            from .streams import overlap_streams
+            self.streams = overlap_streams(engine.device, admit_cus_per_se)
         self.free = deque(range(engine.cfg.max_batch))
         self.active: Dict[int, Request] = {}
         self.pending: deque = deque()
@@ -126,7 +126,9 @@ class ContinuousBatcher:
 
     def _use_decode_stream(self, s):
         """decode moves between the unmasked stream and the masked one; the new stream waits for what the old one has queued"""
-        if self._dec_last is not None and self._dec_last is not s:
+        if self._dec_last is None:                   # first use: whatever the caller queued (weights, inputs) comes first
+            s.wait_stream(torch.cuda.current_stream(self.engine.device))
+        elif self._dec_last is not s:
             s.wait_stream(self._dec_last)
         self._dec_last = s
         return s
@@ -140,6 +142,7 @@ class ContinuousBatcher:
         shared = "_shared" if self.active else ""
         if self.active:
             s = self.streams.admit
+            s.wait_stream(torch.cuda.current_stream(self.engine.device))     # the request's images were produced on the caller's stream
             self.stats["staged_shared"] += len(grp)
             if self._commit_ev is not None:
                 s.wait_event(self._commit_ev)          # the previous group's last commit reads the engine's admission scratch

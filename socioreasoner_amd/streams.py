@@ -42,6 +42,19 @@ def masked_stream(device, cu_lo: int, cu_hi: int) -> "torch.cuda.ExternalStream"
     return torch.cuda.ExternalStream(s.value, device=dev)
 
 
+_sets = {}
+
+
+def overlap_streams(device, admit_cus_per_se: int = 3) -> "OverlapStreams":
+    """One stream set per (device, split) for the life of the process: schedulers come and go (one per generate call), HIP streams
+    created with a CU mask are never handed back by torch."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(admit_cus_per_se))
+    if key not in _sets:
+        _sets[key] = OverlapStreams(dev, admit_cus_per_se)
+    return _sets[key]
+
+
 class OverlapStreams:
     """decode_full: unmasked, used while no admission is in flight; decode / admit: the two halves of the chip."""
 
