@@ -115,14 +115,16 @@ __global__ __launch_bounds__(256) void k_rmsnorm_row(bf16_t* x, const bf16_t* xi
 // float32 math, one rounding.  cos/sin tables [n_rows][hd/2] (the two halves of HF's emb are identical).
 // one thread = 8 rotary pairs: 16-byte loads of x[d..d+7] and x[d+half..], two float4 each of cos / sin (hd/2 % 8 == 0)
 __global__ __launch_bounds__(256) void k_vit_rope(bf16_t* qkv, int n_rows, int n_heads, int hd, const float* cos_t,
-                                                  const float* sin_t) {
+                                                  const float* sin_t, int paired) {
     const int half = hd / 2, C = n_heads * hd, nch = half / 8, per_row = 2 * n_heads * nch;
     const long long task = (long long)blockIdx.x * 256 + threadIdx.x;
     if (task >= (long long)n_rows * per_row) return;
     const int row = (int)(task / per_row), rem = (int)(task % per_row);
     const int sec = rem / (n_heads * nch), h = (rem / nch) % n_heads, c = rem % nch;
-    bf16_t* p = qkv + (size_t)row * 3 * C + sec * C + h * hd + c * 8;
-    const uint4 u1 = *reinterpret_cast<const uint4*>(p), u2 = *reinterpret_cast<const uint4*>(p + half);
+    // HF channel order: x1 = d, x2 = d + half.  Paired order (vit_qk_perm): 8 x1 then their 8 x2 in every group of 16
+    bf16_t* p = qkv + (size_t)row * 3 * C + sec * C + h * hd + (paired ? c * 16 : c * 8);
+    bf16_t* p2 = paired ? p + 8 : p + half;
+    const uint4 u1 = *reinterpret_cast<const uint4*>(p), u2 = *reinterpret_cast<const uint4*>(p2);
     const float4* cp = reinterpret_cast<const float4*>(cos_t + (size_t)row * half + c * 8);
     const float4* sp = reinterpret_cast<const float4*>(sin_t + (size_t)row * half + c * 8);
     const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
@@ -131,12 +133,12 @@ __global__ __launch_bounds__(256) void k_vit_rope(bf16_t* qkv, int n_rows, int n
     const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     float o1[8], o2[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        o1[e] = x1[e] * cc[e] + (-x2[e]) * ss[e];
-        o2[e] = x2[e] * cc[e] + x1[e] * ss[e];
+    for (int e = 0; e < 8; ++e) {      // float32 mul, mul, add as HF's eager ops do (hf:124-135): no fused multiply-add
+        o1[e] = __fadd_rn(__fmul_rn(x1[e], cc[e]), __fmul_rn(-x2[e], ss[e]));
+        o2[e] = __fadd_rn(__fmul_rn(x2[e], cc[e]), __fmul_rn(x1[e], ss[e]));
     }
     *reinterpret_cast<uint4*>(p) = uint4{pack2(o1[0], o1[1]), pack2(o1[2], o1[3]), pack2(o1[4], o1[5]), pack2(o1[6], o1[7])};
-    *reinterpret_cast<uint4*>(p + half) = uint4{pack2(o2[0], o2[1]), pack2(o2[2], o2[3]), pack2(o2[4], o2[5]), pack2(o2[6], o2[7])};
+    *reinterpret_cast<uint4*>(p2) = uint4{pack2(o2[0], o2[1]), pack2(o2[2], o2[3]), pack2(o2[4], o2[5]), pack2(o2[6], o2[7])};
 }
 
 // V^T for the attention kernel: vt[h][d][row] = qkv[row][2C + h*hd + d]; 64 rows x one head per block via LDS, 16-byte
@@ -360,13 +362,19 @@ __global__ __launch_bounds__(256) void k_synth_fill(bf16_t* out, long long n, ui
 }
 
 // weight loader: HF tensor [rows, cols] (bf16 or f32) -> engine layout.  mode 0: dst row = r + row_off;
-// mode 1 / 2: gate / up rows interleaved in blocks of 16 (dst row = (r/16)*32 + r%16 (+16 for up))
+// mode 1 / 2: gate / up rows interleaved in blocks of 16 (dst row = (r/16)*32 + r%16 (+16 for up));
+// mode 3: ViT qkv [3C, .]: the q and k channels of every head go to their paired order (vit_qk_perm, kernels.h; row_off = head dim)
 __global__ __launch_bounds__(256) void k_load2d(const void* src, int dtype, long long rows, long long cols, bf16_t* dst,
                                                 long long dst_ld, int mode, long long row_off, int tiled) {
     const long long n = rows * cols;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const long long r = i / cols, c = i % cols;
-        const long long dr = mode == 0 ? r + row_off : (r / 16) * 32 + (r % 16) + (mode == 2 ? 16 : 0);
+        long long dr;
+        if (mode == 0) dr = r + row_off;
+        else if (mode == 3) {
+            const long long C = rows / 3, hd = row_off;
+            dr = r >= 2 * C ? r : r - (r % hd) + vit_qk_perm((int)(r % hd), (int)hd);      // (C % hd == 0: sections and heads start on multiples of hd)
+        } else dr = (r / 16) * 32 + (r % 16) + (mode == 2 ? 16 : 0);
         const bf16_t v = dtype == 0 ? reinterpret_cast<const bf16_t*>(src)[i] : f2bf(reinterpret_cast<const float*>(src)[i]);
         dst[tiled ? (long long)tiled_offset(dr, c, dst_ld) : dr * dst_ld + c] = v;
     }
@@ -516,12 +524,12 @@ int launch_resid_rmsnorm(hipStream_t s, bf16_t* x, const float* part, int ksplit
     return 0;
 }
 int launch_vit_rope(hipStream_t s, bf16_t* qkv, int n_rows, int n_heads, int head_dim, const float* cos_t,
-                    const float* sin_t, bf16_t* vt, int vt_stride) {
+                    const float* sin_t, bf16_t* vt, int vt_stride, int paired) {
     if (n_rows <= 0) return 0;
     if (head_dim > 128) return -22;
     if (head_dim % 16 != 0 || vt_stride % 8 != 0) return -22;
     const long long tasks = (long long)n_rows * 2 * n_heads * (head_dim / 16);
-    hipLaunchKernelGGL(k_vit_rope, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, qkv, n_rows, n_heads, head_dim, cos_t, sin_t);
+    hipLaunchKernelGGL(k_vit_rope, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, qkv, n_rows, n_heads, head_dim, cos_t, sin_t, paired);
     hipLaunchKernelGGL(k_vit_vtranspose, dim3(cdiv(n_rows, 64), n_heads), dim3(256), 0, s, (const bf16_t*)qkv, n_rows, n_heads,
                        head_dim, vt, vt_stride);
     SR_CHECK_LAUNCH();

@@ -88,6 +88,7 @@ struct sr_engine {
     // ---- ViT activations
     bf16_t *v_pix, *v_x, *v_xn, *v_qkv, *v_attn, *v_act, *v_vt, *v_m1;
     int v_vt_stride;
+    bool v_paired = false;       // ViT q / k channels stored in the paired order (head_dim / 2 % 8 == 0): see vit_qk_perm
     float *v_cos, *v_sin;
     int *v_rowmap_embed, *v_rowmap_merge;
     AttnWork *v_work_win, *v_work_full;
@@ -192,6 +193,7 @@ void carve(sr_engine* e) {
     const sr_config& c = e->c;
     Arena& ar = e->ar;
     e->v_hd = c.v_hidden / c.v_heads;
+    e->v_paired = (e->v_hd / 2) % 8 == 0 && e->v_hd % 16 == 0;
     e->v_pd = c.v_in_ch * c.v_temporal * c.v_patch * c.v_patch;
     e->v_pd_pad = rup(e->v_pd, 64);
     e->v_inter_pad = rup(c.v_inter, 64);
@@ -487,11 +489,23 @@ int gemm(sr_engine* e, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W,
 // (k_quant_mx_act) and multiplied with the fp8 weight image by the block-scaled K = 128 MFMA -- ALWAYS, whatever the row count, so
 // that a sequence's result does not depend on what else is in the batch.
 int lm_gemm(sr_engine* e, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const unsigned char* W8, const float* w_scale, int M,
-            int N, int K, void* out, int ldo, const bf16_t* bias, const bf16_t* resid, int epi) {
-    if (e->c.lm_weight_dtype != 2) return gemm(e, s, A, lda, W, M, N, K, out, ldo, bias, resid, nullptr, epi, 1, w_scale);
+            int N, int K, void* out, int ldo, const bf16_t* bias, const bf16_t* resid, int epi, const QkvRope* rope = nullptr, bool* fused = nullptr) {
+    if (e->c.lm_weight_dtype != 2) {
+        GemmArgs a{A, lda, W, M, N, K, out, ldo, bias, resid, nullptr, 1, w_scale, 0};
+        if (rope) {
+            a.rope = *rope;
+            if (gemm_fuses_lmqkv(a)) { epi = EPI_LMQKV; *fused = true; }
+        }
+        SR_TRY(launch_gemm(s, a, epi));
+        return 0;
+    }
     SR_TRY(launch_quant_mx_act(s, A, lda, M, K, e->t_q8, e->t_qs, e->t_rows_pad));
     GemmArgs a{reinterpret_cast<const bf16_t*>(e->t_q8), K, reinterpret_cast<const bf16_t*>(W8), M, N, K, out, ldo, bias, resid, nullptr, 1, w_scale, 256,
                e->t_qs, e->t_rows_pad};
+    if (rope) {
+        a.rope = *rope;
+        if (gemm_fuses_lmqkv(a)) { epi = EPI_LMQKV; *fused = true; }
+    }
     SR_TRY(launch_gemm256_mx(s, a, epi));
     return 0;
 }
@@ -723,8 +737,9 @@ int sr_load_weight(sr_engine* e, const char* hf_name, const void* p, int dtype, 
         const std::string t = sub;
         if (t == "norm1.weight") { dst = b.norm1; exp_rows = C; exp_cols = 1; }
         else if (t == "norm2.weight") { dst = b.norm2; exp_rows = C; exp_cols = 1; }
-        else if (t == "attn.qkv.weight") { dst = b.qkv_w; exp_rows = 3 * C; exp_cols = C; }
-        else if (t == "attn.qkv.bias") { dst = b.qkv_b; exp_rows = 3 * C; exp_cols = 1; }
+        // q / k channels of every head in paired order (vit_qk_perm): rotary partners 8 apart inside one 16-column tile
+        else if (t == "attn.qkv.weight") { dst = b.qkv_w; exp_rows = 3 * C; exp_cols = C; if (e->v_paired) { mode = 3; row_off = e->v_hd; } }
+        else if (t == "attn.qkv.bias") { dst = b.qkv_b; exp_rows = 3 * C; exp_cols = 1; if (e->v_paired) { mode = 3; row_off = e->v_hd; } }
         else if (t == "attn.proj.weight") { dst = b.proj_w; exp_rows = C; exp_cols = C; }
         else if (t == "attn.proj.bias") { dst = b.proj_b; exp_rows = C; exp_cols = 1; }
         else if (t == "mlp.gate_proj.weight") { dst = b.gu_w; exp_rows = c.v_inter; exp_cols = C; mode = 1; }
@@ -801,8 +816,15 @@ int sr_vit_forward(sr_engine* e, const void* pixels, int pixels_dtype, const int
     for (int blk = 0; blk < c.v_depth; ++blk) {
         const VitBlockW& w = e->vb[blk];
         SR_TRY(launch_rmsnorm(s, e->v_x, w.norm1, e->v_xn, N, C, 1e-6f));
-        if (int rc = gemm(e, s, e->v_xn, C, w.qkv_w, N, 3 * C, C, e->v_qkv, 3 * C, w.qkv_b, nullptr, nullptr, EPI_STORE)) return rc;
-        SR_TRY(launch_vit_rope(s, e->v_qkv, N, c.v_heads, hd, e->v_cos, e->v_sin, e->v_vt, e->v_vt_stride));
+        // qkv Linear; the 2-D rotary embedding and the V transpose ride in the GEMM epilogue when the 256-tile kernel takes the shape
+        // (large batches; needs the paired q / k channel order the loader established), else they are the two launches of round 1
+        {
+            GemmArgs ga{e->v_xn, C, w.qkv_w, N, 3 * C, C, e->v_qkv, 3 * C, w.qkv_b, nullptr, nullptr, 0, nullptr, 0};
+            ga.vrope = VitRope{e->v_cos, e->v_sin, e->v_vt, e->v_vt_stride, C, hd};
+            const bool fused = e->v_paired && gemm_fuses_vitqkv(ga);
+            SR_TRY(launch_gemm(s, ga, fused ? EPI_VITQKV : EPI_STORE));
+            if (!fused) SR_TRY(launch_vit_rope(s, e->v_qkv, N, c.v_heads, hd, e->v_cos, e->v_sin, e->v_vt, e->v_vt_stride, e->v_paired ? 1 : 0));
+        }
         const bool full = is_fullatt(c, blk);
         AttnArgs a{e->v_qkv, 3 * C, e->v_qkv + C, 3 * C, hd, e->v_vt, e->v_vt_stride, (long long)hd * e->v_vt_stride,
                    e->v_attn, C, full ? e->v_work_full : e->v_work_win, full ? e->v_nwork_full : e->v_nwork_win,
@@ -967,10 +989,17 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
         bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
         bf16_t* vc = e->vtcache + (size_t)l * e->kv_layer_elems;
         SR_TRY(launch_rmsnorm(s, e->t_x, w.ln1, e->t_xn, n_tok, H, c.t_rms_eps));
-        if (int rc = lm_gemm(e, s, e->t_xn, H, w.qkv_w, w.qkv_w8, w.qkv_s, n_tok, e->t_qn, H, e->t_qkv, e->t_qn, w.qkv_b, nullptr, EPI_STORE)) return rc;
-        LmRopeArgs ra{e->t_qkv, n_tok, c.t_heads, c.t_kv_heads, e->t_pos3, e->t_slot, e->t_idx, e->rope_cos, e->rope_sin,
-                      c.mrope_section[0], c.mrope_section[0] + c.mrope_section[1], kc, vc, c.max_ctx};
-        SR_TRY(launch_lm_rope_prefill(s, ra));
+        // q/k/v Linear; mRoPE and the KV-cache write ride in the GEMM epilogue when the 256-tile kernel takes the shape (large batches),
+        // otherwise they are the separate launch of round 1 (bit-identical results either way)
+        const QkvRope qr{e->t_pos3, e->t_slot, e->t_idx, e->rope_cos, e->rope_sin, kc, vc, n_tok, c.t_heads, c.t_kv_heads,
+                         c.mrope_section[0], c.mrope_section[0] + c.mrope_section[1], c.max_ctx};
+        bool fused_qkv = false;
+        if (int rc = lm_gemm(e, s, e->t_xn, H, w.qkv_w, w.qkv_w8, w.qkv_s, n_tok, e->t_qn, H, e->t_qkv, e->t_qn, w.qkv_b, nullptr, EPI_STORE, &qr, &fused_qkv)) return rc;
+        if (!fused_qkv) {
+            LmRopeArgs ra{e->t_qkv, n_tok, c.t_heads, c.t_kv_heads, e->t_pos3, e->t_slot, e->t_idx, e->rope_cos, e->rope_sin,
+                          c.mrope_section[0], c.mrope_section[0] + c.mrope_section[1], kc, vc, c.max_ctx};
+            SR_TRY(launch_lm_rope_prefill(s, ra));
+        }
         AttnArgs a{e->t_qkv, e->t_qn, kc, 128, (long long)c.max_ctx * 128, vc, c.max_ctx, (long long)128 * c.max_ctx,
                    e->t_attn, QD, e->t_work, n_work, c.t_heads, e->t_group, scale, 1};
         SR_TRY(launch_attn_prefill(s, a, 128));

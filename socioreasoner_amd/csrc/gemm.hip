@@ -273,14 +273,32 @@ int launch_e(hipStream_t s, const GemmArgs& a) {
 
 }  // namespace
 
+// does the dispatch below send `a` to the 256-tile kernel?  (SR_GEMM256: 0 = never, 2 = whenever the shape is supported -- tuning hook)
+static bool picks_256(const GemmArgs& a) {
+    static const char* g256_env = getenv("SR_GEMM256");
+    const int g256 = g256_env ? atoi(g256_env) : 1;
+    if (a.force_tile == 256) return true;
+    return a.force_tile != 128 && g256 && gemm256_supports(a) && (g256 == 2 || (long)cdiv(a.M, 256) * (a.N / 256) >= 384);
+}
+bool lmqkv_ok(const GemmArgs& a);
+bool gemm_fuses_lmqkv(const GemmArgs& a) {
+    const char* env = getenv("SR_FUSE_QKV");                   // tuning / test hook (read at every call): 0 = separate rotary + cache-write launch as in round 1
+    if (env && atoi(env) == 0) return false;
+    return a.K % BK == 0 && picks_256(a) && gemm256_supports(a) && lmqkv_ok(a);
+}
+
+bool vitqkv_ok(const GemmArgs& a);
+bool gemm_fuses_vitqkv(const GemmArgs& a) {
+    const char* env = getenv("SR_FUSE_QKV");                   // the same hook as above
+    if (env && atoi(env) == 0) return false;
+    return a.K % BK == 0 && picks_256(a) && gemm256_supports(a) && vitqkv_ok(a);
+}
+
 int launch_gemm(hipStream_t s, const GemmArgs& a, int epi) {
     if (a.M <= 0) return 0;
     if (a.K % BK != 0 || a.N % 16 != 0 || (epi == EPI_SWIGLU && a.N % 32 != 0)) return -22;
-    // large M: the 256 x 256 8-phase kernel (gemm256.hip).  SR_GEMM256: 0 = never, 2 = whenever the shape is supported (tuning hook)
-    static const char* g256_env = getenv("SR_GEMM256");
-    const int g256 = g256_env ? atoi(g256_env) : 1;
-    if (a.force_tile == 256) return launch_gemm256(s, a, epi);
-    if (a.force_tile != 128 && g256 && gemm256_supports(a) && (g256 == 2 || (long)cdiv(a.M, 256) * (a.N / 256) >= 384)) return launch_gemm256(s, a, epi);
+    // large M: the 256 x 256 8-phase kernel (gemm256.hip)
+    if (picks_256(a) || epi == EPI_LMQKV || epi == EPI_VITQKV) return launch_gemm256(s, a, epi);
     switch (epi) {
         case EPI_STORE: return launch_e<EPI_STORE>(s, a);
         case EPI_RESID: return launch_e<EPI_RESID>(s, a);

@@ -278,6 +278,168 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
         const auto sy = __builtin_amdgcn_permlane16_swap(ta.y, tb.y, false, false);
         return uint4{sx[0], sy[0], sx[1], sy[1]};
     };
+    if constexpr (EPI == EPI_VITQKV) {
+        // ViT qkv Linear with k_vit_rope + k_vit_vtranspose folded in.  The q / k channels of every head are in the paired order
+        // (vit_qk_perm): inside each 16-column tile columns 0..7 are x1 of 8 rotary pairs and 8..15 their x2, i.e. the partner of a
+        // lane's 4 columns sits in lane ^ 32.  Sections (q | k | v, C columns each) start on tile boundaries: the role is block-uniform.
+        const VitRope& f = p.vrope;
+        const int sec = n0 / f.C, half = f.hd / 2;
+        if (sec < 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint2 t4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ct = n0 - sec * f.C + wn * 64 + j * 16;               // first column of the tile inside its section
+                    const int jl = (ct % f.hd) / 16 * 8 + (fg & 1) * 4;             // rotary pair of this lane's first column
+                    const float4 c4 = rok[i] ? *reinterpret_cast<const float4*>(f.cos_t + (size_t)orow[i] * half + jl) : float4{0.f, 0.f, 0.f, 0.f};
+                    const float4 s4 = rok[i] ? *reinterpret_cast<const float4*>(f.sin_t + (size_t)orow[i] * half + jl) : float4{0.f, 0.f, 0.f, 0.f};
+                    float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (p.bias) { o[0] += lo16(bia[j].x); o[1] += hi16(bia[j].x); o[2] += lo16(bia[j].y); o[3] += hi16(bia[j].y); }
+                    const uint2 own = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};   // the Linear's bf16 output
+                    const uint2 oth = uint2{(uint32_t)__shfl_xor((int)own.x, 32, 64), (uint32_t)__shfl_xor((int)own.y, 32, 64)};
+                    const float me[4] = {lo16(own.x), hi16(own.x), lo16(own.y), hi16(own.y)};
+                    const float ot[4] = {lo16(oth.x), hi16(oth.x), lo16(oth.y), hi16(oth.y)};
+                    const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)      // float32 mul, mul, add (hf:124-135); x1 holder (fg < 2): x1 c - x2 s, x2 holder: x2 c + x1 s
+                        o[r] = __fadd_rn(__fmul_rn(me[r], cc[r]), __fmul_rn(fg < 2 ? -ot[r] : ot[r], ss[r]));
+                    t4[j] = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                }
+                const int odd_ = fg & 1, half8_ = (fg >> 1) * 8;
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const uint4 v = widen(t4[2 * jp], t4[2 * jp + 1]);
+                    const int n = n0 + wn * 64 + (2 * jp + odd_) * 16 + half8_;
+                    if (rok[i]) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow[i] * p.ldo + n) = v;
+                }
+            }
+        } else {
+            // V^T[channel][row]: transposed through LDS (the staging buffers are dead), 4 row tiles per pass, so that every lane stores
+            // 8 consecutive rows of one channel with one 16-byte store
+            constexpr int EX_RS = 136;
+            unsigned char* ex = smem + wave * 64 * EX_RS;
+            __syncthreads();                                     // every wave is done with the staging buffers
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = pass * 4 + ii;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        if (p.bias) { o[0] += lo16(bia[j].x); o[1] += hi16(bia[j].x); o[2] += lo16(bia[j].y); o[3] += hi16(bia[j].y); }
+                        *reinterpret_cast<uint2*>(ex + (ii * 16 + fr) * EX_RS + (j * 16 + fg * 4) * 2) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                    }
+                }
+                __syncthreads();
+                const int ch = n0 - 2 * f.C + wn * 64 + lane;                          // V channel (= head * hd + d) of this lane
+                const int rbase = m0 + wm * 128 + pass * 64;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    uint32_t w4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t lo = *reinterpret_cast<const unsigned short*>(ex + (g * 8 + 2 * e) * EX_RS + lane * 2);
+                        const uint32_t hi = *reinterpret_cast<const unsigned short*>(ex + (g * 8 + 2 * e + 1) * EX_RS + lane * 2);
+                        w4[e] = lo | (hi << 16);
+                    }
+                    if (rbase + g * 8 < p.M) *reinterpret_cast<uint4*>(f.vt + (size_t)ch * f.vt_stride + rbase + g * 8) = uint4{w4[0], w4[1], w4[2], w4[3]};
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
+    if constexpr (EPI == EPI_LMQKV) {
+        // q/k/v Linear of the LM prefill with k_lm_rope_prefill folded in (same bf16 rounding points, bit-identical results):
+        //   q heads : bias, round, mRoPE (hf:557-599: three bf16 ops) -> out;   k heads: the same -> K cache row (slot, idx)
+        //   v heads : bias, round -> V^T cache column (slot, idx)
+        // The 256-column tile holds whole heads (128 columns = the two wave columns 2h, 2h + 1): the rotary partner of column d
+        // (d +- 64) lives in the neighbouring wave at the same (row, column offset) and is traded through LDS (the staging buffers are
+        // dead by now), 4 row tiles per pass.  q / k / v sections start on tile boundaries (launcher check), so the role is block-uniform.
+        const QkvRope& f = p.rope;
+        const int q_cols = f.n_q_heads * 128, qk_cols = q_cols + f.n_kv_heads * 128;
+        const bool is_v = n0 >= qk_cols, is_k = !is_v && n0 >= q_cols;
+        const int hi = wn & 1;                                   // 0: this wave holds x1 (d < 64), 1: x2 (d >= 64)
+        const int kvh = ((is_v ? n0 - qk_cols : n0 - q_cols) >> 7) + (wn >> 1);
+        constexpr int EX_RS = 136;                               // exchange row stride in bytes (64 columns + 8 B pad)
+        unsigned char* ex = smem;
+        __syncthreads();                                         // every wave is done with the staging buffers
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {      // (fully unrolled: a runtime `pass` would index the accumulators dynamically -> scratch)
+            uint2 own[4][4];
+            int pos3v[4][3], slot[4], cidx[4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = pass * 4 + ii;
+                const int m = m0 + wm * 128 + i * 16 + fr;
+                const int mc = rok[i] ? m : 0;
+                if (!is_v) {
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) pos3v[ii][ax] = f.pos3[(size_t)ax * f.n_tok + mc];
+                }
+                if (is_v || is_k) { slot[ii] = f.tok_slot[mc]; cidx[ii] = f.tok_idx[mc]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (p.w_scale) { o[0] *= scl[j].x; o[1] *= scl[j].y; o[2] *= scl[j].z; o[3] *= scl[j].w; }
+                    if (p.bias) { o[0] += lo16(bia[j].x); o[1] += hi16(bia[j].x); o[2] += lo16(bia[j].y); o[3] += hi16(bia[j].y); }
+                    own[ii][j] = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                    if (!is_v) *reinterpret_cast<uint2*>(ex + (wave * 64 + ii * 16 + fr) * EX_RS + (j * 16 + fg * 4) * 2) = own[ii][j];
+                }
+            }
+            if (is_v) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    if (!rok[pass * 4 + ii]) continue;
+                    bf16_t* vt = f.vtcache + ((size_t)(slot[ii] * f.n_kv_heads + kvh) * 128 + hi * 64 + fg * 4) * f.ctx_max + cidx[ii];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf16_t* v4 = vt + (size_t)(j * 16) * f.ctx_max;
+                        v4[0] = (bf16_t)(own[ii][j].x & 0xffffu);
+                        v4[f.ctx_max] = (bf16_t)(own[ii][j].x >> 16);
+                        v4[2 * (size_t)f.ctx_max] = (bf16_t)(own[ii][j].y & 0xffffu);
+                        v4[3 * (size_t)f.ctx_max] = (bf16_t)(own[ii][j].y >> 16);
+                    }
+                }
+                continue;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = pass * 4 + ii;
+                uint2 t4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d0 = j * 16 + fg * 4;              // rotary pair index of this lane's first column (4 consecutive share an axis)
+                    const int ax = d0 < f.sec0 ? 0 : (d0 < f.sec1 ? 1 : 2);
+                    const size_t tb = (size_t)pos3v[ii][ax] * 64 + d0;
+                    const uint2 c4 = *reinterpret_cast<const uint2*>(f.rope_cos + tb), s4 = *reinterpret_cast<const uint2*>(f.rope_sin + tb);
+                    const uint2 oth = *reinterpret_cast<const uint2*>(ex + ((wave ^ 1) * 64 + ii * 16 + fr) * EX_RS + (j * 16 + fg * 4) * 2);
+                    const float me[4] = {lo16(own[ii][j].x), hi16(own[ii][j].x), lo16(own[ii][j].y), hi16(own[ii][j].y)};
+                    const float ot[4] = {lo16(oth.x), hi16(oth.x), lo16(oth.y), hi16(oth.y)};
+                    const float cc[4] = {lo16(c4.x), hi16(c4.x), lo16(c4.y), hi16(c4.y)}, ss[4] = {lo16(s4.x), hi16(s4.x), lo16(s4.y), hi16(s4.y)};
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)      // x1 holder: bf16(bf16(x1 c) + bf16(-x2 s));  x2 holder: bf16(bf16(x2 c) + bf16(x1 s))
+                        o[r] = rbf(rbf(me[r] * cc[r]) + rbf((hi ? ot[r] : -ot[r]) * ss[r]));
+                    t4[j] = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                }
+                const int odd_ = fg & 1, half8_ = (fg >> 1) * 8;
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const uint4 v = widen(t4[2 * jp], t4[2 * jp + 1]);
+                    const int cw = (2 * jp + odd_) * 16 + half8_;            // column inside the wave's 64
+                    if (!rok[i]) continue;
+                    if (is_k) *reinterpret_cast<uint4*>(f.kcache + ((size_t)(slot[ii] * f.n_kv_heads + kvh) * f.ctx_max + cidx[ii]) * 128 + hi * 64 + cw) = v;
+                    else *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow[i] * p.ldo + n0 + wn * 64 + cw) = v;
+                }
+            }
+            __syncthreads();                                     // the next pass overwrites the exchange buffer
+        }
+        return;
+    }
     const int odd = fg & 1, half8 = (fg >> 1) * 8;            // which tile of a pair this lane stores, and its 8-column half
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -370,6 +532,21 @@ int launch256_t(hipStream_t s, const GemmArgs& a) {
 
 }  // namespace
 
+// fused q/k/v epilogue: the q, k and v sections must start on 256-column tile boundaries (whole heads per tile, block-uniform role)
+bool lmqkv_ok(const GemmArgs& a) {
+    const QkvRope& f = a.rope;
+    return f.pos3 && f.tok_slot && f.tok_idx && f.rope_cos && f.rope_sin && f.kcache && f.vtcache && (f.n_q_heads * 128) % BN2 == 0 &&
+           (f.n_kv_heads * 128) % BN2 == 0 && a.N == (f.n_q_heads + 2 * f.n_kv_heads) * 128 && f.sec0 % 4 == 0 && f.sec1 % 4 == 0 && !a.rowmap;
+}
+
+// fused ViT qkv epilogue: sections on tile boundaries, heads made of whole 16-column tiles, paired q / k channel order (the caller's
+// promise), V^T rows padded to the 8-row store granularity
+bool vitqkv_ok(const GemmArgs& a) {
+    const VitRope& f = a.vrope;
+    return f.cos_t && f.sin_t && f.vt && f.C > 0 && f.hd > 0 && f.C % BN2 == 0 && a.N == 3 * f.C && f.hd % 16 == 0 && f.C % f.hd == 0 &&
+           f.vt_stride % 8 == 0 && f.vt_stride >= (a.M + 7) / 8 * 8 && !a.rowmap && !a.w_scale && a.M % 4 == 0;
+}
+
 // shapes the 256-tile kernel takes: whole 256-column tiles, at least two 64-wide k-tiles (M is arbitrary: edge rows are clamped
 // on load and masked on store)
 bool gemm256_supports(const GemmArgs& a) { return a.N % BN2 == 0 && a.K % BK2 == 0 && a.K / BK2 >= 2 && a.M >= 1; }
@@ -382,6 +559,7 @@ int launch_gemm256_mx(hipStream_t s, const GemmArgs& a, int epi) {
         case EPI_RESID: return launch256_t<EPI_RESID, true>(s, a);
         case EPI_SWIGLU: return launch256_t<EPI_SWIGLU, true>(s, a);
         case EPI_F32: return launch256_t<EPI_F32, true>(s, a);
+        case EPI_LMQKV: return lmqkv_ok(a) ? launch256_t<EPI_LMQKV, true>(s, a) : -22;
     }
     return -22;
 }
@@ -394,6 +572,8 @@ int launch_gemm256(hipStream_t s, const GemmArgs& a, int epi) {
         case EPI_SWIGLU: return launch256_t<EPI_SWIGLU>(s, a);
         case EPI_GELU: return launch256_t<EPI_GELU>(s, a);
         case EPI_F32: return launch256_t<EPI_F32>(s, a);
+        case EPI_LMQKV: return lmqkv_ok(a) ? launch256_t<EPI_LMQKV>(s, a) : -22;
+        case EPI_VITQKV: return vitqkv_ok(a) ? launch256_t<EPI_VITQKV>(s, a) : -22;
     }
     return -22;
 }

@@ -5,7 +5,32 @@
 
 // ------------------------------------------------------------------ gemm.hip (MFMA, M large)
 // out[M,N] = A[M,K] . W[N,K]^T, bf16 operands, float32 accumulate.  K % 64 == 0, N % 16 == 0.
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32 = 4 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32 = 4,
+       EPI_LMQKV = 5,     // LM q/k/v Linear + mRoPE + KV-cache write in the epilogue (gemm256.hip only; GemmArgs.rope)
+       EPI_VITQKV = 6 };  // ViT qkv Linear + 2-D rotary + V^T write in the epilogue (gemm256.hip only; GemmArgs.vrope)
+// fused ViT qkv epilogue (replaces k_vit_rope + k_vit_vtranspose).  Needs the q / k output channels of every head in the engine's
+// PAIRED order (vit_qk_perm below): rotary partners 8 columns apart inside one 16-column MFMA tile.
+struct VitRope {
+    const float* cos_t; const float* sin_t;   // [row][head_dim / 2] float32 (hf:124-135 angles)
+    bf16_t* vt; int vt_stride;                // V^T [C][vt_stride]
+    int C, hd;                                // hidden size (= heads * hd), head dim
+};
+// paired channel order of a ViT q / k head (head_dim hd, hd / 2 % 8 == 0): HF channel d = part * hd/2 + j  (part 0: x1, 1: x2 of rotary
+// pair j) sits at (j / 8) * 16 + part * 8 + j % 8.  Dot products q.k are unchanged (same order on both sides).
+__host__ __device__ inline int vit_qk_perm(int d, int hd) {
+    const int half = hd / 2, part = d / half, j = d % half;
+    return (j / 8) * 16 + part * 8 + (j % 8);
+}
+// what the fused LM q/k/v epilogue needs beyond the GEMM operands (the arguments of k_lm_rope_prefill, which it replaces)
+struct QkvRope {
+    const int* pos3;            // [3][n_tok] mRoPE position ids
+    const int* tok_slot;        // [n_tok] cache slot
+    const int* tok_idx;         // [n_tok] index of the token inside its sequence (cache row)
+    const bf16_t* rope_cos;     // [max_pos+1][64] bf16 tables
+    const bf16_t* rope_sin;
+    bf16_t* kcache; bf16_t* vtcache;
+    int n_tok, n_q_heads, n_kv_heads, sec0, sec1, ctx_max;
+};
 struct GemmArgs {
     const bf16_t* A; int lda;
     const bf16_t* W;            // [N,K] row-major (nn.Linear layout); SWIGLU: rows interleaved 16 gate / 16 up
@@ -19,7 +44,12 @@ struct GemmArgs {
     int force_tile;             // 0: launch_gemm picks the kernel; 256 / 128: force gemm256.hip / gemm.hip (tests, tuning)
     const unsigned char* a_scale;   // MX fp8 path (launch_gemm256_mx): e8m0 block scales of A, [K/128][a_rows_pad][4]
     int a_rows_pad;
+    QkvRope rope;               // EPI_LMQKV only
+    VitRope vrope;              // EPI_VITQKV only
 };
+bool gemm_fuses_vitqkv(const GemmArgs& a);
+// true when launch_gemm would run `a` with the fused q/k/v epilogue (same predicate as its dispatch to gemm256.hip)
+bool gemm_fuses_lmqkv(const GemmArgs& a);
 int launch_gemm(hipStream_t s, const GemmArgs& a, int epi);
 // gemm256.hip: 256 x 256 x 64 tile, 8-phase ping-pong schedule (large M); launch_gemm dispatches to it
 bool gemm256_supports(const GemmArgs& a);
@@ -97,7 +127,7 @@ int launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* out,
 int launch_resid_rmsnorm(hipStream_t s, bf16_t* x, const float* part, int ksplit, const bf16_t* w, bf16_t* out,
                          int rows, int H, float eps, int out_tiled = 0);
 int launch_vit_rope(hipStream_t s, bf16_t* qkv, int n_rows, int n_heads, int head_dim, const float* cos_t,
-                    const float* sin_t, bf16_t* vt, int vt_stride);
+                    const float* sin_t, bf16_t* vt, int vt_stride, int paired = 0);
 // prefill: rope q,k in place in qkv [T, (Hq+2Hkv)*128]; write K / V^T into the cache at (slot, pos_in_seq)
 struct LmRopeArgs {
     bf16_t* qkv; int n_tok; int n_q_heads, n_kv_heads;

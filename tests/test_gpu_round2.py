@@ -222,6 +222,41 @@ def test_overlapped_admission_equals_static_batches():
     e.close()
 
 
+@pytest.mark.parametrize("mode,B", [(False, 24), ("mx", 3)])
+def test_fused_qkv_epilogue_equals_separate_rope_launch(mode, B, monkeypatch):
+    """LM prefill q/k/v Linear with mRoPE + KV-cache write in the GEMM epilogue (gemm256.hip EPI_LMQKV) against the separate
+    k_lm_rope_prefill launch of round 1 (SR_FUSE_QKV=0): same bf16 rounding points, so the first-token logits, the logits of the
+    next decode steps (they read the K / V^T cache the epilogue wrote) and the tokens are bit-identical; likewise the ViT qkv Linear
+    with the 2-D rotary embedding + V transpose in its epilogue (EPI_VITQKV) against k_vit_rope + k_vit_vtranspose: same image embeddings.  bf16 at 24 tiles (the
+    256-tile kernel is dispatched from 384 tiles up) and the MX fp8 variant (always on the 256-tile kernel)."""
+    from socioreasoner_amd import hostops, synthetic
+    from socioreasoner_amd.config import geometry_3b
+    from socioreasoner_amd.engine import Engine
+    geom = geometry_3b()
+    e = Engine(geom, max_patches=1024 * B, max_prefill_tokens=448 * B, max_batch=B, max_ctx=512, max_new_tokens=4, lm_fp8=mode)
+    e.load_synthetic_weights(seed=0)
+    grid = (1, 32, 32)
+    imgs = [torch.from_numpy(synthetic.tile_pixels(i)).cuda() for i in range(B)]
+    ids, pos = [], []
+    for i in range(B):
+        x = synthetic.tile_prompt(geom, i, grid)[: 448 - 3 * (i % 5)]          # ragged lengths: sequences start at arbitrary rows of the tiles
+        p, _ = hostops.get_rope_index(torch.from_numpy(x)[None], [grid], None)
+        ids.append(x)
+        pos.append(p[:, 0].numpy())
+    pix = torch.cat([e.patchify(im) for im in imgs], dim=0)
+    res = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("SR_FUSE_QKV", fuse)
+        emb = e.vit_forward(pix, [grid] * B).clone()      # 24 tiles: the ViT qkv GEMM takes the fused 2-D rotary + V^T epilogue as well
+        first = e.prefill(ids, pos, emb, return_logits=True).clone()
+        toks, tr = e.decode(4, trace=True)
+        res[fuse] = (first, toks.clone(), tr.clone(), emb)
+    assert torch.equal(res["0"][3], res["1"][3])
+    assert torch.equal(res["0"][0], res["1"][0])
+    assert torch.equal(res["0"][2], res["1"][2]) and torch.equal(res["0"][1], res["1"][1])
+    e.close()
+
+
 # ------------------------------------------------------------------------------------------------ RCCL on one rank
 def test_rccl_exchange_path_single_rank(tmp_path):
     """The test box has one GPU, so the N > 1 RCCL run belongs to the driver's scaling tier; what CAN run here is the same
