@@ -13,6 +13,16 @@
 // write late) plus a single-tile path that reuses pass 1's scores: bit-identical, but the kernel grows from 44-56 to 116-160 VGPRs
 // and loses to the plain version that lets 4+ blocks per CU cover each other's staging -- LM causal 215 vs 155 us, ViT full 1133 vs
 // 906 us, ViT windows 112 vs 110 us (those read q, k, v exactly once: they sit on the HBM floor of the qkv buffer).
+// Where the time goes (PMC, profiles/r02_pmc_attn_prefill.json, LM causal at 32 x 448 tokens, 159 us): waves wait 62 % of their cycles
+// (SQ_WAIT_ANY), MFMA pipe 13 % busy, ~2950 VALU instructions per wave.  A 64-key tile of K and V^T is re-staged by every (64-query
+// tile, head) block -- 688 MB per layer for 15 MB of unique K / V, 4.1 TB/s out of L2 -- and the staging is synchronous, so the kernel
+// runs at (tiles in flight per CU) / (load latency): everything that lowers the block count per CU loses what it saves.  Measured
+// against this version, same box, ms per 32-tile LM prefill (all bit-identical or within rounding noise, all dropped): pass-1 scores
+// kept in registers for prompts <= 512 keys (no second Q.K^T, 112 VGPRs) 75.2 vs 73.5; 128-query blocks of 8 waves (half the staging)
+// 75.8 vs 74.3; 32 queries per wave (each K / V^T fragment feeds two MFMAs, causal tiles skipped per wave, 168 + 72 registers) 79.1 vs
+// 77.1; masks only on edge tiles + exp2/fma softmax + hoisted staging indices (fewer VALU instructions, 104 VGPRs) 72.6 vs 71.9;
+// MFMA accumulators forced into VGPRs (-amdgpu-mfma-vgpr-form, no v_accvgpr moves) no change.  What would help is staging traffic cut
+// at unchanged occupancy (one block for the 8 query heads of a kv head, <= 64 registers per wave) or asynchronous multi-stage staging.
 #include "kernels.h"
 #include <math.h>
 

@@ -1,28 +1,28 @@
-"""GPU probe: phase timestamps of the fused decode-attention kernel at the bench shape (B=1, ctx 576)."""
-import ctypes as C, sys, os, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from socioreasoner_amd import lib
-L = lib.load()
-B, HQ, HK, CTX = int(os.environ.get("PB", 1)), 16, 2, 640
-P = lambda t: C.c_void_p(t.data_ptr())
-qkv = torch.randn(B, (HQ + 2 * HK) * 128, device="cuda").to(torch.bfloat16)
-pos = torch.full((B,), 600, dtype=torch.int32, device="cuda")
-ctx = torch.full((B,), 576, dtype=torch.int32, device="cuda")
-inv = (1.0 / (1e6 ** (torch.arange(0, 128, 2).float() / 128)))
-ang = torch.arange(CTX + 1).float()[:, None] * inv[None]
-rc, rs = ang.cos().to(torch.bfloat16).cuda(), ang.sin().to(torch.bfloat16).cuda()
-kc = torch.randn(B, HK, CTX, 128, device="cuda").to(torch.bfloat16)
-vc = torch.randn(B, HK, 128, CTX, device="cuda").to(torch.bfloat16)
-out = torch.zeros(B, HQ * 128, dtype=torch.bfloat16, device="cuda")
-dbg = torch.zeros(B * HQ * CTX, dtype=torch.bfloat16, device="cuda")
-s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-for it in range(5):
-    assert L.sr_op_attn_decode(P(qkv), qkv.shape[1], P(pos), P(ctx), P(rc), P(rs), P(kc), P(vc), P(out), HQ * 128, B, HQ, HK, CTX,
-                               C.c_float(128 ** -0.5), P(dbg), s) == 0
-    torch.cuda.synchronize()
-a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-a.record()
-for _ in range(200):
-    L.sr_op_attn_decode(P(qkv), qkv.shape[1], P(pos), P(ctx), P(rc), P(rs), P(kc), P(vc), P(out), HQ * 128, B, HQ, HK, CTX, C.c_float(128 ** -0.5), P(dbg), s)
-b.record(); torch.cuda.synchronize()
-print("avg per launch (back-to-back, us):", a.elapsed_time(b) * 1000 / 200)
+#!/usr/bin/env python3
+"""PMC probe: two admissions (ViT + prefill) of 32 synthetic tiles on the 3B geometry, nothing else (tools/gpu_pmc_attn.sh)."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from socioreasoner_amd import hostops, synthetic  # noqa: E402
+from socioreasoner_amd.config import geometry_3b  # noqa: E402
+from socioreasoner_amd.engine import Engine  # noqa: E402
+
+B = 32
+geom = geometry_3b()
+e = Engine(geom, max_patches=1024 * B, max_prefill_tokens=448 * B, max_batch=B, max_ctx=512, max_new_tokens=4)
+e.load_synthetic_weights(seed=0)
+grid = (1, 32, 32)
+imgs = [torch.from_numpy(synthetic.tile_pixels(i)).cuda() for i in range(B)]
+ids, pos = [], []
+for i in range(B):
+    x = synthetic.tile_prompt(geom, i, grid)
+    p, _ = hostops.get_rope_index(torch.from_numpy(x)[None], [grid], None)
+    ids.append(x)
+    pos.append(p[:, 0].numpy())
+pix = torch.cat([e.patchify(im) for im in imgs], dim=0)
+for _ in range(2):
+    emb = e.vit_forward(pix, [grid] * B)
+    e.prefill(ids, pos, emb)
+torch.cuda.synchronize()
+e.close()
