@@ -104,11 +104,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p, int ntm, int ntn) 
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
-    stage(0, 0);
+    // k-tiles of this block: all of them, or slice blockIdx.y of a split-K launch (EPI_F32 partial products)
+    const int nk_all = p.K / BK, per = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kt0 = min((int)blockIdx.y * per, nk_all), nk = min(kt0 + per, nk_all);
+    if (kt0 < nk) stage(0, kt0);
     __syncthreads();               // the compiler drains the LDS-DMA (vmcnt(0)) in front of the barrier
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
         if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const unsigned char* ab = reinterpret_cast<const unsigned char*>(sm.a[cur]);
         const unsigned char* wb = reinterpret_cast<const unsigned char*>(sm.w[cur]);
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p, int ntm, int ntn) 
                     const float4 sc = *reinterpret_cast<const float4*>(p.w_scale + n);
                     o[0] *= sc.x; o[1] *= sc.y; o[2] *= sc.z; o[3] *= sc.w;
                 }
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow * p.ldo + n) = float4{o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + ((size_t)blockIdx.y * p.M + orow) * p.ldo + n) = float4{o[0], o[1], o[2], o[3]};
             }
         } else {
             uint2 rv[NJ], t4[NJ];
@@ -250,7 +252,7 @@ int launch_t(hipStream_t s, const GemmArgs& a) {
                             (int)smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_gemm<BM, EPI, NW>), dim3(ntm * ntn), dim3(NW * 64), smem, s, a, ntm, ntn);
+    hipLaunchKernelGGL((k_gemm<BM, EPI, NW>), dim3(ntm * ntn, EPI == EPI_F32 && a.ksplit > 1 ? a.ksplit : 1), dim3(NW * 64), smem, s, a, ntm, ntn);
     SR_CHECK_LAUNCH();
     return 0;
 }
@@ -297,6 +299,10 @@ bool gemm_fuses_vitqkv(const GemmArgs& a) {
 int launch_gemm(hipStream_t s, const GemmArgs& a, int epi) {
     if (a.M <= 0) return 0;
     if (a.K % BK != 0 || a.N % 16 != 0 || (epi == EPI_SWIGLU && a.N % 32 != 0)) return -22;
+    if (a.ksplit > 1) {      // split-K partial products (small M): this file's kernel, float32 slabs, no row map
+        if (epi != EPI_F32 || a.rowmap || a.ksplit > a.K / BK) return -22;
+        return launch_e<EPI_F32>(s, a);
+    }
     // large M: the 256 x 256 8-phase kernel (gemm256.hip)
     if (picks_256(a) || epi == EPI_LMQKV || epi == EPI_VITQKV) return launch_gemm256(s, a, epi);
     switch (epi) {

@@ -46,6 +46,8 @@ struct GemmArgs {
     int a_rows_pad;
     QkvRope rope;               // EPI_LMQKV only
     VitRope vrope;              // EPI_VITQKV only
+    int ksplit;                 // > 1 (EPI_F32, gemm.hip kernel only): K is split over gridDim.y blocks, block y writes its float32 partial
+                                // products to out + y * M * ldo (slabs the consumer sums: launch_resid_rmsnorm)
 };
 bool gemm_fuses_vitqkv(const GemmArgs& a);
 // true when launch_gemm would run `a` with the fused q/k/v epilogue (same predicate as its dispatch to gemm256.hip)
