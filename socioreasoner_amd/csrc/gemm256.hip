@@ -379,30 +379,49 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
 #pragma unroll
                     for (int ax = 0; ax < 3; ++ax) pos3v[ii][ax] = f.pos3[(size_t)ax * f.n_tok + mc];
                 }
-                if (is_v || is_k) { slot[ii] = f.tok_slot[mc]; cidx[ii] = f.tok_idx[mc]; }
+                if (is_k) { slot[ii] = f.tok_slot[mc]; cidx[ii] = f.tok_idx[mc]; }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                     if (p.w_scale) { o[0] *= scl[j].x; o[1] *= scl[j].y; o[2] *= scl[j].z; o[3] *= scl[j].w; }
                     if (p.bias) { o[0] += lo16(bia[j].x); o[1] += hi16(bia[j].x); o[2] += lo16(bia[j].y); o[3] += hi16(bia[j].y); }
                     own[ii][j] = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
-                    if (!is_v) *reinterpret_cast<uint2*>(ex + (wave * 64 + ii * 16 + fr) * EX_RS + (j * 16 + fg * 4) * 2) = own[ii][j];
+                    *reinterpret_cast<uint2*>(ex + (wave * 64 + ii * 16 + fr) * EX_RS + (j * 16 + fg * 4) * 2) = own[ii][j];
                 }
             }
             if (is_v) {
+                // V^T[channel][token]: transposed through the exchange buffer so that a lane owns one channel and 8 consecutive rows.  When
+                // those rows are 8 consecutive, 8-aligned cache positions of one sequence (always, for prompts that start on a multiple of 8
+                // packed rows) they leave as one 16-byte store, otherwise token by token.
+                __syncthreads();
+                const unsigned char* exw = ex + wave * 64 * EX_RS + lane * 2;
+                const int rbase = m0 + wm * 128 + pass * 64;
+#pragma unroll 2
+                for (int g = 0; g < 8; ++g) {
+                    const int r0 = rbase + g * 8;
+                    if (r0 >= p.M) break;
+                    uint32_t w4[4];
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    if (!rok[pass * 4 + ii]) continue;
-                    bf16_t* vt = f.vtcache + ((size_t)(slot[ii] * f.n_kv_heads + kvh) * 128 + hi * 64 + fg * 4) * f.ctx_max + cidx[ii];
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t lo = *reinterpret_cast<const unsigned short*>(exw + (g * 8 + 2 * e) * EX_RS);
+                        const uint32_t hi16v = *reinterpret_cast<const unsigned short*>(exw + (g * 8 + 2 * e + 1) * EX_RS);
+                        w4[e] = lo | (hi16v << 16);
+                    }
+                    const int r7 = min(r0 + 7, p.M - 1);
+                    const int s0 = f.tok_slot[r0], i0 = f.tok_idx[r0], s7 = f.tok_slot[r7], i7 = f.tok_idx[r7];
+                    const size_t chan = (size_t)kvh * 128 + hi * 64 + lane;
+                    if (r0 + 7 < p.M && s7 == s0 && i7 == i0 + 7 && (i0 & 7) == 0) {
+                        *reinterpret_cast<uint4*>(f.vtcache + ((size_t)s0 * f.n_kv_heads * 128 + chan) * f.ctx_max + i0) = uint4{w4[0], w4[1], w4[2], w4[3]};
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        bf16_t* v4 = vt + (size_t)(j * 16) * f.ctx_max;
-                        v4[0] = (bf16_t)(own[ii][j].x & 0xffffu);
-                        v4[f.ctx_max] = (bf16_t)(own[ii][j].x >> 16);
-                        v4[2 * (size_t)f.ctx_max] = (bf16_t)(own[ii][j].y & 0xffffu);
-                        v4[3 * (size_t)f.ctx_max] = (bf16_t)(own[ii][j].y >> 16);
+                        for (int e = 0; e < 8; ++e) {
+                            const int r = r0 + e;
+                            if (r < p.M)
+                                f.vtcache[((size_t)f.tok_slot[r] * f.n_kv_heads * 128 + chan) * f.ctx_max + f.tok_idx[r]] = (bf16_t)((w4[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                        }
                     }
                 }
+                __syncthreads();                                 // the next pass overwrites the exchange buffer
                 continue;
             }
             __syncthreads();
