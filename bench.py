@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--static", action="store_true", help="one static batch of --batch tiles per step instead of continuous batching")
     ap.add_argument("--continuous", action="store_true", help="(default for --batch > 1) serve --waves x batch requests through the scheduler")
     ap.add_argument("--waves", type=int, default=4, help="continuous mode: a step serves waves x batch tile requests through the batch rows")
-    ap.add_argument("--admit-cus", type=int, default=3, help="CUs per shader engine (of 8) given to the overlapped admission stream")
+    ap.add_argument("--admit-cus", type=float, default=3, help="CUs per shader engine (of 8) given to the overlapped admission stream")
     ap.add_argument("--no-overlap", action="store_true", help="continuous mode: admit between decode steps on one stream (round-1 behaviour) instead of "
                     "staging the next admission on a CU-masked stream under the running rows' decode")
     ap.add_argument("--no-latency", action="store_true", help="skip the additional batch-1 (configs[1]) measurement")
@@ -328,7 +328,7 @@ def main():
         if continuous:
             phases["scheduler"] = dict({k: v // args.steps for k, v in sched.items()}, overlap=overlap,
                                        decode_step_ms_shared=round(phase_ms.get("decode_shared", 0.0) / max(sched["steps_shared"], 1), 4),
-                                       note=f"spans named *_shared ran concurrently on disjoint CU sets (admission {32 * args.admit_cus} CUs, decode {256 - 32 * args.admit_cus}): they do not add up to ms_per_step" if overlap else None)
+                                       note=f"spans named *_shared ran concurrently on disjoint CU sets (admission {int(32 * args.admit_cus)} CUs, decode {256 - int(32 * args.admit_cus)}): they do not add up to ms_per_step" if overlap else None)
         vit_ms, pre_ms = phase_ms["vit"] / per, phase_ms["prefill"] / per
         phases["vit_mfma_frac"] = round(VIT_GFLOP * B / (vit_ms * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)
         phases["prefill_mfma_frac"] = round(PREFILL_GFLOP * B / (pre_ms * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)

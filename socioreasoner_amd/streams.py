@@ -26,30 +26,50 @@ def _rt():
     return _hip
 
 
-def masked_stream(device, cu_lo: int, cu_hi: int) -> "torch.cuda.ExternalStream":
-    """A stream whose kernels may only run on CUs cu_lo .. cu_hi - 1 of every shader engine (0 <= cu_lo < cu_hi <= 8 on MI355X)."""
-    dev = torch.device(device)
-    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-    words = max(1, n_cu // 32)
-    if not (0 <= cu_lo < cu_hi <= words):
-        raise ValueError(f"CU range {cu_lo}..{cu_hi} outside 0..{words}")
-    mask = (C.c_uint32 * words)(*[0xFFFFFFFF if cu_lo <= g < cu_hi else 0 for g in range(words)])
+def _stream_with_mask(dev, mask_words) -> "torch.cuda.ExternalStream":
+    mask = (C.c_uint32 * len(mask_words))(*mask_words)
     s = C.c_void_p()
     with torch.cuda.device(dev):
-        rc = _rt().hipExtStreamCreateWithCUMask(C.byref(s), words, mask)
+        rc = _rt().hipExtStreamCreateWithCUMask(C.byref(s), len(mask_words), mask)
     if rc != 0:
         raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with {rc}")
     return torch.cuda.ExternalStream(s.value, device=dev)
 
 
+def _cu_words(device):
+    return max(1, torch.cuda.get_device_properties(torch.device(device)).multi_processor_count // 32)
+
+
+def masked_stream(device, cu_lo: int, cu_hi: int) -> "torch.cuda.ExternalStream":
+    """A stream whose kernels may only run on CUs cu_lo .. cu_hi - 1 of every shader engine (0 <= cu_lo < cu_hi <= 8 on MI355X)."""
+    dev = torch.device(device)
+    words = _cu_words(dev)
+    if not (0 <= cu_lo < cu_hi <= words):
+        raise ValueError(f"CU range {cu_lo}..{cu_hi} outside 0..{words}")
+    return _stream_with_mask(dev, [0xFFFFFFFF if cu_lo <= g < cu_hi else 0 for g in range(words)])
+
+
+def split_masks(words: int, admit_cus_per_se: float):
+    """(admission mask, decode mask): the admission gets CU indices 0 .. floor(x) - 1 of every shader engine and, for a fractional x,
+    CU index floor(x) of every other shader engine (x = 2.5 -> 80 of 256 CUs, 2 of the 4 shader engines of every XCD)."""
+    full = int(admit_cus_per_se)
+    frac = admit_cus_per_se - full
+    adm = [0xFFFFFFFF if g < full else 0 for g in range(words)]
+    if frac > 0 and full < words:
+        adm[full] = 0x55555555
+    if not any(adm) or all(a == 0xFFFFFFFF for a in adm):
+        raise ValueError(f"admission share {admit_cus_per_se} of {words} CUs per shader engine leaves one side empty")
+    return adm, [a ^ 0xFFFFFFFF for a in adm]
+
+
 _sets = {}
 
 
-def overlap_streams(device, admit_cus_per_se: int = 3) -> "OverlapStreams":
+def overlap_streams(device, admit_cus_per_se: float = 3) -> "OverlapStreams":
     """One stream set per (device, split) for the life of the process: schedulers come and go (one per generate call), HIP streams
     created with a CU mask are never handed back by torch."""
     dev = torch.device(device)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(admit_cus_per_se))
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), float(admit_cus_per_se))
     if key not in _sets:
         _sets[key] = OverlapStreams(dev, admit_cus_per_se)
     return _sets[key]
@@ -58,9 +78,9 @@ def overlap_streams(device, admit_cus_per_se: int = 3) -> "OverlapStreams":
 class OverlapStreams:
     """decode_full: unmasked, used while no admission is in flight; decode / admit: the two halves of the chip."""
 
-    def __init__(self, device, admit_cus_per_se: int = 3):
+    def __init__(self, device, admit_cus_per_se: float = 3):
         dev = torch.device(device)
-        words = max(1, torch.cuda.get_device_properties(dev).multi_processor_count // 32)
+        adm, dec = split_masks(_cu_words(dev), admit_cus_per_se)
         self.decode_full = torch.cuda.Stream(dev)
-        self.admit = masked_stream(dev, 0, admit_cus_per_se)
-        self.decode = masked_stream(dev, admit_cus_per_se, words)
+        self.admit = _stream_with_mask(dev, adm)
+        self.decode = _stream_with_mask(dev, dec)
