@@ -142,7 +142,7 @@ def main():
             phase_ms["raster"] += e0.elapsed_time(e1)
         return res
 
-    def step_static(nb, phase_ms=None, first=0):
+    def step_static(nb, phase_ms=None, first=0, gather=True):
         e0, e1, e2, e3, e4 = ev(), ev(), ev(), ev(), ev()
         e0.record()
         pix = torch.cat([eng.patchify(im) for im in imgs[first:first + nb]], dim=0)
@@ -160,7 +160,7 @@ def main():
         counts = raster_tail(first, nb)
         e4.record()
         res = torch.cat([toks.to(torch.int64), counts], dim=1)             # [nb, 130] per-tile result row
-        if world > 1 and nb == B:
+        if world > 1 and nb == B and gather:
             res = dp.all_gather_rows(res, nb * world)                      # the one RCCL exchange of the step
         if phase_ms is not None:
             torch.cuda.synchronize(dev)
@@ -188,6 +188,21 @@ def main():
     dt = dp.all_reduce_max(dt, dev)
     tiles_per_s = world * n_req * args.steps / dt
     exchange = dp.exchange_info()
+
+    # ---- the same kernels as ONE static batch of B tiles (no scheduler, whole chip, warm): the phase times the MFMA fractions are quoted on
+    static_ref = None
+    if rank == 0 and continuous and not args.no_latency:
+        st_ms = {"vit": 0.0, "prefill": 0.0, "decode": 0.0, "raster": 0.0}
+        step_static(B, gather=False)          # (rank 0 only: no collective in here)
+        for _ in range(2):
+            step_static(B, st_ms, gather=False)
+        fw = (st_ms["vit"] + st_ms["prefill"]) / 2
+        static_ref = {"workload": f"one static batch of {B} tiles per step (same engine, same kernels, no scheduler)", "steps": 2,
+                      "phase_ms": {k: round(v / 2, 3) for k, v in st_ms.items()},
+                      "decode_step_ms": round(st_ms["decode"] / 2 / (N_NEW - 1), 4),
+                      "vit_mfma_frac": round(VIT_GFLOP * B / (st_ms["vit"] / 2 * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4),
+                      "prefill_mfma_frac": round(PREFILL_GFLOP * B / (st_ms["prefill"] / 2 * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4),
+                      "forward_mfma_frac": round((VIT_GFLOP + PREFILL_GFLOP) * B / (fw * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)}
 
     # ---- configs[1] beside it: one tile at a time on the same engine (batch-1 kernels, hipGraph decode), rank 0 only
     latency = None
@@ -353,7 +368,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not args.fp8 else ("fp8-e4m3 LM linears: prefill fp8 x fp8 on the block-scaled MFMA (MX activations), decode fp8 weights x bf16 activations"
                                                       if args.fp8_mx else "bf16 (fp8-e4m3 LM linear weights, bf16 activations / MFMA)"), "data": "synthetic",
             "config": {"workload": f"SocioReasoner-3B {'fp8-weight' if args.fp8 else 'bf16'}, {B} batch row(s)/GPU, "
-                                   + (f"continuous batching (admit on finish): {n_req} tile requests per step through {B} rows, " if continuous else "static batch, ")
+                                   + (f"continuous batching ({'next admission overlapped with decode' if overlap else 'admit on finish'}): {n_req} tile requests per step through {B} rows, " if continuous else "static batch, ")
                                    + f"448x448 synthetic tiles, 448-token prompt, greedy decode of {N_NEW} tokens (EOS ignored), raster tail; random-init "
                                    f"weights (counter-based generator, seed 0)" + (f" [{cfg_name}]" if cfg_name else ""),
                        "tiles_per_gpu_per_step": n_req,
@@ -362,7 +377,7 @@ def main():
                        "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",
                        "exchange": dict(exchange, payload="float32 logits all-gather per decode step (verification mode)" if args.gather_logits
                                         else "one all-gather of 1 KB result rows per tile and step")},
-            "roofline": roof, "cpu_baseline": cpu, "phase_ms_per_step": phases, "latency_b1": latency,
+            "roofline": roof, "cpu_baseline": cpu, "phase_ms_per_step": phases, "static_batch": static_ref, "latency_b1": latency,
             "weights_load_s": round(load_s, 1), "workspace_GB": round(eng.workspace_bytes / 1e9, 2),
             "result_checksum": int(res.sum().item()),
         }

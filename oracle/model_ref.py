@@ -11,8 +11,8 @@ version 5.15.0 in the build container), whose *bf16 eager* semantics are restate
   * deviation (documented in DESIGN.md): the LM-head returns un-rounded float32 logits
     (HF returns bf16 logits, hf:1386-1387), so that the 1e-3 logit tolerance is meaningful.
 
-Pinned by tests/test_oracle_vs_hf_golden.py against fixtures generated from the real HF modules
-(tools/make_golden.py).  Sequences are processed un-padded (the reference left-pads to 4096 and masks,
+Pinned by tests/test_oracle_golden.py against fixtures generated from the real HF modules
+(tools/make_golden.py; full 3B depth: tools/make_golden_full.py -> tests/golden/hf_full3b.npz).  Sequences are processed un-padded (the reference left-pads to 4096 and masks,
 /root/reference/roll/datasets/collator.py:444-564; padding never changes un-masked results).
 """
 from __future__ import annotations
