@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="batch rows per GPU (32 = configs[2], the default; 1 = configs[1])")
     ap.add_argument("--static", action="store_true", help="one static batch of --batch tiles per step instead of continuous batching")
     ap.add_argument("--continuous", action="store_true", help="(default for --batch > 1) serve --waves x batch requests through the scheduler")
+    ap.add_argument("--tile", type=int, default=448, choices=[448, 896], help="tile edge in pixels (896 = BASELINE.json configs[4]'s high-res tiles: 4096 patches, "
+                    "1024 image tokens, 1216-token prompt); the MFMA fractions are only quoted for 448")
     ap.add_argument("--waves", type=int, default=4, help="continuous mode: a step serves waves x batch tile requests through the batch rows")
     ap.add_argument("--admit-cus", type=float, default=3, help="CUs per shader engine (of 8) given to the overlapped admission stream")
     ap.add_argument("--no-overlap", action="store_true", help="continuous mode: admit between decode steps on one stream (round-1 behaviour) instead of "
@@ -86,7 +88,13 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     geom = geometry_3b()
-    eng = Engine(geom, max_patches=1024 * B, max_prefill_tokens=448 * B, max_batch=B, max_ctx=640, max_new_tokens=N_NEW, device=str(dev), lm_fp8="mx" if args.fp8_mx else args.fp8,
+    global GRID, VIT_GFLOP, PREFILL_GFLOP
+    GRID = (1, args.tile // 14, args.tile // 14)
+    NPATCH = GRID[1] * GRID[2]
+    S_PROMPT = 96 + 94 + 2 + NPATCH // 4
+    if args.tile != 448:
+        VIT_GFLOP = PREFILL_GFLOP = float("nan")       # (the constants above are the 448-tile counts)
+    eng = Engine(geom, max_patches=NPATCH * B, max_prefill_tokens=S_PROMPT * B, max_batch=B, max_ctx=max(640, (S_PROMPT + N_NEW + 63) // 64 * 64), max_new_tokens=N_NEW, device=str(dev), lm_fp8="mx" if args.fp8_mx else args.fp8,
                  kv_slots=2 * B if overlap else 0)      # spare KV slots: the next requests are prefilled while the current rows decode
     t0 = time.time()
     eng.load_synthetic_weights(seed=0)
@@ -95,7 +103,7 @@ def main():
     # ---- synthetic inputs, resident in HBM.  Request k of a step is tile (rank * n_req + k)
     n_req = args.waves * B if continuous else B
     tiles = [rank * n_req + i for i in range(n_req)]
-    imgs = [torch.from_numpy(synthetic.tile_pixels(i)).to(dev) for i in tiles]
+    imgs = [torch.from_numpy(synthetic.tile_pixels(i, args.tile, args.tile)).to(dev) for i in tiles]
     ids = [synthetic.tile_prompt(geom, i, GRID) for i in tiles]
     pos3 = []
     for x in ids:
@@ -312,7 +320,7 @@ def main():
         steps_total = args.steps * (N_NEW - 1)
         # continuous mode: the decode steps that had the chip to themselves (steps that shared it with an admission are listed apart)
         decode_step_ms = phase_ms["decode"] / steps_total if not continuous else phase_ms["decode"] / max(sched["steps"] - sched["steps_shared"], 1)
-        kv_bytes = 36864.0 * (448 + N_NEW / 2) * B
+        kv_bytes = 36864.0 * (S_PROMPT + N_NEW / 2) * B
         # HBM traffic per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950 note):
         # measured ratio traffic / algorithmic bytes of this kernel family x the algorithmic bytes of one launch
         traffic, pmc = None, None
@@ -335,7 +343,7 @@ def main():
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_per_launch / (a1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "avg_launch_us": round(a1 * 1e3, 2),
                                    "traffic": round(pmc["traffic_over_algorithmic_weighted_batch1"] * bytes_per_launch) if pmc else None,
-                                   "decode_step_achieved_GBs": round((wl + wh + 36864.0 * (448 + N_NEW / 2)) / (latency["decode_step_ms"] * 1e-3) / 1e9, 1)}
+                                   "decode_step_achieved_GBs": round((wl + wh + 36864.0 * (S_PROMPT + N_NEW / 2)) / (latency["decode_step_ms"] * 1e-3) / 1e9, 1)}
         del wq, wo, wg, wd, wv
         # batches of B tiles inside the timed region whose admission had the whole chip (the MFMA fractions are quoted on those)
         per = (sched["admitted"] - sched["staged_shared"]) / B if continuous else args.steps
@@ -361,7 +369,11 @@ def main():
                 return t.float().cpu().reshape(tuple(shape))
             eng.close()                   # the GPU is idle while the host cores are timed
             cpu = cpu_baseline(dev_weight)
-        cfg_name = "BASELINE.json configs[2]" if B == 32 and continuous and not args.fp8 else "BASELINE.json configs[1]" if B == 1 and not args.fp8 else None
+        cfg_name = None
+        if args.tile == 448 and not args.fp8:
+            cfg_name = "BASELINE.json configs[2]" if B == 32 and continuous else "BASELINE.json configs[1]" if B == 1 else None
+        elif args.tile == 896 and args.fp8:
+            cfg_name = "BASELINE.json configs[4], one GPU's share"
         out = {
             "metric": "satellite tiles/sec (448x448, SocioReasoner-3B)", "value": round(tiles_per_s, 4), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -369,7 +381,7 @@ def main():
                                                       if args.fp8_mx else "bf16 (fp8-e4m3 LM linear weights, bf16 activations / MFMA)"), "data": "synthetic",
             "config": {"workload": f"SocioReasoner-3B {'fp8-weight' if args.fp8 else 'bf16'}, {B} batch row(s)/GPU, "
                                    + (f"continuous batching ({'next admission overlapped with decode' if overlap else 'admit on finish'}): {n_req} tile requests per step through {B} rows, " if continuous else "static batch, ")
-                                   + f"448x448 synthetic tiles, 448-token prompt, greedy decode of {N_NEW} tokens (EOS ignored), raster tail; random-init "
+                                   + f"{args.tile}x{args.tile} synthetic tiles, {S_PROMPT}-token prompt, greedy decode of {N_NEW} tokens (EOS ignored), raster tail; random-init "
                                    f"weights (counter-based generator, seed 0)" + (f" [{cfg_name}]" if cfg_name else ""),
                        "tiles_per_gpu_per_step": n_req,
                        "scheduling": ("continuous batching through B rows; the next requests' ViT + prefill are staged into spare KV slots on a CU-masked stream under the running rows' decode"
@@ -381,7 +393,15 @@ def main():
             "weights_load_s": round(load_s, 1), "workspace_GB": round(eng.workspace_bytes / 1e9, 2),
             "result_checksum": int(res.sum().item()),
         }
-        print(json.dumps(out), flush=True)
+        def clean(o):       # NaN (fractions that are not quoted for this workload) -> null
+            if isinstance(o, float) and o != o:
+                return None
+            if isinstance(o, dict):
+                return {k: clean(v) for k, v in o.items()}
+            if isinstance(o, list):
+                return [clean(v) for v in o]
+            return o
+        print(json.dumps(clean(out)), flush=True)
     dp.barrier()
     eng.close()
 
