@@ -595,3 +595,19 @@ def test_host_ops_agree_with_oracle_on_random_inputs():
                 if max(h, w) / min(h, w) > 200:
                     continue
                 assert hostops.smart_resize(h, w, factor=28, min_pixels=56 * 56, max_pixels=mx) == H.smart_resize(h, w, 28, 56 * 56, mx)
+
+
+def test_cu_mask_split_for_overlapped_admission():
+    """socioreasoner_amd/streams.py: the admission / decode CU masks are complementary, cover every CU exactly once and take the same
+    CU indices in every shader engine (whole 32-bit words) for integer shares; a fractional share alternates shader engines."""
+    from socioreasoner_amd.streams import split_masks
+    adm, dec = split_masks(8, 3)
+    assert adm == [0xFFFFFFFF] * 3 + [0] * 5 and dec == [0] * 3 + [0xFFFFFFFF] * 5
+    for share in (1, 2, 2.5, 3, 3.5, 7):
+        a, d = split_masks(8, share)
+        assert all((x & y) == 0 and (x | y) == 0xFFFFFFFF for x, y in zip(a, d))
+        assert sum(bin(x).count("1") for x in a) == int(32 * share)
+    with pytest.raises(ValueError):
+        split_masks(8, 0)
+    with pytest.raises(ValueError):
+        split_masks(8, 8)
