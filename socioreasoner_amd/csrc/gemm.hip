@@ -25,18 +25,22 @@ namespace {
 
 constexpr int BN = 128, BK = 64;
 
-template <int BM>
+template <int BM, int NS = 2>
 struct Smem {
-    bf16_t a[2][BM * BK];
-    bf16_t w[2][BN * BK];
+    bf16_t a[NS][BM * BK];
+    bf16_t w[NS][BN * BK];
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * (BK * 2) + ((chunk ^ (row & 7)) << 4); }
 
-template <int BM, int EPI, int NW = 4>
+// NS = LDS stages.  2: the double-buffered loop described above (one __syncthreads per k-tile, the compiler drains the LDS-DMA in front
+// of it).  NS > 2 (small M: a few hundred blocks, each walking 20 .. 172 k-tiles): a ring with NS - 1 k-tiles of LDS-DMA in flight, ONE
+// counted s_waitcnt vmcnt + raw s_barrier per k-tile -- with one k-tile in flight the loop ran at the memory round trip (0.8 us per
+// k-tile: the batch-1 LM down-projection, K = 11008, took 140 us on 112 CUs); same k order, bit-identical results.
+template <int BM, int EPI, int NW = 4, int NS = 2>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p, int ntm, int ntn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Smem<BM>& sm = *reinterpret_cast<Smem<BM>*>(smem_raw);
+    Smem<BM, NS>& sm = *reinterpret_cast<Smem<BM, NS>*>(smem_raw);
     constexpr int MI = BM / 32;       // 16-row m-tiles per wave (waves are arranged 2 x NW/2)
     constexpr int WNC = NW / 2;       // wave columns
     constexpr int NJ = BN / WNC / 16; // 16-col n-tiles per wave: 4 (NW = 4) or 2 (NW = 8)
@@ -107,11 +111,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p, int ntm, int ntn) 
     // k-tiles of this block: all of them, or slice blockIdx.y of a split-K launch (EPI_F32 partial products)
     const int nk_all = p.K / BK, per = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
     const int kt0 = min((int)blockIdx.y * per, nk_all), nk = min(kt0 + per, nk_all);
-    if (kt0 < nk) stage(0, kt0);
-    __syncthreads();               // the compiler drains the LDS-DMA (vmcnt(0)) in front of the barrier
-    for (int kt = kt0; kt < nk; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    auto compute = [&](int cur) {
         const unsigned char* ab = reinterpret_cast<const unsigned char*>(sm.a[cur]);
         const unsigned char* wb = reinterpret_cast<const unsigned char*>(sm.w[cur]);
 #pragma unroll
@@ -137,7 +137,44 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p, int ntm, int ntn) 
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+    };
+    if constexpr (NS == 2) {
+        if (kt0 < nk) stage(0, kt0);
+        __syncthreads();               // the compiler drains the LDS-DMA (vmcnt(0)) in front of the barrier
+        for (int kt = kt0; kt < nk; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            compute(cur);
+            __syncthreads();
+        }
+    } else {
+        // ring: stages kt .. kt + NS - 2 are in flight or landed when k-tile kt is computed.  A stage is G = A_G + W_G LDS-DMA
+        // instructions per wave; "vmcnt(G * j)" = everything but the newest j stages of THIS wave has landed, the barrier extends that
+        // to every wave's share and also says that all waves are done reading the buffer the next issue overwrites (it was read in the
+        // previous iteration).
+        constexpr int G = A_G + W_G;
+        static_assert(NS <= 6 && G * (NS - 2) <= 60, "one wait case per stage count; vmcnt is a 6-bit counter");
+#pragma unroll
+        for (int j = 0; j < NS - 1; ++j)
+            if (kt0 + j < nk) stage(j, kt0 + j);
+        int buf = 0;
+        for (int kt = kt0; kt < nk; ++kt) {
+            const int ahead = min(nk - 1 - kt, NS - 2);      // stages newer than kt that this wave has issued
+            switch (ahead) {                                  // (immediate operand: one case per count)
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G) : "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G * 2) : "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G * 3) : "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G * 4) : "memory"); break;
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + NS - 1 < nk) stage(buf == 0 ? NS - 1 : buf - 1, kt + NS - 1);      // = (buf + NS - 1) % NS: the buffer of k-tile kt - 1
+            compute(buf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads are done before it can reach the next barrier
+            __builtin_amdgcn_sched_barrier(0);
+            buf = buf + 1 == NS ? 0 : buf + 1;
+        }
     }
 
     // ---- epilogue.  lane owns row m = .. + fr and columns n = .. + fg*4 + {0,1,2,3} of every 16x16 tile.
@@ -242,17 +279,17 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p, int ntm, int ntn) 
     }
 }
 
-template <int BM, int EPI, int NW = 4>
+template <int BM, int EPI, int NW = 4, int NS = 2>
 int launch_t(hipStream_t s, const GemmArgs& a) {
     int ntm = cdiv(a.M, BM), ntn = cdiv(a.N, BN);
-    size_t smem = sizeof(Smem<BM>);
+    size_t smem = sizeof(Smem<BM, NS>);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, EPI, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem);
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, EPI, NW, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (r != hipSuccess) return (int)r;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_gemm<BM, EPI, NW>), dim3(ntm * ntn, EPI == EPI_F32 && a.ksplit > 1 ? a.ksplit : 1), dim3(NW * 64), smem, s, a, ntm, ntn);
+    hipLaunchKernelGGL((k_gemm<BM, EPI, NW, NS>), dim3(ntm * ntn, EPI == EPI_F32 && a.ksplit > 1 ? a.ksplit : 1), dim3(NW * 64), smem, s, a, ntm, ntn);
     SR_CHECK_LAUNCH();
     return 0;
 }
@@ -270,6 +307,13 @@ int launch_e(hipStream_t s, const GemmArgs& a) {
         if constexpr (EPI == EPI_SWIGLU || EPI == EPI_RESID) return launch_t<128, EPI, 8>(s, a);
         return launch_t<128, EPI>(s, a);
     }
+    // at most one block per CU, each walking the whole K: the 6-stage ring (5 k-tiles of LDS-DMA in flight; 144 KB of LDS).  With more
+    // blocks than CUs the three co-resident blocks of the double-buffered loop cover each other better (ViT qkv at batch 1, 480 blocks:
+    // 6.06 vs 6.47 ms per ViT pass)
+    const char* ring_env = getenv("SR_GEMM_RING");            // tuning / test hook (read at every call): 0 = never, 2 = whenever K allows
+    const int ring = ring_env ? atoi(ring_env) : 1;
+    const long blocks64 = (long)cdiv(a.M, 64) * cdiv(a.N, BN);
+    if (a.K / BK >= 8 && (ring == 2 || (ring == 1 && blocks64 <= 256))) return launch_t<64, EPI, 4, 6>(s, a);
     return launch_t<64, EPI>(s, a);
 }
 

@@ -92,6 +92,37 @@ def test_gemm256_equals_gemm128_bit_for_bit(L):
         assert bool(torch.isfinite(outs[0].float()).all()) and float(outs[0].float().abs().max()) > 0
 
 
+def test_small_m_ring_gemm_equals_double_buffered_loop(L, monkeypatch):
+    """Small M (a few hundred blocks that each walk the whole K): gemm.hip runs a 6-stage LDS ring with counted vmcnt waits and one
+    raw barrier per k-tile (SR_GEMM_RING=0: the double-buffered loop).  Same k order, so EXACTLY the same results -- batch-1 shapes of
+    the LM and the ViT, ragged M, short K (fewer k-tiles than stages + 2), every epilogue; and run-to-run identical bits (a read of a
+    stage that is still being filled would show up as differences)."""
+    torch.manual_seed(1)
+    for (M, N, K, epi, tiled) in [(448, 2048, 11008, EPI_RESID, True), (448, 2560, 2048, EPI_STORE, True), (448, 2048, 2048, EPI_RESID, True),
+                                   (1024, 1280, 3456, EPI_RESID, False), (1024, 3840, 1280, EPI_STORE, False), (1024, 1280, 1280, EPI_RESID, False),
+                                   (130, 512, 512, EPI_F32, False), (64, 256, 576, EPI_GELU, False), (200, 768, 1024, EPI_SWIGLU, True), (37, 128, 640, EPI_STORE, False)]:
+        a = (torch.randn(M, K, device="cuda") * 1.0).to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda") * 0.03).to(torch.bfloat16)
+        b = (torch.randn(N, device="cuda") * 0.1).to(torch.bfloat16) if epi != EPI_F32 else None
+        No = N // 2 if epi == EPI_SWIGLU else N
+        res0 = (torch.randn(M, No, device="cuda")).to(torch.bfloat16) if epi == EPI_RESID else None
+        outs = []
+        for ring in ("0", "2", "2", "2"):
+            monkeypatch.setenv("SR_GEMM_RING", ring)
+            out = torch.zeros(M, No, dtype=torch.float32 if epi == EPI_F32 else torch.bfloat16, device="cuda")
+            res = None
+            if epi == EPI_RESID:
+                out.copy_(res0)
+                res = out
+            rc = L.sr_op_gemm(P(a), K, P(w), M, N, K, P(out), No, P(b), P(res), None, epi | F128 | (TILED if tiled else 0), sp())
+            assert rc == 0, (M, N, K, epi)
+            torch.cuda.synchronize()
+            outs.append(out)
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), (M, N, K, epi, float((outs[0].float() - o.float()).abs().max()))
+        assert bool(torch.isfinite(outs[0].float()).all()) and float(outs[0].float().abs().max()) > 0
+
+
 def test_gemm256_race_screen(L):
     """The LDS-DMA pipeline keeps loads in flight across barriers: repeat one launch many times on the same inputs and
     require identical bits every time (an early read of a buffer still being filled shows up as run-to-run differences)."""
