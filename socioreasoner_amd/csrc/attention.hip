@@ -211,52 +211,63 @@ __global__ __launch_bounds__(256) void k_attn_dec_scores(DecodeAttnArgs p) {
     __shared__ __attribute__((aligned(16))) bf16_t k_s[128];
     __shared__ float cs[64], sn[64];
     const int b = blockIdx.x, kvh = blockIdx.y, z = blockIdx.z;
-    const int nkeys = p.ctx_len[b];
-    if (z * 64 >= nkeys) return;
-    const int slot = p.slots ? p.slots[b] : b;
-    const int idx = nkeys - 1;                    // cache row of the new token
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int G = p.group, HQ = p.n_q_heads, HK = p.n_kv_heads;
-    bf16_t* kc = p.kcache + (size_t)(slot * HK + kvh) * p.ctx_max * DEC_HD;
-    bf16_t* vc = p.vtcache + (size_t)(slot * HK + kvh) * DEC_HD * p.ctx_max;
     const bf16_t* row = p.qkv + (size_t)b * p.qkv_stride;
-    const int ntiles = (nkeys + 15) / 16;
-    const int t = z * 4 + wave;
-    // early K prefetch (independent of the new token; its row is patched from LDS below)
-    bf16x8 kf[4];
-    const int key = min(t * 16 + fr, nkeys - 1);
-    if (t < ntiles) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(kc + (size_t)key * DEC_HD + kk * 32 + fg * 8);
-    }
-    // raw q / k / v of the new token go out before anything waits (they do not depend on the rotary table):
+    // Everything that does not depend on the row's device-side state goes out FIRST, so that it travels together with the state loads
+    // (ctx_len / slot / frozen) instead of one memory round trip behind them: the raw q / k / v of the new token and the rotary cos | sin
+    // of its position (k_step wrote them for this step; without that buffer they hang off pos[b] like before).
     //   threads 0..127  : query head tid >> 3, 16-byte chunks (tid & 7) of both rotary halves
-    //   threads 128..191: key element pair (d, d + 64) when this block owns the new token's cache row
-    //   threads 192..255: V^T append (no rotary) -- done right here
-    const bool owner = z == (idx >> 6) && !(p.frozen && p.frozen[b]);
+    //   threads 128..191: key element pair (d, d + 64)          (used by the block that owns the new token's cache row)
+    //   threads 192..255: value element pair (d, d + 64)        (V^T append, no rotary, same block)
     const int qh = tid >> 3, qc = tid & 7;
     uint4 q1 = uint4{0, 0, 0, 0}, q2 = q1;
     float kx1 = 0.f, kx2 = 0.f;
+    bf16_t vx1 = 0, vx2 = 0;
     if (tid < 128) {
         if (qh < G) {
             const bf16_t* q = row + (kvh * G + qh) * DEC_HD + qc * 8;
             q1 = *reinterpret_cast<const uint4*>(q);
             q2 = *reinterpret_cast<const uint4*>(q + 64);
         }
-    } else if (owner) {
-        if (tid < 192) {
-            const bf16_t* k = row + (HQ + kvh) * DEC_HD + (tid - 128);
-            kx1 = bf2f(k[0]);
-            kx2 = bf2f(k[64]);
-        } else {
-            const int d = tid - 192;
-            const bf16_t* v = row + (HQ + HK + kvh) * DEC_HD + d;
-            vc[(size_t)d * p.ctx_max + idx] = v[0];
-            vc[(size_t)(d + 64) * p.ctx_max + idx] = v[64];
-        }
+    } else if (tid < 192) {
+        const bf16_t* k = row + (HQ + kvh) * DEC_HD + (tid - 128);
+        kx1 = bf2f(k[0]);
+        kx2 = bf2f(k[64]);
+    } else {
+        const bf16_t* v = row + (HQ + HK + kvh) * DEC_HD + (tid - 192);
+        vx1 = v[0];
+        vx2 = v[64];
     }
-    if (tid < 64) {
+    float csv = 0.f;
+    if (p.row_cs && tid < 128) csv = p.row_cs[(size_t)b * 128 + tid];
+    const int nkeys = p.ctx_len[b];
+    const int slot = p.slots ? p.slots[b] : b;
+    const bool frozen = p.frozen && p.frozen[b];
+    if (z * 64 >= nkeys) return;
+    const int idx = nkeys - 1;                    // cache row of the new token
+    bf16_t* kc = p.kcache + (size_t)(slot * HK + kvh) * p.ctx_max * DEC_HD;
+    bf16_t* vc = p.vtcache + (size_t)(slot * HK + kvh) * DEC_HD * p.ctx_max;
+    const int ntiles = (nkeys + 15) / 16;
+    const int t = z * 4 + wave;
+    // K prefetch (independent of the new token; its row is patched from LDS below): in flight while q / k are rotated
+    bf16x8 kf[4];
+    const int key = min(t * 16 + fr, nkeys - 1);
+    if (t < ntiles) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8*>(kc + (size_t)key * DEC_HD + kk * 32 + fg * 8);
+    }
+    const bool owner = z == (idx >> 6) && !frozen;
+    if (owner && tid >= 192) {
+        const int d = tid - 192;
+        vc[(size_t)d * p.ctx_max + idx] = vx1;
+        vc[(size_t)(d + 64) * p.ctx_max + idx] = vx2;
+    }
+    if (p.row_cs) {
+        if (tid < 64) cs[tid] = csv;
+        else if (tid < 128) sn[tid - 64] = csv;
+    } else if (tid < 64) {
         const int pos = p.pos[b];
         cs[tid] = bf2f(p.rope_cos[(size_t)pos * 64 + tid]);
         sn[tid] = bf2f(p.rope_sin[(size_t)pos * 64 + tid]);
@@ -307,11 +318,28 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
     f32x4* ored = reinterpret_cast<f32x4*>(dsm);
     bf16_t* sb = reinterpret_cast<bf16_t*>(ored + DT * 3 * 64);
     const int b = blockIdx.x, kvh = blockIdx.y, dt0 = blockIdx.z * DT;
-    const int slot = p.slots ? p.slots[b] : b;
-    const int nkeys = p.ctx_len[b];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int G = p.group, HK = p.n_kv_heads;
+    // Short caches (ctx_max <= 1024): the score rows of this kv head are requested in full BEFORE the row's state (ctx_len, slot) is
+    // known -- their address does not depend on it -- so that they arrive together with it and the softmax runs while V^T is still in
+    // flight, instead of one round trip later.  Columns past the context hold stale values; they are masked below like the padding.
+    const bf16_t* sg = p.scores + (size_t)(b * HK + kvh) * G * p.ctx_max;
+    constexpr int SPEC = 4;
+    const int nvm = p.ctx_max / 8;
+    const bool spec = p.ctx_max <= 1024 && G * nvm <= 256 * SPEC;
+    uint4 su[SPEC];
+#pragma unroll
+    for (int k = 0; k < SPEC; ++k) su[k] = uint4{0, 0, 0, 0};
+    if (spec) {
+#pragma unroll
+        for (int k = 0; k < SPEC; ++k) {
+            const int i = tid + k * 256;
+            if (i < G * nvm) su[k] = *reinterpret_cast<const uint4*>(sg + (size_t)(i / nvm) * p.ctx_max + (i % nvm) * 8);
+        }
+    }
+    const int slot = p.slots ? p.slots[b] : b;
+    const int nkeys = p.ctx_len[b];
     const bf16_t* vc = p.vtcache + (size_t)(slot * HK + kvh) * DEC_HD * p.ctx_max;
     const int npad = (nkeys + 31) / 32 * 32, nkb = npad / 32, nvec = npad / 8;
     const uint4 z4 = uint4{0, 0, 0, 0};
@@ -326,10 +354,17 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
             if (wave + 4 * i < nkb) vf0[d][i] = *reinterpret_cast<const bf16x8*>(vrow[d] + (wave + 4 * i) * 32);
     }
     // scores of all heads of this kv head -> LDS
-    const bf16_t* sg = p.scores + (size_t)(b * HK + kvh) * G * p.ctx_max;
-    for (int i = tid; i < G * nvec; i += 256) {
-        const int h = i / nvec, v = i % nvec;
-        *reinterpret_cast<uint4*>(sb + h * s_stride + v * 8) = *reinterpret_cast<const uint4*>(sg + (size_t)h * p.ctx_max + v * 8);
+    if (spec) {
+#pragma unroll
+        for (int k = 0; k < SPEC; ++k) {
+            const int i = tid + k * 256;
+            if (i < G * nvm && i % nvm < nvec) *reinterpret_cast<uint4*>(sb + (i / nvm) * s_stride + (i % nvm) * 8) = su[k];
+        }
+    } else {
+        for (int i = tid; i < G * nvec; i += 256) {
+            const int h = i / nvec, v = i % nvec;
+            *reinterpret_cast<uint4*>(sb + h * s_stride + v * 8) = *reinterpret_cast<const uint4*>(sg + (size_t)h * p.ctx_max + v * 8);
+        }
     }
     __syncthreads();
     // softmax per head (float32), probabilities rounded to bf16 in place; tail zero-filled

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_next_ids(const float* amax_val, const i
 __global__ __launch_bounds__(256) void k_step(StepArgs a) {
     __shared__ float sv[4];
     __shared__ int si[4];
-    __shared__ int s_feed;
+    __shared__ int s_feed, s_pos;
     const int b = blockIdx.x, tid = threadIdx.x;
     int bi = reduce_amax_partials(a.amax_val, a.amax_idx, a.n_part, b, sv, si);
     if (tid == 0) {
@@ -337,11 +337,17 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
         int feed = tok;
         if (a.forced && step < a.max_new) feed = a.forced[(size_t)b * a.max_new + step];
         if (fin) feed = 0;
-        if (!fin && !is_eos) { a.ctx_len[b] += 1; a.pos[b] += 1; }
+        int pos = a.pos[b];
+        if (!fin && !is_eos) { a.ctx_len[b] += 1; pos += 1; a.pos[b] = pos; }
         a.step[b] = step + 1;
         s_feed = feed;
+        s_pos = pos;
     }
     __syncthreads();
+    if (a.row_cs && tid < 128) {       // rotary cos | sin of the position the coming forward pass uses, as the float32 values the attention kernel multiplies with
+        const bf16_t* t = tid < 64 ? a.rope_cos : a.rope_sin;
+        a.row_cs[(size_t)b * 128 + tid] = bf2f(t[(size_t)s_pos * 64 + (tid & 63)]);
+    }
     for (int c = tid; c < a.H / 8; c += 256) {
         const bf16_t* from = a.table + (a.table_tiled ? tiled_offset(s_feed, (size_t)c * 8, a.H) : (size_t)s_feed * a.H + c * 8);
         reinterpret_cast<uint4*>(a.x + (size_t)b * a.H)[c] = *reinterpret_cast<const uint4*>(from);

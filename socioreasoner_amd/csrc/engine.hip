@@ -107,6 +107,7 @@ struct sr_engine {
     // ---- decode state (device)
     bf16_t *d_xa, *d_xb, *d_xn, *d_qkv, *d_attn, *d_act, *d_scores;    // d_xa / d_xb: residual stream ping-pong
     float *d_logits, *d_slabs, *d_amax_val;
+    float* d_row_cs = nullptr;               // [32][128] rotary cos | sin of every row's current position (k_step -> decode attention)
     int *d_amax_idx, *d_cur_tok, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
     int n_part = 0;      // LM-head blocks = partial argmax entries per row
     // continuous batching (sr_rows_*): admission scratch so that a prefill never touches the pending tokens of running rows
@@ -312,6 +313,7 @@ void carve(sr_engine* e) {
     e->d_amax_val_adm = ar.take<float>(B * e->n_part);
     e->d_amax_idx_adm = ar.take<int>(B * e->n_part);
     e->d_row_limit = ar.take<int>(32);
+    e->d_row_cs = ar.take<float>(32 * 128);
     e->d_ngen = ar.take<int>(32);
     e->d_adm = ar.take<int>(5 * 32);
     e->d_adm_slots = ar.take<int>(32);
@@ -598,7 +600,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         if (fused && pending) { bf16_t* t = x; x = x_alt; x_alt = t; }     // block 0 wrote the updated stream there
         pending = false;
         DecodeAttnArgs da{e->d_qkv, e->t_qn, e->d_pos, e->d_ctx_len, e->d_slots, e->rope_cos, e->rope_sin, kc, vc, e->d_attn, QD,
-                          B, c.t_heads, c.t_kv_heads, e->t_group, c.max_ctx, scale, e->d_scores, xt, e->d_finished};
+                          B, c.t_heads, c.t_kv_heads, e->t_group, c.max_ctx, scale, e->d_scores, xt, e->d_finished, e->d_row_cs};
         SR_TRY(launch_attn_decode(s, da));
         GemvArgs go = gv(e->d_attn, QD, w.o_w, B, H, QD, x, H);
         go.W8 = w.o_w8; go.w_scale = w.o_s; go.x_tiled = xt;
@@ -619,7 +621,8 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
 
 int enqueue_step(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, hipStream_t s, const long long* chosen = nullptr) {
     StepArgs a{e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(e->c.t_vocab, B, e->c.t_hidden, fused_norms(e, B) ? 1 : 0), e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished,
-               e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden, 1, chosen, e->d_row_limit, e->d_ngen};
+               e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden, 1, chosen, e->d_row_limit, e->d_ngen,
+               e->rope_cos, e->rope_sin, e->d_row_cs};
     SR_TRY(launch_step(s, a));
     return 0;
 }

@@ -118,6 +118,7 @@ struct DecodeAttnArgs {
     int out_tiled;                        // write `out` fragment-ordered (tiled16x64, K = out_stride): it is the o_proj GEMV's x
     const int* frozen;                    // [B] or null: rows whose flag is set append nothing to the cache (finished rows: their
                                           // KV slot may already be staged for the next sequence -- sr_admit_stage)
+    const float* row_cs;                  // [B][128] or null: cos | sin of pos[b] as float32 (written by k_step); null: looked up from the tables
 };
 int launch_attn_decode(hipStream_t s, const DecodeAttnArgs& a);
 int attn_decode_prepare(int ctx_max, int group);
@@ -162,6 +163,9 @@ struct StepArgs {
     const long long* chosen;    // optional [B]: this step's token picked by the caller (replaces the greedy argmax)
     const int* row_limit;       // optional [B]: a row finishes after this many generated tokens (continuous batching)
     int* n_gen;                 // [B]: tokens generated while the row was live (pads written after eos are not counted)
+    const bf16_t* rope_cos; const bf16_t* rope_sin;     // optional LM rotary tables [pos][64] ...
+    float* row_cs;              // ... and [B][128]: cos | sin of every row's NEW position, for the decode attention of this step (which then
+                                // does not have to chase pos[b] -> table row through two dependent loads in every layer)
 };
 // fp8 quantisation of a fragment-ordered bf16 matrix [N, K]: scale[n] = amax_n / 448 (1 if the row is zero),
 // q = fp8(W / scale) -> W8 (tiled8); W itself is overwritten with q as bf16 (what the prefill GEMM multiplies, scaled in its epilogue)
