@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--continuous", action="store_true", help="(default for --batch > 1) serve --waves x batch requests through the scheduler")
     ap.add_argument("--tile", type=int, default=448, choices=[448, 896], help="tile edge in pixels (896 = BASELINE.json configs[4]'s high-res tiles: 4096 patches, "
                     "1024 image tokens, 1216-token prompt); the MFMA fractions are only quoted for 448")
+    ap.add_argument("--pair", action="store_true", help="reference-faithful sample: TWO images (map + satellite tile) per request, 706-token prompt "
+                    "(SURVEY.md section 8(D) 'reported separately'); value is then samples/s")
     ap.add_argument("--waves", type=int, default=4, help="continuous mode: a step serves waves x batch tile requests through the batch rows")
     ap.add_argument("--admit-cus", type=float, default=3, help="CUs per shader engine (of 8) given to the overlapped admission stream")
     ap.add_argument("--no-overlap", action="store_true", help="continuous mode: admit between decode steps on one stream (round-1 behaviour) instead of "
@@ -91,10 +93,11 @@ def main():
     global GRID, VIT_GFLOP, PREFILL_GFLOP
     GRID = (1, args.tile // 14, args.tile // 14)
     NPATCH = GRID[1] * GRID[2]
-    S_PROMPT = 96 + 94 + 2 + NPATCH // 4
-    if args.tile != 448:
+    NIMG = 2 if args.pair else 1
+    S_PROMPT = 96 + 94 + NIMG * (2 + NPATCH // 4)
+    if args.tile != 448 or args.pair:
         VIT_GFLOP = PREFILL_GFLOP = float("nan")       # (the constants above are the 448-tile counts)
-    eng = Engine(geom, max_patches=NPATCH * B, max_prefill_tokens=S_PROMPT * B, max_batch=B, max_ctx=max(640, (S_PROMPT + N_NEW + 63) // 64 * 64), max_new_tokens=N_NEW, device=str(dev), lm_fp8="mx" if args.fp8_mx else args.fp8,
+    eng = Engine(geom, max_patches=NPATCH * NIMG * B, max_prefill_tokens=S_PROMPT * B, max_batch=B, max_ctx=max(640, (S_PROMPT + N_NEW + 63) // 64 * 64), max_new_tokens=N_NEW, device=str(dev), lm_fp8="mx" if args.fp8_mx else args.fp8,
                  kv_slots=2 * B if overlap else 0)      # spare KV slots: the next requests are prefilled while the current rows decode
     t0 = time.time()
     eng.load_synthetic_weights(seed=0)
@@ -103,11 +106,11 @@ def main():
     # ---- synthetic inputs, resident in HBM.  Request k of a step is tile (rank * n_req + k)
     n_req = args.waves * B if continuous else B
     tiles = [rank * n_req + i for i in range(n_req)]
-    imgs = [torch.from_numpy(synthetic.tile_pixels(i, args.tile, args.tile)).to(dev) for i in tiles]
-    ids = [synthetic.tile_prompt(geom, i, GRID) for i in tiles]
+    imgs = [[torch.from_numpy(synthetic.tile_pixels(NIMG * i + j, args.tile, args.tile)).to(dev) for j in range(NIMG)] for i in tiles]
+    ids = [synthetic.tile_prompt(geom, i, GRID, n_images=NIMG) for i in tiles]
     pos3 = []
     for x in ids:
-        p, _ = hostops.get_rope_index(torch.from_numpy(x)[None], [GRID], None, image_token_id=geom.image_token_id,
+        p, _ = hostops.get_rope_index(torch.from_numpy(x)[None], [GRID] * NIMG, None, image_token_id=geom.image_token_id,
                                       vision_start_token_id=geom.vision_start_token_id)
         pos3.append(p[:, 0].numpy())
     mk = [synthetic.tile_masks(i) for i in tiles]
@@ -133,7 +136,7 @@ def main():
         rows of a wave finish together; the point is the measured cost of the request-level path)."""
         from socioreasoner_amd.serving import ContinuousBatcher, Request
         cb = ContinuousBatcher(eng, eos=[], pad_id=0, steps_per_poll=16, time_phases=phase_ms is not None, overlap=overlap, admit_cus_per_se=args.admit_cus)
-        reqs = [Request(ids=ids[k], pos3=pos3[k], max_new=N_NEW, images=[imgs[k]], grids=[GRID]) for k in range(n_req)]
+        reqs = [Request(ids=ids[k], pos3=pos3[k], max_new=N_NEW, images=imgs[k], grids=[GRID] * NIMG) for k in range(n_req)]
         toks = cb.run(reqs)
         e0, e1 = ev(), ev()
         e0.record()
@@ -153,8 +156,8 @@ def main():
     def step_static(nb, phase_ms=None, first=0, gather=True):
         e0, e1, e2, e3, e4 = ev(), ev(), ev(), ev(), ev()
         e0.record()
-        pix = torch.cat([eng.patchify(im) for im in imgs[first:first + nb]], dim=0)
-        emb = eng.vit_forward(pix, [GRID] * nb)
+        pix = torch.cat([eng.patchify(im) for grp in imgs[first:first + nb] for im in grp], dim=0)
+        emb = eng.vit_forward(pix, [GRID] * (nb * NIMG))
         e1.record()
         first_logits = eng.prefill(ids[first:first + nb], pos3[first:first + nb], emb, return_logits=args.gather_logits)
         e2.record()
@@ -375,13 +378,14 @@ def main():
         elif args.tile == 896 and args.fp8:
             cfg_name = "BASELINE.json configs[4], one GPU's share"
         out = {
-            "metric": "satellite tiles/sec (448x448, SocioReasoner-3B)", "value": round(tiles_per_s, 4), "unit": "tiles/s",
+            "metric": "satellite tiles/sec (448x448, SocioReasoner-3B)" if not args.pair else "reference-faithful samples/sec (map + satellite tile per sample, SocioReasoner-3B)",
+            "value": round(tiles_per_s, 4), "unit": "tiles/s" if not args.pair else "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not args.fp8 else ("fp8-e4m3 LM linears: prefill fp8 x fp8 on the block-scaled MFMA (MX activations), decode fp8 weights x bf16 activations"
                                                       if args.fp8_mx else "bf16 (fp8-e4m3 LM linear weights, bf16 activations / MFMA)"), "data": "synthetic",
             "config": {"workload": f"SocioReasoner-3B {'fp8-weight' if args.fp8 else 'bf16'}, {B} batch row(s)/GPU, "
                                    + (f"continuous batching ({'next admission overlapped with decode' if overlap else 'admit on finish'}): {n_req} tile requests per step through {B} rows, " if continuous else "static batch, ")
-                                   + f"{args.tile}x{args.tile} synthetic tiles, {S_PROMPT}-token prompt, greedy decode of {N_NEW} tokens (EOS ignored), raster tail; random-init "
+                                   + f"{NIMG} x {args.tile}x{args.tile} synthetic image(s) per request, {S_PROMPT}-token prompt, greedy decode of {N_NEW} tokens (EOS ignored), raster tail; random-init "
                                    f"weights (counter-based generator, seed 0)" + (f" [{cfg_name}]" if cfg_name else ""),
                        "tiles_per_gpu_per_step": n_req,
                        "scheduling": ("continuous batching through B rows; the next requests' ViT + prefill are staged into spare KV slots on a CU-masked stream under the running rows' decode"
