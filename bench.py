@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--pair", action="store_true", help="reference-faithful sample: TWO images (map + satellite tile) per request, 706-token prompt "
                     "(SURVEY.md section 8(D) 'reported separately'); value is then samples/s")
     ap.add_argument("--waves", type=int, default=4, help="continuous mode: a step serves waves x batch tile requests through the batch rows")
-    ap.add_argument("--admit-cus", type=float, default=3, help="CUs per shader engine (of 8) given to the overlapped admission stream")
+    ap.add_argument("--admit-cus", default="auto", help="CUs per shader engine (of 8) given to the overlapped admission stream, or auto (chosen per admission)")
     ap.add_argument("--no-overlap", action="store_true", help="continuous mode: admit between decode steps on one stream (round-1 behaviour) instead of "
                     "staging the next admission on a CU-masked stream under the running rows' decode")
     ap.add_argument("--no-latency", action="store_true", help="skip the additional batch-1 (configs[1]) measurement")
@@ -135,7 +135,7 @@ def main():
         """waves x B requests through B rows: the later ones are admitted as rows free up (EOS is ignored by the metric, so all
         rows of a wave finish together; the point is the measured cost of the request-level path)."""
         from socioreasoner_amd.serving import ContinuousBatcher, Request
-        cb = ContinuousBatcher(eng, eos=[], pad_id=0, steps_per_poll=16, time_phases=phase_ms is not None, overlap=overlap, admit_cus_per_se=args.admit_cus)
+        cb = ContinuousBatcher(eng, eos=[], pad_id=0, steps_per_poll=16, time_phases=phase_ms is not None, overlap=overlap, admit_cus_per_se=args.admit_cus if args.admit_cus == "auto" else float(args.admit_cus))
         reqs = [Request(ids=ids[k], pos3=pos3[k], max_new=N_NEW, images=imgs[k], grids=[GRID] * NIMG) for k in range(n_req)]
         toks = cb.run(reqs)
         e0, e1 = ev(), ev()
@@ -150,6 +150,7 @@ def main():
                 phase_ms[k] = phase_ms.get(k, 0.0) + v
             for k in ("admitted", "staged_shared", "steps", "steps_shared"):
                 sched[k] = sched.get(k, 0) + cb.stats[k]
+            shares.extend(cb.stats["shares"])
             phase_ms["raster"] += e0.elapsed_time(e1)
         return res
 
@@ -180,6 +181,7 @@ def main():
         return res
 
     phase_ms = {"vit": 0.0, "prefill": 0.0, "decode": 0.0, "raster": 0.0}
+    shares = []         # CU share (of 8 per shader engine) of every overlapped admission
     sched = {}          # continuous mode: requests admitted / staged under decode, decode steps alone / sharing the chip
     step = (lambda rec=False: step_continuous(phase_ms if rec else None)) if continuous else \
         (lambda rec=False: step_static(B, phase_ms if rec else None))
@@ -352,9 +354,9 @@ def main():
         per = (sched["admitted"] - sched["staged_shared"]) / B if continuous else args.steps
         phases = {k: round(v / args.steps, 3) for k, v in phase_ms.items()}
         if continuous:
-            phases["scheduler"] = dict({k: v // args.steps for k, v in sched.items()}, overlap=overlap,
+            phases["scheduler"] = dict({k: v // args.steps for k, v in sched.items()}, overlap=overlap, admit_cus_per_se=shares,
                                        decode_step_ms_shared=round(phase_ms.get("decode_shared", 0.0) / max(sched["steps_shared"], 1), 4),
-                                       note=f"spans named *_shared ran concurrently on disjoint CU sets (admission {int(32 * args.admit_cus)} CUs, decode {256 - int(32 * args.admit_cus)}): they do not add up to ms_per_step" if overlap else None)
+                                       note=f"spans named *_shared ran concurrently on disjoint CU sets (admission share of the CUs: {args.admit_cus} of 8 per shader engine): they do not add up to ms_per_step" if overlap else None)
         vit_ms, pre_ms = phase_ms["vit"] / per, phase_ms["prefill"] / per
         phases["vit_mfma_frac"] = round(VIT_GFLOP * B / (vit_ms * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)
         phases["prefill_mfma_frac"] = round(PREFILL_GFLOP * B / (pre_ms * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)

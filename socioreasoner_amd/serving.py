@@ -29,11 +29,16 @@ class Request:
 
 class ContinuousBatcher:
     def __init__(self, engine, eos: Sequence[int], pad_id: int, steps_per_poll: int = 8, sampling: Optional[dict] = None,
-                 time_phases: bool = False, overlap: bool = False, admit_cus_per_se: int = 3):
+                 time_phases: bool = False, overlap: bool = False, admit_cus_per_se="auto"):
         """sampling: None = greedy, else {"temperature", "top_k" (1..1024), "top_p", "seed"} shared by all requests.
         time_phases: bracket every ViT / prefill / decode call with events on the launch stream (phase_ms() sums them).
         overlap: admissions are STAGED into spare KV slots (engine.kv_slots > max_batch) on a CU-masked side stream while the running
-        rows keep decoding on the rest of the chip, and committed into rows as they free up (socioreasoner_amd/streams.py)."""
+        rows keep decoding on the rest of the chip, and committed into rows as they free up (socioreasoner_amd/streams.py).
+        admit_cus_per_se: CUs (of 8 per shader engine) of the admission stream, or "auto": chosen per admission so that it ends about
+        when the running rows do -- share = ceil(8 A / (A + D)), A = the group's admission time on the whole chip (rate measured on the
+        first, unshared admission, scaled by the group's patch / token count), D = the running rows' remaining decode time (step time
+        measured on the first chunk); 3 until both are known.  Measured: 448-pixel tiles 2 / 3 / 4 CUs -> 72.3 / 79.3 / 77.1 tiles/s
+        (auto: 3); two-image samples 3 / 4 / 5 -> 59.3 / 66.6 / 64.6 samples/s (auto: 4)."""
         self.engine, self.eos, self.pad_id, self.steps_per_poll = engine, [int(e) for e in eos], int(pad_id), steps_per_poll
         self._ev = [] if time_phases else None
         self.overlap = bool(overlap) and engine.kv_slots > engine.cfg.max_batch
@@ -42,13 +47,23 @@ class ContinuousBatcher:
         self.free_slots = deque(range(engine.kv_slots))
         self._dec_last = None
         self._commit_ev = None
+        self._auto = admit_cus_per_se == "auto"
+        self._share = 3 if self._auto else admit_cus_per_se
+        # calibration of the "auto" share: ms per work unit of an unshared admission, ms per decode step with the chip to itself.  Kept on
+        # the engine, so that the next scheduler on it (one per generate call) starts calibrated
+        self._adm_rate, self._step_ms = getattr(engine, "_sched_cal", (None, None))
+        self._cal_adm = self._cal_step = None      # (start event, end event, units / steps) of a measurement in flight
+        self._cnt_last: Dict[int, int] = {}
         if self.overlap:
             from .streams import overlap_streams
-            self.streams = overlap_streams(engine.device, admit_cus_per_se)
+            self.streams = overlap_streams(engine.device, self._share)
+            c = engine.cfg     # relative cost of a patch (ViT) and of a prompt token (LM prefill): their linear-layer parameter counts
+            self._wp = c.v_depth * (4 * c.v_hidden * c.v_hidden + 3 * c.v_hidden * c.v_inter)
+            self._wt = c.t_layers * (c.t_hidden * (2 * c.t_heads + 2 * c.t_kv_heads) * 128 + 3 * c.t_hidden * c.t_inter)
         self.free = deque(range(engine.cfg.max_batch))
         self.active: Dict[int, Request] = {}
         self.pending: deque = deque()
-        self.stats = {"admitted": 0, "steps": 0, "admissions": 0, "staged_shared": 0, "steps_shared": 0}
+        self.stats = {"admitted": 0, "steps": 0, "admissions": 0, "staged_shared": 0, "steps_shared": 0, "shares": []}
         engine.rows_begin()
         if sampling:
             engine.rows_sampling(float(sampling["temperature"]), int(sampling["top_k"]), float(sampling.get("top_p", 1.0)), int(sampling.get("seed", 0)))
@@ -133,14 +148,41 @@ class ContinuousBatcher:
         self._dec_last = s
         return s
 
+    # measured on MI355X (bench.py --admit-cus 2 / 3 / 4): an admission confined to c of the 8 CUs of every shader engine takes
+    # (8 / c) x _ADM_EFF[c] as long as on the whole chip, a decode step on the other 8 - c CUs _DEC_SLOW[c] as long
+    _ADM_EFF = {2: 0.86, 3: 0.886, 4: 0.913, 5: 0.94}
+    _DEC_SLOW = {2: 1.20, 3: 1.265, 4: 1.36, 5: 1.55}
+
+    def _pick_share(self, a_ms: float, steps_left: float) -> int:
+        """CUs per shader engine for an admission that takes a_ms on the whole chip while the running rows still have steps_left decode
+        steps in front of them: the share with the shortest predicted time until those rows are done AND the admission has landed
+        (decode runs on the small CU set until the poll after the admission ends, on the whole chip afterwards)."""
+        best, best_t = 3, None
+        for c in (2, 3, 4, 5):
+            ta = a_ms * (8.0 / c) * self._ADM_EFF[c]
+            sc = self._step_ms * self._DEC_SLOW[c]
+            shared = -(-(ta / sc) // self.steps_per_poll) * self.steps_per_poll      # steps decoded next to the admission (whole chunks)
+            t = ta if shared >= steps_left else shared * sc + (steps_left - shared) * self._step_ms
+            if best_t is None or t < best_t - 1e-9:
+                best, best_t = c, t
+        return best
+
     def _stage(self):
         grp = self._take_group(min(len(self.free_slots), self.engine.cfg.max_batch))
         if not grp:
             return
         slots = [self.free_slots.popleft() for _ in grp]
+        units = sum(self._wp * sum(t * h * w for t, h, w in r.grids) + self._wt * len(r.ids) for r in grp)
         # with rows running: the admission's half of the chip; with nothing to decode there is nothing to share the chip with
         shared = "_shared" if self.active else ""
         if self.active:
+            if self._auto and self._adm_rate is not None and self._step_ms is not None:
+                left = [max(r.max_new - self._cnt_last.get(row, 0), 1) for row, r in self.active.items()]
+                share = self._pick_share(units * self._adm_rate, sum(left) / len(left))
+                if share != self._share:
+                    from .streams import overlap_streams
+                    self._share, self.streams = share, overlap_streams(self.engine.device, share)
+            self.stats["shares"].append(self._share)
             s = self.streams.admit
             s.wait_stream(torch.cuda.current_stream(self.engine.device))     # the request's images were produced on the caller's stream
             self.stats["staged_shared"] += len(grp)
@@ -148,7 +190,11 @@ class ContinuousBatcher:
                 s.wait_event(self._commit_ev)          # the previous group's last commit reads the engine's admission scratch
         else:
             s = self._use_decode_stream(self.streams.decode_full)
+        cal = self._auto and not shared and self._adm_rate is None and self._cal_adm is None
         with torch.cuda.stream(s):
+            if cal:
+                c0 = torch.cuda.Event(enable_timing=True)
+                c0.record(s)
             t0 = self._mark()
             emb = None
             ims = [im for r in grp for im in r.images]
@@ -159,8 +205,10 @@ class ContinuousBatcher:
             self.engine.admit_stage(slots, [r.ids for r in grp], [r.pos3 for r in grp], [r.max_new for r in grp], emb)
             self._span("vit" + shared, t0, t1)
             self._span("prefill" + shared, t1, self._mark())
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=cal)
             ev.record(s)
+            if cal:
+                self._cal_adm = (c0, ev, units)
         self.staged = (grp, slots, ev, emb)            # emb kept alive until the side stream is done with it
         self.stats["admissions"] += 1
 
@@ -178,6 +226,7 @@ class ContinuousBatcher:
         for row, slot, r in zip(rows, slots[:k], grp[:k]):
             self.active[row] = r
             self.row_slot[row] = slot
+            self._cnt_last[row] = 0
         self.stats["admitted"] += k
         del grp[:k], slots[:k]
         if not grp:
@@ -195,16 +244,36 @@ class ContinuousBatcher:
             return
         busy = self.staged is not None and not self.staged[2].query()
         s = self._use_decode_stream(self.streams.decode if busy else self.streams.decode_full)
+        # (step-time calibration: a chunk with the chip to itself -- no admission in flight and none about to be staged under it)
+        cal = (self._auto and not busy and not (self.staged is None and self.pending and self.free_slots)
+               and self._step_ms is None and self._cal_step is None)
         with torch.cuda.stream(s):
+            if cal:
+                c0 = torch.cuda.Event(enable_timing=True)
+                c0.record(s)
             t0 = self._mark()
             self.engine.rows_step(self.steps_per_poll, self.eos, self.pad_id)
             self._span("decode_shared" if busy else "decode", t0, self._mark())
+            if cal:
+                c1 = torch.cuda.Event(enable_timing=True)
+                c1.record(s)
+                self._cal_step = (c0, c1, self.steps_per_poll)
         self.stats["steps"] += self.steps_per_poll
         self.stats["steps_shared"] += self.steps_per_poll if busy else 0
         if self.staged is None and self.pending and self.free_slots:
             self._stage()                              # the host side of the next admission is prepared while the chunk above runs
         with torch.cuda.stream(s):
             fin, cnt = self.engine.rows_poll()
+            if self._auto:          # (the poll synchronised the decode stream: finished measurements can be read without waiting)
+                self._cnt_last = {row: int(cnt[row]) for row in self.active}
+                if self._cal_step is not None and self._cal_step[1].query():
+                    self._step_ms = self._cal_step[0].elapsed_time(self._cal_step[1]) / self._cal_step[2]
+                    self._cal_step = None
+                    self.engine._sched_cal = (self._adm_rate, self._step_ms)
+                if self._cal_adm is not None and self._cal_adm[1].query():
+                    self._adm_rate = self._cal_adm[0].elapsed_time(self._cal_adm[1]) / max(self._cal_adm[2], 1)
+                    self._cal_adm = None
+                    self.engine._sched_cal = (self._adm_rate, self._step_ms)
             for row in [r for r in self.active if fin[r]]:
                 req = self.active.pop(row)
                 toks = self.engine.row_tokens(row, int(cnt[row])).cpu().tolist()
