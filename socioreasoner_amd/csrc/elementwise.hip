@@ -508,23 +508,25 @@ int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, lon
     return 0;
 }
 
-int launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int H, float eps, int out_tiled) {
+int launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int H, float eps, int out_tiled, int per_wave) {
     if (rows <= 0) return 0;
     if (H % 8 != 0 || H > 64 * 8 * 12) return -22;
     if (out_tiled && !(rows <= 64 && H <= 2048 && H % 64 == 0)) return -22;
     dim3 g(cdiv(rows, 4)), b(256);
-    if (rows <= 64 && H <= 2048) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps, out_tiled);
+    if (out_tiled && per_wave) return -22;
+    if (!per_wave && rows <= 64 && H <= 2048) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps, out_tiled);
     else if (H <= 2048) hipLaunchKernelGGL((k_rmsnorm<4>), g, b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps);
     else hipLaunchKernelGGL((k_rmsnorm<12>), g, b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps);
     SR_CHECK_LAUNCH();
     return 0;
 }
 int launch_resid_rmsnorm(hipStream_t s, bf16_t* x, const float* part, int ksplit, const bf16_t* w, bf16_t* out, int rows,
-                         int H, float eps, int out_tiled) {
+                         int H, float eps, int out_tiled, int per_wave) {
     if (rows <= 0) return 0;
     if (H % 8 != 0 || H > 2048) return -22;
     if (out_tiled && !(rows <= 64 && ksplit <= 4 && H % 64 == 0)) return -22;
-    if (rows <= 64 && ksplit <= 4) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), dim3(256), 0, s, x, (const bf16_t*)x, part, ksplit, w, out, rows, H, eps, out_tiled);
+    if (out_tiled && per_wave) return -22;
+    if (!per_wave && rows <= 64 && ksplit <= 4) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), dim3(256), 0, s, x, (const bf16_t*)x, part, ksplit, w, out, rows, H, eps, out_tiled);
     else hipLaunchKernelGGL((k_rmsnorm<4>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, (const bf16_t*)x, part, ksplit, w, out, rows, H, eps);
     SR_CHECK_LAUNCH();
     return 0;

@@ -318,7 +318,7 @@ void carve(sr_engine* e) {
     e->d_adm = ar.take<int>(5 * 32);
     e->d_adm_slots = ar.take<int>(32);
     e->d_xadm = ar.take<bf16_t>(B * H);           // admission scratch of its own: an admission may run on another stream while rows decode
-    e->d_xadm_n = ar.take<bf16_t>(((B + 15) / 16 * 16) * H);
+    e->d_xadm_n = ar.take<bf16_t>((size_t)32 * H);      // (the admission's 32-row LM-head GEMV addresses two 16-row groups whatever the batch)
     e->d_sampled = ar.take<long long>(32);
     e->d_adm_pick = ar.take<long long>(32);
     e->seen_words = (c.t_vocab + 31) / 32;
@@ -837,7 +837,7 @@ int sr_vit_forward(sr_engine* e, const void* pixels, int pixels_dtype, const int
     const float scale = (float)(1.0 / sqrt((double)hd));
     for (int blk = 0; blk < c.v_depth; ++blk) {
         const VitBlockW& w = e->vb[blk];
-        SR_TRY(launch_rmsnorm(s, e->v_x, w.norm1, e->v_xn, N, C, 1e-6f));
+        SR_TRY(launch_rmsnorm(s, e->v_x, w.norm1, e->v_xn, N, C, 1e-6f, 0, 1));
         // qkv Linear; the 2-D rotary embedding and the V transpose ride in the GEMM epilogue when the 256-tile kernel takes the shape
         // (large batches; needs the paired q / k channel order the loader established), else they are the two launches of round 1
         {
@@ -853,12 +853,12 @@ int sr_vit_forward(sr_engine* e, const void* pixels, int pixels_dtype, const int
                    c.v_heads, 1, scale, 0};
         SR_TRY(launch_attn_prefill(s, a, hd));
         if (int rc = gemm(e, s, e->v_attn, C, w.proj_w, N, C, C, e->v_x, C, w.proj_b, e->v_x, nullptr, EPI_RESID)) return rc;
-        SR_TRY(launch_rmsnorm(s, e->v_x, w.norm2, e->v_xn, N, C, 1e-6f));
+        SR_TRY(launch_rmsnorm(s, e->v_x, w.norm2, e->v_xn, N, C, 1e-6f, 0, 1));
         if (int rc = gemm(e, s, e->v_xn, C, w.gu_w, N, 2 * e->v_inter_pad, C, e->v_act, e->v_inter_pad, w.gu_b, nullptr, nullptr, EPI_SWIGLU)) return rc;
         if (int rc = gemm(e, s, e->v_act, e->v_inter_pad, w.down_w, N, C, e->v_inter_pad, e->v_x, C, w.down_b, e->v_x, nullptr, EPI_RESID)) return rc;
     }
     // merger (hf:137-150) with the inverse window permutation fused into the last store (hf:463-465)
-    SR_TRY(launch_rmsnorm(s, e->v_x, e->ln_q, e->v_xn, N, C, 1e-6f));
+    SR_TRY(launch_rmsnorm(s, e->v_x, e->ln_q, e->v_xn, N, C, 1e-6f, 0, 1));
     const int T = N / (c.v_merge * c.v_merge);
     if (int rc = gemm(e, s, e->v_xn, e->v_mh, e->fc1_w, T, e->v_mh, e->v_mh, e->v_m1, e->v_mh, e->fc1_b, nullptr, nullptr, EPI_GELU)) return rc;
     if (int rc = gemm(e, s, e->v_m1, e->v_mh, e->fc2_w, T, c.v_out_hidden, e->v_mh, out, c.v_out_hidden, e->fc2_b, nullptr, e->v_rowmap_merge, EPI_STORE)) return rc;
@@ -1012,8 +1012,8 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
         const LmLayerW& w = e->ll[l];
         bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
         bf16_t* vc = e->vtcache + (size_t)l * e->kv_layer_elems;
-        if (pending) SR_TRY(launch_resid_rmsnorm(s, e->t_x, e->t_slabs, SPLITK_KS, w.ln1, e->t_xn, n_tok, H, c.t_rms_eps));
-        else SR_TRY(launch_rmsnorm(s, e->t_x, w.ln1, e->t_xn, n_tok, H, c.t_rms_eps));
+        if (pending) SR_TRY(launch_resid_rmsnorm(s, e->t_x, e->t_slabs, SPLITK_KS, w.ln1, e->t_xn, n_tok, H, c.t_rms_eps, 0, 1));
+        else SR_TRY(launch_rmsnorm(s, e->t_x, w.ln1, e->t_xn, n_tok, H, c.t_rms_eps, 0, 1));
         // q/k/v Linear; mRoPE and the KV-cache write ride in the GEMM epilogue when the 256-tile kernel takes the shape (large batches),
         // otherwise they are the separate launch of round 1 (bit-identical results either way)
         const QkvRope qr{e->t_pos3, e->t_slot, e->t_idx, e->rope_cos, e->rope_sin, kc, vc, n_tok, c.t_heads, c.t_kv_heads,
@@ -1030,10 +1030,10 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
         SR_TRY(launch_attn_prefill(s, a, 128));
         if (splitk) {
             if (int rc = lm_gemm(e, s, e->t_attn, QD, w.o_w, w.o_w8, w.o_s, n_tok, H, QD, e->t_slabs, H, nullptr, nullptr, EPI_F32, nullptr, nullptr, SPLITK_KS)) return rc;
-            SR_TRY(launch_resid_rmsnorm(s, e->t_x, e->t_slabs, SPLITK_KS, w.ln2, e->t_xn, n_tok, H, c.t_rms_eps));
+            SR_TRY(launch_resid_rmsnorm(s, e->t_x, e->t_slabs, SPLITK_KS, w.ln2, e->t_xn, n_tok, H, c.t_rms_eps, 0, 1));
         } else {
             if (int rc = lm_gemm(e, s, e->t_attn, QD, w.o_w, w.o_w8, w.o_s, n_tok, H, QD, e->t_x, H, nullptr, e->t_x, EPI_RESID)) return rc;
-            SR_TRY(launch_rmsnorm(s, e->t_x, w.ln2, e->t_xn, n_tok, H, c.t_rms_eps));
+            SR_TRY(launch_rmsnorm(s, e->t_x, w.ln2, e->t_xn, n_tok, H, c.t_rms_eps, 0, 1));
         }
         if (int rc = lm_gemm(e, s, e->t_xn, H, w.gu_w, w.gu_w8, w.gu_s, n_tok, 2 * e->t_inter_pad, H, e->t_act, e->t_inter_pad, nullptr, nullptr, EPI_SWIGLU)) return rc;
         if (splitk) {
@@ -1043,9 +1043,9 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
     }
     // last position of every sequence -> final norm -> tied LM head (hf:1386-1387) -> greedy token
     // (split-K: the last down-projection's slabs still have to reach t_x; the norm output is only used by the all-positions path)
-    if (pending) SR_TRY(launch_resid_rmsnorm(s, e->t_x, e->t_slabs, SPLITK_KS, e->final_norm, e->t_xn, n_tok, H, c.t_rms_eps));
+    if (pending) SR_TRY(launch_resid_rmsnorm(s, e->t_x, e->t_slabs, SPLITK_KS, e->final_norm, e->t_xn, n_tok, H, c.t_rms_eps, 0, 1));
     if (all_logits_out) {       // every position: final norm over all rows, tied LM head as an MFMA GEMM with float32 output
-        if (!pending) SR_TRY(launch_rmsnorm(s, e->t_x, e->final_norm, e->t_xn, n_tok, H, c.t_rms_eps));
+        if (!pending) SR_TRY(launch_rmsnorm(s, e->t_x, e->final_norm, e->t_xn, n_tok, H, c.t_rms_eps, 0, 1));
         if (int rc = gemm(e, s, e->t_xn, H, e->embed, n_tok, c.t_vocab, H, all_logits_out, c.t_vocab, nullptr, nullptr, nullptr, EPI_F32, 1)) return rc;
     }
     // (an admission keeps to scratch of its own -- d_xadm / d_xadm_n, the *_adm logits and partials -- because it may run on another
@@ -1061,16 +1061,15 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
         e->rows_mode = false;
         return 0;
     }
-    // admission: final norm + LM head into the admission scratch (B <= 4 fuses the norm), greedy first token, then install the rows
+    // admission: final norm + LM head into the admission scratch, greedy first token, then install the rows.  ONE kernel path whatever the
+    // number of sequences admitted together (block-per-row norm, 32-row MFMA GEMV -- what a static batch of more than 16 runs), so that a
+    // request's first token does not depend on how the scheduler grouped it
     {
         GemvArgs g = gv(xl, H, e->embed, B, c.t_vocab, H, e->d_logits_adm, c.t_vocab);
         g.amax_val = e->d_amax_val_adm; g.amax_idx = e->d_amax_idx_adm;
-        if (fused_norms(e, B)) { g.norm_w = e->final_norm; g.eps = c.t_rms_eps; }
-        else {
-            const int xt = x_tiled_ok(e) ? 1 : 0;
-            SR_TRY(launch_rmsnorm(s, xl, e->final_norm, e->d_xadm_n, B, H, c.t_rms_eps, xt));
-            g.x = e->d_xadm_n; g.x_tiled = xt;
-        }
+        const int xt = x_tiled_ok(e) ? 1 : 0;
+        SR_TRY(launch_rmsnorm(s, xl, e->final_norm, e->d_xadm_n, B, H, c.t_rms_eps, xt));
+        g.x = e->d_xadm_n; g.x_tiled = xt; g.force32 = 1;
         SR_TRY(launch_gemv(s, g, GV_F32));
     }
     if (logits_out) SR_TRY((int)hipMemcpyAsync(logits_out, e->d_logits_adm, (size_t)B * c.t_vocab * 4, hipMemcpyDeviceToDevice, s));

@@ -612,6 +612,7 @@ int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
 bool use_32(const GemvArgs& a, int mode) {
     static const char* env = getenv("SR_GEMV32");               // tuning hook (tools/bench_gemv.py): 0 = never, 2 = always
     const int force = env ? atoi(env) : 1;
+    if (a.force32 && a.N % 32 == 0 && !a.norm_w) return true;
     if (force == 0 || a.M <= 16 || a.N % 32 != 0 || a.norm_w) return false;
     return force == 2 || mode == GV_F32 || (mode == GV_PARTIAL && a.ksplit >= 4);
 }

@@ -80,6 +80,7 @@ struct GemvArgs {
     int x_tiled;                            // x is stored fragment-ordered (tiled16x64 of a [ceil16(M), K] matrix, common.h): a wave's
                                             // x load is 1 KB contiguous instead of 16 rows x 64 B (batches > 4, no fused norm)
     int out_tiled;                          // SWIGLU: write the activation fragment-ordered (it is the next GEMV's x)
+    int force32;                            // always the 32-row MFMA variant (whatever M): a row's result then does not depend on how many rows share the launch
 };
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode);
 int gemv_f32_blocks(int N, int M, int K, int has_norm);
@@ -125,10 +126,12 @@ int attn_decode_prepare(int ctx_max, int group);
 
 // ------------------------------------------------------------------ elementwise.hip
 // out_tiled (decode rows only): `out` is written fragment-ordered (tiled16x64 of [ceil16(rows), H]) for the consuming GEMV
-int launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int H, float eps, int out_tiled = 0);
+// per_wave: always the wave-per-row kernel.  The block-per-row kernel (rows <= 64: decode) sums the squares in another order, and a
+// prefill must give a prompt the same bits whether 47 or 4700 rows are normalised with it.
+int launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int H, float eps, int out_tiled = 0, int per_wave = 0);
 // h = r(x + r(sum_ks part[ks] + bias)) written back to x; out = rmsnorm(h) * w.   part may be null (plain norm).
 int launch_resid_rmsnorm(hipStream_t s, bf16_t* x, const float* part, int ksplit, const bf16_t* w, bf16_t* out,
-                         int rows, int H, float eps, int out_tiled = 0);
+                         int rows, int H, float eps, int out_tiled = 0, int per_wave = 0);
 int launch_vit_rope(hipStream_t s, bf16_t* qkv, int n_rows, int n_heads, int head_dim, const float* cos_t,
                     const float* sin_t, bf16_t* vt, int vt_stride, int paired = 0);
 // prefill: rope q,k in place in qkv [T, (Hq+2Hkv)*128]; write K / V^T into the cache at (slot, pos_in_seq)

@@ -329,6 +329,61 @@ def test_small_prefill_split_k_residual_gemms(monkeypatch):
     e.close()
 
 
+def test_request_tokens_do_not_depend_on_admission_grouping():
+    """A request's tokens must not depend on how the scheduler grouped it: admitted alone or with others, in one stream or staged under
+    decode.  Found by tools/soak_overlap.py: a 47-token text prompt admitted ALONE got other tokens from its 9th token on than the same
+    prompt admitted next to a second one -- prefills of <= 64 rows took the block-per-row RMSNorm (another summation order: one bf16 ulp
+    in token 44 at layer 7, a near-tie eight steps later), and the admission's LM head switched kernels with the group size.  Now: prefill
+    norms always wave-per-row, admission LM head always block-per-row norm + 32-row MFMA GEMV.  Checked: lone vs paired admission bit for
+    bit, and random request mixes (seeds that include the failing one) through the overlapped and the one-stream scheduler."""
+    import numpy as np
+    from socioreasoner_amd import hostops, synthetic
+    from socioreasoner_amd.config import geometry_3b
+    from socioreasoner_amd.engine import Engine
+    from socioreasoner_amd.serving import ContinuousBatcher, Request
+    geom = geometry_3b()
+    B, G = 32, 40
+    e = Engine(geom, max_patches=1024 * B, max_prefill_tokens=448 * B, max_batch=B, max_ctx=512, max_new_tokens=G, kv_slots=56)
+    e.load_synthetic_weights(seed=0)
+    grid = (1, 32, 32)
+    imgs = [torch.from_numpy(synthetic.tile_pixels(i)).cuda() for i in range(8)]
+
+    def mix(seed):
+        rng = np.random.default_rng(seed)
+        n = int(rng.integers(40, 90))
+        spec = []
+        for _ in range(n):
+            if rng.random() < 0.35:
+                x = rng.integers(1000, 60000, size=int(rng.integers(8, 120))).astype(np.int64)
+                p, _ = hostops.get_rope_index(torch.from_numpy(x)[None], None, None)
+                spec.append((x, p[:, 0].numpy(), int(rng.integers(1, 12)), None))
+            else:
+                x = synthetic.tile_prompt(geom, int(rng.integers(0, 1000)), grid)[: 448 - int(rng.integers(0, 40))]
+                p, _ = hostops.get_rope_index(torch.from_numpy(x)[None], [grid], None)
+                spec.append((x, p[:, 0].numpy(), int(rng.integers(2, G + 1)), int(rng.integers(0, 8))))
+        return spec, int(rng.choice([1, 2, 4, 8]))
+    spec, _ = mix(108)
+    x, p, m, _ = spec[39]                                   # the 47-token prompt of the original failure
+    assert len(x) == 47
+
+    def direct(rows):
+        e.rows_begin()
+        e.admit(rows, [x] * len(rows), [p] * len(rows), [m] * len(rows), None)
+        e.rows_step(m, [], 0)
+        _, cnt = e.rows_poll()
+        return [e.row_tokens(r, int(cnt[r])).cpu().tolist() for r in rows]
+    alone, pair, five = direct([7]), direct([7, 9]), direct([0, 1, 2, 3, 4])
+    assert alone[0] == pair[0] == pair[1] and all(t == alone[0] for t in five)
+    for seed in (108, 103, 111):
+        spec, spp = mix(seed)
+        mk = lambda: [Request(ids=a, pos3=b, max_new=c, images=[imgs[k]] if k is not None else [], grids=[grid] if k is not None else [])
+                      for a, b, c, k in spec]
+        o = ContinuousBatcher(e, eos=[], pad_id=0, steps_per_poll=spp, overlap=True).run(mk())
+        r = ContinuousBatcher(e, eos=[], pad_id=0, steps_per_poll=4).run(mk())
+        assert o == r, (seed, [i for i in range(len(o)) if o[i] != r[i]])
+    e.close()
+
+
 # ------------------------------------------------------------------------------------------------ RCCL on one rank
 def test_rccl_exchange_path_single_rank(tmp_path):
     """The test box has one GPU, so the N > 1 RCCL run belongs to the driver's scaling tier; what CAN run here is the same
