@@ -25,6 +25,7 @@
 // at unchanged occupancy (one block for the 8 query heads of a kv head, <= 64 registers per wave) or asynchronous multi-stage staging.
 #include "kernels.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -178,6 +179,230 @@ __global__ __launch_bounds__(256) void k_attn_prefill(AttnArgs p) {
     }
     if (q_valid) {
         bf16_t* optr = p.out + (size_t)(wk.q_row0 + q_local) * p.out_stride + h * HD + fg * 4;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            uint2 v = {pack2(oacc[dt][0], oacc[dt][1]), pack2(oacc[dt][2], oacc[dt][3])};
+            *reinterpret_cast<uint2*>(optr + dt * 16) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- prefill, round 3
+// k_attn_prefill2: the SAME per-wave arithmetic as k_attn_prefill (a wave = 16 queries of one head against 64-key tiles, two passes, same
+// MFMA order, same softmax sums: results are bit-identical, tests/test_gpu_round3.py), but
+//   * a block is 8 waves that share every staged K / V^T tile: QW query sub-tiles x 8 / QW heads of ONE kv head -- 32 queries x 4 of
+//     the 8 query heads of a kv head for the LM (causal, GQA), 128 queries of one head for the ViT's full-attention blocks (MHA) -- so a
+//     staged tile serves 128 (query, head) rows instead of 64 (PMC round 2: 688 MB of staging per LM layer for 15 MB of unique K / V,
+//     waves parked 62 % of their cycles, MFMA pipe 13 % busy), two blocks per CU (<= 128 registers, <= 80 KB of LDS);
+//   * tiles arrive by LDS-DMA (global_load_lds, 16 B per lane, no VGPR round trip) into an NS-deep ring; pass 1 and pass 2 are ONE
+//     sequence of 2 x n_tiles steps, so the pipeline never drains between the passes; per step one counted `s_waitcnt vmcnt` + one raw
+//     `s_barrier` (the structure of gemm.hip's small-M ring): the loads of step u + NS - 1 are issued right after the barrier that
+//     proves step u - 1's buffer free, and stay in flight across barriers while step u is multiplied.  The DMA is issued from inline
+//     asm: hipcc (ROCm 7.2) otherwise puts an `s_waitcnt vmcnt(0)` in front of the first V^T fragment read of every step (its LDS-DMA
+//     alias rule cannot tell the ring's buffers apart), which drains the ring it is meant to keep full.  The waits are therefore
+//     counted by hand: 2 DMA instructions per wave and pass-1 step (K), 4 per pass-2 step (K + V^T), nothing else in the loop
+//     touches vmcnt (no spills: checked with -Rpass-analysis=kernel-resource-usage);
+//   * LDS rows keep a power-of-two pitch and the 16-byte chunk index is XOR-swizzled on the SOURCE side (LDS-DMA writes linearly):
+//     K rows 256 B, chunk ^ (row & 15) -> conflict-free ds_read_b128 fragments; V^T rows 128 B, chunk ^ ((row >> 1) & 7) -> conflict-free
+//     ds_read_b64 pairs.  head_dim 80 uses the same 256-B K pitch; its pad chunks (d 80..95 of the 96-wide MFMA k range) are zeroed
+//     once and never written again (masked-off DMA lanes);
+//   * blocks are dealt to XCDs in contiguous runs of (work item, head group, sub-tile), so the K / V of a sequence stay in ONE XCD's L2.
+// Keys past the end of a sequence: K rows are clamped (their scores are masked); V^T columns are read as they are -- P is exactly 0
+// there, and the caller guarantees FINITE contents (AttnArgs.v2_ok: the engine zeroes the KV cache and the ViT's V^T buffer when it is
+// created, and only ever stores finite bf16 values into them).
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// one LDS-DMA instruction: 64 lanes x 16 B from gbase + voff (bytes, per lane) to LDS [lds_dst, lds_dst + 1 KB), invisible to hipcc's
+// waitcnt bookkeeping (MI355X guide 5.7: M0 is written in the statement that uses it and restored)
+__device__ __forceinline__ void dma16(const void* gbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void wait_vmcnt(int n) {      // immediate operand: one case per count
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
+template <int HD, bool CAUSAL, int QW, int NS>
+__global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_units, int Y, int subs) {
+    using C = PrefillCfg<HD>;
+    constexpr int NH = 8 / QW;                  // heads per block
+    constexpr int QTB = QW * 16;                // queries per block
+    constexpr int K_BYTES = KT * 256, V_BYTES = HD * 128, ST_BYTES = K_BYTES + V_BYTES;
+    constexpr int VI = HD * 8 / 64;             // 1-KB LDS-DMA pieces per V^T tile (16 at hd 128, 10 at hd 80)
+    static_assert(NS >= 2 && NS <= 4 && VI > 8 && VI <= 16, "ring depth / V^T pieces");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+
+    // block -> (work item, head group, query sub-tile); XCD x (blocks x, x + 8, ...) takes a contiguous run of units
+    int unit;
+    {
+        const int flat = blockIdx.x, q8 = n_units / 8, r8 = n_units % 8, xcd = flat % 8, idx = flat / 8;
+        unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const AttnWork wk0 = p.work[unit / (Y * subs)];
+    const int h0 = ((unit / subs) % Y) * NH, sub = unit % subs;
+    const int q_off = wk0.q_off + sub * QTB;
+    if (q_off >= wk0.seq_len) return;           // the work item's last sub-tiles may be empty
+    const int q_row0 = wk0.q_row0 + sub * QTB, seq_len = wk0.seq_len;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = h0 + wave / QW, kvh = h0 / p.group;
+
+    const int q_local = (wave % QW) * 16 + fr;
+    const int qpos = q_off + q_local;
+    const bool q_valid = qpos < seq_len;
+    const int q_rows_valid = min(QTB, seq_len - q_off);
+    const bf16_t* qptr = p.q + (size_t)(q_row0 + min(q_local, q_rows_valid - 1)) * p.q_stride + h * HD;
+    bf16x8 qf[C::KS];
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+        const int d = kk * 32 + fg * 8;
+        if (d < HD) qf[kk] = *reinterpret_cast<const bf16x8*>(qptr + d);
+        else qf[kk] = __builtin_bit_cast(bf16x8, uint4{0, 0, 0, 0});
+    }
+
+    // hipcc must see the Q fragments ARRIVE before the tile loop: it does not count the asm DMA below, so a wait for these loads placed
+    // inside the loop (`vmcnt(0)` at their first use, repeated on every iteration) would drain the ring each step
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) asm volatile("" : "+v"(qf[kk]));
+
+    const bf16_t* kbase = p.k + (size_t)wk0.k_row0 * p.k_stride + (size_t)kvh * p.k_head_stride;
+    const bf16_t* vbase = p.vt + wk0.vt_off + (size_t)kvh * p.vt_head_stride;
+    const int kv_end = CAUSAL ? min(seq_len, q_off + QTB) : seq_len;
+    const int nt = (kv_end + KT - 1) / KT, total = 2 * nt;
+
+    // ---- LDS-DMA sources of this lane: wave-uniform base (SGPRs) + a 32-bit byte offset per lane.
+    // K pieces wave and wave + 8: LDS 16-byte position piece * 64 + lane = (row, physical chunk); the lane fetches logical chunk kc.
+    const int krow = wave * 4 + (lane >> 4), kc = ((lane & 15) ^ (krow & 15)) * 8;     // second piece: row + 32, same chunk (32 % 16 == 0)
+    const bool k_on = kc < HD;
+    // V^T pieces wave and wave + 8 (beyond VI: pieces 0.. once more -- same bytes to the same place, keeps every wave's DMA count equal)
+    const int vp1 = wave + 8 < VI ? wave + 8 : wave + 8 - VI;
+    const int vrow0 = wave * 8 + (lane >> 3), vrow1 = vp1 * 8 + (lane >> 3);
+    const unsigned voff0 = (unsigned)(vrow0 * p.vt_stride + ((lane & 7) ^ ((vrow0 >> 1) & 7)) * 8) * 2u;
+    const unsigned voff1 = (unsigned)(vrow1 * p.vt_stride + ((lane & 7) ^ ((vrow1 >> 1) & 7)) * 8) * 2u;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem2;
+
+    if constexpr (HD != 128) {          // pad chunks of the K rows: zero once (whole K regions), before any DMA lands
+        for (int i = tid; i < NS * K_BYTES / 16; i += 512)
+            *reinterpret_cast<uint4*>(smem2 + (i / (K_BYTES / 16)) * ST_BYTES + (i % (K_BYTES / 16)) * 16) = uint4{0, 0, 0, 0};
+        __syncthreads();
+    }
+    auto issue = [&](int step, int buf) {
+        const bool pass2 = step >= nt;
+        const int kv0 = (pass2 ? step - nt : step) * KT;
+        const unsigned st = lds0 + buf * ST_BYTES;
+        const unsigned ko0 = (unsigned)(min(kv0 + krow, seq_len - 1) * p.k_stride + kc) * 2u;
+        const unsigned ko1 = (unsigned)(min(kv0 + krow + 32, seq_len - 1) * p.k_stride + kc) * 2u;
+        if (k_on) {
+            dma16(kbase, ko0, st + wave * 1024);
+            dma16(kbase, ko1, st + (wave + 8) * 1024);
+        }
+        if (pass2) {
+            dma16(vbase, voff0 + (unsigned)kv0 * 2u, st + K_BYTES + wave * 1024);
+            dma16(vbase, voff1 + (unsigned)kv0 * 2u, st + K_BYTES + vp1 * 1024);
+        }
+    };
+
+    // scores of 16 keys of a staged tile: s[r] = key kv0 + t*16 + fg*4 + r against query fr of this wave (as k_attn_prefill)
+    auto scores16 = [&](const unsigned char* ks, int kv0, int t, float (&s)[4]) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < C::KS; ++kk) {
+            bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + (t * 16 + fr) * 256 + (((kk * 4 + fg) ^ fr) << 4));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kidx = kv0 + t * 16 + fg * 4 + r;
+            const bool ok = kidx < seq_len && (!CAUSAL || kidx <= qpos);
+            const float v = rbf(rbf(acc[r]) * p.scale);
+            s[r] = ok ? v : -INFINITY;
+        }
+    };
+
+    float m = -INFINITY, l = 0.f, inv_l = 0.f;
+    f32x4 oacc[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int j = 0; j < NS - 1; ++j)
+        if (j < total) issue(j, j);
+    int buf = 0;
+    for (int u = 0; u < total; ++u) {
+        // DMA instructions of the steps issued after step u (u + 1 .. u + NS - 2): 2 per pass-1 step, 4 per pass-2 step
+        int later = 0;
+#pragma unroll
+        for (int j = 1; j <= NS - 2; ++j)
+            if (u + j < total) later += (u + j >= nt) ? 4 : 2;
+        wait_vmcnt(later);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + NS - 1 < total) issue(u + NS - 1, buf == 0 ? NS - 1 : buf - 1);     // the buffer step u - 1 was computed from
+        const unsigned char* ks = smem2 + buf * ST_BYTES;
+        const unsigned char* vs = ks + K_BYTES;
+        if (u < nt) {
+            // ---------------- pass 1: row max m and sum l = sum exp(s - m)
+            const int kv0 = u * KT;
+            float s[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) scores16(ks, kv0, t, s[t]);
+            float tm = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tm = fmaxf(tm, s[t][r]);
+            tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+            tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+            const float mn = fmaxf(m, tm);
+            float ts = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ts += __expf(s[t][r] - mn);
+            ts += __shfl_xor(ts, 16, 64);
+            ts += __shfl_xor(ts, 32, 64);
+            l = l * __expf(m - mn) + ts;
+            m = mn;
+            if (u == nt - 1) inv_l = 1.0f / l;
+        } else {
+            // ---------------- pass 2: P = bf16(exp(s - m) / l);  O^T += V^T . P^T   (32 keys at a time: fewer live registers)
+            const int kv0 = (u - nt) * KT;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float s0[4], s1[4];
+                scores16(ks, kv0, 2 * kb, s0);
+                scores16(ks, kv0, 2 * kb + 1, s1);
+                uint4 pv;
+                pv.x = pack2(__expf(s0[0] - m) * inv_l, __expf(s0[1] - m) * inv_l);
+                pv.y = pack2(__expf(s0[2] - m) * inv_l, __expf(s0[3] - m) * inv_l);
+                pv.z = pack2(__expf(s1[0] - m) * inv_l, __expf(s1[1] - m) * inv_l);
+                pv.w = pack2(__expf(s1[2] - m) * inv_l, __expf(s1[3] - m) * inv_l);
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pv);
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt) {
+                    const int d = dt * 16 + fr;
+                    const unsigned char* vr = vs + d * 128 + (fg & 1) * 8;
+                    const int sw = (d >> 1) & 7, c0 = kb * 4 + (fg >> 1);
+                    uint2 v0 = *reinterpret_cast<const uint2*>(vr + ((c0 ^ sw) << 4));          // keys kb*32 + fg*4 .. +3
+                    uint2 v1 = *reinterpret_cast<const uint2*>(vr + (((c0 + 2) ^ sw) << 4));    // keys kb*32 + 16 + fg*4 .. +3
+                    const bf16x8 vf = __builtin_bit_cast(bf16x8, uint4{v0.x, v0.y, v1.x, v1.y});
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS reads are done before it can reach the next barrier
+        __builtin_amdgcn_sched_barrier(0);
+        buf = buf + 1 == NS ? 0 : buf + 1;
+    }
+    if (q_valid) {
+        bf16_t* optr = p.out + (size_t)(q_row0 + q_local) * p.out_stride + h * HD + fg * 4;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
             uint2 v = {pack2(oacc[dt][0], oacc[dt][1]), pack2(oacc[dt][2], oacc[dt][3])};
@@ -465,8 +690,41 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
 
 }  // namespace
 
+template <int HD, bool CAUSAL, int QW, int NS>
+static int launch_prefill2(hipStream_t s, const AttnArgs& a) {
+    constexpr int NH = 8 / QW, QTB = QW * 16;
+    constexpr int smem = NS * (KT * 256 + HD * 128);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_prefill2<HD, CAUSAL, QW, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (r != hipSuccess) return (int)r;
+        attr = true;
+    }
+    const int Y = a.n_heads / NH, subs = a.q_tile / QTB, n_units = a.n_work * Y * subs;
+    hipLaunchKernelGGL((k_attn_prefill2<HD, CAUSAL, QW, NS>), dim3(n_units), dim3(512), smem, s, a, n_units, Y, subs);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+
+// which kernel takes the launch: 2 = k_attn_prefill2 (8-wave blocks sharing LDS-DMA-staged tiles; needs a.v2_ok from the caller:
+// 16-byte aligned V^T key runs with finite contents, work items cut at a.q_tile queries), 1 = k_attn_prefill.  SR_ATTN2=0 forces the
+// round-2 kernel (read at every call: the bit-identity tests flip it).
+int attn_prefill_variant(const AttnArgs& a, int head_dim) {
+    const char* env = getenv("SR_ATTN2");
+    if (env && atoi(env) == 0) return 1;
+    if (!a.v2_ok) return 1;
+    if (head_dim == 128 && a.causal && a.q_tile == 64 && a.group % 4 == 0 && a.n_heads % 4 == 0) return 2;
+    if (head_dim == 80 && !a.causal && a.q_tile == 128 && a.group == 1) return 2;
+    return 1;
+}
+
 int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim) {
     if (a.n_work <= 0) return 0;
+    if (attn_prefill_variant(a, head_dim) == 2) {
+        if (head_dim == 128) return launch_prefill2<128, true, 2, 2>(s, a);       // 32 queries x 4 heads, 2 x 32 KB ring
+        return launch_prefill2<80, false, 8, 3>(s, a);                            // 128 queries x 1 head, 3 x 26 KB ring
+    }
+    if (a.q_tile != 0 && a.q_tile != 64) return -22;           // k_attn_prefill walks 64-query work items
     dim3 grid(a.n_work, a.n_heads), block(256);
     if (head_dim == 80 && !a.causal) hipLaunchKernelGGL((k_attn_prefill<80, false>), grid, block, 0, s, a);
     else if (head_dim == 128 && a.causal) hipLaunchKernelGGL((k_attn_prefill<128, true>), grid, block, 0, s, a);

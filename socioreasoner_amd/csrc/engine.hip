@@ -92,7 +92,8 @@ struct sr_engine {
     bool v_paired = false;       // ViT q / k channels stored in the paired order (head_dim / 2 % 8 == 0): see vit_qk_perm
     float *v_cos, *v_sin;
     int *v_rowmap_embed, *v_rowmap_merge;
-    AttnWork *v_work_win, *v_work_full;
+    AttnWork *v_work_win, *v_work_full, *v_work_full128;     // full attention: 64-query items (k_attn_prefill) and 128-query items (k_attn_prefill2)
+    int v_nwork_full128; bool v_full_aligned;
     int v_nwork_win = 0, v_nwork_full = 0;
     std::vector<int64_t> v_grid_cached;
     // ---- LM activations
@@ -273,6 +274,7 @@ void carve(sr_engine* e) {
     e->v_rowmap_merge = ar.take<int>(NP / 4);
     e->v_work_win = ar.take<AttnWork>(NP / 4 + 64);
     e->v_work_full = ar.take<AttnWork>(NP / 64 + 64);
+    e->v_work_full128 = ar.take<AttnWork>(NP / 128 + 64);
 
     // LM prefill activations
     const size_t TP = c.max_prefill_tokens;
@@ -339,7 +341,7 @@ void carve(sr_engine* e) {
     e->vtcache = ar.take<bf16_t>(e->kv_layer_elems * c.t_layers);
 
     // control staging: ViT needs NP*(8 + 4*hd) + work lists; prefill needs ~24 B per token + work lists
-    e->stage_bytes = NP * (8 + 4 * (size_t)e->v_hd) + (NP / 4 + NP / 64 + 128) * sizeof(AttnWork) + TP * 28 +
+    e->stage_bytes = NP * (8 + 4 * (size_t)e->v_hd) + (NP / 4 + NP / 64 + NP / 128 + 192) * sizeof(AttnWork) + TP * 28 +
                      (TP / 64 + 64) * sizeof(AttnWork) + 4096;
     e->d_stage = ar.take<char>(e->stage_bytes);
 }
@@ -419,7 +421,8 @@ int vit_prepare(sr_engine* e, const int64_t* grid, int n_img, hipStream_t s, int
     int* h_rm_merge = h_rm_embed + N;
     AttnWork* h_win = reinterpret_cast<AttnWork*>(((uintptr_t)(h_rm_merge + N / unit) + 15) & ~(uintptr_t)15);
     int n_win = 0;
-    std::vector<AttnWork> full;
+    std::vector<AttnWork> full, full128;
+    bool aligned = true;         // every image starts on a multiple of 8 patches: 16-byte aligned V^T key runs (k_attn_prefill2's LDS-DMA)
 
     int unit_base = 0, row_base = 0, new_unit = 0;
     for (int im = 0; im < n_img; ++im) {
@@ -455,12 +458,16 @@ int vit_prepare(sr_engine* e, const int64_t* grid, int n_img, hipStream_t s, int
             }
         const int len = gh * gw;
         for (int q0 = 0; q0 < len; q0 += 64) full.push_back(AttnWork{row_base + q0, len, q0, row_base, (long long)row_base});
+        for (int q0 = 0; q0 < len; q0 += 128) full128.push_back(AttnWork{row_base + q0, len, q0, row_base, (long long)row_base});
+        if (row_base % 8) aligned = false;
         unit_base += lh * lw;
         row_base += len;
     }
     AttnWork* h_full = h_win + n_win;
     memcpy(h_full, full.data(), full.size() * sizeof(AttnWork));
-    const size_t total = reinterpret_cast<char*>(h_full + full.size()) - hp;
+    AttnWork* h_full128 = h_full + full.size();
+    memcpy(h_full128, full128.data(), full128.size() * sizeof(AttnWork));
+    const size_t total = reinterpret_cast<char*>(h_full128 + full128.size()) - hp;
     if (total > e->stage_bytes) return fail(e, -12, "control staging too small");
     SR_TRY(stage_upload(e, 0, total, s));
     // device-side views into the mirror; copied out so that later prefill uploads cannot clobber them
@@ -472,7 +479,10 @@ int vit_prepare(sr_engine* e, const int64_t* grid, int n_img, hipStream_t s, int
     SR_TRY((int)hipMemcpyAsync(e->v_work_win, dmirror(h_win), n_win * sizeof(AttnWork), hipMemcpyDeviceToDevice, s));
     SR_TRY((int)hipMemcpyAsync(e->v_work_full, dmirror(h_full), full.size() * sizeof(AttnWork), hipMemcpyDeviceToDevice, s));
     e->v_nwork_win = n_win;
+    SR_TRY((int)hipMemcpyAsync(e->v_work_full128, dmirror(h_full128), full128.size() * sizeof(AttnWork), hipMemcpyDeviceToDevice, s));
     e->v_nwork_full = (int)full.size();
+    e->v_nwork_full128 = (int)full128.size();
+    e->v_full_aligned = aligned;
     e->v_grid_cached = key;
     return 0;
 }
@@ -850,7 +860,12 @@ int sr_vit_forward(sr_engine* e, const void* pixels, int pixels_dtype, const int
         const bool full = is_fullatt(c, blk);
         AttnArgs a{e->v_qkv, 3 * C, e->v_qkv + C, 3 * C, hd, e->v_vt, e->v_vt_stride, (long long)hd * e->v_vt_stride,
                    e->v_attn, C, full ? e->v_work_full : e->v_work_win, full ? e->v_nwork_full : e->v_nwork_win,
-                   c.v_heads, 1, scale, 0};
+                   c.v_heads, 1, scale, 0, 64, 0};
+        if (full && e->v_full_aligned) {      // full attention: 128-query blocks that share LDS-DMA-staged tiles (k_attn_prefill2) where it applies
+            AttnArgs a2 = a;
+            a2.work = e->v_work_full128; a2.n_work = e->v_nwork_full128; a2.q_tile = 128; a2.v2_ok = 1;
+            if (attn_prefill_variant(a2, hd) == 2) a = a2;
+        }
         SR_TRY(launch_attn_prefill(s, a, hd));
         if (int rc = gemm(e, s, e->v_attn, C, w.proj_w, N, C, C, e->v_x, C, w.proj_b, e->v_x, nullptr, EPI_RESID)) return rc;
         SR_TRY(launch_rmsnorm(s, e->v_x, w.norm2, e->v_xn, N, C, 1e-6f, 0, 1));
@@ -1026,7 +1041,7 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
             SR_TRY(launch_lm_rope_prefill(s, ra));
         }
         AttnArgs a{e->t_qkv, e->t_qn, kc, 128, (long long)c.max_ctx * 128, vc, c.max_ctx, (long long)128 * c.max_ctx,
-                   e->t_attn, QD, e->t_work, n_work, c.t_heads, e->t_group, scale, 1};
+                   e->t_attn, QD, e->t_work, n_work, c.t_heads, e->t_group, scale, 1, 64, 1};      // max_ctx % 64 == 0: aligned, readable key runs
         SR_TRY(launch_attn_prefill(s, a, 128));
         if (splitk) {
             if (int rc = lm_gemm(e, s, e->t_attn, QD, w.o_w, w.o_w8, w.o_s, n_tok, H, QD, e->t_slabs, H, nullptr, nullptr, EPI_F32, nullptr, nullptr, SPLITK_KS)) return rc;

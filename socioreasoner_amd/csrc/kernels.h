@@ -99,8 +99,12 @@ struct AttnArgs {
     int n_heads, group;                   // kv head = h / group
     float scale;
     int causal;
+    int q_tile;                           // queries per work item: 0 / 64 (k_attn_prefill), or 128 (k_attn_prefill2, MHA full attention)
+    int v2_ok;                            // caller's promise for k_attn_prefill2: vt + vt_off + 64 * j is 16-byte aligned for every work item,
+                                          // the V^T rows are readable (and finite) up to the end of the last 64-key tile
 };
 int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim);
+int attn_prefill_variant(const AttnArgs& a, int head_dim);   // 2: k_attn_prefill2 takes it, 1: k_attn_prefill
 
 // decode: q/k/v rows (after the Linear bias, before rope) -> mRoPE -> KV-cache append -> attention (two launches)
 struct DecodeAttnArgs {

@@ -1,0 +1,145 @@
+"""Round 3 GPU tests.
+
+1. "As close to exact arithmetic as the reference is" (VERDICT round 2, next #3): tests/golden/hf_truth3b.npz holds, for the full-depth
+   3B model on the bench tile, the reference-faithful pair, a 756 x 756 tile (reference default max_pixels) and configs[4]'s 896 x 896
+   tile, the outputs of HF in bf16 (the reference's eager path, /root/reference/roll/distributed/strategy/hf_strategy.py:49-94) AND of
+   HF in float32 on the same bf16-representable weights.  Asserted per stage: err(HIP -> float32) <= BAND x err(HF-bf16 -> float32),
+   rms and max, on identical elements -- plus the direct comparison with HF-bf16 the round-2 tests make, at the new shapes.
+2. k_attn_prefill2 (LDS-DMA ring, shared tiles) is bit-identical to k_attn_prefill.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import bits_to_f32
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# Two CORRECT bf16 implementations do not sit at exactly the same distance from float32: the CPU oracle of this repo lands at
+# 0.94 .. 1.09 x HF-bf16's rms error and 0.95 .. 1.25 x its max error over the four samples (tools/make_golden_truth.py prints both).
+RMS_BAND, MAX_BAND = 1.15, 1.6
+
+
+def err(got: torch.Tensor, want: torch.Tensor):
+    d = (got.float().cpu() - want.float().cpu()).flatten()
+    return {"max": float(d.abs().max()), "rms": float(d.pow(2).mean().sqrt()), "bias": float(d.mean())}
+
+
+def record(name, payload):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "hf_truth_r03.json")
+    cur = json.load(open(path)) if os.path.exists(path) else {}
+    cur[name] = payload
+    json.dump(cur, open(path, "w"), indent=1)
+
+
+def in_band(hip, ref, what):
+    assert hip["rms"] <= RMS_BAND * ref["rms"] and hip["max"] <= MAX_BAND * ref["max"] and abs(hip["bias"]) <= 3e-3, (what, hip, ref)
+    return {"hip_vs_f32": hip, "hf_bf16_vs_f32": ref, "rms_ratio": hip["rms"] / ref["rms"], "max_ratio": hip["max"] / ref["max"]}
+
+
+@pytest.mark.parametrize("tag", ["tile448", "pair448", "tile756", "tile896"])
+def test_full_depth_3b_distance_to_float32_truth(golden_dir, tag):
+    from socioreasoner_amd import synthetic
+    from socioreasoner_amd.config import geometry_3b
+    from socioreasoner_amd.engine import Engine
+    g = np.load(os.path.join(golden_dir, "hf_truth3b.npz"))
+    G, stride, ps, ls = int(g["g_new"][0]), int(g["stride"][0]), int(g["pool_stride"][0]), int(g["last_f32_stride"][0])
+    geom = geometry_3b()
+    tiles, hw = g[f"{tag}_tiles"].tolist(), int(g[f"{tag}_hw"][0])
+    grid = (1, hw // 14, hw // 14)
+    ids, pos3 = g[f"{tag}_ids"], g[f"{tag}_pos3"]
+    S, N = len(ids), len(tiles) * grid[1] * grid[2]
+    e = Engine(geom, max_patches=N, max_prefill_tokens=(S + 63) // 64 * 64, max_batch=1, max_ctx=(S + G + 64) // 64 * 64, max_new_tokens=G)
+    e.load_synthetic_weights(seed=0)
+    assert np.array_equal(ids, synthetic.tile_prompt(geom, tiles[0], grid, n_images=len(tiles)))
+    pix = torch.cat([e.patchify(torch.from_numpy(synthetic.tile_pixels(i, hw, hw)).cuda()) for i in tiles], dim=0)
+    emb = e.vit_forward(pix, [grid] * len(tiles))
+    res = {}
+    # ---- ViT + merger
+    p16, p32 = bits_to_f32(g[f"{tag}_pooler"]), torch.from_numpy(g[f"{tag}_pooler_f32"])
+    mine = emb.float().cpu().flatten()[::ps]
+    res["pooler"] = in_band(err(mine, p32), err(p16, p32), "pooler")
+    res["pooler"]["hip_vs_hf_bf16"] = err(mine, p16)
+    # ---- prefill, last position
+    logits = e.prefill([ids], [pos3], emb, return_logits=True)[0].cpu()
+    l16, l32 = bits_to_f32(g[f"{tag}_logits_last"]), torch.from_numpy(g[f"{tag}_logits_last_f32"])
+    res["prefill_logits"] = in_band(err(logits[::ls], l32), err(l16[::ls], l32), "prefill logits")
+    res["prefill_logits"]["hip_vs_hf_bf16"] = d16 = err(logits, l16)
+    ocal = g[f"{tag}_oracle_logits_last"]            # this repo's CPU oracle against HF-bf16: [max, rms, mean, absmax]
+    assert d16["rms"] <= 1.5 * ocal[1] and d16["max"] <= 2.0 * ocal[0], (d16, ocal.tolist())
+    hf_tokens = g[f"{tag}_tokens"].tolist()
+    if float(g[f"{tag}_first_margin"][0]) > 2 * d16["max"]:
+        assert int(logits.argmax()) == hf_tokens[0]
+    # ---- teacher-forced decode through the KV cache
+    _, trace = e.decode(G, trace=True, forced=torch.tensor([hf_tokens], dtype=torch.int32), use_graph=False)
+    s16, s32 = g[f"{tag}_sample"], g[f"{tag}_sample_f32"]
+    t_idx, t16, t32, margin = g[f"{tag}_top_idx"], g[f"{tag}_top_val"], g[f"{tag}_top_val_f32"], g[f"{tag}_margin"]
+    steps, agree = [], 0
+    for k in range(G - 1):
+        lg = trace[k + 1, 0].cpu()
+        st = in_band(err(lg[::stride], torch.from_numpy(s32[k])), err(bits_to_f32(s16[k]), torch.from_numpy(s32[k])), f"step {k}")
+        top = lg[torch.from_numpy(t_idx[k]).long()]
+        e_top, e_top16 = err(top, torch.from_numpy(t32[k])), err(torch.from_numpy(t16[k]), torch.from_numpy(t32[k]))
+        # 32 values are too few for a ratio of maxima: the top-32 logits stay inside the band the strided sample set
+        assert e_top["max"] <= MAX_BAND * max(e_top16["max"], st["hf_bf16_vs_f32"]["max"]), (k, e_top, e_top16)
+        tok_eq = int(lg.argmax()) == hf_tokens[k + 1]
+        agree += tok_eq
+        if margin[k] > 2 * max(st["hip_vs_f32"]["max"], err(lg[::stride], bits_to_f32(s16[k]))["max"]):
+            assert tok_eq, (k, float(margin[k]))
+        steps.append(st)
+    res["decode_steps"] = {"rms_ratio_max": max(s["rms_ratio"] for s in steps), "max_ratio_max": max(s["max_ratio"] for s in steps),
+                           "hip_rms_max": max(s["hip_vs_f32"]["rms"] for s in steps), "hf_rms_max": max(s["hf_bf16_vs_f32"]["rms"] for s in steps),
+                           "greedy_tokens_equal_hf": f"{agree}/{G - 1}"}
+    print(tag, json.dumps(res))
+    record(tag, res)
+    e.close()
+
+
+def _run_prefill(e, geom, tiles, hw, monkeypatch, attn2):
+    from socioreasoner_amd import hostops, synthetic
+    monkeypatch.setenv("SR_ATTN2", attn2)
+    grid = (1, hw // 14, hw // 14)
+    pix = torch.cat([e.patchify(torch.from_numpy(synthetic.tile_pixels(i, hw, hw)).cuda()) for i in tiles], dim=0)
+    emb = e.vit_forward(pix, [grid] * len(tiles))
+    ids, p3 = [], []
+    for i in tiles:
+        x = synthetic.tile_prompt(geom, i, grid, n_pre=11 + 7 * i, n_post=5 + 3 * i)       # ragged prompts
+        pos3, _ = hostops.get_rope_index(torch.from_numpy(x)[None], [grid], None, image_token_id=geom.image_token_id,
+                                         vision_start_token_id=geom.vision_start_token_id)
+        ids.append(x)
+        p3.append(pos3[:, 0].numpy())
+    logits = e.prefill(ids, p3, emb, return_logits=True)
+    toks = e.decode(4)
+    torch.cuda.synchronize()
+    return emb.clone(), logits.clone(), toks.clone()
+
+
+@pytest.mark.parametrize("hw", [448, 896, 756])
+def test_attention_v2_equals_round2_kernel_bit_for_bit(monkeypatch, hw):
+    """ViT full-attention blocks (hd 80, 128-query blocks) and the causal GQA prefill (hd 128, 32 queries x 4 heads): the LDS-DMA
+    kernel against the round-2 kernel on the same engine -- pooler, prefill logits and the first decoded tokens, torch.equal.
+    448: four tiles (three images start off the first, ragged prompts, partial key tiles); 896: 4096 keys; 756: windows of 36..64
+    patches and an image whose patch count is not a multiple of 64 (the second image starts 4 patches off a 16-byte boundary:
+    the engine must keep that launch on the round-2 kernel)."""
+    from socioreasoner_amd.config import geometry_3b
+    from socioreasoner_amd.engine import Engine
+    geom = geometry_3b()
+    geom.vision.depth, geom.text.num_hidden_layers = 8, 3                 # 7 windowed blocks + full-attention block 7; 3 LM layers
+    geom.vision.fullatt_block_indexes = (7,)
+    tiles = {448: [0, 1, 2, 3], 896: [0], 756: [0, 1]}[hw]
+    n = (hw // 14) ** 2
+    e = Engine(geom, max_patches=len(tiles) * n, max_prefill_tokens=len(tiles) * (n // 4 + 64), max_batch=len(tiles),
+               max_ctx=(n // 4 + 64 + 63) // 64 * 64 + 64, max_new_tokens=4)
+    e.load_synthetic_weights(seed=0)
+    a = _run_prefill(e, geom, tiles, hw, monkeypatch, "0")
+    b = _run_prefill(e, geom, tiles, hw, monkeypatch, "1")
+    for x, y, what in zip(a, b, ("pooler", "prefill logits", "tokens")):
+        assert torch.equal(x, y), (what, float((x.float() - y.float()).abs().max()))
+    assert torch.isfinite(b[1]).all()
+    e.close()
