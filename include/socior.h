@@ -157,6 +157,10 @@ int sr_decode_step(sr_engine* e, const int64_t* dev_last_ids, int B, float* dev_
  *                   at its limit, later positions are not written.  Asynchronous.
  *   sr_rows_poll  : host copies of the per-row finished flags and generated-token counts (synchronises the stream).
  *   sr_rows_read  : the first n generated tokens of a row (int32, device to device).
+ *   sr_rows_abort : the rows host_rows[0..n) stop NOW (their finished flag is set between two steps: no further token is logged,
+ *                   nothing more is appended to their KV slot); the next sr_rows_poll reports them finished and the caller may
+ *                   re-use row and slot at once -- what vLLM's abort_request does for the reference's ABORT command
+ *                   (/root/reference/roll/distributed/strategy/vllm_strategy.py:188-193).
  *   sr_rows_sampling : (optional, after sr_rows_begin) all rows draw their tokens with k_sample (temperature > 0, 1 <= top_k <= 1024,
  *                   0 < top_p <= 1) instead of the greedy arg-max; temperature 0 switches back. */
 int sr_rows_begin(sr_engine* e, void* stream);
@@ -177,6 +181,7 @@ int sr_admit_commit(sr_engine* e, const int32_t* host_rows, int n, void* stream)
 int sr_rows_step(sr_engine* e, int n_steps, const int32_t* host_eos, int n_eos, int32_t pad_id, void* stream);
 int sr_rows_poll(sr_engine* e, int32_t* host_finished, int32_t* host_steps, void* stream);
 int sr_rows_read(sr_engine* e, int row, int32_t* dev_tokens_out, int n, void* stream);
+int sr_rows_abort(sr_engine* e, const int32_t* host_rows, int n, void* stream);
 
 /* K19-K22 raster tail -- replaces seg_strategy.py:58-65 (union, cv2.INTER_NEAREST resize),
  * rlvr_socioseg_vlm_pipeline_infer.py:45-58 (IoU counts) and :383-452 (render).  No engine needed. */

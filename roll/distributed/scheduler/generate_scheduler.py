@@ -2,8 +2,11 @@
 
 The reference fans a batch out to its DP workers through Ray (level 0) or dispatches single requests to the least
 loaded worker and collects them through callbacks (level 1).  Here every torchrun rank already holds its shard of the
-batch (socioreasoner_amd.dp), so the scheduler drives the LOCAL worker: level 0 is one ``generate`` call, level 1
-splits the batch into single-prompt requests served by the worker's request loop and re-assembled in prompt order."""
+batch (socioreasoner_amd.dp): level 0 is one ``generate`` call on the local worker; level 1 splits the batch into
+single-prompt requests and -- with more than one rank -- deals them out ACROSS the ranks like the reference does
+(least requests in flight first, ``max_running_requests`` per worker, reference :57, 180-187), each rank's request loop
+serving what it is handed and every rank getting the answers of its own prompts back in prompt order
+(socioreasoner_amd/dispatch.py); with one rank the local request loop serves them all."""
 from __future__ import annotations
 
 import threading
@@ -27,12 +30,20 @@ def expand_num_return_sequences(data: DataProto, n: int) -> DataProto:
 
 
 class GenerateScheduler:
+    max_running_requests = 128          # per worker (reference :57)
+
     def __init__(self):
         self.lock = threading.Lock()
         self.results: Dict[int, List[int]] = {}
         self.done = threading.Event()
+        self.round = 0                  # generate calls so far: every rank counts them alike, keys of different calls never meet
+        self.sink = None                # cross-rank mode: where finished requests are reported
+        self.last_dispatch_stats = None
 
     def report_response(self, data: DataProto):
+        if self.sink is not None:       # cross-rank dispatch: the request may belong to another rank
+            self.sink(int(data.meta_info["request_id"]), data.meta_info["output_token_ids"][0])
+            return
         with self.lock:
             self.results[int(data.meta_info["request_id"])] = data.meta_info["output_token_ids"][0]
             if len(self.results) == self.expected:
@@ -58,23 +69,43 @@ class GenerateScheduler:
         return self._generate_requests(data, worker, gc, pipeline_config)
 
     def _generate_requests(self, data: DataProto, worker, gc, pipeline_config) -> DataProto:
-        B = len(data)
-        self.results, self.expected = {}, B
-        self.done.clear()
-        worker.start_server(DataProto(meta_info={}), request_complete_callback=self.report_response)
-        for i in range(B):
-            req = DataProto(batch={k: v[i:i + 1] for k, v in data.batch.items()},
-                            non_tensor_batch={k: v[i:i + 1] for k, v in data.non_tensor_batch.items()},
-                            meta_info={"request_id": i, "generation_config": dict(gc, num_return_sequences=1)})
-            worker.add_request(GenerateRequestType.ADD, req)
         import time
-        deadline = time.monotonic() + float(pipeline_config.get("rpc_timeout") or 3600)
-        while not self.done.wait(timeout=0.2):
-            worker.add_request(GenerateRequestType.ALIVE_CHECK)         # raises if the server thread died
-            if time.monotonic() > deadline:
+        import torch.distributed as dist
+        B = len(data)
+        self.round += 1
+        reqs = [DataProto(batch={k: v[i:i + 1] for k, v in data.batch.items()},
+                          non_tensor_batch={k: v[i:i + 1] for k, v in data.non_tensor_batch.items()},
+                          meta_info={"request_id": i, "generation_config": dict(gc, num_return_sequences=1)}) for i in range(B)]
+        timeout = float(pipeline_config.get("rpc_timeout") or 3600)
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        worker.start_server(DataProto(meta_info={}), request_complete_callback=self.report_response)
+        if world > 1:
+            # request-level dispatch over all ranks (reference generate_opt_level_1): collective -- every rank is in this call
+            from socioreasoner_amd.dispatch import CrossRankDispatcher, default_store
+            cap = int(pipeline_config.get("max_running_requests") or self.max_running_requests)
+            disp = CrossRankDispatcher(default_store(), dist.get_rank(), world, self.round, max_running_requests=cap, timeout_s=timeout)
+            try:
+                got = disp.run(reqs, add_request=lambda r: worker.add_request(GenerateRequestType.ADD, r),
+                               make_result_sink=lambda cb: setattr(self, "sink", cb),
+                               make_request=lambda b, n, m: DataProto(batch=b, non_tensor_batch=n, meta_info=m),
+                               alive_check=lambda: worker.add_request(GenerateRequestType.ALIVE_CHECK))
+            finally:
+                self.sink = None
                 worker.stop_server()
-                raise TimeoutError(f"{B - len(self.results)} of {B} generation requests did not complete")
-        worker.stop_server()
+            self.last_dispatch_stats = disp.stats
+            self.results = {i: got[i] for i in range(B)}
+        else:
+            self.results, self.expected = {}, B
+            self.done.clear()
+            for req in reqs:
+                worker.add_request(GenerateRequestType.ADD, req)
+            deadline = time.monotonic() + timeout
+            while not self.done.wait(timeout=0.2):
+                worker.add_request(GenerateRequestType.ALIVE_CHECK)         # raises if the server thread died
+                if time.monotonic() > deadline:
+                    worker.stop_server()
+                    raise TimeoutError(f"{B - len(self.results)} of {B} generation requests did not complete")
+            worker.stop_server()
         pad = worker.tokenizer.pad_token_id
         rows = [self.results[i] for i in range(B)]                      # re-sorted by prompt id (reference :293-294)
         output_ids = hostops.gather_outputs_to_pad_tensor(rows, pad, device=data.batch["input_ids"].device)

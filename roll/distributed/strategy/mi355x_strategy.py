@@ -435,12 +435,8 @@ class Mi355xStrategy(InferenceStrategy):
             elif name == "ABORT":
                 rid = req.meta_info["request_id"]
                 sampled = [p for p in sampled if p.meta_info.get("request_id") != rid]
-                if batcher is not None:      # queued requests can be dropped; a running row finishes and is discarded
-                    batcher.pending = type(batcher.pending)(r for r in batcher.pending if r.tag.meta_info.get("request_id") != rid)
-                    # (an ABORT may name a row that was already aborted: keep the tag.  Staged requests -- prefilled, waiting for a row -- run too)
-                    for r in list(batcher.active.values()) + (list(batcher.staged[0]) if batcher.staged is not None else []):
-                        if r.tag.meta_info.get("request_id") == rid:
-                            r.aborted = True
+                if batcher is not None:      # queued requests are dropped, running rows stop now and free row + KV slot at the next poll
+                    batcher.abort(lambda r: r.tag.meta_info.get("request_id") == rid)
             elif name == "STOP":
                 stop = True
             if batcher is not None and not batcher.idle() and (self.command_queue.empty() or len(batcher.active) > 0):

@@ -203,14 +203,20 @@ __global__ __launch_bounds__(256) void k_attn_prefill(AttnArgs p) {
 //     counted by hand: 2 DMA instructions per wave and pass-1 step (K), 4 per pass-2 step (K + V^T), nothing else in the loop
 //     touches vmcnt (no spills: checked with -Rpass-analysis=kernel-resource-usage);
 //   * LDS rows keep a power-of-two pitch and the 16-byte chunk index is XOR-swizzled on the SOURCE side (LDS-DMA writes linearly):
-//     K rows 256 B, chunk ^ (row & 15) -> conflict-free ds_read_b128 fragments; V^T rows 128 B, chunk ^ ((row >> 1) & 7) -> conflict-free
-//     ds_read_b64 pairs.  head_dim 80 uses the same 256-B K pitch; its pad chunks (d 80..95 of the 96-wide MFMA k range) are zeroed
+//     K rows 256 B, chunk ^ (row & 15) -> conflict-free ds_read_b128 fragments; V^T rows 128 B, chunk ^ vt_swz(row) -> ds_read2_b64
+//     pairs (2-way conflicts, see vt_swz).  head_dim 80 uses the same 256-B K pitch; its pad chunks (d 80..95 of the 96-wide MFMA k range) are zeroed
 //     once and never written again (masked-off DMA lanes);
 //   * blocks are dealt to XCDs in contiguous runs of (work item, head group, sub-tile), so the K / V of a sequence stay in ONE XCD's L2.
 // Keys past the end of a sequence: K rows are clamped (their scores are masked); V^T columns are read as they are -- P is exactly 0
 // there, and the caller guarantees FINITE contents (AttnArgs.v2_ok: the engine zeroes the KV cache and the ViT's V^T buffer when it is
 // created, and only ever stores finite bf16 values into them).
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// V^T tile swizzle: 16-byte chunk (8 keys) c of row d is stored at chunk c ^ vt_swz(d).  Only chunk bits 0 and 2 are touched, so the two
+// 4-key runs a lane feeds to one P.V MFMA (32 B apart: chunk bit 1) keep a CONSTANT distance and load as one ds_read2_b64 into four
+// consecutive registers -- with the full 3-bit swizzle the pair was assembled by 48 v_mov per step, 8 % of an issue-bound kernel's
+// instructions.  Price: 2-way instead of conflict-free b64 reads (rows d and d + 8 share their slots); LDS is not what bounds the kernel.
+__device__ __forceinline__ int vt_swz(int d) { return ((d >> 1) & 1) | (((d >> 2) & 1) << 2); }
 
 // one LDS-DMA instruction: 64 lanes x 16 B from gbase + voff (bytes, per lane) to LDS [lds_dst, lds_dst + 1 KB), invisible to hipcc's
 // waitcnt bookkeeping (MI355X guide 5.7: M0 is written in the statement that uses it and restored)
@@ -284,8 +290,8 @@ __global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_unit
     // V^T pieces wave and wave + 8 (beyond VI: pieces 0.. once more -- same bytes to the same place, keeps every wave's DMA count equal)
     const int vp1 = wave + 8 < VI ? wave + 8 : wave + 8 - VI;
     const int vrow0 = wave * 8 + (lane >> 3), vrow1 = vp1 * 8 + (lane >> 3);
-    const unsigned voff0 = (unsigned)(vrow0 * p.vt_stride + ((lane & 7) ^ ((vrow0 >> 1) & 7)) * 8) * 2u;
-    const unsigned voff1 = (unsigned)(vrow1 * p.vt_stride + ((lane & 7) ^ ((vrow1 >> 1) & 7)) * 8) * 2u;
+    const unsigned voff0 = (unsigned)(vrow0 * p.vt_stride + ((lane & 7) ^ vt_swz(vrow0)) * 8) * 2u;
+    const unsigned voff1 = (unsigned)(vrow1 * p.vt_stride + ((lane & 7) ^ vt_swz(vrow1)) * 8) * 2u;
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem2;
 
     if constexpr (HD != 128) {          // pad chunks of the K rows: zero once (whole K regions), before any DMA lands
@@ -309,22 +315,31 @@ __global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_unit
         }
     };
 
-    // scores of 16 keys of a staged tile: s[r] = key kv0 + t*16 + fg*4 + r against query fr of this wave (as k_attn_prefill)
-    auto scores16 = [&](const unsigned char* ks, int kv0, int t, float (&s)[4]) {
+    // scores of 16 keys of a staged tile: s[r] = key kv0 + t*16 + fg*4 + r against query fr of this wave (as k_attn_prefill).
+    // `masked` is wave-uniform: false on tiles every query of the wave sees in full (all but the diagonal / last tile) -- the kernel is
+    // instruction-issue bound (PMC round 3: ~3800 instructions per wave, 4 waves per SIMD, ACTIVE_INST_ANY x 4 = 113 % of the wave cycles),
+    // and the two compares + select per score are 15 % of them
+    auto scores16 = [&](const unsigned char* ks, int kv0, int t, float (&s)[4], bool masked) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < C::KS; ++kk) {
             bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + (t * 16 + fr) * 256 + (((kk * 4 + fg) ^ fr) << 4));
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
         }
+        if (masked) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int kidx = kv0 + t * 16 + fg * 4 + r;
-            const bool ok = kidx < seq_len && (!CAUSAL || kidx <= qpos);
-            const float v = rbf(rbf(acc[r]) * p.scale);
-            s[r] = ok ? v : -INFINITY;
+            for (int r = 0; r < 4; ++r) {
+                const int kidx = kv0 + t * 16 + fg * 4 + r;
+                const bool ok = kidx < seq_len && (!CAUSAL || kidx <= qpos);
+                const float v = rbf(rbf(acc[r]) * p.scale);
+                s[r] = ok ? v : -INFINITY;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] = rbf(rbf(acc[r]) * p.scale);
         }
     };
+    const int q_first = q_off + (wave % QW) * 16;       // first query position of this wave
 
     float m = -INFINITY, l = 0.f, inv_l = 0.f;
     f32x4 oacc[C::DT];
@@ -350,9 +365,10 @@ __global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_unit
         if (u < nt) {
             // ---------------- pass 1: row max m and sum l = sum exp(s - m)
             const int kv0 = u * KT;
+            const bool masked = kv0 + KT > seq_len || (CAUSAL && kv0 + KT - 1 > q_first);
             float s[4][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) scores16(ks, kv0, t, s[t]);
+            for (int t = 0; t < 4; ++t) scores16(ks, kv0, t, s[t], masked);
             float tm = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -374,11 +390,12 @@ __global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_unit
         } else {
             // ---------------- pass 2: P = bf16(exp(s - m) / l);  O^T += V^T . P^T   (32 keys at a time: fewer live registers)
             const int kv0 = (u - nt) * KT;
+            const bool masked = kv0 + KT > seq_len || (CAUSAL && kv0 + KT - 1 > q_first);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 float s0[4], s1[4];
-                scores16(ks, kv0, 2 * kb, s0);
-                scores16(ks, kv0, 2 * kb + 1, s1);
+                scores16(ks, kv0, 2 * kb, s0, masked);
+                scores16(ks, kv0, 2 * kb + 1, s1, masked);
                 uint4 pv;
                 pv.x = pack2(__expf(s0[0] - m) * inv_l, __expf(s0[1] - m) * inv_l);
                 pv.y = pack2(__expf(s0[2] - m) * inv_l, __expf(s0[3] - m) * inv_l);
@@ -388,10 +405,10 @@ __global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_unit
 #pragma unroll
                 for (int dt = 0; dt < C::DT; ++dt) {
                     const int d = dt * 16 + fr;
-                    const unsigned char* vr = vs + d * 128 + (fg & 1) * 8;
-                    const int sw = (d >> 1) & 7, c0 = kb * 4 + (fg >> 1);
-                    uint2 v0 = *reinterpret_cast<const uint2*>(vr + ((c0 ^ sw) << 4));          // keys kb*32 + fg*4 .. +3
-                    uint2 v1 = *reinterpret_cast<const uint2*>(vr + (((c0 + 2) ^ sw) << 4));    // keys kb*32 + 16 + fg*4 .. +3
+                    const int c0 = kb * 4 + (fg >> 1);                                           // bit 1 of c0 is clear and vt_swz() leaves it alone:
+                    const unsigned char* vr = vs + d * 128 + (fg & 1) * 8 + ((c0 ^ vt_swz(d)) << 4);   // the second run sits exactly 32 B behind the first
+                    uint2 v0 = *reinterpret_cast<const uint2*>(vr);             // keys kb*32 + fg*4 .. +3
+                    uint2 v1 = *reinterpret_cast<const uint2*>(vr + 32);        // keys kb*32 + 16 + fg*4 .. +3   (one ds_read2_b64: 4 consecutive registers)
                     const bf16x8 vf = __builtin_bit_cast(bf16x8, uint4{v0.x, v0.y, v1.x, v1.y});
                     oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
                 }

@@ -409,6 +409,11 @@ __global__ void k_admit_rows(AdmitArgs a) {
     }
 }
 
+// continuous batching: rows named by the mask stop now (k_step then logs pads for them and leaves their cache slot alone)
+__global__ void k_rows_abort(unsigned mask, int* finished) {
+    if (threadIdx.x < 32 && ((mask >> threadIdx.x) & 1u)) finished[threadIdx.x] = 1;
+}
+
 // fp8 weight quantisation, one block per 16-row tile of a fragment-ordered bf16 matrix (see kernels.h)
 __global__ __launch_bounds__(256) void k_quant_f8(bf16_t* W, int K, unsigned char* W8, float* scale) {
     __shared__ float amax_s[16][17];
@@ -540,6 +545,12 @@ int launch_vit_rope(hipStream_t s, bf16_t* qkv, int n_rows, int n_heads, int hea
     hipLaunchKernelGGL(k_vit_rope, dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, s, qkv, n_rows, n_heads, head_dim, cos_t, sin_t, paired);
     hipLaunchKernelGGL(k_vit_vtranspose, dim3(cdiv(n_rows, 64), n_heads), dim3(256), 0, s, (const bf16_t*)qkv, n_rows, n_heads,
                        head_dim, vt, vt_stride);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_rows_abort(hipStream_t s, unsigned row_mask, int* finished) {
+    if (!row_mask) return 0;
+    hipLaunchKernelGGL(k_rows_abort, dim3(1), dim3(64), 0, s, row_mask, finished);
     SR_CHECK_LAUNCH();
     return 0;
 }

@@ -1407,6 +1407,18 @@ int sr_rows_read(sr_engine* e, int row, int32_t* dev_tokens_out, int n, void* st
     return 0;
 }
 
+int sr_rows_abort(sr_engine* e, const int32_t* host_rows, int n, void* stream) {
+    enter(e);
+    if (!e || !e->rows_mode || !host_rows || n < 0) return fail(e, -22, "sr_rows_abort: bad argument / not in rows mode");
+    unsigned mask = 0;
+    for (int i = 0; i < n; ++i) {
+        if (host_rows[i] < 0 || host_rows[i] >= e->c.max_batch || host_rows[i] >= 32) return fail(e, -22, "sr_rows_abort: row %d out of range", host_rows[i]);
+        mask |= 1u << host_rows[i];
+    }
+    SR_TRY(launch_rows_abort((hipStream_t)stream, mask, e->d_finished));
+    return 0;
+}
+
 int sr_decode_step(sr_engine* e, const int64_t* dev_last_ids, int B, float* dev_logits_out, int64_t* dev_next_ids, void* stream) {
     enter(e);
     if (!e) return fail(e, -22, "sr_decode_step: null engine");

@@ -116,7 +116,8 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None, sizes=None) -
     dev = local.device
     xdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev     # gloo exchanges host tensors
     if all(sz == mx for sz in sizes):
-        return _gather_equal(local.to(xdev).contiguous(), world, group).reshape((n_total,) + tuple(local.shape[1:])).to(dev)
+        # (clone: on the RCCL path _gather_equal hands out its process-wide exchange buffer, which the next call overwrites)
+        return _gather_equal(local.to(xdev).contiguous(), world, group).reshape((n_total,) + tuple(local.shape[1:])).to(dev, copy=True)
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=xdev)
     pad[: local.shape[0]] = local.to(xdev)
     full = _gather_equal(pad, world, group)

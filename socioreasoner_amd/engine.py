@@ -288,6 +288,11 @@ class Engine:
         L.check(self.lib.sr_rows_poll(self._h, fin.ctypes.data_as(L._i32p), cnt.ctypes.data_as(L._i32p), self._s()), self._h, "sr_rows_poll")
         return fin, cnt
 
+    def rows_abort(self, rows: Sequence[int]):
+        """The named rows stop now: the next rows_poll reports them finished, row and KV slot can be re-used at once."""
+        rw = np.asarray(list(rows), dtype=np.int32)
+        L.check(self.lib.sr_rows_abort(self._h, rw.ctypes.data_as(L._i32p), len(rw), self._s()), self._h, "sr_rows_abort")
+
     def row_tokens(self, row: int, n: int) -> torch.Tensor:
         out = torch.empty(n, dtype=torch.int32, device=self.device)
         L.check(self.lib.sr_rows_read(self._h, row, C.c_void_p(out.data_ptr()), n, self._s()), self._h, "sr_rows_read")

@@ -96,6 +96,26 @@ class ContinuousBatcher:
     def idle(self) -> bool:
         return not self.pending and not self.active and self.staged is None
 
+    def abort(self, match: Callable[[Request], bool]) -> int:
+        """ABORT (reference vllm_strategy.py:188-193 -> vLLM abort_request): queued requests are dropped, running rows stop NOW and
+        give row and KV slot back at the next poll (sr_rows_abort), requests that are prefilled but still wait for a row are stopped the
+        moment they are installed.  Their results are discarded (Request.aborted).  Returns the number of requests hit."""
+        n0 = len(self.pending)
+        self.pending = deque(r for r in self.pending if not match(r))
+        hit = n0 - len(self.pending)
+        rows = [row for row, r in self.active.items() if match(r) and not r.aborted]
+        for row in rows:
+            self.active[row].aborted = True
+        if rows:
+            s = self._dec_last if (self.overlap and self._dec_last is not None) else torch.cuda.current_stream(self.engine.device)
+            with torch.cuda.stream(s):              # ordered between two decode chunks of the rows' own stream
+                self.engine.rows_abort(rows)
+        for r in (self.staged[0] if self.staged is not None else []):
+            if match(r) and not r.aborted:
+                r.aborted = True
+                hit += 1
+        return hit + len(rows)
+
     def _admit(self):
         cfg = self.engine.cfg
         grp, ntok, npatch = [], 0, 0
@@ -228,6 +248,10 @@ class ContinuousBatcher:
             self.active[row] = r
             self.row_slot[row] = slot
             self._cnt_last[row] = 0
+        dead = [row for row, r in zip(rows, grp[:k]) if r.aborted]      # aborted while they waited for a row: stop before the first step
+        if dead:
+            with torch.cuda.stream(s):
+                self.engine.rows_abort(dead)
         self.stats["admitted"] += k
         del grp[:k], slots[:k]
         if not grp:
