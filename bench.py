@@ -32,6 +32,7 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16
 # algorithmic work per tile
 VIT_GFLOP, PREFILL_GFLOP = 1342.9, 2516.3
 N_NEW = 128
+RAGGED_LO, RAGGED_HI = 64, 192      # ragged phase: per-request max_new uniform in [64, 192] (mean 128)
 GRID = (1, 32, 32)
 
 
@@ -97,7 +98,7 @@ def main():
     S_PROMPT = 96 + 94 + NIMG * (2 + NPATCH // 4)
     if args.tile != 448 or args.pair:
         VIT_GFLOP = PREFILL_GFLOP = float("nan")       # (the constants above are the 448-tile counts)
-    eng = Engine(geom, max_patches=NPATCH * NIMG * B, max_prefill_tokens=S_PROMPT * B, max_batch=B, max_ctx=max(640, (S_PROMPT + N_NEW + 63) // 64 * 64), max_new_tokens=N_NEW, device=str(dev), lm_fp8="mx" if args.fp8_mx else args.fp8,
+    eng = Engine(geom, max_patches=NPATCH * NIMG * B, max_prefill_tokens=S_PROMPT * B, max_batch=B, max_ctx=max(640, (S_PROMPT + RAGGED_HI + 63) // 64 * 64), max_new_tokens=RAGGED_HI, device=str(dev), lm_fp8="mx" if args.fp8_mx else args.fp8,
                  kv_slots=2 * B if overlap else 0)      # spare KV slots: the next requests are prefilled while the current rows decode
     t0 = time.time()
     eng.load_synthetic_weights(seed=0)
@@ -201,6 +202,16 @@ def main():
     dt = dp.all_reduce_max(dt, dev)
     tiles_per_s = world * n_req * args.steps / dt
     exchange = dp.exchange_info()
+    if world > 1:
+        # the N-rank record verifies itself: the communicator really has N ranks (hard error otherwise -- a scaling number from a
+        # degenerate group would be worthless), and what RCCL logged about its transports is reported as checks, not guessed
+        assert exchange["nranks"] == world == args.gpus, exchange
+        if exchange.get("backend") == "nccl":
+            exchange["checks"] = {"rccl_logged_nranks_eq_world": exchange.get("log_nranks") == [world],
+                                  "channels_via_p2p_xgmi": exchange.get("channels_via_p2p", 0) > 0,
+                                  "no_channel_via_net": exchange.get("channels_via_net", 0) == 0,
+                                  "no_host_staging": True}      # all_gather_into_tensor on device buffers (dp._gather_equal)
+            exchange["verified"] = all(exchange["checks"].values())
 
     # ---- the same kernels as ONE static batch of B tiles (no scheduler, whole chip, warm): the phase times the MFMA fractions are quoted on
     static_ref = None
@@ -216,6 +227,46 @@ def main():
                       "vit_mfma_frac": round(VIT_GFLOP * B / (st_ms["vit"] / 2 * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4),
                       "prefill_mfma_frac": round(PREFILL_GFLOP * B / (st_ms["prefill"] / 2 * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4),
                       "forward_mfma_frac": round((VIT_GFLOP + PREFILL_GFLOP) * B / (fw * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)}
+
+    # ---- admit-on-finish TIMED: the same requests with ragged answer lengths (per-request max_new uniform in [64, 192], mean 128, seeded),
+    # through the same scheduler, against static batches of B that each run to their longest answer.  The headline's rows all stop on
+    # the same step (EOS is ignored by the metric), so only this phase shows what refilling rows as they free up is worth.
+    ragged = None
+    if rank == 0 and continuous and not args.no_latency:
+        import numpy as _np
+        from socioreasoner_amd.serving import ContinuousBatcher, Request
+        lens = _np.random.default_rng(4000).integers(RAGGED_LO, RAGGED_HI + 1, n_req).tolist()
+
+        def ragged_run(ov):
+            cb = ContinuousBatcher(eng, eos=[], pad_id=0, steps_per_poll=16, overlap=ov,
+                                   admit_cus_per_se=args.admit_cus if args.admit_cus == "auto" else float(args.admit_cus))
+            reqs = [Request(ids=ids[k], pos3=pos3[k], max_new=int(lens[k]), images=imgs[k], grids=[GRID] * NIMG) for k in range(n_req)]
+            torch.cuda.synchronize(dev)
+            t_ = time.perf_counter()
+            toks_ = cb.run(reqs)
+            torch.cuda.synchronize(dev)
+            dt_ = time.perf_counter() - t_
+            assert [len(t) for t in toks_] == lens
+            return dt_, cb.stats["steps"]
+
+        ragged_run(overlap)                                   # warm (graphs, calibration)
+        r_dt, r_steps = ragged_run(overlap)
+        # static batches: B requests at a time, every batch decodes until its longest answer is done
+        torch.cuda.synchronize(dev)
+        t_ = time.perf_counter()
+        s_steps = 0
+        for lo in range(0, n_req, B):
+            pix = torch.cat([eng.patchify(im) for grp in imgs[lo:lo + B] for im in grp], dim=0)
+            emb = eng.vit_forward(pix, [GRID] * (min(B, n_req - lo) * NIMG))
+            eng.prefill(ids[lo:lo + B], pos3[lo:lo + B], emb)
+            eng.decode(max(lens[lo:lo + B]))
+            s_steps += max(lens[lo:lo + B])
+        torch.cuda.synchronize(dev)
+        s_dt = time.perf_counter() - t_
+        ragged = {"workload": f"{n_req} requests, max_new uniform in [{RAGGED_LO}, {RAGGED_HI}] (mean {sum(lens) / len(lens):.1f}, seed 4000), {B} rows",
+                  "continuous_tiles_per_s": round(n_req / r_dt, 3), "continuous_tokens_per_s": round(sum(lens) / r_dt, 1), "continuous_decode_steps": r_steps,
+                  "static_batches_tiles_per_s": round(n_req / s_dt, 3), "static_batches_decode_steps": s_steps,
+                  "gain": round(s_dt / r_dt, 4)}
 
     # ---- configs[1] beside it: one tile at a time on the same engine (batch-1 kernels, hipGraph decode), rank 0 only
     latency = None
@@ -328,9 +379,14 @@ def main():
         kv_bytes = 36864.0 * (S_PROMPT + N_NEW / 2) * B
         # HBM traffic per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950 note):
         # measured ratio traffic / algorithmic bytes of this kernel family x the algorithmic bytes of one launch
-        traffic, pmc = None, None
+        traffic, pmc, insitu = None, None, None
+        PMC_FILE = "r02_pmc_gemv_traffic.json"
+        try:     # rocprofv3 kernel-trace average of the same kernels inside the full decode step (committed summary of the static-batch trace)
+            insitu = json.load(open(os.path.join(ROOT, "profiles", "r03_gemv_in_situ.json")))["batch32" if B > 4 else "batch1"]
+        except Exception:  # noqa: BLE001
+            pass
         try:     # profiles/r02_pmc_gemv_traffic.json: FETCH_SIZE passes of this kernel family at batch 32 and batch 1 (tools/gpu_pmc_r2.sh)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_gemv_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             traffic = round(pmc["traffic_over_algorithmic_weighted_batch32" if B > 4 else "traffic_over_algorithmic_weighted_batch1"] * bytes_per_launch)
         except Exception:  # noqa: BLE001
             pass
@@ -338,7 +394,11 @@ def main():
             traffic = None       # the PMC calibration under profiles/ was taken on the bf16 stream
         roof = {"bound": "hbm", "kernel": f"k_gemv family at batch {B} (decode weight stream, all LM linears + LM head)" + (" [fp8 layer linears]" if args.fp8 else ""),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_ms * 1e3, 2),
+                "traffic": traffic, "traffic_source": (f"profiles/{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel family): measured "
+                                                       "traffic / algorithmic bytes ratio x the algorithmic bytes of one launch -- NOT measured in this run") if traffic else None,
+                "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_ms * 1e3, 2),
+                "avg_launch_us_source": "HIP events around the 145-launch sequence replayed on weight-sized operands, in this run",
+                "avg_launch_us_in_situ_rocprof": insitu,
                 "launches_per_decode_step": n_launch,
                 "decode_step_ms": round(decode_step_ms, 4) if decode_step_ms > 0 else None,
                 "decode_step_achieved_GBs": round((wl + wh + kv_bytes) / (decode_step_ms * 1e-3) / 1e9, 1) if decode_step_ms > 0 else None}
@@ -361,7 +421,7 @@ def main():
         phases["vit_mfma_frac"] = round(VIT_GFLOP * B / (vit_ms * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)
         phases["prefill_mfma_frac"] = round(PREFILL_GFLOP * B / (pre_ms * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)
         phases["forward_mfma_frac"] = round((VIT_GFLOP + PREFILL_GFLOP) * B / ((vit_ms + pre_ms) * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)
-        cpu = None
+        cpu = cpu_hf = None
         if world == 1 and not args.no_cpu_baseline:
             def dev_weight(name, shape, base):
                 # synthetic parameter from the device generator (bit-identical to oracle/weights.py, pinned by
@@ -374,6 +434,10 @@ def main():
                 return t.float().cpu().reshape(tuple(shape))
             eng.close()                   # the GPU is idle while the host cores are timed
             cpu = cpu_baseline(dev_weight)
+            try:
+                cpu_hf = cpu_baseline_hf_bf16()
+            except Exception as e_:  # noqa: BLE001  (transformers missing / too little host memory: reported, never fatal)
+                cpu_hf = {"value": None, "error": f"{type(e_).__name__}: {e_}"[:200]}
         cfg_name = None
         if args.tile == 448 and not args.fp8:
             cfg_name = "BASELINE.json configs[2]" if B == 32 and continuous else "BASELINE.json configs[1]" if B == 1 else None
@@ -395,7 +459,7 @@ def main():
                        "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",
                        "exchange": dict(exchange, payload="float32 logits all-gather per decode step (verification mode)" if args.gather_logits
                                         else "one all-gather of 1 KB result rows per tile and step")},
-            "roofline": roof, "cpu_baseline": cpu, "phase_ms_per_step": phases, "static_batch": static_ref, "latency_b1": latency,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_torch_bf16": cpu_hf, "phase_ms_per_step": phases, "static_batch": static_ref, "ragged": ragged, "latency_b1": latency,
             "weights_load_s": round(load_s, 1), "workspace_GB": round(eng.workspace_bytes / 1e9, 2),
             "result_checksum": int(res.sum().item()),
         }
@@ -453,6 +517,72 @@ def cpu_baseline(weight_source=None):
             "seconds_per_tile": round(total, 2),
             "phases_s": {"vit": round(vit_s, 2), "prefill": round(prefill_s, 2), "decode_127_steps": round(decode_s, 2),
                          "decode_s_per_step_measured": round((t3 - t2) / nd, 3)}}
+
+
+def cpu_baseline_hf_bf16():
+    """Library-grade CPU number beside the port: HF transformers' own Qwen2_5_VLForConditionalGeneration --
+    the module the reference's hf_infer strategy calls (/root/reference/roll/distributed/strategy/hf_strategy.py:49-94) -- in bf16
+    with sdpa attention on this host's cores, 3B geometry, random weights (values do not matter for the time), the same tile shape:
+    ViT + 448-token prefill + 16 decode steps through the KV cache (x 127 / 16 for a tile's decode)."""
+    from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLConfig
+    from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VLForConditionalGeneration
+    from socioreasoner_amd import hostops, synthetic
+    from socioreasoner_amd.config import geometry_3b
+    g = geometry_3b()
+    v, t = g.vision, g.text
+    c = Qwen2_5_VLConfig(
+        vision_config=dict(depth=v.depth, hidden_size=v.hidden_size, num_heads=v.num_heads, intermediate_size=v.intermediate_size,
+                           patch_size=v.patch_size, temporal_patch_size=v.temporal_patch_size, spatial_merge_size=v.spatial_merge_size,
+                           window_size=v.window_size, fullatt_block_indexes=list(v.fullatt_block_indexes), out_hidden_size=v.out_hidden_size,
+                           hidden_act="silu"),
+        text_config=dict(num_hidden_layers=t.num_hidden_layers, hidden_size=t.hidden_size, num_attention_heads=t.num_attention_heads,
+                         num_key_value_heads=t.num_key_value_heads, intermediate_size=t.intermediate_size, vocab_size=t.vocab_size,
+                         rms_norm_eps=t.rms_norm_eps, rope_parameters={"rope_type": "default", "rope_theta": t.rope_theta,
+                                                                       "mrope_section": list(t.mrope_section)},
+                         max_position_embeddings=32768, tie_word_embeddings=True, bos_token_id=None, eos_token_id=None),
+        image_token_id=g.image_token_id, video_token_id=g.image_token_id + 1, vision_start_token_id=g.vision_start_token_id,
+        vision_end_token_id=g.vision_end_token_id, tie_word_embeddings=True)
+    c._attn_implementation = "sdpa"
+    t0 = time.perf_counter()
+    with torch.device("meta"):
+        model = Qwen2_5_VLForConditionalGeneration(c)
+    model = model.to(torch.bfloat16).to_empty(device="cpu").eval()
+    with torch.no_grad():
+        for i_, p_ in enumerate(model.parameters()):     # finite, non-zero values: CPU GEMM time does not depend on them, a random fill of 3.75 G
+            p_.fill_(0.004 + 0.001 * (i_ % 7))            # elements would cost a minute of the run
+        for m_ in model.modules():           # rotary inv_freq buffers were emptied with the rest
+            if hasattr(m_, "inv_freq") and hasattr(m_, "original_inv_freq"):
+                inv, _ = m_.compute_default_rope_parameters(m_.config)
+                m_.inv_freq = inv.float()
+                m_.original_inv_freq = inv.float().clone()
+            elif hasattr(m_, "inv_freq") and hasattr(m_, "theta"):
+                m_.inv_freq = (1.0 / (m_.theta ** (torch.arange(0, m_.dim, 2, dtype=torch.float) / m_.dim))).float()
+    build_s = time.perf_counter() - t0
+    from oracle import host_ref as H          # (patchify of the baseline's input only)
+    pv, _ = H.patchify(synthetic.tile_pixels(0))
+    pv = torch.from_numpy(pv).to(torch.bfloat16)
+    ids = synthetic.tile_prompt(g, 0, GRID)
+    p3, _ = hostops.get_rope_index(torch.from_numpy(ids)[None], [GRID], None)
+    S, nd = len(ids), 16
+    grid_t = torch.tensor([list(GRID)])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        o = model(input_ids=torch.from_numpy(ids)[None], attention_mask=torch.ones(1, S, dtype=torch.long), position_ids=p3,
+                  pixel_values=pv, image_grid_thw=grid_t, use_cache=True)
+        t1 = time.perf_counter()
+        pkv, nxt, base = o.past_key_values, int(o.logits[0, -1].float().argmax()), int(p3.max()) + 1
+        for k in range(nd):
+            o = model(input_ids=torch.tensor([[nxt]]), attention_mask=torch.ones(1, S + k + 1, dtype=torch.long),
+                      position_ids=torch.full((3, 1, 1), base + k, dtype=torch.long), past_key_values=pkv, use_cache=True)
+            pkv, nxt = o.past_key_values, int(o.logits[0, -1].float().argmax())
+        t2 = time.perf_counter()
+    fwd_s, dec_s = t1 - t0, (N_NEW - 1) * (t2 - t1) / nd
+    return {"value": round(1.0 / (fwd_s + dec_s), 5), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "torch-bf16",
+            "sample": f"transformers Qwen2_5_VLForConditionalGeneration (what the reference's hf_infer strategy calls), bf16, sdpa, random weights, one synthetic "
+                      f"448x448 tile at FULL depth: ViT + 448-token prefill in one forward, {nd} decode steps through the KV cache measured (x 127 / {nd})",
+            "seconds_per_tile": round(fwd_s + dec_s, 2),
+            "phases_s": {"vit_plus_prefill": round(fwd_s, 2), "decode_127_steps": round(dec_s, 2), "decode_s_per_step_measured": round((t2 - t1) / nd, 4)},
+            "model_build_s": round(build_s, 1)}
 
 
 if __name__ == "__main__":

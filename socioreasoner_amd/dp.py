@@ -25,6 +25,11 @@ def shard_range(n: int, rank: int, world: int):
     return start, start + sizes[rank]
 
 
+# ranks 1..N-1 of the bench wait in a barrier while rank 0 alone times the static reference, the batch-1 run and the CPU baselines
+# (a minute or two): the collective timeout must not be what ends that wait
+_PG_TIMEOUT = __import__("datetime").timedelta(minutes=30)
+
+
 def init_distributed(backend: str | None = None):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).  Returns (rank, world, local_rank).
 
@@ -53,11 +58,11 @@ def init_distributed(backend: str | None = None):
             if torch.cuda.device_count() < world:
                 raise RuntimeError(f"backend nccl (RCCL) needs one GPU per rank: {world} ranks, {torch.cuda.device_count()} GPU(s)")
             torch.cuda.set_device(local)
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"), timeout=_PG_TIMEOUT)
         else:
             if have_gpu:      # more ranks than GPUs: share the devices, exchange over gloo
                 local = local % torch.cuda.device_count()
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=_PG_TIMEOUT)
     return rank, world, local
 
 

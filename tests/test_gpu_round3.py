@@ -143,3 +143,47 @@ def test_attention_v2_equals_round2_kernel_bit_for_bit(monkeypatch, hw):
         assert torch.equal(x, y), (what, float((x.float() - y.float()).abs().max()))
     assert torch.isfinite(b[1]).all()
     e.close()
+
+
+def test_abort_frees_the_row_at_once():
+    """ABORT of a RUNNING request (reference vllm_strategy.py:188-193): the row stops between two decode chunks, the next poll hands row
+    and KV slot to the waiting request, the aborted request reports nothing, the other requests decode exactly what they decode
+    without the aborted neighbour."""
+    from socioreasoner_amd import hostops, synthetic
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.engine import Engine
+    from socioreasoner_amd.serving import ContinuousBatcher, Request
+    geom = geometry_tiny()
+    e = Engine(geom, max_patches=256, max_prefill_tokens=256, max_batch=2, max_ctx=192, max_new_tokens=64)
+    e.load_synthetic_weights(seed=0)
+
+    def req(i, max_new):
+        ids = np.random.default_rng(50 + i).integers(0, 200, 20 + i).astype(np.int64)
+        pos3, _ = hostops.get_rope_index(torch.from_numpy(ids)[None], None, None)
+        return Request(ids=ids, pos3=pos3[:, 0].numpy(), max_new=max_new, tag=i)
+
+    def serve(abort_first):
+        cb = ContinuousBatcher(e, eos=[], pad_id=0, steps_per_poll=4)
+        a, b, c = req(0, 64), req(1, 64), req(2, 8)
+        for r in (a, b, c):
+            cb.submit(r)
+        done, order = {}, []
+        cb.pump(lambda r, t: (done.__setitem__(r.tag, t), order.append(r.tag)))     # a and b are running, c waits for a row
+        assert len(cb.active) == 2 and len(cb.pending) == 1
+        if abort_first:
+            assert cb.abort(lambda r: r.tag == 0) == 1
+        pumps = 0
+        while not cb.idle():
+            cb.pump(lambda r, t: (None if r.aborted else (done.__setitem__(r.tag, t), order.append(r.tag))))
+            pumps += 1
+            if abort_first and pumps == 1:
+                assert 0 not in [r.tag for r in cb.active.values()], "the aborted row must be free after ONE poll"
+        return done, order, pumps
+
+    clean, order0, _ = serve(False)
+    got, order1, pumps = serve(True)
+    assert 0 not in got and got[1] == clean[1] and got[2] == clean[2]
+    assert len(clean[1]) == 64 and len(clean[2]) == 8
+    assert order1 == [2, 1], order1           # c took the aborted row and finished long before b; without the abort it waits for a row
+    assert order0[-1] == 2
+    e.close()
