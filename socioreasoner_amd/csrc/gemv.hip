@@ -33,7 +33,9 @@ __device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(b
 // WAVES = 4 : the dispatched configuration -- many small blocks, K split over the 4 waves.
 // STAGE     : x (optionally + pending residual slabs, optionally RMS-normalised) is prepared in LDS by the prologue
 //             (used for batches <= 4, where the prologue is a few KB per block).
-template <int MODE, int MT, int KP, bool STAGE, int WAVES, bool F8 = false>
+// XN        : x (fragment-ordered, raw residual stream) is RMS-normalised in registers right before it is multiplied: the row scales come
+//             from per-(16-column tile, row) partial sums of squares the producing GEMV's epilogue wrote (GemvArgs.ss_in)
+template <int MODE, int MT, int KP, bool STAGE, int WAVES, bool F8 = false, bool XN = false>
 __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;     // 16-row W tiles per wave
     constexpr int TPB = WAVES / KP;                    // wave-tiles per block
@@ -54,7 +56,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     // waits for the oldest slot.  The first fills do not depend on x: they go out before the prologue's second pass.
     // F8: the stream is the fp8 image (1 KB per 16 x 64 block): ONE 16-byte load per lane and chunk, widened to the two
     // bf16 MFMA operands at consume time (exact), the per-channel scale multiplies the float32 accumulator.
-    constexpr int U = ((F8 && STAGE) ? 16 : 8) / T;      // x rides the ring in registers when it is not staged: keep it short there
+    constexpr int U = ((F8 && STAGE) ? 16 : (WAVES >= 16 && MT == 2) ? 4 : 8) / T;      // x rides the ring in registers when it is not staged: keep it short there
+                                                             // (16-wave blocks get 128 registers per lane: half the ring at 32 batch rows)
     constexpr int WL = F8 ? 1 : 2;
     u32x4 w[U][T][WL];
     const int cend = min(c0 + per, nchunks);
@@ -210,6 +213,39 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // XN: 1 / rms of the rows this lane multiplies (m = fr and 16 + fr).  The partial sums [n_ss][32] are added in a fixed order: lane
+    // (tg = lane / 8, rq = lane % 8) sums tiles tg, tg + 8, ... for rows 4 rq .. 4 rq + 3, then the 8 lane groups are combined
+    float xn_rs[MT];
+    if constexpr (XN) {
+        const int tg = lane >> 3, rq = lane & 7;
+        float4 a4 = float4{0.f, 0.f, 0.f, 0.f};
+        for (int j = tg; j < p.n_ss; j += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(p.ss_in + (size_t)j * 32 + rq * 4);
+            a4.x += v.x; a4.y += v.y; a4.z += v.z; a4.w += v.w;
+        }
+#pragma unroll
+        for (int o = 8; o <= 32; o <<= 1) {
+            a4.x += __shfl_xor(a4.x, o, 64); a4.y += __shfl_xor(a4.y, o, 64); a4.z += __shfl_xor(a4.z, o, 64); a4.w += __shfl_xor(a4.w, o, 64);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mt * 16 + fr, src = m >> 2;          // lane src (any tg) holds rows 4 src .. 4 src + 3
+            const float s0 = __shfl(a4.x, src, 64), s1 = __shfl(a4.y, src, 64), s2 = __shfl(a4.z, src, 64), s3 = __shfl(a4.w, src, 64);
+            const float ssum = (m & 3) == 0 ? s0 : (m & 3) == 1 ? s1 : (m & 3) == 2 ? s2 : s3;
+            xn_rs[mt] = 1.0f / sqrtf(ssum / (float)p.K + p.eps);
+        }
+    }
+    // XN: x_norm = bf16(w * bf16(x * rs))  (hf:65-79), 8 values at a time
+    auto xnorm8 = [&](u32x4 xr, u32x4 wr, float rs) -> u32x4 {
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = rbf(lo16(xr[q]) * rs), b = rbf(hi16(xr[q]) * rs);
+            o[q] = pack2(lo16(wr[q]) * a, hi16(wr[q]) * b);
+        }
+        return o;
+    };
+
     if (active) {
         const bf16_t* xrow[MT];
         bool xok[MT];
@@ -252,6 +288,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                     constexpr int xu_static = 0;
                     const int xu = STAGE ? xu_static : u;
                     if constexpr (STAGE) fill_x(0, c + u);
+                    if constexpr (XN) {          // the lane's 16 k of this chunk: k = (c + u) * 64 + fg * 16 + 0 .. 15 (two 8-runs = the two k-steps)
+                        const bf16_t* wn = p.xn_w + (size_t)(c + u) * 64 + fg * 16;
+                        const u32x4 w0 = *reinterpret_cast<const u32x4*>(wn), w1 = *reinterpret_cast<const u32x4*>(wn + 8);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            xv[u][mt][0] = xnorm8(xv[u][mt][0], w0, xn_rs[mt]);
+                            xv[u][mt][1] = xnorm8(xv[u][mt][1], w1, xn_rs[mt]);
+                        }
+                    }
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
                         u32x4 w0, w1;
@@ -324,8 +369,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     }
     float bestv[MT];
     int besti[MT];
+    float ss_row[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { bestv[mt] = -INFINITY; besti[mt] = 0x7fffffff; }
+    for (int mt = 0; mt < MT; ++mt) { bestv[mt] = -INFINITY; besti[mt] = 0x7fffffff; ss_row[mt] = 0.f; }
     if (active && kp == 0) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -355,7 +401,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                     o[0] = lo16(rv.x) + rbf(o[0]); o[1] = hi16(rv.x) + rbf(o[1]);
                     o[2] = lo16(rv.y) + rbf(o[2]); o[3] = hi16(rv.y) + rbf(o[3]);
                 }
-                *reinterpret_cast<uint2*>(optr) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                const uint2 packed = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                *reinterpret_cast<uint2*>(optr) = packed;
+                if constexpr (MODE == GV_RESID) {
+                    if (p.h_tiled) {      // the consumer GEMV normalises on the fly: fragment-ordered copy + this tile's share of the row's sum of squares
+                        *reinterpret_cast<uint2*>(p.h_tiled + tiled_offset((size_t)m, (size_t)n, (size_t)p.ldo)) = packed;
+                        const float h0 = lo16(packed.x), h1 = hi16(packed.x), h2 = lo16(packed.y), h3 = hi16(packed.y);
+                        ss_row[mt] = (h0 * h0 + h1 * h1) + (h2 * h2 + h3 * h3);
+                    }
+                }
             } else {
                 const int n = tile * 16 + fg * 4;
                 float* o = reinterpret_cast<float*>(p.out) + ((size_t)(MODE == GV_PARTIAL ? blockIdx.y : 0) * p.M + m) * p.N + n;
@@ -365,6 +419,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                     for (int r = 0; r < 4; ++r)
                         if (acc[0][mt][r] > bestv[mt]) { bestv[mt] = acc[0][mt][r]; besti[mt] = n + r; }
                 }
+            }
+        }
+    }
+    if constexpr (MODE == GV_RESID) {
+        if (p.h_tiled && active && kp == 0) {      // (whole wave: the four lane groups of a row hold its four column quads)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float v = ss_row[mt];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (fg == 0 && mt * 16 + fr < 32) p.ss_out[(size_t)tile * 32 + mt * 16 + fr] = (mt * 16 + fr < p.M) ? v : 0.f;
             }
         }
     }
@@ -561,7 +626,7 @@ int launch_32(hipStream_t s, const GemvArgs& a) {
 
 size_t stage_bytes(const GemvArgs& a) { return ((size_t)a.M * (a.K + 8) * 2 + 15) / 16 * 16; }
 
-template <int MODE, int MT, int KP, bool STAGE, int WAVES, bool F8 = false>
+template <int MODE, int MT, int KP, bool STAGE, int WAVES, bool F8 = false, bool XN = false>
 int launch_k(hipStream_t s, const GemvArgs& a) {
     constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;
     constexpr int TPB = WAVES / KP;
@@ -578,12 +643,12 @@ int launch_k(hipStream_t s, const GemvArgs& a) {
     if (smem > 160 * 1024) return -12;
     static size_t attr = 0;
     if (smem > 64 * 1024 && smem > attr) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemv<MODE, MT, KP, STAGE, WAVES, F8>),
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemv<MODE, MT, KP, STAGE, WAVES, F8, XN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (r != hipSuccess) return (int)r;
         attr = smem;
     }
-    hipLaunchKernelGGL((k_gemv<MODE, MT, KP, STAGE, WAVES, F8>), grid, dim3(WAVES * 64), smem, s, a, ntiles);
+    hipLaunchKernelGGL((k_gemv<MODE, MT, KP, STAGE, WAVES, F8, XN>), grid, dim3(WAVES * 64), smem, s, a, ntiles);
     SR_CHECK_LAUNCH();
     return 0;
 }
@@ -594,6 +659,15 @@ bool can_stage(const GemvArgs& a) { return a.K % 512 == 0 && stage_bytes(a) + 10
 // 29 us): a CU ingests only ~50-100 GB/s, so a serial 128-640 KB prologue per block costs more than the x re-reads it
 // saves, and only 172 of 256 CUs get a block.  Kept as a template parameter for experiments; not dispatched.
 bool use_big(const GemvArgs&, int) { return false; }
+
+// wide blocks (tuning hook SR_GEMV_W = 8 / 16, and GemvArgs.waves): ONE 16-row tile per block, K split over all of its waves.  For
+// N = 2048 outputs (o_proj, down-projection) that is still 128 blocks, but 2 - 4 x the loads in flight per CU, and the down-projection
+// needs no split over blocks (no float32 slabs, residual add in the epilogue)
+template <int MODE, int W>
+int launch_wide(hipStream_t s, const GemvArgs& a) {
+    if (a.K / 64 < 2 * W) return -22;
+    return a.M <= 16 ? launch_k<MODE, 1, W, false, W>(s, a) : launch_k<MODE, 2, W, false, W>(s, a);
+}
 
 template <int MODE, int KP, bool F8 = false>
 int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
@@ -612,6 +686,7 @@ int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
 bool use_32(const GemvArgs& a, int mode) {
     static const char* env = getenv("SR_GEMV32");               // tuning hook (tools/bench_gemv.py): 0 = never, 2 = always
     const int force = env ? atoi(env) : 1;
+    if (a.h_tiled || a.xn_w) return false;                      // the folded RMSNorm lives in the 16-row kernel only
     if (a.force32 && a.N % 32 == 0 && !a.norm_w) return true;
     if (force == 0 || a.M <= 16 || a.N % 32 != 0 || a.norm_w) return false;
     return force == 2 || mode == GV_F32 || (mode == GV_PARTIAL && a.ksplit >= 4);
@@ -650,6 +725,12 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     if (a.n_slabs > 0 && (!a.norm_w || !a.slabs || !a.x_out)) return -22;
     if (a.x_tiled && a.norm_w) return -22;                   // fragment-ordered x: the un-staged paths only
     if (a.out_tiled && (mode != GV_SWIGLU || (a.N / 2) % 64 != 0)) return -22;
+    if (a.xn_w) {        // on-the-fly RMSNorm of a fragment-ordered x (round 3): the 4-wave, K-split-by-4 bf16 kernels of the batch > 4 decode layer
+        if (!a.x_tiled || a.norm_w || a.W8 || !a.ss_in || a.n_ss < 1 || a.M > 32 || a.K / 64 < 8 || !(mode == GV_SWIGLU || mode == GV_BIAS)) return -22;
+        if (mode == GV_SWIGLU) return a.M <= 16 ? launch_k<GV_SWIGLU, 1, 4, false, 4, false, true>(s, a) : launch_k<GV_SWIGLU, 2, 4, false, 4, false, true>(s, a);
+        return a.M <= 16 ? launch_k<GV_BIAS, 1, 4, false, 4, false, true>(s, a) : launch_k<GV_BIAS, 2, 4, false, 4, false, true>(s, a);
+    }
+    if (a.h_tiled && (mode != GV_RESID || !a.ss_out || a.W8 || a.M > 32)) return -22;
     int want = mode == GV_F32 ? 1 : 4;
     static const char* kp_env = getenv("SR_GEMV_KP");          // tuning hook for tools/bench_gemv.py
     if (kp_env && mode != GV_F32) want = atoi(kp_env);
@@ -664,6 +745,24 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
             case GV_RESID: return launch_small<GV_RESID, 4, true>(s, a);
         }
         return -22;
+    }
+    {
+        const char* w_env = getenv("SR_GEMV_W");                 // tuning hook, read at every call
+        const int w = a.waves ? a.waves : (w_env ? atoi(w_env) : 0);
+        if ((w == 8 || w == 16) && !a.norm_w && mode != GV_F32 && (mode != GV_PARTIAL || a.ksplit == 1) && a.K / 64 >= 2 * w) {
+            if (w == 8) switch (mode) {
+                case GV_PARTIAL: return launch_wide<GV_PARTIAL, 8>(s, a);
+                case GV_SWIGLU: return launch_wide<GV_SWIGLU, 8>(s, a);
+                case GV_BIAS: return launch_wide<GV_BIAS, 8>(s, a);
+                case GV_RESID: return launch_wide<GV_RESID, 8>(s, a);
+            }
+            else switch (mode) {
+                case GV_PARTIAL: return launch_wide<GV_PARTIAL, 16>(s, a);
+                case GV_SWIGLU: return launch_wide<GV_SWIGLU, 16>(s, a);
+                case GV_BIAS: return launch_wide<GV_BIAS, 16>(s, a);
+                case GV_RESID: return launch_wide<GV_RESID, 16>(s, a);
+            }
+        }
     }
     if (use_32(a, mode)) {
         switch (mode) {
