@@ -203,8 +203,8 @@ __global__ __launch_bounds__(256) void k_attn_prefill(AttnArgs p) {
 //     counted by hand: 2 DMA instructions per wave and pass-1 step (K), 4 per pass-2 step (K + V^T), nothing else in the loop
 //     touches vmcnt (no spills: checked with -Rpass-analysis=kernel-resource-usage);
 //   * LDS rows keep a power-of-two pitch and the 16-byte chunk index is XOR-swizzled on the SOURCE side (LDS-DMA writes linearly):
-//     K rows 256 B, chunk ^ (row & 15) -> conflict-free ds_read_b128 fragments; V^T rows 128 B, chunk ^ vt_swz(row) -> ds_read2_b64
-//     pairs (2-way conflicts, see vt_swz).  head_dim 80 uses the same 256-B K pitch; its pad chunks (d 80..95 of the 96-wide MFMA k range) are zeroed
+//     K rows 256 B, chunk ^ (row & 15) -> conflict-free ds_read_b128 fragments; V^T rows 128 B, chunk ^ vt_swz(row) -> conflict-free
+//     ds_read_b64 pairs (see vt_swz).  head_dim 80 uses the same 256-B K pitch; its pad chunks (d 80..95 of the 96-wide MFMA k range) are zeroed
 //     once and never written again (masked-off DMA lanes);
 //   * blocks are dealt to XCDs in contiguous runs of (work item, head group, sub-tile), so the K / V of a sequence stay in ONE XCD's L2.
 // Keys past the end of a sequence: K rows are clamped (their scores are masked); V^T columns are read as they are -- P is exactly 0
@@ -212,11 +212,13 @@ __global__ __launch_bounds__(256) void k_attn_prefill(AttnArgs p) {
 // created, and only ever stores finite bf16 values into them).
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// V^T tile swizzle: 16-byte chunk (8 keys) c of row d is stored at chunk c ^ vt_swz(d).  Only chunk bits 0 and 2 are touched, so the two
-// 4-key runs a lane feeds to one P.V MFMA (32 B apart: chunk bit 1) keep a CONSTANT distance and load as one ds_read2_b64 into four
-// consecutive registers -- with the full 3-bit swizzle the pair was assembled by 48 v_mov per step, 8 % of an issue-bound kernel's
-// instructions.  Price: 2-way instead of conflict-free b64 reads (rows d and d + 8 share their slots); LDS is not what bounds the kernel.
-__device__ __forceinline__ int vt_swz(int d) { return ((d >> 1) & 1) | (((d >> 2) & 1) << 2); }
+// V^T tile swizzle: 16-byte chunk (8 keys) c of row d is stored at chunk c ^ vt_swz(d): with 128-byte rows the 16 rows x 2 halves a
+// 32-lane group reads as ds_read_b64 land in 32 distinct 8-byte bank slots only if all three chunk bits are swizzled.
+// Measured alternative (round 3): swizzling bits 0 and 2 only keeps a lane's two 4-key runs at a constant 32 bytes, so the pair loads as
+// ONE ds_read2_b64 into four consecutive registers and the 48 v_mov per step that assemble the MFMA operand disappear (VALU
+// instructions 40 M -> 30 M per launch) -- but the reads are then 2-way conflicted, SQ_LDS_BANK_CONFLICT triples (7.3 M -> 22 M),
+// SQ_WAIT_INST_LDS goes 6.9 M -> 31.7 M and the kernel 118 -> 140 us (LM), 610 -> 705 us (ViT full).  Conflict-free wins.
+__device__ __forceinline__ int vt_swz(int d) { return (d >> 1) & 7; }
 
 // one LDS-DMA instruction: 64 lanes x 16 B from gbase + voff (bytes, per lane) to LDS [lds_dst, lds_dst + 1 KB), invisible to hipcc's
 // waitcnt bookkeeping (MI355X guide 5.7: M0 is written in the statement that uses it and restored)
@@ -405,10 +407,10 @@ __global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_unit
 #pragma unroll
                 for (int dt = 0; dt < C::DT; ++dt) {
                     const int d = dt * 16 + fr;
-                    const int c0 = kb * 4 + (fg >> 1);                                           // bit 1 of c0 is clear and vt_swz() leaves it alone:
-                    const unsigned char* vr = vs + d * 128 + (fg & 1) * 8 + ((c0 ^ vt_swz(d)) << 4);   // the second run sits exactly 32 B behind the first
-                    uint2 v0 = *reinterpret_cast<const uint2*>(vr);             // keys kb*32 + fg*4 .. +3
-                    uint2 v1 = *reinterpret_cast<const uint2*>(vr + 32);        // keys kb*32 + 16 + fg*4 .. +3   (one ds_read2_b64: 4 consecutive registers)
+                    const unsigned char* vr = vs + d * 128 + (fg & 1) * 8;
+                    const int sw = vt_swz(d), c0 = kb * 4 + (fg >> 1);
+                    uint2 v0 = *reinterpret_cast<const uint2*>(vr + ((c0 ^ sw) << 4));          // keys kb*32 + fg*4 .. +3
+                    uint2 v1 = *reinterpret_cast<const uint2*>(vr + (((c0 + 2) ^ sw) << 4));    // keys kb*32 + 16 + fg*4 .. +3
                     const bf16x8 vf = __builtin_bit_cast(bf16x8, uint4{v0.x, v0.y, v1.x, v1.y});
                     oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
                 }
