@@ -196,6 +196,34 @@ int sr_render_overlay(uint8_t* dev_img_rgb, int h, int w, const uint8_t* dev_mas
  * Flag bits OR-ed into `epilogue` / `mode`: 0x100 W fragment-ordered (tiled16x64); sr_op_gemm: 0x200 / 0x400 force the 256- /
  * 128-tile kernel; sr_op_gemv*: 0x800 x fragment-ordered (tiled16x64 of a [ceil16(M), K] matrix), 0x1000 SwiGLU output
  * fragment-ordered. */
+/* ---- SAM2 (Hiera-L) image path behind seg_infer -- /root/reference/roll/distributed/strategy/seg_strategy.py:47-60 calls
+ * SAM2ImagePredictor.set_image / predict; the network (transformers/models/sam2/modeling_sam2.py = the sam2 package's) is driven from
+ * socioreasoner_amd/sam2.py through sr_op_gemm, sr_op_attention and the passes below.  Token matrices are bf16 [rows][ld], channel-last.
+ *   sr_op_attention : softmax(q k^T * scale) v per work item (struct {int q_row0, seq_len, q_off, k_row0; int64 vt_off; int q_len, pad}
+ *                     on the device, one item per q_tile queries of a sequence / window); V is passed TRANSPOSED ([head*hd + d][key]).
+ *                     head_dim 16 / 32 / 80 / 128 (72 runs as 80 with zero channels).  v2_ok: vt key runs are 16-byte aligned and finite.
+ *   sr_op_sam_preprocess : uint8 HWC -> bf16 CHW [3][S][S], /255, bilinear resize, ImageNet normalisation.
+ *   sr_op_im2col    : k x k / stride / pad windows of a CHW image -> GEMM operand rows (optional destination row map).
+ *   sr_op_layernorm : LayerNorm with bias over C channels, pad columns [C, ldo) zeroed.
+ *   sr_op_maxpool_win : 2 x 2 max pooling of tokens stored window by window.
+ *   sr_op_ew        : mode 0 a + b, 1 a + row vector, 2 relu, 3 gelu (erf).
+ *   sr_op_transpose : out[c][r] = in[r][c].
+ *   sr_op_upsample2x_add : FPN top-down step.   sr_op_pixel_shuffle_add : second half of a 2 x 2 / stride 2 transposed convolution.
+ *   sr_op_mask_resize_or : best (arg-max score) of n low-resolution logit maps, bilinear to h x w, > 0, OR into the object union.
+ *   sr_op_gather_rows : out[i] = in[rows[i]]. */
+int sr_op_attention(const void* q, int q_stride, const void* k, int k_stride, long long k_head_stride, const void* vt, int vt_stride,
+                    long long vt_head_stride, void* out, int out_stride, const void* dev_work, int n_work, int n_heads, int group, float scale,
+                    int causal, int head_dim, int q_tile, int v2_ok, void* stream);
+int sr_op_sam_preprocess(const uint8_t* img, int h, int w, void* out_chw, int S, void* stream);
+int sr_op_im2col(const void* chw, int S, int k, int stride, int pad, void* out, int ld, const int32_t* rowmap, void* stream);
+int sr_op_layernorm(const void* x, int ldx, const void* w, const void* b, void* out, int ldo, int rows, int C, float eps, void* stream);
+int sr_op_maxpool_win(const void* in, int ld_in, int C, int n_win, int ws, void* out, int ld_out, void* stream);
+int sr_op_ew(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int rows, int C, int mode, void* stream);
+int sr_op_transpose(const void* in, int ld_in, int rows, int cols, void* out, int ld_out, void* stream);
+int sr_op_upsample2x_add(const void* lat, const void* top, void* out, int H2, int C, int ld, void* stream);
+int sr_op_pixel_shuffle_add(const void* g, int ldg, const void* feat, int ldf, void* out, int ldo, int W, int Co, void* stream);
+int sr_op_mask_resize_or(const float* low, int ld, int col0, int n, int m, const float* score, uint8_t* acc, float* logits_out, int h, int w, void* stream);
+int sr_op_gather_rows(const void* in, const int32_t* rows, void* out, int n, int H, void* stream);
 int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void* out, int ldo, const void* bias,
                const void* resid, const int32_t* rowmap, int epilogue, void* stream);
 /* fp8 x fp8 prefill GEMM on the block-scaled MFMA (BASELINE.json configs[4]): sr_op_quant_mx quantises bf16 activations [M][ldx] to

@@ -57,8 +57,9 @@ __global__ __launch_bounds__(256) void k_attn_prefill(AttnArgs p) {
 
     const int q_local = wave * 16 + fr;                     // query index inside the tile
     const int qpos = wk.q_off + q_local;                    // position inside the sequence
-    const bool q_valid = qpos < wk.seq_len;
-    const int q_rows_valid = min(QT, wk.seq_len - wk.q_off);
+    const int q_len = wk.q_len > 0 ? wk.q_len : wk.seq_len;      // (pooled queries: fewer queries than keys)
+    const bool q_valid = qpos < q_len;
+    const int q_rows_valid = min(QT, q_len - wk.q_off);
     const bf16_t* qptr = p.q + (size_t)(wk.q_row0 + min(q_local, q_rows_valid - 1)) * p.q_stride + h * HD;
 
     bf16x8 qf[C::KS];
@@ -256,7 +257,8 @@ __global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_unit
     const AttnWork wk0 = p.work[unit / (Y * subs)];
     const int h0 = ((unit / subs) % Y) * NH, sub = unit % subs;
     const int q_off = wk0.q_off + sub * QTB;
-    if (q_off >= wk0.seq_len) return;           // the work item's last sub-tiles may be empty
+    const int q_len = wk0.q_len > 0 ? wk0.q_len : wk0.seq_len;
+    if (q_off >= q_len) return;                 // the work item's last sub-tiles may be empty
     const int q_row0 = wk0.q_row0 + sub * QTB, seq_len = wk0.seq_len;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
@@ -264,8 +266,8 @@ __global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_unit
 
     const int q_local = (wave % QW) * 16 + fr;
     const int qpos = q_off + q_local;
-    const bool q_valid = qpos < seq_len;
-    const int q_rows_valid = min(QTB, seq_len - q_off);
+    const bool q_valid = qpos < q_len;
+    const int q_rows_valid = min(QTB, q_len - q_off);
     const bf16_t* qptr = p.q + (size_t)(q_row0 + min(q_local, q_rows_valid - 1)) * p.q_stride + h * HD;
     bf16x8 qf[C::KS];
 #pragma unroll
@@ -748,6 +750,8 @@ int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim) {
     if (head_dim == 80 && !a.causal) hipLaunchKernelGGL((k_attn_prefill<80, false>), grid, block, 0, s, a);
     else if (head_dim == 128 && a.causal) hipLaunchKernelGGL((k_attn_prefill<128, true>), grid, block, 0, s, a);
     else if (head_dim == 128 && !a.causal) hipLaunchKernelGGL((k_attn_prefill<128, false>), grid, block, 0, s, a);
+    else if (head_dim == 16 && !a.causal) hipLaunchKernelGGL((k_attn_prefill<16, false>), grid, block, 0, s, a);      // SAM2 mask decoder: cross attention
+    else if (head_dim == 32 && !a.causal) hipLaunchKernelGGL((k_attn_prefill<32, false>), grid, block, 0, s, a);      //                    token self-attention
     else return -22;
     SR_CHECK_LAUNCH();
     return 0;

@@ -1494,6 +1494,44 @@ int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void*
                (epilogue & 0x200) ? 256 : (epilogue & 0x400) ? 128 : 0};      // bits 9 / 10: force the 256- / 128-tile kernel
     SR_WRAP(launch_gemm((hipStream_t)stream, a, epilogue & 0xff));
 }
+// ---- SAM2 image path (socioreasoner_amd/sam2.py drives these; shapes and layouts: sam.hip, attention.hip)
+int sr_op_attention(const void* q, int q_stride, const void* k, int k_stride, long long k_head_stride, const void* vt, int vt_stride,
+                    long long vt_head_stride, void* out, int out_stride, const void* dev_work, int n_work, int n_heads, int group, float scale,
+                    int causal, int head_dim, int q_tile, int v2_ok, void* stream) {
+    AttnArgs a{(const bf16_t*)q, q_stride, (const bf16_t*)k, k_stride, k_head_stride, (const bf16_t*)vt, vt_stride, vt_head_stride,
+               (bf16_t*)out, out_stride, (const AttnWork*)dev_work, n_work, n_heads, group, scale, causal, q_tile, v2_ok};
+    SR_WRAP(launch_attn_prefill((hipStream_t)stream, a, head_dim));
+}
+int sr_op_sam_preprocess(const uint8_t* img, int h, int w, void* out_chw, int S, void* stream) {
+    SR_WRAP(launch_sam_preprocess((hipStream_t)stream, img, h, w, (bf16_t*)out_chw, S));
+}
+int sr_op_im2col(const void* chw, int S, int k, int stride, int pad, void* out, int ld, const int32_t* rowmap, void* stream) {
+    SR_WRAP(launch_im2col((hipStream_t)stream, (const bf16_t*)chw, S, k, stride, pad, (bf16_t*)out, ld, rowmap));
+}
+int sr_op_layernorm(const void* x, int ldx, const void* w, const void* b, void* out, int ldo, int rows, int C, float eps, void* stream) {
+    SR_WRAP(launch_layernorm((hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out, ldo, rows, C, eps));
+}
+int sr_op_maxpool_win(const void* in, int ld_in, int C, int n_win, int ws, void* out, int ld_out, void* stream) {
+    SR_WRAP(launch_maxpool_win((hipStream_t)stream, (const bf16_t*)in, ld_in, C, n_win, ws, (bf16_t*)out, ld_out));
+}
+int sr_op_ew(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int rows, int C, int mode, void* stream) {
+    SR_WRAP(launch_ew((hipStream_t)stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)out, ldo, rows, C, mode));
+}
+int sr_op_transpose(const void* in, int ld_in, int rows, int cols, void* out, int ld_out, void* stream) {
+    SR_WRAP(launch_transpose((hipStream_t)stream, (const bf16_t*)in, ld_in, rows, cols, (bf16_t*)out, ld_out));
+}
+int sr_op_upsample2x_add(const void* lat, const void* top, void* out, int H2, int C, int ld, void* stream) {
+    SR_WRAP(launch_upsample2x_add((hipStream_t)stream, (const bf16_t*)lat, (const bf16_t*)top, (bf16_t*)out, H2, C, ld));
+}
+int sr_op_pixel_shuffle_add(const void* g, int ldg, const void* feat, int ldf, void* out, int ldo, int W, int Co, void* stream) {
+    SR_WRAP(launch_pixel_shuffle_add((hipStream_t)stream, (const bf16_t*)g, ldg, (const bf16_t*)feat, ldf, (bf16_t*)out, ldo, W, Co));
+}
+int sr_op_mask_resize_or(const float* low, int ld, int col0, int n, int m, const float* score, uint8_t* acc, float* logits_out, int h, int w, void* stream) {
+    SR_WRAP(launch_mask_resize_or((hipStream_t)stream, low, ld, col0, n, m, score, acc, logits_out, h, w));
+}
+int sr_op_gather_rows(const void* in, const int32_t* rows, void* out, int n, int H, void* stream) {
+    SR_WRAP(launch_gather_rows((hipStream_t)stream, (const bf16_t*)in, rows, (bf16_t*)out, n, H));
+}
 int sr_op_quant_mx(const void* x, int ldx, int M, int K, void* q, void* scales, int rows_pad, void* stream) {
     SR_WRAP(launch_quant_mx_act((hipStream_t)stream, (const bf16_t*)x, ldx, M, K, (unsigned char*)q, (unsigned char*)scales, rows_pad));
 }

@@ -95,7 +95,8 @@ int gemv_f32_block_rows(int N, int M, int K, int has_norm);   // vocabulary rows
 // ------------------------------------------------------------------ attention.hip
 // one 64-query tile of one sequence.  K element (kvh, key j, d) = k[(k_row0 + j)*k_stride + kvh*k_head_stride + d];
 // V^T element (kvh, d, key j) = vt[vt_off + kvh*vt_head_stride + d*vt_stride + j]
-struct AttnWork { int q_row0; int seq_len; int q_off; int k_row0; long long vt_off; };
+struct AttnWork { int q_row0; int seq_len; int q_off; int k_row0; long long vt_off;
+                  int q_len; int pad_; };   // q_len: queries of the sequence when they are fewer than its keys (Hiera's pooled queries); 0 = seq_len
 struct AttnArgs {
     const bf16_t* q; int q_stride;        // element (row, h*HD + d) at q[row*q_stride + h*HD + d]
     const bf16_t* k; int k_stride; long long k_head_stride;
@@ -211,6 +212,17 @@ int launch_synth_fill(hipStream_t s, bf16_t* out, long long n, uint32_t key, flo
 int launch_fill_zero(hipStream_t s, void* p, size_t bytes);
 int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, long long cols, bf16_t* dst, long long dst_ld,
                   int mode, long long row_off, int tiled);
+
+// ------------------------------------------------------------------ sam.hip (SAM2 image path: the passes between its GEMMs and attention launches)
+int launch_sam_preprocess(hipStream_t s, const uint8_t* img, int h, int w, bf16_t* out_chw, int S);
+int launch_im2col(hipStream_t s, const bf16_t* chw, int S, int k, int stride, int pad, bf16_t* out, int ld, const int* rowmap);
+int launch_layernorm(hipStream_t s, const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, int ldo, int rows, int C, float eps);
+int launch_maxpool_win(hipStream_t s, const bf16_t* in, int ld_in, int C, int n_win, int ws, bf16_t* out, int ld_out);
+int launch_ew(hipStream_t s, const bf16_t* a, int lda, const bf16_t* b, int ldb, bf16_t* out, int ldo, int rows, int C, int mode);
+int launch_transpose(hipStream_t s, const bf16_t* in, int ld_in, int rows, int cols, bf16_t* out, int ld_out);
+int launch_upsample2x_add(hipStream_t s, const bf16_t* lat, const bf16_t* top, bf16_t* out, int H2, int C, int ld);
+int launch_pixel_shuffle_add(hipStream_t s, const bf16_t* g, int ldg, const bf16_t* feat, int ldf, bf16_t* out, int ldo, int W, int Co);
+int launch_mask_resize_or(hipStream_t s, const float* low, int ld, int col0, int n, int m, const float* score, uint8_t* acc, float* logits_out, int h, int w);
 
 // ------------------------------------------------------------------ raster.hip
 int launch_mask_union(hipStream_t s, uint8_t* acc, const uint8_t* m, size_t n);

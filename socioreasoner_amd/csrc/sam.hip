@@ -1,0 +1,207 @@
+// HBM-bound kernels of the SAM2 (Hiera-L) image path behind seg_infer (SURVEY.md "next" row N1, reference call site
+// /root/reference/roll/distributed/strategy/seg_strategy.py:47-60; arithmetic: transformers/models/sam2/modeling_sam2.py, "hf:").
+// The matrix work of that network runs on the MFMA kernels of gemm.hip / gemm256.hip and on the attention kernels of attention.hip;
+// what is left are coalesced passes over bf16 token matrices [rows][ld] (channel-last, rows padded to whole 64-column k-tiles with
+// zeros so that the next GEMM can consume them as they are), one rounding to bf16 per HF op boundary.
+#include "kernels.h"
+#include <math.h>
+
+namespace {
+
+// ---- predictor pre-processing: uint8 HWC [h][w][3] -> bf16 CHW [3][S][S]: /255, bilinear resize (align_corners = False, as
+// torch.nn.functional.interpolate / torchvision Resize on an upscale), (x - mean) / std
+__global__ __launch_bounds__(256) void k_sam_preprocess(const uint8_t* img, int h, int w, bf16_t* out, int S) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S * S) return;
+    const int y = i / S, x = i % S;
+    const float sy = fmaxf(((float)y + 0.5f) * ((float)h / (float)S) - 0.5f, 0.f), sx = fmaxf(((float)x + 0.5f) * ((float)w / (float)S) - 0.5f, 0.f);
+    const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1), y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float fy = sy - (float)y0, fx = sx - (float)x0;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float p00 = img[((size_t)y0 * w + x0) * 3 + c] / 255.0f, p01 = img[((size_t)y0 * w + x1) * 3 + c] / 255.0f;
+        const float p10 = img[((size_t)y1 * w + x0) * 3 + c] / 255.0f, p11 = img[((size_t)y1 * w + x1) * 3 + c] / 255.0f;
+        const float top = p00 * (1.f - fx) + p01 * fx, bot = p10 * (1.f - fx) + p11 * fx;
+        out[(size_t)c * S * S + i] = f2bf((top * (1.f - fy) + bot * fy - mean[c]) / stdv[c]);
+    }
+}
+
+// ---- patch embedding as a GEMM operand: k x k / stride / pad convolution windows of a CHW image -> rows [ (ty, tx) ][ c*k*k + ky*k + kx ],
+// zero beyond the image and in the pad columns; optional destination row map (window order)
+__global__ __launch_bounds__(256) void k_im2col(const bf16_t* chw, int S, int k, int stride, int pad, int T, bf16_t* out, int ld, const int* rowmap) {
+    const int tok = blockIdx.x;
+    const int ty = tok / T, tx = tok % T, kk = k * k;
+    bf16_t* o = out + (size_t)(rowmap ? rowmap[tok] : tok) * ld;
+    for (int j = threadIdx.x; j < ld; j += 256) {
+        bf16_t v = 0;
+        if (j < 3 * kk) {
+            const int c = j / kk, ky = (j % kk) / k, kx = j % k;
+            const int y = ty * stride - pad + ky, x = tx * stride - pad + kx;
+            if (y >= 0 && y < S && x >= 0 && x < S) v = chw[(size_t)c * S * S + (size_t)y * S + x];
+        }
+        o[j] = v;
+    }
+}
+
+// ---- LayerNorm with bias over C channels of every row (float32 statistics, one rounding), pad columns [C, ld_out) written as zeros.
+// One wave per row (C <= 1152).
+__global__ __launch_bounds__(256) void k_layernorm(const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, int ldo, int rows, int C, float eps) {
+    constexpr int MAXN = 18;                                   // 64 channels per step: C, ldo <= 1152
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const bf16_t* xr = x + (size_t)row * ldx;
+    float v[MAXN];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < C ? bf2f(xr[c]) : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) {
+        const float d = (lane + i * 64) < C ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    bf16_t* o = out + (size_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) {
+        const int c = lane + i * 64;
+        if (c < C) o[c] = f2bf((v[i] - mean) * rstd * bf2f(w[c]) + bf2f(b[c]));
+        else if (c < ldo) o[c] = 0;
+    }
+}
+
+// ---- 2 x 2 max pooling of tokens that are stored window by window ([n_win][ws * ws] rows -> [n_win][(ws/2)^2] rows; hf:290-298, 337-341)
+__global__ __launch_bounds__(256) void k_maxpool_win(const bf16_t* in, int ld_in, int C, int ws, bf16_t* out, int ld_out) {
+    const int h2 = ws / 2, per = h2 * h2;
+    const int orow = blockIdx.x, win = orow / per, py = (orow % per) / h2, px = orow % h2;
+    const bf16_t* base = in + ((size_t)win * ws * ws + (size_t)(2 * py) * ws + 2 * px) * ld_in;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float a = fmaxf(fmaxf(bf2f(base[c]), bf2f(base[ld_in + c])), fmaxf(bf2f(base[(size_t)ws * ld_in + c]), bf2f(base[(size_t)(ws + 1) * ld_in + c])));
+        out[(size_t)orow * ld_out + c] = f2bf(a);
+    }
+}
+
+// ---- elementwise, row-major [rows][ld] with C live columns: mode 0 out = a + b, 1 out = a + vec (row vector), 2 relu(a), 3 gelu(a) (erf form)
+__global__ __launch_bounds__(256) void k_ew(const bf16_t* a, int lda, const bf16_t* b, int ldb, bf16_t* out, int ldo, int rows, int C, int mode) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= (long long)rows * C) return;
+    const int r = (int)(i / C), c = (int)(i % C);
+    const float x = bf2f(a[(size_t)r * lda + c]);
+    float y;
+    if (mode == 0) y = x + bf2f(b[(size_t)r * ldb + c]);
+    else if (mode == 1) y = x + bf2f(b[c]);
+    else if (mode == 2) y = fmaxf(x, 0.f);
+    else y = gelu_f(x);
+    out[(size_t)r * ldo + c] = f2bf(y);
+}
+
+// ---- bf16 matrix transpose: out[c][r] = in[r][c]  (rows x cols), 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void k_transpose(const bf16_t* in, int ld_in, int rows, int cols, bf16_t* out, int ld_out) {
+    __shared__ bf16_t t[32][33];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        t[j][tx] = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < cols && r < rows) out[(size_t)c * ld_out + r] = t[tx][j];
+    }
+}
+
+// ---- FPN top-down step: out[y][x] = bf16(lat[y][x] + top[y/2][x/2])  (nearest 2 x upsampling, hf:246-256)
+__global__ __launch_bounds__(256) void k_upsample2x_add(const bf16_t* lat, const bf16_t* top, bf16_t* out, int H2, int C, int ld) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= (long long)H2 * H2 * C) return;
+    const int c = (int)(i % C), t = (int)(i / C), y = t / H2, x = t % H2;
+    out[(size_t)t * ld + c] = f2bf(bf2f(lat[(size_t)t * ld + c]) + bf2f(top[((size_t)(y / 2) * (H2 / 2) + x / 2) * ld + c]));
+}
+
+// ---- transposed 2 x 2 / stride 2 convolution, second half: the GEMM wrote [H*W][co*4 + dy*2 + dx]; scatter to [(2y+dy)*(2W) + 2x+dx][co]
+// and add the high-resolution feature (hf:1215-1221): out = bf16(conv + feat)
+__global__ __launch_bounds__(256) void k_pixel_shuffle_add(const bf16_t* g, int ldg, const bf16_t* feat, int ldf, bf16_t* out, int ldo, int W, int Co) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    const long long total = 4ll * W * W * Co;
+    if (i >= total) return;
+    const int co = (int)(i % Co), t = (int)(i / Co), Y = t / (2 * W), X = t % (2 * W);
+    const int y = Y >> 1, dy = Y & 1, x = X >> 1, dx = X & 1;
+    out[(size_t)t * ldo + co] = f2bf(bf2f(g[((size_t)y * W + x) * ldg + co * 4 + dy * 2 + dx]) + bf2f(feat[(size_t)t * ldf + co]));
+}
+
+// ---- predictor post-processing (one launch per object): bilinear resize (align_corners = False) of the BEST of n low-resolution mask
+// logit maps (float32 [m*m][ld], column i = mask i; best = first arg-max of score[0..n)) to h x w, threshold at 0, OR into the
+// running object union (seg_strategy.py:57-60); optionally the resized logits of all n masks (tests)
+__global__ __launch_bounds__(256) void k_mask_resize_or(const float* low, int ld, int col0, int n, int m, const float* score, uint8_t* acc, float* logits_out, int h, int w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * w) return;
+    int best = 0;
+    for (int k = 1; k < n; ++k)
+        if (score[col0 + k] > score[col0 + best]) best = k;
+    const int y = i / w, x = i % w;
+    const float sy = fmaxf(((float)y + 0.5f) * ((float)m / (float)h) - 0.5f, 0.f), sx = fmaxf(((float)x + 0.5f) * ((float)m / (float)w) - 0.5f, 0.f);
+    const int y0 = min((int)sy, m - 1), x0 = min((int)sx, m - 1), y1 = min(y0 + 1, m - 1), x1 = min(x0 + 1, m - 1);
+    const float fy = sy - (float)y0, fx = sx - (float)x0;
+    for (int k = 0; k < n; ++k) {
+        if (!logits_out && k != best) continue;
+        const int c = col0 + k;
+        const float top = low[((size_t)y0 * m + x0) * ld + c] * (1.f - fx) + low[((size_t)y0 * m + x1) * ld + c] * fx;
+        const float bot = low[((size_t)y1 * m + x0) * ld + c] * (1.f - fx) + low[((size_t)y1 * m + x1) * ld + c] * fx;
+        const float v = top * (1.f - fy) + bot * fy;
+        if (logits_out) logits_out[(size_t)k * h * w + i] = v;
+        if (k == best && v > 0.f) acc[i] = 1;
+    }
+}
+
+}  // namespace
+
+#define LAUNCH_OK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; return 0; } while (0)
+
+int launch_sam_preprocess(hipStream_t s, const uint8_t* img, int h, int w, bf16_t* out, int S) {
+    hipLaunchKernelGGL(k_sam_preprocess, dim3(cdiv(S * S, 256)), dim3(256), 0, s, img, h, w, out, S);
+    LAUNCH_OK();
+}
+int launch_im2col(hipStream_t s, const bf16_t* chw, int S, int k, int stride, int pad, bf16_t* out, int ld, const int* rowmap) {
+    const int T = (S + 2 * pad - k) / stride + 1;
+    if (ld < 3 * k * k) return -22;
+    hipLaunchKernelGGL(k_im2col, dim3(T * T), dim3(256), 0, s, chw, S, k, stride, pad, T, out, ld, rowmap);
+    LAUNCH_OK();
+}
+int launch_layernorm(hipStream_t s, const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, int ldo, int rows, int C, float eps) {
+    if (rows <= 0) return 0;
+    if (C > 1152 || ldo > 1152) return -22;
+    hipLaunchKernelGGL(k_layernorm, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, w, b, out, ldo, rows, C, eps);
+    LAUNCH_OK();
+}
+int launch_maxpool_win(hipStream_t s, const bf16_t* in, int ld_in, int C, int n_win, int ws, bf16_t* out, int ld_out) {
+    if (ws % 2) return -22;
+    hipLaunchKernelGGL(k_maxpool_win, dim3(n_win * (ws / 2) * (ws / 2)), dim3(256), 0, s, in, ld_in, C, ws, out, ld_out);
+    LAUNCH_OK();
+}
+int launch_ew(hipStream_t s, const bf16_t* a, int lda, const bf16_t* b, int ldb, bf16_t* out, int ldo, int rows, int C, int mode) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_ew, dim3((unsigned)(((long long)rows * C + 255) / 256)), dim3(256), 0, s, a, lda, b, ldb, out, ldo, rows, C, mode);
+    LAUNCH_OK();
+}
+int launch_transpose(hipStream_t s, const bf16_t* in, int ld_in, int rows, int cols, bf16_t* out, int ld_out) {
+    hipLaunchKernelGGL(k_transpose, dim3(cdiv(rows, 32), cdiv(cols, 32)), dim3(256), 0, s, in, ld_in, rows, cols, out, ld_out);
+    LAUNCH_OK();
+}
+int launch_upsample2x_add(hipStream_t s, const bf16_t* lat, const bf16_t* top, bf16_t* out, int H2, int C, int ld) {
+    hipLaunchKernelGGL(k_upsample2x_add, dim3((unsigned)(((long long)H2 * H2 * C + 255) / 256)), dim3(256), 0, s, lat, top, out, H2, C, ld);
+    LAUNCH_OK();
+}
+int launch_pixel_shuffle_add(hipStream_t s, const bf16_t* g, int ldg, const bf16_t* feat, int ldf, bf16_t* out, int ldo, int W, int Co) {
+    hipLaunchKernelGGL(k_pixel_shuffle_add, dim3((unsigned)((4ll * W * W * Co + 255) / 256)), dim3(256), 0, s, g, ldg, feat, ldf, out, ldo, W, Co);
+    LAUNCH_OK();
+}
+int launch_mask_resize_or(hipStream_t s, const float* low, int ld, int col0, int n, int m, const float* score, uint8_t* acc, float* logits_out, int h, int w) {
+    hipLaunchKernelGGL(k_mask_resize_or, dim3(cdiv(h * w, 256)), dim3(256), 0, s, low, ld, col0, n, m, score, acc, logits_out, h, w);
+    LAUNCH_OK();
+}

@@ -72,6 +72,17 @@ SIGNATURES = {
     "sr_op_gemv_fused": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, C.c_float, _vp, _i, _vp, _vp, _vp, _vp]),
     "sr_op_gemv_f32_blocks": (C.c_int, [_i, _i, _i, _i]),
     "sr_op_attn_decode": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _vp, _vp]),
+    "sr_op_attention": (C.c_int, [_vp, _i, _vp, _i, C.c_longlong, _vp, _i, C.c_longlong, _vp, _i, _vp, _i, _i, _i, C.c_float, _i, _i, _i, _i, _vp]),
+    "sr_op_sam_preprocess": (C.c_int, [_vp, _i, _i, _vp, _i, _vp]),
+    "sr_op_im2col": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "sr_op_layernorm": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, C.c_float, _vp]),
+    "sr_op_maxpool_win": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "sr_op_ew": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "sr_op_transpose": (C.c_int, [_vp, _i, _i, _i, _vp, _i, _vp]),
+    "sr_op_upsample2x_add": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sr_op_pixel_shuffle_add": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "sr_op_mask_resize_or": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "sr_op_gather_rows": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
     "sr_op_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i, _i, C.c_float, _vp]),
     "sr_op_resid_rmsnorm": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, C.c_float, _vp]),
     "sr_op_argmax": (C.c_int, [_vp, _i, _i, _vp, _vp]),

@@ -217,3 +217,33 @@ def test_weight_generator_properties():
     assert (w2 == w.reshape(-1)).all()
     assert (WG.synth_f32("a", (64,), seed=0) != WG.synth_f32("b", (64,), seed=0)).any()
     assert WG.tensor_key("model.norm.weight", 0) == WG.tensor_key("model.norm.weight", 0)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "large"])
+def test_sam2_oracle_matches_hf_sam2_model(golden_dir, tag):
+    """oracle/sam2_ref.py (float32) against HF Sam2Model's float32 outputs (tools/make_golden_sam2.py): stage outputs, FPN / decoder
+    features, low-resolution mask logits, IoU scores, the selected 756 x 756 mask -- for a box, a box with clicks, and a single click."""
+    from oracle import sam2_ref as S
+    from socioreasoner_amd import synthetic
+    g = np.load(os.path.join(golden_dir, "sam2.npz"))
+    geom = S.geometry_tiny() if tag == "tiny" else S.geometry_large()
+    W = S.synthetic_weights(geom)
+    hw, st = int(g[f"{tag}_hw"][0]), int(g[f"stride_{tag}"][0])
+    o = S.Sam2Oracle(W, geom)
+    o.set_image(synthetic.tile_pixels(int(g[f"{tag}_img_seed"][0]), hw, hw))
+    for i, x in enumerate(o.stages):
+        want = g[f"{tag}_stage{i}_f32"]
+        assert np.abs(x.flatten()[::st].numpy() - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), i
+    for i, x in enumerate(o.feats):
+        want = g[f"{tag}_feat{i}_f32"]
+        assert np.abs(x.flatten()[::st].numpy() - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), i
+    for p in range(3):
+        box = g[f"{tag}_p{p}_box"].tolist() or None
+        pts = g[f"{tag}_p{p}_pts"]
+        masks, iou, low = o.predict(pts if len(pts) else None, g[f"{tag}_p{p}_labels"] if len(pts) else None, box)
+        assert np.abs(low - g[f"{tag}_p{p}_low"]).max() <= 1e-3, p
+        assert np.abs(iou - g[f"{tag}_p{p}_iou"]).max() <= 1e-5, p
+        best = int(np.argmax(iou))
+        assert best == int(g[f"{tag}_p{p}_best"][0])
+        want = np.unpackbits(g[f"{tag}_p{p}_mask_bits"])[: hw * hw].reshape(hw, hw).astype(bool)
+        assert (masks[best] != want).sum() <= 2, p              # (a logit within 1e-6 of zero may land on either side)
