@@ -231,6 +231,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p, int ntm, int ntn) 
                     const float4 sc = *reinterpret_cast<const float4*>(p.w_scale + n);
                     o[0] *= sc.x; o[1] *= sc.y; o[2] *= sc.z; o[3] *= sc.w;
                 }
+                if (p.bias) { o[0] += bf2f(p.bias[n]); o[1] += bf2f(p.bias[n + 1]); o[2] += bf2f(p.bias[n + 2]); o[3] += bf2f(p.bias[n + 3]); }
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + ((size_t)blockIdx.y * p.M + orow) * p.ldo + n) = float4{o[0], o[1], o[2], o[3]};
             }
         } else {

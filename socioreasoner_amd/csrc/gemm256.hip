@@ -491,6 +491,7 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
                 const int n = n0 + wn * 64 + j * 16 + fg * 4;
                 float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 if (p.w_scale) { o[0] *= scl[j].x; o[1] *= scl[j].y; o[2] *= scl[j].z; o[3] *= scl[j].w; }
+                if (p.bias) { o[0] += bf2f(p.bias[n]); o[1] += bf2f(p.bias[n + 1]); o[2] += bf2f(p.bias[n + 2]); o[3] += bf2f(p.bias[n + 3]); }
                 if (rok[i]) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow[i] * p.ldo + n) = float4{o[0], o[1], o[2], o[3]};
             }
         } else {

@@ -1,0 +1,559 @@
+"""SAM2 (Hiera-L image encoder + prompt encoder + mask decoder) behind the reference's ``seg_infer`` role, on the MI355X kernels of
+``libsocior.so`` (SURVEY.md "next" row N1).
+
+Reference contract (/root/reference/roll/distributed/strategy/seg_strategy.py:26-72, roll/models/model_providers.py:515-562): the
+provider returns a ``SAM2ImagePredictor`` over ``facebook/sam2-hiera-large``; ``segment`` resizes the sample to 756 x 756, calls
+``set_image`` once and ``predict(point_coords, point_labels, box)`` per object (three masks + scores), ORs ``masks[argmax(scores)]``.
+The network is the one of ``transformers.models.sam2.modeling_sam2`` ("hf:" below; same parameters as the sam2 package's checkpoint,
+HF names) -- the oracle restates it (oracle/sam2_ref.py) and tests/test_gpu_sam2.py compares this module with HF's own outputs.
+
+How it runs here.  Host code is Python (like the reference's); every FLOP is in ``libsocior.so``: all Linear / 1 x 1 / patch /
+transposed convolutions are bf16 MFMA GEMMs (``sr_op_gemm``: bias, residual, GELU and destination row maps in the epilogue), all
+attention goes through ``sr_op_attention`` (windowed, pooled-query and global blocks of Hiera; token <-> image attention of the
+decoder), the passes in between are the coalesced kernels of csrc/sam.hip.  Layout decisions:
+
+* tokens are channel-last bf16 matrices [rows][ld], ld = channels rounded up to whole 64-wide k-tiles, pad columns kept zero;
+* head_dim 72 runs as 80: the qkv weight rows / proj weight columns of a head are padded with zeros once at load time;
+* a stage's tokens live in WINDOW ORDER (window, y, x) from the patch embedding on (the GEMM's row map writes them there), so every
+  window is a contiguous run of rows for the attention kernel and no partition / un-partition pass exists; a stage-entry block pools
+  its queries 2 x 2 inside the windows, which leaves the next stage in window order of half the size -- for Hiera-L that IS the next
+  stage's window except between stage 2 and 3 (one row gather); global-attention blocks do not care; the FPN's lateral GEMMs write
+  image order through their row map;
+* the prompt encoder (a dozen 256-vectors) runs on the host in float32.
+
+bf16 storage / float32 accumulation like the LM path; the reference runs SAM2 in float32 -- tests hold this module to the distance
+HF-bf16 itself has from HF-float32 and to exact masks wherever |logit| clears that band."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+EPI_STORE, EPI_RESID, EPI_GELU, EPI_F32 = 0, 1, 3, 4
+_WORK = np.dtype([("q_row0", "<i4"), ("seq_len", "<i4"), ("q_off", "<i4"), ("k_row0", "<i4"), ("vt_off", "<i8"), ("q_len", "<i4"), ("pad", "<i4")])
+_HD_OK = (16, 32, 80, 128)
+
+
+@dataclass
+class Sam2Geometry:
+    """sam2_hiera_l.yaml of the sam2 package (the checkpoint the reference loads)."""
+    image_size: int = 1024
+    embed_dims: Tuple[int, ...] = (144, 288, 576, 1152)
+    heads: Tuple[int, ...] = (2, 4, 8, 16)
+    blocks: Tuple[int, ...] = (2, 6, 36, 4)
+    windows: Tuple[int, ...] = (8, 4, 16, 8)
+    global_blocks: Tuple[int, ...] = (23, 33, 43)
+    bkg_size: int = 7
+    fpn_dim: int = 256
+    top_down_levels: Tuple[int, ...] = (2, 3)
+    dec_heads: int = 8
+    dec_mlp: int = 2048
+    dec_layers: int = 2
+    n_mask_tokens: int = 4
+    ln_eps: float = 1e-6
+
+    def block_table(self):
+        """(stage, dim_in, dim_out, heads, window (0 = global), pooled) per block (hf:457-501)."""
+        out, k = [], 0
+        for s, n in enumerate(self.blocks):
+            for b in range(n):
+                first = s > 0 and b == 0
+                win = 0 if k in self.global_blocks else (self.windows[s - 1] if first else self.windows[s])
+                out.append((s, self.embed_dims[s - 1] if first else self.embed_dims[s], self.embed_dims[s], self.heads[s], win, first))
+                k += 1
+        return out
+
+
+def rup(x: int, m: int = 64) -> int:
+    return (x + m - 1) // m * m
+
+
+def _hd_pad(hd: int) -> int:
+    for v in _HD_OK:
+        if v >= hd:
+            return v
+    raise ValueError(f"head dim {hd} not supported")
+
+
+def window_order(G: int, ws: int) -> np.ndarray:
+    """perm[image index y * G + x] = row of that token when tokens are stored window by window (hf:397-425)."""
+    y, x = np.divmod(np.arange(G * G), G)
+    return (((y // ws) * (G // ws) + x // ws) * ws * ws + (y % ws) * ws + x % ws).astype(np.int32)
+
+
+class Sam2Engine:
+    def __init__(self, geometry: Optional[Sam2Geometry] = None, device="cuda:0"):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.SocioRError("no GPU visible: the product path has no CPU fallback")
+        self.g = geometry or Sam2Geometry()
+        self.device = torch.device(device)
+        g = self.g
+        if g.image_size % 64:
+            raise ValueError("image_size must be a multiple of 64")
+        self.grid = [g.image_size // 4 // (1 << s) for s in range(4)]          # tokens per side of every stage
+        for s in range(4):
+            if self.grid[s] % g.windows[s] or (s and self.grid[s - 1] % g.windows[s - 1]) or g.windows[s] % 2:
+                raise ValueError("window sizes must divide the stage grids (true for Hiera-L at 1024)")
+        self.W: Dict[str, torch.Tensor] = {}
+        self._bufs: Dict[str, torch.Tensor] = {}
+        self._work: Dict[tuple, tuple] = {}
+        self._idx: Dict[str, torch.Tensor] = {}
+        self.image_set = False
+
+    # ------------------------------------------------------------------ plumbing
+    def _s(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _p(t, off_elems: int = 0):
+        return C.c_void_p(t.data_ptr() + off_elems * t.element_size()) if t is not None else None
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise L.SocioRError(f"{what} failed with {rc}")
+
+    def buf(self, name, rows, cols, dtype=torch.bfloat16):
+        """zero-initialised once; pad columns are never written afterwards"""
+        t = self._bufs.get(name)
+        if t is None or t.shape != (rows, cols) or t.dtype != dtype:
+            t = self._bufs[name] = torch.zeros(rows, cols, dtype=dtype, device=self.device)
+        return t
+
+    def gemm(self, A, lda, Wn, M, out, ldo, epi=EPI_STORE, resid=None, rowmap=None, bias=True, a_off=0, out_off=0):
+        w = self.W[Wn + ".weight"]
+        N, K = w.shape
+        b = self.W.get(Wn + ".bias") if bias else None
+        self._ck(self.lib.sr_op_gemm(self._p(A, a_off), lda, self._p(w), M, N, K, self._p(out, out_off), ldo, self._p(b), self._p(resid, out_off if resid is out else 0),
+                                     self._p(rowmap), epi, self._s()), f"gemm {Wn}")
+
+    def layernorm(self, x, ldx, name, out, ldo, rows, Cc, eps):
+        self._ck(self.lib.sr_op_layernorm(self._p(x), ldx, self._p(self.W[name + ".weight"]), self._p(self.W[name + ".bias"]), self._p(out), ldo, rows, Cc,
+                                          C.c_float(eps), self._s()), "layernorm")
+
+    def ew(self, a, lda, b, ldb, out, ldo, rows, Cc, mode):
+        self._ck(self.lib.sr_op_ew(self._p(a), lda, self._p(b), ldb, self._p(out), ldo, rows, Cc, mode, self._s()), "ew")
+
+    def work(self, key, items) -> tuple:
+        w = self._work.get(key)
+        if w is None:
+            arr = np.zeros(len(items), dtype=_WORK)
+            for i, it in enumerate(items):
+                arr[i] = it + (0,) * (7 - len(it))
+            t = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+            w = self._work[key] = (t, len(items))
+        return w
+
+    def attention(self, q, q_stride, k, k_off, k_stride, hdp, vt, vt_stride, out, out_stride, work, heads, scale, q_tile=64, v2_ok=0):
+        wt, n = work
+        self._ck(self.lib.sr_op_attention(self._p(q), q_stride, self._p(k, k_off), k_stride, hdp, self._p(vt), vt_stride, hdp * vt_stride, self._p(out), out_stride,
+                                          self._p(wt), n, heads, 1, C.c_float(scale), 0, hdp, q_tile, v2_ok, self._s()), "attention")
+
+    # ------------------------------------------------------------------ weights (HF names -> device layouts)
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """HF ``Sam2Model`` state dict (or the sam2 checkpoint renamed to it).  Re-laid-out once: K padded to 64-multiples with zeros,
+        head_dim padded to a kernel-supported width, 1 x 1 / patch / transposed convolutions flattened to GEMM operands."""
+        g, dev = self.g, self.device
+        f = lambda name: sd[name].detach().float().cpu()
+
+        def put(name, w2d, bias=None, n_pad=None):
+            N, K = w2d.shape
+            Np = n_pad or N
+            out = torch.zeros(Np, rup(K), dtype=torch.float32)
+            out[:N, :K] = w2d
+            self.W[name + ".weight"] = out.to(torch.bfloat16).to(dev).contiguous()
+            if bias is not None:
+                bb = torch.zeros(Np, dtype=torch.float32)
+                bb[:N] = bias
+                self.W[name + ".bias"] = bb.to(torch.bfloat16).to(dev)
+
+        def put_ln(name):
+            self.W[name + ".weight"] = f(name + ".weight").to(torch.bfloat16).to(dev)
+            self.W[name + ".bias"] = f(name + ".bias").to(torch.bfloat16).to(dev)
+
+        pe = "vision_encoder.backbone."
+        put(pe + "patch_embed.projection", f(pe + "patch_embed.projection.weight").reshape(g.embed_dims[0], -1), f(pe + "patch_embed.projection.bias"))
+        # position embedding: bicubic-resized background grid + tiled window embedding (hf:645-651), stored in stage-0 window order.
+        # Computed in float32 on the host and rounded once (HF's bf16 mode rounds the interpolation too: a parameter-only constant)
+        G0 = self.grid[0]
+        pos = torch.nn.functional.interpolate(f(pe + "pos_embed"), size=(G0, G0), mode="bicubic")
+        win = f(pe + "pos_embed_window")
+        pos = (pos.to(torch.bfloat16) + win.to(torch.bfloat16).tile(1, 1, G0 // win.shape[2], G0 // win.shape[3]))[0].permute(1, 2, 0).reshape(G0 * G0, -1)
+        tab = torch.zeros(G0 * G0, rup(g.embed_dims[0]), dtype=torch.bfloat16)
+        order0 = torch.from_numpy(window_order(G0, g.windows[0]).astype(np.int64))
+        tab[order0, : g.embed_dims[0]] = pos
+        self.W["pos_table"] = tab.to(dev)
+        self.blocks = []
+        for i, (s, din, dout, heads, win_, pooled) in enumerate(g.block_table()):
+            p = f"{pe}blocks.{i}"
+            hd = dout // heads
+            hdp = _hd_pad(hd)
+            HP = heads * hdp
+            put_ln(p + ".layer_norm1")
+            put_ln(p + ".layer_norm2")
+            wq = f(p + ".attn.qkv.weight").reshape(3, heads, hd, din)
+            bq = f(p + ".attn.qkv.bias").reshape(3, heads, hd)
+            wq_p = torch.zeros(3, heads, hdp, din)
+            wq_p[:, :, :hd] = wq
+            bq_p = torch.zeros(3, heads, hdp)
+            bq_p[:, :, :hd] = bq
+            put(p + ".attn.qkv", wq_p.reshape(3 * HP, din), bq_p.reshape(-1))
+            wp = f(p + ".attn.proj.weight").reshape(dout, heads, hd)
+            wp_p = torch.zeros(dout, heads, hdp)
+            wp_p[:, :, :hd] = wp
+            put(p + ".attn.proj", wp_p.reshape(dout, HP), f(p + ".attn.proj.bias"))
+            put(p + ".mlp.proj_in", f(p + ".mlp.proj_in.weight"), f(p + ".mlp.proj_in.bias"))
+            put(p + ".mlp.proj_out", f(p + ".mlp.proj_out.weight"), f(p + ".mlp.proj_out.bias"))
+            if din != dout:
+                put(p + ".proj", f(p + ".proj.weight"), f(p + ".proj.bias"))
+            self.blocks.append(dict(name=p, stage=s, din=din, dout=dout, heads=heads, hd=hd, hdp=hdp, HP=HP, win=win_, pooled=pooled))
+        for j in range(4):
+            n = f"vision_encoder.neck.convs.{j}"
+            put(n, f(n + ".weight").reshape(g.fpn_dim, -1), f(n + ".bias"))
+        Cd = g.fpn_dim
+        self.W["no_mem"] = f("no_memory_embedding").reshape(-1).to(torch.bfloat16).to(dev)
+        self.W["no_mask"] = f("prompt_encoder.no_mask_embed.weight").reshape(-1).to(torch.bfloat16).to(dev)
+        put("mask_decoder.conv_s0", f("mask_decoder.conv_s0.weight").reshape(Cd // 8, Cd), f("mask_decoder.conv_s0.bias"))
+        put("mask_decoder.conv_s1", f("mask_decoder.conv_s1.weight").reshape(Cd // 4, Cd), f("mask_decoder.conv_s1.bias"))
+        md = "mask_decoder.transformer."
+        attn_names = [f"{md}layers.{l}.{a}" for l in range(g.dec_layers) for a in ("self_attn", "cross_attn_token_to_image", "cross_attn_image_to_token")]
+        for a in attn_names + [md + "final_attn_token_to_image"]:
+            for q in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                put(f"{a}.{q}", f(f"{a}.{q}.weight"), f(f"{a}.{q}.bias"))
+        for l in range(g.dec_layers):
+            for k in (1, 2, 3, 4):
+                put_ln(f"{md}layers.{l}.layer_norm{k}")
+            put(f"{md}layers.{l}.mlp.proj_in", f(f"{md}layers.{l}.mlp.proj_in.weight"), f(f"{md}layers.{l}.mlp.proj_in.bias"))
+            put(f"{md}layers.{l}.mlp.proj_out", f(f"{md}layers.{l}.mlp.proj_out.weight"), f(f"{md}layers.{l}.mlp.proj_out.bias"))
+        put_ln(md + "layer_norm_final_attn")
+        put_ln("mask_decoder.upscale_layer_norm")
+        # transposed 2 x 2 / stride 2 convolutions as GEMMs: W[co*4 + dy*2 + dx][ci] (hf:1215-1221)
+        for n in ("mask_decoder.upscale_conv1", "mask_decoder.upscale_conv2"):
+            w = f(n + ".weight")                                        # [ci, co, 2, 2]
+            put(n, w.permute(1, 2, 3, 0).reshape(-1, w.shape[0]), f(n + ".bias").repeat_interleave(4))
+        for i in range(g.n_mask_tokens):
+            n = f"mask_decoder.output_hypernetworks_mlps.{i}"
+            for q in ("proj_in", "layers.0", "proj_out"):
+                put(f"{n}.{q}", f(f"{n}.{q}.weight"), f(f"{n}.{q}.bias"))
+        n = "mask_decoder.iou_prediction_head"
+        put(n + ".proj_in", f(n + ".proj_in.weight"), f(n + ".proj_in.bias"))
+        put(n + ".layers.0", f(n + ".layers.0.weight"), f(n + ".layers.0.bias"))
+        put(n + ".proj_out", f(n + ".proj_out.weight"), f(n + ".proj_out.bias"), n_pad=16)
+        # host-side constants of the prompt encoder and the decoder tokens (float32)
+        self.h = {k: f(k) for k in ("prompt_encoder.shared_embedding.positional_embedding", "prompt_encoder.point_embed.weight",
+                                    "prompt_encoder.not_a_point_embed.weight", "mask_decoder.obj_score_token.weight", "mask_decoder.iou_token.weight",
+                                    "mask_decoder.mask_tokens.weight")}
+        m = g.image_size // 16
+        ax = (torch.arange(m, dtype=torch.float32) + 0.5) / m
+        yy, xx = torch.meshgrid(ax, ax, indexing="ij")
+        self.W["image_pe"] = self._fourier(torch.stack([xx, yy], dim=-1).reshape(-1, 2)).to(torch.bfloat16).to(dev).contiguous()
+        torch.cuda.synchronize(self.device)
+
+    def _fourier(self, coords01: torch.Tensor) -> torch.Tensor:
+        """random-Fourier position encoding (hf:727-749), float32 on the host"""
+        c = (2 * coords01 - 1) @ self.h["prompt_encoder.shared_embedding.positional_embedding"]
+        c = 2 * math.pi * c
+        return torch.cat([torch.sin(c), torch.cos(c)], dim=-1)
+
+    # ------------------------------------------------------------------ image encoder
+    def _index(self, name, arr) -> torch.Tensor:
+        t = self._idx.get(name)
+        if t is None:
+            t = self._idx[name] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(self.device)
+        return t
+
+    def _window_work(self, n_win, n_keys, n_q, tile=64):
+        items = []
+        for w in range(n_win):
+            for q0 in range(0, n_q, tile):
+                items.append((w * n_q + q0, n_keys, q0, w * n_keys, w * n_keys, n_q if n_q != n_keys else 0))
+        return items
+
+    def set_image(self, img_u8: torch.Tensor):
+        """uint8 HWC device tensor (756 x 756 in the reference's flow) -> image embedding + high-resolution features kept on the device."""
+        g, lib, s = self.g, self.lib, self._s
+        assert img_u8.dtype == torch.uint8 and img_u8.is_cuda and img_u8.dim() == 3 and img_u8.shape[2] == 3
+        img_u8 = img_u8.contiguous()
+        self.orig_hw = (int(img_u8.shape[0]), int(img_u8.shape[1]))
+        S = g.image_size
+        chw = self.buf("chw", 3, S * S)
+        self._ck(lib.sr_op_sam_preprocess(self._p(img_u8), self.orig_hw[0], self.orig_hw[1], self._p(chw), S, s()), "preprocess")
+        G0, C0 = self.grid[0], g.embed_dims[0]
+        order0 = self._index("order0", window_order(G0, g.windows[0]))
+        kp = rup(3 * 49)
+        col = self.buf("im2col", G0 * G0, kp)
+        self._ck(lib.sr_op_im2col(self._p(chw), S, 7, 4, 3, self._p(col), kp, self._p(order0), s()), "im2col")
+        x = self.buf("x0", G0 * G0, rup(C0))
+        # x = bf16(pos + bf16(conv + bias)), rows already in window order (hf:664-665)
+        self.gemm(col, kp, "vision_encoder.backbone.patch_embed.projection", G0 * G0, x, rup(C0), EPI_RESID, resid=self.W["pos_table"])
+        ends = set(np.cumsum(g.blocks) - 1)
+        cur_ws = g.windows[0]                 # the window size the current token order is organised by
+        stage_out = []
+        for i, b in enumerate(self.blocks):
+            s_, din, dout, heads, hdp, HP, win, pooled = b["stage"], b["din"], b["dout"], b["heads"], b["hdp"], b["HP"], b["win"], b["pooled"]
+            Gin = self.grid[s_ - 1] if pooled else self.grid[s_]
+            N = Gin * Gin
+            name = b["name"]
+            scale = b["hd"] ** -0.5
+            xn = self.buf(f"xn{s_}{'p' if pooled else ''}", N, rup(din))
+            self.layernorm(x, rup(din), name + ".layer_norm1", xn, rup(din), N, din, g.ln_eps)
+            qkv = self.buf(f"qkv{s_}{'p' if pooled else ''}", N, 3 * HP)
+            self.gemm(xn, rup(din), name + ".attn.qkv", N, qkv, 3 * HP)
+            vts = rup(N) + 64
+            vt = self.buf(f"vt{s_}{'p' if pooled else ''}", HP, vts)
+            self._ck(lib.sr_op_transpose(self._p(qkv, 2 * HP), 3 * HP, N, HP, self._p(vt), vts, s()), "transpose")
+            if pooled:
+                assert win > 0 and win == cur_ws, "stage-entry blocks pool inside the previous stage's windows"
+                Nq, nw = N // 4, N // (win * win)
+                Gout = Gin // 2
+                xnew = self.buf(f"x{s_}", Nq, rup(dout))
+                rfull = self.buf(f"rfull{s_}", N, rup(dout))
+                self.gemm(xn, rup(din), name + ".proj", N, rfull, rup(dout))
+                self._ck(lib.sr_op_maxpool_win(self._p(rfull), rup(dout), dout, nw, win, self._p(xnew), rup(dout), s()), "maxpool")
+                qp = self.buf(f"qp{s_}", Nq, HP)
+                self._ck(lib.sr_op_maxpool_win(self._p(qkv), 3 * HP, HP, nw, win, self._p(qp), HP, s()), "maxpool q")
+                att = self.buf(f"att{s_}", Nq, rup(HP))
+                wk = self.work(("pool", s_), self._window_work(nw, win * win, win * win // 4))
+                self.attention(qp, HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale)
+                x, N, cur_ws = xnew, Nq, win // 2
+                self.gemm(att, rup(HP), name + ".attn.proj", N, x, rup(dout), EPI_RESID, resid=x)
+            else:
+                att = self.buf(f"att{s_}", N, rup(HP))
+                if win > 0:
+                    assert win == cur_ws
+                    wk = self.work(("win", s_), self._window_work(N // (win * win), win * win, win * win))
+                    self.attention(qkv, 3 * HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale)
+                else:           # global attention: token order does not matter
+                    v2 = hdp == 80
+                    tile = 128 if v2 else 64
+                    wk = self.work(("glob", s_, tile), [(q0, N, q0, 0, 0, 0) for q0 in range(0, N, tile)])
+                    self.attention(qkv, 3 * HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale, q_tile=tile, v2_ok=1 if v2 else 0)
+                self.gemm(att, rup(HP), name + ".attn.proj", N, x, rup(dout), EPI_RESID, resid=x)
+            self.layernorm(x, rup(dout), name + ".layer_norm2", xn if not pooled else self.buf(f"xn{s_}", N, rup(dout)), rup(dout), N, dout, g.ln_eps)
+            xn2 = self._bufs[f"xn{s_}"]
+            hid = self.buf(f"hid{s_}", N, 4 * dout)
+            self.gemm(xn2, rup(dout), name + ".mlp.proj_in", N, hid, 4 * dout, EPI_GELU)
+            self.gemm(hid, 4 * dout, name + ".mlp.proj_out", N, x, rup(dout), EPI_RESID, resid=x)
+            if pooled and cur_ws != g.windows[s_]:
+                # the pooled tokens sit in window order of size cur_ws; the stage's own windows are g.windows[s_]: one row gather
+                Gs = self.grid[s_]
+                a, bb = window_order(Gs, cur_ws), window_order(Gs, g.windows[s_])
+                src = np.empty(Gs * Gs, dtype=np.int32)
+                src[bb] = a                                # row bb[i] of the new order takes row a[i] of the old one
+                x2 = self.buf(f"x{s_}g", N, rup(dout))
+                self._ck(lib.sr_op_gather_rows(self._p(x), self._p(self._index(f"regather{s_}", src)), self._p(x2), N, rup(dout), s()), "gather")
+                x, cur_ws = x2, g.windows[s_]
+                self._bufs[f"x{s_}"], self._bufs[f"x{s_}g"] = x2, self._bufs[f"x{s_}"]      # (the stage keeps updating this buffer in place)
+            if i in ends:
+                stage_out.append((x, cur_ws))
+        # ---- FPN neck (hf:216-265): lateral 1 x 1 convolutions written in IMAGE order through the row map, one top-down step
+        Cd = g.fpn_dim
+        lat = []
+        for lvl in range(4):
+            xs, ws = stage_out[lvl]
+            Gs = self.grid[lvl]
+            inv = self._index(f"to_image{lvl}_{ws}", np.argsort(window_order(Gs, ws)).astype(np.int32))   # row r (window order) -> image index
+            o = self.buf(f"lat{lvl}", Gs * Gs, Cd)
+            self.gemm(xs, rup(g.embed_dims[lvl]), f"vision_encoder.neck.convs.{3 - lvl}", Gs * Gs, o, Cd, EPI_STORE, rowmap=inv)
+            lat.append(o)
+        fpn2 = lat[2]
+        if 2 in g.top_down_levels:
+            fpn2 = self.buf("fpn2", self.grid[2] ** 2, Cd)
+            self._ck(lib.sr_op_upsample2x_add(self._p(lat[2]), self._p(lat[3]), self._p(fpn2), self.grid[2], Cd, Cd, s()), "upsample")
+        m2 = self.grid[2] ** 2
+        self.emb = self.buf("emb", m2, Cd)
+        self.ew(fpn2, Cd, self.W["no_mem"], 0, self.emb, Cd, m2, Cd, 1)                      # + no-memory embedding (hf:1499-1500)
+        self.keys0 = self.buf("keys0", m2, Cd)
+        self.ew(self.emb, Cd, self.W["no_mask"], 0, self.keys0, Cd, m2, Cd, 1)                # + dense "no mask" embedding (hf:1193)
+        self.f0 = self.buf("f0", self.grid[0] ** 2, Cd // 8)
+        self.gemm(lat[0], Cd, "mask_decoder.conv_s0", self.grid[0] ** 2, self.f0, Cd // 8)
+        self.f1 = self.buf("f1", self.grid[1] ** 2, Cd // 4)
+        self.gemm(lat[1], Cd, "mask_decoder.conv_s1", self.grid[1] ** 2, self.f1, Cd // 4)
+        self.stage_out = stage_out
+        self.image_set = True
+
+    # ------------------------------------------------------------------ prompt encoder (host, float32) + mask decoder
+    def _tokens(self, coords: np.ndarray, labels: np.ndarray) -> torch.Tensor:
+        """output tokens + sparse prompt embeddings (hf:791-813, 1175-1190): coords in the model's input frame, labels 1 / 0 clicks, 2 / 3 box
+        corners; the encoder's padding point is appended."""
+        g = self.g
+        pts = torch.cat([torch.from_numpy(np.asarray(coords, dtype=np.float32)) + 0.5, torch.zeros(1, 2)], dim=0)
+        lab = torch.cat([torch.from_numpy(np.asarray(labels, dtype=np.int64)), torch.tensor([-1])])
+        e = self._fourier(pts / g.image_size)
+        e = torch.where(lab[:, None] == -1, self.h["prompt_encoder.not_a_point_embed.weight"], e)
+        e = e + self.h["prompt_encoder.point_embed.weight"][lab.clamp(min=0)] * (lab >= 0)[:, None].float()
+        return torch.cat([self.h["mask_decoder.obj_score_token.weight"], self.h["mask_decoder.iou_token.weight"], self.h["mask_decoder.mask_tokens.weight"], e], dim=0)
+
+    def _mha(self, name, q, nq, k, v, nk, internal, out, resid, tag):
+        """Sam2Attention (hf:874-942): out = [resid +] o_proj(attention(q_proj(q), k_proj(k), v_proj(v)))"""
+        g, Cd = self.g, self.g.fpn_dim
+        hd = internal // g.dec_heads
+        qp = self.buf(f"d_qp_{tag}", max(nq, 16), internal)
+        kp = self.buf(f"d_kp_{tag}", max(nk, 16), internal)
+        vp = self.buf(f"d_vp_{tag}", max(nk, 16), internal)
+        self.gemm(q, Cd, name + ".q_proj", nq, qp, internal)
+        self.gemm(k, Cd, name + ".k_proj", nk, kp, internal)
+        self.gemm(v, Cd, name + ".v_proj", nk, vp, internal)
+        vts = rup(nk) + 64
+        vt = self.buf(f"d_vt_{tag}", internal, vts)
+        self._ck(self.lib.sr_op_transpose(self._p(vp), internal, nk, internal, self._p(vt), vts, self._s()), "transpose")
+        o = self.buf(f"d_o_{tag}", max(nq, 16), internal)
+        wk = self.work(("dec", nq, nk), [(q0, nk, q0, 0, 0, nq if nq != nk else 0) for q0 in range(0, nq, 64)])
+        self.attention(qp, internal, kp, 0, internal, hd, vt, vts, o, internal, wk, g.dec_heads, hd ** -0.5)
+        self.gemm(o, internal, name + ".o_proj", nq, out, Cd, EPI_RESID if resid is not None else EPI_STORE, resid=resid)
+
+    def decode(self, coords: np.ndarray, labels: np.ndarray):
+        """-> (low-resolution mask logits float32 [m4 * m4][16] (column i = mask token i), IoU-head logits float32 [16])  on the device"""
+        assert self.image_set, "set_image first"
+        g, Cd, lib = self.g, self.g.fpn_dim, self.lib
+        tok_h = self._tokens(coords, labels)
+        T = tok_h.shape[0]
+        Tp = max(T, 16)
+        tok = self.buf("d_tok", Tp, Cd)
+        tok[:T].copy_(tok_h.to(torch.bfloat16), non_blocking=True)
+        m2 = self.grid[2] ** 2
+        q = self.buf("d_q", Tp, Cd)
+        qx = self.buf("d_qx", Tp, Cd)
+        keys = self.buf("d_keys", m2, Cd)
+        kx = self.buf("d_kx", m2, Cd)
+        keys.copy_(self.keys0)
+        md = "mask_decoder.transformer."
+        eps = 1e-5
+        for l in range(g.dec_layers):
+            p = f"{md}layers.{l}"
+            if l == 0:
+                self._mha(p + ".self_attn", tok, T, tok, tok, T, Cd, q, None, "self")
+            else:
+                self.ew(q, Cd, tok, Cd, qx, Cd, T, Cd, 0)
+                self._mha(p + ".self_attn", qx, T, qx, q, T, Cd, q, q, "self")
+            self.layernorm(q, Cd, p + ".layer_norm1", q, Cd, T, Cd, eps)
+            self.ew(q, Cd, tok, Cd, qx, Cd, T, Cd, 0)
+            self.ew(keys, Cd, self.W["image_pe"], Cd, kx, Cd, m2, Cd, 0)
+            self._mha(p + ".cross_attn_token_to_image", qx, T, kx, keys, m2, Cd // 2, q, q, "t2i")
+            self.layernorm(q, Cd, p + ".layer_norm2", q, Cd, T, Cd, eps)
+            hid = self.buf("d_hid", Tp, g.dec_mlp)
+            self.gemm(q, Cd, p + ".mlp.proj_in", T, hid, g.dec_mlp)
+            self.ew(hid, g.dec_mlp, None, 0, hid, g.dec_mlp, T, g.dec_mlp, 2)
+            self.gemm(hid, g.dec_mlp, p + ".mlp.proj_out", T, q, Cd, EPI_RESID, resid=q)
+            self.layernorm(q, Cd, p + ".layer_norm3", q, Cd, T, Cd, eps)
+            self.ew(q, Cd, tok, Cd, qx, Cd, T, Cd, 0)
+            self._mha(p + ".cross_attn_image_to_token", kx, m2, qx, q, T, Cd // 2, keys, keys, "i2t")
+            self.layernorm(keys, Cd, p + ".layer_norm4", keys, Cd, m2, Cd, eps)
+        self.ew(q, Cd, tok, Cd, qx, Cd, T, Cd, 0)
+        self.ew(keys, Cd, self.W["image_pe"], Cd, kx, Cd, m2, Cd, 0)
+        self._mha(md + "final_attn_token_to_image", qx, T, kx, keys, m2, Cd // 2, q, q, "t2i")
+        self.layernorm(q, Cd, md + "layer_norm_final_attn", q, Cd, T, Cd, eps)
+        # ---- upscaling (hf:1215-1221)
+        G2, G1, G0 = self.grid[2], self.grid[1], self.grid[0]
+        g1 = self.buf("d_g1", m2, Cd)
+        self.gemm(keys, Cd, "mask_decoder.upscale_conv1", m2, g1, Cd)
+        u1 = self.buf("d_u1", G1 * G1, Cd // 4)
+        self._ck(lib.sr_op_pixel_shuffle_add(self._p(g1), Cd, self._p(self.f1), Cd // 4, self._p(u1), Cd // 4, G2, Cd // 4, self._s()), "shuffle1")
+        self.layernorm(u1, Cd // 4, "mask_decoder.upscale_layer_norm", u1, Cd // 4, G1 * G1, Cd // 4, 1e-6)
+        self.ew(u1, Cd // 4, None, 0, u1, Cd // 4, G1 * G1, Cd // 4, 3)
+        g2 = self.buf("d_g2", G1 * G1, Cd // 2)
+        self.gemm(u1, Cd // 4, "mask_decoder.upscale_conv2", G1 * G1, g2, Cd // 2)
+        u2 = self.buf("d_u2", G0 * G0, 64)                                   # Cd / 8 live channels, padded to one k-tile
+        self._ck(lib.sr_op_pixel_shuffle_add(self._p(g2), Cd // 2, self._p(self.f0), Cd // 8, self._p(u2), 64, G1, Cd // 8, self._s()), "shuffle2")
+        self.ew(u2, 64, None, 0, u2, 64, G0 * G0, Cd // 8, 3)
+        # ---- hypernetwork MLPs of the mask tokens, IoU head (hf:1223-1236)
+        hyp = self.buf("d_hyp", 16, 64)
+        h1, h2 = self.buf("d_h1", 16, Cd), self.buf("d_h2", 16, Cd)
+        for i in range(g.n_mask_tokens):
+            n = f"mask_decoder.output_hypernetworks_mlps.{i}"
+            self.gemm(q, Cd, n + ".proj_in", 1, h1, Cd, a_off=(2 + i) * Cd)
+            self.ew(h1, Cd, None, 0, h1, Cd, 1, Cd, 2)
+            self.gemm(h1, Cd, n + ".layers.0", 1, h2, Cd)
+            self.ew(h2, Cd, None, 0, h2, Cd, 1, Cd, 2)
+            self.gemm(h2, Cd, n + ".proj_out", 1, hyp, 64, out_off=i * 64)
+        low = self.buf("d_low", G0 * G0, 16, torch.float32)
+        self._ck(lib.sr_op_gemm(self._p(u2), 64, self._p(hyp), G0 * G0, 16, 64, self._p(low), 16, None, None, None, EPI_F32, self._s()), "mask gemm")
+        n = "mask_decoder.iou_prediction_head"
+        self.gemm(q, Cd, n + ".proj_in", 1, h1, Cd, a_off=1 * Cd)
+        self.ew(h1, Cd, None, 0, h1, Cd, 1, Cd, 2)
+        self.gemm(h1, Cd, n + ".layers.0", 1, h2, Cd)
+        self.ew(h2, Cd, None, 0, h2, Cd, 1, Cd, 2)
+        iou = self.buf("d_iou", 1, 16, torch.float32)
+        self.gemm(h2, Cd, n + ".proj_out", 1, iou, 16, EPI_F32)
+        return low, iou
+
+    # ------------------------------------------------------------------ the predictor's contract
+    def prompt(self, point_coords=None, point_labels=None, box=None):
+        """SAM2ImagePredictor's prompt preparation: coordinates scaled to the model frame, a box = two corner points labelled 2 / 3 in front
+        of the clicks."""
+        h, w = self.orig_hw
+        cs, ls = [], []
+        if box is not None:
+            cs.append(np.asarray(box, dtype=np.float32).reshape(2, 2))
+            ls.append(np.array([2, 3], dtype=np.int64))
+        if point_coords is not None and len(point_coords):
+            cs.append(np.asarray(point_coords, dtype=np.float32).reshape(-1, 2))
+            ls.append(np.asarray(point_labels, dtype=np.int64).reshape(-1))
+        if not cs:
+            raise ValueError("a prompt needs a box or points")
+        c = np.concatenate(cs, axis=0) * np.array([self.g.image_size / w, self.g.image_size / h], dtype=np.float32)
+        return c.astype(np.float32), np.concatenate(ls)
+
+    def predict_or(self, acc_u8: torch.Tensor, point_coords=None, point_labels=None, box=None, logits_out: Optional[torch.Tensor] = None):
+        """One object of ``segment``'s loop, entirely on the device: decode, pick the mask with the highest predicted IoU, resize its logits
+        to the image, threshold at 0, OR into ``acc_u8`` [h, w]."""
+        c, l = self.prompt(point_coords, point_labels, box)
+        low, iou = self.decode(c, l)
+        h, w = self.orig_hw
+        assert acc_u8.shape == (h, w) and acc_u8.dtype == torch.uint8 and acc_u8.is_cuda
+        self._ck(self.lib.sr_op_mask_resize_or(self._p(low), 16, 1, self.g.n_mask_tokens - 1, self.grid[0], self._p(iou), self._p(acc_u8), self._p(logits_out), h, w,
+                                               self._s()), "mask resize")
+        return low, iou
+
+    def predict(self, point_coords=None, point_labels=None, box=None, multimask_output: bool = True, return_logits: bool = False):
+        """(masks [3, h, w] bool (or logits), scores [3], low-resolution logits [3, m, m]) as numpy, like SAM2ImagePredictor.predict."""
+        if not multimask_output:
+            raise NotImplementedError("the reference calls predict with the default multimask_output=True")
+        h, w = self.orig_hw
+        acc = torch.zeros(h, w, dtype=torch.uint8, device=self.device)
+        lg = torch.empty(self.g.n_mask_tokens - 1, h, w, dtype=torch.float32, device=self.device)
+        low, iou = self.predict_or(acc, point_coords, point_labels, box, logits_out=lg)
+        m = self.grid[0]
+        scores = torch.sigmoid(iou[0, 1:self.g.n_mask_tokens]).cpu().numpy()
+        lows = low[:, 1:self.g.n_mask_tokens].t().reshape(-1, m, m).cpu().numpy()
+        out = lg.cpu().numpy()
+        return (out if return_logits else out > 0.0), scores, lows
+
+
+class Sam2Predictor:
+    """What ``SegInferStrategy`` expects from its model provider: ``set_image(PIL / ndarray)`` and ``predict(**prompt)``; also
+    ``segment_objects`` = the whole per-sample loop of seg_strategy.py:47-60 on the device."""
+
+    def __init__(self, engine: Sam2Engine):
+        self.model = self.engine = engine
+
+    def set_image(self, image):
+        arr = np.asarray(image.convert("RGB")) if hasattr(image, "convert") else np.asarray(image)
+        t = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint8))
+        self.engine.set_image(t.to(self.engine.device))
+
+    def predict(self, point_coords=None, point_labels=None, box=None, **kw):
+        return self.engine.predict(point_coords, point_labels, box, **kw)
+
+    def segment_objects(self, prompts: Sequence[dict]) -> torch.Tensor:
+        """OR of the best mask of every object prompt -> uint8 [h, w] on the device (objects whose prompt is malformed are skipped, as the
+        reference's bare ``except: continue`` does)."""
+        h, w = self.engine.orig_hw
+        acc = torch.zeros(h, w, dtype=torch.uint8, device=self.engine.device)
+        for vp in prompts:
+            try:
+                kw = {}
+                if "point_coords" in vp and "point_labels" in vp:
+                    kw["point_coords"], kw["point_labels"] = vp["point_coords"], vp["point_labels"]
+                if "box" in vp:
+                    kw["box"] = vp["box"]
+                self.engine.predict_or(acc, **kw)
+            except (ValueError, KeyError, TypeError):
+                continue
+        return acc

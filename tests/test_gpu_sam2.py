@@ -1,0 +1,89 @@
+"""SAM2 (Hiera-L) on the device against HF ``Sam2Model``'s own outputs (tests/golden/sam2.npz, tools/make_golden_sam2.py).
+
+The reference runs SAM2 in float32; the device path stores bf16 (float32 accumulation).  The fixtures hold HF's float32 run AND HF's
+bfloat16 run of the same network on the same weights: every stage is held to BAND x the distance HF-bf16 itself has from HF-float32,
+and the final 756 x 756 masks must be exact wherever the float32 logit is clear of that distance."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import bits_to_f32
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BAND = 1.6
+
+
+def _err(a, b):
+    d = (torch.as_tensor(a).float().flatten() - torch.as_tensor(b).float().flatten())
+    return float(d.abs().max()), float(d.pow(2).mean().sqrt())
+
+
+def _engine(tag):
+    from oracle import sam2_ref as S
+    from socioreasoner_amd import sam2
+    og = S.geometry_tiny() if tag == "tiny" else S.geometry_large()
+    g = sam2.Sam2Geometry(**{k: getattr(og, k) for k in sam2.Sam2Geometry.__dataclass_fields__})
+    e = sam2.Sam2Engine(g)
+    e.load_state_dict(S.synthetic_weights(og))
+    return e, og
+
+
+@pytest.mark.parametrize("tag", ["tiny", "large"])
+def test_sam2_device_vs_hf(golden_dir, tag):
+    from oracle import sam2_ref as S
+    from socioreasoner_amd import sam2, synthetic
+    g = np.load(os.path.join(golden_dir, "sam2.npz"))
+    e, og = _engine(tag)
+    hw, st = int(g[f"{tag}_hw"][0]), int(g[f"stride_{tag}"][0])
+    img = synthetic.tile_pixels(int(g[f"{tag}_img_seed"][0]), hw, hw)
+    e.set_image(torch.from_numpy(img).cuda())
+    torch.cuda.synchronize()
+    res = {}
+    for i, (x, ws) in enumerate(e.stage_out):
+        G, C = e.grid[i], og.embed_dims[i]
+        perm = torch.from_numpy(sam2.window_order(G, ws).astype(np.int64)).cuda()
+        mine = x[perm][:, :C].float().cpu().flatten()[::st]
+        f32, b16 = torch.from_numpy(g[f"{tag}_stage{i}_f32"]), bits_to_f32(g[f"{tag}_stage{i}_bf16"])
+        (mx, rms), (rmx, rrms) = _err(mine, f32), _err(b16, f32)
+        res[f"stage{i}"] = {"dev_vs_f32": [mx, rms], "hf_bf16_vs_f32": [rmx, rrms]}
+        assert rms <= BAND * rrms + 1e-4 and mx <= 2.5 * rmx + 1e-3, (i, res[f"stage{i}"])
+    for i, (x, C) in enumerate(((e.f0, og.fpn_dim // 8), (e.f1, og.fpn_dim // 4), (e.emb, og.fpn_dim))):
+        mine = x[:, :C].float().cpu().flatten()[::st]
+        f32, b16 = torch.from_numpy(g[f"{tag}_feat{i}_f32"]), bits_to_f32(g[f"{tag}_feat{i}_bf16"])
+        (mx, rms), (rmx, rrms) = _err(mine, f32), _err(b16, f32)
+        res[f"feat{i}"] = {"dev_vs_f32": [mx, rms], "hf_bf16_vs_f32": [rmx, rrms]}
+        assert rms <= BAND * rrms + 1e-4 and mx <= 2.5 * rmx + 1e-3, (i, res[f"feat{i}"])
+    for p in range(3):
+        box = g[f"{tag}_p{p}_box"].tolist() or None
+        pts = g[f"{tag}_p{p}_pts"]
+        logits, scores, low = e.predict(pts if len(pts) else None, g[f"{tag}_p{p}_labels"] if len(pts) else None, box, return_logits=True)
+        ref_low, ref_iou = g[f"{tag}_p{p}_low"], g[f"{tag}_p{p}_iou"]
+        (mx, rms), (rmx, rrms) = _err(low, ref_low), _err(bits_to_f32(g[f"{tag}_p{p}_low_bf16"]), ref_low)
+        res[f"p{p}"] = {"low_dev_vs_f32": [mx, rms], "low_hf_bf16_vs_f32": [rmx, rrms], "iou_dev": scores.tolist(), "iou_f32": ref_iou.tolist()}
+        assert rms <= BAND * rrms and mx <= 2.5 * rmx, (p, res[f"p{p}"])
+        assert np.abs(scores - ref_iou).max() <= max(3 * np.abs(bits_to_f32(g[f"{tag}_p{p}_iou_bf16"]).numpy() - ref_iou).max(), 0.01), (scores, ref_iou)
+        best = int(np.argmax(ref_iou))
+        assert int(np.argmax(scores)) == best
+        # the selected mask: exact wherever the float32 logit clears the bf16 band, and the object union kernel agrees with predict()
+        _, _, up = S.postprocess(torch.from_numpy(ref_low), torch.from_numpy(ref_iou), (hw, hw))
+        clear = up[best].abs() > 2.5 * rmx
+        mine = torch.from_numpy(logits[best] > 0)
+        want = torch.from_numpy(np.unpackbits(g[f"{tag}_p{p}_mask_bits"])[: hw * hw].reshape(hw, hw).astype(bool))
+        assert bool((mine == want)[clear].all()), p
+        res[f"p{p}"]["mask_pixels_differing"] = int((mine != want).sum())
+        res[f"p{p}"]["pixels_inside_band"] = int((~clear).sum())
+        assert (mine != want).sum() <= (~clear).sum()
+        acc = torch.zeros(hw, hw, dtype=torch.uint8, device="cuda")
+        e.predict_or(acc, pts if len(pts) else None, g[f"{tag}_p{p}_labels"] if len(pts) else None, box)
+        assert torch.equal(acc.cpu().bool(), mine)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "sam2_parity_r03.json")
+    cur = json.load(open(path)) if os.path.exists(path) else {}
+    cur[tag] = res
+    json.dump(cur, open(path, "w"), indent=1)
+    print(tag, json.dumps(res))
