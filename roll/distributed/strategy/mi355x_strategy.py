@@ -467,9 +467,10 @@ class Mi355xStrategy(InferenceStrategy):
 
 
 class SegRasterStrategy(InferenceStrategy):
-    """Raster half of SegInferStrategy.segment (seg_strategy.py:26-72) on the device: per-object mask union ->
-    nearest 756 -> 768.  The SAM2 forward itself is third-party and not available offline (SURVEY.md "next" row N1):
-    ``model_provider`` must return an object with set_image(image) / predict(**prompt) -> (masks, scores, _)."""
+    """SegInferStrategy.segment (seg_strategy.py:26-72): 756 x 756 resize, ``set_image``, per object predict -> arg-max score -> OR, nearest
+    756 -> 768.  ``model_provider`` returns the predictor: roll.models.model_providers.sam2_seg_model_provider gives the MI355X SAM2
+    (socioreasoner_amd.sam2.Sam2Predictor: the whole object loop on the device); any object with set_image(image) /
+    predict(**prompt) -> (masks, scores, _) works through the generic loop below."""
     strategy_name = "seg_infer"
 
     def initialize(self, model_provider=None):
@@ -490,6 +491,9 @@ class SegRasterStrategy(InferenceStrategy):
             if self.model is None:
                 raise RuntimeError("seg_infer needs a SAM2-compatible predictor (not available offline)")
             self.model.set_image(image.resize((756, 756)))
+            if hasattr(self.model, "segment_objects"):      # socioreasoner_amd.sam2: decode, arg-max, resize, threshold and OR stay on the device
+                masks.append(raster.resize_nearest(self.model.segment_objects(visual_prompt), 768, 768).cpu().numpy())
+                continue
             acc = torch.zeros(756, 756, dtype=torch.uint8, device="cuda")
             for vp in visual_prompt:
                 try:

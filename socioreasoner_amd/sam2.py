@@ -526,6 +526,118 @@ class Sam2Engine:
         return (out if return_logits else out > 0.0), scores, lows
 
 
+def param_shapes(g: Sam2Geometry) -> List[Tuple[str, tuple, float, float]]:
+    """(HF ``Sam2Model`` parameter name, shape, base, std) of everything ``load_state_dict`` reads.  std is what the synthetic mode draws
+    (no checkpoint offline): N(0, 1 / fan_in) for weights, so that activations stay of order one through 48 blocks."""
+    sp: List[Tuple[str, tuple, float, float]] = []
+
+    def lin(name, out_f, in_f, k=0):
+        sp.append((name + ".weight", (out_f, in_f) if k == 0 else (out_f, in_f, k, k), 0.0, 1.0 / math.sqrt(in_f * max(k, 1) ** 2)))
+        sp.append((name + ".bias", (out_f,), 0.0, 0.02))
+
+    def ln(name, c):
+        sp.append((name + ".weight", (c,), 1.0, 0.02))
+        sp.append((name + ".bias", (c,), 0.0, 0.02))
+
+    C, d0 = g.fpn_dim, g.embed_dims[0]
+    sp.append(("no_memory_embedding", (1, 1, C), 0.0, 0.02))
+    sp.append(("vision_encoder.backbone.pos_embed", (1, d0, g.bkg_size, g.bkg_size), 0.0, 0.02))
+    sp.append(("vision_encoder.backbone.pos_embed_window", (1, d0, g.windows[0], g.windows[0]), 0.0, 0.02))
+    lin("vision_encoder.backbone.patch_embed.projection", d0, 3, 7)
+    for i, (s, din, dout, heads, win, pooled) in enumerate(g.block_table()):
+        p = f"vision_encoder.backbone.blocks.{i}"
+        ln(p + ".layer_norm1", din)
+        lin(p + ".attn.qkv", 3 * dout, din)
+        lin(p + ".attn.proj", dout, dout)
+        ln(p + ".layer_norm2", dout)
+        lin(p + ".mlp.proj_in", 4 * dout, dout)
+        lin(p + ".mlp.proj_out", dout, 4 * dout)
+        if din != dout:
+            lin(p + ".proj", dout, din)
+    for j, c in enumerate(reversed(g.embed_dims)):
+        lin(f"vision_encoder.neck.convs.{j}", C, c, 1)
+    sp.append(("prompt_encoder.shared_embedding.positional_embedding", (2, C // 2), 0.0, 1.0))
+    for n, r in (("prompt_encoder.no_mask_embed", 1), ("prompt_encoder.point_embed", 4), ("prompt_encoder.not_a_point_embed", 1), ("mask_decoder.iou_token", 1),
+                 ("mask_decoder.mask_tokens", g.n_mask_tokens), ("mask_decoder.obj_score_token", 1)):
+        sp.append((n + ".weight", (r, C), 0.0, 0.5))
+    md = "mask_decoder.transformer."
+    for a, internal in [(f"{md}layers.{l}.{a}", C if a == "self_attn" else C // 2) for l in range(g.dec_layers)
+                        for a in ("self_attn", "cross_attn_token_to_image", "cross_attn_image_to_token")] + [(md + "final_attn_token_to_image", C // 2)]:
+        for q in ("q_proj", "k_proj", "v_proj"):
+            lin(f"{a}.{q}", internal, C)
+        lin(f"{a}.o_proj", C, internal)
+    for l in range(g.dec_layers):
+        for k in (1, 2, 3, 4):
+            ln(f"{md}layers.{l}.layer_norm{k}", C)
+        lin(f"{md}layers.{l}.mlp.proj_in", g.dec_mlp, C)
+        lin(f"{md}layers.{l}.mlp.proj_out", C, g.dec_mlp)
+    ln(md + "layer_norm_final_attn", C)
+    sp.append(("mask_decoder.upscale_conv1.weight", (C, C // 4, 2, 2), 0.0, 1.0 / math.sqrt(C)))
+    sp.append(("mask_decoder.upscale_conv1.bias", (C // 4,), 0.0, 0.02))
+    sp.append(("mask_decoder.upscale_conv2.weight", (C // 4, C // 8, 2, 2), 0.0, 1.0 / math.sqrt(C // 4)))
+    sp.append(("mask_decoder.upscale_conv2.bias", (C // 8,), 0.0, 0.02))
+    ln("mask_decoder.upscale_layer_norm", C // 4)
+    for n, out_f in [(f"mask_decoder.output_hypernetworks_mlps.{i}", C // 8) for i in range(g.n_mask_tokens)] + [("mask_decoder.iou_prediction_head", g.n_mask_tokens)]:
+        lin(n + ".proj_in", C, C)
+        lin(n + ".layers.0", C, C)
+        lin(n + ".proj_out", out_f, C)
+    lin("mask_decoder.conv_s0", C // 8, C, 1)
+    lin("mask_decoder.conv_s1", C // 4, C, 1)
+    return sp
+
+
+def synthetic_state_dict(g: Sam2Geometry, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random-init weights of the right shapes (synthetic mode: no checkpoint offline)."""
+    gen = torch.Generator().manual_seed(int(seed))
+    return {n: (base + torch.randn(shape, generator=gen) * std).to(torch.bfloat16) for n, shape, base, std in param_shapes(g)}
+
+
+# the sam2 package's checkpoint (sam2_hiera_large.pt, what the reference's provider loads: model_providers.py:540-541) -> HF names.
+# UNPINNED: neither the package nor a checkpoint is available offline; the table follows the two public module trees.
+_SAM2_RENAMES = [
+    ("image_encoder.trunk.patch_embed.proj.", "vision_encoder.backbone.patch_embed.projection."),
+    ("image_encoder.trunk.pos_embed_window", "vision_encoder.backbone.pos_embed_window"),
+    ("image_encoder.trunk.pos_embed", "vision_encoder.backbone.pos_embed"),
+    ("image_encoder.trunk.blocks.", "vision_encoder.backbone.blocks."),
+    ("image_encoder.neck.convs.", "vision_encoder.neck.convs."),
+    ("sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix", "prompt_encoder.shared_embedding.positional_embedding"),
+    ("sam_prompt_encoder.not_a_point_embed.", "prompt_encoder.not_a_point_embed."),
+    ("sam_prompt_encoder.no_mask_embed.", "prompt_encoder.no_mask_embed."),
+    ("sam_mask_decoder.", "mask_decoder."),
+    ("no_mem_embed", "no_memory_embedding"),
+]
+_SAM2_INNER = [(".norm1.", ".layer_norm1."), (".norm2.", ".layer_norm2."), (".norm3.", ".layer_norm3."), (".norm4.", ".layer_norm4."),
+               (".norm_final_attn.", ".layer_norm_final_attn."), (".out_proj.", ".o_proj."), (".conv.weight", ".weight"), (".conv.bias", ".bias"),
+               ("output_upscaling.0.", "upscale_conv1."), ("output_upscaling.1.", "upscale_layer_norm."), ("output_upscaling.3.", "upscale_conv2.")]
+
+
+def rename_sam2_checkpoint(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """sam2-package parameter names -> HF ``Sam2Model`` names (memory / video modules are dropped)."""
+    out: Dict[str, torch.Tensor] = {}
+    pts = {}
+    for k, v in sd.items():
+        if k.startswith(("memory_", "maskmem", "obj_ptr", "mask_downsample", "no_mem_pos_enc", "no_obj_", "sam_prompt_encoder.mask_downscaling")):
+            continue
+        if k.startswith("sam_prompt_encoder.point_embeddings."):
+            pts[int(k.split(".")[2])] = v
+            continue
+        n = k
+        for a, b in _SAM2_RENAMES:
+            if n.startswith(a):
+                n = b + n[len(a):]
+                break
+        for a, b in _SAM2_INNER:
+            n = n.replace(a, b)
+        if ".mlp.layers." in n and "hypernetworks" not in n and "iou_prediction" not in n and "obj_score" not in n:
+            n = n.replace(".mlp.layers.0.", ".mlp.proj_in.").replace(".mlp.layers.1.", ".mlp.proj_out.")
+        elif any(t in n for t in ("output_hypernetworks_mlps", "iou_prediction_head", "pred_obj_score_head")):
+            n = n.replace(".layers.0.", ".proj_in.").replace(".layers.2.", ".proj_out.").replace(".layers.1.", ".layers.0.")
+        out[n] = v
+    if pts:
+        out["prompt_encoder.point_embed.weight"] = torch.cat([pts[i].reshape(1, -1) for i in sorted(pts)], dim=0)
+    return out
+
+
 class Sam2Predictor:
     """What ``SegInferStrategy`` expects from its model provider: ``set_image(PIL / ndarray)`` and ``predict(**prompt)``; also
     ``segment_objects`` = the whole per-sample loop of seg_strategy.py:47-60 on the device."""
@@ -535,7 +647,7 @@ class Sam2Predictor:
 
     def set_image(self, image):
         arr = np.asarray(image.convert("RGB")) if hasattr(image, "convert") else np.asarray(image)
-        t = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint8))
+        t = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.array(arr, dtype=np.uint8, order="C"))
         self.engine.set_image(t.to(self.engine.device))
 
     def predict(self, point_coords=None, point_labels=None, box=None, **kw):

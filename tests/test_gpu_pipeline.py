@@ -102,25 +102,15 @@ def _canned_boxes(question: str):
     return out
 
 
-def test_pipeline_two_stage_flow_against_oracle(tmp_path):
-    """The reference's run() sequence with a scripted LM (answers are a function of the prompt text): parsing, SAM-prompt
-    construction, union / nearest resize, render onto both images, stage-2 prompt construction and IoU are compared with
-    the oracle restatements step by step (device raster kernels vs numpy / C)."""
+def _scripted_worker(cfg, geom, proc, seen):
+    """An ActorWorker whose strategy answers from a script (a function of the prompt text): stage 1 returns canned boxes (+ malformed
+    objects, one malformed JSON), stage 2 adds two points per box that was found."""
     import json
     import queue
     import re
-    from oracle import host_ref as H
     from roll.distributed.strategy.mi355x_strategy import Mi355xStrategy
     from roll.pipeline.base_worker import ActorWorker
-    from roll.pipeline.rlvr import rlvr_socioseg_vlm_pipeline_infer as P
-    from socioreasoner_amd import hostops, socioseg_data
-    from socioreasoner_amd.config import geometry_tiny
-    from socioreasoner_amd.textproc import SyntheticProcessor
-    geom = geometry_tiny()
-    proc = SyntheticProcessor(geom)
-    cfg = _cfg(tmp_path, resp=400, prompt=2200)
-    cfg.actor_infer.generating_args["temperature"] = 0
-    seen = {"stage2_images": {}, "stage2_text": {}}
+    from socioreasoner_amd import hostops
 
     class Scripted(Mi355xStrategy):
         geom_ = geom
@@ -163,6 +153,30 @@ def test_pipeline_two_stage_flow_against_oracle(tmp_path):
     w = ActorWorker(cfg.actor_infer, cfg, 0, 1, 0, "actor_infer")
     w.strategy = Scripted(w)
     w.strategy.initialize()
+    return w
+
+
+def test_pipeline_two_stage_flow_against_oracle(tmp_path):
+    """The reference's run() sequence with a scripted LM (answers are a function of the prompt text): parsing, SAM-prompt
+    construction, union / nearest resize, render onto both images, stage-2 prompt construction and IoU are compared with
+    the oracle restatements step by step (device raster kernels vs numpy / C)."""
+    import json
+    import queue
+    import re
+    from oracle import host_ref as H
+    from roll.distributed.strategy.mi355x_strategy import Mi355xStrategy
+    from roll.pipeline.base_worker import ActorWorker
+    from roll.pipeline.rlvr import rlvr_socioseg_vlm_pipeline_infer as P
+    from socioreasoner_amd import hostops, socioseg_data
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.textproc import SyntheticProcessor
+    geom = geometry_tiny()
+    proc = SyntheticProcessor(geom)
+    cfg = _cfg(tmp_path, resp=400, prompt=2200)
+    cfg.actor_infer.generating_args["temperature"] = 0
+    seen = {"stage2_images": {}, "stage2_text": {}}
+
+    w = _scripted_worker(cfg, geom, proc, seen)
     samples = socioseg_data.synthetic_socioseg(4)
     pipe = P.SocioSegInferPipeline(cfg, dataset=samples, processor=proc, actor_worker=w)
     acc = pipe.run()

@@ -87,3 +87,61 @@ def test_sam2_device_vs_hf(golden_dir, tag):
     cur[tag] = res
     json.dump(cur, open(path, "w"), indent=1)
     print(tag, json.dumps(res))
+
+
+def test_pipeline_two_stage_flow_with_sam2_on_device(golden_dir, tmp_path):
+    """The reference's run() sequence with the REAL predictor behind seg_infer (SAM2 on the device, tiny geometry, the oracle's synthetic
+    weights) instead of the synthetic stand-in: stage-1 / stage-2 PNGs equal an independent replay (second engine, per-object predict ->
+    arg-max -> OR -> nearest 756 -> 768 with the oracle's raster ops), and stay within the bf16 band of the FLOAT32 oracle's masks."""
+    import json
+    from PIL import Image
+    from oracle import host_ref as H
+    from oracle import sam2_ref as S
+    from roll.pipeline.rlvr import rlvr_socioseg_vlm_pipeline_infer as P
+    from socioreasoner_amd import sam2, socioseg_data
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.textproc import SyntheticProcessor
+    from tests.test_gpu_pipeline import _canned_boxes, _cfg, _scripted_worker
+    geom = geometry_tiny()
+    proc = SyntheticProcessor(geom)
+    cfg = _cfg(tmp_path, resp=400, prompt=2200)
+    cfg.actor_infer.generating_args["temperature"] = 0
+    seen = {"stage2_images": {}, "stage2_text": {}}
+    w = _scripted_worker(cfg, geom, proc, seen)
+    e1, og = _engine("tiny")
+    samples = socioseg_data.synthetic_socioseg(4)
+    pipe = P.SocioSegInferPipeline(cfg, dataset=samples, processor=proc, actor_worker=w, sam_predictor_provider=lambda **_: sam2.Sam2Predictor(e1))
+    acc = pipe.run()
+    res = os.path.join(str(tmp_path), "result")
+    e2, _ = _engine("tiny")
+    replay = sam2.Sam2Predictor(e2)
+    oracle = S.Sam2Oracle(S.synthetic_weights(og), og)
+    n_diff = n_px = 0
+    ious = []
+    for s in samples:
+        q = s["problem"]
+        seg = socioseg_data.load_image(s["sat_image"]).convert("RGB").resize((756, 756))
+        replay.set_image(seg)
+        oracle.set_image(np.asarray(seg))
+
+        def masks_for(prompts, pred):
+            acc_m = np.zeros((756, 756), np.uint8)
+            for pr in prompts:
+                m, sc, _ = pred.predict(**pr)
+                acc_m = H.mask_union([acc_m, np.asarray(m[int(np.argmax(sc))]).astype(np.uint8)])
+            return H.resize_nearest(acc_m, 768, 768)
+        boxes1 = [] if q == "school" else _canned_boxes(q)
+        pr1 = [{"box": np.array(b)} for b in boxes1]
+        pr2 = [{"box": np.array(b), "point_coords": np.array([[(b[0] + b[2]) // 2, (b[1] + b[3]) // 2], [b[2] + 15, b[3] + 15]]), "point_labels": np.array([1, 1])}
+               for b in boxes1]
+        for stage, prompts in (("stage1", pr1), ("stage2", pr2)):
+            got = np.asarray(Image.open(os.path.join(res, stage, s["id"] + ".png")))
+            assert np.array_equal(got, masks_for(prompts, replay) * 255), (s["id"], stage)
+            want32 = masks_for(prompts, oracle)
+            n_diff += int((got != want32 * 255).sum())
+            n_px += got.size
+            if stage == "stage2":
+                ious.append(H.compute_giou(got // 255, np.asarray(s["mask_label"].convert("L"))))
+    assert abs(acc - float(np.mean(ious))) < 1e-12
+    assert n_diff <= 0.02 * n_px, (n_diff, n_px)          # bf16 device masks vs the float32 oracle's: boundary pixels only
+    print("sam2 pipeline: pixels differing from the float32 oracle", n_diff, "of", n_px, "giou_acc", acc)
