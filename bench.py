@@ -61,6 +61,7 @@ def main():
                     "staging the next admission on a CU-masked stream under the running rows' decode")
     ap.add_argument("--no-latency", action="store_true", help="skip the additional batch-1 (configs[1]) measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sam", action="store_true", help="skip the SAM2 (seg_infer) timing")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="BASELINE.json configs[4] weights: LM decoder linears fp8 e4m3, per-channel scale")
     ap.add_argument("--fp8-mx", action="store_true", help="--fp8 plus MX fp8 activations in the prefill linears (fp8 x fp8 block-scaled MFMA, lm_weight_dtype 2)")
@@ -268,6 +269,35 @@ def main():
                   "static_batches_tiles_per_s": round(n_req / s_dt, 3), "static_batches_decode_steps": s_steps,
                   "gain": round(s_dt / r_dt, 4)}
 
+    # ---- SAM2 (Hiera-L) behind seg_infer: the mask half of a tile in the reference's pipeline (seg_strategy.py:47-60) -- 756 x 756 image ->
+    # set_image, then decode + arg-max + resize + OR per object.  Timed beside the LM path (the metric's tile uses synthetic masks: SURVEY 8(D)).
+    sam = None
+    if rank == 0 and not args.no_latency and not args.no_sam:
+        from socioreasoner_amd import sam2 as _sam2
+        sg = _sam2.Sam2Geometry()
+        se = _sam2.Sam2Engine(sg, str(dev))
+        se.load_state_dict(_sam2.synthetic_state_dict(sg))
+        simg = torch.from_numpy(synthetic.tile_pixels(0, 756, 756)).to(dev)
+        sacc = torch.zeros(756, 756, dtype=torch.uint8, device=dev)
+
+        def sam_tile(n_obj=4):
+            se.set_image(simg)
+            for k in range(n_obj):
+                se.predict_or(sacc, [[300 + 20 * k, 320]], [1], [100 + 30 * k, 120, 420 + 30 * k, 600])
+        sam_tile()
+        t_ = {}
+        for nm, fn, reps in (("set_image_ms", lambda: se.set_image(simg), 5), ("predict_ms_per_object", lambda: se.predict_or(sacc, [[300, 320]], [1], [100, 120, 420, 600]), 20),
+                             ("tile_ms_4_objects", sam_tile, 5)):
+            torch.cuda.synchronize(dev)
+            t0_ = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(dev)
+            t_[nm] = round((time.perf_counter() - t0_) / reps * 1e3, 3)
+        sam = dict(t_, workload="SAM2 Hiera-L (216.9 M parameters, random init), one 756 x 756 tile -> 1024 x 1024 input, box + click prompts, 3 masks + scores per object, "
+                                "best mask resized to 756 x 756 and OR-ed on the device", tiles_per_s_4_objects=round(1e3 / t_["tile_ms_4_objects"], 2), dtype="bf16")
+        del se
+
     # ---- configs[1] beside it: one tile at a time on the same engine (batch-1 kernels, hipGraph decode), rank 0 only
     latency = None
     if rank == 0 and B > 1 and not args.no_latency and not args.fp8:
@@ -459,7 +489,7 @@ def main():
                        "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",
                        "exchange": dict(exchange, payload="float32 logits all-gather per decode step (verification mode)" if args.gather_logits
                                         else "one all-gather of 1 KB result rows per tile and step")},
-            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_torch_bf16": cpu_hf, "phase_ms_per_step": phases, "static_batch": static_ref, "ragged": ragged, "latency_b1": latency,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_torch_bf16": cpu_hf, "phase_ms_per_step": phases, "static_batch": static_ref, "ragged": ragged, "sam2": sam, "latency_b1": latency,
             "weights_load_s": round(load_s, 1), "workspace_GB": round(eng.workspace_bytes / 1e9, 2),
             "result_checksum": int(res.sum().item()),
         }

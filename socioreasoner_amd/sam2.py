@@ -249,17 +249,23 @@ class Sam2Engine:
         self.h = {k: f(k) for k in ("prompt_encoder.shared_embedding.positional_embedding", "prompt_encoder.point_embed.weight",
                                     "prompt_encoder.not_a_point_embed.weight", "mask_decoder.obj_score_token.weight", "mask_decoder.iou_token.weight",
                                     "mask_decoder.mask_tokens.weight")}
+        self.h_np = {"pe": self.h["prompt_encoder.shared_embedding.positional_embedding"].numpy().astype(np.float32),
+                     "point": self.h["prompt_encoder.point_embed.weight"].numpy(), "nap": self.h["prompt_encoder.not_a_point_embed.weight"].numpy(),
+                     "out_tokens": torch.cat([self.h["mask_decoder.obj_score_token.weight"], self.h["mask_decoder.iou_token.weight"],
+                                              self.h["mask_decoder.mask_tokens.weight"]], dim=0).numpy()}
         m = g.image_size // 16
         ax = (torch.arange(m, dtype=torch.float32) + 0.5) / m
         yy, xx = torch.meshgrid(ax, ax, indexing="ij")
         self.W["image_pe"] = self._fourier(torch.stack([xx, yy], dim=-1).reshape(-1, 2)).to(torch.bfloat16).to(dev).contiguous()
         torch.cuda.synchronize(self.device)
 
-    def _fourier(self, coords01: torch.Tensor) -> torch.Tensor:
-        """random-Fourier position encoding (hf:727-749), float32 on the host"""
-        c = (2 * coords01 - 1) @ self.h["prompt_encoder.shared_embedding.positional_embedding"]
-        c = 2 * math.pi * c
-        return torch.cat([torch.sin(c), torch.cos(c)], dim=-1)
+    def _fourier(self, coords01) -> torch.Tensor:
+        """random-Fourier position encoding (hf:727-749), float32 on the host.  numpy on purpose: a dozen 2-vectors through torch's
+        CPU ops cost 18 ms per prompt on a 128-thread host (thread-pool wake-ups), 30 us here."""
+        G = self.h_np["pe"]
+        c = (2.0 * np.asarray(coords01, dtype=np.float32) - 1.0) @ G
+        c = np.float32(2.0 * math.pi) * c
+        return torch.from_numpy(np.concatenate([np.sin(c), np.cos(c)], axis=-1).astype(np.float32))
 
     # ------------------------------------------------------------------ image encoder
     def _index(self, name, arr) -> torch.Tensor:
@@ -383,12 +389,12 @@ class Sam2Engine:
         """output tokens + sparse prompt embeddings (hf:791-813, 1175-1190): coords in the model's input frame, labels 1 / 0 clicks, 2 / 3 box
         corners; the encoder's padding point is appended."""
         g = self.g
-        pts = torch.cat([torch.from_numpy(np.asarray(coords, dtype=np.float32)) + 0.5, torch.zeros(1, 2)], dim=0)
-        lab = torch.cat([torch.from_numpy(np.asarray(labels, dtype=np.int64)), torch.tensor([-1])])
-        e = self._fourier(pts / g.image_size)
-        e = torch.where(lab[:, None] == -1, self.h["prompt_encoder.not_a_point_embed.weight"], e)
-        e = e + self.h["prompt_encoder.point_embed.weight"][lab.clamp(min=0)] * (lab >= 0)[:, None].float()
-        return torch.cat([self.h["mask_decoder.obj_score_token.weight"], self.h["mask_decoder.iou_token.weight"], self.h["mask_decoder.mask_tokens.weight"], e], dim=0)
+        pts = np.concatenate([np.asarray(coords, dtype=np.float32) + 0.5, np.zeros((1, 2), np.float32)], axis=0)
+        lab = np.concatenate([np.asarray(labels, dtype=np.int64), np.array([-1])])
+        e = self._fourier(pts / np.float32(g.image_size)).numpy()
+        e = np.where(lab[:, None] == -1, self.h_np["nap"], e)
+        e = e + self.h_np["point"][np.clip(lab, 0, None)] * (lab >= 0)[:, None].astype(np.float32)
+        return torch.from_numpy(np.concatenate([self.h_np["out_tokens"], e.astype(np.float32)], axis=0))
 
     def _mha(self, name, q, nq, k, v, nk, internal, out, resid, tag):
         """Sam2Attention (hf:874-942): out = [resid +] o_proj(attention(q_proj(q), k_proj(k), v_proj(v)))"""

@@ -1,0 +1,23 @@
+"""GPU timing of the SAM2 path at Hiera-L: set_image (756 x 756 tile -> embeddings) and predict_or per object.  Synthetic weights."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from socioreasoner_amd import sam2, synthetic
+g = sam2.Sam2Geometry()
+e = sam2.Sam2Engine(g)
+e.load_state_dict(sam2.synthetic_state_dict(g))
+img = torch.from_numpy(synthetic.tile_pixels(7, 756, 756)).cuda()
+acc = torch.zeros(756, 756, dtype=torch.uint8, device="cuda")
+def run(n_img, n_obj):
+    for _ in range(n_img):
+        e.set_image(img)
+        for k in range(n_obj):
+            e.predict_or(acc, [[300 + k, 300]], [1], [100 + 10 * k, 120, 500, 600])
+run(2, 4)
+torch.cuda.synchronize()
+for name, fn, reps in (("set_image", lambda: e.set_image(img), 10), ("predict_or (box + 1 click)", lambda: e.predict_or(acc, [[300, 300]], [1], [100, 120, 500, 600]), 40)):
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); ev0.record()
+    for _ in range(reps): fn()
+    ev1.record(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"{name:28s}: host issue {1e3 * (t1 - t0) / reps:7.3f} ms  wall {1e3 * (t2 - t0) / reps:7.3f} ms  gpu {ev0.elapsed_time(ev1) / reps:7.3f} ms")
