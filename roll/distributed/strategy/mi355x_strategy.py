@@ -127,7 +127,12 @@ class Mi355xStrategy(InferenceStrategy):
             return
         world = len(args["tgt_devices"]) + 1
         grp = join_named_group(args["group_name"], backend, world, rank, args["master_addr"], args["master_port"])
-        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        # (the HIP current device is per THREAD: an RPC thread of a worker with local_rank > 0 would otherwise join the communicator on
+        # device 0 -- bind everything of the weight-sync path to the ENGINE's device)
+        edev = getattr(getattr(self, "engine", None), "device", None)
+        if backend == "nccl" and edev is not None:
+            torch.cuda.set_device(edev)
+        dev = (edev if edev is not None else torch.device("cuda", torch.cuda.current_device())) if backend == "nccl" else torch.device("cpu")
         dist.all_reduce(torch.zeros(1, device=dev), group=grp)                 # warm-up, like the reference
         self.model_update_comm_plan[args["src_pp_rank"]] = dict(rank=rank, world_size=world, src_pp_rank=args["src_pp_rank"],
                                                                 group_name=args["group_name"], comm_plan=comm_plan, comm_plan_args=args,
@@ -143,14 +148,23 @@ class Mi355xStrategy(InferenceStrategy):
         dist.broadcast(xt, src=0, group=plan["group"])
         return xt
 
+    def _recv_device(self, src_pp_rank):
+        plan = getattr(self, "model_update_comm_plan", {}).get(src_pp_rank)
+        if plan is not None:
+            if plan["device"].type == "cuda":
+                torch.cuda.set_device(plan["device"])
+            return plan["device"]
+        edev = getattr(getattr(self, "engine", None), "device", None)
+        return edev if edev is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+
     def broadcast_bucket(self, src_pp_rank, meta_infos, bucket_size):
-        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        dev = self._recv_device(src_pp_rank)
         buf = self._bcast(src_pp_rank, torch.empty(int(bucket_size), dtype=torch.int8, device=dev))
         if buf is not None:
             self.update_parameter_in_bucket(meta_infos, buf, [0])
 
     def broadcast_parameter(self, src_pp_rank, dtype, shape, parameter_name):
-        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        dev = self._recv_device(src_pp_rank)
         w = self._bcast(src_pp_rank, torch.empty(tuple(shape), dtype=dtype, device=dev))
         if w is not None:
             self.update_parameter(parameter_name, w, [0])

@@ -188,6 +188,8 @@ const char* validate(const sr_config& c) {
     if (c.lm_weight_dtype < 0 || c.lm_weight_dtype > 2) return "lm_weight_dtype 0 (bf16), 1 (fp8 e4m3 weights, per-channel scale) or 2 (1 + MX fp8 activations in prefill)";
     if (c.lm_weight_dtype == 2 && (c.t_hidden % 256 || ((c.t_heads + 2 * c.t_kv_heads) * 128) % 256 || c.t_hidden / 128 < 2))
         return "lm_weight_dtype 2: the block-scaled fp8 GEMM needs hidden and q/k/v widths in multiples of 256";
+    if (c.lm_weight_dtype == 2 && ((c.t_inter + 63) / 64 * 64) % 128)
+        return "lm_weight_dtype 2: the MX activation quantiser needs the padded intermediate size (t_inter rounded up to 64) in multiples of 128";
     if (c.max_patches < 4 || c.max_patches % 4 || c.max_prefill_tokens < 1 || c.max_new_tokens < 1) return "capacities";
     if (c.v_n_fullatt < 0 || c.v_n_fullatt > 16 || c.v_depth < 1 || c.t_layers < 1) return "depths";
     return nullptr;

@@ -16,6 +16,10 @@ import numpy as np
 import torch
 
 
+import os as _os
+_MASK_FIRST_CHUNK = _os.environ.get("SR_MASK_FIRST_CHUNK", "0") == "1"      # A/B hook for the choice documented in _pump_overlap
+
+
 @dataclass
 class Request:
     ids: np.ndarray                       # int64 [S], image placeholders already expanded
@@ -91,6 +95,13 @@ class ContinuousBatcher:
         return out
 
     def submit(self, req: Request):
+        """A request that can never be admitted (more prompt tokens / patches than ONE admission may carry, or no room for a single new
+        token) is refused here: inside the pump it would take KV slots with it when the engine rejects the group."""
+        cfg = self.engine.cfg
+        npatch = sum(t * h * w for t, h, w in req.grids)
+        if len(req.ids) > cfg.max_prefill_tokens or npatch > cfg.max_patches or len(req.ids) + 1 > cfg.max_ctx:
+            raise ValueError(f"request of {len(req.ids)} tokens / {npatch} patches exceeds the engine's capacity "
+                             f"(max_prefill_tokens {cfg.max_prefill_tokens}, max_patches {cfg.max_patches}, max_ctx {cfg.max_ctx})")
         self.pending.append(req)
 
     def idle(self) -> bool:
@@ -133,11 +144,15 @@ class ContinuousBatcher:
         emb = None
         ims = [im for r in grp for im in r.images]
         t0 = self._mark()
-        if ims:
-            pix = torch.cat([self.engine.patchify(im) for im in ims], dim=0)
-            emb = self.engine.vit_forward(pix, [g for r in grp for g in r.grids])
-        t1 = self._mark()
-        self.engine.admit(rows, [r.ids for r in grp], [r.pos3 for r in grp], [r.max_new for r in grp], emb)
+        try:
+            if ims:
+                pix = torch.cat([self.engine.patchify(im) for im in ims], dim=0)
+                emb = self.engine.vit_forward(pix, [g for r in grp for g in r.grids])
+            t1 = self._mark()
+            self.engine.admit(rows, [r.ids for r in grp], [r.pos3 for r in grp], [r.max_new for r in grp], emb)
+        except BaseException:
+            self.free.extendleft(reversed(rows))
+            raise
         self._span("vit", t0, t1)
         self._span("prefill", t1, self._mark())
         for row, r in zip(rows, grp):
@@ -212,6 +227,13 @@ class ContinuousBatcher:
         else:
             s = self._use_decode_stream(self.streams.decode_full)
         cal = self._auto and not shared and self._adm_rate is None and self._cal_adm is None
+        try:
+            self._stage_on(s, grp, slots, shared, cal, units)
+        except BaseException:
+            self.free_slots.extendleft(reversed(slots))          # the group is lost to its caller (the exception says so), the slots are not
+            raise
+
+    def _stage_on(self, s, grp, slots, shared, cal, units):
         with torch.cuda.stream(s):
             if cal:
                 c0 = torch.cuda.Event(enable_timing=True)
@@ -268,7 +290,12 @@ class ContinuousBatcher:
                 self.staged[2].synchronize()
             return
         busy = self.staged is not None and not self.staged[2].query()
-        s = self._use_decode_stream(self.streams.decode if busy else self.streams.decode_full)
+        # The chunk under which the next admission gets staged is queued on the UNMASKED stream: its steps_per_poll steps own every CU and the
+        # admission's first GEMMs queue behind them.  Putting that chunk on the decode CU set instead (SR_MASK_FIRST_CHUNK=1: the admission
+        # starts at once, the chunk decodes on 160 CUs) was measured and is slower -- 76.8 vs 78.3 tiles/s, two runs each, same box: the
+        # admission is not on the critical path for that long, the decode rows are.
+        will_stage = _MASK_FIRST_CHUNK and self.staged is None and bool(self.pending) and bool(self.free_slots)
+        s = self._use_decode_stream(self.streams.decode if (busy or will_stage) else self.streams.decode_full)
         # (step-time calibration: a chunk with the chip to itself -- no admission in flight and none about to be staged under it)
         cal = (self._auto and not busy and not (self.staged is None and self.pending and self.free_slots)
                and self._step_ms is None and self._cal_step is None)
@@ -278,13 +305,13 @@ class ContinuousBatcher:
                 c0.record(s)
             t0 = self._mark()
             self.engine.rows_step(self.steps_per_poll, self.eos, self.pad_id)
-            self._span("decode_shared" if busy else "decode", t0, self._mark())
+            self._span("decode_shared" if (busy or will_stage) else "decode", t0, self._mark())
             if cal:
                 c1 = torch.cuda.Event(enable_timing=True)
                 c1.record(s)
                 self._cal_step = (c0, c1, self.steps_per_poll)
         self.stats["steps"] += self.steps_per_poll
-        self.stats["steps_shared"] += self.steps_per_poll if busy else 0
+        self.stats["steps_shared"] += self.steps_per_poll if (busy or will_stage) else 0
         if self.staged is None and self.pending and self.free_slots:
             self._stage()                              # the host side of the next admission is prepared while the chunk above runs
         with torch.cuda.stream(s):
