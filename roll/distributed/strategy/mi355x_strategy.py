@@ -497,17 +497,24 @@ class SegRasterStrategy(InferenceStrategy):
         return None
 
     def segment(self, batch: DataProto) -> dict:
-        masks = []
-        for image, visual_prompt in zip(batch.non_tensor_batch["seg_image"], batch.non_tensor_batch["visual_prompt"]):
-            if len(visual_prompt) == 0:
-                masks.append(np.zeros((768, 768), dtype=np.uint8))
-                continue
-            if self.model is None:
-                raise RuntimeError("seg_infer needs a SAM2-compatible predictor (not available offline)")
+        images, prompts = list(batch.non_tensor_batch["seg_image"]), list(batch.non_tensor_batch["visual_prompt"])
+        masks: list = [None] * len(images)
+        live = [i for i, vp in enumerate(prompts) if len(vp) > 0]
+        for i in range(len(images)):
+            if i not in live:
+                masks[i] = np.zeros((768, 768), dtype=np.uint8)       # seg_strategy.py:36-38: nothing to segment
+        if live and self.model is None:
+            raise RuntimeError("seg_infer needs a SAM2-compatible predictor (not available offline)")
+        if live and hasattr(self.model, "segment_batch"):
+            # socioreasoner_amd.sam2: the encoder runs over several images per pass (and not at all for an image it has seen: stage 2
+            # segments stage 1's image), decode / arg-max / resize / threshold / OR stay on the device
+            accs = self.model.segment_batch([images[i].resize((756, 756)) for i in live], [prompts[i] for i in live])
+            for i, acc in zip(live, accs):
+                masks[i] = raster.resize_nearest(acc, 768, 768).cpu().numpy()
+            live = []
+        for i in live:
+            image, visual_prompt = images[i], prompts[i]
             self.model.set_image(image.resize((756, 756)))
-            if hasattr(self.model, "segment_objects"):      # socioreasoner_amd.sam2: decode, arg-max, resize, threshold and OR stay on the device
-                masks.append(raster.resize_nearest(self.model.segment_objects(visual_prompt), 768, 768).cpu().numpy())
-                continue
             acc = torch.zeros(756, 756, dtype=torch.uint8, device="cuda")
             for vp in visual_prompt:
                 try:
@@ -517,7 +524,7 @@ class SegRasterStrategy(InferenceStrategy):
                     raster.mask_union_(acc, torch.from_numpy(best).cuda())
                 except Exception:  # noqa: BLE001  (the reference swallows per-object failures, seg_strategy.py:61-62)
                     continue
-            masks.append(raster.resize_nearest(acc, 768, 768).cpu().numpy())
+            masks[i] = raster.resize_nearest(acc, 768, 768).cpu().numpy()
         out = np.empty(len(masks), dtype=object)
         for i, m in enumerate(masks):
             out[i] = m

@@ -573,6 +573,13 @@ bool fold_ln2() {
     const char* env = getenv("SR_FOLD_LN2");
     return env && atoi(env) == 1;
 }
+// SR_DEFER_LN: the batch > 4 decode layer's RMSNorms as DEFERRED row scales (gemv.hip XN == 2): the producing GEMV's epilogue stores
+// bf16(h * w_ln) and the rows' partial sums of squares, the consuming GEMV scales its float32 sums by 1 / rms(row).  No norm launch, no
+// per-element work in the consumer.
+int defer_ln() {
+    const char* env = getenv("SR_DEFER_LN");
+    return env ? atoi(env) : 0;
+}
 int ks_down(const sr_engine* e, int B) { return (B > 16 && e->t_inter_pad / 64 >= 32) ? 4 : e->ks_down; }
 
 // LM head on B rows of `x` (+ optional pending slabs): float32 logits + per-block argmax partials.
@@ -634,11 +641,14 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         // of squares, the gate/up GEMV turns them into the row scales and normalises its x fragments in registers (same formula and
         // rounding points as k_rmsnorm_row; the sum of squares is added in another order).
         const bool fold2 = !fused && xt && !w.o_w8 && fold_ln2();
+        const bool defer2 = !fused && xt && !w.o_w8 && !w.gu_w8 && !fold2 && defer_ln() >= 1;
         if (fold2) { go.h_tiled = e->d_ht; go.ss_out = e->d_ss; }
+        if (defer2) { go.h_tiled = e->d_ht; go.ss_out = e->d_ss; go.xn_w = w.ln2; }
         SR_TRY(launch_gemv(s, go, GV_RESID));
         GemvArgs gg = gv(x, H, w.gu_w, B, 2 * e->t_inter_pad, H, e->d_act, e->t_inter_pad);
         gg.W8 = w.gu_w8; gg.w_scale = w.gu_s;
         if (fused) { gg.norm_w = w.ln2; gg.eps = c.t_rms_eps; }
+        else if (defer2) { gg.x = e->d_ht; gg.x_tiled = 1; gg.out_tiled = 1; gg.ss_in = e->d_ss; gg.n_ss = H / 16; gg.eps = c.t_rms_eps; }
         else if (fold2) { gg.x = e->d_ht; gg.x_tiled = 1; gg.out_tiled = 1; gg.xn_w = w.ln2; gg.ss_in = e->d_ss; gg.n_ss = H / 16; gg.eps = c.t_rms_eps; }
         else { SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt)); gg.x = e->d_xn; gg.x_tiled = xt; gg.out_tiled = xt; }
         SR_TRY(launch_gemv(s, gg, GV_SWIGLU));

@@ -28,6 +28,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 from dataclasses import dataclass
+from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -283,79 +284,95 @@ class Sam2Engine:
 
     def set_image(self, img_u8: torch.Tensor):
         """uint8 HWC device tensor (756 x 756 in the reference's flow) -> image embedding + high-resolution features kept on the device."""
+        self.set_images([img_u8])
+
+    def set_images(self, imgs: Sequence[torch.Tensor]):
+        """The image encoder over B images AT ONCE: their tokens are stacked along the row axis (image b = rows [b N, (b + 1) N) of every
+        stage, each in window order), so every GEMM / LayerNorm / pooling launch covers all of them -- at one image the GEMMs of stages 3 / 4
+        have 4096 / 1024 rows, too few for 256 CUs.  ``select(b)`` then points the decoder at image b's features."""
         g, lib, s = self.g, self.lib, self._s
-        assert img_u8.dtype == torch.uint8 and img_u8.is_cuda and img_u8.dim() == 3 and img_u8.shape[2] == 3
-        img_u8 = img_u8.contiguous()
-        self.orig_hw = (int(img_u8.shape[0]), int(img_u8.shape[1]))
+        B = len(imgs)
+        assert B >= 1
         S = g.image_size
-        chw = self.buf("chw", 3, S * S)
-        self._ck(lib.sr_op_sam_preprocess(self._p(img_u8), self.orig_hw[0], self.orig_hw[1], self._p(chw), S, s()), "preprocess")
         G0, C0 = self.grid[0], g.embed_dims[0]
+        N0 = G0 * G0
+        tag = f"@{B}"
+        chw = self.buf("chw" + tag, B * 3, S * S)
         order0 = self._index("order0", window_order(G0, g.windows[0]))
         kp = rup(3 * 49)
-        col = self.buf("im2col", G0 * G0, kp)
-        self._ck(lib.sr_op_im2col(self._p(chw), S, 7, 4, 3, self._p(col), kp, self._p(order0), s()), "im2col")
-        x = self.buf("x0", G0 * G0, rup(C0))
+        col = self.buf("im2col" + tag, B * N0, kp)
+        self.orig_hws = []
+        for b, im in enumerate(imgs):
+            assert im.dtype == torch.uint8 and im.is_cuda and im.dim() == 3 and im.shape[2] == 3
+            im = im.contiguous()
+            self.orig_hws.append((int(im.shape[0]), int(im.shape[1])))
+            self._ck(lib.sr_op_sam_preprocess(self._p(im), int(im.shape[0]), int(im.shape[1]), self._p(chw, b * 3 * S * S), S, s()), "preprocess")
+            self._ck(lib.sr_op_im2col(self._p(chw, b * 3 * S * S), S, 7, 4, 3, self._p(col, b * N0 * kp), kp, self._p(order0), s()), "im2col")
+        pos = self.W.get("pos_table" + tag)
+        if pos is None:
+            pos = self.W["pos_table" + tag] = self.W["pos_table"].repeat(B, 1).contiguous()
+        x = self.buf("x0" + tag, B * N0, rup(C0))
         # x = bf16(pos + bf16(conv + bias)), rows already in window order (hf:664-665)
-        self.gemm(col, kp, "vision_encoder.backbone.patch_embed.projection", G0 * G0, x, rup(C0), EPI_RESID, resid=self.W["pos_table"])
+        self.gemm(col, kp, "vision_encoder.backbone.patch_embed.projection", B * N0, x, rup(C0), EPI_RESID, resid=pos)
         ends = set(np.cumsum(g.blocks) - 1)
         cur_ws = g.windows[0]                 # the window size the current token order is organised by
         stage_out = []
-        for i, b in enumerate(self.blocks):
-            s_, din, dout, heads, hdp, HP, win, pooled = b["stage"], b["din"], b["dout"], b["heads"], b["hdp"], b["HP"], b["win"], b["pooled"]
+        for i, blk in enumerate(self.blocks):
+            s_, din, dout, heads, hdp, HP, win, pooled = blk["stage"], blk["din"], blk["dout"], blk["heads"], blk["hdp"], blk["HP"], blk["win"], blk["pooled"]
             Gin = self.grid[s_ - 1] if pooled else self.grid[s_]
-            N = Gin * Gin
-            name = b["name"]
-            scale = b["hd"] ** -0.5
-            xn = self.buf(f"xn{s_}{'p' if pooled else ''}", N, rup(din))
+            Ni = Gin * Gin                     # tokens per image
+            N = B * Ni
+            name = blk["name"]
+            scale = blk["hd"] ** -0.5
+            sfx = ("p" if pooled else "") + tag
+            xn = self.buf(f"xn{s_}{sfx}", N, rup(din))
             self.layernorm(x, rup(din), name + ".layer_norm1", xn, rup(din), N, din, g.ln_eps)
-            qkv = self.buf(f"qkv{s_}{'p' if pooled else ''}", N, 3 * HP)
+            qkv = self.buf(f"qkv{s_}{sfx}", N, 3 * HP)
             self.gemm(xn, rup(din), name + ".attn.qkv", N, qkv, 3 * HP)
             vts = rup(N) + 64
-            vt = self.buf(f"vt{s_}{'p' if pooled else ''}", HP, vts)
+            vt = self.buf(f"vt{s_}{sfx}", HP, vts)
             self._ck(lib.sr_op_transpose(self._p(qkv, 2 * HP), 3 * HP, N, HP, self._p(vt), vts, s()), "transpose")
             if pooled:
                 assert win > 0 and win == cur_ws, "stage-entry blocks pool inside the previous stage's windows"
                 Nq, nw = N // 4, N // (win * win)
-                Gout = Gin // 2
-                xnew = self.buf(f"x{s_}", Nq, rup(dout))
-                rfull = self.buf(f"rfull{s_}", N, rup(dout))
+                xnew = self.buf(f"x{s_}{tag}", Nq, rup(dout))
+                rfull = self.buf(f"rfull{s_}{tag}", N, rup(dout))
                 self.gemm(xn, rup(din), name + ".proj", N, rfull, rup(dout))
                 self._ck(lib.sr_op_maxpool_win(self._p(rfull), rup(dout), dout, nw, win, self._p(xnew), rup(dout), s()), "maxpool")
-                qp = self.buf(f"qp{s_}", Nq, HP)
+                qp = self.buf(f"qp{s_}{tag}", Nq, HP)
                 self._ck(lib.sr_op_maxpool_win(self._p(qkv), 3 * HP, HP, nw, win, self._p(qp), HP, s()), "maxpool q")
-                att = self.buf(f"att{s_}", Nq, rup(HP))
-                wk = self.work(("pool", s_), self._window_work(nw, win * win, win * win // 4))
+                att = self.buf(f"att{s_}{tag}", Nq, rup(HP))
+                wk = self.work(("pool", s_, B), self._window_work(nw, win * win, win * win // 4))
                 self.attention(qp, HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale)
-                x, N, cur_ws = xnew, Nq, win // 2
+                x, N, Ni, cur_ws = xnew, Nq, Ni // 4, win // 2
                 self.gemm(att, rup(HP), name + ".attn.proj", N, x, rup(dout), EPI_RESID, resid=x)
             else:
-                att = self.buf(f"att{s_}", N, rup(HP))
+                att = self.buf(f"att{s_}{tag}", N, rup(HP))
                 if win > 0:
                     assert win == cur_ws
-                    wk = self.work(("win", s_), self._window_work(N // (win * win), win * win, win * win))
+                    wk = self.work(("win", s_, B), self._window_work(N // (win * win), win * win, win * win))
                     self.attention(qkv, 3 * HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale)
-                else:           # global attention: token order does not matter
-                    v2 = hdp == 80
+                else:           # global attention inside every image: token order does not matter
+                    v2 = hdp == 80 and Ni % 8 == 0
                     tile = 128 if v2 else 64
-                    wk = self.work(("glob", s_, tile), [(q0, N, q0, 0, 0, 0) for q0 in range(0, N, tile)])
+                    wk = self.work(("glob", s_, tile, B), [(b * Ni + q0, Ni, q0, b * Ni, b * Ni, 0) for b in range(B) for q0 in range(0, Ni, tile)])
                     self.attention(qkv, 3 * HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale, q_tile=tile, v2_ok=1 if v2 else 0)
                 self.gemm(att, rup(HP), name + ".attn.proj", N, x, rup(dout), EPI_RESID, resid=x)
-            self.layernorm(x, rup(dout), name + ".layer_norm2", xn if not pooled else self.buf(f"xn{s_}", N, rup(dout)), rup(dout), N, dout, g.ln_eps)
-            xn2 = self._bufs[f"xn{s_}"]
-            hid = self.buf(f"hid{s_}", N, 4 * dout)
+            xn2 = self.buf(f"xn{s_}{tag}", N, rup(dout))
+            self.layernorm(x, rup(dout), name + ".layer_norm2", xn2, rup(dout), N, dout, g.ln_eps)
+            hid = self.buf(f"hid{s_}{tag}", N, 4 * dout)
             self.gemm(xn2, rup(dout), name + ".mlp.proj_in", N, hid, 4 * dout, EPI_GELU)
             self.gemm(hid, 4 * dout, name + ".mlp.proj_out", N, x, rup(dout), EPI_RESID, resid=x)
             if pooled and cur_ws != g.windows[s_]:
                 # the pooled tokens sit in window order of size cur_ws; the stage's own windows are g.windows[s_]: one row gather
                 Gs = self.grid[s_]
-                a, bb = window_order(Gs, cur_ws), window_order(Gs, g.windows[s_])
+                a_, b_ = window_order(Gs, cur_ws), window_order(Gs, g.windows[s_])
                 src = np.empty(Gs * Gs, dtype=np.int32)
-                src[bb] = a                                # row bb[i] of the new order takes row a[i] of the old one
-                x2 = self.buf(f"x{s_}g", N, rup(dout))
-                self._ck(lib.sr_op_gather_rows(self._p(x), self._p(self._index(f"regather{s_}", src)), self._p(x2), N, rup(dout), s()), "gather")
+                src[b_] = a_                               # row b_[i] of the new order takes row a_[i] of the old one
+                src = np.concatenate([src + k * Gs * Gs for k in range(B)])
+                x2 = self.buf(f"x{s_}g{tag}", N, rup(dout))
+                self._ck(lib.sr_op_gather_rows(self._p(x), self._p(self._index(f"regather{s_}{tag}", src)), self._p(x2), N, rup(dout), s()), "gather")
                 x, cur_ws = x2, g.windows[s_]
-                self._bufs[f"x{s_}"], self._bufs[f"x{s_}g"] = x2, self._bufs[f"x{s_}"]      # (the stage keeps updating this buffer in place)
             if i in ends:
                 stage_out.append((x, cur_ws))
         # ---- FPN neck (hf:216-265): lateral 1 x 1 convolutions written in IMAGE order through the row map, one top-down step
@@ -364,24 +381,45 @@ class Sam2Engine:
         for lvl in range(4):
             xs, ws = stage_out[lvl]
             Gs = self.grid[lvl]
-            inv = self._index(f"to_image{lvl}_{ws}", np.argsort(window_order(Gs, ws)).astype(np.int32))   # row r (window order) -> image index
-            o = self.buf(f"lat{lvl}", Gs * Gs, Cd)
-            self.gemm(xs, rup(g.embed_dims[lvl]), f"vision_encoder.neck.convs.{3 - lvl}", Gs * Gs, o, Cd, EPI_STORE, rowmap=inv)
+            inv1 = np.argsort(window_order(Gs, ws)).astype(np.int32)                                  # row r (window order) -> image index
+            inv = self._index(f"to_image{lvl}_{ws}{tag}", np.concatenate([inv1 + k * Gs * Gs for k in range(B)]))
+            o = self.buf(f"lat{lvl}{tag}", B * Gs * Gs, Cd)
+            self.gemm(xs, rup(g.embed_dims[lvl]), f"vision_encoder.neck.convs.{3 - lvl}", B * Gs * Gs, o, Cd, EPI_STORE, rowmap=inv)
             lat.append(o)
+        m2, n3 = self.grid[2] ** 2, self.grid[3] ** 2
         fpn2 = lat[2]
         if 2 in g.top_down_levels:
-            fpn2 = self.buf("fpn2", self.grid[2] ** 2, Cd)
-            self._ck(lib.sr_op_upsample2x_add(self._p(lat[2]), self._p(lat[3]), self._p(fpn2), self.grid[2], Cd, Cd, s()), "upsample")
-        m2 = self.grid[2] ** 2
-        self.emb = self.buf("emb", m2, Cd)
-        self.ew(fpn2, Cd, self.W["no_mem"], 0, self.emb, Cd, m2, Cd, 1)                      # + no-memory embedding (hf:1499-1500)
-        self.keys0 = self.buf("keys0", m2, Cd)
-        self.ew(self.emb, Cd, self.W["no_mask"], 0, self.keys0, Cd, m2, Cd, 1)                # + dense "no mask" embedding (hf:1193)
-        self.f0 = self.buf("f0", self.grid[0] ** 2, Cd // 8)
-        self.gemm(lat[0], Cd, "mask_decoder.conv_s0", self.grid[0] ** 2, self.f0, Cd // 8)
-        self.f1 = self.buf("f1", self.grid[1] ** 2, Cd // 4)
-        self.gemm(lat[1], Cd, "mask_decoder.conv_s1", self.grid[1] ** 2, self.f1, Cd // 4)
-        self.stage_out = stage_out
+            fpn2 = self.buf("fpn2" + tag, B * m2, Cd)
+            for b in range(B):
+                self._ck(lib.sr_op_upsample2x_add(self._p(lat[2], b * m2 * Cd), self._p(lat[3], b * n3 * Cd), self._p(fpn2, b * m2 * Cd), self.grid[2], Cd, Cd, s()), "upsample")
+        emb = self.buf("emb" + tag, B * m2, Cd)
+        self.ew(fpn2, Cd, self.W["no_mem"], 0, emb, Cd, B * m2, Cd, 1)                      # + no-memory embedding (hf:1499-1500)
+        keys0 = self.buf("keys0" + tag, B * m2, Cd)
+        self.ew(emb, Cd, self.W["no_mask"], 0, keys0, Cd, B * m2, Cd, 1)                    # + dense "no mask" embedding (hf:1193)
+        f0 = self.buf("f0" + tag, B * self.grid[0] ** 2, Cd // 8)
+        self.gemm(lat[0], Cd, "mask_decoder.conv_s0", B * self.grid[0] ** 2, f0, Cd // 8)
+        f1 = self.buf("f1" + tag, B * self.grid[1] ** 2, Cd // 4)
+        self.gemm(lat[1], Cd, "mask_decoder.conv_s1", B * self.grid[1] ** 2, f1, Cd // 4)
+        self.stage_out, self.n_images = stage_out, B
+        self._feat = (emb, keys0, f0, f1)
+        self.select(0)
+
+    def select(self, b: int):
+        """point the decoder at image b of the last set_images call"""
+        emb, keys0, f0, f1 = self._feat
+        m2, n0, n1 = self.grid[2] ** 2, self.grid[0] ** 2, self.grid[1] ** 2
+        self.emb, self.keys0 = emb[b * m2:(b + 1) * m2], keys0[b * m2:(b + 1) * m2]
+        self.f0, self.f1 = f0[b * n0:(b + 1) * n0], f1[b * n1:(b + 1) * n1]
+        self.orig_hw = self.orig_hws[b]
+        self.image_set = True
+
+    def features(self) -> dict:
+        """the selected image's decoder inputs as an object that outlives the next set_images call (an embedding cache: the reference's
+        two stages segment the same satellite image)"""
+        return {"emb": self.emb.clone(), "keys0": self.keys0.clone(), "f0": self.f0.clone(), "f1": self.f1.clone(), "orig_hw": self.orig_hw}
+
+    def use_features(self, ft: dict):
+        self.emb, self.keys0, self.f0, self.f1, self.orig_hw = ft["emb"], ft["keys0"], ft["f0"], ft["f1"], ft["orig_hw"]
         self.image_set = True
 
     # ------------------------------------------------------------------ prompt encoder (host, float32) + mask decoder
@@ -648,16 +686,65 @@ class Sam2Predictor:
     """What ``SegInferStrategy`` expects from its model provider: ``set_image(PIL / ndarray)`` and ``predict(**prompt)``; also
     ``segment_objects`` = the whole per-sample loop of seg_strategy.py:47-60 on the device."""
 
-    def __init__(self, engine: Sam2Engine):
+    def __init__(self, engine: Sam2Engine, batch: int = 8, cache_images: int = 256):
         self.model = self.engine = engine
+        self.batch = max(1, int(batch))               # images per encoder pass
+        self.cache_images = int(cache_images)         # embeddings kept (10 MB each at Hiera-L): stage 2 segments stage 1's image again
+        self._cache: "OrderedDict[bytes, dict]" = OrderedDict()
+        self.stats = {"images": 0, "encoded": 0, "cache_hits": 0, "encoder_passes": 0}
+
+    @staticmethod
+    def _host_u8(image) -> np.ndarray:
+        arr = np.asarray(image.convert("RGB")) if hasattr(image, "convert") else np.asarray(image)
+        return np.ascontiguousarray(arr, dtype=np.uint8)
 
     def set_image(self, image):
-        arr = np.asarray(image.convert("RGB")) if hasattr(image, "convert") else np.asarray(image)
-        t = image if isinstance(image, torch.Tensor) else torch.from_numpy(np.array(arr, dtype=np.uint8, order="C"))
+        t = image if isinstance(image, torch.Tensor) else torch.from_numpy(self._host_u8(image))
         self.engine.set_image(t.to(self.engine.device))
 
     def predict(self, point_coords=None, point_labels=None, box=None, **kw):
         return self.engine.predict(point_coords, point_labels, box, **kw)
+
+    def embed(self, images: Sequence) -> List[dict]:
+        """image embeddings of a list of host images: the ones seen before come from the cache (keyed by a hash of the pixels), the rest go
+        through the encoder ``batch`` at a time.  Same numbers either way: the encoder is deterministic and images do not interact."""
+        import xxhash
+        arrs = [self._host_u8(im) for im in images]
+        keys = [xxhash.xxh3_128_digest(a.data) + bytes(str(a.shape), "ascii") for a in arrs]
+        feats: Dict[bytes, dict] = {}
+        todo = []
+        for k, a in zip(keys, arrs):
+            if k in feats or k in todo:
+                continue
+            if k in self._cache:
+                self._cache.move_to_end(k)
+                feats[k] = self._cache[k]
+                self.stats["cache_hits"] += 1
+            else:
+                todo.append(k)
+        by_key = dict(zip(keys, arrs))
+        for i in range(0, len(todo), self.batch):
+            chunk = todo[i:i + self.batch]
+            self.engine.set_images([torch.from_numpy(by_key[k]).to(self.engine.device, non_blocking=True) for k in chunk])
+            self.stats["encoder_passes"] += 1
+            self.stats["encoded"] += len(chunk)
+            for b, k in enumerate(chunk):
+                self.engine.select(b)
+                feats[k] = self.engine.features()
+                if self.cache_images > 0:
+                    self._cache[k] = feats[k]
+                    while len(self._cache) > self.cache_images:
+                        self._cache.popitem(last=False)
+        self.stats["images"] += len(arrs)
+        return [feats[k] for k in keys]
+
+    def segment_batch(self, images: Sequence, prompts: Sequence[Sequence[dict]]) -> List[torch.Tensor]:
+        """seg_strategy.py:40-66 over a whole batch: embeddings (batched / cached), then the object loop of every sample on the device"""
+        out = []
+        for ft, vps in zip(self.embed(images), prompts):
+            self.engine.use_features(ft)
+            out.append(self.segment_objects(vps))
+        return out
 
     def segment_objects(self, prompts: Sequence[dict]) -> torch.Tensor:
         """OR of the best mask of every object prompt -> uint8 [h, w] on the device (objects whose prompt is malformed are skipped, as the

@@ -145,3 +145,35 @@ def test_pipeline_two_stage_flow_with_sam2_on_device(golden_dir, tmp_path):
     assert abs(acc - float(np.mean(ious))) < 1e-12
     assert n_diff <= 0.02 * n_px, (n_diff, n_px)          # bf16 device masks vs the float32 oracle's: boundary pixels only
     print("sam2 pipeline: pixels differing from the float32 oracle", n_diff, "of", n_px, "giou_acc", acc)
+
+
+def test_sam2_batched_encoder_equals_one_image_at_a_time_and_cache_replays():
+    """set_images over B images stacks their tokens in every launch; the features of image b must be the ones a set_image of that image
+    alone leaves (same kernels, same order of arithmetic per row => bit-for-bit), and the predictor's embedding cache must hand them back."""
+    from socioreasoner_amd import sam2, synthetic
+    e, og = _engine("tiny")
+    hw = 189
+    imgs = [torch.from_numpy(synthetic.tile_pixels(40 + i, hw, hw)).cuda() for i in range(3)]
+    single = []
+    for im in imgs:
+        e.set_image(im)
+        single.append(e.features())
+    e.set_images(imgs)
+    for b in range(3):
+        e.select(b)
+        ft = e.features()
+        for k in ("emb", "keys0", "f0", "f1"):
+            assert torch.equal(ft[k].view(torch.int16), single[b][k].view(torch.int16)), (b, k)
+    pr = sam2.Sam2Predictor(e, batch=2)
+    host = [im.cpu().numpy() for im in imgs]
+    prompts = [[{"point_coords": [[60 + 9 * i, 70]], "point_labels": [1], "box": [20, 30, 150, 160]}, {"box": [10, 10, 90, 120]}, {"oops": 1}] for i in range(3)]
+    a = pr.segment_batch(host, prompts)
+    assert pr.stats["encoded"] == 3 and pr.stats["encoder_passes"] == 2 and pr.stats["cache_hits"] == 0
+    b_ = pr.segment_batch(host[::-1] + [host[0]], prompts[::-1] + [prompts[0]])       # stage 2: same images again (and one twice)
+    assert pr.stats["encoded"] == 3 and pr.stats["cache_hits"] == 3
+    for x, y in zip(a + [a[0]], b_[2::-1] + [b_[3]]):
+        assert torch.equal(x, y)
+    for i in range(3):                                                                  # against the one-image path
+        e.set_image(imgs[i])
+        assert torch.equal(pr.segment_objects(prompts[i]), a[i])
+        assert int(a[i].sum()) > 0

@@ -7,7 +7,7 @@ P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 B = int(os.environ.get("PB", 1))
 H, QN, I, V = 2048, 2560, 11008, 151936
-R = 12
+R = int(os.environ.get("PR", 12))
 x = torch.randn(B, I, device="cuda").to(torch.bfloat16)
 nw = torch.ones(H, device="cuda").to(torch.bfloat16)
 bias = torch.zeros(QN, device="cuda").to(torch.bfloat16)

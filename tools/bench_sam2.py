@@ -15,7 +15,12 @@ def run(n_img, n_obj):
             e.predict_or(acc, [[300 + k, 300]], [1], [100 + 10 * k, 120, 500, 600])
 run(2, 4)
 torch.cuda.synchronize()
-for name, fn, reps in (("set_image", lambda: e.set_image(img), 10), ("predict_or (box + 1 click)", lambda: e.predict_or(acc, [[300, 300]], [1], [100, 120, 500, 600]), 40)):
+imgs8 = [torch.from_numpy(synthetic.tile_pixels(7 + i, 756, 756)).cuda() for i in range(8)]
+for nb in (2, 4, 8):
+    e.set_images(imgs8[:nb])
+torch.cuda.synchronize()
+for name, fn, reps in (("set_image", lambda: e.set_image(img), 10), ("set_images x2", lambda: e.set_images(imgs8[:2]), 5), ("set_images x4", lambda: e.set_images(imgs8[:4]), 5),
+                       ("set_images x8", lambda: e.set_images(imgs8), 5), ("predict_or (box + 1 click)", lambda: e.predict_or(acc, [[300, 300]], [1], [100, 120, 500, 600]), 40)):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); t0 = time.perf_counter(); ev0.record()
     for _ in range(reps): fn()
