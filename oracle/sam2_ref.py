@@ -165,7 +165,7 @@ def synthetic_weights(g: Sam2Geometry, seed: int = 0, dtype=torch.float32) -> di
 # ------------------------------------------------------------------------------------------------ predictor pre / post-processing
 def preprocess(img_u8: np.ndarray, size: int = 1024, dtype=torch.float32) -> torch.Tensor:
     """uint8 HWC -> float [1, 3, size, size]: /255, bilinear resize (align_corners False), ImageNet normalisation."""
-    x = torch.from_numpy(np.ascontiguousarray(img_u8)).permute(2, 0, 1)[None].float() / 255.0
+    x = torch.from_numpy(np.array(img_u8, dtype=np.uint8, order="C")).permute(2, 0, 1)[None].float() / 255.0
     x = F.interpolate(x, size=(size, size), mode="bilinear", align_corners=False)
     mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
     std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)

@@ -31,6 +31,19 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float silu_f(float x) { return x * (1.0f / (1.0f + __expf(-x))); }
 // nn.GELU() (erf form), float32 internally
 __device__ __forceinline__ float gelu_f(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+// The same function for callers that opt in (GemmArgs.gelu_fast; the SAM2 image encoder): x * Phi(x) with Phi from erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2), t = 1 / (1 + p z), z = |x| / sqrt(2) >= 0
+// (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute on erfc: the same size as the float32 erff's own error after the 1 + erf
+// cancellation at negative x, and three orders below the bf16 rounding every caller applies next).  ~14 instructions against the device
+// library erff's ~40: the GELU epilogue of the short-K GEMMs of SAM2's
+// first stages is mostly this function (encoder over 8 tiles: 41.9 -> 38.8 ms).  The LM's merger keeps erff: its float32-truth band
+// (tests/test_gpu_round3.py) was measured with it.
+__device__ __forceinline__ float gelu_fast_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float half_erfc = 0.5f * poly * __expf(-z * z);
+    return x * (x >= 0.f ? 1.0f - half_erfc : half_erfc);
+}
 
 // Fragment-ordered ("tiled16x64") weight layout of a [N, K] matrix (N % 16 == 0, K % 64 == 0): every 16-row x 64-k
 // block is 2 KB contiguous, stored in the order the decode GEMV's MFMA A-operand wants it --

@@ -76,6 +76,65 @@ __global__ __launch_bounds__(256) void k_layernorm(const bf16_t* x, int ldx, con
     }
 }
 
+// The same LayerNorm, 16 bytes per lane: LP lanes share a row (64 / LP rows per wave), each lane holds NV runs of 8 channels.  Same formula
+// and rounding point as k_layernorm; the float32 statistics are summed in another order.  (k_layernorm moved 2 bytes per lane: 1.1 TB/s on
+// the 524 288 x 144 rows of Hiera-L's first stage.)
+template <int LP, int NV>
+__global__ __launch_bounds__(256) void k_layernorm_v(const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, int ldo, int rows, int C, float eps) {
+    constexpr int RW = 64 / LP;
+    const int lane = threadIdx.x & 63, l = lane % LP;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW + lane / LP;
+    const bool live = row < rows;
+    const bf16_t* xr = x + (size_t)(live ? row : 0) * ldx;
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c0 = (l + i * LP) * 8;
+        uint4 u = uint4{0, 0, 0, 0};
+        if (live && c0 < ldx && c0 < C) u = *reinterpret_cast<const uint4*>(xr + c0);
+        const float t[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[i][e] = c0 + e < C ? t[e] : 0.f;
+            s += v[i][e];
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < LP; o <<= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = (l + i * LP) * 8 + e < C ? v[i][e] - mean : 0.f;
+            q += d * d;
+        }
+#pragma unroll
+    for (int o = 1; o < LP; o <<= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    if (!live) return;
+    bf16_t* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c0 = (l + i * LP) * 8;
+        if (c0 >= ldo) continue;
+        float o[8];
+        if (c0 < C) {
+            const uint4 wu = *reinterpret_cast<const uint4*>(w + c0), bu = *reinterpret_cast<const uint4*>(b + c0);      // (w, b padded to 8 by the caller's layout: C % 8 == 0)
+            const float wf[8] = {lo16(wu.x), hi16(wu.x), lo16(wu.y), hi16(wu.y), lo16(wu.z), hi16(wu.z), lo16(wu.w), hi16(wu.w)};
+            const float bf[8] = {lo16(bu.x), hi16(bu.x), lo16(bu.y), hi16(bu.y), lo16(bu.z), hi16(bu.z), lo16(bu.w), hi16(bu.w)};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * wf[e] + bf[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.f;
+        }
+        *reinterpret_cast<uint4*>(orow + c0) = uint4{pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+    }
+}
+
 // ---- 2 x 2 max pooling of tokens that are stored window by window ([n_win][ws * ws] rows -> [n_win][(ws/2)^2] rows; hf:290-298, 337-341)
 __global__ __launch_bounds__(256) void k_maxpool_win(const bf16_t* in, int ld_in, int C, int ws, bf16_t* out, int ld_out) {
     const int h2 = ws / 2, per = h2 * h2;
@@ -113,6 +172,37 @@ __global__ __launch_bounds__(256) void k_transpose(const bf16_t* in, int ld_in, 
     for (int j = ty; j < 32; j += 8) {
         const int c = c0 + j, r = r0 + tx;
         if (c < cols && r < rows) out[(size_t)c * ld_out + r] = t[tx][j];
+    }
+}
+
+// The same transpose with 16-byte accesses on both sides: 64 x 64 tiles, rows padded to 66 elements in LDS (a column walk then steps 33
+// banks).  Needs cols, both leading dimensions and both base addresses in units of 8 elements; the row tail is stored element by element.
+__global__ __launch_bounds__(256) void k_transpose_v(const bf16_t* in, int ld_in, int rows, int cols, bf16_t* out, int ld_out) {
+    __shared__ __attribute__((aligned(16))) bf16_t t[64 * 66];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, v = threadIdx.x & 7, q = threadIdx.x >> 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = r0 + q + 32 * j, c = c0 + v * 8;
+        uint4 u = uint4{0, 0, 0, 0};
+        if (r < rows && c < cols) u = *reinterpret_cast<const uint4*>(in + (size_t)r * ld_in + c);
+        uint32_t* d = reinterpret_cast<uint32_t*>(t + (q + 32 * j) * 66 + v * 8);          // 4-byte aligned: 66 and 8 are even
+        d[0] = u.x; d[1] = u.y; d[2] = u.z; d[3] = u.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cl = q + 32 * j, c = c0 + cl, rl = v * 8, r = r0 + rl;
+        if (c >= cols || r >= rows) continue;
+        bf16_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = t[(rl + k) * 66 + cl];
+        bf16_t* o = out + (size_t)c * ld_out + r;
+        if (r + 8 <= rows) {
+            *reinterpret_cast<uint4*>(o) = uint4{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                                                 (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16)};
+        } else {
+            for (int k = 0; k < 8 && r + k < rows; ++k) o[k] = e[k];
+        }
     }
 }
 
@@ -176,6 +266,15 @@ int launch_im2col(hipStream_t s, const bf16_t* chw, int S, int k, int stride, in
 int launch_layernorm(hipStream_t s, const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, int ldo, int rows, int C, float eps) {
     if (rows <= 0) return 0;
     if (C > 1152 || ldo > 1152) return -22;
+    const bool vec = C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)x | (uintptr_t)out | (uintptr_t)w | (uintptr_t)b) % 16 == 0 && ldo <= 1536;
+    if (vec) {
+        const int span = ldo > C ? ldo : C;                 // columns a row's lanes must cover (pad columns are written as zeros)
+        if (span <= 256) hipLaunchKernelGGL((k_layernorm_v<32, 1>), dim3(cdiv(rows, 8)), dim3(256), 0, s, x, ldx, w, b, out, ldo, rows, C, eps);
+        else if (span <= 512) hipLaunchKernelGGL((k_layernorm_v<64, 1>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, w, b, out, ldo, rows, C, eps);
+        else if (span <= 1024) hipLaunchKernelGGL((k_layernorm_v<64, 2>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, w, b, out, ldo, rows, C, eps);
+        else hipLaunchKernelGGL((k_layernorm_v<64, 3>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, w, b, out, ldo, rows, C, eps);
+        LAUNCH_OK();
+    }
     hipLaunchKernelGGL(k_layernorm, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, w, b, out, ldo, rows, C, eps);
     LAUNCH_OK();
 }
@@ -190,6 +289,10 @@ int launch_ew(hipStream_t s, const bf16_t* a, int lda, const bf16_t* b, int ldb,
     LAUNCH_OK();
 }
 int launch_transpose(hipStream_t s, const bf16_t* in, int ld_in, int rows, int cols, bf16_t* out, int ld_out) {
+    if (cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in | (uintptr_t)out) % 16 == 0) {
+        hipLaunchKernelGGL(k_transpose_v, dim3(cdiv(rows, 64), cdiv(cols, 64)), dim3(256), 0, s, in, ld_in, rows, cols, out, ld_out);
+        LAUNCH_OK();
+    }
     hipLaunchKernelGGL(k_transpose, dim3(cdiv(rows, 32), cdiv(cols, 32)), dim3(256), 0, s, in, ld_in, rows, cols, out, ld_out);
     LAUNCH_OK();
 }

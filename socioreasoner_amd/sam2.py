@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -37,6 +38,7 @@ import torch
 from . import lib as L
 
 EPI_STORE, EPI_RESID, EPI_GELU, EPI_F32 = 0, 1, 3, 4
+GELU_FAST = 0x800          # sr_op_gemm: the GELU epilogue through gelu_fast_f (csrc/common.h)
 _WORK = np.dtype([("q_row0", "<i4"), ("seq_len", "<i4"), ("q_off", "<i4"), ("k_row0", "<i4"), ("vt_off", "<i8"), ("q_len", "<i4"), ("pad", "<i4")])
 _HD_OK = (16, 32, 80, 128)
 
@@ -350,8 +352,11 @@ class Sam2Engine:
                 att = self.buf(f"att{s_}{tag}", N, rup(HP))
                 if win > 0:
                     assert win == cur_ws
-                    wk = self.work(("win", s_, B), self._window_work(N // (win * win), win * win, win * win))
-                    self.attention(qkv, 3 * HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale)
+                    # windows of >= 128 tokens (stage 3: 16 x 16) go to the 8-wave kernel: 128 queries share each LDS-DMA-staged K / V^T tile
+                    v2 = hdp == 80 and (win * win) % 128 == 0 and os.environ.get("SR_SAM_WIN_V2", "1") != "0"
+                    tile = 128 if v2 else 64
+                    wk = self.work(("win", s_, B, tile), self._window_work(N // (win * win), win * win, win * win, tile=tile))
+                    self.attention(qkv, 3 * HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale, q_tile=tile, v2_ok=1 if v2 else 0)
                 else:           # global attention inside every image: token order does not matter
                     v2 = hdp == 80 and Ni % 8 == 0
                     tile = 128 if v2 else 64
@@ -361,7 +366,7 @@ class Sam2Engine:
             xn2 = self.buf(f"xn{s_}{tag}", N, rup(dout))
             self.layernorm(x, rup(dout), name + ".layer_norm2", xn2, rup(dout), N, dout, g.ln_eps)
             hid = self.buf(f"hid{s_}{tag}", N, 4 * dout)
-            self.gemm(xn2, rup(dout), name + ".mlp.proj_in", N, hid, 4 * dout, EPI_GELU)
+            self.gemm(xn2, rup(dout), name + ".mlp.proj_in", N, hid, 4 * dout, EPI_GELU | GELU_FAST)
             self.gemm(hid, 4 * dout, name + ".mlp.proj_out", N, x, rup(dout), EPI_RESID, resid=x)
             if pooled and cur_ws != g.windows[s_]:
                 # the pooled tokens sit in window order of size cur_ws; the stage's own windows are g.windows[s_]: one row gather
@@ -696,7 +701,7 @@ class Sam2Predictor:
     @staticmethod
     def _host_u8(image) -> np.ndarray:
         arr = np.asarray(image.convert("RGB")) if hasattr(image, "convert") else np.asarray(image)
-        return np.ascontiguousarray(arr, dtype=np.uint8)
+        return np.array(arr, dtype=np.uint8, order="C")          # (a copy: PIL hands out read-only buffers)
 
     def set_image(self, image):
         t = image if isinstance(image, torch.Tensor) else torch.from_numpy(self._host_u8(image))
