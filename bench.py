@@ -280,31 +280,35 @@ def main():
         simg = torch.from_numpy(synthetic.tile_pixels(0, 756, 756)).to(dev)
         sacc = torch.zeros(756, 756, dtype=torch.uint8, device=dev)
 
-        def sam_tile(n_obj=4):
-            se.set_image(simg)
-            for k in range(n_obj):
-                se.predict_or(sacc, [[300 + 20 * k, 320]], [1], [100 + 30 * k, 120, 420 + 30 * k, 600])
-        sam_tile()
-        t_ = {}
-        simgs = [torch.from_numpy(synthetic.tile_pixels(i, 756, 756)).to(dev) for i in range(8)]
+        sobj = [dict(point_coords=[[300 + 20 * k, 320]], point_labels=[1], box=[100 + 30 * k, 120, 420 + 30 * k, 600]) for k in range(4)]
 
-        def sam_tiles8(n_obj=4):
+        def sam_tile():                      # the reference's loop: one image, one object at a time
+            se.set_image(simg)
+            for o in sobj:
+                se.predict_or(sacc, **o)
+
+        def sam_tiles8():                    # 8 tiles per encoder pass, the 4 objects of a tile per decoder pass
             se.set_images(simgs)
             for b_ in range(8):
                 se.select(b_)
-                for k in range(n_obj):
-                    se.predict_or(sacc, [[300 + 20 * k, 320]], [1], [100 + 30 * k, 120, 420 + 30 * k, 600])
+                se.predict_or_many(sacc, sobj)
+        simgs = [torch.from_numpy(synthetic.tile_pixels(i, 756, 756)).to(dev) for i in range(8)]
+        sam_tile()
         sam_tiles8()
-        for nm, fn, reps in (("set_image_ms", lambda: se.set_image(simg), 5), ("set_images_8_ms", lambda: se.set_images(simgs), 3), ("tiles8_ms_4_objects", sam_tiles8, 3), ("predict_ms_per_object", lambda: se.predict_or(sacc, [[300, 320]], [1], [100, 120, 420, 600]), 20),
-                             ("tile_ms_4_objects", sam_tile, 5)):
+        t_ = {}
+        for nm, fn, reps in (("set_image_ms", lambda: se.set_image(simg), 5), ("set_images_8_ms", lambda: se.set_images(simgs), 3),
+                             ("predict_ms_per_object", lambda: se.predict_or(sacc, **sobj[0]), 20), ("predict_ms_4_objects_one_pass", lambda: se.predict_or_many(sacc, sobj), 20),
+                             ("tile_ms_4_objects", sam_tile, 5), ("tiles8_ms_4_objects", sam_tiles8, 3)):
             torch.cuda.synchronize(dev)
             t0_ = time.perf_counter()
             for _ in range(reps):
                 fn()
             torch.cuda.synchronize(dev)
             t_[nm] = round((time.perf_counter() - t0_) / reps * 1e3, 3)
-        sam = dict(t_, workload="SAM2 Hiera-L (216.9 M parameters, random init), one 756 x 756 tile -> 1024 x 1024 input, box + click prompts, 3 masks + scores per object, "
-                                "best mask resized to 756 x 756 and OR-ed on the device", tiles_per_s_4_objects=round(1e3 / t_["tile_ms_4_objects"], 2), tiles_per_s_4_objects_encoder_batch_8=round(8e3 / t_["tiles8_ms_4_objects"], 2), dtype="bf16")
+        sam = dict(t_, workload="SAM2 Hiera-L (216.9 M parameters, random init), 756 x 756 tiles -> 1024 x 1024 input, box + click prompts, 3 masks + scores per object, "
+                                "best mask resized to 756 x 756 and OR-ed on the device; tile_ms = one tile and one object at a time (the reference's loop), "
+                                "tiles8_ms = 8 tiles per encoder pass and a tile's 4 objects per decoder pass (what seg_infer runs)",
+                   tiles_per_s_4_objects=round(1e3 / t_["tile_ms_4_objects"], 2), tiles_per_s_4_objects_batched=round(8e3 / t_["tiles8_ms_4_objects"], 2), dtype="bf16")
         del se
 
     # ---- configs[1] beside it: one tile at a time on the same engine (batch-1 kernels, hipGraph decode), rank 0 only

@@ -109,6 +109,9 @@ class Sam2Engine:
         self._work: Dict[tuple, tuple] = {}
         self._idx: Dict[str, torch.Tensor] = {}
         self.image_set = False
+        self._cur = None
+        self._graphs: Dict[int, tuple] = {}
+        self.graph_decode = os.environ.get("SR_SAM_GRAPH", "1") != "0"
 
     # ------------------------------------------------------------------ plumbing
     def _s(self):
@@ -163,6 +166,7 @@ class Sam2Engine:
         """HF ``Sam2Model`` state dict (or the sam2 checkpoint renamed to it).  Re-laid-out once: K padded to 64-multiples with zeros,
         head_dim padded to a kernel-supported width, 1 x 1 / patch / transposed convolutions flattened to GEMM operands."""
         g, dev = self.g, self.device
+        self._graphs.clear()            # (captured launches hold the old weights' addresses)
         f = lambda name: sd[name].detach().float().cpu()
 
         def put(name, w2d, bias=None, n_pad=None):
@@ -409,14 +413,22 @@ class Sam2Engine:
         self._feat = (emb, keys0, f0, f1)
         self.select(0)
 
+    def _set_current(self, emb, keys0, f0, f1, hw):
+        """the decoder reads the image through FIXED buffers (its launches are replayed from a captured graph): 10 MB of copies per image"""
+        cur = self._cur
+        if cur is None:
+            cur = self._cur = tuple(torch.empty_like(t) for t in (emb, keys0, f0, f1))
+        for d, t in zip(cur, (emb, keys0, f0, f1)):
+            d.copy_(t)
+        self.emb, self.keys0, self.f0, self.f1 = cur
+        self.orig_hw = hw
+        self.image_set = True
+
     def select(self, b: int):
         """point the decoder at image b of the last set_images call"""
         emb, keys0, f0, f1 = self._feat
         m2, n0, n1 = self.grid[2] ** 2, self.grid[0] ** 2, self.grid[1] ** 2
-        self.emb, self.keys0 = emb[b * m2:(b + 1) * m2], keys0[b * m2:(b + 1) * m2]
-        self.f0, self.f1 = f0[b * n0:(b + 1) * n0], f1[b * n1:(b + 1) * n1]
-        self.orig_hw = self.orig_hws[b]
-        self.image_set = True
+        self._set_current(emb[b * m2:(b + 1) * m2], keys0[b * m2:(b + 1) * m2], f0[b * n0:(b + 1) * n0], f1[b * n1:(b + 1) * n1], self.orig_hws[b])
 
     def features(self) -> dict:
         """the selected image's decoder inputs as an object that outlives the next set_images call (an embedding cache: the reference's
@@ -424,8 +436,7 @@ class Sam2Engine:
         return {"emb": self.emb.clone(), "keys0": self.keys0.clone(), "f0": self.f0.clone(), "f1": self.f1.clone(), "orig_hw": self.orig_hw}
 
     def use_features(self, ft: dict):
-        self.emb, self.keys0, self.f0, self.f1, self.orig_hw = ft["emb"], ft["keys0"], ft["f0"], ft["f1"], ft["orig_hw"]
-        self.image_set = True
+        self._set_current(ft["emb"], ft["keys0"], ft["f0"], ft["f1"], ft["orig_hw"])
 
     # ------------------------------------------------------------------ prompt encoder (host, float32) + mask decoder
     def _tokens(self, coords: np.ndarray, labels: np.ndarray) -> torch.Tensor:
@@ -439,10 +450,17 @@ class Sam2Engine:
         e = e + self.h_np["point"][np.clip(lab, 0, None)] * (lab >= 0)[:, None].astype(np.float32)
         return torch.from_numpy(np.concatenate([self.h_np["out_tokens"], e.astype(np.float32)], axis=0))
 
-    def _mha(self, name, q, nq, k, v, nk, internal, out, resid, tag):
-        """Sam2Attention (hf:874-942): out = [resid +] o_proj(attention(q_proj(q), k_proj(k), v_proj(v)))"""
-        g, Cd = self.g, self.g.fpn_dim
+    TOK = 16        # row stride of one object's tokens in the decoder's token matrices (prompts of up to 16 tokens share one captured launch sequence)
+
+    def _mha(self, name, q, k, v, q_side, k_side, Ts, internal, out, resid, tag):
+        """Sam2Attention (hf:874-942) for every object of the batch: out = [resid +] o_proj(attention(q_proj(q), k_proj(k), v_proj(v))).
+        ``q_side`` / ``k_side``: "tok" (object o = rows [o TOK, o TOK + Ts[o])) or "img" (rows [o m2, (o + 1) m2)); the objects are stacked
+        along the rows of every operand, the attention work list keeps them apart."""
+        g, Cd, NB, m2, TOK = self.g, self.g.fpn_dim, len(Ts), self.grid[2] ** 2, self.TOK
         hd = internal // g.dec_heads
+        sq, sk = (TOK if q_side == "tok" else m2), (TOK if k_side == "tok" else m2)
+        nq, nk = NB * sq, NB * sk
+        tag = f"{tag}{NB}" if TOK == 16 else f"{tag}{NB}w{TOK}"          # (captured graphs hold addresses: a buffer never changes shape)
         qp = self.buf(f"d_qp_{tag}", max(nq, 16), internal)
         kp = self.buf(f"d_kp_{tag}", max(nk, 16), internal)
         vp = self.buf(f"d_vp_{tag}", max(nk, 16), internal)
@@ -453,83 +471,134 @@ class Sam2Engine:
         vt = self.buf(f"d_vt_{tag}", internal, vts)
         self._ck(self.lib.sr_op_transpose(self._p(vp), internal, nk, internal, self._p(vt), vts, self._s()), "transpose")
         o = self.buf(f"d_o_{tag}", max(nq, 16), internal)
-        wk = self.work(("dec", nq, nk), [(q0, nk, q0, 0, 0, nq if nq != nk else 0) for q0 in range(0, nq, 64)])
+        items = []
+        for ob, T in enumerate(Ts):
+            lq, lk = (T if q_side == "tok" else m2), (T if k_side == "tok" else m2)
+            items += [(ob * sq + q0, lk, q0, ob * sk, ob * sk, lq if lq != lk else 0) for q0 in range(0, lq, 64)]
+        wk = self.work(("dec", q_side, k_side, Ts, TOK), items)
         self.attention(qp, internal, kp, 0, internal, hd, vt, vts, o, internal, wk, g.dec_heads, hd ** -0.5)
         self.gemm(o, internal, name + ".o_proj", nq, out, Cd, EPI_RESID if resid is not None else EPI_STORE, resid=resid)
 
     def decode(self, coords: np.ndarray, labels: np.ndarray):
-        """-> (low-resolution mask logits float32 [m4 * m4][16] (column i = mask token i), IoU-head logits float32 [16])  on the device"""
+        """one object -> (low-resolution mask logits float32 [m4 * m4][16] (column i = mask token i), IoU-head logits float32 [1][16])"""
+        low, iou = self.decode_many([(coords, labels)])
+        return low, iou
+
+    def decode_many(self, prompts: Sequence[Tuple[np.ndarray, np.ndarray]]):
+        """The mask decoder for several objects of the CURRENT image at once (objects stacked along the rows of every launch: the decoder
+        is ~110 dependent launches of a few microseconds, whatever the row count) -> (low [NB * m4 * m4][16] float32, iou [NB][16] float32)."""
         assert self.image_set, "set_image first"
-        g, Cd, lib = self.g, self.g.fpn_dim, self.lib
-        tok_h = self._tokens(coords, labels)
-        T = tok_h.shape[0]
-        Tp = max(T, 16)
-        tok = self.buf("d_tok", Tp, Cd)
-        tok[:T].copy_(tok_h.to(torch.bfloat16), non_blocking=True)
+        Cd, TOK = self.g.fpn_dim, self.TOK
+        toks = [self._tokens(c, l) for c, l in prompts]
+        Ts = tuple(int(t.shape[0]) for t in toks)
+        NB = len(Ts)
+        stride = max(TOK, max(Ts))
+        if stride > TOK:               # a very long prompt: one object at a time, rows as wide as it needs, no captured graph
+            assert NB == 1, "prompts of more than 10 points are decoded one object at a time"
+            self.TOK, keep = (stride + 15) // 16 * 16, TOK
+            try:
+                tok = self.buf("d_tok_long", self.TOK, Cd)
+                tok.zero_()
+                tok[:Ts[0]].copy_(toks[0].to(torch.bfloat16))
+                return self._decode_launches(Ts, tok)
+            finally:
+                self.TOK = keep
+        tok = self.buf(f"d_tok{NB}", NB * TOK, Cd)
+        host = torch.zeros(NB * TOK, Cd, dtype=torch.bfloat16)
+        for ob, t in enumerate(toks):
+            host[ob * TOK:ob * TOK + Ts[ob]] = t.to(torch.bfloat16)
+        tok.copy_(host, non_blocking=True)
+        # ~110 launches of a few microseconds each: issued one by one the host is the bottleneck (0.8 ms per call).  The launch sequence
+        # is captured once per tuple of token counts (every buffer keeps its shape and address) and replayed.
+        if not self.graph_decode:
+            return self._decode_launches(Ts, tok)
+        gr = self._graphs.get(Ts)
+        if gr is None:
+            out = self._decode_launches(Ts, tok)     # eager once: allocates every buffer / work list, raises kernel attributes
+            torch.cuda.synchronize(self.device)
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg, capture_error_mode="thread_local"):
+                out = self._decode_launches(Ts, tok)
+            gr = self._graphs[Ts] = (cg, out)
+        gr[0].replay()
+        return gr[1]
+
+    def _decode_launches(self, Ts: Tuple[int, ...], tok: torch.Tensor):
+        g, Cd, lib, TOK = self.g, self.g.fpn_dim, self.lib, self.TOK
+        NB = len(Ts)
         m2 = self.grid[2] ** 2
-        q = self.buf("d_q", Tp, Cd)
-        qx = self.buf("d_qx", Tp, Cd)
-        keys = self.buf("d_keys", m2, Cd)
-        kx = self.buf("d_kx", m2, Cd)
-        keys.copy_(self.keys0)
+        NT, NI = NB * TOK, NB * m2                                              # token rows, image rows
+        sfx = f"{NB}" if TOK == 16 else f"{NB}w{TOK}"
+        q = self.buf(f"d_q{sfx}", max(NT, 16), Cd)
+        qx = self.buf(f"d_qx{sfx}", max(NT, 16), Cd)
+        keys = self.buf(f"d_keys{sfx}", NI, Cd)
+        kx = self.buf(f"d_kx{sfx}", NI, Cd)
+        keys.view(NB, m2, Cd).copy_(self.keys0)
+        pe = self.W.get(f"image_pe@{NB}")
+        if pe is None:
+            pe = self.W[f"image_pe@{NB}"] = self.W["image_pe"].repeat(NB, 1).contiguous()
         md = "mask_decoder.transformer."
         eps = 1e-5
         for l in range(g.dec_layers):
             p = f"{md}layers.{l}"
             if l == 0:
-                self._mha(p + ".self_attn", tok, T, tok, tok, T, Cd, q, None, "self")
+                self._mha(p + ".self_attn", tok, tok, tok, "tok", "tok", Ts, Cd, q, None, "self")
             else:
-                self.ew(q, Cd, tok, Cd, qx, Cd, T, Cd, 0)
-                self._mha(p + ".self_attn", qx, T, qx, q, T, Cd, q, q, "self")
-            self.layernorm(q, Cd, p + ".layer_norm1", q, Cd, T, Cd, eps)
-            self.ew(q, Cd, tok, Cd, qx, Cd, T, Cd, 0)
-            self.ew(keys, Cd, self.W["image_pe"], Cd, kx, Cd, m2, Cd, 0)
-            self._mha(p + ".cross_attn_token_to_image", qx, T, kx, keys, m2, Cd // 2, q, q, "t2i")
-            self.layernorm(q, Cd, p + ".layer_norm2", q, Cd, T, Cd, eps)
-            hid = self.buf("d_hid", Tp, g.dec_mlp)
-            self.gemm(q, Cd, p + ".mlp.proj_in", T, hid, g.dec_mlp)
-            self.ew(hid, g.dec_mlp, None, 0, hid, g.dec_mlp, T, g.dec_mlp, 2)
-            self.gemm(hid, g.dec_mlp, p + ".mlp.proj_out", T, q, Cd, EPI_RESID, resid=q)
-            self.layernorm(q, Cd, p + ".layer_norm3", q, Cd, T, Cd, eps)
-            self.ew(q, Cd, tok, Cd, qx, Cd, T, Cd, 0)
-            self._mha(p + ".cross_attn_image_to_token", kx, m2, qx, q, T, Cd // 2, keys, keys, "i2t")
-            self.layernorm(keys, Cd, p + ".layer_norm4", keys, Cd, m2, Cd, eps)
-        self.ew(q, Cd, tok, Cd, qx, Cd, T, Cd, 0)
-        self.ew(keys, Cd, self.W["image_pe"], Cd, kx, Cd, m2, Cd, 0)
-        self._mha(md + "final_attn_token_to_image", qx, T, kx, keys, m2, Cd // 2, q, q, "t2i")
-        self.layernorm(q, Cd, md + "layer_norm_final_attn", q, Cd, T, Cd, eps)
+                self.ew(q, Cd, tok, Cd, qx, Cd, NT, Cd, 0)
+                self._mha(p + ".self_attn", qx, qx, q, "tok", "tok", Ts, Cd, q, q, "self")
+            self.layernorm(q, Cd, p + ".layer_norm1", q, Cd, NT, Cd, eps)
+            self.ew(q, Cd, tok, Cd, qx, Cd, NT, Cd, 0)
+            self.ew(keys, Cd, pe, Cd, kx, Cd, NI, Cd, 0)
+            self._mha(p + ".cross_attn_token_to_image", qx, kx, keys, "tok", "img", Ts, Cd // 2, q, q, "t2i")
+            self.layernorm(q, Cd, p + ".layer_norm2", q, Cd, NT, Cd, eps)
+            hid = self.buf(f"d_hid{sfx}", max(NT, 16), g.dec_mlp)
+            self.gemm(q, Cd, p + ".mlp.proj_in", NT, hid, g.dec_mlp)
+            self.ew(hid, g.dec_mlp, None, 0, hid, g.dec_mlp, NT, g.dec_mlp, 2)
+            self.gemm(hid, g.dec_mlp, p + ".mlp.proj_out", NT, q, Cd, EPI_RESID, resid=q)
+            self.layernorm(q, Cd, p + ".layer_norm3", q, Cd, NT, Cd, eps)
+            self.ew(q, Cd, tok, Cd, qx, Cd, NT, Cd, 0)
+            self._mha(p + ".cross_attn_image_to_token", kx, qx, q, "img", "tok", Ts, Cd // 2, keys, keys, "i2t")
+            self.layernorm(keys, Cd, p + ".layer_norm4", keys, Cd, NI, Cd, eps)
+        self.ew(q, Cd, tok, Cd, qx, Cd, NT, Cd, 0)
+        self.ew(keys, Cd, pe, Cd, kx, Cd, NI, Cd, 0)
+        self._mha(md + "final_attn_token_to_image", qx, kx, keys, "tok", "img", Ts, Cd // 2, q, q, "t2i")
+        self.layernorm(q, Cd, md + "layer_norm_final_attn", q, Cd, NT, Cd, eps)
         # ---- upscaling (hf:1215-1221)
         G2, G1, G0 = self.grid[2], self.grid[1], self.grid[0]
-        g1 = self.buf("d_g1", m2, Cd)
-        self.gemm(keys, Cd, "mask_decoder.upscale_conv1", m2, g1, Cd)
-        u1 = self.buf("d_u1", G1 * G1, Cd // 4)
-        self._ck(lib.sr_op_pixel_shuffle_add(self._p(g1), Cd, self._p(self.f1), Cd // 4, self._p(u1), Cd // 4, G2, Cd // 4, self._s()), "shuffle1")
-        self.layernorm(u1, Cd // 4, "mask_decoder.upscale_layer_norm", u1, Cd // 4, G1 * G1, Cd // 4, 1e-6)
-        self.ew(u1, Cd // 4, None, 0, u1, Cd // 4, G1 * G1, Cd // 4, 3)
-        g2 = self.buf("d_g2", G1 * G1, Cd // 2)
-        self.gemm(u1, Cd // 4, "mask_decoder.upscale_conv2", G1 * G1, g2, Cd // 2)
-        u2 = self.buf("d_u2", G0 * G0, 64)                                   # Cd / 8 live channels, padded to one k-tile
-        self._ck(lib.sr_op_pixel_shuffle_add(self._p(g2), Cd // 2, self._p(self.f0), Cd // 8, self._p(u2), 64, G1, Cd // 8, self._s()), "shuffle2")
-        self.ew(u2, 64, None, 0, u2, 64, G0 * G0, Cd // 8, 3)
-        # ---- hypernetwork MLPs of the mask tokens, IoU head (hf:1223-1236)
-        hyp = self.buf("d_hyp", 16, 64)
-        h1, h2 = self.buf("d_h1", 16, Cd), self.buf("d_h2", 16, Cd)
+        n1, n0 = G1 * G1, G0 * G0
+        g1 = self.buf(f"d_g1{sfx}", NI, Cd)
+        self.gemm(keys, Cd, "mask_decoder.upscale_conv1", NI, g1, Cd)
+        u1 = self.buf(f"d_u1{sfx}", NB * n1, Cd // 4)
+        for ob in range(NB):
+            self._ck(lib.sr_op_pixel_shuffle_add(self._p(g1, ob * m2 * Cd), Cd, self._p(self.f1), Cd // 4, self._p(u1, ob * n1 * (Cd // 4)), Cd // 4, G2, Cd // 4, self._s()), "shuffle1")
+        self.layernorm(u1, Cd // 4, "mask_decoder.upscale_layer_norm", u1, Cd // 4, NB * n1, Cd // 4, 1e-6)
+        self.ew(u1, Cd // 4, None, 0, u1, Cd // 4, NB * n1, Cd // 4, 3)
+        g2 = self.buf(f"d_g2{sfx}", NB * n1, Cd // 2)
+        self.gemm(u1, Cd // 4, "mask_decoder.upscale_conv2", NB * n1, g2, Cd // 2)
+        u2 = self.buf(f"d_u2{sfx}", NB * n0, 64)                                 # Cd / 8 live channels, padded to one k-tile
+        for ob in range(NB):
+            self._ck(lib.sr_op_pixel_shuffle_add(self._p(g2, ob * n1 * (Cd // 2)), Cd // 2, self._p(self.f0), Cd // 8, self._p(u2, ob * n0 * 64), 64, G1, Cd // 8, self._s()), "shuffle2")
+        self.ew(u2, 64, None, 0, u2, 64, NB * n0, Cd // 8, 3)
+        # ---- hypernetwork MLPs of the mask tokens, IoU head (hf:1223-1236): token t of every object = rows t, t + TOK, ... (lda = TOK * Cd)
+        hyp = self.buf(f"d_hyp{sfx}", NB * 16, 64)                               # object o's 4 filters = rows 16 o .. 16 o + 3
+        h1, h2 = self.buf(f"d_h1{sfx}", max(NB, 16), Cd), self.buf(f"d_h2{sfx}", max(NB, 16), Cd)
         for i in range(g.n_mask_tokens):
             n = f"mask_decoder.output_hypernetworks_mlps.{i}"
-            self.gemm(q, Cd, n + ".proj_in", 1, h1, Cd, a_off=(2 + i) * Cd)
-            self.ew(h1, Cd, None, 0, h1, Cd, 1, Cd, 2)
-            self.gemm(h1, Cd, n + ".layers.0", 1, h2, Cd)
-            self.ew(h2, Cd, None, 0, h2, Cd, 1, Cd, 2)
-            self.gemm(h2, Cd, n + ".proj_out", 1, hyp, 64, out_off=i * 64)
-        low = self.buf("d_low", G0 * G0, 16, torch.float32)
-        self._ck(lib.sr_op_gemm(self._p(u2), 64, self._p(hyp), G0 * G0, 16, 64, self._p(low), 16, None, None, None, EPI_F32, self._s()), "mask gemm")
+            self.gemm(q, TOK * Cd, n + ".proj_in", NB, h1, Cd, a_off=(2 + i) * Cd)
+            self.ew(h1, Cd, None, 0, h1, Cd, NB, Cd, 2)
+            self.gemm(h1, Cd, n + ".layers.0", NB, h2, Cd)
+            self.ew(h2, Cd, None, 0, h2, Cd, NB, Cd, 2)
+            self.gemm(h2, Cd, n + ".proj_out", NB, hyp, 16 * 64, out_off=i * 64)
+        low = self.buf(f"d_low{sfx}", NB * n0, 16, torch.float32)
+        for ob in range(NB):
+            self._ck(lib.sr_op_gemm(self._p(u2, ob * n0 * 64), 64, self._p(hyp, ob * 16 * 64), n0, 16, 64, self._p(low, ob * n0 * 16), 16, None, None, None, EPI_F32, self._s()), "mask gemm")
         n = "mask_decoder.iou_prediction_head"
-        self.gemm(q, Cd, n + ".proj_in", 1, h1, Cd, a_off=1 * Cd)
-        self.ew(h1, Cd, None, 0, h1, Cd, 1, Cd, 2)
-        self.gemm(h1, Cd, n + ".layers.0", 1, h2, Cd)
-        self.ew(h2, Cd, None, 0, h2, Cd, 1, Cd, 2)
-        iou = self.buf("d_iou", 1, 16, torch.float32)
-        self.gemm(h2, Cd, n + ".proj_out", 1, iou, 16, EPI_F32)
+        self.gemm(q, TOK * Cd, n + ".proj_in", NB, h1, Cd, a_off=1 * Cd)
+        self.ew(h1, Cd, None, 0, h1, Cd, NB, Cd, 2)
+        self.gemm(h1, Cd, n + ".layers.0", NB, h2, Cd)
+        self.ew(h2, Cd, None, 0, h2, Cd, NB, Cd, 2)
+        iou = self.buf(f"d_iou{sfx}", NB, 16, torch.float32)
+        self.gemm(h2, Cd, n + ".proj_out", NB, iou, 16, EPI_F32)
         return low, iou
 
     # ------------------------------------------------------------------ the predictor's contract
@@ -552,13 +621,31 @@ class Sam2Engine:
     def predict_or(self, acc_u8: torch.Tensor, point_coords=None, point_labels=None, box=None, logits_out: Optional[torch.Tensor] = None):
         """One object of ``segment``'s loop, entirely on the device: decode, pick the mask with the highest predicted IoU, resize its logits
         to the image, threshold at 0, OR into ``acc_u8`` [h, w]."""
-        c, l = self.prompt(point_coords, point_labels, box)
-        low, iou = self.decode(c, l)
+        return self.predict_or_many(acc_u8, [dict(point_coords=point_coords, point_labels=point_labels, box=box)], logits_out=logits_out)
+
+    MAX_OBJECTS = 8     # objects per decoder pass
+
+    def predict_or_many(self, acc_u8: torch.Tensor, prompts: Sequence[dict], logits_out: Optional[torch.Tensor] = None):
+        """``segment``'s object loop for several objects per decoder pass (seg_strategy.py:47-60; the union does not depend on the order:
+        the objects are sorted by prompt length so that equal multisets of lengths share a captured launch sequence)."""
         h, w = self.orig_hw
         assert acc_u8.shape == (h, w) and acc_u8.dtype == torch.uint8 and acc_u8.is_cuda
-        self._ck(self.lib.sr_op_mask_resize_or(self._p(low), 16, 1, self.g.n_mask_tokens - 1, self.grid[0], self._p(iou), self._p(acc_u8), self._p(logits_out), h, w,
-                                               self._s()), "mask resize")
-        return low, iou
+        assert logits_out is None or len(prompts) == 1
+        return self.or_objects(acc_u8, [self.prompt(p.get("point_coords"), p.get("point_labels"), p.get("box")) for p in prompts], logits_out)
+
+    def or_objects(self, acc_u8: torch.Tensor, prepared: Sequence[Tuple[np.ndarray, np.ndarray]], logits_out: Optional[torch.Tensor] = None):
+        """``prepared``: (coords in the model frame, labels) per object, as ``prompt`` returns them"""
+        h, w = self.orig_hw
+        ps = sorted(prepared, key=lambda cl: len(cl[1]))
+        long_ = [cl for cl in ps if len(cl[1]) + self.g.n_mask_tokens + 3 > self.TOK]
+        ps = [cl for cl in ps if len(cl[1]) + self.g.n_mask_tokens + 3 <= self.TOK]
+        n0, out = self.grid[0] ** 2, None
+        for chunk in [ps[i:i + self.MAX_OBJECTS] for i in range(0, len(ps), self.MAX_OBJECTS)] + [[cl] for cl in long_]:
+            low, iou = out = self.decode_many(chunk)
+            for ob in range(len(chunk)):
+                self._ck(self.lib.sr_op_mask_resize_or(self._p(low, ob * n0 * 16), 16, 1, self.g.n_mask_tokens - 1, self.grid[0], self._p(iou, ob * 16), self._p(acc_u8),
+                                                       self._p(logits_out), h, w, self._s()), "mask resize")
+        return out
 
     def predict(self, point_coords=None, point_labels=None, box=None, multimask_output: bool = True, return_logits: bool = False):
         """(masks [3, h, w] bool (or logits), scores [3], low-resolution logits [3, m, m]) as numpy, like SAM2ImagePredictor.predict."""
@@ -756,6 +843,7 @@ class Sam2Predictor:
         reference's bare ``except: continue`` does)."""
         h, w = self.engine.orig_hw
         acc = torch.zeros(h, w, dtype=torch.uint8, device=self.engine.device)
+        good = []
         for vp in prompts:
             try:
                 kw = {}
@@ -763,7 +851,9 @@ class Sam2Predictor:
                     kw["point_coords"], kw["point_labels"] = vp["point_coords"], vp["point_labels"]
                 if "box" in vp:
                     kw["box"] = vp["box"]
-                self.engine.predict_or(acc, **kw)
+                good.append(self.engine.prompt(**kw))
             except (ValueError, KeyError, TypeError):
                 continue
+        if good:
+            self.engine.or_objects(acc, good)
         return acc

@@ -177,3 +177,32 @@ def test_sam2_batched_encoder_equals_one_image_at_a_time_and_cache_replays():
         e.set_image(imgs[i])
         assert torch.equal(pr.segment_objects(prompts[i]), a[i])
         assert int(a[i].sum()) > 0
+
+
+def test_sam2_objects_decoded_together_equal_one_at_a_time():
+    """or_objects stacks the objects of an image along the rows of every decoder launch (and replays a captured launch sequence): logits,
+    scores and the union must be what the one-object calls give, for mixed prompt lengths and more objects than one pass takes."""
+    from socioreasoner_amd import synthetic
+    e, og = _engine("tiny")
+    hw = 189
+    e.set_image(torch.from_numpy(synthetic.tile_pixels(77, hw, hw)).cuda())
+    prompts = [dict(box=[20 + 3 * i, 30, 120 + 4 * i, 150]) if i % 3 == 0 else
+               dict(box=[10, 15 + 2 * i, 90 + i, 140], point_coords=[[50 + i, 60 + k] for k in range(1 + i % 2)], point_labels=[1] * (1 + i % 2)) for i in range(11)]
+    prompts.append(dict(point_coords=[[30 + 5 * k, 40 + 3 * k] for k in range(12)], point_labels=[1, 0] * 6))      # 19 tokens: the wide path
+    m = e.grid[0]
+    singles, acc1 = [], torch.zeros(hw, hw, dtype=torch.uint8, device="cuda")
+    for p in prompts:
+        low, iou = e.predict_or(acc1, **p)
+        singles.append((low.clone(), iou.clone()))
+    for graph in (True, False):
+        e.graph_decode = graph
+        for _ in range(2):                      # second round: replayed graphs
+            acc2 = torch.zeros_like(acc1)
+            e.predict_or_many(acc2, prompts)
+            assert torch.equal(acc1, acc2) and int(acc1.sum()) > 0
+    e.graph_decode = True
+    prep = sorted((e.prompt(p.get("point_coords"), p.get("point_labels"), p.get("box")) for p in prompts[:5]), key=lambda cl: len(cl[1]))
+    order = sorted(range(5), key=lambda i: len(e.prompt(prompts[i].get("point_coords"), prompts[i].get("point_labels"), prompts[i].get("box"))[1]))
+    low, iou = e.decode_many(prep)
+    for r, i in enumerate(order):
+        assert torch.equal(low[r * m * m:(r + 1) * m * m], singles[i][0]) and torch.equal(iou[r], singles[i][1][0]), (r, i)

@@ -161,3 +161,64 @@ def test_world_size_8_sharding_and_exchange_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("ok") == 8
+
+
+def _to_sam2_package_names(sd):
+    """HF Sam2Model names -> the sam2 package's (the two public module trees; hand-written inverse of socioreasoner_amd.sam2's table)"""
+    import torch
+    out = {}
+    for k, v in sd.items():
+        n = k
+        if n == "no_memory_embedding":
+            n = "no_mem_embed"
+        elif n.startswith("vision_encoder.backbone."):
+            n = "image_encoder.trunk." + n[len("vision_encoder.backbone."):]
+            n = n.replace("patch_embed.projection.", "patch_embed.proj.").replace(".layer_norm1.", ".norm1.").replace(".layer_norm2.", ".norm2.")
+            n = n.replace(".mlp.proj_in.", ".mlp.layers.0.").replace(".mlp.proj_out.", ".mlp.layers.1.")
+        elif n.startswith("vision_encoder.neck.convs."):
+            n = "image_encoder.neck.convs." + n[len("vision_encoder.neck.convs."):].replace(".weight", ".conv.weight").replace(".bias", ".conv.bias")
+        elif n == "prompt_encoder.shared_embedding.positional_embedding":
+            n = "sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"
+        elif n == "prompt_encoder.point_embed.weight":
+            for i in range(v.shape[0]):
+                out[f"sam_prompt_encoder.point_embeddings.{i}.weight"] = v[i:i + 1].clone()
+            continue
+        elif n.startswith("prompt_encoder."):
+            n = "sam_" + n
+        elif n.startswith("mask_decoder."):
+            n = "sam_" + n
+            for a, b in ((".layer_norm_final_attn.", ".norm_final_attn."), (".layer_norm1.", ".norm1."), (".layer_norm2.", ".norm2."), (".layer_norm3.", ".norm3."),
+                         (".layer_norm4.", ".norm4."), (".o_proj.", ".out_proj."), ("upscale_conv1.", "output_upscaling.0."), ("upscale_layer_norm.", "output_upscaling.1."),
+                         ("upscale_conv2.", "output_upscaling.3.")):
+                n = n.replace(a, b)
+            if "hypernetworks" in n or "iou_prediction_head" in n:
+                n = n.replace(".layers.0.", ".layers.1.").replace(".proj_in.", ".layers.0.").replace(".proj_out.", ".layers.2.")
+            else:
+                n = n.replace(".mlp.proj_in.", ".mlp.layers.0.").replace(".mlp.proj_out.", ".mlp.layers.1.")
+        out[n] = v
+    # what the real checkpoint also carries and the image path never reads
+    for extra in ("memory_encoder.fuser.layers.0.gamma", "memory_attention.layers.0.norm1.weight", "maskmem_tpos_enc", "obj_ptr_proj.layers.0.weight", "no_mem_pos_enc",
+                  "no_obj_ptr", "mask_downsample.weight", "sam_prompt_encoder.mask_downscaling.0.weight", "sam_mask_decoder.pred_obj_score_head.layers.0.weight"):
+        out[extra] = torch.zeros(1)
+    return out
+
+
+def test_sam2_package_checkpoint_names_map_onto_the_names_the_engine_loads():
+    """roll.models.model_providers.sam2_seg_model_provider renames a sam2-package checkpoint (model_providers.py:540-541 of the reference loads
+    sam2_hiera_large.pt) before Sam2Engine.load_state_dict: every parameter the engine expects must come out, with its tensor, and the
+    memory / video modules must be dropped."""
+    import torch
+    from socioreasoner_amd import sam2
+    g = sam2.Sam2Geometry()
+    names = sam2.param_shapes(g)
+    sd = {n: torch.full((1,) if not shp else tuple(min(int(d), 4) for d in shp), float(i)) for i, (n, shp, _, _) in enumerate(names)}
+    sd["prompt_encoder.point_embed.weight"] = torch.arange(4 * 3, dtype=torch.float32).reshape(4, 3)
+    pkg = _to_sam2_package_names(sd)
+    assert not any(k.startswith(("vision_encoder.", "prompt_encoder.", "mask_decoder.")) for k in pkg)
+    back = sam2.rename_sam2_checkpoint(pkg)
+    missing = sorted(set(sd) - set(back))
+    assert not missing, missing[:8]
+    for k in sd:
+        assert torch.equal(back[k], sd[k]), k
+    extra = set(back) - set(sd)
+    assert extra <= {"mask_decoder.pred_obj_score_head.proj_in.weight"}, sorted(extra)[:8]      # (object-score head: loaded by HF, unused by predict)
