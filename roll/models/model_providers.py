@@ -33,6 +33,15 @@ def sam2_seg_model_provider(model_args=None, training_args=None, is_trainable: b
         eng = sam2.Sam2Engine(g, dev)
         eng.load_state_dict(sam2.synthetic_state_dict(g, seed=0))
         return sam2.Sam2Predictor(eng)
+    if not os.path.isdir(path):
+        # a hub id (facebook/sam2-hiera-large in the reference's YAML) with nothing on disk: like the LM's `pretrain`, the geometry with
+        # random weights, said loudly -- there is no network to fetch a checkpoint from
+        import warnings
+        warnings.warn(f"seg_infer: no checkpoint directory at {path!r}; running SAM2 Hiera-L with SYNTHETIC weights")
+        g = sam2.Sam2Geometry()
+        eng = sam2.Sam2Engine(g, dev)
+        eng.load_state_dict(sam2.synthetic_state_dict(g, seed=0))
+        return sam2.Sam2Predictor(eng)
     eng = sam2.Sam2Engine(sam2.Sam2Geometry(), dev)
     pt = os.path.join(path, "sam2_hiera_large.pt")
     if os.path.exists(pt):

@@ -11,7 +11,8 @@ dispatch and the per-sample IoUs gathered with one RCCL all-gather), and nothing
   data      : a SocioSeg folder (roll/datasets/dataset.py layout) via data_args.dataset_dir, else synthetic tiles;
   processor : the checkpoint's HF processor when `pretrain` is a directory, else textproc.SyntheticProcessor
               (byte-level tokenizer with the Qwen special-token ids);
-  SAM2      : `sam_predictor_provider` (anything with set_image / predict), else SyntheticSamPredictor, which turns the
+  SAM2      : `sam_predictor_provider` (anything with set_image / predict), else roll.models.model_providers.sam2_seg_model_provider (the
+              MI355X SAM2) when seg_infer.model_args names a model, else SyntheticSamPredictor, which turns the
               parsed boxes / points into masks so that every raster step after SAM2 runs for real on the device.
 The batch keys, the order of operations and the files written follow the reference's `run()` step by step.
 """
@@ -241,6 +242,17 @@ def _obj(values) -> np.ndarray:
     return a
 
 
+def _default_sam_provider(model_args=None, **kw):
+    """seg_worker.py:540 of the reference hands ``sam2_seg_model_provider`` to the strategy.  Same here when ``seg_infer.model_args`` names a
+    model (roll.models.model_providers: the MI355X SAM2); a configuration without one (unit tests of the host flow) gets the stand-in
+    that turns prompts into rectangles."""
+    path = model_args.get("model_name_or_path") if hasattr(model_args, "get") else getattr(model_args, "model_name_or_path", None)
+    if not path:
+        return socioseg_data.SyntheticSamPredictor()
+    from roll.models.model_providers import sam2_seg_model_provider
+    return sam2_seg_model_provider(model_args=model_args, **kw)
+
+
 class SocioSegInferPipeline(BasePipeline):
     def __init__(self, pipeline_config, sam_predictor_provider=None, dataset: Optional[List[Dict]] = None, processor=None,
                  actor_worker=None):
@@ -271,8 +283,7 @@ class SocioSegInferPipeline(BasePipeline):
         if hasattr(self.actor_infer.strategy, "tokenizer"):
             self.actor_infer.strategy.tokenizer = self.tokenizer
         self.seg_infer = SegWorker(cfg.seg_infer, cfg, self.rank, self.world, local, "seg_infer")
-        self.seg_infer.initialize(cfg, model_provider=sam_predictor_provider or (lambda **_: socioseg_data.SyntheticSamPredictor()),
-                                  tokenizer=self.tokenizer)
+        self.seg_infer.initialize(cfg, model_provider=sam_predictor_provider or _default_sam_provider, tokenizer=self.tokenizer)
         # ---- data: this rank's contiguous shard (np.array_split sizes, like the reference's DP dispatch)
         if dataset is None:
             dargs = (cfg.actor_train or {}).get("data_args") or {}
@@ -342,7 +353,21 @@ class SocioSegInferPipeline(BasePipeline):
         n_ret = int((cfg.actor_infer.generating_args or {}).get("num_return_sequences", 1) or 1)
         all_giou: List[float] = []
         global_step = 0
+        import time as _time
+        from concurrent.futures import ThreadPoolExecutor
+        self.timing = {k: 0.0 for k in ("collate", "generate_stage1", "segment_stage1", "stage2_prompts", "generate_stage2", "segment_stage2", "score_and_write")}
+        clock = [_time.perf_counter()]
+
+        def lap(name):          # wall time since the previous lap (the reference times generate / seg with _Timer: ...infer.py:625-704)
+            now = _time.perf_counter()
+            self.timing[name] += now - clock[0]
+            clock[0] = now
+        # PNG encoding of four 768 x 768 images per sample was the largest single term of a batch on the driver (zlib; PIL releases the GIL):
+        # the files are written by a small pool while the next batch generates; run() returns after the last one is on disk
+        writers = ThreadPoolExecutor(max_workers=int(os.environ.get("SOCIOSEG_WRITERS", 8)))
+        pending = []
         for batch_dict in get_dataloader(self.dataset, self.batch_size, self.data_collator):
+            lap("collate")
             self.model_update(global_step)
             batch = DataProto.from_single_dict(batch_dict)
             batch.meta_info = {"global_step": global_step}
@@ -351,6 +376,7 @@ class SocioSegInferPipeline(BasePipeline):
             gen_batch.rename(["map_input_ids", "map_attention_mask", "map_position_ids"], ["input_ids", "attention_mask", "position_ids"])
             gen_batch.non_tensor_batch["multi_modal_data"] = gen_batch.non_tensor_batch.pop("multi_modal_map_data")
             out = self._generate(gen_batch, global_step)
+            lap("generate_stage1")
             out.rename(["input_ids", "attention_mask", "position_ids", "responses", "response_mask", "prompts", "prompt_mask"],
                        ["map_input_ids", "map_attention_mask", "map_position_ids", "map_responses", "map_response_mask", "map_prompts", "map_prompt_mask"])
             out.batch.pop("prompt_id", None)
@@ -360,6 +386,7 @@ class SocioSegInferPipeline(BasePipeline):
             # ---- stage-1 masks: responses -> SAM prompts -> union / nearest resize on the device
             seg_batch = batch.pop(batch_keys=["map_responses", "map_prompts"], non_tensor_batch_keys=["seg_image"])
             seg_out = self.seg_infer.segment_v4_map(seg_batch)
+            lap("segment_stage1")
             batch = batch.union(seg_out)
             batch.non_tensor_batch["map_mask"] = batch.non_tensor_batch.pop("mask")
             batch.non_tensor_batch["map_visual_prompt"] = batch.non_tensor_batch.pop("visual_prompt")
@@ -373,12 +400,15 @@ class SocioSegInferPipeline(BasePipeline):
             ga = cfg.actor_infer.generating_args or {}
             keep = ga.get("num_return_sequences", 1)
             ga["num_return_sequences"] = 1                      # stage 2 never fans out (reference :838-852)
+            lap("stage2_prompts")
             out = self._generate(gen_batch, global_step)
+            lap("generate_stage2")
             ga["num_return_sequences"] = keep
             out.batch.pop("prompt_id", None)
             batch = batch.union(out)
             seg_batch = batch.pop(batch_keys=["responses", "prompts"], non_tensor_batch_keys=["seg_image"])
             seg_out = self.seg_infer.segment_v4_sat(seg_batch)
+            lap("segment_stage2")
             seg_out.meta_info.pop("metrics", None)
             batch = batch.union(seg_out)
             batch.non_tensor_batch["sat_mask"] = batch.non_tensor_batch.pop("mask")
@@ -394,17 +424,28 @@ class SocioSegInferPipeline(BasePipeline):
                 vp2 = nt["sat_visual_prompt"][i][0] if len(nt["sat_visual_prompt"][i]) else {}
                 sid = nt["id"][i]
                 from PIL import Image
-                Image.fromarray(nt["map_mask"][i].astype(np.uint8) * 255).save(os.path.join(dirs["stage1"], f"{sid}.png"))
-                Image.fromarray(nt["sat_mask"][i].astype(np.uint8) * 255).save(os.path.join(dirs["stage2"], f"{sid}.png"))
-                draw_visual_prompt(nt["seg_image"][i], nt["map_mask"][i], vp1).save(os.path.join(dirs["render1"], f"{sid}.png"))
-                draw_visual_prompt(nt["seg_image"][i], nt["sat_mask"][i], vp2).save(os.path.join(dirs["render2"], f"{sid}.png"))
-                with open(os.path.join(dirs["stage1"], f"{sid}.txt"), "w") as f:
-                    f.write(map_response_list[i])
-                with open(os.path.join(dirs["stage2"], f"{sid}.txt"), "w") as f:
-                    f.write(sat_response_list[i])
+
+                # the overlays run on the device from THIS thread (the HIP current device is per thread); the pool only encodes and writes
+                r1, r2 = draw_visual_prompt(nt["seg_image"][i], nt["map_mask"][i], vp1), draw_visual_prompt(nt["seg_image"][i], nt["sat_mask"][i], vp2)
+
+                def write(sid=sid, m1=nt["map_mask"][i], m2=nt["sat_mask"][i], r1=r1, r2=r2, t1=map_response_list[i], t2=sat_response_list[i]):
+                    Image.fromarray(m1.astype(np.uint8) * 255).save(os.path.join(dirs["stage1"], f"{sid}.png"))
+                    Image.fromarray(m2.astype(np.uint8) * 255).save(os.path.join(dirs["stage2"], f"{sid}.png"))
+                    r1.save(os.path.join(dirs["render1"], f"{sid}.png"))
+                    r2.save(os.path.join(dirs["render2"], f"{sid}.png"))
+                    with open(os.path.join(dirs["stage1"], f"{sid}.txt"), "w") as f:
+                        f.write(t1)
+                    with open(os.path.join(dirs["stage2"], f"{sid}.txt"), "w") as f:
+                        f.write(t2)
+                pending.append(writers.submit(write))
             print(f"giou_acc: {np.mean(giou_list)}")
             all_giou.extend(giou_list)
             global_step += 1
+            lap("score_and_write")
+        for fut in pending:
+            fut.result()                # (re-raises a failed write)
+        writers.shutdown()
+        lap("score_and_write")
         local = torch.tensor(all_giou, dtype=torch.float64).reshape(-1, 1)
         if self.world > 1:
             # samples are array_split over the ranks and every sample contributes n_ret rows

@@ -110,8 +110,12 @@ def test_pipeline_two_stage_flow_with_sam2_on_device(golden_dir, tmp_path):
     w = _scripted_worker(cfg, geom, proc, seen)
     e1, og = _engine("tiny")
     samples = socioseg_data.synthetic_socioseg(4)
-    pipe = P.SocioSegInferPipeline(cfg, dataset=samples, processor=proc, actor_worker=w, sam_predictor_provider=lambda **_: sam2.Sam2Predictor(e1))
+    served = sam2.Sam2Predictor(e1)
+    pipe = P.SocioSegInferPipeline(cfg, dataset=samples, processor=proc, actor_worker=w, sam_predictor_provider=lambda **_: served)
     acc = pipe.run()
+    # seg_infer went through segment_batch: the encoder ran once per satellite image (stage 2 found stage 1's embedding in the cache)
+    assert served.stats["encoded"] <= len(samples) and served.stats["cache_hits"] >= 1, served.stats
+    assert served.stats["encoder_passes"] < served.stats["images"], served.stats
     res = os.path.join(str(tmp_path), "result")
     e2, _ = _engine("tiny")
     replay = sam2.Sam2Predictor(e2)
