@@ -151,12 +151,14 @@ def test_pipeline_two_stage_flow_with_sam2_on_device(golden_dir, tmp_path):
     print("sam2 pipeline: pixels differing from the float32 oracle", n_diff, "of", n_px, "giou_acc", acc)
 
 
-def test_sam2_batched_encoder_equals_one_image_at_a_time_and_cache_replays():
+@pytest.mark.parametrize("tag", ["tiny", "large"])
+def test_sam2_batched_encoder_equals_one_image_at_a_time_and_cache_replays(tag):
     """set_images over B images stacks their tokens in every launch; the features of image b must be the ones a set_image of that image
     alone leaves (same kernels, same order of arithmetic per row => bit-for-bit), and the predictor's embedding cache must hand them back."""
     from socioreasoner_amd import sam2, synthetic
-    e, og = _engine("tiny")
-    hw = 189
+    e, og = _engine(tag)
+    hw = 189 if tag == "tiny" else 756
+    sc = hw / 189.0
     imgs = [torch.from_numpy(synthetic.tile_pixels(40 + i, hw, hw)).cuda() for i in range(3)]
     single = []
     for im in imgs:
@@ -170,7 +172,8 @@ def test_sam2_batched_encoder_equals_one_image_at_a_time_and_cache_replays():
             assert torch.equal(ft[k].view(torch.int16), single[b][k].view(torch.int16)), (b, k)
     pr = sam2.Sam2Predictor(e, batch=2)
     host = [im.cpu().numpy() for im in imgs]
-    prompts = [[{"point_coords": [[60 + 9 * i, 70]], "point_labels": [1], "box": [20, 30, 150, 160]}, {"box": [10, 10, 90, 120]}, {"oops": 1}] for i in range(3)]
+    prompts = [[{"point_coords": [[(60 + 9 * i) * sc, 70 * sc]], "point_labels": [1], "box": [20 * sc, 30 * sc, 150 * sc, 160 * sc]},
+                {"box": [10 * sc, 10 * sc, 90 * sc, 120 * sc]}, {"oops": 1}] for i in range(3)]
     a = pr.segment_batch(host, prompts)
     assert pr.stats["encoded"] == 3 and pr.stats["encoder_passes"] == 2 and pr.stats["cache_hits"] == 0
     b_ = pr.segment_batch(host[::-1] + [host[0]], prompts[::-1] + [prompts[0]])       # stage 2: same images again (and one twice)
@@ -183,16 +186,19 @@ def test_sam2_batched_encoder_equals_one_image_at_a_time_and_cache_replays():
         assert int(a[i].sum()) > 0
 
 
-def test_sam2_objects_decoded_together_equal_one_at_a_time():
+@pytest.mark.parametrize("tag", ["tiny", "large"])
+def test_sam2_objects_decoded_together_equal_one_at_a_time(tag):
     """or_objects stacks the objects of an image along the rows of every decoder launch (and replays a captured launch sequence): logits,
     scores and the union must be what the one-object calls give, for mixed prompt lengths and more objects than one pass takes."""
     from socioreasoner_amd import synthetic
-    e, og = _engine("tiny")
-    hw = 189
+    e, og = _engine(tag)
+    hw = 189 if tag == "tiny" else 756
+    sc = hw / 189.0
     e.set_image(torch.from_numpy(synthetic.tile_pixels(77, hw, hw)).cuda())
-    prompts = [dict(box=[20 + 3 * i, 30, 120 + 4 * i, 150]) if i % 3 == 0 else
-               dict(box=[10, 15 + 2 * i, 90 + i, 140], point_coords=[[50 + i, 60 + k] for k in range(1 + i % 2)], point_labels=[1] * (1 + i % 2)) for i in range(11)]
-    prompts.append(dict(point_coords=[[30 + 5 * k, 40 + 3 * k] for k in range(12)], point_labels=[1, 0] * 6))      # 19 tokens: the wide path
+    prompts = [dict(box=[(20 + 3 * i) * sc, 30 * sc, (120 + 4 * i) * sc, 150 * sc]) if i % 3 == 0 else
+               dict(box=[10 * sc, (15 + 2 * i) * sc, (90 + i) * sc, 140 * sc], point_coords=[[(50 + i) * sc, (60 + k) * sc] for k in range(1 + i % 2)],
+                    point_labels=[1] * (1 + i % 2)) for i in range(11)]
+    prompts.append(dict(point_coords=[[(30 + 5 * k) * sc, (40 + 3 * k) * sc] for k in range(12)], point_labels=[1, 0] * 6))      # 19 tokens: the wide path
     m = e.grid[0]
     singles, acc1 = [], torch.zeros(hw, hw, dtype=torch.uint8, device="cuda")
     for p in prompts:
