@@ -233,7 +233,7 @@ def main():
     # through the same scheduler, against static batches of B that each run to their longest answer.  The headline's rows all stop on
     # the same step (EOS is ignored by the metric), so only this phase shows what refilling rows as they free up is worth.
     ragged = None
-    if rank == 0 and continuous and not args.no_latency:
+    if rank == 0 and world == 1 and continuous and not args.no_latency:      # (single-GPU side measurements: N > 1 runs go straight to the line)
         import numpy as _np
         from socioreasoner_amd.serving import ContinuousBatcher, Request
         lens = _np.random.default_rng(4000).integers(RAGGED_LO, RAGGED_HI + 1, n_req).tolist()
@@ -272,7 +272,7 @@ def main():
     # ---- SAM2 (Hiera-L) behind seg_infer: the mask half of a tile in the reference's pipeline (seg_strategy.py:47-60) -- 756 x 756 image ->
     # set_image, then decode + arg-max + resize + OR per object.  Timed beside the LM path (the metric's tile uses synthetic masks: SURVEY 8(D)).
     sam = None
-    if rank == 0 and not args.no_latency and not args.no_sam:
+    if rank == 0 and world == 1 and not args.no_latency and not args.no_sam:
         from socioreasoner_amd import sam2 as _sam2
         sg = _sam2.Sam2Geometry()
         se = _sam2.Sam2Engine(sg, str(dev))
@@ -313,7 +313,7 @@ def main():
 
     # ---- configs[1] beside it: one tile at a time on the same engine (batch-1 kernels, hipGraph decode), rank 0 only
     latency = None
-    if rank == 0 and B > 1 and not args.no_latency and not args.fp8:
+    if rank == 0 and world == 1 and B > 1 and not args.no_latency and not args.fp8:
         lat_ms = {"vit": 0.0, "prefill": 0.0, "decode": 0.0, "raster": 0.0}
         step_static(1)
         torch.cuda.synchronize(dev)
