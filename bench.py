@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--admit-cus", default="auto", help="CUs per shader engine (of 8) given to the overlapped admission stream, or auto (chosen per admission)")
     ap.add_argument("--no-overlap", action="store_true", help="continuous mode: admit between decode steps on one stream (round-1 behaviour) instead of "
                     "staging the next admission on a CU-masked stream under the running rows' decode")
+    ap.add_argument("--poll", type=int, default=16, help="continuous mode: decode steps queued per scheduling round (rows are released / admitted between rounds)")
+    ap.add_argument("--poll-ragged", type=int, default=4, help="the same for the ragged phase (0 = --poll): rows that end on different steps are refilled sooner with short "
+                    "rounds -- measured 59.8 / 60.8 / 62.1 tiles/s at 16 / 8 / 4")
     ap.add_argument("--no-latency", action="store_true", help="skip the additional batch-1 (configs[1]) measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sam", action="store_true", help="skip the SAM2 (seg_infer) timing")
@@ -137,7 +140,7 @@ def main():
         """waves x B requests through B rows: the later ones are admitted as rows free up (EOS is ignored by the metric, so all
         rows of a wave finish together; the point is the measured cost of the request-level path)."""
         from socioreasoner_amd.serving import ContinuousBatcher, Request
-        cb = ContinuousBatcher(eng, eos=[], pad_id=0, steps_per_poll=16, time_phases=phase_ms is not None, overlap=overlap, admit_cus_per_se=args.admit_cus if args.admit_cus == "auto" else float(args.admit_cus))
+        cb = ContinuousBatcher(eng, eos=[], pad_id=0, steps_per_poll=args.poll, time_phases=phase_ms is not None, overlap=overlap, admit_cus_per_se=args.admit_cus if args.admit_cus == "auto" else float(args.admit_cus))
         reqs = [Request(ids=ids[k], pos3=pos3[k], max_new=N_NEW, images=imgs[k], grids=[GRID] * NIMG) for k in range(n_req)]
         toks = cb.run(reqs)
         e0, e1 = ev(), ev()
@@ -239,7 +242,7 @@ def main():
         lens = _np.random.default_rng(4000).integers(RAGGED_LO, RAGGED_HI + 1, n_req).tolist()
 
         def ragged_run(ov):
-            cb = ContinuousBatcher(eng, eos=[], pad_id=0, steps_per_poll=16, overlap=ov,
+            cb = ContinuousBatcher(eng, eos=[], pad_id=0, steps_per_poll=args.poll_ragged or args.poll, overlap=ov,
                                    admit_cus_per_se=args.admit_cus if args.admit_cus == "auto" else float(args.admit_cus))
             reqs = [Request(ids=ids[k], pos3=pos3[k], max_new=int(lens[k]), images=imgs[k], grids=[GRID] * NIMG) for k in range(n_req)]
             torch.cuda.synchronize(dev)
@@ -264,7 +267,7 @@ def main():
             s_steps += max(lens[lo:lo + B])
         torch.cuda.synchronize(dev)
         s_dt = time.perf_counter() - t_
-        ragged = {"workload": f"{n_req} requests, max_new uniform in [{RAGGED_LO}, {RAGGED_HI}] (mean {sum(lens) / len(lens):.1f}, seed 4000), {B} rows",
+        ragged = {"workload": f"{n_req} requests, max_new uniform in [{RAGGED_LO}, {RAGGED_HI}] (mean {sum(lens) / len(lens):.1f}, seed 4000), {B} rows, {args.poll_ragged or args.poll} decode steps per scheduling round",
                   "continuous_tiles_per_s": round(n_req / r_dt, 3), "continuous_tokens_per_s": round(sum(lens) / r_dt, 1), "continuous_decode_steps": r_steps,
                   "static_batches_tiles_per_s": round(n_req / s_dt, 3), "static_batches_decode_steps": s_steps,
                   "gain": round(s_dt / r_dt, 4)}
