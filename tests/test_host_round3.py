@@ -222,3 +222,19 @@ def test_sam2_package_checkpoint_names_map_onto_the_names_the_engine_loads():
         assert torch.equal(back[k], sd[k]), k
     extra = set(back) - set(sd)
     assert extra <= {"mask_decoder.pred_obj_score_head.proj_in.weight"}, sorted(extra)[:8]      # (object-score head: loaded by HF, unused by predict)
+
+
+def test_seg_infer_provider_default_follows_the_configuration():
+    """seg_worker.py:540 of the reference hands sam2_seg_model_provider to the strategy; here a configuration that names no SAM2 model keeps the
+    offline stand-in (host-flow tests), one that names a model goes to the MI355X SAM2 provider -- which refuses to run without a GPU
+    instead of falling back to anything."""
+    import pytest
+    import torch
+    from roll.pipeline.rlvr import rlvr_socioseg_vlm_pipeline_infer as P
+    from socioreasoner_amd import socioseg_data
+    assert isinstance(P._default_sam_provider(model_args={}), socioseg_data.SyntheticSamPredictor)
+    assert isinstance(P._default_sam_provider(model_args=None), socioseg_data.SyntheticSamPredictor)
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception) as ei:
+            P._default_sam_provider(model_args={"model_name_or_path": "synthetic:sam2-tiny"})
+        assert "GPU" in str(ei.value) or "cuda" in str(ei.value).lower() or "HIP" in str(ei.value)
