@@ -188,6 +188,156 @@ __global__ __launch_bounds__(256) void k_attn_prefill(AttnArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- few queries, many keys
+// SAM2's token-to-image attentions: <= 16 queries (one object's prompt tokens) against 4096 image keys per head.  k_attn_prefill gives such a
+// work item one wave with live queries and walks the 2 x 64 key tiles one after the other (130 us of pure latency per launch, a third of the
+// mask decoder).  Here ALL waves of the block serve the same <= 16 queries and split the key tiles (wave w: tiles w, w + NW, ...), each staging
+// its own tiles in its own LDS region (no block barrier in the loops).  Same two passes and the same P = bf16(exp(s - m) / l) with the GLOBAL
+// row max / sum, which the waves combine through LDS after pass 1 (flash-decoding's rescale, fixed order); the P.V partial sums of the waves
+// are added in wave order.  Deterministic; differs from the one-wave walk only in the float32 association of l and of the P.V sum.
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void k_attn_fewq(AttnArgs p) {
+    using C = PrefillCfg<HD>;
+    constexpr int WB = C::K_BYTES + C::V_BYTES;                 // per-wave staging
+    static_assert(C::DT * 64 * 16 <= WB, "a wave's P.V partial sums reuse its staging region");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NW * WB + NW * 16 * 8];
+    const AttnWork wk = p.work[blockIdx.x];
+    const int h = blockIdx.y, kvh = h / p.group;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    unsigned char* ks = smem + wave * WB;
+    unsigned char* vs = ks + C::K_BYTES;
+    float* ml = reinterpret_cast<float*>(smem + NW * WB);       // [NW][16][2]: (m, l) of every wave and query
+    const int q_len = wk.q_len > 0 ? wk.q_len : wk.seq_len;
+    const int nq = min(16, q_len - wk.q_off);                   // live queries (<= 16 by contract: AttnArgs.q_tile == 16)
+    const bool q_valid = fr < nq;
+    const bf16_t* qptr = p.q + (size_t)(wk.q_row0 + min(fr, nq - 1)) * p.q_stride + h * HD;
+    bf16x8 qf[C::KS];
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+        const int d = kk * 32 + fg * 8;
+        if (d < HD) qf[kk] = *reinterpret_cast<const bf16x8*>(qptr + d);
+        else qf[kk] = __builtin_bit_cast(bf16x8, uint4{0, 0, 0, 0});
+    }
+    const bf16_t* kbase = p.k + (size_t)wk.k_row0 * p.k_stride + (size_t)kvh * p.k_head_stride;
+    const bf16_t* vbase = p.vt + wk.vt_off + (size_t)kvh * p.vt_head_stride;
+    const int ntile = (wk.seq_len + KT - 1) / KT;
+    auto stage_k = [&](int kv0) {
+        constexpr int CH = C::HDP / 8;
+        for (int c = lane; c < KT * CH; c += 64) {
+            const int row = c / CH, ch = c % CH;
+            uint4 v = uint4{0, 0, 0, 0};
+            if (ch * 8 < HD) v = *reinterpret_cast<const uint4*>(kbase + (size_t)min(kv0 + row, wk.seq_len - 1) * p.k_stride + ch * 8);
+            *reinterpret_cast<uint4*>(ks + row * C::K_RS + ch * 16) = v;
+        }
+    };
+    auto stage_v = [&](int kv0) {
+        for (int c = lane; c < HD * (KT / 4); c += 64) {
+            const int d = c / (KT / 4), g4 = c % (KT / 4);
+            const int j0 = kv0 + g4 * 4;
+            uint2 v = uint2{0, 0};
+            if (j0 < wk.seq_len) {
+                v = *reinterpret_cast<const uint2*>(vbase + (size_t)d * p.vt_stride + j0);
+                if (j0 + 1 >= wk.seq_len) v.x &= 0x0000ffffu;
+                if (j0 + 2 >= wk.seq_len) v.y = 0;
+                else if (j0 + 3 >= wk.seq_len) v.y &= 0x0000ffffu;
+            }
+            *reinterpret_cast<uint2*>(vs + d * VT_RS + g4 * 8) = v;
+        }
+    };
+    auto scores = [&](int kv0, float (&s)[4][4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < C::KS; ++kk) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + (t * 16 + fr) * C::K_RS + (kk * 4 + fg) * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = (kv0 + t * 16 + fg * 4 + r < wk.seq_len) ? rbf(rbf(acc[r]) * p.scale) : -INFINITY;
+        }
+    };
+    // ---- pass 1 over this wave's tiles
+    float m = -INFINITY, l = 0.f;
+    for (int ti = wave; ti < ntile; ti += NW) {
+        stage_k(ti * KT);
+        float s[4][4];
+        scores(ti * KT, s);
+        float tm = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tm = fmaxf(tm, s[t][r]);
+        tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        const float mn = fmaxf(m, tm);
+        float ts = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ts += __expf(s[t][r] - mn);
+        ts += __shfl_xor(ts, 16, 64);
+        ts += __shfl_xor(ts, 32, 64);
+        l = l * __expf(m - mn) + ts;
+        m = mn;
+    }
+    if (fg == 0) { ml[(wave * 16 + fr) * 2] = m; ml[(wave * 16 + fr) * 2 + 1] = l; }
+    __syncthreads();
+    float gm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) gm = fmaxf(gm, ml[(w * 16 + fr) * 2]);
+    float gl = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const float mw = ml[(w * 16 + fr) * 2];
+        if (mw > -INFINITY) gl += ml[(w * 16 + fr) * 2 + 1] * __expf(mw - gm);        // (a wave without tiles contributes nothing)
+    }
+    const float inv_l = 1.0f / gl;
+    // ---- pass 2 over the same tiles
+    f32x4 oacc[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ti = wave; ti < ntile; ti += NW) {
+        stage_k(ti * KT);
+        stage_v(ti * KT);
+        float s[4][4];
+        scores(ti * KT, s);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint4 pv;
+            pv.x = pack2(__expf(s[2 * kb][0] - gm) * inv_l, __expf(s[2 * kb][1] - gm) * inv_l);
+            pv.y = pack2(__expf(s[2 * kb][2] - gm) * inv_l, __expf(s[2 * kb][3] - gm) * inv_l);
+            pv.z = pack2(__expf(s[2 * kb + 1][0] - gm) * inv_l, __expf(s[2 * kb + 1][1] - gm) * inv_l);
+            pv.w = pack2(__expf(s[2 * kb + 1][2] - gm) * inv_l, __expf(s[2 * kb + 1][3] - gm) * inv_l);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pv);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+                const unsigned char* vr = vs + (dt * 16 + fr) * VT_RS + kb * 64 + fg * 8;
+                const uint2 v0 = *reinterpret_cast<const uint2*>(vr), v1 = *reinterpret_cast<const uint2*>(vr + 32);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, uint4{v0.x, v0.y, v1.x, v1.y}), pf, oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+    // the wave's partial sums go into its own (now dead) staging region
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) reinterpret_cast<f32x4*>(ks)[dt * 64 + lane] = oacc[dt];
+    __syncthreads();
+    if (wave == 0 && q_valid) {
+        bf16_t* optr = p.out + (size_t)(wk.q_row0 + fr) * p.out_stride + h * HD + fg * 4;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            f32x4 o = reinterpret_cast<const f32x4*>(smem)[dt * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const f32x4 o2 = reinterpret_cast<const f32x4*>(smem + w * WB)[dt * 64 + lane];
+                o[0] += o2[0]; o[1] += o2[1]; o[2] += o2[2]; o[3] += o2[3];
+            }
+            *reinterpret_cast<uint2*>(optr + dt * 16) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- prefill, round 3
 // k_attn_prefill2: the SAME per-wave arithmetic as k_attn_prefill (a wave = 16 queries of one head against 64-key tiles, two passes, same
 // MFMA order, same softmax sums: results are bit-identical, tests/test_gpu_round3.py), but
@@ -948,6 +1098,12 @@ int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim) {
     if (attn_prefill_variant(a, head_dim) == 2) {
         if (head_dim == 128) return launch_prefill2<128, true, 2, 2>(s, a);       // 32 queries x 4 heads, 2 x 32 KB ring
         return launch_prefill2<80, false, 8, 3>(s, a);                            // 128 queries x 1 head, 3 x 26 KB ring
+    }
+    if (a.q_tile == 16) {      // work items of <= 16 queries (SAM2 token-to-image attention): the waves of a block split the keys
+        if (a.causal || head_dim != 16) return -22;
+        hipLaunchKernelGGL((k_attn_fewq<16, 8>), dim3(a.n_work, a.n_heads), dim3(512), 0, s, a);
+        SR_CHECK_LAUNCH();
+        return 0;
     }
     if (a.q_tile != 0 && a.q_tile != 64) return -22;           // k_attn_prefill walks 64-query work items
     dim3 grid(a.n_work, a.n_heads), block(256);

@@ -39,6 +39,7 @@ from . import lib as L
 
 EPI_STORE, EPI_RESID, EPI_GELU, EPI_F32 = 0, 1, 3, 4
 GELU_FAST = 0x800          # sr_op_gemm: the GELU epilogue through gelu_fast_f (csrc/common.h)
+_FEWQ = os.environ.get("SR_SAM_FEWQ", "1") != "0"
 _WORK = np.dtype([("q_row0", "<i4"), ("seq_len", "<i4"), ("q_off", "<i4"), ("k_row0", "<i4"), ("vt_off", "<i8"), ("q_len", "<i4"), ("pad", "<i4")])
 _HD_OK = (16, 32, 80, 128)
 
@@ -476,7 +477,9 @@ class Sam2Engine:
             lq, lk = (T if q_side == "tok" else m2), (T if k_side == "tok" else m2)
             items += [(ob * sq + q0, lk, q0, ob * sk, ob * sk, lq if lq != lk else 0) for q0 in range(0, lq, 64)]
         wk = self.work(("dec", q_side, k_side, Ts, TOK), items)
-        self.attention(qp, internal, kp, 0, internal, hd, vt, vts, o, internal, wk, g.dec_heads, hd ** -0.5)
+        # token -> image: <= 16 queries against m2 keys per object and head -- the kernel whose waves split the keys (q_tile = 16 says so)
+        few = q_side == "tok" and k_side == "img" and hd == 16 and max(Ts) <= 16 and _FEWQ
+        self.attention(qp, internal, kp, 0, internal, hd, vt, vts, o, internal, wk, g.dec_heads, hd ** -0.5, q_tile=16 if few else 64)
         self.gemm(o, internal, name + ".o_proj", nq, out, Cd, EPI_RESID if resid is not None else EPI_STORE, resid=resid)
 
     def decode(self, coords: np.ndarray, labels: np.ndarray):
