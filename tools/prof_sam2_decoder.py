@@ -9,6 +9,6 @@ e.load_state_dict(sam2.synthetic_state_dict(g))
 e.set_image(torch.from_numpy(synthetic.tile_pixels(7, 756, 756)).cuda())
 acc = torch.zeros(756, 756, dtype=torch.uint8, device="cuda")
 objs = [dict(point_coords=[[300 + 20 * k, 320]], point_labels=[1], box=[100 + 30 * k, 120, 420 + 30 * k, 600]) for k in range(4)]
-for _ in range(12):
+for _ in range(60):
     e.predict_or_many(acc, objs)
 torch.cuda.synchronize()
