@@ -194,7 +194,7 @@ int sr_render_overlay(uint8_t* dev_img_rgb, int h, int w, const uint8_t* dev_mas
 /* Single-kernel entry points used by the parity tests and micro-benchmarks (same kernels the engine launches).
  * All pointers are device pointers; layouts are documented in DESIGN.md "Kernels".
  * Flag bits OR-ed into `epilogue` / `mode`: 0x100 W fragment-ordered (tiled16x64); sr_op_gemm: 0x200 / 0x400 force the 256- /
- * 128-tile kernel, 0x800 the GELU epilogue through the erfc-polynomial form (|error| 4e-7, SAM2 image encoder); sr_op_gemv*: 0x800 x fragment-ordered (tiled16x64 of a [ceil16(M), K] matrix), 0x1000 SwiGLU output
+ * 128-tile kernel, 0x800 the GELU epilogue through the erfc-polynomial form (|error| 4e-7, SAM2 image encoder), 0x1000 ReLU in its place (SAM2 mask decoder MLPs); sr_op_gemv*: 0x800 x fragment-ordered (tiled16x64 of a [ceil16(M), K] matrix), 0x1000 SwiGLU output
  * fragment-ordered. */
 /* ---- SAM2 (Hiera-L) image path behind seg_infer -- /root/reference/roll/distributed/strategy/seg_strategy.py:47-60 calls
  * SAM2ImagePredictor.set_image / predict; the network (transformers/models/sam2/modeling_sam2.py = the sam2 package's) is driven from

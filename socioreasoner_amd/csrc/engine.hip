@@ -1504,7 +1504,7 @@ int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void*
     GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, M, N, K, out, ldo, (const bf16_t*)bias, (const bf16_t*)resid, rowmap,
                (epilogue & 0x100) ? 1 : 0, nullptr,      // bit 8 of `epilogue`: W is fragment-ordered (tiled16x64)
                (epilogue & 0x200) ? 256 : (epilogue & 0x400) ? 128 : 0};      // bits 9 / 10: force the 256- / 128-tile kernel
-    a.gelu_fast = (epilogue & 0x800) ? 1 : 0;                      // bit 11: EPI_GELU through gelu_fast_f
+    a.gelu_fast = (epilogue & 0x1000) ? 2 : (epilogue & 0x800) ? 1 : 0;      // bit 11: EPI_GELU through gelu_fast_f; bit 12: ReLU instead of GELU
     SR_WRAP(launch_gemm((hipStream_t)stream, a, epilogue & 0xff));
 }
 // ---- SAM2 image path (socioreasoner_amd/sam2.py drives these; shapes and layouts: sam.hip, attention.hip)

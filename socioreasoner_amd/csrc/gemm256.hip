@@ -519,7 +519,7 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
                     o[2] = lo16(rv[j].y) + rbf(o[2]); o[3] = hi16(rv[j].y) + rbf(o[3]);
                 } else if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = p.gelu_fast ? gelu_fast_f(rbf(o[r])) : gelu_f(rbf(o[r]));
+                    for (int r = 0; r < 4; ++r) o[r] = p.gelu_fast == 2 ? fmaxf(rbf(o[r]), 0.f) : p.gelu_fast ? gelu_fast_f(rbf(o[r])) : gelu_f(rbf(o[r]));
                 }
                 t4[j] = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
             }

@@ -48,7 +48,7 @@ struct GemmArgs {
     VitRope vrope;              // EPI_VITQKV only
     int ksplit;                 // > 1 (EPI_F32, gemm.hip kernel only): K is split over gridDim.y blocks, block y writes its float32 partial
                                 // products to out + y * M * ldo (slabs the consumer sums: launch_resid_rmsnorm)
-    int gelu_fast;              // EPI_GELU: gelu_fast_f (common.h) instead of the erff form
+    int gelu_fast;              // EPI_GELU: 1 = gelu_fast_f (common.h) instead of the erff form, 2 = ReLU (the activation epilogue's third function)
 };
 bool gemm_fuses_vitqkv(const GemmArgs& a);
 // true when launch_gemm would run `a` with the fused q/k/v epilogue (same predicate as its dispatch to gemm256.hip)

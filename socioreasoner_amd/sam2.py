@@ -39,6 +39,7 @@ from . import lib as L
 
 EPI_STORE, EPI_RESID, EPI_GELU, EPI_F32 = 0, 1, 3, 4
 GELU_FAST = 0x800          # sr_op_gemm: the GELU epilogue through gelu_fast_f (csrc/common.h)
+RELU = 0x1000              # sr_op_gemm with EPI_GELU: ReLU as the activation of the epilogue
 _FEWQ = os.environ.get("SR_SAM_FEWQ", "1") != "0"
 _WORK = np.dtype([("q_row0", "<i4"), ("seq_len", "<i4"), ("q_off", "<i4"), ("k_row0", "<i4"), ("vt_off", "<i8"), ("q_len", "<i4"), ("pad", "<i4")])
 _HD_OK = (16, 32, 80, 128)
@@ -510,7 +511,12 @@ class Sam2Engine:
         host = torch.zeros(NB * TOK, Cd, dtype=torch.bfloat16)
         for ob, t in enumerate(toks):
             host[ob * TOK:ob * TOK + Ts[ob]] = t.to(torch.bfloat16)
-        tok.copy_(host, non_blocking=True)
+        # pageable -> device in pieces of 16 KB (two objects): larger pageable copies wait for the stream to drain (the host then sits behind
+        # the previous pass, 0.8 ms per call from three objects on); pinned staging buffers were measured too and cost MORE host time here
+        # (0.5 ms per call for one object, 2 ms for four)
+        step = 2 * TOK
+        for r0 in range(0, NB * TOK, step):
+            tok[r0:r0 + step].copy_(host[r0:r0 + step], non_blocking=True)
         # ~110 launches of a few microseconds each: issued one by one the host is the bottleneck (0.8 ms per call).  The launch sequence
         # is captured once per tuple of token counts (every buffer keeps its shape and address) and replayed.
         if not self.graph_decode:
@@ -555,8 +561,7 @@ class Sam2Engine:
             self._mha(p + ".cross_attn_token_to_image", qx, kx, keys, "tok", "img", Ts, Cd // 2, q, q, "t2i")
             self.layernorm(q, Cd, p + ".layer_norm2", q, Cd, NT, Cd, eps)
             hid = self.buf(f"d_hid{sfx}", max(NT, 16), g.dec_mlp)
-            self.gemm(q, Cd, p + ".mlp.proj_in", NT, hid, g.dec_mlp)
-            self.ew(hid, g.dec_mlp, None, 0, hid, g.dec_mlp, NT, g.dec_mlp, 2)
+            self.gemm(q, Cd, p + ".mlp.proj_in", NT, hid, g.dec_mlp, EPI_GELU | RELU)
             self.gemm(hid, g.dec_mlp, p + ".mlp.proj_out", NT, q, Cd, EPI_RESID, resid=q)
             self.layernorm(q, Cd, p + ".layer_norm3", q, Cd, NT, Cd, eps)
             self.ew(q, Cd, tok, Cd, qx, Cd, NT, Cd, 0)
@@ -587,19 +592,15 @@ class Sam2Engine:
         h1, h2 = self.buf(f"d_h1{sfx}", max(NB, 16), Cd), self.buf(f"d_h2{sfx}", max(NB, 16), Cd)
         for i in range(g.n_mask_tokens):
             n = f"mask_decoder.output_hypernetworks_mlps.{i}"
-            self.gemm(q, TOK * Cd, n + ".proj_in", NB, h1, Cd, a_off=(2 + i) * Cd)
-            self.ew(h1, Cd, None, 0, h1, Cd, NB, Cd, 2)
-            self.gemm(h1, Cd, n + ".layers.0", NB, h2, Cd)
-            self.ew(h2, Cd, None, 0, h2, Cd, NB, Cd, 2)
+            self.gemm(q, TOK * Cd, n + ".proj_in", NB, h1, Cd, EPI_GELU | RELU, a_off=(2 + i) * Cd)
+            self.gemm(h1, Cd, n + ".layers.0", NB, h2, Cd, EPI_GELU | RELU)
             self.gemm(h2, Cd, n + ".proj_out", NB, hyp, 16 * 64, out_off=i * 64)
         low = self.buf(f"d_low{sfx}", NB * n0, 16, torch.float32)
         for ob in range(NB):
             self._ck(lib.sr_op_gemm(self._p(u2, ob * n0 * 64), 64, self._p(hyp, ob * 16 * 64), n0, 16, 64, self._p(low, ob * n0 * 16), 16, None, None, None, EPI_F32, self._s()), "mask gemm")
         n = "mask_decoder.iou_prediction_head"
-        self.gemm(q, TOK * Cd, n + ".proj_in", NB, h1, Cd, a_off=1 * Cd)
-        self.ew(h1, Cd, None, 0, h1, Cd, NB, Cd, 2)
-        self.gemm(h1, Cd, n + ".layers.0", NB, h2, Cd)
-        self.ew(h2, Cd, None, 0, h2, Cd, NB, Cd, 2)
+        self.gemm(q, TOK * Cd, n + ".proj_in", NB, h1, Cd, EPI_GELU | RELU, a_off=1 * Cd)
+        self.gemm(h1, Cd, n + ".layers.0", NB, h2, Cd, EPI_GELU | RELU)
         iou = self.buf(f"d_iou{sfx}", NB, 16, torch.float32)
         self.gemm(h2, Cd, n + ".proj_out", NB, iou, 16, EPI_F32)
         return low, iou
