@@ -788,6 +788,7 @@ class Sam2Predictor:
         self.cache_images = int(cache_images)         # embeddings kept (10 MB each at Hiera-L): stage 2 segments stage 1's image again
         self._cache: "OrderedDict[bytes, dict]" = OrderedDict()
         self.stats = {"images": 0, "encoded": 0, "cache_hits": 0, "encoder_passes": 0}
+        self._upload = None                           # side stream of the image uploads (embed)
 
     @staticmethod
     def _host_u8(image) -> np.ndarray:
@@ -819,9 +820,21 @@ class Sam2Predictor:
             else:
                 todo.append(k)
         by_key = dict(zip(keys, arrs))
+        main = torch.cuda.current_stream(self.engine.device)
+        if self._upload is None:
+            self._upload = torch.cuda.Stream(self.engine.device)
         for i in range(0, len(todo), self.batch):
             chunk = todo[i:i + self.batch]
-            self.engine.set_images([torch.from_numpy(by_key[k]).to(self.engine.device, non_blocking=True) for k in chunk])
+            # pageable host -> device copies are stream-ordered AND host-synchronous: issued on the compute stream the host would sit behind
+            # the previous chunk's encoder pass and the GPU would idle during the next uploads; on their own stream they overlap it
+            with torch.cuda.stream(self._upload):
+                dev_imgs = [torch.from_numpy(by_key[k]).to(self.engine.device, non_blocking=True) for k in chunk]
+                up = torch.cuda.Event()
+                up.record(self._upload)
+            main.wait_event(up)
+            for t in dev_imgs:
+                t.record_stream(main)
+            self.engine.set_images(dev_imgs)
             self.stats["encoder_passes"] += 1
             self.stats["encoded"] += len(chunk)
             for b, k in enumerate(chunk):
