@@ -426,7 +426,7 @@ def main():
         # HBM traffic per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950 note):
         # measured ratio traffic / algorithmic bytes of this kernel family x the algorithmic bytes of one launch
         traffic, pmc, insitu = None, None, None
-        PMC_FILE = "r02_pmc_gemv_traffic.json"
+        PMC_FILE = "r03_pmc_gemv_traffic.json"
         try:     # rocprofv3 kernel-trace average of the same kernels inside the full decode step (committed summary of the static-batch trace)
             insitu = json.load(open(os.path.join(ROOT, "profiles", "r03_gemv_in_situ.json")))["batch32" if B > 4 else "batch1"]
         except Exception:  # noqa: BLE001
