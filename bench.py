@@ -431,7 +431,7 @@ def main():
             insitu = json.load(open(os.path.join(ROOT, "profiles", "r03_gemv_in_situ.json")))["batch32" if B > 4 else "batch1"]
         except Exception:  # noqa: BLE001
             pass
-        try:     # profiles/r02_pmc_gemv_traffic.json: FETCH_SIZE passes of this kernel family at batch 32 and batch 1 (tools/gpu_pmc_r2.sh)
+        try:     # profiles/r03_pmc_gemv_traffic.json: FETCH_SIZE / WRITE_SIZE passes of this kernel family at batch 32 and batch 1 (tools/gpu_r3_pmc_gemv.sh)
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             traffic = round(pmc["traffic_over_algorithmic_weighted_batch32" if B > 4 else "traffic_over_algorithmic_weighted_batch1"] * bytes_per_launch)
         except Exception:  # noqa: BLE001
