@@ -782,9 +782,9 @@ class Sam2Predictor:
     """What ``SegInferStrategy`` expects from its model provider: ``set_image(PIL / ndarray)`` and ``predict(**prompt)``; also
     ``segment_objects`` = the whole per-sample loop of seg_strategy.py:47-60 on the device."""
 
-    def __init__(self, engine: Sam2Engine, batch: int = 8, cache_images: int = 256):
+    def __init__(self, engine: Sam2Engine, batch: int = 16, cache_images: int = 256):
         self.model = self.engine = engine
-        self.batch = max(1, int(batch))               # images per encoder pass
+        self.batch = max(1, int(batch))               # images per encoder pass (measured per tile: 5.41 / 5.19 / 5.10 ms at 8 / 12 / 16)
         self.cache_images = int(cache_images)         # embeddings kept (10 MB each at Hiera-L): stage 2 segments stage 1's image again
         self._cache: "OrderedDict[bytes, dict]" = OrderedDict()
         self.stats = {"images": 0, "encoded": 0, "cache_hits": 0, "encoder_passes": 0}
