@@ -188,6 +188,95 @@ __global__ __launch_bounds__(256) void k_attn_prefill(AttnArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- 64-token windows, no LDS
+// The ViT's window blocks (28 of its 32 layers): every window is exactly 64 tokens, so the K tile (64 x 80) and the V^T tile (80 x 64) of a
+// (window, head) are 40 + 48 registers of MFMA fragments, loaded straight from global memory in the layouts the MFMAs want (the same row /
+// key permutations k_attn_prefill reads from LDS).  ONE WAVE does a whole (window, head): no LDS, no barrier, every load issued before the
+// first MFMA; k_attn_prefill staged the tiles synchronously through VGPRs into LDS twice (two passes) with two block barriers each.  The
+// arithmetic per output is the same sequence (scores, max / sum over the lane's 16 keys then across the four lane groups, P = bf16(exp(s - m)
+// / l), P.V over the two 32-key blocks in order): BIT-IDENTICAL to k_attn_prefill<80, false> (tests/test_gpu_round3.py).
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_win64(AttnArgs p) {
+    using C = PrefillCfg<HD>;
+    const AttnWork wk = p.work[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = blockIdx.y * 4 + wave, kvh = h / p.group;
+    if (h >= p.n_heads) return;
+    const int fr = lane & 15, fg = lane >> 4;
+    const bf16_t* kbase = p.k + (size_t)wk.k_row0 * p.k_stride + (size_t)kvh * p.k_head_stride;
+    const bf16_t* vbase = p.vt + wk.vt_off + (size_t)kvh * p.vt_head_stride;
+    const bf16x8 zero8 = __builtin_bit_cast(bf16x8, uint4{0, 0, 0, 0});
+    bf16x8 kf[4][C::KS];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int kk = 0; kk < C::KS; ++kk) {
+            const int d = kk * 32 + fg * 8;
+            kf[t][kk] = d < HD ? *reinterpret_cast<const bf16x8*>(kbase + (size_t)(t * 16 + fr) * p.k_stride + d) : zero8;
+        }
+    bf16x8 vf[C::DT][2];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const bf16_t* vr = vbase + (size_t)(dt * 16 + fr) * p.vt_stride + kb * 32 + fg * 4;
+            const uint2 v0 = *reinterpret_cast<const uint2*>(vr), v1 = *reinterpret_cast<const uint2*>(vr + 16);   // keys kb*32 + fg*4 .. +3 and + 16
+            vf[dt][kb] = __builtin_bit_cast(bf16x8, uint4{v0.x, v0.y, v1.x, v1.y});
+        }
+    bf16x8 qf[4][C::KS];
+#pragma unroll
+    for (int qs = 0; qs < 4; ++qs)
+#pragma unroll
+        for (int kk = 0; kk < C::KS; ++kk) {
+            const int d = kk * 32 + fg * 8;
+            qf[qs][kk] = d < HD ? *reinterpret_cast<const bf16x8*>(p.q + (size_t)(wk.q_row0 + qs * 16 + fr) * p.q_stride + h * HD + d) : zero8;
+        }
+#pragma unroll
+    for (int qs = 0; qs < 4; ++qs) {
+        float s[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < C::KS; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][kk], qf[qs][kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = rbf(rbf(acc[r]) * p.scale);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[t][r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) l += __expf(s[t][r] - m);
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv_l = 1.0f / l;
+        f32x4 oacc[C::DT];
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            uint4 pv;
+            pv.x = pack2(__expf(s[2 * kb][0] - m) * inv_l, __expf(s[2 * kb][1] - m) * inv_l);
+            pv.y = pack2(__expf(s[2 * kb][2] - m) * inv_l, __expf(s[2 * kb][3] - m) * inv_l);
+            pv.z = pack2(__expf(s[2 * kb + 1][0] - m) * inv_l, __expf(s[2 * kb + 1][1] - m) * inv_l);
+            pv.w = pack2(__expf(s[2 * kb + 1][2] - m) * inv_l, __expf(s[2 * kb + 1][3] - m) * inv_l);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pv);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt][kb], pf, oacc[dt], 0, 0, 0);
+        }
+        bf16_t* optr = p.out + (size_t)(wk.q_row0 + qs * 16 + fr) * p.out_stride + h * HD + fg * 4;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) *reinterpret_cast<uint2*>(optr + dt * 16) = uint2{pack2(oacc[dt][0], oacc[dt][1]), pack2(oacc[dt][2], oacc[dt][3])};
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- few queries, many keys
 // SAM2's token-to-image attentions: <= 16 queries (one object's prompt tokens) against 4096 image keys per head.  k_attn_prefill gives such a
 // work item one wave with live queries and walks the 2 x 64 key tiles one after the other (130 us of pure latency per launch, a third of the
@@ -1098,6 +1187,14 @@ int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim) {
     if (attn_prefill_variant(a, head_dim) == 2) {
         if (head_dim == 128) return launch_prefill2<128, true, 2, 2>(s, a);       // 32 queries x 4 heads, 2 x 32 KB ring
         return launch_prefill2<80, false, 8, 3>(s, a);                            // 128 queries x 1 head, 3 x 26 KB ring
+    }
+    if (a.win64 && head_dim == 80 && !a.causal && a.n_heads % 4 == 0) {      // every item = one 64-token window starting at its first query (caller's promise)
+        const char* env = getenv("SR_ATTN_WIN64");
+        if (!(env && atoi(env) == 0)) {
+            hipLaunchKernelGGL((k_attn_win64<80>), dim3(a.n_work, a.n_heads / 4), dim3(256), 0, s, a);
+            SR_CHECK_LAUNCH();
+            return 0;
+        }
     }
     if (a.q_tile == 16) {      // work items of <= 16 queries (SAM2 token-to-image attention): the waves of a block split the keys
         if (a.causal || head_dim != 16) return -22;

@@ -94,6 +94,7 @@ struct sr_engine {
     int *v_rowmap_embed, *v_rowmap_merge;
     AttnWork *v_work_win, *v_work_full, *v_work_full128;     // full attention: 64-query items (k_attn_prefill) and 128-query items (k_attn_prefill2)
     int v_nwork_full128; bool v_full_aligned;
+    bool v_win_all64;              // every window of the cached grids is a full 8 x 8 merge-unit window (64 tokens): k_attn_win64 applies
     int v_nwork_win = 0, v_nwork_full = 0;
     std::vector<int64_t> v_grid_cached;
     // ---- LM activations
@@ -428,6 +429,7 @@ int vit_prepare(sr_engine* e, const int64_t* grid, int n_img, hipStream_t s, int
     int n_win = 0;
     std::vector<AttnWork> full, full128;
     bool aligned = true;         // every image starts on a multiple of 8 patches: 16-byte aligned V^T key runs (k_attn_prefill2's LDS-DMA)
+    bool all64 = true;           // every window holds exactly 64 tokens (k_attn_win64)
 
     int unit_base = 0, row_base = 0, new_unit = 0;
     for (int im = 0; im < n_img; ++im) {
@@ -458,6 +460,7 @@ int vit_prepare(sr_engine* e, const int64_t* grid, int n_img, hipStream_t s, int
                         ++new_unit;
                     }
                 const int len = (new_unit - start_unit) * unit;
+                if (len != 64 || (start_unit * unit) % 4) all64 = false;
                 for (int q0 = 0; q0 < len; q0 += 64)
                     h_win[n_win++] = AttnWork{start_unit * unit + q0, len, q0, start_unit * unit, (long long)start_unit * unit};
             }
@@ -488,6 +491,7 @@ int vit_prepare(sr_engine* e, const int64_t* grid, int n_img, hipStream_t s, int
     e->v_nwork_full = (int)full.size();
     e->v_nwork_full128 = (int)full128.size();
     e->v_full_aligned = aligned;
+    e->v_win_all64 = all64;
     e->v_grid_cached = key;
     return 0;
 }
@@ -893,6 +897,7 @@ int sr_vit_forward(sr_engine* e, const void* pixels, int pixels_dtype, const int
         AttnArgs a{e->v_qkv, 3 * C, e->v_qkv + C, 3 * C, hd, e->v_vt, e->v_vt_stride, (long long)hd * e->v_vt_stride,
                    e->v_attn, C, full ? e->v_work_full : e->v_work_win, full ? e->v_nwork_full : e->v_nwork_win,
                    c.v_heads, 1, scale, 0, 64, 0};
+        if (!full && e->v_win_all64 && e->v_vt_stride % 4 == 0) a.win64 = 1;     // one wave per (window, head), operands straight into registers
         if (full && e->v_full_aligned) {      // full attention: 128-query blocks that share LDS-DMA-staged tiles (k_attn_prefill2) where it applies
             AttnArgs a2 = a;
             a2.work = e->v_work_full128; a2.n_work = e->v_nwork_full128; a2.q_tile = 128; a2.v2_ok = 1;

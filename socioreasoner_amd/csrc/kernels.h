@@ -110,6 +110,8 @@ struct AttnArgs {
     int q_tile;                           // queries per work item: 0 / 64 (k_attn_prefill), or 128 (k_attn_prefill2, MHA full attention)
     int v2_ok;                            // caller's promise for k_attn_prefill2: vt + vt_off + 64 * j is 16-byte aligned for every work item,
                                           // the V^T rows are readable (and finite) up to the end of the last 64-key tile
+    int win64;                            // caller's promise for k_attn_win64: EVERY work item is one whole window of exactly 64 tokens (q_off 0,
+                                          // seq_len 64, no pooled queries) whose V^T key run starts 8-byte aligned
 };
 int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim);
 int attn_prefill_variant(const AttnArgs& a, int head_dim);   // 2: k_attn_prefill2 takes it, 1: k_attn_prefill

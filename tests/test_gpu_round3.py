@@ -266,3 +266,26 @@ def test_fp8_modes_distance_to_float32_truth_and_to_hf_bf16(golden_dir, mode):
     margin = float(g[f"{tag}_first_margin"][0])
     if margin > 2 * max(e_q["max"], err(out[mode][1], l16)["max"]):
         assert int(out[mode][1].argmax()) == int(g[f"{tag}_tokens"][0])
+
+
+@pytest.mark.parametrize("hw", [448, 896, 756])
+def test_window_attention_without_lds_equals_the_staged_kernel_bit_for_bit(monkeypatch, hw):
+    """k_attn_win64 (one wave per (window, head), K / V^T fragments straight from global memory) against k_attn_prefill<80> on the ViT's window
+    blocks at full 3B depth: the vision embeddings must be identical.  756-pixel tiles have ragged border windows: the engine must keep the
+    staged kernel there (same result by construction)."""
+    from socioreasoner_amd import synthetic
+    from socioreasoner_amd.config import geometry_3b
+    from socioreasoner_amd.engine import Engine
+    geom = geometry_3b()
+    grid = (1, hw // 14, hw // 14)
+    n = 2
+    e = Engine(geom, max_patches=n * grid[1] * grid[2], max_prefill_tokens=64, max_batch=1, max_ctx=128, max_new_tokens=8)
+    e.load_synthetic_weights(seed=0)
+    pix = torch.cat([e.patchify(torch.from_numpy(synthetic.tile_pixels(70 + i, hw, hw)).cuda()) for i in range(n)], dim=0)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SR_ATTN_WIN64", mode)
+        out[mode] = e.vit_forward(pix, [grid] * n).clone()
+        torch.cuda.synchronize()
+    assert torch.equal(out["0"].view(torch.int16), out["1"].view(torch.int16))
+    e.close()
