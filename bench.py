@@ -43,6 +43,31 @@ def lm_weight_bytes(g):
     return per_layer * t.num_hidden_layers, t.vocab_size * t.hidden_size * 2
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks ourselves -- one process per GPU under
+    torch.distributed.run on 127.0.0.1 (the reference fans a batch out over its DP workers the same way:
+    /root/reference/roll/distributed/scheduler/decorator.py:106-181) -- and return their exit code; None = this process is a rank
+    (or N == 1) and runs the bench itself.  Refuses (exit code 2) when the node has fewer GPUs than ranks, unless
+    SR_DIST_BACKEND=gloo asks for the host-staged development layout in which ranks share devices."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and os.environ.get("SR_DIST_BACKEND") != "gloo":
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs (one rank per GPU over RCCL), this node has {have}; "
+              f"set SR_DIST_BACKEND=gloo to let ranks share devices on a development box", file=sys.stderr, flush=True)
+        return 2
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +96,9 @@ def main():
     ap.add_argument("--gather-logits", action="store_true",
                     help="verification mode (static batch): all-gather the float32 logits of every decode step (north_star's literal exchange)")
     args = ap.parse_args()
+    rc = self_launch(args)
+    if rc is not None:
+        sys.exit(rc)
     if args.fp8_mx:
         args.fp8 = True
     B = args.batch
@@ -91,7 +119,9 @@ def main():
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
         os.environ["SR_RCCL_LOG"] = os.environ["NCCL_DEBUG_FILE"] = f"/tmp/sr_rccl_{os.getpid()}_rank{os.environ.get('RANK', '0')}.log"
     rank, world, local = dp.init_distributed()      # RCCL when ranks > 1 (gloo only if SR_DIST_BACKEND=gloo asks for it)
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s): launch `python bench.py --gpus N` (self-launching) or "
+                         f"torchrun --nproc-per-node N bench.py --gpus N")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     geom = geometry_3b()
@@ -278,41 +308,51 @@ def main():
     if rank == 0 and world == 1 and not args.no_latency and not args.no_sam:
         from socioreasoner_amd import sam2 as _sam2
         sg = _sam2.Sam2Geometry()
-        se = _sam2.Sam2Engine(sg, str(dev))
-        se.load_state_dict(_sam2.synthetic_state_dict(sg))
         simg = torch.from_numpy(synthetic.tile_pixels(0, 756, 756)).to(dev)
-        sacc = torch.zeros(756, 756, dtype=torch.uint8, device=dev)
-
-        sobj = [dict(point_coords=[[300 + 20 * k, 320]], point_labels=[1], box=[100 + 30 * k, 120, 420 + 30 * k, 600]) for k in range(4)]
-
-        def sam_tile():                      # the reference's loop: one image, one object at a time
-            se.set_image(simg)
-            for o in sobj:
-                se.predict_or(sacc, **o)
-
-        def sam_tiles8():                    # 8 tiles per encoder pass, the 4 objects of a tile per decoder pass
-            se.set_images(simgs)
-            for b_ in range(8):
-                se.select(b_)
-                se.predict_or_many(sacc, sobj)
         simgs = [torch.from_numpy(synthetic.tile_pixels(i, 756, 756)).to(dev) for i in range(8)]
-        sam_tile()
-        sam_tiles8()
-        t_ = {}
-        for nm, fn, reps in (("set_image_ms", lambda: se.set_image(simg), 5), ("set_images_8_ms", lambda: se.set_images(simgs), 3),
-                             ("predict_ms_per_object", lambda: se.predict_or(sacc, **sobj[0]), 20), ("predict_ms_4_objects_one_pass", lambda: se.predict_or_many(sacc, sobj), 20),
-                             ("tile_ms_4_objects", sam_tile, 5), ("tiles8_ms_4_objects", sam_tiles8, 3)):
-            torch.cuda.synchronize(dev)
-            t0_ = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            torch.cuda.synchronize(dev)
-            t_[nm] = round((time.perf_counter() - t0_) / reps * 1e3, 3)
-        sam = dict(t_, workload="SAM2 Hiera-L (216.9 M parameters, random init), 756 x 756 tiles -> 1024 x 1024 input, box + click prompts, 3 masks + scores per object, "
-                                "best mask resized to 756 x 756 and OR-ed on the device; tile_ms = one tile and one object at a time (the reference's loop), "
-                                "tiles8_ms = 8 tiles per encoder pass and a tile's 4 objects per decoder pass (what seg_infer runs)",
-                   tiles_per_s_4_objects=round(1e3 / t_["tile_ms_4_objects"], 2), tiles_per_s_4_objects_batched=round(8e3 / t_["tiles8_ms_4_objects"], 2), dtype="bf16")
-        del se
+        sobj = [dict(point_coords=[[300 + 20 * k, 320]], point_labels=[1], box=[100 + 30 * k, 120, 420 + 30 * k, 600]) for k in range(4)]
+        ssd = _sam2.synthetic_state_dict(sg)
+
+        def sam_mode(dtype):
+            se = _sam2.Sam2Engine(sg, str(dev), dtype=dtype)
+            se.load_state_dict(ssd)
+            sacc = torch.zeros(756, 756, dtype=torch.uint8, device=dev)
+
+            def sam_tile():                      # the reference's loop: one image, one object at a time
+                se.set_image(simg)
+                for o in sobj:
+                    se.predict_or(sacc, **o)
+
+            def sam_tiles8():                    # 8 tiles per encoder pass, the 4 objects of a tile per decoder pass
+                se.set_images(simgs)
+                for b_ in range(8):
+                    se.select(b_)
+                    se.predict_or_many(sacc, sobj)
+            sam_tile()
+            sam_tiles8()
+            t_ = {}
+            for nm, fn, reps in (("set_image_ms", lambda: se.set_image(simg), 5), ("set_images_8_ms", lambda: se.set_images(simgs), 3),
+                                 ("predict_ms_per_object", lambda: se.predict_or(sacc, **sobj[0]), 20), ("predict_ms_4_objects_one_pass", lambda: se.predict_or_many(sacc, sobj), 20),
+                                 ("tile_ms_4_objects", sam_tile, 5), ("tiles8_ms_4_objects", sam_tiles8, 3)):
+                torch.cuda.synchronize(dev)
+                t0_ = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize(dev)
+                t_[nm] = round((time.perf_counter() - t0_) / reps * 1e3, 3)
+            del se
+            torch.cuda.empty_cache()
+            return dict(t_, tiles_per_s_4_objects=round(1e3 / t_["tile_ms_4_objects"], 2), tiles_per_s_4_objects_batched=round(8e3 / t_["tiles8_ms_4_objects"], 2))
+        # Hiera-L encoder: 1.57 TFLOP of Linear layers + 0.21 TFLOP of attention per 1024 x 1024 input
+        f32 = sam_mode(torch.float32)
+        f32["dtype"] = "float32 (the reference's precision: seg_infer's default; v_mfma_f32_32x32x2_f32 / 16x16x4_f32, peak 157 TF/s)"
+        f32["encoder_mfma_f32_frac_batched"] = round(1.78e12 * 8 / (f32["set_images_8_ms"] * 1e-3) / 157.3e12, 4)
+        b16 = sam_mode(torch.bfloat16)
+        b16["dtype"] = "bf16 storage / float32 accumulation (opt-in: sam2_compute_dtype bf16; masks differ from float32's inside the bf16 noise band)"
+        sam = {"workload": "SAM2 Hiera-L (216.9 M parameters, random init), 756 x 756 tiles -> 1024 x 1024 input, box + click prompts, 3 masks + scores per object, "
+                           "best mask resized to 756 x 756 and OR-ed on the device; tile_ms = one tile and one object at a time (the reference's loop), "
+                           "tiles8_ms = 8 tiles per encoder pass and a tile's 4 objects per decoder pass (what seg_infer runs)",
+               "float32": f32, "bf16": b16}
 
     # ---- configs[1] beside it: one tile at a time on the same engine (batch-1 kernels, hipGraph decode), rank 0 only
     latency = None

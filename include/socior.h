@@ -226,6 +226,25 @@ int sr_op_mask_resize_or(const float* low, int ld, int col0, int n, int m, const
 int sr_op_gather_rows(const void* in, const int32_t* rows, void* out, int n, int H, void* stream);
 int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void* out, int ldo, const void* bias,
                const void* resid, const int32_t* rowmap, int epilogue, void* stream);
+/* ---- SAM2 at the REFERENCE's precision.  The reference builds SAM2ImagePredictor(build_sam2(...)) in float32 and calls it without
+ * autocast (/root/reference/roll/models/model_providers.py:540-548, roll/distributed/strategy/seg_strategy.py:47-60): these are the
+ * float32 forms of the entry points above (same argument meaning, float32 row-major matrices [rows][ld], ld % 4 == 0, 16-byte aligned)
+ * that socioreasoner_amd/sam2.py drives when Sam2Engine(dtype=float32) -- the default behind seg_infer.
+ *   sr_op_gemm_f32      : out = act(A . W^T + bias) (+ resid) on the f32-input MFMA (exact float32 fmaf chains); epilogue 0 store, 1 residual,
+ *                         3 GELU (erf form; | 0x1000 = ReLU), 4 = 0; K % 16 == 0, N % 4 == 0.
+ *   sr_op_attention_f32 : softmax(q k^T * scale) v per work item (the struct of sr_op_attention, <= 64 queries per item; vt_off unused:
+ *                         V is ROW-major, element (key j, head h, d) = v[(k_row0 + j) * v_stride + h * head_dim + d]); head_dim 16 / 32 / 80. */
+int sr_op_gemm_f32(const float* A, int lda, const float* W, int M, int N, int K, float* out, int ldo, const float* bias, const float* resid,
+                   const int32_t* rowmap, int epilogue, void* stream);
+int sr_op_attention_f32(const float* q, int q_stride, const float* k, int k_stride, const float* v, int v_stride, float* out, int out_stride,
+                        const void* dev_work, int n_work, int n_heads, float scale, int head_dim, void* stream);
+int sr_op_sam_preprocess_f32(const uint8_t* img, int h, int w, float* out_chw, int S, void* stream);
+int sr_op_im2col_f32(const float* chw, int S, int k, int stride, int pad, float* out, int ld, const int32_t* rowmap, void* stream);
+int sr_op_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* out, int ldo, int rows, int C, float eps, void* stream);
+int sr_op_maxpool_win_f32(const float* in, int ld_in, int C, int n_win, int ws, float* out, int ld_out, void* stream);
+int sr_op_ew_f32(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int rows, int C, int mode, void* stream);
+int sr_op_upsample2x_add_f32(const float* lat, const float* top, float* out, int H2, int C, int ld, void* stream);
+int sr_op_pixel_shuffle_add_f32(const float* g, int ldg, const float* feat, int ldf, float* out, int ldo, int W, int Co, void* stream);
 /* fp8 x fp8 prefill GEMM on the block-scaled MFMA (BASELINE.json configs[4]): sr_op_quant_mx quantises bf16 activations [M][ldx] to
  * OCP-MX e4m3 (q [M][K] bytes + e8m0 scales [K/128][rows_pad][4]); sr_op_gemm_mx multiplies them with an fp8 weight image (tiled8,
  * per-output-channel float32 scale) -- out = bf16((q_x . q_w^T with block scales) * w_scale + bias), epilogues 0 / 1 / 2 / 4 as sr_op_gemm */

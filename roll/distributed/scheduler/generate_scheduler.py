@@ -68,12 +68,22 @@ class GenerateScheduler:
             return out
         return self._generate_requests(data, worker, gc, pipeline_config)
 
-    def _generate_requests(self, data: DataProto, worker, gc, pipeline_config) -> DataProto:
+    def join_idle_round(self, actor_cluster, pipeline_config) -> None:
+        """Request-level mode across ranks is COLLECTIVE: every rank must enter every round.  The pipeline shards the samples with
+        np.array_split sizes and walks its shard in batches, so ranks can own different numbers of batches (65 samples on 2 ranks at
+        batch 32: two and one); a rank that has run out of batches joins the remaining rounds with no requests of its own and serves
+        what the dispatcher hands it.  No-op below level 1 or with a single rank."""
+        import torch.distributed as dist
+        if int(pipeline_config.get("generate_opt_level") or 0) < 1 or not dist.is_initialized() or dist.get_world_size() == 1:
+            return
+        self._generate_requests(None, actor_cluster, {}, pipeline_config)
+
+    def _generate_requests(self, data, worker, gc, pipeline_config) -> DataProto:
         import time
         import torch.distributed as dist
-        B = len(data)
+        B = len(data) if data is not None else 0
         self.round += 1
-        reqs = [DataProto(batch={k: v[i:i + 1] for k, v in data.batch.items()},
+        reqs = [] if data is None else [DataProto(batch={k: v[i:i + 1] for k, v in data.batch.items()},
                           non_tensor_batch={k: v[i:i + 1] for k, v in data.non_tensor_batch.items()},
                           meta_info={"request_id": i, "generation_config": dict(gc, num_return_sequences=1)}) for i in range(B)]
         timeout = float(pipeline_config.get("rpc_timeout") or 3600)
@@ -94,6 +104,8 @@ class GenerateScheduler:
                 worker.stop_server()
             self.last_dispatch_stats = disp.stats
             self.results = {i: got[i] for i in range(B)}
+            if data is None:
+                return None
         else:
             self.results, self.expected = {}, B
             self.done.clear()

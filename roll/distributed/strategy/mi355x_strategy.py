@@ -515,13 +515,14 @@ class SegRasterStrategy(InferenceStrategy):
         for i in live:
             image, visual_prompt = images[i], prompts[i]
             self.model.set_image(image.resize((756, 756)))
-            acc = torch.zeros(756, 756, dtype=torch.uint8, device="cuda")
+            dev = getattr(getattr(self.model, "engine", None), "device", None) or torch.device("cuda", torch.cuda.current_device())
+            acc = torch.zeros(756, 756, dtype=torch.uint8, device=dev)
             for vp in visual_prompt:
                 try:
                     prompt = {k: vp[k] for k in ("point_coords", "point_labels", "box") if k in vp}
                     pred_masks, scores, _ = self.model.predict(**prompt)
                     best = np.ascontiguousarray(np.asarray(pred_masks[int(np.argmax(scores))]).astype(np.uint8))
-                    raster.mask_union_(acc, torch.from_numpy(best).cuda())
+                    raster.mask_union_(acc, torch.from_numpy(best).to(dev))
                 except Exception:  # noqa: BLE001  (the reference swallows per-object failures, seg_strategy.py:61-62)
                     continue
             masks[i] = raster.resize_nearest(acc, 768, 768).cpu().numpy()

@@ -442,6 +442,11 @@ class SocioSegInferPipeline(BasePipeline):
             all_giou.extend(giou_list)
             global_step += 1
             lap("score_and_write")
+        # request-level dispatch across ranks is collective: a rank whose shard had fewer batches than the largest shard joins the
+        # other ranks' remaining rounds (two generate calls per batch) with no requests of its own
+        most = max(-(-s_ // self.batch_size) for s_ in dp.split_sizes(self.n_samples, self.world))
+        for _ in range(2 * (most - global_step)):
+            self.generate_scheduler.join_idle_round(self.actor_infer, self.pipeline_config)
         for fut in pending:
             fut.result()                # (re-raises a failed write)
         writers.shutdown()

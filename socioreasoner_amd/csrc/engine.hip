@@ -1550,6 +1550,40 @@ int sr_op_mask_resize_or(const float* low, int ld, int col0, int n, int m, const
 int sr_op_gather_rows(const void* in, const int32_t* rows, void* out, int n, int H, void* stream) {
     SR_WRAP(launch_gather_rows((hipStream_t)stream, (const bf16_t*)in, rows, (bf16_t*)out, n, H));
 }
+// ---- SAM2 at the reference's precision (float32 storage and arithmetic: sam_f32.hip and sam.hip's float instantiations)
+int sr_op_gemm_f32(const float* A, int lda, const float* W, int M, int N, int K, float* out, int ldo, const float* bias, const float* resid,
+                   const int32_t* rowmap, int epilogue, void* stream) {
+    const int e = epilogue & 0xff;
+    if (e != EPI_STORE && e != EPI_RESID && e != EPI_GELU && e != EPI_F32) return -22;
+    GemmF32Args a{A, lda, W, M, N, K, out, ldo, bias, e == EPI_RESID ? resid : nullptr, rowmap, e == EPI_GELU ? ((epilogue & 0x1000) ? 2 : 1) : 0};
+    SR_WRAP(launch_gemm_f32((hipStream_t)stream, a));
+}
+int sr_op_attention_f32(const float* q, int q_stride, const float* k, int k_stride, const float* v, int v_stride, float* out, int out_stride,
+                        const void* dev_work, int n_work, int n_heads, float scale, int head_dim, void* stream) {
+    AttnF32Args a{q, q_stride, k, k_stride, v, v_stride, out, out_stride, (const AttnWork*)dev_work, n_work, n_heads, scale};
+    SR_WRAP(launch_attn_f32((hipStream_t)stream, a, head_dim));
+}
+int sr_op_sam_preprocess_f32(const uint8_t* img, int h, int w, float* out_chw, int S, void* stream) {
+    SR_WRAP(launch_sam_preprocess_f32((hipStream_t)stream, img, h, w, out_chw, S));
+}
+int sr_op_im2col_f32(const float* chw, int S, int k, int stride, int pad, float* out, int ld, const int32_t* rowmap, void* stream) {
+    SR_WRAP(launch_im2col_f32((hipStream_t)stream, chw, S, k, stride, pad, out, ld, rowmap));
+}
+int sr_op_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* out, int ldo, int rows, int C, float eps, void* stream) {
+    SR_WRAP(launch_layernorm_f32((hipStream_t)stream, x, ldx, w, b, out, ldo, rows, C, eps));
+}
+int sr_op_maxpool_win_f32(const float* in, int ld_in, int C, int n_win, int ws, float* out, int ld_out, void* stream) {
+    SR_WRAP(launch_maxpool_win_f32((hipStream_t)stream, in, ld_in, C, n_win, ws, out, ld_out));
+}
+int sr_op_ew_f32(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int rows, int C, int mode, void* stream) {
+    SR_WRAP(launch_ew_f32((hipStream_t)stream, a, lda, b, ldb, out, ldo, rows, C, mode));
+}
+int sr_op_upsample2x_add_f32(const float* lat, const float* top, float* out, int H2, int C, int ld, void* stream) {
+    SR_WRAP(launch_upsample2x_add_f32((hipStream_t)stream, lat, top, out, H2, C, ld));
+}
+int sr_op_pixel_shuffle_add_f32(const float* g, int ldg, const float* feat, int ldf, float* out, int ldo, int W, int Co, void* stream) {
+    SR_WRAP(launch_pixel_shuffle_add_f32((hipStream_t)stream, g, ldg, feat, ldf, out, ldo, W, Co));
+}
 int sr_op_quant_mx(const void* x, int ldx, int M, int K, void* q, void* scales, int rows_pad, void* stream) {
     SR_WRAP(launch_quant_mx_act((hipStream_t)stream, (const bf16_t*)x, ldx, M, K, (unsigned char*)q, (unsigned char*)scales, rows_pad));
 }

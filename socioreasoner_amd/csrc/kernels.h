@@ -227,6 +227,38 @@ int launch_upsample2x_add(hipStream_t s, const bf16_t* lat, const bf16_t* top, b
 int launch_pixel_shuffle_add(hipStream_t s, const bf16_t* g, int ldg, const bf16_t* feat, int ldf, bf16_t* out, int ldo, int W, int Co);
 int launch_mask_resize_or(hipStream_t s, const float* low, int ld, int col0, int n, int m, const float* score, uint8_t* acc, float* logits_out, int h, int w);
 
+// float32 storage mode of the same passes (the reference runs SAM2 in float32) + the float32 GEMM / attention of sam_f32.hip
+int launch_sam_preprocess_f32(hipStream_t s, const uint8_t* img, int h, int w, float* out_chw, int S);
+int launch_im2col_f32(hipStream_t s, const float* chw, int S, int k, int stride, int pad, float* out, int ld, const int* rowmap);
+int launch_layernorm_f32(hipStream_t s, const float* x, int ldx, const float* w, const float* b, float* out, int ldo, int rows, int C, float eps);
+int launch_maxpool_win_f32(hipStream_t s, const float* in, int ld_in, int C, int n_win, int ws, float* out, int ld_out);
+int launch_ew_f32(hipStream_t s, const float* a, int lda, const float* b, int ldb, float* out, int ldo, int rows, int C, int mode);
+int launch_upsample2x_add_f32(hipStream_t s, const float* lat, const float* top, float* out, int H2, int C, int ld);
+int launch_pixel_shuffle_add_f32(hipStream_t s, const float* g, int ldg, const float* feat, int ldf, float* out, int ldo, int W, int Co);
+// out[M][N] = act(A . W^T + bias) (+ resid), everything float32 row-major; K % 16 == 0, N / lda / ldo % 4 == 0, 16-byte aligned bases
+struct GemmF32Args {
+    const float* A; int lda;
+    const float* W;             // [N][K]
+    int M, N, K;
+    float* out; int ldo;
+    const float* bias;          // [N] or null
+    const float* resid;         // [*, ldo] indexed by DESTINATION row (may alias out) or null; added after the activation
+    const int* rowmap;          // optional destination row per source row
+    int act;                    // 0 none, 1 GELU (erf form), 2 ReLU
+};
+int launch_gemm_f32(hipStream_t s, const GemmF32Args& a);
+// float32 attention over the same work items as launch_attn_prefill (q_tile 64); V is ROW-major here ([key][head * hd + d])
+struct AttnF32Args {
+    const float* q; int q_stride;
+    const float* k; int k_stride;
+    const float* v; int v_stride;
+    float* out; int out_stride;
+    const AttnWork* work; int n_work;
+    int n_heads;
+    float scale;
+};
+int launch_attn_f32(hipStream_t s, const AttnF32Args& a, int head_dim);
+
 // ------------------------------------------------------------------ raster.hip
 int launch_mask_union(hipStream_t s, uint8_t* acc, const uint8_t* m, size_t n);
 int launch_resize_nearest_u8(hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);

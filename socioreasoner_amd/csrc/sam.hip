@@ -8,9 +8,17 @@
 
 namespace {
 
+// element access of the two storage modes: bf16 (bit patterns, one rounding per HF op boundary) and float32 (the reference's own
+// precision for SAM2: /root/reference/roll/models/model_providers.py:540-548 builds the predictor in float32, no autocast)
+__device__ __forceinline__ float ldf(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ void stf(bf16_t* p, float v) { *p = f2bf(v); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+
 // ---- predictor pre-processing: uint8 HWC [h][w][3] -> bf16 CHW [3][S][S]: /255, bilinear resize (align_corners = False, as
 // torch.nn.functional.interpolate / torchvision Resize on an upscale), (x - mean) / std
-__global__ __launch_bounds__(256) void k_sam_preprocess(const uint8_t* img, int h, int w, bf16_t* out, int S) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_sam_preprocess(const uint8_t* img, int h, int w, T* out, int S) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= S * S) return;
     const int y = i / S, x = i % S;
@@ -23,18 +31,19 @@ __global__ __launch_bounds__(256) void k_sam_preprocess(const uint8_t* img, int 
         const float p00 = img[((size_t)y0 * w + x0) * 3 + c] / 255.0f, p01 = img[((size_t)y0 * w + x1) * 3 + c] / 255.0f;
         const float p10 = img[((size_t)y1 * w + x0) * 3 + c] / 255.0f, p11 = img[((size_t)y1 * w + x1) * 3 + c] / 255.0f;
         const float top = p00 * (1.f - fx) + p01 * fx, bot = p10 * (1.f - fx) + p11 * fx;
-        out[(size_t)c * S * S + i] = f2bf((top * (1.f - fy) + bot * fy - mean[c]) / stdv[c]);
+        stf(out + (size_t)c * S * S + i, (top * (1.f - fy) + bot * fy - mean[c]) / stdv[c]);
     }
 }
 
 // ---- patch embedding as a GEMM operand: k x k / stride / pad convolution windows of a CHW image -> rows [ (ty, tx) ][ c*k*k + ky*k + kx ],
 // zero beyond the image and in the pad columns; optional destination row map (window order)
-__global__ __launch_bounds__(256) void k_im2col(const bf16_t* chw, int S, int k, int stride, int pad, int T, bf16_t* out, int ld, const int* rowmap) {
+template <typename E>
+__global__ __launch_bounds__(256) void k_im2col(const E* chw, int S, int k, int stride, int pad, int T, E* out, int ld, const int* rowmap) {
     const int tok = blockIdx.x;
     const int ty = tok / T, tx = tok % T, kk = k * k;
-    bf16_t* o = out + (size_t)(rowmap ? rowmap[tok] : tok) * ld;
+    E* o = out + (size_t)(rowmap ? rowmap[tok] : tok) * ld;
     for (int j = threadIdx.x; j < ld; j += 256) {
-        bf16_t v = 0;
+        E v = 0;
         if (j < 3 * kk) {
             const int c = j / kk, ky = (j % kk) / k, kx = j % k;
             const int y = ty * stride - pad + ky, x = tx * stride - pad + kx;
@@ -46,17 +55,18 @@ __global__ __launch_bounds__(256) void k_im2col(const bf16_t* chw, int S, int k,
 
 // ---- LayerNorm with bias over C channels of every row (float32 statistics, one rounding), pad columns [C, ld_out) written as zeros.
 // One wave per row (C <= 1152).
-__global__ __launch_bounds__(256) void k_layernorm(const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, int ldo, int rows, int C, float eps) {
+template <typename E>
+__global__ __launch_bounds__(256) void k_layernorm(const E* x, int ldx, const E* w, const E* b, E* out, int ldo, int rows, int C, float eps) {
     constexpr int MAXN = 18;                                   // 64 channels per step: C, ldo <= 1152
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
-    const bf16_t* xr = x + (size_t)row * ldx;
+    const E* xr = x + (size_t)row * ldx;
     float v[MAXN];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXN; ++i) {
         const int c = lane + i * 64;
-        v[i] = c < C ? bf2f(xr[c]) : 0.f;
+        v[i] = c < C ? ldf(xr + c) : 0.f;
         s += v[i];
     }
     const float mean = wave_sum(s) / (float)C;
@@ -67,11 +77,11 @@ __global__ __launch_bounds__(256) void k_layernorm(const bf16_t* x, int ldx, con
         q += d * d;
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-    bf16_t* o = out + (size_t)row * ldo;
+    E* o = out + (size_t)row * ldo;
 #pragma unroll
     for (int i = 0; i < MAXN; ++i) {
         const int c = lane + i * 64;
-        if (c < C) o[c] = f2bf((v[i] - mean) * rstd * bf2f(w[c]) + bf2f(b[c]));
+        if (c < C) stf(o + c, (v[i] - mean) * rstd * ldf(w + c) + ldf(b + c));
         else if (c < ldo) o[c] = 0;
     }
 }
@@ -136,28 +146,30 @@ __global__ __launch_bounds__(256) void k_layernorm_v(const bf16_t* x, int ldx, c
 }
 
 // ---- 2 x 2 max pooling of tokens that are stored window by window ([n_win][ws * ws] rows -> [n_win][(ws/2)^2] rows; hf:290-298, 337-341)
-__global__ __launch_bounds__(256) void k_maxpool_win(const bf16_t* in, int ld_in, int C, int ws, bf16_t* out, int ld_out) {
+template <typename E>
+__global__ __launch_bounds__(256) void k_maxpool_win(const E* in, int ld_in, int C, int ws, E* out, int ld_out) {
     const int h2 = ws / 2, per = h2 * h2;
     const int orow = blockIdx.x, win = orow / per, py = (orow % per) / h2, px = orow % h2;
-    const bf16_t* base = in + ((size_t)win * ws * ws + (size_t)(2 * py) * ws + 2 * px) * ld_in;
+    const E* base = in + ((size_t)win * ws * ws + (size_t)(2 * py) * ws + 2 * px) * ld_in;
     for (int c = threadIdx.x; c < C; c += 256) {
-        const float a = fmaxf(fmaxf(bf2f(base[c]), bf2f(base[ld_in + c])), fmaxf(bf2f(base[(size_t)ws * ld_in + c]), bf2f(base[(size_t)(ws + 1) * ld_in + c])));
-        out[(size_t)orow * ld_out + c] = f2bf(a);
+        const float a = fmaxf(fmaxf(ldf(base + c), ldf(base + ld_in + c)), fmaxf(ldf(base + (size_t)ws * ld_in + c), ldf(base + (size_t)(ws + 1) * ld_in + c)));
+        stf(out + (size_t)orow * ld_out + c, a);
     }
 }
 
 // ---- elementwise, row-major [rows][ld] with C live columns: mode 0 out = a + b, 1 out = a + vec (row vector), 2 relu(a), 3 gelu(a) (erf form)
-__global__ __launch_bounds__(256) void k_ew(const bf16_t* a, int lda, const bf16_t* b, int ldb, bf16_t* out, int ldo, int rows, int C, int mode) {
+template <typename E>
+__global__ __launch_bounds__(256) void k_ew(const E* a, int lda, const E* b, int ldb, E* out, int ldo, int rows, int C, int mode) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= (long long)rows * C) return;
     const int r = (int)(i / C), c = (int)(i % C);
-    const float x = bf2f(a[(size_t)r * lda + c]);
+    const float x = ldf(a + (size_t)r * lda + c);
     float y;
-    if (mode == 0) y = x + bf2f(b[(size_t)r * ldb + c]);
-    else if (mode == 1) y = x + bf2f(b[c]);
+    if (mode == 0) y = x + ldf(b + (size_t)r * ldb + c);
+    else if (mode == 1) y = x + ldf(b + c);
     else if (mode == 2) y = fmaxf(x, 0.f);
     else y = gelu_f(x);
-    out[(size_t)r * ldo + c] = f2bf(y);
+    stf(out + (size_t)r * ldo + c, y);
 }
 
 // ---- bf16 matrix transpose: out[c][r] = in[r][c]  (rows x cols), 32 x 32 tiles through LDS
@@ -207,22 +219,24 @@ __global__ __launch_bounds__(256) void k_transpose_v(const bf16_t* in, int ld_in
 }
 
 // ---- FPN top-down step: out[y][x] = bf16(lat[y][x] + top[y/2][x/2])  (nearest 2 x upsampling, hf:246-256)
-__global__ __launch_bounds__(256) void k_upsample2x_add(const bf16_t* lat, const bf16_t* top, bf16_t* out, int H2, int C, int ld) {
+template <typename E>
+__global__ __launch_bounds__(256) void k_upsample2x_add(const E* lat, const E* top, E* out, int H2, int C, int ld) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= (long long)H2 * H2 * C) return;
     const int c = (int)(i % C), t = (int)(i / C), y = t / H2, x = t % H2;
-    out[(size_t)t * ld + c] = f2bf(bf2f(lat[(size_t)t * ld + c]) + bf2f(top[((size_t)(y / 2) * (H2 / 2) + x / 2) * ld + c]));
+    stf(out + (size_t)t * ld + c, ldf(lat + (size_t)t * ld + c) + ldf(top + ((size_t)(y / 2) * (H2 / 2) + x / 2) * ld + c));
 }
 
 // ---- transposed 2 x 2 / stride 2 convolution, second half: the GEMM wrote [H*W][co*4 + dy*2 + dx]; scatter to [(2y+dy)*(2W) + 2x+dx][co]
 // and add the high-resolution feature (hf:1215-1221): out = bf16(conv + feat)
-__global__ __launch_bounds__(256) void k_pixel_shuffle_add(const bf16_t* g, int ldg, const bf16_t* feat, int ldf, bf16_t* out, int ldo, int W, int Co) {
+template <typename E>
+__global__ __launch_bounds__(256) void k_pixel_shuffle_add(const E* g, int ldg, const E* feat, int ldfe, E* out, int ldo, int W, int Co) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     const long long total = 4ll * W * W * Co;
     if (i >= total) return;
     const int co = (int)(i % Co), t = (int)(i / Co), Y = t / (2 * W), X = t % (2 * W);
     const int y = Y >> 1, dy = Y & 1, x = X >> 1, dx = X & 1;
-    out[(size_t)t * ldo + co] = f2bf(bf2f(g[((size_t)y * W + x) * ldg + co * 4 + dy * 2 + dx]) + bf2f(feat[(size_t)t * ldf + co]));
+    stf(out + (size_t)t * ldo + co, ldf(g + ((size_t)y * W + x) * ldg + co * 4 + dy * 2 + dx) + ldf(feat + (size_t)t * ldfe + co));
 }
 
 // ---- predictor post-processing (one launch per object): bilinear resize (align_corners = False) of the BEST of n low-resolution mask
@@ -254,13 +268,48 @@ __global__ __launch_bounds__(256) void k_mask_resize_or(const float* low, int ld
 #define LAUNCH_OK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; return 0; } while (0)
 
 int launch_sam_preprocess(hipStream_t s, const uint8_t* img, int h, int w, bf16_t* out, int S) {
-    hipLaunchKernelGGL(k_sam_preprocess, dim3(cdiv(S * S, 256)), dim3(256), 0, s, img, h, w, out, S);
+    hipLaunchKernelGGL(k_sam_preprocess<bf16_t>, dim3(cdiv(S * S, 256)), dim3(256), 0, s, img, h, w, out, S);
     LAUNCH_OK();
 }
 int launch_im2col(hipStream_t s, const bf16_t* chw, int S, int k, int stride, int pad, bf16_t* out, int ld, const int* rowmap) {
     const int T = (S + 2 * pad - k) / stride + 1;
     if (ld < 3 * k * k) return -22;
-    hipLaunchKernelGGL(k_im2col, dim3(T * T), dim3(256), 0, s, chw, S, k, stride, pad, T, out, ld, rowmap);
+    hipLaunchKernelGGL(k_im2col<bf16_t>, dim3(T * T), dim3(256), 0, s, chw, S, k, stride, pad, T, out, ld, rowmap);
+    LAUNCH_OK();
+}
+// ---- the float32 storage mode of the same passes (sam_f32.hip holds its GEMM and attention)
+int launch_sam_preprocess_f32(hipStream_t s, const uint8_t* img, int h, int w, float* out, int S) {
+    hipLaunchKernelGGL(k_sam_preprocess<float>, dim3(cdiv(S * S, 256)), dim3(256), 0, s, img, h, w, out, S);
+    LAUNCH_OK();
+}
+int launch_im2col_f32(hipStream_t s, const float* chw, int S, int k, int stride, int pad, float* out, int ld, const int* rowmap) {
+    const int T = (S + 2 * pad - k) / stride + 1;
+    if (ld < 3 * k * k) return -22;
+    hipLaunchKernelGGL(k_im2col<float>, dim3(T * T), dim3(256), 0, s, chw, S, k, stride, pad, T, out, ld, rowmap);
+    LAUNCH_OK();
+}
+int launch_layernorm_f32(hipStream_t s, const float* x, int ldx, const float* w, const float* b, float* out, int ldo, int rows, int C, float eps) {
+    if (rows <= 0) return 0;
+    if (C > 1152 || ldo > 1152) return -22;
+    hipLaunchKernelGGL(k_layernorm<float>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, w, b, out, ldo, rows, C, eps);
+    LAUNCH_OK();
+}
+int launch_maxpool_win_f32(hipStream_t s, const float* in, int ld_in, int C, int n_win, int ws, float* out, int ld_out) {
+    if (ws % 2) return -22;
+    hipLaunchKernelGGL(k_maxpool_win<float>, dim3(n_win * (ws / 2) * (ws / 2)), dim3(256), 0, s, in, ld_in, C, ws, out, ld_out);
+    LAUNCH_OK();
+}
+int launch_ew_f32(hipStream_t s, const float* a, int lda, const float* b, int ldb, float* out, int ldo, int rows, int C, int mode) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(k_ew<float>, dim3((unsigned)(((long long)rows * C + 255) / 256)), dim3(256), 0, s, a, lda, b, ldb, out, ldo, rows, C, mode);
+    LAUNCH_OK();
+}
+int launch_upsample2x_add_f32(hipStream_t s, const float* lat, const float* top, float* out, int H2, int C, int ld) {
+    hipLaunchKernelGGL(k_upsample2x_add<float>, dim3((unsigned)(((long long)H2 * H2 * C + 255) / 256)), dim3(256), 0, s, lat, top, out, H2, C, ld);
+    LAUNCH_OK();
+}
+int launch_pixel_shuffle_add_f32(hipStream_t s, const float* g, int ldg, const float* feat, int ldf, float* out, int ldo, int W, int Co) {
+    hipLaunchKernelGGL(k_pixel_shuffle_add<float>, dim3((unsigned)((4ll * W * W * Co + 255) / 256)), dim3(256), 0, s, g, ldg, feat, ldf, out, ldo, W, Co);
     LAUNCH_OK();
 }
 int launch_layernorm(hipStream_t s, const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, int ldo, int rows, int C, float eps) {
@@ -275,17 +324,17 @@ int launch_layernorm(hipStream_t s, const bf16_t* x, int ldx, const bf16_t* w, c
         else hipLaunchKernelGGL((k_layernorm_v<64, 3>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, w, b, out, ldo, rows, C, eps);
         LAUNCH_OK();
     }
-    hipLaunchKernelGGL(k_layernorm, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, w, b, out, ldo, rows, C, eps);
+    hipLaunchKernelGGL(k_layernorm<bf16_t>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, w, b, out, ldo, rows, C, eps);
     LAUNCH_OK();
 }
 int launch_maxpool_win(hipStream_t s, const bf16_t* in, int ld_in, int C, int n_win, int ws, bf16_t* out, int ld_out) {
     if (ws % 2) return -22;
-    hipLaunchKernelGGL(k_maxpool_win, dim3(n_win * (ws / 2) * (ws / 2)), dim3(256), 0, s, in, ld_in, C, ws, out, ld_out);
+    hipLaunchKernelGGL(k_maxpool_win<bf16_t>, dim3(n_win * (ws / 2) * (ws / 2)), dim3(256), 0, s, in, ld_in, C, ws, out, ld_out);
     LAUNCH_OK();
 }
 int launch_ew(hipStream_t s, const bf16_t* a, int lda, const bf16_t* b, int ldb, bf16_t* out, int ldo, int rows, int C, int mode) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(k_ew, dim3((unsigned)(((long long)rows * C + 255) / 256)), dim3(256), 0, s, a, lda, b, ldb, out, ldo, rows, C, mode);
+    hipLaunchKernelGGL(k_ew<bf16_t>, dim3((unsigned)(((long long)rows * C + 255) / 256)), dim3(256), 0, s, a, lda, b, ldb, out, ldo, rows, C, mode);
     LAUNCH_OK();
 }
 int launch_transpose(hipStream_t s, const bf16_t* in, int ld_in, int rows, int cols, bf16_t* out, int ld_out) {
@@ -297,11 +346,11 @@ int launch_transpose(hipStream_t s, const bf16_t* in, int ld_in, int rows, int c
     LAUNCH_OK();
 }
 int launch_upsample2x_add(hipStream_t s, const bf16_t* lat, const bf16_t* top, bf16_t* out, int H2, int C, int ld) {
-    hipLaunchKernelGGL(k_upsample2x_add, dim3((unsigned)(((long long)H2 * H2 * C + 255) / 256)), dim3(256), 0, s, lat, top, out, H2, C, ld);
+    hipLaunchKernelGGL(k_upsample2x_add<bf16_t>, dim3((unsigned)(((long long)H2 * H2 * C + 255) / 256)), dim3(256), 0, s, lat, top, out, H2, C, ld);
     LAUNCH_OK();
 }
 int launch_pixel_shuffle_add(hipStream_t s, const bf16_t* g, int ldg, const bf16_t* feat, int ldf, bf16_t* out, int ldo, int W, int Co) {
-    hipLaunchKernelGGL(k_pixel_shuffle_add, dim3((unsigned)((4ll * W * W * Co + 255) / 256)), dim3(256), 0, s, g, ldg, feat, ldf, out, ldo, W, Co);
+    hipLaunchKernelGGL(k_pixel_shuffle_add<bf16_t>, dim3((unsigned)((4ll * W * W * Co + 255) / 256)), dim3(256), 0, s, g, ldg, feat, ldf, out, ldo, W, Co);
     LAUNCH_OK();
 }
 int launch_mask_resize_or(hipStream_t s, const float* low, int ld, int col0, int n, int m, const float* score, uint8_t* acc, float* logits_out, int h, int w) {

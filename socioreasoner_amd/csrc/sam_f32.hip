@@ -1,0 +1,247 @@
+// SAM2 at the REFERENCE's precision: float32 storage, float32 MFMA.
+//
+// The reference builds its segmenter as SAM2ImagePredictor(build_sam2(cfg, ckpt)) and calls set_image / predict without autocast
+// (/root/reference/roll/models/model_providers.py:540-548, roll/distributed/strategy/seg_strategy.py:47-60; the YAML's `dtype: bf16`,
+// examples/infer/rlvr_megatron.yaml:112, is never applied): every Linear, attention and normalisation of Hiera-L and of the mask decoder
+// runs in float32 there, and north_star asks for EXACT decoded mask pixels.  The bf16 kernels (gemm*.hip, attention.hip) cannot give
+// that (1 000-1 500 of 571 536 pixels differ: profiles/r03_sam2_parity.json); these two kernels are the float32 mode of
+// socioreasoner_amd/sam2.py (Sam2Engine(dtype=torch.float32)), the passes in between are sam.hip's templates instantiated for float.
+//
+// gfx950 has no xf32 / tf32 path: f32-input MFMA (v_mfma_f32_32x32x2_f32, v_mfma_f32_16x16x4_f32) runs at the float32 VECTOR rate,
+// 157 TF/s = 1/16 of the bf16 rate (MI355X_MICROARCH.md "Matrix cores"), each product and sum an exact float32 fmaf chain -- the
+// arithmetic torch's CPU float32 path performs, up to the order of the sums.
+#include "kernels.h"
+#include <math.h>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ GEMM
+// out[M][N] = act(A[M][K] . W[N][K]^T + bias) (+ resid), all float32, row-major, K % 16 == 0, N % 4 == 0.
+// 128 x 128 x 16 tiles, 4 waves (2 x 2), each wave 64 x 64 as 2 x 2 v_mfma_f32_32x32x2_f32.  The MFMA is issued as D = W_frag x A_frag,
+// so a lane owns 4 CONSECUTIVE output columns of one row (16-byte epilogue accesses).  LDS holds both operands k-major ([k][row], pitch
+// 132: fragment reads are one conflict-free ds_read_b32 per operand and k-step); tiles are staged global -> registers -> LDS, the loads
+// of k-tile i + 1 in flight under the MFMAs of k-tile i (32 MFMAs x 64 cycles per wave and k-tile: the matrix pipe is the bound, LDS
+// at ~25 % of its cycles).
+constexpr int GB = 128, GK = 16, GP = GB + 4;
+
+__global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmF32Args p, int n_tiles_n) {
+    __shared__ float As[2][GK][GP];
+    __shared__ float Ws[2][GK][GP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / n_tiles_n) * GB, n0 = (tile % n_tiles_n) * GB;      // neighbouring blocks share the A rows; W (small) stays in L2
+    const int lr = tid >> 2, lc = (tid & 3) * 4;                                // staging: rows lr, lr + 64; k = lc .. lc + 3
+    const float* arow[2];
+    const float* wrow[2];
+    bool aok[2], wok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int gm = m0 + lr + 64 * j, gn = n0 + lr + 64 * j;
+        aok[j] = gm < p.M;
+        wok[j] = gn < p.N;
+        arow[j] = p.A + (size_t)(aok[j] ? gm : 0) * p.lda + lc;
+        wrow[j] = p.W + (size_t)(wok[j] ? gn : 0) * p.K + lc;
+    }
+    float4 ra[2], rw[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ra[j] = aok[j] ? *reinterpret_cast<const float4*>(arow[j] + k0) : float4{0.f, 0.f, 0.f, 0.f};
+            rw[j] = wok[j] ? *reinterpret_cast<const float4*>(wrow[j] + k0) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = lr + 64 * j;
+            As[b][lc + 0][r] = ra[j].x; As[b][lc + 1][r] = ra[j].y; As[b][lc + 2][r] = ra[j].z; As[b][lc + 3][r] = ra[j].w;
+            Ws[b][lc + 0][r] = rw[j].x; Ws[b][lc + 1][r] = rw[j].y; Ws[b][lc + 2][r] = rw[j].z; Ws[b][lc + 3][r] = rw[j].w;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.f;
+    const int nk = p.K / GK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int kg = lane >> 5, col = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * GK);
+#pragma unroll
+        for (int s = 0; s < GK / 2; ++s) {
+            const int kk = 2 * s + kg;
+            float wf[2], af[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[j] = Ws[cur][kk][wn * 64 + j * 32 + col];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = As[cur][kk][wm * 64 + i * 32 + col];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    // epilogue: D[n][m], lane (kg, col): m = col, n = 8 * (v / 4) + 4 * kg + v % 4
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + col;
+        if (m >= p.M) continue;
+        const size_t orow = (size_t)(p.rowmap ? p.rowmap[m] : m) * p.ldo;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * kg;
+                if (n >= p.N) continue;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[j][i][4 * q + e];
+                    if (p.bias) x += p.bias[n + e];
+                    if (p.act == 1) x = gelu_f(x);
+                    else if (p.act == 2) x = fmaxf(x, 0.f);
+                    o[e] = x;
+                }
+                if (p.resid) {
+                    const float4 r = *reinterpret_cast<const float4*>(p.resid + orow + n);
+                    o[0] = r.x + o[0]; o[1] = r.y + o[1]; o[2] = r.z + o[2]; o[3] = r.w + o[3];
+                }
+                *reinterpret_cast<float4*>(p.out + orow + n) = float4{o[0], o[1], o[2], o[3]};
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+// softmax(q k^T * scale) v per work item (AttnWork, kernels.h: one tile of <= 64 queries of one sequence / window), float32 throughout,
+// online softmax over 64-key tiles.  One block = 4 waves x 16 queries of ONE head.  Everything is computed transposed, as in
+// attention.hip: S^T = K . Q^T (v_mfma_f32_16x16x4_f32: A = K rows from LDS, B = Q^T held in registers for the whole pass), whose
+// accumulator layout -- lane (g, c) holds keys 4 g .. 4 g + 3 of query c -- IS the B operand of O^T += V^T . P^T for the key
+// permutation the V^T fragment reads follow, so P never moves between lanes.  K rows have pitch HD + 2 and V rows HD + 4 floats: both
+// fragment reads are conflict-free ds_read_b32.
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_f32(AttnF32Args p) {
+    constexpr int PK = HD + 2, PV = HD + 4, NS = HD / 4, ND = HD / 16;
+    __shared__ __attribute__((aligned(16))) float Ks[64 * PK];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * PV];
+    const AttnWork w = p.work[blockIdx.x];
+    const int h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int nq = min(64, (w.q_len ? w.q_len : w.seq_len) - w.q_off);
+    const int qi = wave * 16 + c;                                   // this lane's query inside the tile
+    const bool qok = qi < nq;
+    float qreg[NS];
+    {
+        const float* qp = p.q + (size_t)(w.q_row0 + (qok ? qi : 0)) * p.q_stride + h * HD + g;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qreg[s] = qok ? qp[4 * s] : 0.f;
+    }
+    f32x4 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun = -INFINITY, lrun = 0.f;
+    const float* kbase = p.k + (size_t)w.k_row0 * p.k_stride + h * HD;
+    const float* vbase = p.v + (size_t)w.k_row0 * p.v_stride + h * HD;
+    for (int j0 = 0; j0 < w.seq_len; j0 += 64) {
+        __syncthreads();                                            // the previous tile's fragment reads are done
+        for (int e = tid; e < 64 * (HD / 4); e += 256) {
+            const int r = e / (HD / 4), d4 = (e % (HD / 4)) * 4;
+            float4 kv = float4{0.f, 0.f, 0.f, 0.f}, vv = kv;
+            if (j0 + r < w.seq_len) {
+                kv = *reinterpret_cast<const float4*>(kbase + (size_t)(j0 + r) * p.k_stride + d4);
+                vv = *reinterpret_cast<const float4*>(vbase + (size_t)(j0 + r) * p.v_stride + d4);
+            }
+            float2* kd = reinterpret_cast<float2*>(Ks + r * PK + d4);          // (pitch HD + 2: rows are 8-byte aligned)
+            kd[0] = float2{kv.x, kv.y};
+            kd[1] = float2{kv.z, kv.w};
+            *reinterpret_cast<float4*>(Vs + r * PV + d4) = vv;
+        }
+        __syncthreads();
+        // S^T tile t: keys 16 t + 4 g + v (v = 0..3) of query c
+        f32x4 sc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* kr = Ks + c * PK + g;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)            // four independent accumulator chains: the 40-cycle dependent latency of the 16x16x4 form stays hidden
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[16 * t * PK + 4 * s], qreg[s], sc[t], 0, 0, 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const bool live = j0 + 16 * t + 4 * g + v < w.seq_len;
+                sc[t][v] = live ? sc[t][v] * p.scale : -INFINITY;
+                mx = fmaxf(mx, sc[t][v]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);                         // finite: key j0 of every tile is live
+        const float alpha = expf(mrun - mnew);                      // (exp(-inf) = 0 on the first tile)
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                sc[t][v] = expf(sc[t][v] - mnew);
+                ps += sc[t][v];
+            }
+        lrun = lrun * alpha + ps;
+        mrun = mnew;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
+        }
+        // O^T[d][q] += sum_key V[key][d] P[key][q]: A = V^T fragment (row d = 16 dt + c, k = g -> key 16 t + 4 g + v), B = P^T (this lane's sc[t][v])
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float* vr = Vs + (16 * t + 4 * g + v) * PV + c;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[16 * d], sc[t][v], o[d], 0, 0, 0);
+            }
+    }
+    lrun += __shfl_xor(lrun, 16, 64);
+    lrun += __shfl_xor(lrun, 32, 64);
+    if (!qok) return;
+    const float inv = 1.0f / lrun;
+    float* op = p.out + (size_t)(w.q_row0 + qi) * p.out_stride + h * HD + 4 * g;       // O^T accumulator: d = 16 dt + 4 g + v, query c
+#pragma unroll
+    for (int d = 0; d < ND; ++d) *reinterpret_cast<float4*>(op + 16 * d) = float4{o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv};
+}
+
+}  // namespace
+
+int launch_gemm_f32(hipStream_t s, const GemmF32Args& a) {
+    if (a.M <= 0 || a.N <= 0) return 0;
+    if (a.K % GK || a.N % 4 || a.ldo % 4 || a.lda % 4 || (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.out | (uintptr_t)a.resid) & 15)) return -22;
+    const int tn = cdiv(a.N, GB), tm = cdiv(a.M, GB);
+    hipLaunchKernelGGL(k_gemm_f32, dim3((unsigned)tn * (unsigned)tm), dim3(256), 0, s, a, tn);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_attn_f32(hipStream_t s, const AttnF32Args& a, int head_dim) {
+    if (a.n_work <= 0) return 0;
+    if ((a.q_stride | a.k_stride | a.v_stride | a.out_stride) % 4 || (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.out) & 15)) return -22;
+    const dim3 grid(a.n_work, a.n_heads);
+    switch (head_dim) {
+        case 16: hipLaunchKernelGGL(k_attn_f32<16>, grid, dim3(256), 0, s, a); break;
+        case 32: hipLaunchKernelGGL(k_attn_f32<32>, grid, dim3(256), 0, s, a); break;
+        case 80: hipLaunchKernelGGL(k_attn_f32<80>, grid, dim3(256), 0, s, a); break;
+        default: return -22;
+    }
+    SR_CHECK_LAUNCH();
+    return 0;
+}

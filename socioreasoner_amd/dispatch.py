@@ -78,11 +78,32 @@ class CrossRankDispatcher:
         connection, and a get that waits for a key inside the client would keep the dispatcher thread of the same process from
         ever writing it."""
         deadline = time.monotonic() + self.timeout_s
+        polls = 0
         while not self.store.check([key]):
+            polls += 1
             if self.errors or time.monotonic() > deadline:
                 raise TimeoutError(f"rank {self.rank}: key {key!r} never appeared")
+            if polls % 64 == 0 and self.aborted():
+                raise RuntimeError(f"rank {self.rank}: another rank aborted the dispatch round while waiting for {key!r}")
             time.sleep(self.poll_s)
         return self.store.get(key)
+
+    def aborted(self) -> bool:
+        """any rank's failure path sets 'abort': the others stop waiting instead of running into the round's timeout"""
+        return bool(self.store.check(["abort"]))
+
+    def _abort(self) -> None:
+        try:
+            self._set("abort", 1)
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _drop(self, key: str) -> None:
+        """a consumed key leaves the store (rank 0's TCPStore would otherwise keep every pickled request of the run)"""
+        try:
+            self.store.delete_key(key)
+        except Exception:  # noqa: BLE001  (stores without delete support: the key simply stays)
+            pass
 
     def _get_int(self, key: str) -> int:
         return int(self._wait(key).decode())
@@ -113,12 +134,7 @@ class CrossRankDispatcher:
             self.stats["sent_to"] = sent
         except BaseException as e:  # noqa: BLE001
             self.errors.append(e)
-            for r in range(self.world):                       # do not leave the mailboxes waiting
-                try:
-                    self._set(f"mbox/{r}/{10 ** 9}", -1)
-                    self._set("abort", 1)
-                except Exception:  # noqa: BLE001
-                    pass
+            self._abort()                                     # every rank's polling loops check it
 
     # ------------------------------------------------------------------ every rank
     def run(self, requests: List, add_request: Callable, make_result_sink: Callable[[Callable], None], make_request: Callable,
@@ -168,6 +184,7 @@ class CrossRankDispatcher:
                         self.stats["shipped_out"] += 1
             except BaseException as e:  # noqa: BLE001
                 self.errors.append(e)
+                self._abort()
 
         def mailbox():           # worker duty: feed the local engine
             try:
@@ -180,12 +197,14 @@ class CrossRankDispatcher:
                         req = requests[gid - off]
                     else:
                         d = pickle.loads(self._wait(f"payload/{gid}"))
+                        self._drop(f"payload/{gid}")
                         req = make_request(d["batch"], d["non_tensor_batch"], d["meta_info"])
                     req.meta_info[request_id_key] = gid
                     add_request(req)
                     k += 1
             except BaseException as e:  # noqa: BLE001
                 self.errors.append(e)
+                self._abort()
 
         threads += [threading.Thread(target=publish, daemon=True), threading.Thread(target=mailbox, daemon=True)]
         for t in threads:
@@ -193,11 +212,20 @@ class CrossRankDispatcher:
         # own results: generated here (callback) or on another rank (store)
         deadline = time.monotonic() + self.timeout_s
         remote_pending = None
+        ticks = 0
         while True:
+            ticks += 1
             if self.errors:
+                self._abort()
                 raise RuntimeError("cross-rank dispatch failed") from self.errors[0]
+            if ticks % 8 == 0 and self.aborted():
+                raise RuntimeError(f"rank {self.rank}: another rank aborted the dispatch round")
             if alive_check is not None:
-                alive_check()
+                try:
+                    alive_check()
+                except BaseException:
+                    self._abort()
+                    raise
             if remote_pending is None and (n_local == 0 or self.store.check([f"assign/{off + i}" for i in range(n_local)])):
                 # which of my requests run elsewhere is known once they are all assigned
                 remote_pending = [i for i in range(n_local) if self._get_int(f"assign/{off + i}") != self.rank]
@@ -206,6 +234,7 @@ class CrossRankDispatcher:
                 for i in remote_pending:
                     if self.store.check([f"result/{off + i}"]):
                         toks = pickle.loads(self.store.get(f"result/{off + i}"))
+                        self._drop(f"result/{off + i}")
                         with lock:
                             results[i] = toks
                             if len(results) == n_local:
@@ -221,9 +250,16 @@ class CrossRankDispatcher:
         total = sum(sizes)
         while sum(self._counter(f"done/{r}") for r in range(self.world)) < total:
             if self.errors:
+                self._abort()
                 raise RuntimeError("cross-rank dispatch failed") from self.errors[0]
+            if self.aborted():
+                raise RuntimeError(f"rank {self.rank}: another rank aborted the dispatch round")
             if alive_check is not None:
-                alive_check()
+                try:
+                    alive_check()
+                except BaseException:
+                    self._abort()
+                    raise
             if time.monotonic() > deadline:
                 raise TimeoutError("cross-rank dispatch: not every request was reported done")
             time.sleep(self.poll_s)

@@ -83,6 +83,15 @@ SIGNATURES = {
     "sr_op_pixel_shuffle_add": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "sr_op_mask_resize_or": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "sr_op_gather_rows": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
+    "sr_op_gemm_f32": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "sr_op_attention_f32": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, C.c_float, _i, _vp]),
+    "sr_op_sam_preprocess_f32": (C.c_int, [_vp, _i, _i, _vp, _i, _vp]),
+    "sr_op_im2col_f32": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "sr_op_layernorm_f32": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, C.c_float, _vp]),
+    "sr_op_maxpool_win_f32": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "sr_op_ew_f32": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "sr_op_upsample2x_add_f32": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sr_op_pixel_shuffle_add_f32": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "sr_op_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i, _i, C.c_float, _vp]),
     "sr_op_resid_rmsnorm": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, C.c_float, _vp]),
     "sr_op_argmax": (C.c_int, [_vp, _i, _i, _vp, _vp]),

@@ -21,8 +21,12 @@ decoder), the passes in between are the coalesced kernels of csrc/sam.hip.  Layo
   image order through their row map;
 * the prompt encoder (a dozen 256-vectors) runs on the host in float32.
 
-bf16 storage / float32 accumulation like the LM path; the reference runs SAM2 in float32 -- tests hold this module to the distance
-HF-bf16 itself has from HF-float32 and to exact masks wherever |logit| clears that band."""
+Two storage modes.  ``dtype=torch.float32`` (the DEFAULT behind seg_infer) is the reference's own precision -- it builds the predictor
+in float32 and calls it without autocast (model_providers.py:540-548; the YAML's ``dtype: bf16`` is never applied there): float32 token
+matrices, the f32-input MFMA GEMM and the float32 attention of csrc/sam_f32.hip, sam.hip's passes instantiated for float; tests hold its
+756 x 756 masks to HF-float32's EXACTLY (outside |logit| < 1e-3).  ``dtype=torch.bfloat16`` is the fast mode (bf16 storage / float32
+accumulation like the LM path, ~3x the throughput): held to the distance HF-bf16 itself has from HF-float32 and to exact masks wherever
+|logit| clears that band."""
 from __future__ import annotations
 
 import ctypes as C
@@ -93,12 +97,16 @@ def window_order(G: int, ws: int) -> np.ndarray:
 
 
 class Sam2Engine:
-    def __init__(self, geometry: Optional[Sam2Geometry] = None, device="cuda:0"):
+    def __init__(self, geometry: Optional[Sam2Geometry] = None, device="cuda:0", dtype=torch.bfloat16):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.SocioRError("no GPU visible: the product path has no CPU fallback")
         self.g = geometry or Sam2Geometry()
         self.device = torch.device(device)
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("Sam2Engine dtype must be torch.float32 (the reference's precision) or torch.bfloat16")
+        self.dt, self.f32 = dtype, dtype == torch.float32
+        self._fn = lambda name: getattr(self.lib, name + ("_f32" if self.f32 else ""))
         g = self.g
         if g.image_size % 64:
             raise ValueError("image_size must be a multiple of 64")
@@ -127,8 +135,9 @@ class Sam2Engine:
         if rc != 0:
             raise L.SocioRError(f"{what} failed with {rc}")
 
-    def buf(self, name, rows, cols, dtype=torch.bfloat16):
+    def buf(self, name, rows, cols, dtype=None):
         """zero-initialised once; pad columns are never written afterwards"""
+        dtype = dtype or self.dt
         t = self._bufs.get(name)
         if t is None or t.shape != (rows, cols) or t.dtype != dtype:
             t = self._bufs[name] = torch.zeros(rows, cols, dtype=dtype, device=self.device)
@@ -138,15 +147,15 @@ class Sam2Engine:
         w = self.W[Wn + ".weight"]
         N, K = w.shape
         b = self.W.get(Wn + ".bias") if bias else None
-        self._ck(self.lib.sr_op_gemm(self._p(A, a_off), lda, self._p(w), M, N, K, self._p(out, out_off), ldo, self._p(b), self._p(resid, out_off if resid is out else 0),
-                                     self._p(rowmap), epi, self._s()), f"gemm {Wn}")
+        self._ck(self._fn("sr_op_gemm")(self._p(A, a_off), lda, self._p(w), M, N, K, self._p(out, out_off), ldo, self._p(b), self._p(resid, out_off if resid is out else 0),
+                                        self._p(rowmap), epi, self._s()), f"gemm {Wn}")
 
     def layernorm(self, x, ldx, name, out, ldo, rows, Cc, eps):
-        self._ck(self.lib.sr_op_layernorm(self._p(x), ldx, self._p(self.W[name + ".weight"]), self._p(self.W[name + ".bias"]), self._p(out), ldo, rows, Cc,
+        self._ck(self._fn("sr_op_layernorm")(self._p(x), ldx, self._p(self.W[name + ".weight"]), self._p(self.W[name + ".bias"]), self._p(out), ldo, rows, Cc,
                                           C.c_float(eps), self._s()), "layernorm")
 
     def ew(self, a, lda, b, ldb, out, ldo, rows, Cc, mode):
-        self._ck(self.lib.sr_op_ew(self._p(a), lda, self._p(b), ldb, self._p(out), ldo, rows, Cc, mode, self._s()), "ew")
+        self._ck(self._fn("sr_op_ew")(self._p(a), lda, self._p(b), ldb, self._p(out), ldo, rows, Cc, mode, self._s()), "ew")
 
     def work(self, key, items) -> tuple:
         w = self._work.get(key)
@@ -158,8 +167,14 @@ class Sam2Engine:
             w = self._work[key] = (t, len(items))
         return w
 
-    def attention(self, q, q_stride, k, k_off, k_stride, hdp, vt, vt_stride, out, out_stride, work, heads, scale, q_tile=64, v2_ok=0):
+    def attention(self, q, q_stride, k, k_off, k_stride, hdp, vt, vt_stride, out, out_stride, work, heads, scale, q_tile=64, v2_ok=0, v=None, v_off=0, v_stride=0):
+        """bf16: V arrives transposed (``vt``); float32: V is read row-major where the projection left it (``v`` + ``v_off``, stride ``v_stride``)"""
         wt, n = work
+        if self.f32:
+            assert q_tile <= 64 and v is not None
+            self._ck(self.lib.sr_op_attention_f32(self._p(q), q_stride, self._p(k, k_off), k_stride, self._p(v, v_off), v_stride, self._p(out), out_stride,
+                                                  self._p(wt), n, heads, C.c_float(scale), hdp, self._s()), "attention_f32")
+            return
         self._ck(self.lib.sr_op_attention(self._p(q), q_stride, self._p(k, k_off), k_stride, hdp, self._p(vt), vt_stride, hdp * vt_stride, self._p(out), out_stride,
                                           self._p(wt), n, heads, 1, C.c_float(scale), 0, hdp, q_tile, v2_ok, self._s()), "attention")
 
@@ -176,15 +191,15 @@ class Sam2Engine:
             Np = n_pad or N
             out = torch.zeros(Np, rup(K), dtype=torch.float32)
             out[:N, :K] = w2d
-            self.W[name + ".weight"] = out.to(torch.bfloat16).to(dev).contiguous()
+            self.W[name + ".weight"] = out.to(self.dt).to(dev).contiguous()
             if bias is not None:
                 bb = torch.zeros(Np, dtype=torch.float32)
                 bb[:N] = bias
-                self.W[name + ".bias"] = bb.to(torch.bfloat16).to(dev)
+                self.W[name + ".bias"] = bb.to(self.dt).to(dev)
 
         def put_ln(name):
-            self.W[name + ".weight"] = f(name + ".weight").to(torch.bfloat16).to(dev)
-            self.W[name + ".bias"] = f(name + ".bias").to(torch.bfloat16).to(dev)
+            self.W[name + ".weight"] = f(name + ".weight").to(self.dt).to(dev)
+            self.W[name + ".bias"] = f(name + ".bias").to(self.dt).to(dev)
 
         pe = "vision_encoder.backbone."
         put(pe + "patch_embed.projection", f(pe + "patch_embed.projection.weight").reshape(g.embed_dims[0], -1), f(pe + "patch_embed.projection.bias"))
@@ -193,8 +208,8 @@ class Sam2Engine:
         G0 = self.grid[0]
         pos = torch.nn.functional.interpolate(f(pe + "pos_embed"), size=(G0, G0), mode="bicubic")
         win = f(pe + "pos_embed_window")
-        pos = (pos.to(torch.bfloat16) + win.to(torch.bfloat16).tile(1, 1, G0 // win.shape[2], G0 // win.shape[3]))[0].permute(1, 2, 0).reshape(G0 * G0, -1)
-        tab = torch.zeros(G0 * G0, rup(g.embed_dims[0]), dtype=torch.bfloat16)
+        pos = (pos.to(self.dt) + win.to(self.dt).tile(1, 1, G0 // win.shape[2], G0 // win.shape[3]))[0].permute(1, 2, 0).reshape(G0 * G0, -1)
+        tab = torch.zeros(G0 * G0, rup(g.embed_dims[0]), dtype=self.dt)
         order0 = torch.from_numpy(window_order(G0, g.windows[0]).astype(np.int64))
         tab[order0, : g.embed_dims[0]] = pos
         self.W["pos_table"] = tab.to(dev)
@@ -226,8 +241,8 @@ class Sam2Engine:
             n = f"vision_encoder.neck.convs.{j}"
             put(n, f(n + ".weight").reshape(g.fpn_dim, -1), f(n + ".bias"))
         Cd = g.fpn_dim
-        self.W["no_mem"] = f("no_memory_embedding").reshape(-1).to(torch.bfloat16).to(dev)
-        self.W["no_mask"] = f("prompt_encoder.no_mask_embed.weight").reshape(-1).to(torch.bfloat16).to(dev)
+        self.W["no_mem"] = f("no_memory_embedding").reshape(-1).to(self.dt).to(dev)
+        self.W["no_mask"] = f("prompt_encoder.no_mask_embed.weight").reshape(-1).to(self.dt).to(dev)
         put("mask_decoder.conv_s0", f("mask_decoder.conv_s0.weight").reshape(Cd // 8, Cd), f("mask_decoder.conv_s0.bias"))
         put("mask_decoder.conv_s1", f("mask_decoder.conv_s1.weight").reshape(Cd // 4, Cd), f("mask_decoder.conv_s1.bias"))
         md = "mask_decoder.transformer."
@@ -265,7 +280,7 @@ class Sam2Engine:
         m = g.image_size // 16
         ax = (torch.arange(m, dtype=torch.float32) + 0.5) / m
         yy, xx = torch.meshgrid(ax, ax, indexing="ij")
-        self.W["image_pe"] = self._fourier(torch.stack([xx, yy], dim=-1).reshape(-1, 2)).to(torch.bfloat16).to(dev).contiguous()
+        self.W["image_pe"] = self._fourier(torch.stack([xx, yy], dim=-1).reshape(-1, 2)).to(self.dt).to(dev).contiguous()
         torch.cuda.synchronize(self.device)
 
     def _fourier(self, coords01) -> torch.Tensor:
@@ -314,8 +329,8 @@ class Sam2Engine:
             assert im.dtype == torch.uint8 and im.is_cuda and im.dim() == 3 and im.shape[2] == 3
             im = im.contiguous()
             self.orig_hws.append((int(im.shape[0]), int(im.shape[1])))
-            self._ck(lib.sr_op_sam_preprocess(self._p(im), int(im.shape[0]), int(im.shape[1]), self._p(chw, b * 3 * S * S), S, s()), "preprocess")
-            self._ck(lib.sr_op_im2col(self._p(chw, b * 3 * S * S), S, 7, 4, 3, self._p(col, b * N0 * kp), kp, self._p(order0), s()), "im2col")
+            self._ck(self._fn("sr_op_sam_preprocess")(self._p(im), int(im.shape[0]), int(im.shape[1]), self._p(chw, b * 3 * S * S), S, s()), "preprocess")
+            self._ck(self._fn("sr_op_im2col")(self._p(chw, b * 3 * S * S), S, 7, 4, 3, self._p(col, b * N0 * kp), kp, self._p(order0), s()), "im2col")
         pos = self.W.get("pos_table" + tag)
         if pos is None:
             pos = self.W["pos_table" + tag] = self.W["pos_table"].repeat(B, 1).contiguous()
@@ -338,20 +353,23 @@ class Sam2Engine:
             qkv = self.buf(f"qkv{s_}{sfx}", N, 3 * HP)
             self.gemm(xn, rup(din), name + ".attn.qkv", N, qkv, 3 * HP)
             vts = rup(N) + 64
-            vt = self.buf(f"vt{s_}{sfx}", HP, vts)
-            self._ck(lib.sr_op_transpose(self._p(qkv, 2 * HP), 3 * HP, N, HP, self._p(vt), vts, s()), "transpose")
+            vt = None
+            vkw = dict(v=qkv, v_off=2 * HP, v_stride=3 * HP)          # float32: V is read where the qkv GEMM left it
+            if not self.f32:
+                vt = self.buf(f"vt{s_}{sfx}", HP, vts)
+                self._ck(lib.sr_op_transpose(self._p(qkv, 2 * HP), 3 * HP, N, HP, self._p(vt), vts, s()), "transpose")
             if pooled:
                 assert win > 0 and win == cur_ws, "stage-entry blocks pool inside the previous stage's windows"
                 Nq, nw = N // 4, N // (win * win)
                 xnew = self.buf(f"x{s_}{tag}", Nq, rup(dout))
                 rfull = self.buf(f"rfull{s_}{tag}", N, rup(dout))
                 self.gemm(xn, rup(din), name + ".proj", N, rfull, rup(dout))
-                self._ck(lib.sr_op_maxpool_win(self._p(rfull), rup(dout), dout, nw, win, self._p(xnew), rup(dout), s()), "maxpool")
+                self._ck(self._fn("sr_op_maxpool_win")(self._p(rfull), rup(dout), dout, nw, win, self._p(xnew), rup(dout), s()), "maxpool")
                 qp = self.buf(f"qp{s_}{tag}", Nq, HP)
-                self._ck(lib.sr_op_maxpool_win(self._p(qkv), 3 * HP, HP, nw, win, self._p(qp), HP, s()), "maxpool q")
+                self._ck(self._fn("sr_op_maxpool_win")(self._p(qkv), 3 * HP, HP, nw, win, self._p(qp), HP, s()), "maxpool q")
                 att = self.buf(f"att{s_}{tag}", Nq, rup(HP))
                 wk = self.work(("pool", s_, B), self._window_work(nw, win * win, win * win // 4))
-                self.attention(qp, HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale)
+                self.attention(qp, HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale, **vkw)
                 x, N, Ni, cur_ws = xnew, Nq, Ni // 4, win // 2
                 self.gemm(att, rup(HP), name + ".attn.proj", N, x, rup(dout), EPI_RESID, resid=x)
             else:
@@ -359,20 +377,20 @@ class Sam2Engine:
                 if win > 0:
                     assert win == cur_ws
                     # windows of >= 128 tokens (stage 3: 16 x 16) go to the 8-wave kernel: 128 queries share each LDS-DMA-staged K / V^T tile
-                    v2 = hdp == 80 and (win * win) % 128 == 0 and os.environ.get("SR_SAM_WIN_V2", "1") != "0"
+                    v2 = hdp == 80 and (win * win) % 128 == 0 and os.environ.get("SR_SAM_WIN_V2", "1") != "0" and not self.f32
                     tile = 128 if v2 else 64
                     wk = self.work(("win", s_, B, tile), self._window_work(N // (win * win), win * win, win * win, tile=tile))
-                    self.attention(qkv, 3 * HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale, q_tile=tile, v2_ok=1 if v2 else 0)
+                    self.attention(qkv, 3 * HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale, q_tile=tile, v2_ok=1 if v2 else 0, **vkw)
                 else:           # global attention inside every image: token order does not matter
-                    v2 = hdp == 80 and Ni % 8 == 0
+                    v2 = hdp == 80 and Ni % 8 == 0 and not self.f32
                     tile = 128 if v2 else 64
                     wk = self.work(("glob", s_, tile, B), [(b * Ni + q0, Ni, q0, b * Ni, b * Ni, 0) for b in range(B) for q0 in range(0, Ni, tile)])
-                    self.attention(qkv, 3 * HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale, q_tile=tile, v2_ok=1 if v2 else 0)
+                    self.attention(qkv, 3 * HP, qkv, HP, 3 * HP, hdp, vt, vts, att, rup(HP), wk, heads, scale, q_tile=tile, v2_ok=1 if v2 else 0, **vkw)
                 self.gemm(att, rup(HP), name + ".attn.proj", N, x, rup(dout), EPI_RESID, resid=x)
             xn2 = self.buf(f"xn{s_}{tag}", N, rup(dout))
             self.layernorm(x, rup(dout), name + ".layer_norm2", xn2, rup(dout), N, dout, g.ln_eps)
             hid = self.buf(f"hid{s_}{tag}", N, 4 * dout)
-            self.gemm(xn2, rup(dout), name + ".mlp.proj_in", N, hid, 4 * dout, EPI_GELU | GELU_FAST)
+            self.gemm(xn2, rup(dout), name + ".mlp.proj_in", N, hid, 4 * dout, EPI_GELU | (0 if self.f32 else GELU_FAST))
             self.gemm(hid, 4 * dout, name + ".mlp.proj_out", N, x, rup(dout), EPI_RESID, resid=x)
             if pooled and cur_ws != g.windows[s_]:
                 # the pooled tokens sit in window order of size cur_ws; the stage's own windows are g.windows[s_]: one row gather
@@ -382,7 +400,8 @@ class Sam2Engine:
                 src[b_] = a_                               # row b_[i] of the new order takes row a_[i] of the old one
                 src = np.concatenate([src + k * Gs * Gs for k in range(B)])
                 x2 = self.buf(f"x{s_}g{tag}", N, rup(dout))
-                self._ck(lib.sr_op_gather_rows(self._p(x), self._p(self._index(f"regather{s_}{tag}", src)), self._p(x2), N, rup(dout), s()), "gather")
+                # (a row copy: the float32 mode passes its rows as twice as many 2-byte elements)
+                self._ck(lib.sr_op_gather_rows(self._p(x), self._p(self._index(f"regather{s_}{tag}", src)), self._p(x2), N, rup(dout) * (2 if self.f32 else 1), s()), "gather")
                 x, cur_ws = x2, g.windows[s_]
             if i in ends:
                 stage_out.append((x, cur_ws))
@@ -402,7 +421,7 @@ class Sam2Engine:
         if 2 in g.top_down_levels:
             fpn2 = self.buf("fpn2" + tag, B * m2, Cd)
             for b in range(B):
-                self._ck(lib.sr_op_upsample2x_add(self._p(lat[2], b * m2 * Cd), self._p(lat[3], b * n3 * Cd), self._p(fpn2, b * m2 * Cd), self.grid[2], Cd, Cd, s()), "upsample")
+                self._ck(self._fn("sr_op_upsample2x_add")(self._p(lat[2], b * m2 * Cd), self._p(lat[3], b * n3 * Cd), self._p(fpn2, b * m2 * Cd), self.grid[2], Cd, Cd, s()), "upsample")
         emb = self.buf("emb" + tag, B * m2, Cd)
         self.ew(fpn2, Cd, self.W["no_mem"], 0, emb, Cd, B * m2, Cd, 1)                      # + no-memory embedding (hf:1499-1500)
         keys0 = self.buf("keys0" + tag, B * m2, Cd)
@@ -470,8 +489,10 @@ class Sam2Engine:
         self.gemm(k, Cd, name + ".k_proj", nk, kp, internal)
         self.gemm(v, Cd, name + ".v_proj", nk, vp, internal)
         vts = rup(nk) + 64
-        vt = self.buf(f"d_vt_{tag}", internal, vts)
-        self._ck(self.lib.sr_op_transpose(self._p(vp), internal, nk, internal, self._p(vt), vts, self._s()), "transpose")
+        vt = None
+        if not self.f32:
+            vt = self.buf(f"d_vt_{tag}", internal, vts)
+            self._ck(self.lib.sr_op_transpose(self._p(vp), internal, nk, internal, self._p(vt), vts, self._s()), "transpose")
         o = self.buf(f"d_o_{tag}", max(nq, 16), internal)
         items = []
         for ob, T in enumerate(Ts):
@@ -479,8 +500,8 @@ class Sam2Engine:
             items += [(ob * sq + q0, lk, q0, ob * sk, ob * sk, lq if lq != lk else 0) for q0 in range(0, lq, 64)]
         wk = self.work(("dec", q_side, k_side, Ts, TOK), items)
         # token -> image: <= 16 queries against m2 keys per object and head -- the kernel whose waves split the keys (q_tile = 16 says so)
-        few = q_side == "tok" and k_side == "img" and hd == 16 and max(Ts) <= 16 and _FEWQ
-        self.attention(qp, internal, kp, 0, internal, hd, vt, vts, o, internal, wk, g.dec_heads, hd ** -0.5, q_tile=16 if few else 64)
+        few = q_side == "tok" and k_side == "img" and hd == 16 and max(Ts) <= 16 and _FEWQ and not self.f32
+        self.attention(qp, internal, kp, 0, internal, hd, vt, vts, o, internal, wk, g.dec_heads, hd ** -0.5, q_tile=16 if few else 64, v=vp, v_off=0, v_stride=internal)
         self.gemm(o, internal, name + ".o_proj", nq, out, Cd, EPI_RESID if resid is not None else EPI_STORE, resid=resid)
 
     def decode(self, coords: np.ndarray, labels: np.ndarray):
@@ -503,18 +524,18 @@ class Sam2Engine:
             try:
                 tok = self.buf("d_tok_long", self.TOK, Cd)
                 tok.zero_()
-                tok[:Ts[0]].copy_(toks[0].to(torch.bfloat16))
+                tok[:Ts[0]].copy_(toks[0].to(self.dt))
                 return self._decode_launches(Ts, tok)
             finally:
                 self.TOK = keep
         tok = self.buf(f"d_tok{NB}", NB * TOK, Cd)
-        host = torch.zeros(NB * TOK, Cd, dtype=torch.bfloat16)
+        host = torch.zeros(NB * TOK, Cd, dtype=self.dt)
         for ob, t in enumerate(toks):
-            host[ob * TOK:ob * TOK + Ts[ob]] = t.to(torch.bfloat16)
+            host[ob * TOK:ob * TOK + Ts[ob]] = t.to(self.dt)
         # pageable -> device in pieces of 16 KB (two objects): larger pageable copies wait for the stream to drain (the host then sits behind
         # the previous pass, 0.8 ms per call from three objects on); pinned staging buffers were measured too and cost MORE host time here
         # (0.5 ms per call for one object, 2 ms for four)
-        step = 2 * TOK
+        step = (1 if self.f32 else 2) * TOK
         for r0 in range(0, NB * TOK, step):
             tok[r0:r0 + step].copy_(host[r0:r0 + step], non_blocking=True)
         # ~110 launches of a few microseconds each: issued one by one the host is the bottleneck (0.8 ms per call).  The launch sequence
@@ -578,14 +599,14 @@ class Sam2Engine:
         self.gemm(keys, Cd, "mask_decoder.upscale_conv1", NI, g1, Cd)
         u1 = self.buf(f"d_u1{sfx}", NB * n1, Cd // 4)
         for ob in range(NB):
-            self._ck(lib.sr_op_pixel_shuffle_add(self._p(g1, ob * m2 * Cd), Cd, self._p(self.f1), Cd // 4, self._p(u1, ob * n1 * (Cd // 4)), Cd // 4, G2, Cd // 4, self._s()), "shuffle1")
+            self._ck(self._fn("sr_op_pixel_shuffle_add")(self._p(g1, ob * m2 * Cd), Cd, self._p(self.f1), Cd // 4, self._p(u1, ob * n1 * (Cd // 4)), Cd // 4, G2, Cd // 4, self._s()), "shuffle1")
         self.layernorm(u1, Cd // 4, "mask_decoder.upscale_layer_norm", u1, Cd // 4, NB * n1, Cd // 4, 1e-6)
         self.ew(u1, Cd // 4, None, 0, u1, Cd // 4, NB * n1, Cd // 4, 3)
         g2 = self.buf(f"d_g2{sfx}", NB * n1, Cd // 2)
         self.gemm(u1, Cd // 4, "mask_decoder.upscale_conv2", NB * n1, g2, Cd // 2)
         u2 = self.buf(f"d_u2{sfx}", NB * n0, 64)                                 # Cd / 8 live channels, padded to one k-tile
         for ob in range(NB):
-            self._ck(lib.sr_op_pixel_shuffle_add(self._p(g2, ob * n1 * (Cd // 2)), Cd // 2, self._p(self.f0), Cd // 8, self._p(u2, ob * n0 * 64), 64, G1, Cd // 8, self._s()), "shuffle2")
+            self._ck(self._fn("sr_op_pixel_shuffle_add")(self._p(g2, ob * n1 * (Cd // 2)), Cd // 2, self._p(self.f0), Cd // 8, self._p(u2, ob * n0 * 64), 64, G1, Cd // 8, self._s()), "shuffle2")
         self.ew(u2, 64, None, 0, u2, 64, NB * n0, Cd // 8, 3)
         # ---- hypernetwork MLPs of the mask tokens, IoU head (hf:1223-1236): token t of every object = rows t, t + TOK, ... (lda = TOK * Cd)
         hyp = self.buf(f"d_hyp{sfx}", NB * 16, 64)                               # object o's 4 filters = rows 16 o .. 16 o + 3
@@ -597,7 +618,7 @@ class Sam2Engine:
             self.gemm(h2, Cd, n + ".proj_out", NB, hyp, 16 * 64, out_off=i * 64)
         low = self.buf(f"d_low{sfx}", NB * n0, 16, torch.float32)
         for ob in range(NB):
-            self._ck(lib.sr_op_gemm(self._p(u2, ob * n0 * 64), 64, self._p(hyp, ob * 16 * 64), n0, 16, 64, self._p(low, ob * n0 * 16), 16, None, None, None, EPI_F32, self._s()), "mask gemm")
+            self._ck(self._fn("sr_op_gemm")(self._p(u2, ob * n0 * 64), 64, self._p(hyp, ob * 16 * 64), n0, 16, 64, self._p(low, ob * n0 * 16), 16, None, None, None, EPI_F32, self._s()), "mask gemm")
         n = "mask_decoder.iou_prediction_head"
         self.gemm(q, TOK * Cd, n + ".proj_in", NB, h1, Cd, EPI_GELU | RELU, a_off=1 * Cd)
         self.gemm(h1, Cd, n + ".layers.0", NB, h2, Cd, EPI_GELU | RELU)

@@ -1,0 +1,340 @@
+"""Round 4 GPU tests.
+
+1. SAM2 at the REFERENCE's precision (float32: /root/reference/roll/models/model_providers.py:540-548 builds the predictor without a dtype,
+   roll/distributed/strategy/seg_strategy.py:47-60 calls it without autocast): the float32 mode of socioreasoner_amd.sam2 (csrc/sam_f32.hip)
+   against HF ``Sam2Model``'s float32 run (tests/golden/sam2.npz) -- every stage to float32 round-off, and the 756 x 756 masks EXACT
+   outside |logit| < 1e-3.  The two float32 kernels are also checked op by op against float64 torch.
+2. BASELINE.json configs[4] AS NAMED: fp8 weights on the block-scaled fp8 MFMA (lm_weight_dtype 2, MX activations) on an 896 x 896
+   tile (4096 patches, S = 1216) at full depth, next to HF's float32 / bf16 runs of that tile (tests/golden/hf_truth3b.npz).
+3. `python bench.py --gpus N` launches its own N ranks and refuses a node with fewer GPUs.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import bits_to_f32
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EPI_STORE, EPI_RESID, EPI_GELU, EPI_F32, RELU = 0, 1, 3, 4, 0x1000
+
+
+@pytest.fixture(scope="module")
+def L():
+    from socioreasoner_amd import lib
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return lib.load()
+
+
+def sp():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def P(t, off=0):
+    return C.c_void_p(t.data_ptr() + off * t.element_size()) if t is not None else None
+
+
+def record(fname, name, payload):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, fname)
+    cur = json.load(open(path)) if os.path.exists(path) else {}
+    cur[name] = payload
+    json.dump(cur, open(path, "w"), indent=1)
+
+
+# ------------------------------------------------------------------------------------------------ float32 kernels, op by op
+@pytest.mark.parametrize("M,N,K,epi,rowmap", [(300, 144, 192, EPI_STORE, False), (1000, 480, 160, EPI_RESID, False), (257, 576, 576, EPI_GELU, False),
+                                              (64, 2048, 256, EPI_GELU | RELU, False), (5, 16, 256, EPI_F32, False), (4096, 256, 1152, EPI_STORE, True),
+                                              (130, 132, 64, EPI_RESID, True)])
+def test_gemm_f32_vs_float64(L, M, N, K, epi, rowmap):
+    """sr_op_gemm_f32 (v_mfma_f32_32x32x2_f32 tiles) against float64: every epilogue, ragged M / N tiles, destination row map, operands
+    with leading dimensions wider than K.  The MFMA is an exact float32 fmaf chain: the error is float32 round-off of a K-term sum."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    lda, ldo = K + 16, N + 8
+    A = torch.randn(M, lda, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    rm = torch.randperm(M, generator=g).to(torch.int32) if rowmap else None
+    base = torch.randn(M, ldo, generator=g)
+    out = base.clone().cuda()
+    resid = out if (epi & 0xff) == EPI_RESID else None
+    rc = L.sr_op_gemm_f32(P(A.cuda()), lda, P(W.cuda()), M, N, K, P(out), ldo, P(bias.cuda()), P(resid), P(rm.cuda()) if rowmap else None, epi, sp())
+    assert rc == 0
+    y = A[:, :K].double() @ W.double().t() + bias.double()
+    if (epi & 0xff) == EPI_GELU:
+        y = torch.relu(y) if epi & RELU else torch.nn.functional.gelu(y)
+    want = base.clone().double()
+    dst = rm.long() if rowmap else torch.arange(M)
+    want[dst, :N] = (want[dst, :N] if (epi & 0xff) == EPI_RESID else 0) + y
+    got = out.cpu().double()
+    assert torch.equal(got[:, N:], base[:, N:].double())                     # columns beyond N are not touched
+    err = float((got - want).abs().max())
+    assert err <= 2e-6 * K ** 0.5 + 1e-6, err
+
+
+@pytest.mark.parametrize("hd,n_heads,seq,n_q", [(80, 2, 64, 64), (80, 3, 256, 256), (80, 2, 4096, 128), (32, 8, 7, 7), (16, 8, 4096, 9), (80, 4, 64, 16),
+                                                (32, 2, 100, 100), (16, 4, 16, 16)])
+def test_attention_f32_vs_float64(L, hd, n_heads, seq, n_q):
+    """sr_op_attention_f32 (online softmax over 64-key tiles on v_mfma_f32_16x16x4_f32) against float64: whole windows, the 4096-key global
+    blocks, ragged key counts, fewer queries than keys (Hiera's pooled queries; the decoder's token -> image attention), two work items per
+    sequence and two sequences per launch."""
+    from socioreasoner_amd.sam2 import _WORK
+    g = torch.Generator().manual_seed(hd * 1000 + seq)
+    HP = n_heads * hd
+    n_seq = 2
+    qkv = torch.randn(n_seq * seq, 3 * HP, generator=g)
+    qkv[:, :HP] *= 2.0
+    qrows = torch.randn(n_seq * n_q, HP, generator=g) * 2.0 if n_q != seq else None
+    items = []
+    for s_ in range(n_seq):
+        for q0 in range(0, n_q, 64):
+            items.append((s_ * n_q + q0, seq, q0, s_ * seq, 0, n_q if n_q != seq else 0, 0))
+    arr = np.zeros(len(items), dtype=_WORK)
+    for i, it in enumerate(items):
+        arr[i] = it
+    work = torch.from_numpy(arr.view(np.uint8).copy()).cuda()
+    d_qkv = qkv.cuda()
+    d_q = qrows.cuda() if qrows is not None else d_qkv
+    q_stride = HP if qrows is not None else 3 * HP
+    out = torch.full((n_seq * n_q, HP), 7.0, device="cuda")
+    scale = hd ** -0.5
+    rc = L.sr_op_attention_f32(P(d_q), q_stride, P(d_qkv, HP), 3 * HP, P(d_qkv, 2 * HP), 3 * HP, P(out), HP, P(work), len(items), n_heads, C.c_float(scale), hd, sp())
+    assert rc == 0
+    got = out.cpu().double()
+    for s_ in range(n_seq):
+        kv = qkv[s_ * seq:(s_ + 1) * seq].double()
+        q = (qrows[s_ * n_q:(s_ + 1) * n_q] if qrows is not None else kv[:, :HP]).double()
+        k, v = kv[:, HP:2 * HP], kv[:, 2 * HP:]
+        for h in range(n_heads):
+            sl = slice(h * hd, (h + 1) * hd)
+            p = torch.softmax(q[:, sl] @ k[:, sl].t() * scale, dim=-1)
+            want = p @ v[:, sl]
+            err = float((got[s_ * n_q:(s_ + 1) * n_q, sl] - want).abs().max())
+            assert err <= 1e-5, (s_, h, err)
+
+
+# ------------------------------------------------------------------------------------------------ SAM2, float32 mode vs HF float32
+def _engine_f32(tag):
+    from oracle import sam2_ref as S
+    from socioreasoner_amd import sam2
+    og = S.geometry_tiny() if tag == "tiny" else S.geometry_large()
+    g = sam2.Sam2Geometry(**{k: getattr(og, k) for k in sam2.Sam2Geometry.__dataclass_fields__})
+    e = sam2.Sam2Engine(g, dtype=torch.float32)
+    e.load_state_dict(S.synthetic_weights(og))
+    return e, og
+
+
+@pytest.mark.parametrize("tag", ["tiny", "large"])
+def test_sam2_float32_mode_equals_hf_float32(golden_dir, tag):
+    """The reference's precision: every stage output, the decoder's features, the low-resolution logits and the predicted IoUs against HF
+    float32 to float32 round-off (TOL), and the 756 x 756 mask of every prompt EXACT wherever HF's resized logit is further than 1e-3 from
+    the threshold; inside that band (~180 of 571 536 pixels at Hiera-L) two float32 implementations may legitimately differ: at most 10 do."""
+    from oracle import sam2_ref as S
+    from socioreasoner_amd import sam2, synthetic
+    g = np.load(os.path.join(golden_dir, "sam2.npz"))
+    e, og = _engine_f32(tag)
+    hw, st = int(g[f"{tag}_hw"][0]), int(g[f"stride_{tag}"][0])
+    img = synthetic.tile_pixels(int(g[f"{tag}_img_seed"][0]), hw, hw)
+    e.set_image(torch.from_numpy(img).cuda())
+    torch.cuda.synchronize()
+    res, fails = {}, []
+
+    def err(a, b):
+        d = (torch.as_tensor(a).double().flatten() - torch.as_tensor(b).double().flatten())
+        return float(d.abs().max()), float(d.pow(2).mean().sqrt()), float(torch.as_tensor(b).double().abs().max())
+
+    def check(ok, what):            # every number is recorded before the first failure is raised (one GPU run tells the whole story)
+        if not ok:
+            fails.append(what)
+    for i, (x, ws) in enumerate(e.stage_out):
+        G, Cc = e.grid[i], og.embed_dims[i]
+        assert x.dtype == torch.float32
+        perm = torch.from_numpy(sam2.window_order(G, ws).astype(np.int64)).cuda()
+        mx, rms, amax = err(x[perm][:, :Cc].cpu().flatten()[::st], g[f"{tag}_stage{i}_f32"])
+        res[f"stage{i}"] = {"max": mx, "rms": rms, "ref_absmax": amax}
+        check(mx <= 2e-4 * max(amax, 1.0), (f"stage{i}", res[f"stage{i}"]))
+    for i, (x, Cc) in enumerate(((e.f0, og.fpn_dim // 8), (e.f1, og.fpn_dim // 4), (e.emb, og.fpn_dim))):
+        mx, rms, amax = err(x[:, :Cc].cpu().flatten()[::st], g[f"{tag}_feat{i}_f32"])
+        res[f"feat{i}"] = {"max": mx, "rms": rms, "ref_absmax": amax}
+        check(mx <= 2e-4 * max(amax, 1.0), (f"feat{i}", res[f"feat{i}"]))
+    for p in range(3):
+        box = g[f"{tag}_p{p}_box"].tolist() or None
+        pts = g[f"{tag}_p{p}_pts"]
+        logits, scores, low = e.predict(pts if len(pts) else None, g[f"{tag}_p{p}_labels"] if len(pts) else None, box, return_logits=True)
+        ref_low, ref_iou = g[f"{tag}_p{p}_low"], g[f"{tag}_p{p}_iou"]
+        mx, rms, amax = err(low, ref_low)
+        best = int(np.argmax(ref_iou))
+        _, _, up = S.postprocess(torch.from_numpy(ref_low), torch.from_numpy(ref_iou), (hw, hw))
+        clear = up[best].abs() >= 1e-3
+        mine = torch.from_numpy(logits[best] > 0)
+        want = torch.from_numpy(np.unpackbits(g[f"{tag}_p{p}_mask_bits"])[: hw * hw].reshape(hw, hw).astype(bool))
+        n_band, n_diff = int((~clear).sum()), int((mine != want).sum())
+        acc = torch.zeros(hw, hw, dtype=torch.uint8, device="cuda")
+        e.predict_or(acc, pts if len(pts) else None, g[f"{tag}_p{p}_labels"] if len(pts) else None, box)
+        res[f"p{p}"] = {"low_logits_max_err": mx, "low_logits_rms_err": rms, "low_logits_absmax": amax, "iou_max_err": float(np.abs(scores - ref_iou).max()),
+                        "mask_pixels": int(hw * hw), "mask_pixels_differing_from_hf_float32": n_diff, "pixels_with_abs_logit_below_1e-3": n_band,
+                        "resized_logits_max_err": float((torch.from_numpy(logits[best]).double() - up[best].double()).abs().max())}
+        check(mx <= 1e-3, (p, "low-resolution logits", mx))                 # float32 logits of |x| up to ~18 through 48 blocks + decoder
+        check(np.abs(scores - ref_iou).max() <= 1e-4, (p, "iou", scores.tolist(), ref_iou.tolist()))
+        check(int(np.argmax(scores)) == best, (p, "best mask"))
+        check(bool((mine == want)[clear].all()), (p, "mask differs outside the 1e-3 band", n_diff))
+        check(n_diff <= 10, (p, "more than 10 pixels differ inside the band", n_diff, n_band))   # (HF float32 itself has ~180 of 571 536 pixels inside it)
+        check(torch.equal(acc.cpu().bool(), mine), (p, "predict_or != predict"))
+    res["dtype"] = "float32"
+    record("sam2_parity_r04.json", tag, res)
+    print(tag, json.dumps(res))
+    assert not fails, fails
+
+
+def test_sam2_float32_batched_encoder_and_object_batches_are_bit_identical():
+    """Batching in the float32 mode: tokens of B images stacked along the rows, several objects per decoder pass and the replayed
+    launch graph give the bits of the one-image / one-object calls (rows never interact in any float32 kernel)."""
+    from socioreasoner_amd import synthetic
+    e, og = _engine_f32("tiny")
+    hw = 189
+    imgs = [torch.from_numpy(synthetic.tile_pixels(40 + i, hw, hw)).cuda() for i in range(3)]
+    single = []
+    for im in imgs:
+        e.set_image(im)
+        single.append(e.features())
+    e.set_images(imgs)
+    for b in range(3):
+        e.select(b)
+        ft = e.features()
+        for k in ("emb", "keys0", "f0", "f1"):
+            assert torch.equal(ft[k], single[b][k]), (b, k)
+    prompts = [dict(box=[20 + 3 * i, 30, 120 + 4 * i, 150]) if i % 2 == 0 else dict(box=[10, 15 + 2 * i, 90 + i, 140], point_coords=[[50 + i, 60]], point_labels=[1])
+               for i in range(5)]
+    one = torch.zeros(hw, hw, dtype=torch.uint8, device="cuda")
+    lows = []
+    for pr in prompts:
+        low, iou = e.predict_or(one, **pr)
+        lows.append((low.clone(), iou.clone()))
+    many = torch.zeros(hw, hw, dtype=torch.uint8, device="cuda")
+    e.predict_or_many(many, prompts)
+    e.predict_or_many(many, prompts)                       # (second call: graph replay)
+    assert torch.equal(one, many) and int(one.sum()) > 0
+
+
+def test_seg_infer_provider_defaults_to_the_reference_precision(monkeypatch):
+    """roll.models.model_providers.sam2_seg_model_provider: float32 unless sam2_compute_dtype / SR_SAM2_DTYPE opts into bf16 (the reference
+    ignores the YAML's `dtype: bf16`); a path that is neither synthetic:* nor a directory raises unless SR_ALLOW_SYNTHETIC_WEIGHTS=1."""
+    from roll.models.model_providers import sam2_seg_model_provider
+    monkeypatch.delenv("SR_SAM2_DTYPE", raising=False)
+    monkeypatch.delenv("SR_ALLOW_SYNTHETIC_WEIGHTS", raising=False)
+    p = sam2_seg_model_provider(model_args={"model_name_or_path": "synthetic:sam2-tiny", "dtype": "bf16"})
+    assert p.engine.dt == torch.float32
+    p = sam2_seg_model_provider(model_args={"model_name_or_path": "synthetic:sam2-tiny", "sam2_compute_dtype": "bf16"})
+    assert p.engine.dt == torch.bfloat16
+    with pytest.raises(FileNotFoundError):
+        sam2_seg_model_provider(model_args={"model_name_or_path": "facebook/sam2-hiera-lrage"})
+
+
+# ------------------------------------------------------------------------------------------------ configs[4] as named
+def test_full_size_config5_fp8_mx_896_tile(golden_dir):
+    """BASELINE.json configs[4] = "fp8 weights (CDNA4 fp8 MFMA), 896 x 896": lm_weight_dtype 2 (prefill linears on
+    v_mfma_scale_f32_16x16x128_f8f6f4 with OCP-MX activations, decode W8A16) on the 896 x 896 tile of tests/golden/hf_truth3b.npz
+    (4096 patches, S = 1216), FULL depth.  There is no reference implementation of an fp8 mode (the reference ships bf16), so this
+    test pins what can be pinned: the vision tower is bit-identical to the bf16 engine's; graph == eager; the last-position logits
+    and 15 teacher-forced decode steps are measured against HF's float32 run of the same tile and recorded as multiples of HF-bf16's
+    own distance (bounded loosely: a broken scale / operand layout at K = 11008, M = 1216 shows as 10-100 x), unbiased; the MX
+    quantiser of this shape (M = 1216 rows, K = 11008) is bit-exact against the oracle's definition."""
+    from oracle import model_ref as MR
+    from socioreasoner_amd import lib as LIB
+    from socioreasoner_amd import synthetic
+    from socioreasoner_amd.config import geometry_3b
+    from socioreasoner_amd.engine import Engine
+    g = np.load(os.path.join(golden_dir, "hf_truth3b.npz"))
+    tag = "tile896"
+    G, stride, ps, ls = int(g["g_new"][0]), int(g["stride"][0]), int(g["pool_stride"][0]), int(g["last_f32_stride"][0])
+    geom = geometry_3b()
+    tiles, hw = g[f"{tag}_tiles"].tolist(), int(g[f"{tag}_hw"][0])
+    assert hw == 896
+    grid = (1, hw // 14, hw // 14)
+    ids, pos3 = g[f"{tag}_ids"], g[f"{tag}_pos3"]
+    S, N = len(ids), len(tiles) * grid[1] * grid[2]
+    assert S == 1216 and N == 4096
+    hf_tokens = g[f"{tag}_tokens"].tolist()
+    forced = torch.tensor([hf_tokens], dtype=torch.int32)
+    out = {}
+    for name, fp8 in (("bf16", False), ("mx", "mx")):
+        e = Engine(geom, max_patches=N, max_prefill_tokens=(S + 63) // 64 * 64, max_batch=1, max_ctx=(S + G + 64) // 64 * 64, max_new_tokens=G, lm_fp8=fp8)
+        e.load_synthetic_weights(seed=0)
+        pix = torch.cat([e.patchify(torch.from_numpy(synthetic.tile_pixels(i, hw, hw)).cuda()) for i in tiles], dim=0)
+        emb = e.vit_forward(pix, [grid] * len(tiles))
+        logits = e.prefill([ids], [pos3], emb, return_logits=True)[0].cpu().clone()
+        _, trace = e.decode(G, trace=True, forced=forced, use_graph=False)
+        trace = trace[:, 0].cpu().clone()
+        graph = eager = None
+        if name == "mx":
+            e.prefill([ids], [pos3], emb)
+            eager = e.decode(8, use_graph=False).cpu().clone()
+            e.prefill([ids], [pos3], emb)
+            graph = e.decode(8, use_graph=True).cpu().clone()
+        out[name] = (emb.float().cpu().flatten()[::ps].clone(), logits, trace, eager, graph)
+        e.close()
+    assert torch.equal(out["bf16"][0], out["mx"][0])                        # the ViT never sees the LM's weight format
+    assert torch.equal(out["mx"][3], out["mx"][4])                          # graph == eager
+
+    def err(a, b):
+        d = (a.float() - b.float()).flatten()
+        return {"max": float(d.abs().max()), "rms": float(d.pow(2).mean().sqrt()), "bias": float(d.mean())}
+    l16, l32 = bits_to_f32(g[f"{tag}_logits_last"]), torch.from_numpy(g[f"{tag}_logits_last_f32"])
+    ref = err(l16[::ls], l32)
+    e_bf, e_q = err(out["bf16"][1][::ls], l32), err(out["mx"][1][::ls], l32)
+    res = {"prefill_logits": {"hf_bf16_vs_f32": ref, "hip_bf16_vs_f32": e_bf, "hip_mx_vs_f32": e_q, "hip_mx_vs_hip_bf16": err(out["mx"][1], out["bf16"][1]),
+                              "rms_ratio_to_hf_bf16": e_q["rms"] / ref["rms"], "max_ratio_to_hf_bf16": e_q["max"] / ref["max"]}}
+    assert e_q["rms"] <= 14.0 * ref["rms"] and e_q["max"] <= 14.0 * ref["max"] and abs(e_q["bias"]) <= 2e-2, res
+    assert e_q["rms"] >= 0.9 * e_bf["rms"]
+    s16, s32 = g[f"{tag}_sample"], g[f"{tag}_sample_f32"]
+    worst = {"rms_ratio": 0.0, "max_ratio": 0.0, "bias": 0.0}
+    for k in range(G - 1):
+        lg = out["mx"][2][k + 1]
+        r16 = err(bits_to_f32(s16[k]), torch.from_numpy(s32[k]))
+        eq = err(lg[::stride], torch.from_numpy(s32[k]))
+        worst = {"rms_ratio": max(worst["rms_ratio"], eq["rms"] / r16["rms"]), "max_ratio": max(worst["max_ratio"], eq["max"] / r16["max"]),
+                 "bias": max(worst["bias"], abs(eq["bias"]))}
+    res["decode_steps_w8a16_after_mx_prefill"] = worst
+    assert worst["rms_ratio"] <= 14.0 and worst["max_ratio"] <= 16.0 and worst["bias"] <= 2e-2, worst
+    margin = float(g[f"{tag}_first_margin"][0])
+    if margin > 2 * max(e_q["max"], err(out["mx"][1], l16)["max"]):
+        assert int(out["mx"][1].argmax()) == hf_tokens[0]
+    # the activation quantiser at this configuration's largest shape (the down-projection's input: M = 1216 rows, K = 11008)
+    lib = LIB.load()
+    M, K = S, geom.text.intermediate_size
+    gen = torch.Generator().manual_seed(11)
+    x = (torch.randn(M, K, generator=gen) * torch.logspace(-2, 2, K)).to(torch.bfloat16)
+    rows_pad = (M + 255) // 256 * 256
+    q = torch.zeros(M, K, dtype=torch.uint8, device="cuda")
+    sc = torch.zeros(K // 128, rows_pad, 4, dtype=torch.uint8, device="cuda")
+    assert lib.sr_op_quant_mx(P(x.cuda()), K, M, K, P(q), P(sc), rows_pad, sp()) == 0
+    xq, ex = MR.mx_quantize(x.float())
+    want_el = (xq.reshape(M, K // 32, 32) / torch.ldexp(torch.ones(M, K // 32), ex)[..., None]).reshape(M, K).to(torch.float8_e4m3fn)
+    assert torch.equal(q.cpu(), want_el.view(torch.uint8))
+    assert torch.equal(sc[:, :M].cpu(), (ex + 127).to(torch.uint8).reshape(M, K // 128, 4).permute(1, 0, 2))
+    record("hf_truth_r04.json", "fp8_mx_tile896", res)
+    print(json.dumps(res))
+
+
+# ------------------------------------------------------------------------------------------------ bench.py launches its own ranks
+def test_bench_gpus_n_self_launches_and_refuses_too_few_gpus():
+    """`python bench.py --gpus 2` (no torchrun around it): on a box with fewer than 2 GPUs it must exit non-zero with a clear message
+    -- never print a one-rank line under an N-GPU flag --; with SR_DIST_BACKEND=gloo (ranks share the device, host-staged exchange) it
+    starts 2 ranks itself and the line says n_gpus 2 / exchange.nranks 2.  DP contract: /root/reference/roll/distributed/scheduler/decorator.py:106-181."""
+    common = ["--gpus", "2", "--batch", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-latency", "--no-sam"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SR_DIST_BACKEND")}
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, "bench.py"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "needs 2 visible GPUs" in r.stderr, (r.returncode, r.stderr[-500:])
+        assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = subprocess.run([sys.executable, "bench.py"] + common, cwd=ROOT, env=dict(env, SR_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["exchange"]["nranks"] == 2 and line["config"]["parallelism"] == "dp2"

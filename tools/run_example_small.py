@@ -14,6 +14,7 @@ from roll.pipeline.rlvr.rlvr_socioseg_vlm_pipeline_infer import SocioSegConfig, 
 
 n, new, out = int(os.environ.get("SOCIOSEG_NUM_SAMPLES", 64)), int(os.environ.get("NEW_TOKENS", 128)), os.environ.get("OUT", "/tmp/example_out")
 os.environ["SOCIOSEG_NUM_SAMPLES"] = str(n)
+os.environ.setdefault("SR_ALLOW_SYNTHETIC_WEIGHTS", "1")       # no SAM2 checkpoint offline: random weights on purpose (the provider refuses otherwise)
 cfg = load_yaml_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "infer"), "rlvr_megatron")
 cfg["response_length"] = new
 cfg["actor_infer"]["generating_args"]["max_new_tokens"] = new
