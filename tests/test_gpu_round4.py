@@ -65,8 +65,10 @@ def test_gemm_f32_vs_float64(L, M, N, K, epi, rowmap):
     base = torch.randn(M, ldo, generator=g)
     out = base.clone().cuda()
     resid = out if (epi & 0xff) == EPI_RESID else None
-    rc = L.sr_op_gemm_f32(P(A.cuda()), lda, P(W.cuda()), M, N, K, P(out), ldo, P(bias.cuda()), P(resid), P(rm.cuda()) if rowmap else None, epi, sp())
+    dA, dW, db, drm = A.cuda(), W.cuda(), bias.cuda(), (rm.cuda() if rowmap else None)      # (held: a temporary's block would be handed to the next .cuda())
+    rc = L.sr_op_gemm_f32(P(dA), lda, P(dW), M, N, K, P(out), ldo, P(db), P(resid), P(drm), epi, sp())
     assert rc == 0
+    torch.cuda.synchronize()
     y = A[:, :K].double() @ W.double().t() + bias.double()
     if (epi & 0xff) == EPI_GELU:
         y = torch.relu(y) if epi & RELU else torch.nn.functional.gelu(y)
