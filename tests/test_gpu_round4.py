@@ -195,6 +195,31 @@ def test_sam2_float32_mode_equals_hf_float32(golden_dir, tag):
     assert not fails, fails
 
 
+def test_sam2_device_predictor_contract_against_hf_processor(golden_dir):
+    """The device predictor's prompt preparation and mask post-processing against HF's Sam2Processor / native box path / post_process_masks
+    (tests/golden/sam2_contract.npz; the oracle-side twin is tests/test_oracle_golden.py::test_sam2_predictor_contract_against_hf_processor)."""
+    from socioreasoner_amd import synthetic
+    g = np.load(os.path.join(golden_dir, "sam2_contract.npz"))
+    hw = int(g["hw"][0])
+    e, og = _engine_f32("tiny")
+    e.set_image(torch.from_numpy(synthetic.tile_pixels(7, hw, hw)).cuda())
+    for p in range(3):
+        box = g[f"p{p}_box"].tolist() or None
+        pts = g[f"p{p}_pts"]
+        labels = g[f"p{p}_labels"] if len(pts) else None
+        c, l = e.prompt(pts if len(pts) else None, labels, box)
+        nb = 2 if box is not None else 0
+        if box is not None:
+            assert np.array_equal(c[:2].reshape(-1), g[f"p{p}_hf_boxes"]) and l[:2].tolist() == [2, 3]
+        assert np.array_equal(c[nb:], g[f"p{p}_hf_points"].reshape(-1, 2))
+        logits, scores, low = e.predict(pts if len(pts) else None, labels, box, return_logits=True)
+        assert np.abs(low - g[f"p{p}_low_native"]).max() <= 2e-4 and np.abs(scores - g[f"p{p}_iou_native"]).max() <= 1e-5
+        want = np.unpackbits(g[f"p{p}_masks_bits"])[: 3 * hw * hw].reshape(3, hw, hw).astype(bool)
+        mine = logits > 0
+        # (the device resizes ITS logits, 1e-5 from HF's: a pixel whose logit is that close to 0 may differ)
+        assert int((mine != want).sum()) <= 3, (p, int((mine != want).sum()))
+
+
 def test_sam2_float32_batched_encoder_and_object_batches_are_bit_identical():
     """Batching in the float32 mode: tokens of B images stacked along the rows, several objects per decoder pass and the replayed
     launch graph give the bits of the one-image / one-object calls (rows never interact in any float32 kernel)."""

@@ -22,12 +22,12 @@ def _err(a, b):
     return float(d.abs().max()), float(d.pow(2).mean().sqrt())
 
 
-def _engine(tag):
+def _engine(tag, dtype=torch.bfloat16):
     from oracle import sam2_ref as S
     from socioreasoner_amd import sam2
     og = S.geometry_tiny() if tag == "tiny" else S.geometry_large()
     g = sam2.Sam2Geometry(**{k: getattr(og, k) for k in sam2.Sam2Geometry.__dataclass_fields__})
-    e = sam2.Sam2Engine(g)
+    e = sam2.Sam2Engine(g, dtype=dtype)
     e.load_state_dict(S.synthetic_weights(og))
     return e, og
 
@@ -89,10 +89,13 @@ def test_sam2_device_vs_hf(golden_dir, tag):
     print(tag, json.dumps(res))
 
 
-def test_pipeline_two_stage_flow_with_sam2_on_device(golden_dir, tmp_path):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pipeline_two_stage_flow_with_sam2_on_device(golden_dir, tmp_path, dtype):
     """The reference's run() sequence with the REAL predictor behind seg_infer (SAM2 on the device, tiny geometry, the oracle's synthetic
     weights) instead of the synthetic stand-in: stage-1 / stage-2 PNGs equal an independent replay (second engine, per-object predict ->
-    arg-max -> OR -> nearest 756 -> 768 with the oracle's raster ops), and stay within the bf16 band of the FLOAT32 oracle's masks."""
+    arg-max -> OR -> nearest 756 -> 768 with the oracle's raster ops).  float32 (the reference's precision, seg_infer's default): the
+    PNGs ARE the float32 oracle's masks (a pixel whose logit is within float32 round-off of 0 may differ: at most 8 of 4.7 M);
+    bf16: within the bf16 band of them."""
     import json
     from PIL import Image
     from oracle import host_ref as H
@@ -108,7 +111,7 @@ def test_pipeline_two_stage_flow_with_sam2_on_device(golden_dir, tmp_path):
     cfg.actor_infer.generating_args["temperature"] = 0
     seen = {"stage2_images": {}, "stage2_text": {}}
     w = _scripted_worker(cfg, geom, proc, seen)
-    e1, og = _engine("tiny")
+    e1, og = _engine("tiny", dtype)
     samples = socioseg_data.synthetic_socioseg(4)
     served = sam2.Sam2Predictor(e1)
     pipe = P.SocioSegInferPipeline(cfg, dataset=samples, processor=proc, actor_worker=w, sam_predictor_provider=lambda **_: served)
@@ -117,7 +120,7 @@ def test_pipeline_two_stage_flow_with_sam2_on_device(golden_dir, tmp_path):
     assert served.stats["encoded"] <= len(samples) and served.stats["cache_hits"] >= 1, served.stats
     assert served.stats["encoder_passes"] < served.stats["images"], served.stats
     res = os.path.join(str(tmp_path), "result")
-    e2, _ = _engine("tiny")
+    e2, _ = _engine("tiny", dtype)
     replay = sam2.Sam2Predictor(e2)
     oracle = S.Sam2Oracle(S.synthetic_weights(og), og)
     n_diff = n_px = 0
@@ -147,7 +150,10 @@ def test_pipeline_two_stage_flow_with_sam2_on_device(golden_dir, tmp_path):
             if stage == "stage2":
                 ious.append(H.compute_giou(got // 255, np.asarray(s["mask_label"].convert("L"))))
     assert abs(acc - float(np.mean(ious))) < 1e-12
-    assert n_diff <= 0.02 * n_px, (n_diff, n_px)          # bf16 device masks vs the float32 oracle's: boundary pixels only
+    if dtype == torch.float32:
+        assert n_diff <= 8, (n_diff, n_px)                # the reference's precision: the oracle's masks themselves
+    else:
+        assert n_diff <= 0.02 * n_px, (n_diff, n_px)      # bf16 device masks vs the float32 oracle's: boundary pixels only
     print("sam2 pipeline: pixels differing from the float32 oracle", n_diff, "of", n_px, "giou_acc", acc)
 
 

@@ -247,3 +247,35 @@ def test_sam2_oracle_matches_hf_sam2_model(golden_dir, tag):
         assert best == int(g[f"{tag}_p{p}_best"][0])
         want = np.unpackbits(g[f"{tag}_p{p}_mask_bits"])[: hw * hw].reshape(hw, hw).astype(bool)
         assert (masks[best] != want).sum() <= 2, p              # (a logit within 1e-6 of zero may land on either side)
+
+
+def test_sam2_predictor_contract_against_hf_processor(golden_dir):
+    """What the sam2 package's predictor does AROUND the network, pinned to HF's independent implementation of the same contract
+    (tests/golden/sam2_contract.npz, tools/make_golden_sam2_contract.py): (1) prompt scaling -- ``Sam2Processor``'s normalised points / boxes
+    equal ``oracle.sam2_ref.prompt_points`` (the box as its two corners in front of the clicks); (2) box handling -- HF's NATIVE ``input_boxes``
+    path (corners + 0.5, point_embed[2] / [3], padding point) gives the logits / IoUs the oracle computes from the box-as-labelled-points
+    form; (3) post-processing -- ``Sam2ImageProcessor.post_process_masks`` (bilinear, align_corners False, > 0) equals
+    ``oracle.sam2_ref.postprocess`` on the same logits, all three masks.  Still unpinned: SAM2Transforms' resize + normalisation (torchvision)
+    and the sam2_hiera_large.pt name table."""
+    from oracle import sam2_ref as S
+    from socioreasoner_amd import synthetic
+    g = np.load(os.path.join(golden_dir, "sam2_contract.npz"))
+    hw, size = int(g["hw"][0]), int(g["image_size"][0])
+    geom = S.geometry_tiny()
+    assert geom.image_size == size
+    o = S.Sam2Oracle(S.synthetic_weights(geom), geom)
+    o.set_image(synthetic.tile_pixels(7, hw, hw))
+    for p in range(3):
+        box = g[f"p{p}_box"].tolist() or None
+        pts = g[f"p{p}_pts"]
+        labels = g[f"p{p}_labels"] if len(pts) else None
+        c, l = S.prompt_points(box, pts if len(pts) else None, labels, (hw, hw), size)
+        nb = 2 if box is not None else 0
+        if box is not None:                                                    # (1) the processor's scaled box = the two corner points, labels 2 / 3
+            assert np.array_equal(c[:2].numpy().reshape(-1), g[f"p{p}_hf_boxes"]) and l[:2].tolist() == [2, 3]
+        assert np.array_equal(c[nb:].numpy(), g[f"p{p}_hf_points"].reshape(-1, 2)) and l[nb:].tolist() == (labels.tolist() if labels is not None else [])
+        masks, iou, low = o.predict(pts if len(pts) else None, labels, box)   # (2) against HF's native box path
+        assert np.abs(low - g[f"p{p}_low_native"]).max() <= 2e-4 and np.abs(iou - g[f"p{p}_iou_native"]).max() <= 1e-5, p
+        _, m3, _ = S.postprocess(torch.from_numpy(g[f"p{p}_low_native"]), torch.from_numpy(g[f"p{p}_iou_native"]), (hw, hw))    # (3)
+        want = np.unpackbits(g[f"p{p}_masks_bits"])[: 3 * hw * hw].reshape(3, hw, hw)
+        assert np.array_equal(m3.numpy(), want), p
