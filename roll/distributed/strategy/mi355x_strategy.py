@@ -65,7 +65,13 @@ class Mi355xStrategy(InferenceStrategy):
         sc = dict(_get(sa, "strategy_config", None) or {})
         margs = _get(self.worker_config, "model_args")
         path = str(_get(margs, "model_name_or_path", "") or sc.get("model", "synthetic:3b"))
-        self.geom = geometry_tiny() if path.endswith("synthetic:tiny") else geometry_3b()
+        import os
+        if os.path.isfile(os.path.join(path, "config.json")):    # a checkpoint directory brings its own geometry
+            import json
+            from socioreasoner_amd.config import geometry_from_hf_config
+            self.geom = geometry_from_hf_config(json.load(open(os.path.join(path, "config.json"))))
+        else:
+            self.geom = geometry_tiny() if path.endswith("synthetic:tiny") else geometry_3b()
         pc = getattr(self.worker, "pipeline_config", None)
         prompt_len = int(_get(pc, "prompt_length", 4096))
         resp_len = int(_get(pc, "response_length", 2048))
@@ -86,13 +92,13 @@ class Mi355xStrategy(InferenceStrategy):
                              max_batch=self.max_batch, max_ctx=max_ctx, max_new_tokens=min(resp_len, max_ctx - 1),
                              lm_fp8={"fp8": True, "fp8_e4m3": True, "fp8_mx": "mx"}.get(str(sc.get("quantization", "") or "").lower(), False),   # vLLM's knob name; fp8_mx: + MX fp8 activations in prefill
                              device=f"cuda:{int(_get(getattr(self.worker, 'rank_info', None), 'local_rank', 0) or 0)}")
-        import os
         if os.path.isdir(path):
             self.engine.load_safetensors_dir(path)
-            try:
-                from transformers import AutoTokenizer
+            if any(os.path.exists(os.path.join(path, f)) for f in ("tokenizer.json", "tokenizer_config.json", "vocab.json")):
+                from transformers import AutoTokenizer       # (a checkpoint with tokenizer files that do not load is an error, not a stub)
                 self.tokenizer = AutoTokenizer.from_pretrained(path)
-            except Exception:  # noqa: BLE001
+            else:
+                logger.warning("checkpoint directory %r has no tokenizer files: token ids in, token ids out only", path)
                 self.tokenizer = _StubTokenizer(self.geom)
         else:
             logger.warning("no checkpoint directory at %r: using synthetic weights (seed 0)", path)

@@ -268,8 +268,8 @@ class SocioSegInferPipeline(BasePipeline):
         if processor is None:
             path = str((cfg.actor_infer.model_args or {}).get("model_name_or_path") or cfg.get("pretrain") or "")
             if os.path.isdir(path):
-                from transformers import AutoProcessor
-                processor = AutoProcessor.from_pretrained(path)
+                from socioreasoner_amd.textproc import load_hf_processor
+                processor = load_hf_processor(path)         # AutoProcessor.from_pretrained (reference :518-521)
             else:
                 from socioreasoner_amd.textproc import SyntheticProcessor
                 processor = SyntheticProcessor(self.geom)
@@ -277,6 +277,9 @@ class SocioSegInferPipeline(BasePipeline):
         margs = (cfg.actor_train or {}).get("model_args") or cfg.actor_infer.model_args or {}
         self.processor.image_processor.max_pixels = int(margs.get("max_pixels") or 768 * 768)
         self.processor.image_processor.min_pixels = int(margs.get("min_pixels") or 56 * 56)
+        sz = getattr(self.processor.image_processor, "size", None)
+        if sz is not None and hasattr(sz, "longest_edge"):       # transformers 5 keeps the two bounds in `size`; the attributes above are what process_image reads
+            sz.longest_edge, sz.shortest_edge = self.processor.image_processor.max_pixels, self.processor.image_processor.min_pixels
         self.tokenizer = self.processor.tokenizer
         self.tokenizer.padding_side = "left"
         self.actor_infer.tokenizer = self.tokenizer

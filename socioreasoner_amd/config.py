@@ -99,3 +99,46 @@ def geometry_tiny() -> ModelGeometry:
                           intermediate_size=1000, vocab_size=2048),
         image_token_id=2040, video_token_id=2041, vision_start_token_id=2042, vision_end_token_id=2043,
         eos_token_id=2044, pad_token_id=2045)
+
+
+def geometry_from_hf_config(cfg: dict) -> ModelGeometry:
+    """``config.json`` of a Qwen2.5-VL checkpoint directory -> geometry.  Both layouts are read: the reference-era one (text fields at the
+    top level, ``rope_scaling.mrope_section``; what ``vvangfaye/SocioReasoner-3B`` ships -- /root/reference/mcore_adapter/src/mcore_adapter/
+    models/qwen2_5_vl/config_qwen2_5_vl.py:11-15 for the token ids) and the transformers-5 one (``text_config`` / ``rope_parameters``)."""
+    vc = dict(cfg.get("vision_config") or {})
+    tc = dict(cfg.get("text_config") or {})
+    t = lambda k, d=None: tc.get(k, cfg.get(k, d))
+    rope = t("rope_parameters") or t("rope_scaling") or {}
+    dv, dt = VisionGeometry(), TextGeometry()
+    heads = int(t("num_attention_heads", dt.num_attention_heads))
+    hidden = int(t("hidden_size", dt.hidden_size))
+    vision = VisionGeometry(depth=int(vc.get("depth", dv.depth)), hidden_size=int(vc.get("hidden_size", dv.hidden_size)),
+                            num_heads=int(vc.get("num_heads", dv.num_heads)), intermediate_size=int(vc.get("intermediate_size", dv.intermediate_size)),
+                            patch_size=int(vc.get("patch_size", dv.patch_size)), temporal_patch_size=int(vc.get("temporal_patch_size", dv.temporal_patch_size)),
+                            spatial_merge_size=int(vc.get("spatial_merge_size", dv.spatial_merge_size)), window_size=int(vc.get("window_size", dv.window_size)),
+                            fullatt_block_indexes=tuple(vc.get("fullatt_block_indexes", dv.fullatt_block_indexes)),
+                            out_hidden_size=int(vc.get("out_hidden_size", hidden)), in_channels=int(vc.get("in_channels", vc.get("in_chans", dv.in_channels))))
+    text = TextGeometry(num_hidden_layers=int(t("num_hidden_layers", dt.num_hidden_layers)), hidden_size=hidden, num_attention_heads=heads,
+                        num_key_value_heads=int(t("num_key_value_heads", dt.num_key_value_heads)), head_dim=int(t("head_dim") or hidden // heads),
+                        intermediate_size=int(t("intermediate_size", dt.intermediate_size)), vocab_size=int(t("vocab_size", dt.vocab_size)),
+                        rms_norm_eps=float(t("rms_norm_eps", dt.rms_norm_eps)), rope_theta=float(rope.get("rope_theta") or t("rope_theta", dt.rope_theta)),
+                        mrope_section=tuple(rope.get("mrope_section") or dt.mrope_section))
+    d = ModelGeometry()
+    eos = cfg.get("eos_token_id", tc.get("eos_token_id", d.eos_token_id))
+    return ModelGeometry(vision=vision, text=text, image_token_id=int(cfg.get("image_token_id", d.image_token_id)),
+                         video_token_id=int(cfg.get("video_token_id", d.video_token_id)), vision_start_token_id=int(cfg.get("vision_start_token_id", d.vision_start_token_id)),
+                         vision_end_token_id=int(cfg.get("vision_end_token_id", d.vision_end_token_id)),
+                         eos_token_id=int(eos[0] if isinstance(eos, (list, tuple)) else eos), pad_token_id=int(cfg.get("pad_token_id", tc.get("pad_token_id", d.pad_token_id)) or d.pad_token_id))
+
+
+def geometry_to_hf_config(g: ModelGeometry) -> dict:
+    """The reference-era ``config.json`` of this geometry (what a checkpoint directory carries)."""
+    v, t = g.vision, g.text
+    return {"architectures": ["Qwen2_5_VLForConditionalGeneration"], "model_type": "qwen2_5_vl", "hidden_size": t.hidden_size, "num_hidden_layers": t.num_hidden_layers,
+            "num_attention_heads": t.num_attention_heads, "num_key_value_heads": t.num_key_value_heads, "intermediate_size": t.intermediate_size, "vocab_size": t.vocab_size,
+            "rms_norm_eps": t.rms_norm_eps, "rope_theta": t.rope_theta, "rope_scaling": {"type": "mrope", "mrope_section": list(t.mrope_section)}, "tie_word_embeddings": True,
+            "hidden_act": "silu", "torch_dtype": "bfloat16", "image_token_id": g.image_token_id, "video_token_id": g.video_token_id,
+            "vision_start_token_id": g.vision_start_token_id, "vision_end_token_id": g.vision_end_token_id, "eos_token_id": g.eos_token_id, "pad_token_id": g.pad_token_id, "bos_token_id": g.pad_token_id,
+            "vision_config": {"model_type": "qwen2_5_vl", "depth": v.depth, "hidden_size": v.hidden_size, "num_heads": v.num_heads, "intermediate_size": v.intermediate_size,
+                              "patch_size": v.patch_size, "temporal_patch_size": v.temporal_patch_size, "spatial_merge_size": v.spatial_merge_size, "window_size": v.window_size,
+                              "fullatt_block_indexes": list(v.fullatt_block_indexes), "out_hidden_size": v.out_hidden_size, "in_chans": v.in_channels, "hidden_act": "silu"}}

@@ -176,3 +176,92 @@ class SyntheticProcessor:
         if grids:
             f["image_grid_thw"] = torch.tensor(grids, dtype=torch.long)
         return f
+
+
+def load_hf_processor(path: str):
+    """The checkpoint's own processor (reference: ``default_processor_provider`` -> ``AutoProcessor.from_pretrained``,
+    /root/reference/roll/pipeline/rlvr/rlvr_socioseg_vlm_pipeline_infer.py:518-521).  ``AutoProcessor`` first; where torchvision is absent
+    (this image) transformers 5 cannot build Qwen2.5-VL's VIDEO processor and AutoProcessor raises ImportError -- then the same
+    ``Qwen2_5_VLProcessor`` class is assembled from the checkpoint's files with HF's PIL image backend and no video processor (the
+    pipeline never feeds videos): HF's own ``__call__`` / ``apply_chat_template`` / image processor run either way."""
+    import os
+    try:
+        from transformers import AutoProcessor
+        return AutoProcessor.from_pretrained(path)
+    except ImportError:
+        pass
+    import json
+    import types
+    from transformers import AutoTokenizer
+    from transformers.models.qwen2_5_vl.processing_qwen2_5_vl import Qwen2_5_VLProcessor
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+
+    class _NoVideoProcessor(Qwen2_5_VLProcessor):
+        def check_argument_for_proper_class(self, argument_name, argument):
+            if argument_name == "video_processor":
+                return type(argument)
+            return super().check_argument_for_proper_class(argument_name, argument)
+    tok = AutoTokenizer.from_pretrained(path)
+    ip = Qwen2VLImageProcessorPil.from_pretrained(path)
+    tmpl = getattr(tok, "chat_template", None)
+    for name in ("chat_template.jinja", "chat_template.json"):
+        f = os.path.join(path, name)
+        if os.path.exists(f):
+            txt = open(f, encoding="utf-8").read()
+            tmpl = json.loads(txt)["chat_template"] if name.endswith(".json") else txt
+            break
+    video = types.SimpleNamespace(merge_size=getattr(ip, "merge_size", 2), temporal_patch_size=getattr(ip, "temporal_patch_size", 2))
+    return _NoVideoProcessor(image_processor=ip, tokenizer=tok, video_processor=video, chat_template=tmpl)
+
+
+QWEN_CHAT_TEMPLATE = (
+    "{% for message in messages %}{% if loop.first and message['role'] != 'system' %}<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n{% endif %}"
+    "<|im_start|>{{ message['role'] }}\n{% if message['content'] is string %}{{ message['content'] }}<|im_end|>\n{% else %}{% for content in message['content'] %}"
+    "{% if content['type'] == 'image' or 'image' in content or 'image_url' in content %}<|vision_start|><|image_pad|><|vision_end|>"
+    "{% elif 'text' in content %}{{ content['text'] }}{% endif %}{% endfor %}<|im_end|>\n{% endif %}{% endfor %}"
+    "{% if add_generation_prompt %}<|im_start|>assistant\n{% endif %}")
+
+
+def write_checkpoint_dir(path: str, geom: ModelGeometry, tensors: Dict[str, torch.Tensor]) -> None:
+    """Writes an HF-style Qwen2.5-VL checkpoint DIRECTORY for ``geom`` around ``tensors`` (HF-named weights): model.safetensors, config.json,
+    preprocessor_config.json, a ``tokenizers`` byte-level BPE tokenizer.json whose ids are ByteTokenizer's (bytes = 0..255, the Qwen special
+    tokens at the geometry's ids, no merges) and the Qwen2-VL chat template.  Real SocioReasoner-3B files cannot be fetched offline; this
+    is how the checkpoint branches of the pipeline (AutoProcessor / AutoTokenizer / safetensors loader / config.json geometry) are driven
+    end to end by tests and tools -- the files have the real ones' names and schema."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    from tokenizers import AddedToken, Tokenizer, decoders, models, pre_tokenizers
+    from socioreasoner_amd.config import geometry_to_hf_config
+    os.makedirs(path, exist_ok=True)
+    save_file({k: v.contiguous() for k, v in tensors.items()}, os.path.join(path, "model.safetensors"))
+    json.dump(geometry_to_hf_config(geom), open(os.path.join(path, "config.json"), "w"), indent=1)
+    # GPT-2's byte <-> printable-character table (the alphabet of every byte-level BPE, Qwen's included)
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    ref = ByteTokenizer(geom)
+    vocab = {chr(c): b for b, c in zip(bs, cs)}
+    taken = set(ref.special.values())
+    for i in range(256, geom.text.vocab_size):
+        if i not in taken:
+            vocab[f"<|unused_{i}|>"] = i
+    vocab.update(ref.special)
+    tok = Tokenizer(models.BPE(vocab=vocab, merges=[]))
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)
+    tok.decoder = decoders.ByteLevel()
+    tok.add_special_tokens([AddedToken(k, special=True, normalized=False) for k in ref.special])
+    tok.save(os.path.join(path, "tokenizer.json"))
+    json.dump({"tokenizer_class": "Qwen2TokenizerFast", "eos_token": ref.eos_token, "pad_token": ref.pad_token, "model_max_length": 32768,
+               "additional_special_tokens": [k for k in ref.special if k not in (ref.eos_token, ref.pad_token)], "chat_template": QWEN_CHAT_TEMPLATE},
+              open(os.path.join(path, "tokenizer_config.json"), "w"), indent=1)
+    v = geom.vision
+    json.dump({"image_processor_type": "Qwen2VLImageProcessor", "processor_class": "Qwen2_5_VLProcessor", "patch_size": v.patch_size, "merge_size": v.spatial_merge_size,
+               "temporal_patch_size": v.temporal_patch_size, "min_pixels": 3136, "max_pixels": 12845056, "image_mean": [0.48145466, 0.4578275, 0.40821073],
+               "image_std": [0.26862954, 0.26130258, 0.27577711], "do_resize": True, "do_rescale": True, "do_normalize": True, "do_convert_rgb": True, "resample": 3,
+               "rescale_factor": 1 / 255}, open(os.path.join(path, "preprocessor_config.json"), "w"), indent=1)
+    open(os.path.join(path, "chat_template.jinja"), "w", encoding="utf-8").write(QWEN_CHAT_TEMPLATE)

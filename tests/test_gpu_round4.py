@@ -365,3 +365,65 @@ def test_bench_gpus_n_self_launches_and_refuses_too_few_gpus():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["exchange"]["nranks"] == 2 and line["config"]["parallelism"] == "dp2"
+
+
+# ------------------------------------------------------------------------------------------------ N2: the checkpoint branches, end to end
+def test_pipeline_on_a_checkpoint_directory_and_a_socioseg_folder(tmp_path, monkeypatch):
+    """SocioSegInferPipeline driven the way a real run drives it -- ``pretrain`` = a checkpoint DIRECTORY (config.json geometry, safetensors
+    through sr_load_weight, AutoProcessor / AutoTokenizer: reference rlvr_socioseg_vlm_pipeline_infer.py:270-315, 518-521), the dataset
+    a SocioSeg folder on disk (roll/datasets/dataset.py:49-119) -- against the same run on the offline stand-ins (device-generated weights,
+    SyntheticProcessor / ByteTokenizer, in-memory samples).  The checkpoint holds the generator's weights and its tokenizer.json has the
+    stand-in's ids (textproc.write_checkpoint_dir), so every written file must be identical; and HF's pixel_values of a sample equal the
+    rows sr_patchify_u8 produces from the same image."""
+    import filecmp
+    from oracle import model_ref as MR
+    from oracle import weights as WG
+    from roll.pipeline.rlvr.rlvr_config import SocioSegConfig
+    from roll.pipeline.rlvr.rlvr_socioseg_vlm_pipeline_infer import SocioSegInferPipeline
+    from socioreasoner_amd import socioseg_data, textproc
+    from socioreasoner_amd.config import geometry_tiny
+    geom = geometry_tiny()
+    rcfg = MR.config_tiny()
+    W = WG.LazyWeights(rcfg, seed=0)
+    tensors = {n: W[n].to(torch.bfloat16) for n, _, _ in WG.param_specs(rcfg)}
+    ck, data = str(tmp_path / "ckpt"), str(tmp_path / "data")
+    textproc.write_checkpoint_dir(ck, geom, tensors)
+    socioseg_data.write_socioseg_folder(socioseg_data.synthetic_socioseg(3), os.path.join(data, "SocioSeg"))
+    monkeypatch.setenv("SOCIOSEG_NUM_SAMPLES", "3")
+
+    def cfg(out, pretrain, with_data):
+        d = {"output_dir": str(out), "prompt_length": 1600, "response_length": 6, "rollout_batch_size": 3, "pretrain": pretrain,
+             "actor_infer": {"model_args": {"model_name_or_path": pretrain},
+                             "generating_args": {"max_new_tokens": 6, "temperature": 0, "top_k": 1, "top_p": 1.0, "num_beams": 1},
+                             "strategy_args": {"strategy_name": "vllm", "strategy_config": {"max_batch": 4, "max_patches": 4096}}},
+             "seg_infer": {"model_args": {}, "strategy_args": {"strategy_name": "seg_infer"}}}
+        if with_data:
+            d["actor_train"] = {"data_args": {"dataset_dir": data, "file_name": "SocioSeg"}}
+        return SocioSegConfig.from_dict(d)
+    a = SocioSegInferPipeline(cfg(tmp_path / "out_ckpt", ck, True))
+    assert "Qwen2_5_VLProcessor" in [c.__name__ for c in type(a.processor).__mro__] and type(a.tokenizer).__module__.startswith("transformers")
+    assert a.actor_infer.strategy.geom == geom and type(a.actor_infer.strategy.tokenizer).__module__.startswith("transformers")
+    # HF's pixel_values of a collated sample against the device patchify of the same image
+    im = a.dataset["image"][0][0]
+    feats = a.processor.image_processor(images=[im], return_tensors="pt")
+    eng = a.actor_infer.strategy.engine
+    rows = eng.patchify(torch.from_numpy(np.asarray(im).copy()).cuda())
+    assert torch.equal(rows[:, :feats["pixel_values"].shape[1]].cpu(), feats["pixel_values"].to(torch.bfloat16))
+    acc_a = a.run()
+    eng.close()
+    b = SocioSegInferPipeline(cfg(tmp_path / "out_synth", "synthetic:tiny", False))
+    assert type(b.processor).__name__ == "SyntheticProcessor"
+    acc_b = b.run()
+    b.actor_infer.strategy.engine.close()
+    assert acc_a == acc_b
+    ra, rb = os.path.join(str(tmp_path / "out_ckpt"), "result"), os.path.join(str(tmp_path / "out_synth"), "result")
+    n = 0
+    for sub in ("stage1", "stage2", "render1", "render2"):
+        names = sorted(os.listdir(os.path.join(ra, sub)))
+        assert names == sorted(os.listdir(os.path.join(rb, sub))) and names
+        for f in names:
+            assert filecmp.cmp(os.path.join(ra, sub, f), os.path.join(rb, sub, f), shallow=False), (sub, f)
+            n += 1
+    assert n == 3 * 6
+    txt = open(os.path.join(ra, "stage1", sorted(f for f in os.listdir(os.path.join(ra, "stage1")) if f.endswith(".txt"))[0])).read()
+    assert len(txt) > 0

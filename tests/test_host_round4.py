@@ -133,3 +133,59 @@ def test_dispatch_abort_reaches_waiting_ranks():
     assert b._wait("payload/3") == b"x"
     b._drop("payload/3")
     assert not store.check(["sr_dispatch/1/payload/3"])
+
+
+def test_checkpoint_directory_processor_equals_the_offline_stand_in(tmp_path):
+    """N2: the branch a REAL checkpoint takes -- config.json geometry, AutoProcessor / AutoTokenizer (HF's own
+    Qwen2_5_VLProcessor.__call__, chat template and PIL image processor; reference rlvr_socioseg_vlm_pipeline_infer.py:186-257, 270-315,
+    518-521), the SocioSeg folder reader (roll/datasets/dataset.py:49-119) -- driven from a checkpoint directory written with the real
+    files' names and schema (socioreasoner_amd.textproc.write_checkpoint_dir: the tokenizer is a byte-level BPE whose ids are the stand-in's).
+    The collated batch must equal, field by field, what the offline stand-ins (SyntheticProcessor / ByteTokenizer, in-memory samples)
+    produce, and HF's pixel_values must be the oracle's patchify of the images the payload carries."""
+    import json
+    import numpy as np
+    import torch
+    from oracle import host_ref as H
+    from roll.datasets.collator import DataCollatorWithPaddingForMultiSeg
+    from roll.pipeline.rlvr import rlvr_socioseg_vlm_pipeline_infer as P
+    from socioreasoner_amd import socioseg_data, textproc
+    from socioreasoner_amd.config import geometry_from_hf_config, geometry_tiny
+    geom = geometry_tiny()
+    ck, data = str(tmp_path / "ckpt"), str(tmp_path / "data")
+    textproc.write_checkpoint_dir(ck, geom, {"model.norm.weight": torch.ones(geom.text.hidden_size, dtype=torch.bfloat16)})
+    assert geometry_from_hf_config(json.load(open(os.path.join(ck, "config.json")))) == geom
+    samples = socioseg_data.synthetic_socioseg(3, size=448)
+    samples[1]["map_image"] = samples[1]["map_image"].resize((500, 380))          # a size smart_resize has to round
+    socioseg_data.write_socioseg_folder(samples, os.path.join(data, "SocioSeg"))
+    loaded = socioseg_data.load_socioseg_folder(os.path.join(data, "SocioSeg"), "test")
+    assert [s["id"] for s in loaded] == [s["id"] for s in samples] and all(isinstance(s["map_image"], str) for s in loaded)
+    hf = textproc.load_hf_processor(ck)
+    st = textproc.SyntheticProcessor(geom)
+    assert type(hf).__mro__[1].__name__ == "Qwen2_5_VLProcessor" or type(hf).__name__ == "Qwen2_5_VLProcessor"
+    assert hf.tokenizer.pad_token_id == geom.pad_token_id and hf.tokenizer.eos_token_id == geom.eos_token_id
+    out = {}
+    for name, proc, src in (("hf", hf, loaded), ("standin", st, samples)):
+        proc.image_processor.max_pixels, proc.image_processor.min_pixels = 768 * 768, 56 * 56
+        proc.tokenizer.padding_side = "left"
+        raw = {k: [s[k] for s in src] for k in ("id", "problem", "map_image", "sat_image", "mask_label")}
+        ds = P.encode_function(raw, proc)
+        coll = DataCollatorWithPaddingForMultiSeg(tokenizer=proc.tokenizer, processor=proc, extra_data_provider=P.get_extra_data_provider(processor=proc),
+                                                  max_length=1600, image_key="image", padding="max_length", gt_object_key="gt_object", gt_bbox_key="gt_bbox")
+        out[name] = next(iter(P.get_dataloader(ds, 3, coll)))
+    a, b = out["hf"], out["standin"]
+    for k in ("map_input_ids", "map_attention_mask", "map_position_ids"):
+        assert torch.equal(torch.as_tensor(a[k]), torch.as_tensor(b[k])), k
+    for i in range(3):
+        pa, pb = a["multi_modal_map_data"][i], b["multi_modal_map_data"][i]
+        assert list(pa["prompt_token_ids"]) == list(pb["prompt_token_ids"])
+        ims_a, ims_b = pa["multi_modal_data"]["image"], pb["multi_modal_data"]["image"]
+        assert [im.size for im in ims_a] == [im.size for im in ims_b] and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(ims_a, ims_b))
+        # HF's own pixel_values of those images = the oracle's patchify (what sr_patchify_u8 is tested against bit for bit on the GPU)
+        feats = hf.image_processor(images=ims_a, return_tensors="pt")
+        want = np.concatenate([H.patchify(np.asarray(im))[0] for im in ims_a], axis=0)
+        assert np.array_equal(feats["pixel_values"].numpy(), want)
+        assert feats["image_grid_thw"].tolist() == [[1, im.size[1] // 14, im.size[0] // 14] for im in ims_a]
+    assert a["question"].tolist() == b["question"].tolist() and a["gt_bbox"].tolist() == b["gt_bbox"].tolist()
+    # stage-2 text goes through the same tokenizer: decode(encode(text)) round-trips, special tokens keep their ids
+    text = P.format_prompt_2("school", '[{"bbox_2d": [1, 2, 3, 4]}]', hf)
+    assert hf.tokenizer.encode(text, add_special_tokens=False) == st.tokenizer.encode(text) and hf.tokenizer.decode(st.tokenizer.encode(text)) == text
