@@ -81,7 +81,7 @@ class ByteTokenizer:
                 if not skip_special_tokens:
                     parts.append(self.by_id[t])
             else:
-                parts.append("�")          # an id no text maps to (random-weight models emit these)
+                parts.append(f"<|unused_{t}|>")   # an id no text maps to (random-weight models emit these): the name write_checkpoint_dir gives it
         if run:
             parts.append(run.decode("utf-8", errors="replace"))
         return "".join(parts)
