@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--admit-cus", default="auto", help="CUs per shader engine (of 8) given to the overlapped admission stream, or auto (chosen per admission)")
     ap.add_argument("--no-overlap", action="store_true", help="continuous mode: admit between decode steps on one stream (round-1 behaviour) instead of "
                     "staging the next admission on a CU-masked stream under the running rows' decode")
+    ap.add_argument("--drain", action="store_true", help="continuous mode: drain the batch rows between steps (every step starts with an exposed admission on an idle "
+                    "engine, rounds 1-3) instead of serving the steps' requests as ONE stream (step k + 1's first admission staged under step k's last rows)")
     ap.add_argument("--poll", type=int, default=16, help="continuous mode: decode steps queued per scheduling round (rows are released / admitted between rounds)")
     ap.add_argument("--poll-ragged", type=int, default=4, help="the same for the ragged phase (0 = --poll): rows that end on different steps are refilled sooner with short "
                     "rounds -- measured 59.8 / 60.8 / 62.1 tiles/s at 16 / 8 / 4")
@@ -161,32 +163,44 @@ def main():
         for j in range(4):
             raster.mask_union_(acc, masks[j, lo:lo + n].reshape(n * 756, 756))
         up = raster.resize_nearest(acc, n * 768, 768).reshape(n, 768, 768)
-        counts = torch.empty(n, 2, dtype=torch.int64, device=dev)
-        for b in range(n):
-            counts[b] = raster.iou_counts(up[b], gts[lo + b])
-        return counts
+        return raster.iou_counts_batched(up, gts[lo:lo + n])          # one launch for the n tiles
 
-    def step_continuous(phase_ms=None):
-        """waves x B requests through B rows: the later ones are admitted as rows free up (EOS is ignored by the metric, so all
-        rows of a wave finish together; the point is the measured cost of the request-level path)."""
+    def steps_continuous(k_steps, phase_ms=None):
+        """k_steps steps of waves x B requests each through B rows, served as ONE request stream: the later requests are admitted as rows
+        free up (EOS is ignored by the metric, so all rows of a wave finish together; the point is the measured cost of the request-level
+        path), step k + 1's first group is staged under step k's last rows like any other group; a step's raster tail and result exchange
+        run when its last request completes.  --drain: one scheduler per step on an idle engine (rounds 1-3)."""
         from socioreasoner_amd.serving import ContinuousBatcher, Request
-        cb = ContinuousBatcher(eng, eos=[], pad_id=0, steps_per_poll=args.poll, time_phases=phase_ms is not None, overlap=overlap, admit_cus_per_se=args.admit_cus if args.admit_cus == "auto" else float(args.admit_cus))
-        reqs = [Request(ids=ids[k], pos3=pos3[k], max_new=N_NEW, images=imgs[k], grids=[GRID] * NIMG) for k in range(n_req)]
-        toks = cb.run(reqs)
-        e0, e1 = ev(), ev()
-        e0.record()
-        counts = raster_tail(0, n_req)
-        e1.record()
-        res = torch.cat([torch.tensor(toks, dtype=torch.int64, device=dev), counts], dim=1)
-        if world > 1:
-            res = dp.all_gather_rows(res, n_req * world)
-        if phase_ms is not None:
-            for k, v in cb.phase_ms().items():
-                phase_ms[k] = phase_ms.get(k, 0.0) + v
-            for k in ("admitted", "staged_shared", "steps", "steps_shared"):
-                sched[k] = sched.get(k, 0) + cb.stats[k]
-            shares.extend(cb.stats["shares"])
-            phase_ms["raster"] += e0.elapsed_time(e1)
+        res = None
+        groups = [[s_] for s_ in range(k_steps)] if args.drain else [list(range(k_steps))]
+        for grp in groups:
+            cb = ContinuousBatcher(eng, eos=[], pad_id=0, steps_per_poll=args.poll, time_phases=phase_ms is not None, overlap=overlap, admit_cus_per_se=args.admit_cus if args.admit_cus == "auto" else float(args.admit_cus))
+            reqs = [Request(ids=ids[k], pos3=pos3[k], max_new=N_NEW, images=imgs[k], grids=[GRID] * NIMG, tag=(s_, k)) for s_ in grp for k in range(n_req)]
+            toks = {s_: [None] * n_req for s_ in grp}
+            left = {s_: n_req for s_ in grp}
+            spans, out = [], {}
+
+            def finished(req, t):
+                s_, k = req.tag
+                toks[s_][k] = t
+                left[s_] -= 1
+                if left[s_] == 0:           # the step's last request: its raster tail + the one exchange of the step (every rank gets here in step order)
+                    e0, e1 = ev(), ev()
+                    e0.record()
+                    counts = raster_tail(0, n_req)
+                    e1.record()
+                    spans.append((e0, e1))
+                    r_ = torch.cat([torch.tensor(toks[s_], dtype=torch.int64, device=dev), counts], dim=1)
+                    out[s_] = dp.all_gather_rows(r_, n_req * world) if world > 1 else r_
+            cb.run_stream(reqs, finished)
+            res = out[grp[-1]]
+            if phase_ms is not None:
+                for k, v in cb.phase_ms().items():
+                    phase_ms[k] = phase_ms.get(k, 0.0) + v
+                for k in ("admitted", "staged_shared", "steps", "steps_shared"):
+                    sched[k] = sched.get(k, 0) + cb.stats[k]
+                shares.extend(cb.stats["shares"])
+                phase_ms["raster"] += sum(a.elapsed_time(b_) for a, b_ in spans)
         return res
 
     def step_static(nb, phase_ms=None, first=0, gather=True):
@@ -218,18 +232,22 @@ def main():
     phase_ms = {"vit": 0.0, "prefill": 0.0, "decode": 0.0, "raster": 0.0}
     shares = []         # CU share (of 8 per shader engine) of every overlapped admission
     sched = {}          # continuous mode: requests admitted / staged under decode, decode steps alone / sharing the chip
-    step = (lambda rec=False: step_continuous(phase_ms if rec else None)) if continuous else \
-        (lambda rec=False: step_static(B, phase_ms if rec else None))
+    def run_steps(k_steps, rec=False):
+        if continuous:
+            return steps_continuous(k_steps, phase_ms if rec else None)
+        r_ = None
+        for _ in range(k_steps):
+            r_ = step_static(B, phase_ms if rec else None)
+        return r_
 
     if world > 1:      # open the RCCL communicator outside the timed region even with --warmup 0
         dp.all_gather_rows(torch.zeros(B, 1, dtype=torch.int64, device=dev), B * world)
-    for _ in range(args.warmup):
-        step()
+    if args.warmup:
+        run_steps(args.warmup)
     dp.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step(True)
+    res = run_steps(args.steps, True)
     torch.cuda.synchronize(dev)
     dp.barrier()
     dt = time.perf_counter() - t0
@@ -261,6 +279,19 @@ def main():
                       "vit_mfma_frac": round(VIT_GFLOP * B / (st_ms["vit"] / 2 * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4),
                       "prefill_mfma_frac": round(PREFILL_GFLOP * B / (st_ms["prefill"] / 2 * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4),
                       "forward_mfma_frac": round((VIT_GFLOP + PREFILL_GFLOP) * B / (fw * 1e-3) / 1e3 / MFMA_PEAK_TFLOPS, 4)}
+
+    # ---- the same step on a DRAINED engine (rounds 1-3's definition of a step: every step starts with an exposed admission on idle rows)
+    drained = None
+    if rank == 0 and world == 1 and continuous and not args.drain and not args.no_latency:
+        args.drain = True
+        torch.cuda.synchronize(dev)
+        t_ = time.perf_counter()
+        steps_continuous(1)
+        torch.cuda.synchronize(dev)
+        d_ = time.perf_counter() - t_
+        args.drain = False
+        drained = {"workload": "ONE step on an idle engine: its first admission is exposed, its last rows decode with nothing staged under them", "tiles_per_s": round(n_req / d_, 3),
+                   "ms_per_step": round(d_ * 1e3, 2)}
 
     # ---- admit-on-finish TIMED: the same requests with ragged answer lengths (per-request max_new uniform in [64, 192], mean 128, seeded),
     # through the same scheduler, against static batches of B that each run to their longest answer.  The headline's rows all stop on
@@ -536,7 +567,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not args.fp8 else ("fp8-e4m3 LM linears: prefill fp8 x fp8 on the block-scaled MFMA (MX activations), decode fp8 weights x bf16 activations"
                                                       if args.fp8_mx else "bf16 (fp8-e4m3 LM linear weights, bf16 activations / MFMA)"), "data": "synthetic",
             "config": {"workload": f"SocioReasoner-3B {'fp8-weight' if args.fp8 else 'bf16'}, {B} batch row(s)/GPU, "
-                                   + (f"continuous batching ({'next admission overlapped with decode' if overlap else 'admit on finish'}): {n_req} tile requests per step through {B} rows, " if continuous else "static batch, ")
+                                   + (f"continuous batching ({'next admission overlapped with decode' if overlap else 'admit on finish'}): {n_req} tile requests per step through {B} rows"
+                                      + (" (rows drained between steps), " if args.drain else f", the {args.steps} steps served as one request stream, ") if continuous else "static batch, ")
                                    + f"{NIMG} x {args.tile}x{args.tile} synthetic image(s) per request, {S_PROMPT}-token prompt, greedy decode of {N_NEW} tokens (EOS ignored), raster tail; random-init "
                                    f"weights (counter-based generator, seed 0)" + (f" [{cfg_name}]" if cfg_name else ""),
                        "tiles_per_gpu_per_step": n_req,
@@ -545,7 +577,7 @@ def main():
                        "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",
                        "exchange": dict(exchange, payload="float32 logits all-gather per decode step (verification mode)" if args.gather_logits
                                         else "one all-gather of 1 KB result rows per tile and step")},
-            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_torch_bf16": cpu_hf, "phase_ms_per_step": phases, "static_batch": static_ref, "ragged": ragged, "sam2": sam, "latency_b1": latency,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_torch_bf16": cpu_hf, "phase_ms_per_step": phases, "static_batch": static_ref, "drained_step": drained, "ragged": ragged, "sam2": sam, "latency_b1": latency,
             "weights_load_s": round(load_s, 1), "workspace_GB": round(eng.workspace_bytes / 1e9, 2),
             "result_checksum": int(res.sum().item()),
         }

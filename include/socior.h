@@ -188,6 +188,8 @@ int sr_rows_abort(sr_engine* e, const int32_t* host_rows, int n, void* stream);
 int sr_mask_union(uint8_t* dev_acc, const uint8_t* dev_mask, size_t n, void* stream);
 int sr_resize_nearest_u8(const uint8_t* dev_src, int sh, int sw, uint8_t* dev_dst, int dh, int dw, void* stream);
 int sr_iou_counts(const uint8_t* dev_pred, const uint8_t* dev_gt, size_t n, int64_t* dev_out2, void* stream);
+/* the same counts for n_items (prediction, ground truth) pairs of n bytes each, stored back to back, in ONE launch: dev_out [n_items][2] */
+int sr_iou_counts_batched(const uint8_t* dev_pred, const uint8_t* dev_gt, size_t n, int n_items, int64_t* dev_out, void* stream);
 int sr_render_overlay(uint8_t* dev_img_rgb, int h, int w, const uint8_t* dev_mask, int mh, int mw,
                       const int32_t* dev_boxes, int n_boxes, void* stream);
 

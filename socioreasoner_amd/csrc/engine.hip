@@ -1501,6 +1501,9 @@ int sr_resize_nearest_u8(const uint8_t* src, int sh, int sw, uint8_t* dst, int d
 int sr_iou_counts(const uint8_t* p, const uint8_t* g, size_t n, int64_t* out2, void* stream) {
     SR_WRAP(launch_iou_counts((hipStream_t)stream, p, g, n, reinterpret_cast<long long*>(out2)));
 }
+int sr_iou_counts_batched(const uint8_t* p, const uint8_t* g, size_t n, int n_items, int64_t* out, void* stream) {
+    SR_WRAP(launch_iou_counts_batched((hipStream_t)stream, p, g, n, n_items, reinterpret_cast<long long*>(out)));
+}
 int sr_render_overlay(uint8_t* img, int h, int w, const uint8_t* mask, int mh, int mw, const int32_t* boxes, int nb, void* stream) {
     SR_WRAP(launch_render_overlay((hipStream_t)stream, img, h, w, mask, mh, mw, boxes, nb));
 }

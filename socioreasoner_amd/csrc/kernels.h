@@ -263,5 +263,6 @@ int launch_attn_f32(hipStream_t s, const AttnF32Args& a, int head_dim);
 int launch_mask_union(hipStream_t s, uint8_t* acc, const uint8_t* m, size_t n);
 int launch_resize_nearest_u8(hipStream_t s, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw);
 int launch_iou_counts(hipStream_t s, const uint8_t* p, const uint8_t* g, size_t n, long long* out2);
+int launch_iou_counts_batched(hipStream_t s, const uint8_t* p, const uint8_t* g, size_t n, int n_items, long long* out);     // out [n_items][2], zeroed here
 int launch_render_overlay(hipStream_t s, uint8_t* img, int h, int w, const uint8_t* mask, int mh, int mw,
                           const int* boxes, int nb);

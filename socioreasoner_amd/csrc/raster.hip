@@ -59,6 +59,44 @@ __global__ __launch_bounds__(256) void k_iou_counts(const uint8_t* p, const uint
     }
 }
 
+// The same counts for n_items (prediction, ground truth) pairs of n bytes each in ONE launch (the raster tail of a batch of tiles:
+// rlvr_socioseg_vlm_pipeline_infer.py:45-58 per sample): grid (blocks per item, items), 16 bytes per lane and load when n % 16 == 0.
+__global__ __launch_bounds__(256) void k_iou_counts_batched(const uint8_t* p, const uint8_t* g, size_t n, unsigned long long* out) {
+    const size_t item = blockIdx.y;
+    const uint8_t* pp = p + item * n;
+    const uint8_t* gg = g + item * n;
+    unsigned inter = 0, uni = 0;              // <= n / (blocks * 256) * 16 per lane: far below 2^32
+    const size_t nv = (n % 16 == 0 && ((uintptr_t)pp | (uintptr_t)gg) % 16 == 0) ? n / 16 : 0;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < nv; i += stride) {
+        const uint4 a = reinterpret_cast<const uint4*>(pp)[i], b = reinterpret_cast<const uint4*>(gg)[i];
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // byte > 0 -> bit 0 of the byte: OR the byte's bits down (x | x >> 1 | ... ) without crossing byte borders
+            uint32_t x = aw[q], y = bw[q];
+            x |= (x >> 4) & 0x0f0f0f0fu; x |= (x >> 2) & 0x03030303u; x |= (x >> 1) & 0x01010101u; x &= 0x01010101u;
+            y |= (y >> 4) & 0x0f0f0f0fu; y |= (y >> 2) & 0x03030303u; y |= (y >> 1) & 0x01010101u; y &= 0x01010101u;
+            inter += __popc(x & y);
+            uni += __popc(x | y);
+        }
+    }
+    for (size_t i = nv * 16 + blockIdx.x * 256ull + threadIdx.x; i < n; i += stride) {
+        const int a = pp[i] > 0, b = gg[i] > 0;
+        inter += a & b;
+        uni += a | b;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        inter += __shfl_xor(inter, o, 64);
+        uni += __shfl_xor(uni, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[item * 2 + 0], (unsigned long long)inter);
+        atomicAdd(&out[item * 2 + 1], (unsigned long long)uni);
+    }
+}
+
 // one thread per pixel: rectangles first (reference draws them before compositing), then the overlay
 __global__ __launch_bounds__(256) void k_render(uint8_t* img, int h, int w, const uint8_t* mask, int mh, int mw,
                                                 const int* boxes, int nb) {
@@ -121,6 +159,18 @@ int launch_iou_counts(hipStream_t s, const uint8_t* p, const uint8_t* g, size_t 
     size_t blocks = (n + 256 * 16 - 1) / (256 * 16);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(k_iou_counts, dim3((unsigned)blocks), dim3(256), 0, s, p, g, n, reinterpret_cast<unsigned long long*>(out2));
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+int launch_iou_counts_batched(hipStream_t s, const uint8_t* p, const uint8_t* g, size_t n, int n_items, long long* out) {
+    if (n_items <= 0) return 0;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)n_items * 2 * sizeof(long long), s);
+    if (e != hipSuccess) return (int)e;
+    if (n == 0) return 0;
+    size_t blocks = (n + 256 * 64 - 1) / (256 * 64);          // 4 x 16 bytes per lane
+    if (blocks > 64) blocks = 64;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_iou_counts_batched, dim3((unsigned)blocks, (unsigned)n_items), dim3(256), 0, s, p, g, n, reinterpret_cast<unsigned long long*>(out));
     SR_CHECK_LAUNCH();
     return 0;
 }

@@ -64,6 +64,7 @@ SIGNATURES = {
     "sr_mask_union": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "sr_resize_nearest_u8": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp]),
     "sr_iou_counts": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
+    "sr_iou_counts_batched": (C.c_int, [_vp, _vp, C.c_size_t, _i, _vp, _vp]),
     "sr_render_overlay": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "sr_op_gemm": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "sr_op_quant_mx": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),

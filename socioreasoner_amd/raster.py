@@ -41,6 +41,17 @@ def iou_counts(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def iou_counts_batched(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    """(intersection, union) pixel counts of n (prediction, ground truth) pairs, uint8 [n, h, w] each, in ONE launch -> int64 [n, 2]."""
+    assert pred.dtype == torch.uint8 and gt.dtype == torch.uint8 and pred.is_cuda and pred.shape == gt.shape and pred.dim() == 3
+    pred, gt = pred.contiguous(), gt.contiguous()
+    n = int(pred.shape[0])
+    out = torch.empty(n, 2, dtype=torch.int64, device=pred.device)
+    L.check(L.load().sr_iou_counts_batched(C.c_void_p(pred.data_ptr()), C.c_void_p(gt.data_ptr()), pred[0].numel() if n else 0, n, C.c_void_p(out.data_ptr()), _s(pred)),
+            None, "sr_iou_counts_batched")
+    return out
+
+
 def compute_giou(pred: torch.Tensor, gt: torch.Tensor) -> float:
     i, u = iou_counts(pred, gt).tolist()
     return 1.0 if u == 0 else i / u

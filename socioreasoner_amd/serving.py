@@ -356,6 +356,16 @@ class ContinuousBatcher:
             self.free.append(row)
             on_complete(req, toks)
 
+    def run_stream(self, requests: Sequence[Request], on_complete: Callable[[Request, List[int]], None]) -> None:
+        """Serve a stream of requests, reporting each as it completes (in completion order): what a server does -- the next requests'
+        admission is staged under the running rows' last decode steps instead of after them."""
+        for r in requests:
+            self.submit(r)
+        while not self.idle():
+            self.pump(on_complete)
+        if self.overlap and self._dec_last is not None:      # hand back to the caller's stream
+            torch.cuda.current_stream(self.engine.device).wait_stream(self._dec_last)
+
     def run(self, requests: Sequence[Request]) -> List[List[int]]:
         """Serve a fixed list of requests; returns their token lists in request order."""
         order = {id(r): i for i, r in enumerate(requests)}

@@ -427,3 +427,19 @@ def test_pipeline_on_a_checkpoint_directory_and_a_socioseg_folder(tmp_path, monk
     assert n == 3 * 6
     txt = open(os.path.join(ra, "stage1", sorted(f for f in os.listdir(os.path.join(ra, "stage1")) if f.endswith(".txt"))[0])).read()
     assert len(txt) > 0
+
+
+@pytest.mark.parametrize("n,h,w", [(5, 768, 768), (3, 37, 53), (1, 16, 16), (4, 100, 33)])
+def test_batched_iou_counts_bit_exact(n, h, w):
+    """sr_iou_counts_batched (one launch for the raster tail of n tiles; compute_giou of the reference, rlvr_socioseg_vlm_pipeline_infer.py:
+    45-58, per sample) against the C oracle and the per-tile kernel: any non-zero byte counts as set, sizes that are not multiples of 16."""
+    from oracle import raster_ref as R
+    from socioreasoner_amd import raster
+    rng = np.random.default_rng(n * 1000 + h)
+    p = (rng.random((n, h, w)) < 0.4).astype(np.uint8) * rng.integers(1, 256, (n, h, w), dtype=np.uint8)
+    g = (rng.random((n, h, w)) < 0.5).astype(np.uint8) * rng.integers(1, 256, (n, h, w), dtype=np.uint8)
+    p[0] = 0 if n > 1 else p[0]
+    dp_, dg = torch.from_numpy(p).cuda(), torch.from_numpy(g).cuda()
+    got = raster.iou_counts_batched(dp_, dg).cpu().tolist()
+    for i in range(n):
+        assert got[i] == list(R.iou_counts(p[i], g[i])) == raster.iou_counts(dp_[i], dg[i]).tolist(), i
