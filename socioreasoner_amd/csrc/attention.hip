@@ -949,208 +949,9 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
 }
 
 
-// ---- ONE launch per layer for batches >= 16 and caches of <= 1024 keys (round 3 experiment, off by default: attn_decode_one_launch): a block of 8 waves per (sequence, kv head) does what the two
-// kernels above do -- rotary + cache append, scores of all keys (wave w: key tiles w, w + 8, ...), exact softmax (wave h: head h), O^T = V^T . P^T
-// (wave w: d-tile w) -- with the score rows in LDS instead of the scratch buffer.  At batch 32 there are 64 blocks, each pulling its 2 x 131 KB
-// of K / V^T once (all loads of a wave issued before anything depends on them); nothing is recomputed, unlike the one-launch variant measured
-// in round 1.  BIT-IDENTICAL to k_attn_dec_scores + k_attn_dec_pv: same score rounding, same softmax, and the P.V sum keeps their association
-// -- four partial sums over the key blocks kb = 0, 1, 2, 3 (mod 4), added ((p0 + p1) + p2) + p3 -- so the two paths can be switched freely.
-// The new token's K row / V^T column are patched in from LDS (the prefetch was issued before the append).
-// NKT: key tiles per wave (ctx_max <= 128 NKT), NV2: key blocks 16 .. 15 + NV2 of the second V^T prefetch (ctx_max <= 32 (17 + NV2))
-template <int NKT, int NV2>
-__global__ __launch_bounds__(512) void k_attn_dec_one(DecodeAttnArgs p, int s_stride) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    bf16_t* q_s = reinterpret_cast<bf16_t*>(dsm);                    // [16][136]
-    bf16_t* k_s = q_s + 16 * 136;                                    // [128]
-    bf16_t* v_s = k_s + 128;                                         // [128]
-    float* cs = reinterpret_cast<float*>(v_s + 128);                 // [64]
-    float* sn = cs + 64;                                             // [64]
-    bf16_t* sb = reinterpret_cast<bf16_t*>(sn + 64);                 // [group][s_stride]
-    const int b = blockIdx.x, kvh = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fg = lane >> 4;
-    const int G = p.group, HQ = p.n_q_heads, HK = p.n_kv_heads;
-    const bf16_t* row = p.qkv + (size_t)b * p.qkv_stride;
-    // the new token's q / k / v and rotary cos | sin: requested first, they travel with the row's state (as in k_attn_dec_scores)
-    const int qh = tid >> 3, qc = tid & 7;
-    uint4 q1 = uint4{0, 0, 0, 0}, q2 = q1;
-    float kx1 = 0.f, kx2 = 0.f;
-    bf16_t vx1 = 0, vx2 = 0;
-    if (tid < 128) {
-        if (qh < G) {
-            const bf16_t* q = row + (kvh * G + qh) * DEC_HD + qc * 8;
-            q1 = *reinterpret_cast<const uint4*>(q);
-            q2 = *reinterpret_cast<const uint4*>(q + 64);
-        }
-    } else if (tid < 192) {
-        const bf16_t* k = row + (HQ + kvh) * DEC_HD + (tid - 128);
-        kx1 = bf2f(k[0]);
-        kx2 = bf2f(k[64]);
-    } else if (tid < 256) {
-        const bf16_t* v = row + (HQ + HK + kvh) * DEC_HD + (tid - 192);
-        vx1 = v[0];
-        vx2 = v[64];
-    }
-    float csv = 0.f;
-    if (p.row_cs && tid < 128) csv = p.row_cs[(size_t)b * 128 + tid];
-    const int nkeys = p.ctx_len[b];
-    const int slot = p.slots ? p.slots[b] : b;
-    const bool frozen = p.frozen && p.frozen[b];
-    const int idx = nkeys - 1;                    // cache row of the new token
-    bf16_t* kc = p.kcache + (size_t)(slot * HK + kvh) * p.ctx_max * DEC_HD;
-    bf16_t* vc = p.vtcache + (size_t)(slot * HK + kvh) * DEC_HD * p.ctx_max;
-    const int ntiles = (nkeys + 15) / 16, nkb = (nkeys + 31) / 32, nvec = nkb * 4;
-    // every cache load of this wave goes out now: K tiles wave, wave + 8, ... (<= 8 of them at 1024 keys) and the V^T rows of d-tile `wave`
-    bf16x8 kf[NKT][4];
-#pragma unroll
-    for (int i = 0; i < NKT; ++i) {
-        const int t = wave + 8 * i;
-        if (t < ntiles) {
-            const int key = min(t * 16 + fr, nkeys - 1);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) kf[i][kk] = *reinterpret_cast<const bf16x8*>(kc + (size_t)key * DEC_HD + kk * 32 + fg * 8);
-        }
-    }
-    const bf16_t* vrow = vc + (size_t)(wave * 16 + fr) * p.ctx_max + fg * 8;
-    bf16x8 vf[16];                                  // key blocks 0 .. 15 now; 16 .. 30 once the K registers are free (after the scores); the LAST
-#pragma unroll                                      // block (it holds the new token) travels apart
-    for (int i = 0; i < 16; ++i)
-        if (i < nkb - 1) vf[i] = *reinterpret_cast<const bf16x8*>(vrow + i * 32);
-    bf16x8 vlast = *reinterpret_cast<const bf16x8*>(vrow + (nkb - 1) * 32);
-    if (!frozen && tid >= 192 && tid < 256) {
-        const int d = tid - 192;
-        vc[(size_t)d * p.ctx_max + idx] = vx1;
-        vc[(size_t)(d + 64) * p.ctx_max + idx] = vx2;
-        v_s[d] = vx1;
-        v_s[d + 64] = vx2;
-    }
-    if (p.row_cs) {
-        if (tid < 64) cs[tid] = csv;
-        else if (tid < 128) sn[tid - 64] = csv;
-    } else if (tid < 64) {
-        const int pos = p.pos[b];
-        cs[tid] = bf2f(p.rope_cos[(size_t)pos * 64 + tid]);
-        sn[tid] = bf2f(p.rope_sin[(size_t)pos * 64 + tid]);
-    }
-    __syncthreads();
-    if (tid < 128) {
-        const float x1[8] = {lo16(q1.x), hi16(q1.x), lo16(q1.y), hi16(q1.y), lo16(q1.z), hi16(q1.z), lo16(q1.w), hi16(q1.w)};
-        const float x2[8] = {lo16(q2.x), hi16(q2.x), lo16(q2.y), hi16(q2.y), lo16(q2.z), hi16(q2.z), lo16(q2.w), hi16(q2.w)};
-        float o1[8], o2[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rope_pair(x1[e], x2[e], cs[qc * 8 + e], sn[qc * 8 + e], o1[e], o2[e]);
-        *reinterpret_cast<uint4*>(q_s + qh * 136 + qc * 8) = uint4{pack2(o1[0], o1[1]), pack2(o1[2], o1[3]), pack2(o1[4], o1[5]), pack2(o1[6], o1[7])};
-        *reinterpret_cast<uint4*>(q_s + qh * 136 + 64 + qc * 8) = uint4{pack2(o2[0], o2[1]), pack2(o2[2], o2[3]), pack2(o2[4], o2[5]), pack2(o2[6], o2[7])};
-    } else if (!frozen && tid < 192) {
-        const int d = tid - 128;
-        float o1, o2;
-        rope_pair(kx1, kx2, cs[d], sn[d], o1, o2);
-        const bf16_t b1 = f2bf(o1), b2 = f2bf(o2);
-        kc[(size_t)idx * DEC_HD + d] = b1;
-        kc[(size_t)idx * DEC_HD + d + 64] = b2;
-        k_s[d] = b1;
-        k_s[d + 64] = b2;
-    }
-    __syncthreads();
-    // ---- scores of this wave's key tiles -> LDS (scaled, rounded to bf16: the values k_attn_dec_scores hands to k_attn_dec_pv)
-#pragma unroll
-    for (int i = 0; i < NKT; ++i) {
-        const int t = wave + 8 * i;
-        if (t < ntiles) {
-            const int key = min(t * 16 + fr, nkeys - 1);
-            if (key == idx && !frozen) {          // rows of (or clamped to) the new token come from LDS
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) kf[i][kk] = *reinterpret_cast<const bf16x8*>(k_s + kk * 32 + fg * 8);
-            }
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8 qf = *reinterpret_cast<const bf16x8*>(q_s + fr * 136 + kk * 32 + fg * 8);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i][kk], qf, acc, 0, 0, 0);
-            }
-            if (fr < G)
-                *reinterpret_cast<uint2*>(sb + fr * s_stride + t * 16 + fg * 4) =
-                    uint2{pack2(rbf(acc[0]) * p.scale, rbf(acc[1]) * p.scale), pack2(rbf(acc[2]) * p.scale, rbf(acc[3]) * p.scale)};
-        }
-    }
-    bf16x8 vg[NV2 > 0 ? NV2 : 1];                   // (in flight during the softmax)
-#pragma unroll
-    for (int i = 0; i < NV2; ++i)
-        if (16 + i < nkb - 1) vg[i] = *reinterpret_cast<const bf16x8*>(vrow + (16 + i) * 32);
-    __syncthreads();
-    // ---- softmax per head (float32), probabilities rounded to bf16 in place, tail zero-filled (nvec <= 128 at 1024 keys)
-    for (int hh = wave; hh < G; hh += 8) {
-        bf16_t* srow = sb + hh * s_stride;
-        float v[2][8];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int vi = lane + i * 64;
-            if (vi < nvec) {
-                const uint4 u = *reinterpret_cast<const uint4*>(srow + vi * 8);
-                const float t[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    v[i][e] = (vi * 8 + e < nkeys) ? t[e] : -INFINITY;
-                    mx = fmaxf(mx, v[i][e]);
-                }
-            }
-        }
-        mx = wave_max(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            if (lane + i * 64 < nvec) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { v[i][e] = __expf(v[i][e] - mx); sum += v[i][e]; }
-            }
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int vi = lane + i * 64;
-            if (vi < nvec)
-                *reinterpret_cast<uint4*>(srow + vi * 8) = uint4{pack2(v[i][0] * inv, v[i][1] * inv), pack2(v[i][2] * inv, v[i][3] * inv),
-                                                                  pack2(v[i][4] * inv, v[i][5] * inv), pack2(v[i][6] * inv, v[i][7] * inv)};
-        }
-    }
-    __syncthreads();
-    // ---- O^T[d-tile wave][head]: partial sums by key block mod 4, in the order the four waves of k_attn_dec_pv accumulate and combine them
-    f32x4 part[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) part[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 16 + NV2; ++i)
-        if (i < nkb - 1) {
-            uint4 pv = uint4{0, 0, 0, 0};
-            if (fr < G) pv = *reinterpret_cast<const uint4*>(sb + fr * s_stride + i * 32 + fg * 8);
-            part[i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(i < 16 ? vf[i < 16 ? i : 0] : vg[i >= 16 ? i - 16 : 0], __builtin_bit_cast(bf16x8, pv), part[i & 3], 0, 0, 0);
-        }
-    {   // the last key block: the new token's V^T column comes from LDS (this wave's prefetch was issued before the append)
-        typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
-        const int kl = nkb - 1;
-        u16x8 t = __builtin_bit_cast(u16x8, vlast);
-        if (!frozen && fg == ((idx & 31) >> 3)) {
-            const unsigned short nv = v_s[wave * 16 + fr];
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (e == (idx & 7)) t[e] = nv;
-        }
-        uint4 pv = uint4{0, 0, 0, 0};
-        if (fr < G) pv = *reinterpret_cast<const uint4*>(sb + fr * s_stride + kl * 32 + fg * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j == (kl & 3)) part[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, t), __builtin_bit_cast(bf16x8, pv), part[j], 0, 0, 0);
-    }
-    if (fr < G) {
-        f32x4 o = part[0];
-#pragma unroll
-        for (int j = 1; j < 4; ++j) { o[0] += part[j][0]; o[1] += part[j][1]; o[2] += part[j][2]; o[3] += part[j][3]; }
-        const uint2 v2 = {pack2(o[0], o[1]), pack2(o[2], o[3])};
-        const int col = (kvh * G + fr) * DEC_HD + wave * 16 + fg * 4;
-        *reinterpret_cast<uint2*>(p.out + (p.out_tiled ? tiled_offset((size_t)b, (size_t)col, (size_t)p.out_stride) : (size_t)b * p.out_stride + col)) = v2;
-    }
-}
+// (the one-launch decode attention of round 3, k_attn_dec_one -- bit-identical and slower, 2.617 vs 2.545 ms per step -- is no longer compiled in:
+// tools/experiments/README.md)
+
 
 }  // namespace
 
@@ -1234,28 +1035,9 @@ int attn_decode_prepare(int ctx_max, int group) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_dec_pv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 }
 
-// SR_ATTN_DEC1=1: batches >= 16 over caches of <= 1024 keys through ONE launch (k_attn_dec_one); 2: any batch (the bit-identity test).
-// MEASURED AND LEFT OFF (round 3, static batch of 32, same box, two runs each): decode step 2.617 ms with it, 2.545 ms with the two
-// launches -- the one kernel costs ~15.7 us per layer against 5.3 + 8.4: its 64 blocks pull 262 KB of cache each on 64 of the 256 CUs
-// (a CU ingests ~50 GB/s), then walk scores -> softmax -> P.V behind three barriers; the two-launch path spreads the same bytes over 640 and
-// 256 blocks, and that buys more than the launch boundary and the 2.6 MB score scratch cost.  Read at every call.
-bool attn_decode_one_launch(const DecodeAttnArgs& a) {
-    const char* env = getenv("SR_ATTN_DEC1");
-    const int mode = env ? atoi(env) : 0;
-    if (mode != 1 && mode != 2) return false;
-    return (a.B >= 16 || mode == 2) && a.ctx_max <= 1024 && a.group <= 16 && a.group * (a.ctx_max + 8) * 2 + 6144 <= 64 * 1024;
-}
-
 int launch_attn_decode(hipStream_t s, const DecodeAttnArgs& a) {
     if (a.B <= 0) return 0;
     if (a.group > 16 || a.ctx_max % 64 != 0 || !a.scores) return -22;
-    if (attn_decode_one_launch(a)) {
-        const size_t smem = (16 * 136 + 256) * sizeof(bf16_t) + 128 * sizeof(float) + (size_t)a.group * (a.ctx_max + 8) * sizeof(bf16_t);
-        if (a.ctx_max <= 640) hipLaunchKernelGGL((k_attn_dec_one<5, 3>), dim3(a.B, a.n_kv_heads), dim3(512), smem, s, a, a.ctx_max + 8);
-        else hipLaunchKernelGGL((k_attn_dec_one<8, 15>), dim3(a.B, a.n_kv_heads), dim3(512), smem, s, a, a.ctx_max + 8);
-        SR_CHECK_LAUNCH();
-        return 0;
-    }
     hipLaunchKernelGGL(k_attn_dec_scores, dim3(a.B, a.n_kv_heads, a.ctx_max / 64), dim3(256), 0, s, a);
     if (a.B >= 16) hipLaunchKernelGGL(k_attn_dec_pv<2>, dim3(a.B, a.n_kv_heads, DEC_HD / 32), dim3(256), dec_smem(a.ctx_max, a.group, 2), s, a, a.ctx_max + 8);
     else hipLaunchKernelGGL(k_attn_dec_pv<1>, dim3(a.B, a.n_kv_heads, DEC_HD / 16), dim3(256), dec_smem(a.ctx_max, a.group, 1), s, a, a.ctx_max + 8);

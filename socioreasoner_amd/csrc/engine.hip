@@ -108,7 +108,6 @@ struct sr_engine {
     AttnWork* t_work;
     // ---- decode state (device)
     bf16_t *d_xa, *d_xb, *d_xn, *d_qkv, *d_attn, *d_act, *d_scores;    // d_xa / d_xb: residual stream ping-pong
-    bf16_t* d_ht; float* d_ss;            // batches > 4: fragment-ordered copy of the post-attention residual rows + their partial sums of squares (folded ln2)
     float *d_logits, *d_slabs, *d_amax_val;
     float* d_row_cs = nullptr;               // [32][128] rotary cos | sin of every row's current position (k_step -> decode attention)
     int *d_amax_idx, *d_cur_tok, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
@@ -307,8 +306,6 @@ void carve(sr_engine* e) {
     e->d_xb = ar.take<bf16_t>(B * H);
     const size_t Bp = (B + 15) / 16 * 16;           // the fragment-ordered x buffers of the batch > 4 decode path hold whole 16-row groups
     e->d_xn = ar.take<bf16_t>(Bp * H);
-    e->d_ht = ar.take<bf16_t>(Bp * H);
-    e->d_ss = ar.take<float>((size_t)(H / 16 + 1) * 32);
     e->d_qkv = ar.take<bf16_t>(B * e->t_qn);
     e->d_attn = ar.take<bf16_t>(Bp * c.t_heads * 128);
     e->d_act = ar.take<bf16_t>(Bp * e->t_inter_pad);
@@ -563,26 +560,7 @@ GemvArgs gv(const bf16_t* x, int ldx, const bf16_t* W, int M, int N, int K, void
 bool fused_norms(const sr_engine* e, int B) { return B <= 4 && e->c.t_hidden % 512 == 0; }
 // fragment-ordered activations between the launches of the batch > 4 decode layer (x_tiled): needs whole 64-wide k chunks
 bool x_tiled_ok(const sr_engine* e) {
-    static const char* env = getenv("SR_XTILED");          // tuning hook: 0 = row-major x as in round 1
-    if (env && atoi(env) == 0) return false;
     return e->c.t_hidden % 64 == 0 && (e->c.t_heads * 128) % 64 == 0 && e->t_inter_pad % 64 == 0 && e->c.t_hidden <= 2048;
-}
-// Experiment hook (read when a decode graph is built): SR_FOLD_LN2=1 folds the post-attention RMSNorm of the batch > 4 decode layer between
-// o_proj and gate/up (7 launches per layer instead of 8).  MEASURED AND LEFT OFF (round 3, same box, static batch of 32): decode step
-// 2.87 ms folded against 2.55 ms with the norm as its own launch.  The launch it saves costs 4.7 us; normalising the x fragments in the
-// consumer costs ~13 us per layer: the 2752 waves of the gate/up GEMV each re-normalise their 32 x 512 slice (688 x redundant over the
-// chip), ~1400 VALU instructions per wave at ~4 issue cycles each on SIMDs that hold 2.7 waves.  At batch <= 4 the same fold is free
-// (one row, staged once per block) and ships; at batch 32 a norm has to be computed ONCE, which means its own pass over the rows.
-bool fold_ln2() {
-    const char* env = getenv("SR_FOLD_LN2");
-    return env && atoi(env) == 1;
-}
-// SR_DEFER_LN: the batch > 4 decode layer's RMSNorms as DEFERRED row scales (gemv.hip XN == 2): the producing GEMV's epilogue stores
-// bf16(h * w_ln) and the rows' partial sums of squares, the consuming GEMV scales its float32 sums by 1 / rms(row).  No norm launch, no
-// per-element work in the consumer.
-int defer_ln() {
-    const char* env = getenv("SR_DEFER_LN");
-    return env ? atoi(env) : 0;
 }
 int ks_down(const sr_engine* e, int B) { return (B > 16 && e->t_inter_pad / 64 >= 32) ? 4 : e->ks_down; }
 
@@ -640,20 +618,10 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         SR_TRY(launch_attn_decode(s, da));
         GemvArgs go = gv(e->d_attn, QD, w.o_w, B, H, QD, x, H);
         go.W8 = w.o_w8; go.w_scale = w.o_s; go.x_tiled = xt;
-        // batches > 4, round-3 experiment (fold_ln2(), off: measured slower): the post-attention RMSNorm folded between o_proj and gate/up --
-        // o_proj's epilogue also stores the new residual rows fragment-ordered together with each 16-column tile's share of the rows' sums
-        // of squares, the gate/up GEMV turns them into the row scales and normalises its x fragments in registers (same formula and
-        // rounding points as k_rmsnorm_row; the sum of squares is added in another order).
-        const bool fold2 = !fused && xt && !w.o_w8 && fold_ln2();
-        const bool defer2 = !fused && xt && !w.o_w8 && !w.gu_w8 && !fold2 && defer_ln() >= 1;
-        if (fold2) { go.h_tiled = e->d_ht; go.ss_out = e->d_ss; }
-        if (defer2) { go.h_tiled = e->d_ht; go.ss_out = e->d_ss; go.xn_w = w.ln2; }
         SR_TRY(launch_gemv(s, go, GV_RESID));
         GemvArgs gg = gv(x, H, w.gu_w, B, 2 * e->t_inter_pad, H, e->d_act, e->t_inter_pad);
         gg.W8 = w.gu_w8; gg.w_scale = w.gu_s;
         if (fused) { gg.norm_w = w.ln2; gg.eps = c.t_rms_eps; }
-        else if (defer2) { gg.x = e->d_ht; gg.x_tiled = 1; gg.out_tiled = 1; gg.ss_in = e->d_ss; gg.n_ss = H / 16; gg.eps = c.t_rms_eps; }
-        else if (fold2) { gg.x = e->d_ht; gg.x_tiled = 1; gg.out_tiled = 1; gg.xn_w = w.ln2; gg.ss_in = e->d_ss; gg.n_ss = H / 16; gg.eps = c.t_rms_eps; }
         else { SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt)); gg.x = e->d_xn; gg.x_tiled = xt; gg.out_tiled = xt; }
         SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
         GemvArgs gd = gv(e->d_act, e->t_inter_pad, w.down_w, B, H, e->t_inter_pad, e->d_slabs, H);

@@ -22,12 +22,8 @@
 #include <stdlib.h>
 #include <type_traits>
 
-// Ring depth (64-wide k chunks in flight per wave) of the batch-17..32 gate/up launch.  4 -> 184 registers, 2 blocks per CU, the 688 blocks
-// run as 512 + 176; 3 -> 152 registers, 3 blocks per CU, all 688 resident at once -- and measured SLOWER (round 3, static batch of 32:
-// decode step 2.544 vs 2.512 ms): the shorter ring costs more than the second dispatch round.
-#ifndef SR_GU_RING
-#define SR_GU_RING 4
-#endif
+// (Measured dead ends of round 3 -- RMSNorm folded into / deferred behind the consuming GEMV, 8- and 16-wave blocks, a 3-deep gate/up ring --
+// are no longer compiled into the library: tools/experiments/README.md.)
 
 namespace {
 
@@ -40,13 +36,7 @@ __device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(b
 // WAVES = 4 : the dispatched configuration -- many small blocks, K split over the 4 waves.
 // STAGE     : x (optionally + pending residual slabs, optionally RMS-normalised) is prepared in LDS by the prologue
 //             (used for batches <= 4, where the prologue is a few KB per block).
-// XN        : x (fragment-ordered, raw residual stream) is RMS-normalised in registers right before it is multiplied: the row scales come
-//             from per-(16-column tile, row) partial sums of squares the producing GEMV's epilogue wrote (GemvArgs.ss_in)
-// XN == 2   : DEFERRED row scale.  1 / rms(row) is a per-row scalar, so it commutes with the product over k: the producer's epilogue stores
-//             bf16(h * w_ln) (fragment-ordered) beside h, this kernel multiplies those rows as they are and scales the float32 sums by
-//             1 / rms(row) in its epilogue -- nothing per element, nothing per k.  Rounding points differ from hf:65-79 (bf16(h w) instead of
-//             bf16(w bf16(h rs)): one rounding fewer); tests/test_gpu_round3.py holds the layer stack to its distance from the float32 truth.
-template <int MODE, int MT, int KP, bool STAGE, int WAVES, bool F8 = false, int XN = 0>
+template <int MODE, int MT, int KP, bool STAGE, int WAVES, bool F8 = false>
 __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;     // 16-row W tiles per wave
     constexpr int TPB = WAVES / KP;                    // wave-tiles per block
@@ -67,8 +57,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     // waits for the oldest slot.  The first fills do not depend on x: they go out before the prologue's second pass.
     // F8: the stream is the fp8 image (1 KB per 16 x 64 block): ONE 16-byte load per lane and chunk, widened to the two
     // bf16 MFMA operands at consume time (exact), the per-channel scale multiplies the float32 accumulator.
-    constexpr int U = (T == 2 && MT == 2 && !STAGE && !F8 && WAVES == 4) ? SR_GU_RING : ((F8 && STAGE) ? 16 : (WAVES >= 16 && MT == 2) ? 4 : 8) / T;      // x rides the ring in registers when it is not staged: keep it short there
-                                                             // (16-wave blocks get 128 registers per lane: half the ring at 32 batch rows)
+    constexpr int U = ((F8 && STAGE) ? 16 : 8) / T;          // (gate / up at 17..32 rows: 4 -> 184 registers, 2 blocks per CU; x rides the ring in registers when it is not staged)
     constexpr int WL = F8 ? 1 : 2;
     u32x4 w[U][T][WL];
     const int cend = min(c0 + per, nchunks);
@@ -104,10 +93,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     };
     // epilogue operands (bias / residual) are fetched first: they are the oldest loads in flight, so the epilogue never
     // waits a memory round trip for them
-    uint2 ep_bias[MT], ep_res[MT], ep_lnw = uint2{0, 0};
-    if constexpr (MODE == GV_RESID) {
-        if (active && kp == 0 && p.h_tiled && p.xn_w) ep_lnw = *reinterpret_cast<const uint2*>(p.xn_w + tile * 16 + fg * 4);
-    }
+    uint2 ep_bias[MT], ep_res[MT];
     if constexpr (MODE == GV_BIAS || MODE == GV_RESID) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -118,17 +104,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                 if (MODE == GV_BIAS && p.bias) ep_bias[mt] = *reinterpret_cast<const uint2*>(p.bias + n);
                 if (MODE == GV_RESID) ep_res[mt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.out) + (size_t)m * p.ldo + n);
             }
-        }
-    }
-    // XN == 2: the rows' partial sums of squares go out FIRST (oldest loads in flight, like the bias).  The KP waves of a block split the
-    // (<= 128) partials: wave kp takes tiles kp * 32 + (lane / 8) + 8 i for rows 4 (lane % 8) .. + 3, and leaves its sums in LDS for the
-    // epilogue wave, which adds the KP shares in fixed order after the K-reduction barrier.
-    float4 ss_pre[4];
-    if constexpr (XN == 2) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = kp * (128 / KP) + (lane >> 3) + 8 * i;
-            ss_pre[i] = (i * 8 < 128 / KP && j < p.n_ss) ? *reinterpret_cast<const float4*>(p.ss_in + (size_t)j * 32 + (lane & 7) * 4) : float4{0.f, 0.f, 0.f, 0.f};
         }
     }
     if constexpr (!STAGE) first_fills();
@@ -238,42 +213,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // XN: 1 / rms of the rows this lane multiplies (m = fr and 16 + fr).  The partial sums [n_ss][32] are added in a fixed order: lane
-    // (tg = lane / 8, rq = lane % 8) sums tiles tg, tg + 8, ... for rows 4 rq .. 4 rq + 3, then the 8 lane groups are combined
-    float xn_rs[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xn_rs[mt] = 1.f;
-    auto row_scales = [&]() {
-        const int tg = lane >> 3, rq = lane & 7;
-        float4 a4 = float4{0.f, 0.f, 0.f, 0.f};
-        for (int j = tg; j < p.n_ss; j += 8) {
-            const float4 v = *reinterpret_cast<const float4*>(p.ss_in + (size_t)j * 32 + rq * 4);
-            a4.x += v.x; a4.y += v.y; a4.z += v.z; a4.w += v.w;
-        }
-#pragma unroll
-        for (int o = 8; o <= 32; o <<= 1) {
-            a4.x += __shfl_xor(a4.x, o, 64); a4.y += __shfl_xor(a4.y, o, 64); a4.z += __shfl_xor(a4.z, o, 64); a4.w += __shfl_xor(a4.w, o, 64);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = mt * 16 + fr, src = m >> 2;          // lane src (any tg) holds rows 4 src .. 4 src + 3
-            const float s0 = __shfl(a4.x, src, 64), s1 = __shfl(a4.y, src, 64), s2 = __shfl(a4.z, src, 64), s3 = __shfl(a4.w, src, 64);
-            const float ssum = (m & 3) == 0 ? s0 : (m & 3) == 1 ? s1 : (m & 3) == 2 ? s2 : s3;
-            xn_rs[mt] = 1.0f / sqrtf(ssum / (float)p.K + p.eps);
-        }
-    };
-    if constexpr (XN == 1) row_scales();
-    // XN: x_norm = bf16(w * bf16(x * rs))  (hf:65-79), 8 values at a time
-    auto xnorm8 = [&](u32x4 xr, u32x4 wr, float rs) -> u32x4 {
-        u32x4 o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float a = rbf(lo16(xr[q]) * rs), b = rbf(hi16(xr[q]) * rs);
-            o[q] = pack2(lo16(wr[q]) * a, hi16(wr[q]) * b);
-        }
-        return o;
-    };
-
     if (active) {
         const bf16_t* xrow[MT];
         bool xok[MT];
@@ -316,15 +255,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                     constexpr int xu_static = 0;
                     const int xu = STAGE ? xu_static : u;
                     if constexpr (STAGE) fill_x(0, c + u);
-                    if constexpr (XN == 1) {     // the lane's 16 k of this chunk: k = (c + u) * 64 + fg * 16 + 0 .. 15 (two 8-runs = the two k-steps)
-                        const bf16_t* wn = p.xn_w + (size_t)(c + u) * 64 + fg * 16;
-                        const u32x4 w0 = *reinterpret_cast<const u32x4*>(wn), w1 = *reinterpret_cast<const u32x4*>(wn + 8);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {
-                            xv[u][mt][0] = xnorm8(xv[u][mt][0], w0, xn_rs[mt]);
-                            xv[u][mt][1] = xnorm8(xv[u][mt][1], w1, xn_rs[mt]);
-                        }
-                    }
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
                         u32x4 w0, w1;
@@ -358,17 +288,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     // ---------------------------------------------------------------- in-block K reduction (fixed order kp = 1, 2, 3)
     // reuses the staged-x region once every wave is done reading it
     f32x4* rbuf = reinterpret_cast<f32x4*>(STAGE ? smem : reinterpret_cast<unsigned char*>(red + 128));   // [TPB][KP-1][T*MT][64]
-    if constexpr (XN == 2) {
-        static_assert(XN != 2 || (KP == 4 && WAVES == 4 && !STAGE), "deferred row scale: 4-wave blocks, K split by 4");
-        float4 a4 = ss_pre[0];
-#pragma unroll
-        for (int i = 1; i < 4; ++i) { a4.x += ss_pre[i].x; a4.y += ss_pre[i].y; a4.z += ss_pre[i].z; a4.w += ss_pre[i].w; }
-#pragma unroll
-        for (int o = 8; o <= 32; o <<= 1) {
-            a4.x += __shfl_xor(a4.x, o, 64); a4.y += __shfl_xor(a4.y, o, 64); a4.z += __shfl_xor(a4.z, o, 64); a4.w += __shfl_xor(a4.w, o, 64);
-        }
-        if ((lane >> 3) == 0) *reinterpret_cast<float4*>(red + wave * 32 + (lane & 7) * 4) = a4;      // this wave's share, rows 4 (lane % 8) ..
-    }
     if constexpr (KP > 1) {
         if constexpr (STAGE) __syncthreads();
         if (kp > 0) {
@@ -379,16 +298,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                     rbuf[((tp * (KP - 1) + (kp - 1)) * (T * MT) + t * MT + mt) * 64 + lane] = acc[t][mt];
         }
         __syncthreads();
-        if constexpr (XN == 2) {
-            if (kp == 0) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int m = mt * 16 + fr;
-                    const float ssum = ((red[(tp * KP) * 32 + m] + red[(tp * KP + 1) * 32 + m]) + red[(tp * KP + 2) * 32 + m]) + red[(tp * KP + 3) * 32 + m];
-                    xn_rs[mt] = 1.0f / sqrtf(ssum / (float)p.K + p.eps);
-                }
-            }
-        }
         if (kp == 0) {
 #pragma unroll
             for (int k = 1; k < KP; ++k)
@@ -418,9 +327,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     }
     float bestv[MT];
     int besti[MT];
-    float ss_row[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { bestv[mt] = -INFINITY; besti[mt] = 0x7fffffff; ss_row[mt] = 0.f; }
+    for (int mt = 0; mt < MT; ++mt) { bestv[mt] = -INFINITY; besti[mt] = 0x7fffffff; }
     if (active && kp == 0) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -430,7 +338,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float g = rbf(XN == 2 ? acc[0][mt][r] * xn_rs[mt] : acc[0][mt][r]), u = rbf(XN == 2 ? acc[1][mt][r] * xn_rs[mt] : acc[1][mt][r]);
+                    float g = rbf(acc[0][mt][r]), u = rbf(acc[1][mt][r]);
                     o[r] = rbf(silu_f(g)) * u;
                 }
                 uint2 v = {pack2(o[0], o[1]), pack2(o[2], o[3])};
@@ -441,10 +349,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                 const int n = tile * 16 + fg * 4;
                 bf16_t* optr = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n;
                 float o[4] = {acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3]};
-                if constexpr (XN == 2) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] *= xn_rs[mt];
-                }
                 if (MODE == GV_BIAS && p.bias) {
                     const uint2 b = ep_bias[mt];
                     o[0] += lo16(b.x); o[1] += hi16(b.x); o[2] += lo16(b.y); o[3] += hi16(b.y);
@@ -454,21 +358,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                     o[0] = lo16(rv.x) + rbf(o[0]); o[1] = hi16(rv.x) + rbf(o[1]);
                     o[2] = lo16(rv.y) + rbf(o[2]); o[3] = hi16(rv.y) + rbf(o[3]);
                 }
-                const uint2 packed = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
-                *reinterpret_cast<uint2*>(optr) = packed;
-                if constexpr (MODE == GV_RESID) {
-                    if (p.h_tiled) {      // the consumer GEMV normalises: fragment-ordered copy (times the norm weight when the consumer only
-                                          // applies the row scale, XN == 2) + this tile's share of the row's sum of squares
-                        const float h0 = lo16(packed.x), h1 = hi16(packed.x), h2 = lo16(packed.y), h3 = hi16(packed.y);
-                        uint2 hs = packed;
-                        if (p.xn_w) {
-                            const uint2 wv = ep_lnw;
-                            hs = uint2{pack2(h0 * lo16(wv.x), h1 * hi16(wv.x)), pack2(h2 * lo16(wv.y), h3 * hi16(wv.y))};
-                        }
-                        *reinterpret_cast<uint2*>(p.h_tiled + tiled_offset((size_t)m, (size_t)n, (size_t)p.ldo)) = hs;
-                        ss_row[mt] = (h0 * h0 + h1 * h1) + (h2 * h2 + h3 * h3);
-                    }
-                }
+                *reinterpret_cast<uint2*>(optr) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
             } else {
                 const int n = tile * 16 + fg * 4;
                 float* o = reinterpret_cast<float*>(p.out) + ((size_t)(MODE == GV_PARTIAL ? blockIdx.y : 0) * p.M + m) * p.N + n;
@@ -478,17 +368,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                     for (int r = 0; r < 4; ++r)
                         if (acc[0][mt][r] > bestv[mt]) { bestv[mt] = acc[0][mt][r]; besti[mt] = n + r; }
                 }
-            }
-        }
-    }
-    if constexpr (MODE == GV_RESID) {
-        if (p.h_tiled && active && kp == 0) {      // (whole wave: the four lane groups of a row hold its four column quads)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float v = ss_row[mt];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                if (fg == 0 && mt * 16 + fr < 32) p.ss_out[(size_t)tile * 32 + mt * 16 + fr] = (mt * 16 + fr < p.M) ? v : 0.f;
             }
         }
     }
@@ -685,7 +564,7 @@ int launch_32(hipStream_t s, const GemvArgs& a) {
 
 size_t stage_bytes(const GemvArgs& a) { return ((size_t)a.M * (a.K + 8) * 2 + 15) / 16 * 16; }
 
-template <int MODE, int MT, int KP, bool STAGE, int WAVES, bool F8 = false, int XN = 0>
+template <int MODE, int MT, int KP, bool STAGE, int WAVES, bool F8 = false>
 int launch_k(hipStream_t s, const GemvArgs& a) {
     constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;
     constexpr int TPB = WAVES / KP;
@@ -702,31 +581,20 @@ int launch_k(hipStream_t s, const GemvArgs& a) {
     if (smem > 160 * 1024) return -12;
     static size_t attr = 0;
     if (smem > 64 * 1024 && smem > attr) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemv<MODE, MT, KP, STAGE, WAVES, F8, XN>),
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemv<MODE, MT, KP, STAGE, WAVES, F8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (r != hipSuccess) return (int)r;
         attr = smem;
     }
-    hipLaunchKernelGGL((k_gemv<MODE, MT, KP, STAGE, WAVES, F8, XN>), grid, dim3(WAVES * 64), smem, s, a, ntiles);
+    hipLaunchKernelGGL((k_gemv<MODE, MT, KP, STAGE, WAVES, F8>), grid, dim3(WAVES * 64), smem, s, a, ntiles);
     SR_CHECK_LAUNCH();
     return 0;
 }
 
 // x can be staged in LDS when a whole padded copy fits and the prologue's row segmentation works
 bool can_stage(const GemvArgs& a) { return a.K % 512 == 0 && stage_bytes(a) + 1024 <= 150 * 1024; }
-// 16-wave blocks that stage x once for 4 weight tiles were measured SLOWER at M = 32 (qkv 30 vs 11 us, gate/up 34 vs
-// 29 us): a CU ingests only ~50-100 GB/s, so a serial 128-640 KB prologue per block costs more than the x re-reads it
-// saves, and only 172 of 256 CUs get a block.  Kept as a template parameter for experiments; not dispatched.
-bool use_big(const GemvArgs&, int) { return false; }
-
-// wide blocks (tuning hook SR_GEMV_W = 8 / 16, and GemvArgs.waves): ONE 16-row tile per block, K split over all of its waves.  For
-// N = 2048 outputs (o_proj, down-projection) that is still 128 blocks, but 2 - 4 x the loads in flight per CU, and the down-projection
-// needs no split over blocks (no float32 slabs, residual add in the epilogue)
-template <int MODE, int W>
-int launch_wide(hipStream_t s, const GemvArgs& a) {
-    if (a.K / 64 < 2 * W) return -22;
-    return a.M <= 16 ? launch_k<MODE, 1, W, false, W>(s, a) : launch_k<MODE, 2, W, false, W>(s, a);
-}
+// (16-wave blocks that stage x once for 4 weight tiles were measured SLOWER at M = 32 -- qkv 30 vs 11 us, gate/up 34 vs 29 us: a CU ingests
+// only ~50-100 GB/s, so a serial 128-640 KB prologue per block costs more than the x re-reads it saves, and only 172 of 256 CUs get a block.)
 
 template <int MODE, int KP, bool F8 = false>
 int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
@@ -743,12 +611,9 @@ int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
 // measured at M = 32 (us, 16-row / 32-row variant): LM head 187 / 140, down-projection with 4 slabs 17.4 / 13.4;
 // qkv 9.6 / 11.5, o_proj 9.2 / 9.9, gate/up 22.9 / 25.4 (the 32-row tiles halve the wave count of the small launches)
 bool use_32(const GemvArgs& a, int mode) {
-    static const char* env = getenv("SR_GEMV32");               // tuning hook (tools/bench_gemv.py): 0 = never, 2 = always
-    const int force = env ? atoi(env) : 1;
-    if (a.h_tiled || a.xn_w || a.ss_in) return false;           // the folded RMSNorm lives in the 16-row kernel only
     if (a.force32 && a.N % 32 == 0 && !a.norm_w) return true;
-    if (force == 0 || a.M <= 16 || a.N % 32 != 0 || a.norm_w) return false;
-    return force == 2 || mode == GV_F32 || (mode == GV_PARTIAL && a.ksplit >= 4);
+    if (a.M <= 16 || a.N % 32 != 0 || a.norm_w) return false;
+    return mode == GV_F32 || (mode == GV_PARTIAL && a.ksplit >= 4);
 }
 
 int gemv_f32_blocks(int N, int M, int K, int has_norm) {
@@ -784,20 +649,7 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     if (a.n_slabs > 0 && (!a.norm_w || !a.slabs || !a.x_out)) return -22;
     if (a.x_tiled && a.norm_w) return -22;                   // fragment-ordered x: the un-staged paths only
     if (a.out_tiled && (mode != GV_SWIGLU || (a.N / 2) % 64 != 0)) return -22;
-    if (a.ss_in && !a.xn_w) {        // deferred row scale (XN == 2): plain x = bf16(h * w_ln) rows from the producer, 1 / rms in the epilogue
-        if (a.norm_w || a.W8 || a.n_ss < 1 || a.n_ss > 128 || a.M > 32 || a.K / 64 < 8 || !(mode == GV_SWIGLU || mode == GV_BIAS)) return -22;
-        if (mode == GV_SWIGLU) return a.M <= 16 ? launch_k<GV_SWIGLU, 1, 4, false, 4, false, 2>(s, a) : launch_k<GV_SWIGLU, 2, 4, false, 4, false, 2>(s, a);
-        return a.M <= 16 ? launch_k<GV_BIAS, 1, 4, false, 4, false, 2>(s, a) : launch_k<GV_BIAS, 2, 4, false, 4, false, 2>(s, a);
-    }
-    if (a.xn_w && mode != GV_RESID) {        // on-the-fly RMSNorm of a fragment-ordered x (round 3): the 4-wave, K-split-by-4 bf16 kernels of the batch > 4 decode layer
-        if (!a.x_tiled || a.norm_w || a.W8 || !a.ss_in || a.n_ss < 1 || a.M > 32 || a.K / 64 < 8 || !(mode == GV_SWIGLU || mode == GV_BIAS)) return -22;
-        if (mode == GV_SWIGLU) return a.M <= 16 ? launch_k<GV_SWIGLU, 1, 4, false, 4, false, 1>(s, a) : launch_k<GV_SWIGLU, 2, 4, false, 4, false, 1>(s, a);
-        return a.M <= 16 ? launch_k<GV_BIAS, 1, 4, false, 4, false, 1>(s, a) : launch_k<GV_BIAS, 2, 4, false, 4, false, 1>(s, a);
-    }
-    if (a.h_tiled && (mode != GV_RESID || !a.ss_out || a.W8 || a.M > 32)) return -22;
     int want = mode == GV_F32 ? 1 : 4;
-    static const char* kp_env = getenv("SR_GEMV_KP");          // tuning hook for tools/bench_gemv.py
-    if (kp_env && mode != GV_F32) want = atoi(kp_env);
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
     if (a.W8) {          // fp8 weight stream (decode of the quantised LM linears); the in-block K split is always 4 there
         if (!a.w_scale || mode == GV_F32) return -22;
@@ -809,24 +661,6 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
             case GV_RESID: return launch_small<GV_RESID, 4, true>(s, a);
         }
         return -22;
-    }
-    {
-        const char* w_env = getenv("SR_GEMV_W");                 // tuning hook, read at every call
-        const int w = a.waves ? a.waves : (w_env ? atoi(w_env) : 0);
-        if ((w == 8 || w == 16) && !a.norm_w && mode != GV_F32 && (mode != GV_PARTIAL || a.ksplit == 1) && a.K / 64 >= 2 * w) {
-            if (w == 8) switch (mode) {
-                case GV_PARTIAL: return launch_wide<GV_PARTIAL, 8>(s, a);
-                case GV_SWIGLU: return launch_wide<GV_SWIGLU, 8>(s, a);
-                case GV_BIAS: return launch_wide<GV_BIAS, 8>(s, a);
-                case GV_RESID: return launch_wide<GV_RESID, 8>(s, a);
-            }
-            else switch (mode) {
-                case GV_PARTIAL: return launch_wide<GV_PARTIAL, 16>(s, a);
-                case GV_SWIGLU: return launch_wide<GV_SWIGLU, 16>(s, a);
-                case GV_BIAS: return launch_wide<GV_BIAS, 16>(s, a);
-                case GV_RESID: return launch_wide<GV_RESID, 16>(s, a);
-            }
-        }
     }
     if (use_32(a, mode)) {
         switch (mode) {

@@ -81,12 +81,6 @@ struct GemvArgs {
     int x_tiled;                            // x is stored fragment-ordered (tiled16x64 of a [ceil16(M), K] matrix, common.h): a wave's
                                             // x load is 1 KB contiguous instead of 16 rows x 64 B (batches > 4, no fused norm)
     int out_tiled;                          // SWIGLU: write the activation fragment-ordered (it is the next GEMV's x)
-    // ---- RMSNorm folded between two GEMVs at batches > 4 (round 3; replaces one k_rmsnorm_row launch per layer):
-    bf16_t* h_tiled;                        // RESID: the updated residual rows are ALSO stored fragment-ordered here (the consumer's x) ...
-    float* ss_out;                          // ... with the sum of squares of each row's 16 new values, [N / 16][32] (tile-major)
-    const bf16_t* xn_w; const float* ss_in; int n_ss;   // SWIGLU / BIAS, x_tiled: x is the RAW residual stream; it is normalised on the fly,
-                                            // x_norm = bf16(xn_w * bf16(x * rs)), rs from the n_ss partial sums per row (eps above)
-    int waves;                              // 8 / 16: one 16-row tile per block with K split over that many waves (0: the 4-wave default)
     int force32;                            // always the 32-row MFMA variant (whatever M): a row's result then does not depend on how many rows share the launch
 };
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode);

@@ -16,10 +16,6 @@ import numpy as np
 import torch
 
 
-import os as _os
-_MASK_FIRST_CHUNK = _os.environ.get("SR_MASK_FIRST_CHUNK", "0") == "1"      # A/B hook for the choice documented in _pump_overlap
-
-
 @dataclass
 class Request:
     ids: np.ndarray                       # int64 [S], image placeholders already expanded
@@ -296,11 +292,10 @@ class ContinuousBatcher:
             return
         busy = self.staged is not None and not self.staged[2].query()
         # The chunk under which the next admission gets staged is queued on the UNMASKED stream: its steps_per_poll steps own every CU and the
-        # admission's first GEMMs queue behind them.  Putting that chunk on the decode CU set instead (SR_MASK_FIRST_CHUNK=1: the admission
-        # starts at once, the chunk decodes on 160 CUs) was measured and is slower -- 76.8 vs 78.3 tiles/s, two runs each, same box: the
-        # admission is not on the critical path for that long, the decode rows are.
-        will_stage = _MASK_FIRST_CHUNK and self.staged is None and bool(self.pending) and bool(self.free_slots)
-        s = self._use_decode_stream(self.streams.decode if (busy or will_stage) else self.streams.decode_full)
+        # admission's first GEMMs queue behind them.  Putting that chunk on the decode CU set instead (the admission starts at once, the
+        # chunk decodes on 160 CUs) was measured and is slower -- 76.8 vs 78.3 tiles/s, two runs each, same box: the admission is not on
+        # the critical path for that long, the decode rows are.
+        s = self._use_decode_stream(self.streams.decode if busy else self.streams.decode_full)
         # (step-time calibration: a chunk with the chip to itself -- no admission in flight and none about to be staged under it)
         cal = (self._auto and not busy and not (self.staged is None and self.pending and self.free_slots)
                and self._step_ms is None and self._cal_step is None)
@@ -310,13 +305,13 @@ class ContinuousBatcher:
                 c0.record(s)
             t0 = self._mark()
             self.engine.rows_step(self.steps_per_poll, self.eos, self.pad_id)
-            self._span("decode_shared" if (busy or will_stage) else "decode", t0, self._mark())
+            self._span("decode_shared" if busy else "decode", t0, self._mark())
             if cal:
                 c1 = torch.cuda.Event(enable_timing=True)
                 c1.record(s)
                 self._cal_step = (c0, c1, self.steps_per_poll)
         self.stats["steps"] += self.steps_per_poll
-        self.stats["steps_shared"] += self.steps_per_poll if (busy or will_stage) else 0
+        self.stats["steps_shared"] += self.steps_per_poll if busy else 0
         if self.staged is None and self.pending and self.free_slots:
             self._stage()                              # the host side of the next admission is prepared while the chunk above runs
         with torch.cuda.stream(s):
