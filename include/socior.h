@@ -42,7 +42,8 @@ typedef struct sr_config {
     /* capacities that size the workspace */
     int32_t max_patches;         /* ViT rows (all images of one sr_vit_forward call) */
     int32_t max_prefill_tokens;  /* packed prompt tokens of one sr_prefill call */
-    int32_t max_batch;           /* KV-cache slots = concurrent sequences (<= 32) */
+    int32_t max_batch;           /* batch rows = concurrent sequences (<= 128; more than 32 rows: bf16 LM weights, decode GEMVs stream
+                                  * each weight tile once for all rows -- csrc/gemv.hip k_gemv32g) */
     int32_t max_ctx;             /* KV rows per slot, multiple of 64 (prompt + generated) */
     int32_t max_new_tokens;      /* rows of the device token log */
     /* storage of the LM decoder linears (q/k/v, o, gate/up, down) -- BASELINE.json configs[4]:

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm(bf16_t* x, const bf16_t* xin, c
     }
 }
 
-// Decode-sized variant (rows <= 64): one block of 256 threads per row, every load issued up front, so the launch is
+// Decode-sized variant (rows <= 128 = the engine's row cap): one block of 256 threads per row, every load issued up front, so the launch is
 // one memory latency deep instead of a wave-serial chain (6.5 -> ~3.5 us at 32 rows).  H <= 2048, H % 8 == 0.
 __global__ __launch_bounds__(256) void k_rmsnorm_row(bf16_t* x, const bf16_t* xin, const float* part, int ksplit,
                                                      const bf16_t* w, bf16_t* out, int rows, int H, float eps, int out_tiled) {
@@ -410,8 +410,9 @@ __global__ void k_admit_rows(AdmitArgs a) {
 }
 
 // continuous batching: rows named by the mask stop now (k_step then logs pads for them and leaves their cache slot alone)
-__global__ void k_rows_abort(unsigned mask, int* finished) {
-    if (threadIdx.x < 32 && ((mask >> threadIdx.x) & 1u)) finished[threadIdx.x] = 1;
+__global__ void k_rows_abort(uint4 mask, int* finished) {
+    const unsigned w[4] = {mask.x, mask.y, mask.z, mask.w};
+    if (threadIdx.x < 128 && ((w[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1u)) finished[threadIdx.x] = 1;
 }
 
 // fp8 weight quantisation, one block per 16-row tile of a fragment-ordered bf16 matrix (see kernels.h)
@@ -516,10 +517,10 @@ int launch_load2d(hipStream_t s, const void* src, int dtype, long long rows, lon
 int launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int H, float eps, int out_tiled, int per_wave) {
     if (rows <= 0) return 0;
     if (H % 8 != 0 || H > 64 * 8 * 12) return -22;
-    if (out_tiled && !(rows <= 64 && H <= 2048 && H % 64 == 0)) return -22;
+    if (out_tiled && !(rows <= 128 && H <= 2048 && H % 64 == 0)) return -22;
     dim3 g(cdiv(rows, 4)), b(256);
     if (out_tiled && per_wave) return -22;
-    if (!per_wave && rows <= 64 && H <= 2048) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps, out_tiled);
+    if (!per_wave && rows <= 128 && H <= 2048) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps, out_tiled);
     else if (H <= 2048) hipLaunchKernelGGL((k_rmsnorm<4>), g, b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps);
     else hipLaunchKernelGGL((k_rmsnorm<12>), g, b, 0, s, (bf16_t*)nullptr, x, (const float*)nullptr, 0, w, out, rows, H, eps);
     SR_CHECK_LAUNCH();
@@ -529,9 +530,9 @@ int launch_resid_rmsnorm(hipStream_t s, bf16_t* x, const float* part, int ksplit
                          int H, float eps, int out_tiled, int per_wave) {
     if (rows <= 0) return 0;
     if (H % 8 != 0 || H > 2048) return -22;
-    if (out_tiled && !(rows <= 64 && ksplit <= 4 && H % 64 == 0)) return -22;
+    if (out_tiled && !(rows <= 128 && ksplit <= 4 && H % 64 == 0)) return -22;
     if (out_tiled && per_wave) return -22;
-    if (!per_wave && rows <= 64 && ksplit <= 4) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), dim3(256), 0, s, x, (const bf16_t*)x, part, ksplit, w, out, rows, H, eps, out_tiled);
+    if (!per_wave && rows <= 128 && ksplit <= 4) hipLaunchKernelGGL(k_rmsnorm_row, dim3(rows), dim3(256), 0, s, x, (const bf16_t*)x, part, ksplit, w, out, rows, H, eps, out_tiled);
     else hipLaunchKernelGGL((k_rmsnorm<4>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, (const bf16_t*)x, part, ksplit, w, out, rows, H, eps);
     SR_CHECK_LAUNCH();
     return 0;
@@ -548,9 +549,9 @@ int launch_vit_rope(hipStream_t s, bf16_t* qkv, int n_rows, int n_heads, int hea
     SR_CHECK_LAUNCH();
     return 0;
 }
-int launch_rows_abort(hipStream_t s, unsigned row_mask, int* finished) {
-    if (!row_mask) return 0;
-    hipLaunchKernelGGL(k_rows_abort, dim3(1), dim3(64), 0, s, row_mask, finished);
+int launch_rows_abort(hipStream_t s, const unsigned row_mask[4], int* finished) {
+    if (!(row_mask[0] | row_mask[1] | row_mask[2] | row_mask[3])) return 0;
+    hipLaunchKernelGGL(k_rows_abort, dim3(1), dim3(128), 0, s, uint4{row_mask[0], row_mask[1], row_mask[2], row_mask[3]}, finished);
     SR_CHECK_LAUNCH();
     return 0;
 }

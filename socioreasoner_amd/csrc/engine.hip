@@ -27,6 +27,8 @@ namespace {
 
 thread_local char g_err[512] = "ok";
 
+constexpr int MAXB = 128;     // batch rows an engine can be configured with (the reference's request-level mode keeps up to 128 requests
+                              // in flight per worker: /root/reference/roll/distributed/scheduler/generate_scheduler.py:57)
 constexpr int SPLITK_KS = 4, SPLITK_ROWS = 1024;      // split-K of the residual GEMMs of small prefills (prefill_splitk below)
 struct VitBlockW { bf16_t *norm1, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2, *gu_w, *gu_b, *down_w, *down_b; };
 struct LmLayerW {
@@ -102,19 +104,19 @@ struct sr_engine {
     float* t_slabs = nullptr;    // [SPLITK_KS][SPLITK_ROWS][hidden] float32: split-K partial products of the residual GEMMs of a SMALL prefill
     int n_slots = 0;                         // KV-cache slots (>= max_batch): spare slots take admissions prefilled UNDER the running rows' decode
     int staged_n = 0, staged_off = 0;        // sequences of a staged admission that still wait for rows / already installed
-    bf16_t *d_xadm = nullptr, *d_xadm_n = nullptr; int* d_adm_slots = nullptr; int h_rows[32];
+    bf16_t *d_xadm = nullptr, *d_xadm_n = nullptr; int* d_adm_slots = nullptr; int h_rows[MAXB];
     unsigned char *t_q8 = nullptr, *t_qs = nullptr; int t_rows_pad = 0;     // lm_weight_dtype 2: MX-quantised GEMM input of the prefill
     int *t_src, *t_pos3, *t_slot, *t_idx, *t_lastrow;
     AttnWork* t_work;
     // ---- decode state (device)
     bf16_t *d_xa, *d_xb, *d_xn, *d_qkv, *d_attn, *d_act, *d_scores;    // d_xa / d_xb: residual stream ping-pong
     float *d_logits, *d_slabs, *d_amax_val;
-    float* d_row_cs = nullptr;               // [32][128] rotary cos | sin of every row's current position (k_step -> decode attention)
+    float* d_row_cs = nullptr;               // [MAXB][128] rotary cos | sin of every row's current position (k_step -> decode attention)
     int *d_amax_idx, *d_cur_tok, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
     int n_part = 0;      // LM-head blocks = partial argmax entries per row
     // continuous batching (sr_rows_*): admission scratch so that a prefill never touches the pending tokens of running rows
     float *d_logits_adm = nullptr, *d_amax_val_adm = nullptr;
-    int *d_amax_idx_adm = nullptr, *d_row_limit = nullptr, *d_ngen = nullptr, *d_adm = nullptr;   // d_adm: [rows | ctx | pos | limit | first_tok] x 32
+    int *d_amax_idx_adm = nullptr, *d_row_limit = nullptr, *d_ngen = nullptr, *d_adm = nullptr;   // d_adm: [rows | ctx | pos | limit | first_tok] x MAXB
     bool rows_mode = false;
     bool finalized = false;        // sr_finalize_weights ran (fp8 mode: the LM linears are quantised)
     bf16_t *kcache, *vtcache;
@@ -133,7 +135,7 @@ struct sr_engine {
     hipGraphExec_t step_graph[2] = {nullptr, nullptr};   // sr_decode_step: [0] engine-greedy token, [1] caller-chosen token
     int step_graph_B[2] = {-1, -1};
     long long *d_chosen = nullptr, *d_next = nullptr, *d_sampled = nullptr;
-    unsigned* d_seen = nullptr;    // [32][seen_words] token bitmask for the repetition penalty
+    unsigned* d_seen = nullptr;    // [MAXB][seen_words] token bitmask for the repetition penalty
     int seen_words = 0;
     // continuous batching with sampling (sr_rows_sampling): parameters shared by all rows; 0 temperature = greedy
     float rows_temp = 0.f, rows_topp = 1.f; int rows_topk = 0; unsigned rows_seed = 0, adm_count = 0;
@@ -182,8 +184,9 @@ const char* validate(const sr_config& c) {
     if (c.t_hidden % 64 || c.t_vocab % 16) return "t_hidden % 64, t_vocab % 16";
     if (c.t_heads % c.t_kv_heads || c.t_heads / c.t_kv_heads > 16) return "GQA group must divide and be <= 16";
     if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] != 64) return "mrope_section must sum to 64";
-    if (c.max_batch < 1 || c.max_batch > 32) return "max_batch in 1..32";
-    if (c.kv_slots != 0 && (c.kv_slots < c.max_batch || c.kv_slots > 64)) return "kv_slots 0 (= max_batch) or max_batch..64";
+    if (c.max_batch < 1 || c.max_batch > MAXB) return "max_batch in 1..128";
+    if (c.kv_slots != 0 && (c.kv_slots < c.max_batch || c.kv_slots > 2 * MAXB)) return "kv_slots 0 (= max_batch) or max_batch..256";
+    if (c.max_batch > 32 && c.lm_weight_dtype != 0) return "more than 32 batch rows: bf16 LM weights only (the fp8 decode stream has no row-group kernel)";
     if (c.max_ctx < 64 || c.max_ctx % 64) return "max_ctx multiple of 64";
     if (c.lm_weight_dtype < 0 || c.lm_weight_dtype > 2) return "lm_weight_dtype 0 (bf16), 1 (fp8 e4m3 weights, per-channel scale) or 2 (1 + MX fp8 activations in prefill)";
     if (c.lm_weight_dtype == 2 && (c.t_hidden % 256 || ((c.t_heads + 2 * c.t_kv_heads) * 128) % 256 || c.t_hidden / 128 < 2))
@@ -296,7 +299,7 @@ void carve(sr_engine* e) {
     e->t_pos3 = ar.take<int>(3 * TP);
     e->t_slot = ar.take<int>(TP);
     e->t_idx = ar.take<int>(TP);
-    e->t_lastrow = ar.take<int>(32);
+    e->t_lastrow = ar.take<int>(MAXB);
     e->t_work = ar.take<AttnWork>(TP / 64 + 64);
     e->t_slabs = ar.take<float>((size_t)SPLITK_KS * std::min<size_t>(TP, SPLITK_ROWS) * c.t_hidden);
 
@@ -317,25 +320,25 @@ void carve(sr_engine* e) {
     e->d_logits_adm = ar.take<float>(B * c.t_vocab);
     e->d_amax_val_adm = ar.take<float>(B * e->n_part);
     e->d_amax_idx_adm = ar.take<int>(B * e->n_part);
-    e->d_row_limit = ar.take<int>(32);
-    e->d_row_cs = ar.take<float>(32 * 128);
-    e->d_ngen = ar.take<int>(32);
-    e->d_adm = ar.take<int>(5 * 32);
-    e->d_adm_slots = ar.take<int>(32);
+    e->d_row_limit = ar.take<int>(MAXB);
+    e->d_row_cs = ar.take<float>(MAXB * 128);
+    e->d_ngen = ar.take<int>(MAXB);
+    e->d_adm = ar.take<int>(5 * MAXB);
+    e->d_adm_slots = ar.take<int>(MAXB);
     e->d_xadm = ar.take<bf16_t>(B * H);           // admission scratch of its own: an admission may run on another stream while rows decode
-    e->d_xadm_n = ar.take<bf16_t>((size_t)32 * H);      // (the admission's 32-row LM-head GEMV addresses two 16-row groups whatever the batch)
-    e->d_sampled = ar.take<long long>(32);
-    e->d_adm_pick = ar.take<long long>(32);
+    e->d_xadm_n = ar.take<bf16_t>((size_t)std::max<size_t>(32, Bp) * H);      // (the admission's 32-row LM-head GEMV addresses two 16-row groups whatever the batch)
+    e->d_sampled = ar.take<long long>(MAXB);
+    e->d_adm_pick = ar.take<long long>(MAXB);
     e->seen_words = (c.t_vocab + 31) / 32;
-    e->d_seen = ar.take<unsigned>((size_t)32 * e->seen_words);
-    e->d_chosen = ar.take<long long>(32);
-    e->d_next = ar.take<long long>(32);
-    e->d_cur_tok = ar.take<int>(32);
-    e->d_ctx_len = ar.take<int>(32);
-    e->d_pos = ar.take<int>(32);
-    e->d_finished = ar.take<int>(32);
-    e->d_step = ar.take<int>(32);
-    e->d_slots = ar.take<int>(32);
+    e->d_seen = ar.take<unsigned>((size_t)MAXB * e->seen_words);
+    e->d_chosen = ar.take<long long>(MAXB);
+    e->d_next = ar.take<long long>(MAXB);
+    e->d_cur_tok = ar.take<int>(MAXB);
+    e->d_ctx_len = ar.take<int>(MAXB);
+    e->d_pos = ar.take<int>(MAXB);
+    e->d_finished = ar.take<int>(MAXB);
+    e->d_step = ar.take<int>(MAXB);
+    e->d_slots = ar.take<int>(MAXB);
     e->d_eos = ar.take<int>(32);
     e->d_tokens = ar.take<int>(B * c.max_new_tokens);
     e->n_slots = c.kv_slots ? c.kv_slots : c.max_batch;
@@ -345,7 +348,7 @@ void carve(sr_engine* e) {
 
     // control staging: ViT needs NP*(8 + 4*hd) + work lists; prefill needs ~24 B per token + work lists
     e->stage_bytes = NP * (8 + 4 * (size_t)e->v_hd) + (NP / 4 + NP / 64 + NP / 128 + 192) * sizeof(AttnWork) + TP * 28 +
-                     (TP / 64 + 64) * sizeof(AttnWork) + 4096;
+                     (TP / 64 + 64) * sizeof(AttnWork) + 4096 + 5 * MAXB * sizeof(int);
     e->d_stage = ar.take<char>(e->stage_bytes);
 }
 
@@ -925,7 +928,7 @@ static int commit_admission(sr_engine* e, const int32_t* rows, int n, hipStream_
     for (int i = 0; i < n; ++i) e->h_rows[off + i] = rows[i];
     SR_TRY((int)hipMemcpyAsync(e->d_adm + off, e->h_rows + off, (size_t)n * 4, hipMemcpyHostToDevice, s));
     const int MB = c.max_batch;
-    AdmitArgs aa{e->d_adm + off, e->d_adm + 32 + off, e->d_adm + 64 + off, e->d_adm + 96 + off, e->d_adm + 128 + off, n,
+    AdmitArgs aa{e->d_adm + off, e->d_adm + MAXB + off, e->d_adm + 2 * MAXB + off, e->d_adm + 3 * MAXB + off, e->d_adm + 4 * MAXB + off, n,
                  e->d_ctx_len, e->d_pos, e->d_slots, e->d_finished, e->d_step, e->d_row_limit, e->d_ngen,
                  e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(c.t_vocab, MB, c.t_hidden, fused_norms(e, MB) ? 1 : 0), e->d_adm_slots + off};
     SR_TRY(launch_admit_rows(s, aa));
@@ -963,8 +966,9 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
     int* h_slot = h_pos + 3 * n_tok;
     int* h_idx = h_slot + n_tok;
     int* h_last = h_idx + n_tok;
-    int* h_state = h_last + 32;             // [ctx_len(32) | pos(32) | slots(32) | limit(32)]
-    AttnWork* h_work = reinterpret_cast<AttnWork*>(((uintptr_t)(h_state + 128) + 15) & ~(uintptr_t)15);
+    int* h_state = h_last + MAXB;           // [ctx_len | pos | slots | limit] x MAXB
+    for (int i = 0; i < 4 * MAXB; ++i) h_state[i] = 0;
+    AttnWork* h_work = reinterpret_cast<AttnWork*>(((uintptr_t)(h_state + 4 * MAXB) + 15) & ~(uintptr_t)15);
     int n_work = 0, img_row = 0, t0 = 0;
     const int KVH = c.t_kv_heads;
     for (int b = 0; b < B; ++b) {
@@ -989,10 +993,10 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
             h_work[n_work++] = AttnWork{t0 + q0, S, q0, slots[b] * KVH * c.max_ctx, (long long)slots[b] * KVH * 128 * c.max_ctx};
         h_last[b] = t0 + S - 1;
         h_state[b] = S;                     // keys in the cache; k_step_advance adds the new token before each forward
-        h_state[32 + b] = (int)maxpos;      // decode positions continue at max+1 on all three axes
+        h_state[MAXB + b] = (int)maxpos;      // decode positions continue at max+1 on all three axes
                                             // (reference rule: roll/utils/functionals.py:816-818)
-        h_state[64 + b] = slots[b];
-        h_state[96 + b] = limits ? limits[b] : 0x7f7f7f7f;
+        h_state[2 * MAXB + b] = slots[b];
+        h_state[3 * MAXB + b] = limits ? limits[b] : 0x7f7f7f7f;
         t0 += S;
     }
     if (image_embeds && img_row != n_image_rows)
@@ -1005,21 +1009,21 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
     SR_TRY((int)hipMemcpyAsync(e->t_pos3, dmirror(h_pos), (size_t)n_tok * 12, hipMemcpyDeviceToDevice, s));
     SR_TRY((int)hipMemcpyAsync(e->t_slot, dmirror(h_slot), (size_t)n_tok * 4, hipMemcpyDeviceToDevice, s));
     SR_TRY((int)hipMemcpyAsync(e->t_idx, dmirror(h_idx), (size_t)n_tok * 4, hipMemcpyDeviceToDevice, s));
-    SR_TRY((int)hipMemcpyAsync(e->t_lastrow, dmirror(h_last), 32 * 4, hipMemcpyDeviceToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->t_lastrow, dmirror(h_last), MAXB * 4, hipMemcpyDeviceToDevice, s));
     SR_TRY((int)hipMemcpyAsync(e->t_work, dmirror(h_work), n_work * sizeof(AttnWork), hipMemcpyDeviceToDevice, s));
     if (!limits) {       // static batch: rows 0..B-1 are (re)initialised, all other rows are dropped
-        SR_TRY((int)hipMemcpyAsync(e->d_ctx_len, dmirror(h_state), 32 * 4, hipMemcpyDeviceToDevice, s));
-        SR_TRY((int)hipMemcpyAsync(e->d_pos, dmirror(h_state + 32), 32 * 4, hipMemcpyDeviceToDevice, s));
-        SR_TRY((int)hipMemcpyAsync(e->d_slots, dmirror(h_state + 64), 32 * 4, hipMemcpyDeviceToDevice, s));
-        SR_TRY((int)hipMemsetAsync(e->d_finished, 0, 32 * 4, s));
-        SR_TRY((int)hipMemsetAsync(e->d_step, 0, 32 * 4, s));
-        SR_TRY((int)hipMemsetAsync(e->d_row_limit, 0x7f, 32 * 4, s));
-        SR_TRY((int)hipMemsetAsync(e->d_ngen, 0, 32 * 4, s));
+        SR_TRY((int)hipMemcpyAsync(e->d_ctx_len, dmirror(h_state), MAXB * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemcpyAsync(e->d_pos, dmirror(h_state + MAXB), MAXB * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemcpyAsync(e->d_slots, dmirror(h_state + 2 * MAXB), MAXB * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemsetAsync(e->d_finished, 0, MAXB * 4, s));
+        SR_TRY((int)hipMemsetAsync(e->d_step, 0, MAXB * 4, s));
+        SR_TRY((int)hipMemsetAsync(e->d_row_limit, 0x7f, MAXB * 4, s));
+        SR_TRY((int)hipMemsetAsync(e->d_ngen, 0, MAXB * 4, s));
     } else {             // admission: [rows | ctx | pos | limit] for the new rows only; installed after the LM head below
-        SR_TRY((int)hipMemcpyAsync(e->d_adm_slots, dmirror(h_state + 64), 32 * 4, hipMemcpyDeviceToDevice, s));
-        SR_TRY((int)hipMemcpyAsync(e->d_adm + 32, dmirror(h_state), 32 * 4, hipMemcpyDeviceToDevice, s));
-        SR_TRY((int)hipMemcpyAsync(e->d_adm + 64, dmirror(h_state + 32), 32 * 4, hipMemcpyDeviceToDevice, s));
-        SR_TRY((int)hipMemcpyAsync(e->d_adm + 96, dmirror(h_state + 96), 32 * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemcpyAsync(e->d_adm_slots, dmirror(h_state + 2 * MAXB), MAXB * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemcpyAsync(e->d_adm + MAXB, dmirror(h_state), MAXB * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemcpyAsync(e->d_adm + 2 * MAXB, dmirror(h_state + MAXB), MAXB * 4, hipMemcpyDeviceToDevice, s));
+        SR_TRY((int)hipMemcpyAsync(e->d_adm + 3 * MAXB, dmirror(h_state + 3 * MAXB), MAXB * 4, hipMemcpyDeviceToDevice, s));
     }
 
     // ---- forward over the packed tokens
@@ -1093,7 +1097,7 @@ static int prefill_impl(sr_engine* e, const int64_t* ids, const int64_t* pos3, c
         SR_TRY(launch_gemv(s, g, GV_F32));
     }
     if (logits_out) SR_TRY((int)hipMemcpyAsync(logits_out, e->d_logits_adm, (size_t)B * c.t_vocab * 4, hipMemcpyDeviceToDevice, s));
-    SR_TRY(launch_argmax(s, e->d_logits_adm, B, c.t_vocab, e->d_adm + 128));
+    SR_TRY(launch_argmax(s, e->d_logits_adm, B, c.t_vocab, e->d_adm + 4 * MAXB));
     if (e->rows_temp > 0.f) {      // sampling mode: the first token of the new rows is drawn from the admission logits
         SampleArgs sa{e->d_logits_adm, c.t_vocab, B, 1.0f / e->rows_temp, e->rows_topk, e->rows_topp, 1.0f, nullptr, e->seen_words,
                       e->rows_seed ^ (0x9E3779B9u * ++e->adm_count), nullptr, e->d_adm_pick, nullptr, 0, 0};
@@ -1113,8 +1117,8 @@ int sr_prefill(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int3
 int sr_forward_logits(sr_engine* e, const int64_t* ids, const int64_t* pos3, const int32_t* seq_lens, int B, const void* image_embeds,
                       int n_image_rows, float* all_logits_out, void* stream) {
     if (!all_logits_out) return fail(e, -22, "sr_forward_logits: null output");
-    if (!e || B < 1 || B > 32) return fail(e, -22, "sr_forward_logits: bad batch");
-    int32_t slots[32];
+    if (!e || B < 1 || B > MAXB) return fail(e, -22, "sr_forward_logits: bad batch");
+    int32_t slots[MAXB];
     for (int b = 0; b < B; ++b) slots[b] = b;
     return prefill_impl(e, ids, pos3, seq_lens, slots, B, image_embeds, n_image_rows, nullptr, stream, nullptr, all_logits_out);
 }
@@ -1125,15 +1129,15 @@ int sr_rows_begin(sr_engine* e, void* stream) {
     enter(e);
     if (!e) return fail(e, -22, "sr_rows_begin: null engine");
     hipStream_t s = (hipStream_t)stream;
-    std::vector<int> st(5 * 32, 0);
-    for (int i = 0; i < 32; ++i) { st[i] = 1; st[64 + i] = 1; st[96 + i] = 0; st[128 + i] = i; }   // ctx 1 | pos 0 | finished 1 | step 0 | slots
-    SR_TRY((int)hipMemcpyAsync(e->d_ctx_len, st.data(), 128, hipMemcpyHostToDevice, s));
-    SR_TRY((int)hipMemcpyAsync(e->d_pos, st.data() + 32, 128, hipMemcpyHostToDevice, s));
-    SR_TRY((int)hipMemcpyAsync(e->d_finished, st.data() + 64, 128, hipMemcpyHostToDevice, s));
-    SR_TRY((int)hipMemcpyAsync(e->d_step, st.data() + 96, 128, hipMemcpyHostToDevice, s));
-    SR_TRY((int)hipMemcpyAsync(e->d_slots, st.data() + 128, 128, hipMemcpyHostToDevice, s));
-    SR_TRY((int)hipMemsetAsync(e->d_row_limit, 0, 128, s));
-    SR_TRY((int)hipMemsetAsync(e->d_ngen, 0, 128, s));
+    std::vector<int> st(5 * MAXB, 0);
+    for (int i = 0; i < MAXB; ++i) { st[i] = 1; st[2 * MAXB + i] = 1; st[3 * MAXB + i] = 0; st[4 * MAXB + i] = i; }   // ctx 1 | pos 0 | finished 1 | step 0 | slots
+    SR_TRY((int)hipMemcpyAsync(e->d_ctx_len, st.data(), MAXB * 4, hipMemcpyHostToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->d_pos, st.data() + MAXB, MAXB * 4, hipMemcpyHostToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->d_finished, st.data() + 2 * MAXB, MAXB * 4, hipMemcpyHostToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->d_step, st.data() + 3 * MAXB, MAXB * 4, hipMemcpyHostToDevice, s));
+    SR_TRY((int)hipMemcpyAsync(e->d_slots, st.data() + 4 * MAXB, MAXB * 4, hipMemcpyHostToDevice, s));
+    SR_TRY((int)hipMemsetAsync(e->d_row_limit, 0, MAXB * 4, s));
+    SR_TRY((int)hipMemsetAsync(e->d_ngen, 0, MAXB * 4, s));
     SR_TRY((int)hipStreamSynchronize(s));
     e->rows_mode = true;
     e->staged_n = e->staged_off = 0;
@@ -1415,10 +1419,10 @@ int sr_rows_read(sr_engine* e, int row, int32_t* dev_tokens_out, int n, void* st
 int sr_rows_abort(sr_engine* e, const int32_t* host_rows, int n, void* stream) {
     enter(e);
     if (!e || !e->rows_mode || !host_rows || n < 0) return fail(e, -22, "sr_rows_abort: bad argument / not in rows mode");
-    unsigned mask = 0;
+    unsigned mask[MAXB / 32] = {};
     for (int i = 0; i < n; ++i) {
-        if (host_rows[i] < 0 || host_rows[i] >= e->c.max_batch || host_rows[i] >= 32) return fail(e, -22, "sr_rows_abort: row %d out of range", host_rows[i]);
-        mask |= 1u << host_rows[i];
+        if (host_rows[i] < 0 || host_rows[i] >= e->c.max_batch || host_rows[i] >= MAXB) return fail(e, -22, "sr_rows_abort: row %d out of range", host_rows[i]);
+        mask[host_rows[i] >> 5] |= 1u << (host_rows[i] & 31);
     }
     SR_TRY(launch_rows_abort((hipStream_t)stream, mask, e->d_finished));
     return 0;

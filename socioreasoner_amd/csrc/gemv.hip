@@ -545,6 +545,194 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- batches 33..128
+// The same 32-row-tile kernel for G groups of 32 batch rows (round 4: the reference's request-level mode keeps up to 128 requests in flight
+// per worker, /root/reference/roll/distributed/scheduler/generate_scheduler.py:57): a wave streams its weight tile ONCE and multiplies it with
+// the x fragments of every group (G accumulators), so the bytes per decode step stay those of batch 32 while the rows per step double or
+// quadruple.  The x fragments of all groups ride the ring with the weights (ring depth 3 at G = 2, 2 at G = 4: 16 registers per group and
+// slot); at G = 4 a wave reads 4 x as many x bytes (from L2) as weight bytes (from HBM).  Per row the arithmetic is that of k_gemv32 (same
+// MFMA, same k order, same split over waves and the same reduction order), so a row's result does not depend on which group it sits in.
+template <int MODE, int KP, int G>
+__global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int ntiles32) {
+    constexpr int WAVES = 4, TPB = WAVES / KP, U = (G <= 2) ? 3 : 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, half = (lane >> 4) & 1, kg = lane >> 5, m0 = lane & 31;
+    const int tp = wave / KP, kp = wave % KP;
+    const int tile = blockIdx.x * TPB + tp;
+    const bool active = tile < ntiles32;
+    const int nchunks = p.K / 64;
+    const int ks = (MODE == GV_PARTIAL) ? p.ksplit : 1;
+    const int per = (nchunks + ks * KP - 1) / (ks * KP);
+    const int c0 = min(((MODE == GV_PARTIAL ? blockIdx.y : 0) * KP + kp) * per, nchunks);
+    const int cend = min(c0 + per, nchunks);
+    const int t16 = (active ? tile : 0) * 2 + half;
+    const bf16_t* wbase = p.w_tiled ? p.W + (size_t)t16 * nchunks * 1024 + kg * 512 + fr * 8
+                                    : p.W + (size_t)(t16 * 16 + fr) * p.K + kg * 8;
+    const size_t w_c = p.w_tiled ? 1024 : 64, w_s = p.w_tiled ? 128 : 16;
+    // x of row group g = x of group 0 + g * x_g elements (fragment order: two 16-row tiles further; row-major: 32 rows further).  Fragment-
+    // ordered x holds whole 16-row groups: rows beyond ceil16(M) do not exist -- never read them (m_rd); row-major x: rows beyond M
+    const bf16_t* xbase = p.x_tiled ? p.x + ((size_t)(m0 >> 4) * nchunks * 2 + kg) * 512 + (m0 & 15) * 8 : p.x + (size_t)m0 * p.ldx + kg * 8;
+    const size_t x_c = p.x_tiled ? 1024 : 64, x_s = p.x_tiled ? 128 : 16, x_g = p.x_tiled ? (size_t)nchunks * 2048 : (size_t)32 * p.ldx;
+    const int m_rd = p.x_tiled ? (p.M + 15) / 16 * 16 : p.M;
+    u32x4 w[U][4], xv[U][G][4];
+    auto fill = [&](int u, int c) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) w[u][st] = ldg_nt(wbase + (size_t)c * w_c + st * w_s);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+                xv[u][g][st] = (m0 + 32 * g < m_rd) ? *reinterpret_cast<const u32x4*>(xbase + g * x_g + (size_t)c * x_c + st * x_s) : u32x4{0, 0, 0, 0};
+        }
+    };
+    f32x16 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c0 + u < cend) fill(u, c0 + u);
+        for (int c = c0; c < cend; c += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (c + u < cend) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(w[u][st]), as_frag(xv[u][g][st]), acc[g], 0, 0, 0);
+                    if (c + U + u < cend) fill(u, c + U + u);
+                }
+            }
+        }
+    }
+    if constexpr (KP > 1) {
+        f32x16* rbuf = reinterpret_cast<f32x16*>(smem);          // [TPB][KP-1][G][64]
+        if (kp > 0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) rbuf[((tp * (KP - 1) + (kp - 1)) * G + g) * 64 + lane] = acc[g];
+        }
+        __syncthreads();
+        if (kp == 0) {
+#pragma unroll
+            for (int k = 1; k < KP; ++k)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const f32x16 o = rbuf[((tp * (KP - 1) + (k - 1)) * G + g) * 64 + lane];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[g][i] += o[i];
+                }
+        }
+    }
+    float bestv[G];
+    int besti[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { bestv[g] = -INFINITY; besti[g] = 0x7fffffff; }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int m = m0 + 32 * g;
+        if (!(active && kp == 0 && m < p.M)) continue;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int nl = 8 * g4 + 4 * kg;
+            if constexpr (MODE == GV_SWIGLU) {
+                if (g4 < 2) {
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float gt = rbf(acc[g][g4 * 4 + r]), up = rbf(acc[g][(g4 + 2) * 4 + r]);
+                        o[r] = rbf(silu_f(gt)) * up;
+                    }
+                    bf16_t* ob = reinterpret_cast<bf16_t*>(p.out);
+                    *reinterpret_cast<uint2*>(ob + (p.out_tiled ? tiled_offset((size_t)m, (size_t)(tile * 16 + nl), (size_t)(p.N / 2))
+                                                                : (size_t)m * (p.N / 2) + tile * 16 + nl)) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                }
+            } else if constexpr (MODE == GV_BIAS || MODE == GV_RESID) {
+                const int n = tile * 32 + nl;
+                bf16_t* optr = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo + n;
+                float o[4] = {acc[g][g4 * 4], acc[g][g4 * 4 + 1], acc[g][g4 * 4 + 2], acc[g][g4 * 4 + 3]};
+                if (MODE == GV_BIAS && p.bias) {
+                    const uint2 b = *reinterpret_cast<const uint2*>(p.bias + n);
+                    o[0] += lo16(b.x); o[1] += hi16(b.x); o[2] += lo16(b.y); o[3] += hi16(b.y);
+                }
+                if constexpr (MODE == GV_RESID) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(optr);
+                    o[0] = lo16(rv.x) + rbf(o[0]); o[1] = hi16(rv.x) + rbf(o[1]);
+                    o[2] = lo16(rv.y) + rbf(o[2]); o[3] = hi16(rv.y) + rbf(o[3]);
+                }
+                *reinterpret_cast<uint2*>(optr) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+            } else {
+                const int n = tile * 32 + nl;
+                float* o = reinterpret_cast<float*>(p.out) + ((size_t)(MODE == GV_PARTIAL ? blockIdx.y : 0) * p.M + m) * p.N + n;
+                *reinterpret_cast<float4*>(o) = float4{acc[g][g4 * 4], acc[g][g4 * 4 + 1], acc[g][g4 * 4 + 2], acc[g][g4 * 4 + 3]};
+                if constexpr (MODE == GV_F32) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (acc[g][g4 * 4 + r] > bestv[g] || (acc[g][g4 * 4 + r] == bestv[g] && n + r < besti[g])) { bestv[g] = acc[g][g4 * 4 + r]; besti[g] = n + r; }
+                }
+            }
+        }
+    }
+    if constexpr (MODE == GV_F32) {
+        if (p.amax_val) {                                          // KP == 1: smem is free
+            float* av = reinterpret_cast<float*>(smem);            // [WAVES][32 G]
+            int* ai = reinterpret_cast<int*>(av + WAVES * 32 * G);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float bv = bestv[g];
+                int bi = besti[g];
+                const float ov = __shfl_xor(bv, 32, 64);
+                const int oi = __shfl_xor(bi, 32, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                if (kg == 0) { av[wave * 32 * G + 32 * g + m0] = bv; ai[wave * 32 * G + 32 * g + m0] = bi; }
+            }
+            __syncthreads();
+            if (tid < p.M) {
+                float bv = av[tid];
+                int bi = ai[tid];
+                for (int w2 = 1; w2 < WAVES; ++w2) {
+                    const float v2 = av[w2 * 32 * G + tid];
+                    const int i2 = ai[w2 * 32 * G + tid];
+                    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+                }
+                p.amax_val[(size_t)tid * gridDim.x + blockIdx.x] = bv;
+                p.amax_idx[(size_t)tid * gridDim.x + blockIdx.x] = bi;
+            }
+        }
+    }
+}
+
+template <int MODE, int KP, int G>
+int launch_32g(hipStream_t s, const GemvArgs& a) {
+    constexpr int TPB = 4 / KP;
+    const int ntiles = a.N / 32;
+    dim3 grid(cdiv(ntiles, TPB), MODE == GV_PARTIAL ? a.ksplit : 1);
+    size_t smem = (size_t)TPB * (KP > 1 ? KP - 1 : 0) * G * 64 * sizeof(f32x16);
+    if (smem < (size_t)4 * 32 * G * 8) smem = (size_t)4 * 32 * G * 8;
+    hipLaunchKernelGGL((k_gemv32g<MODE, KP, G>), grid, dim3(256), smem, s, a, ntiles);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+template <int MODE, int G>
+int launch_32g_kp(hipStream_t s, const GemvArgs& a, int kp) {
+    if constexpr (MODE == GV_F32) return launch_32g<MODE, 1, G>(s, a);
+    else return kp == 4 ? launch_32g<MODE, 4, G>(s, a) : kp == 2 ? launch_32g<MODE, 2, G>(s, a) : launch_32g<MODE, 1, G>(s, a);
+}
+template <int G>
+int launch_32g_mode(hipStream_t s, const GemvArgs& a, int mode, int kp) {
+    switch (mode) {
+        case GV_PARTIAL: return launch_32g_kp<GV_PARTIAL, G>(s, a, kp);
+        case GV_SWIGLU: return launch_32g_kp<GV_SWIGLU, G>(s, a, kp);
+        case GV_F32: return launch_32g_kp<GV_F32, G>(s, a, kp);
+        case GV_BIAS: return launch_32g_kp<GV_BIAS, G>(s, a, kp);
+        case GV_RESID: return launch_32g_kp<GV_RESID, G>(s, a, kp);
+    }
+    return -22;
+}
+
 // Measured and dropped (round 2): sharing x through LDS at batches 5..32 -- the 4 waves of a block own 4 DIFFERENT weight tiles
 // over the SAME k range, the block stages each 64-wide x chunk once (double-buffered groups of 4 chunks, one barrier per group), so
 // the loads per weight chunk drop from 2 + 4 to 2 + 1/4.  Correct, but slower everywhere: gate/up 25.3 vs 23.1 us at M = 32 (22.0 vs
@@ -641,7 +829,14 @@ int gemv_pick_kp(int K, int ksplit, int want) {
 
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     if (a.M <= 0) return 0;
-    if (a.M > 32 || a.K % 64 != 0 || a.N % 16 != 0) return -22;
+    if (a.M > 128 || a.K % 64 != 0 || a.N % 16 != 0) return -22;
+    if (a.M > 32) {      // 33..128 rows: the 32-row-tile kernel over 2 / 4 row groups per weight pass (bf16 stream, no fused norm)
+        if (a.N % 32 != 0 || a.norm_w || a.W8 || a.n_slabs) return -22;
+        if (mode == GV_PARTIAL && (a.ksplit < 1 || a.ksplit > a.K / 64)) return -22;
+        if (a.out_tiled && (mode != GV_SWIGLU || (a.N / 2) % 64 != 0)) return -22;
+        const int kp32 = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, mode == GV_F32 ? 1 : 4);
+        return a.M <= 64 ? launch_32g_mode<2>(s, a, mode, kp32) : launch_32g_mode<4>(s, a, mode, kp32);
+    }
     if (mode == GV_SWIGLU && a.N % 32 != 0) return -22;
     if (mode == GV_PARTIAL && (a.ksplit < 1 || a.ksplit > a.K / 64)) return -22;
     if (a.norm_w && !(mode == GV_BIAS || mode == GV_SWIGLU || mode == GV_F32)) return -22;

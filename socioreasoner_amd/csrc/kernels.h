@@ -190,7 +190,7 @@ struct AdmitArgs {
     const int* kv_slot;         // KV-cache slot of each admitted sequence (null: slot = row)
 };
 int launch_admit_rows(hipStream_t s, const AdmitArgs& a);
-int launch_rows_abort(hipStream_t s, unsigned row_mask, int* finished);      // finished[b] = 1 for every bit b of row_mask (rows < 32)
+int launch_rows_abort(hipStream_t s, const unsigned row_mask[4], int* finished);      // finished[b] = 1 for every bit b of the 128-bit row mask
 // ------------------------------------------------------------------ sample.hip
 struct SampleArgs {
     const float* logits; int V; int B;      // float32 [B, V]

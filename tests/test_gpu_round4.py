@@ -443,3 +443,48 @@ def test_batched_iou_counts_bit_exact(n, h, w):
     got = raster.iou_counts_batched(dp_, dg).cpu().tolist()
     for i in range(n):
         assert got[i] == list(R.iou_counts(p[i], g[i])) == raster.iou_counts(dp_[i], dg[i]).tolist(), i
+
+
+# ------------------------------------------------------------------------------------------------ more than 32 batch rows
+@pytest.mark.parametrize("B", [48, 128])
+def test_rows_mode_above_32_rows_tiny_engine(B):
+    """max_batch above 32 (the reference's request-level mode keeps up to 128 requests in flight per worker: generate_scheduler.py:57):
+    continuous batching through B rows of a tiny-geometry engine with overlapped admission -- every request's tokens equal those of the
+    same request served ALONE by the same engine (per-row arithmetic does not depend on the row's 32-row group or on its neighbours); a
+    request aborted in a row >= 32 frees that row at the next poll (128-bit row mask)."""
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.engine import Engine
+    from socioreasoner_amd.serving import ContinuousBatcher, Request
+    geom = geometry_tiny()
+    e = Engine(geom, max_patches=1024, max_prefill_tokens=64 * B, max_batch=B, max_ctx=128, max_new_tokens=24, kv_slots=2 * B)
+    e.load_synthetic_weights(seed=0)
+    rng = np.random.default_rng(B)
+    n_req = 2 * B + 5
+    ids = [rng.integers(0, 2000, int(rng.integers(5, 40))).astype(np.int64) for _ in range(n_req)]
+    pos = [np.tile(np.arange(len(x)), (3, 1)).astype(np.int64) for x in ids]
+    max_new = [int(rng.integers(3, 24)) for _ in range(n_req)]
+    mk = lambda i: Request(ids=ids[i], pos3=pos[i], max_new=max_new[i], tag=i)
+    cb = ContinuousBatcher(e, eos=[], pad_id=0, steps_per_poll=4, overlap=True)
+    got = cb.run([mk(i) for i in range(n_req)])
+    assert cb.stats["admitted"] == n_req and max(cb.row_slot.keys() | {0}) < B
+    alone = {}
+    for i in list(range(0, n_req, 7)) + [n_req - 1]:
+        c1 = ContinuousBatcher(e, eos=[], pad_id=0, steps_per_poll=4)
+        alone[i] = c1.run([mk(i)])[0]
+    for i, t in alone.items():
+        assert got[i] == t and len(t) == max_new[i], (i, got[i][:6], t[:6])
+    # abort a request that sits in a row >= 32
+    cb = ContinuousBatcher(e, eos=[], pad_id=0, steps_per_poll=2)
+    reqs = [Request(ids=ids[i], pos3=pos[i], max_new=24, tag=i) for i in range(B)]
+    for r in reqs:
+        cb.submit(r)
+    done = {}
+    cb.pump(lambda r, t: done.__setitem__(r.tag, t))
+    victim = next(r for row, r in cb.active.items() if row >= 32)
+    assert cb.abort(lambda r: r is victim) == 1
+    cb.pump(lambda r, t: done.__setitem__(r.tag, t))
+    assert victim.tag not in [r.tag for r in cb.active.values()], "the aborted row must be free after one poll"
+    while not cb.idle():
+        cb.pump(lambda r, t: (None if r.aborted else done.__setitem__(r.tag, t)))
+    assert victim.tag not in done and len(done) == B - 1
+    e.close()
