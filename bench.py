@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the additional batch-1 (configs[1]) measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sam", action="store_true", help="skip the SAM2 (seg_infer) timing")
+    ap.add_argument("--no-more-rows", action="store_true", help="skip the 64- and 128-row points (child processes)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="BASELINE.json configs[4] weights: LM decoder linears fp8 e4m3, per-channel scale")
     ap.add_argument("--fp8-mx", action="store_true", help="--fp8 plus MX fp8 activations in the prefill linears (fp8 x fp8 block-scaled MFMA, lm_weight_dtype 2)")
@@ -292,6 +293,27 @@ def main():
         args.drain = False
         drained = {"workload": "ONE step on an idle engine: its first admission is exposed, its last rows decode with nothing staged under them", "tiles_per_s": round(n_req / d_, 3),
                    "ms_per_step": round(d_ * 1e3, 2)}
+
+    # ---- beyond the headline's 32 rows (not the headline: BASELINE.json configs[2] says batch = 32): the same workload through 64 and 128 batch
+    # rows per GPU (the reference's request-level mode keeps up to 128 requests in flight per worker, generate_scheduler.py:57).  The decode
+    # GEMVs stream every weight tile once for all rows (k_gemv32g), so rows per step grow faster than the step.  Each point is this
+    # script run as a child process (own engine, 2 steps of 2 x rows requests, no side measurements).
+    more_rows = None
+    if rank == 0 and world == 1 and continuous and B == 32 and args.tile == 448 and not args.pair and not args.fp8 and not args.no_latency and not args.no_more_rows:
+        import subprocess
+        more_rows = {}
+        for rows_ in (64, 128):
+            cmd = [sys.executable, os.path.abspath(__file__), "--batch", str(rows_), "--steps", "2", "--warmup", "1", "--waves", "2", "--no-latency", "--no-cpu-baseline", "--no-sam"]
+            try:
+                r_ = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+                j_ = json.loads([ln for ln in r_.stdout.splitlines() if ln.startswith("{")][-1])
+                more_rows[str(rows_)] = {"tiles_per_s": j_["value"], "ms_per_step": j_["ms_per_step"], "tiles_per_step": j_["config"]["tiles_per_gpu_per_step"],
+                                         "decode_step_ms_alone": j_["roofline"]["decode_step_ms"], "decode_step_ms_shared": j_["phase_ms_per_step"]["scheduler"]["decode_step_ms_shared"],
+                                         "gemv_avg_launch_us": j_["roofline"]["avg_launch_us"], "gemv_hbm_frac": j_["roofline"]["frac"],
+                                         "forward_mfma_frac": j_["phase_ms_per_step"]["forward_mfma_frac"], "vit_mfma_frac": j_["phase_ms_per_step"]["vit_mfma_frac"],
+                                         "workspace_GB": j_["workspace_GB"]}
+            except Exception as e_:  # noqa: BLE001
+                more_rows[str(rows_)] = {"error": f"{type(e_).__name__}: {e_}"[:300]}
 
     # ---- admit-on-finish TIMED: the same requests with ragged answer lengths (per-request max_new uniform in [64, 192], mean 128, seeded),
     # through the same scheduler, against static batches of B that each run to their longest answer.  The headline's rows all stop on
@@ -577,7 +599,7 @@ def main():
                        "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",
                        "exchange": dict(exchange, payload="float32 logits all-gather per decode step (verification mode)" if args.gather_logits
                                         else "one all-gather of 1 KB result rows per tile and step")},
-            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_torch_bf16": cpu_hf, "phase_ms_per_step": phases, "static_batch": static_ref, "drained_step": drained, "ragged": ragged, "sam2": sam, "latency_b1": latency,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_torch_bf16": cpu_hf, "phase_ms_per_step": phases, "static_batch": static_ref, "drained_step": drained, "more_rows_per_gpu": more_rows, "ragged": ragged, "sam2": sam, "latency_b1": latency,
             "weights_load_s": round(load_s, 1), "workspace_GB": round(eng.workspace_bytes / 1e9, 2),
             "result_checksum": int(res.sum().item()),
         }

@@ -551,7 +551,8 @@ int launch_vit_rope(hipStream_t s, bf16_t* qkv, int n_rows, int n_heads, int hea
 }
 int launch_rows_abort(hipStream_t s, const unsigned row_mask[4], int* finished) {
     if (!(row_mask[0] | row_mask[1] | row_mask[2] | row_mask[3])) return 0;
-    hipLaunchKernelGGL(k_rows_abort, dim3(1), dim3(128), 0, s, uint4{row_mask[0], row_mask[1], row_mask[2], row_mask[3]}, finished);
+    const uint4 m = make_uint4(row_mask[0], row_mask[1], row_mask[2], row_mask[3]);      // (a braced initialiser inside the launch macro's argument list is split at its commas)
+    hipLaunchKernelGGL(k_rows_abort, dim3(1), dim3(128), 0, s, m, finished);
     SR_CHECK_LAUNCH();
     return 0;
 }
