@@ -519,12 +519,12 @@ def main():
         # HBM traffic per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950 note):
         # measured ratio traffic / algorithmic bytes of this kernel family x the algorithmic bytes of one launch
         traffic, pmc, insitu = None, None, None
-        PMC_FILE = "r03_pmc_gemv_traffic.json"
+        PMC_FILE = "r04_pmc_gemv_traffic.json"
         try:     # rocprofv3 kernel-trace average of the same kernels inside the full decode step (committed summary of the static-batch trace)
-            insitu = json.load(open(os.path.join(ROOT, "profiles", "r03_gemv_in_situ.json")))["batch32" if B > 4 else "batch1"]
+            insitu = json.load(open(os.path.join(ROOT, "profiles", "r04_gemv_in_situ.json")))["batch32" if B > 4 else "batch1"] if B in (1, 32) else None
         except Exception:  # noqa: BLE001
             pass
-        try:     # profiles/r03_pmc_gemv_traffic.json: FETCH_SIZE / WRITE_SIZE passes of this kernel family at batch 32 and batch 1 (tools/gpu_r3_pmc_gemv.sh)
+        try:     # profiles/r04_pmc_gemv_traffic.json: FETCH_SIZE / WRITE_SIZE passes of this kernel family at batch 32 and batch 1 (tools/gpu_r4_profiles.sh)
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             traffic = round(pmc["traffic_over_algorithmic_weighted_batch32" if B > 4 else "traffic_over_algorithmic_weighted_batch1"] * bytes_per_launch)
         except Exception:  # noqa: BLE001
