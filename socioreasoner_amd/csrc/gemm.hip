@@ -345,7 +345,8 @@ int launch_gemm(hipStream_t s, const GemmArgs& a, int epi) {
     if (a.M <= 0) return 0;
     if (a.K % BK != 0 || a.N % 16 != 0 || (epi == EPI_SWIGLU && a.N % 32 != 0)) return -22;
     if (a.ksplit > 1) {      // split-K partial products (small M): this file's kernel, float32 slabs, no row map
-        if (epi != EPI_F32 || a.rowmap || a.ksplit > a.K / BK) return -22;
+        // (a bias would be added once per slab -- the float32 epilogue adds it in every block: refused, the consumer of the slabs adds it)
+        if (epi != EPI_F32 || a.rowmap || a.bias || a.ksplit > a.K / BK) return -22;
         return launch_e<EPI_F32>(s, a);
     }
     // large M: the 256 x 256 8-phase kernel (gemm256.hip)

@@ -557,7 +557,9 @@ __global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int
     constexpr int WAVES = 4, TPB = WAVES / KP, U = (G <= 2) ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, half = (lane >> 4) & 1, kg = lane >> 5, m0 = lane & 31;
+    // BIAS / RESID / SWIGLU launches may split the ROWS over gridDim.y (32 G rows per y): the narrow matrices (N = 2048 / 2560: 64 / 80 tiles)
+    // otherwise leave three quarters of the CUs without a block, and their few MB of weights cost nothing to stream twice
+    const int fr = lane & 15, half = (lane >> 4) & 1, kg = lane >> 5, m0 = (lane & 31) + (MODE != GV_PARTIAL ? (int)blockIdx.y * 32 * G : 0);
     const int tp = wave / KP, kp = wave % KP;
     const int tile = blockIdx.x * TPB + tp;
     const bool active = tile < ntiles32;
@@ -709,7 +711,7 @@ template <int MODE, int KP, int G>
 int launch_32g(hipStream_t s, const GemvArgs& a) {
     constexpr int TPB = 4 / KP;
     const int ntiles = a.N / 32;
-    dim3 grid(cdiv(ntiles, TPB), MODE == GV_PARTIAL ? a.ksplit : 1);
+    dim3 grid(cdiv(ntiles, TPB), MODE == GV_PARTIAL ? a.ksplit : cdiv(a.M, 32 * G));
     size_t smem = (size_t)TPB * (KP > 1 ? KP - 1 : 0) * G * 64 * sizeof(f32x16);
     if (smem < (size_t)4 * 32 * G * 8) smem = (size_t)4 * 32 * G * 8;
     hipLaunchKernelGGL((k_gemv32g<MODE, KP, G>), grid, dim3(256), smem, s, a, ntiles);
@@ -835,7 +837,9 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
         if (mode == GV_PARTIAL && (a.ksplit < 1 || a.ksplit > a.K / 64)) return -22;
         if (a.out_tiled && (mode != GV_SWIGLU || (a.N / 2) % 64 != 0)) return -22;
         const int kp32 = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, mode == GV_F32 ? 1 : 4);
-        return a.M <= 64 ? launch_32g_mode<2>(s, a, mode, kp32) : launch_32g_mode<4>(s, a, mode, kp32);
+        // 65..128 rows of a NARROW matrix (q/k/v, o_proj): two row halves of 64 over gridDim.y (G = 2) -- twice the blocks, two blocks per CU
+        const bool narrow = (mode == GV_BIAS || mode == GV_RESID) && a.N <= 4096;
+        return (a.M <= 64 || narrow) ? launch_32g_mode<2>(s, a, mode, kp32) : launch_32g_mode<4>(s, a, mode, kp32);
     }
     if (mode == GV_SWIGLU && a.N % 32 != 0) return -22;
     if (mode == GV_PARTIAL && (a.ksplit < 1 || a.ksplit > a.K / 64)) return -22;

@@ -46,7 +46,7 @@ struct GemmArgs {
     int a_rows_pad;
     QkvRope rope;               // EPI_LMQKV only
     VitRope vrope;              // EPI_VITQKV only
-    int ksplit;                 // > 1 (EPI_F32, gemm.hip kernel only): K is split over gridDim.y blocks, block y writes its float32 partial
+    int ksplit;                 // > 1 (EPI_F32, gemm.hip kernel only, bias must be null): K is split over gridDim.y blocks, block y writes its float32 partial
                                 // products to out + y * M * ldo (slabs the consumer sums: launch_resid_rmsnorm)
     int gelu_fast;              // EPI_GELU: 1 = gelu_fast_f (common.h) instead of the erff form, 2 = ReLU (the activation epilogue's third function)
 };

@@ -296,6 +296,9 @@ class ContinuousBatcher:
         # chunk decodes on 160 CUs) was measured and is slower -- 76.8 vs 78.3 tiles/s, two runs each, same box: the admission is not on
         # the critical path for that long, the decode rows are.
         s = self._use_decode_stream(self.streams.decode if busy else self.streams.decode_full)
+        # bookkeeping only: a chunk under which the next admission gets staged shares the chip with it from the moment the admission's first
+        # kernel starts (round 3 counted it as "alone", which made the unshared step look 6 % slower than the static one: tools/probe_rows_step.py)
+        shares = busy or (self.staged is None and bool(self.pending) and bool(self.free_slots))
         # (step-time calibration: a chunk with the chip to itself -- no admission in flight and none about to be staged under it)
         cal = (self._auto and not busy and not (self.staged is None and self.pending and self.free_slots)
                and self._step_ms is None and self._cal_step is None)
@@ -305,13 +308,13 @@ class ContinuousBatcher:
                 c0.record(s)
             t0 = self._mark()
             self.engine.rows_step(self.steps_per_poll, self.eos, self.pad_id)
-            self._span("decode_shared" if busy else "decode", t0, self._mark())
+            self._span("decode_shared" if shares else "decode", t0, self._mark())
             if cal:
                 c1 = torch.cuda.Event(enable_timing=True)
                 c1.record(s)
                 self._cal_step = (c0, c1, self.steps_per_poll)
         self.stats["steps"] += self.steps_per_poll
-        self.stats["steps_shared"] += self.steps_per_poll if busy else 0
+        self.stats["steps_shared"] += self.steps_per_poll if shares else 0
         if self.staged is None and self.pending and self.free_slots:
             self._stage()                              # the host side of the next admission is prepared while the chunk above runs
         with torch.cuda.stream(s):
