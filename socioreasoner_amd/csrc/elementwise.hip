@@ -411,8 +411,11 @@ __global__ void k_admit_rows(AdmitArgs a) {
 
 // continuous batching: rows named by the mask stop now (k_step then logs pads for them and leaves their cache slot alone)
 __global__ void k_rows_abort(uint4 mask, int* finished) {
-    const unsigned w[4] = {mask.x, mask.y, mask.z, mask.w};
-    if (threadIdx.x < 128 && ((w[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1u)) finished[threadIdx.x] = 1;
+    // (selects, not an indexed local array: on this toolchain the indexed form read word 0 for every lane of the first wave -- rows 32..63 took
+    // rows 0..31's bits; tools/probe_abort.py)
+    const unsigned g = threadIdx.x >> 5;
+    const unsigned word = g == 0 ? mask.x : g == 1 ? mask.y : g == 2 ? mask.z : mask.w;
+    if (threadIdx.x < 128 && ((word >> (threadIdx.x & 31)) & 1u)) finished[threadIdx.x] = 1;
 }
 
 // fp8 weight quantisation, one block per 16-row tile of a fragment-ordered bf16 matrix (see kernels.h)

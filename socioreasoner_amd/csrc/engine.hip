@@ -625,8 +625,18 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         GemvArgs gg = gv(x, H, w.gu_w, B, 2 * e->t_inter_pad, H, e->d_act, e->t_inter_pad);
         gg.W8 = w.gu_w8; gg.w_scale = w.gu_s;
         if (fused) { gg.norm_w = w.ln2; gg.eps = c.t_rms_eps; }
+        else if (B > 64 && !w.gu_w8) {
+            // more than 64 rows: gate/up as an LDS-tiled MFMA GEMM (gemm.hip, 64 x 128 tiles: every block stages its x tile ONCE for its four
+            // waves).  The row-group GEMV reads G x the weight bytes of x from L2 per wave (43 us at 128 rows); the other launches keep the GEMV
+            // (their narrow matrices would give the tile kernel 32-40 blocks).  Row-major x in, fragment-ordered activation out (the down GEMV's x).
+            SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, 0));
+            GemmArgs ga{e->d_xn, H, w.gu_w, B, 2 * e->t_inter_pad, H, e->d_act, e->t_inter_pad, nullptr, nullptr, nullptr, 1, nullptr, 128};
+            ga.out_tiled = xt;
+            SR_TRY(launch_gemm(s, ga, EPI_SWIGLU));
+            gg.M = 0;       // (done)
+        }
         else { SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt)); gg.x = e->d_xn; gg.x_tiled = xt; gg.out_tiled = xt; }
-        SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
+        if (gg.M > 0) SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
         GemvArgs gd = gv(e->d_act, e->t_inter_pad, w.down_w, B, H, e->t_inter_pad, e->d_slabs, H);
         gd.ksplit = ks_down(e, B);
         gd.W8 = w.down_w8; gd.w_scale = w.down_s; gd.x_tiled = xt;
@@ -712,6 +722,7 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
     if (r == hipSuccess) r = (hipError_t)launch_rope_table(nullptr, e->inv_freq, e->c.max_ctx + 1, e->rope_cos, e->rope_sin);
     if (r == hipSuccess) r = hipDeviceSynchronize();
     if (r == hipSuccess) r = (hipError_t)attn_decode_prepare(e->c.max_ctx, e->t_group);
+    if (r == hipSuccess && e->c.max_batch > 64) r = (hipError_t)gemm_prepare_decode();
     if (r != hipSuccess) {
         int rc = fail(nullptr, (int)r, "engine init: %s", hipGetErrorString(r));
         sr_engine_destroy(e);

@@ -215,11 +215,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p, int ntm, int ntn) 
                 const uint4 v = widen(t2[0], t2[1]);
                 const int ngs = n0 + wn * 64 + odd * 32;                     // gate-column base of the output tile this lane stores
                 const int no = (n0 + wn * 64) / 2 + odd * 16 + half8;
-                if (rok && ngs < p.N) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + no) = v;
+                // out_tiled: the activation leaves fragment-ordered (tiled16x64 of [ceil16(M)][ldo]: 8 consecutive k of a row stay 16 contiguous
+                // bytes) -- it is the x operand of the decode down-projection GEMV at more than 64 batch rows
+                if (rok && ngs < p.N) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (p.out_tiled ? tiled_offset((size_t)orow, (size_t)no, (size_t)p.ldo) : (size_t)orow * p.ldo + no)) = v;
             } else {
                 const int ng = n0 + wn * (NJ * 16) + fg * 4;
                 const int no = (n0 + wn * (NJ * 16)) / 2 + fg * 4;
-                if (rok && ng < p.N) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + no) = t2[0];
+                if (rok && ng < p.N) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (p.out_tiled ? tiled_offset((size_t)orow, (size_t)no, (size_t)p.ldo) : (size_t)orow * p.ldo + no)) = t2[0];
             }
         } else if constexpr (EPI == EPI_F32) {
 #pragma unroll
@@ -280,16 +282,23 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p, int ntm, int ntn) 
     }
 }
 
+// raises the kernel's dynamic-LDS limit once per process (never inside a stream capture: gemm_prepare_decode below)
+template <int BM, int EPI, int NW, int NS>
+int ensure_attr() {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, EPI, NW, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<BM, NS>));
+        if (r != hipSuccess) return (int)r;
+        attr_done = true;
+    }
+    return 0;
+}
+
 template <int BM, int EPI, int NW = 4, int NS = 2>
 int launch_t(hipStream_t s, const GemmArgs& a) {
     int ntm = cdiv(a.M, BM), ntn = cdiv(a.N, BN);
     size_t smem = sizeof(Smem<BM, NS>);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, EPI, NW, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (r != hipSuccess) return (int)r;
-        attr_done = true;
-    }
+    if (int rc = ensure_attr<BM, EPI, NW, NS>()) return rc;
     hipLaunchKernelGGL((k_gemm<BM, EPI, NW, NS>), dim3(ntm * ntn, EPI == EPI_F32 && a.ksplit > 1 ? a.ksplit : 1), dim3(NW * 64), smem, s, a, ntm, ntn);
     SR_CHECK_LAUNCH();
     return 0;
@@ -320,6 +329,13 @@ int launch_e(hipStream_t s, const GemmArgs& a) {
 
 }  // namespace
 
+// The decode layer of an engine with more than 64 batch rows launches its gate/up as a tile GEMM INSIDE the captured decode step: the
+// attribute call of that kernel must have happened before the capture starts (sr_engine_create calls this)
+int gemm_prepare_decode() {
+    if (int rc = ensure_attr<64, EPI_SWIGLU, 4, 2>()) return rc;
+    return ensure_attr<64, EPI_SWIGLU, 4, 6>();
+}
+
 // does the dispatch below send `a` to the 256-tile kernel?  (SR_GEMM256: 0 = never, 2 = whenever the shape is supported -- tuning hook)
 static bool picks_256(const GemmArgs& a) {
     static const char* g256_env = getenv("SR_GEMM256");
@@ -344,6 +360,10 @@ bool gemm_fuses_vitqkv(const GemmArgs& a) {
 int launch_gemm(hipStream_t s, const GemmArgs& a, int epi) {
     if (a.M <= 0) return 0;
     if (a.K % BK != 0 || a.N % 16 != 0 || (epi == EPI_SWIGLU && a.N % 32 != 0)) return -22;
+    if (a.out_tiled) {      // fragment-ordered SwiGLU output: this file's kernel only (the decode gate/up at more than 64 rows), whole 64-wide k chunks
+        if (epi != EPI_SWIGLU || a.ldo % 64 != 0 || a.rowmap || a.ksplit > 1 || a.force_tile == 256) return -22;
+        return launch_e<EPI_SWIGLU>(s, a);
+    }
     if (a.ksplit > 1) {      // split-K partial products (small M): this file's kernel, float32 slabs, no row map
         // (a bias would be added once per slab -- the float32 epilogue adds it in every block: refused, the consumer of the slabs adds it)
         if (epi != EPI_F32 || a.rowmap || a.bias || a.ksplit > a.K / BK) return -22;

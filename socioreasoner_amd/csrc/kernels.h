@@ -49,11 +49,13 @@ struct GemmArgs {
     int ksplit;                 // > 1 (EPI_F32, gemm.hip kernel only, bias must be null): K is split over gridDim.y blocks, block y writes its float32 partial
                                 // products to out + y * M * ldo (slabs the consumer sums: launch_resid_rmsnorm)
     int gelu_fast;              // EPI_GELU: 1 = gelu_fast_f (common.h) instead of the erff form, 2 = ReLU (the activation epilogue's third function)
+    int out_tiled;              // EPI_SWIGLU (gemm.hip kernel): write the activation fragment-ordered (tiled16x64 of [ceil16(M)][ldo], common.h)
 };
 bool gemm_fuses_vitqkv(const GemmArgs& a);
 // true when launch_gemm would run `a` with the fused q/k/v epilogue (same predicate as its dispatch to gemm256.hip)
 bool gemm_fuses_lmqkv(const GemmArgs& a);
 int launch_gemm(hipStream_t s, const GemmArgs& a, int epi);
+int gemm_prepare_decode();      // attribute calls of the tile kernels a decode step launches under stream capture (engines with more than 64 rows)
 // gemm256.hip: 256 x 256 x 64 tile, 8-phase ping-pong schedule (large M); launch_gemm dispatches to it
 bool gemm256_supports(const GemmArgs& a);
 int launch_gemm256(hipStream_t s, const GemmArgs& a, int epi);
