@@ -482,7 +482,7 @@ def test_rows_mode_above_32_rows_tiny_engine(B):
     cb.pump(lambda r, t: done.__setitem__(r.tag, t))
     victim = next(r for row, r in cb.active.items() if row >= 32)
     assert cb.abort(lambda r: r is victim) == 1
-    cb.pump(lambda r, t: done.__setitem__(r.tag, t))
+    cb.pump(lambda r, t: (None if r.aborted else done.__setitem__(r.tag, t)))
     assert victim.tag not in [r.tag for r in cb.active.values()], "the aborted row must be free after one poll"
     while not cb.idle():
         cb.pump(lambda r, t: (None if r.aborted else done.__setitem__(r.tag, t)))
