@@ -25,6 +25,10 @@ done
 python tools/gemv_in_situ.py gpurun_out/r04_bench_s32_kernel_stats.md gpurun_out/r04_bench_b1_kernel_stats.md gpurun_out/r04_gemv_in_situ.json
 cp gpurun_out/r04_gemv_in_situ.json profiles/r04_gemv_in_situ.json
 cp gpurun_out/r04_pmc_gemv_traffic.json profiles/r04_pmc_gemv_traffic.json
+SR_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 1 --warmup 0 --waves 1 --no-latency --no-cpu-baseline --no-sam 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('2 gloo ranks, continuous:', d['value'], d['n_gpus'], d['config']['exchange']['nranks'])"
+OUT=/tmp/example_out SOCIOSEG_NUM_SAMPLES=32 timeout 600 python tools/run_example_small.py 2>/dev/null | tail -1 | cut -c1-600
 timeout 1200 python bench.py > gpurun_out/r04_bench_default.log 2> gpurun_out/r04_bench_default.err; echo "bench exit $?"
 tail -n 1 gpurun_out/r04_bench_default.log > gpurun_out/r04_bench_default_line.json
 cut -c1-300 gpurun_out/r04_bench_default_line.json
