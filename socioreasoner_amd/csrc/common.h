@@ -13,6 +13,16 @@ __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint3
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float lo16(uint32_t u);
+__device__ __forceinline__ float hi16(uint32_t u);
+// a = rbf(a), b = rbf(b) with ONE v_cvt_pk_bf16_f32 (rbf converts its value alone and wastes the instruction's second lane)
+__device__ __forceinline__ void rbf2(float& a, float& b) {
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const uint32_t u = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2_t{a, b}, bf2_t));
+    a = __uint_as_float(u << 16);
+    b = __uint_as_float(u & 0xffff0000u);
+}
 __device__ __forceinline__ float lo16(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi16(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 

@@ -187,11 +187,29 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p, int ntm, int ntn) 
         return uint4{sx[0], sy[0], sx[1], sy[1]};
     };
     const int odd = fg & 1, half8 = (fg >> 1) * 8;
+    int orows[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + fr;
+        orows[i] = (m < p.M && p.rowmap) ? p.rowmap[m] : m;
+    }
+    // EPI_RESID: every residual load of the lane before the first store (the residual may alias the output, so the compiler keeps a load
+    // behind each earlier store: a load -> wait -> store round trip per 16 rows otherwise; see gemm256.hip)
+    uint4 rl[MI][NJ / 2 > 0 ? NJ / 2 : 1];
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jp = 0; jp < NJ / 2; ++jp) {
+                const int n = n0 + wn * (NJ * 16) + (2 * jp + odd) * 16 + half8;
+                rl[i][jp] = (m0 + wm * (BM / 2) + i * 16 + fr < p.M && n < p.N) ? *reinterpret_cast<const uint4*>(p.resid + (size_t)orows[i] * p.ldo + n) : uint4{0, 0, 0, 0};
+            }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 16 + fr;
         const bool rok = m < p.M;                              // (masked rows still take part in the lane exchange)
-        const int orow = (rok && p.rowmap) ? p.rowmap[m] : m;
+        const int orow = orows[i];
         if constexpr (EPI == EPI_SWIGLU) {
             uint2 t2[NJ / 2];
 #pragma unroll
@@ -241,8 +259,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p, int ntm, int ntn) 
             if constexpr (EPI == EPI_RESID) {
 #pragma unroll
                 for (int jp = 0; jp < NJ / 2; ++jp) {
-                    const int n = n0 + wn * (NJ * 16) + (2 * jp + odd) * 16 + half8;
-                    const uint4 l4 = (rok && n < p.N) ? *reinterpret_cast<const uint4*>(p.resid + (size_t)orow * p.ldo + n) : uint4{0, 0, 0, 0};
+                    const uint4 l4 = rl[i][jp];
                     const auto sx = __builtin_amdgcn_permlane16_swap(l4.x, l4.z, false, false);
                     const auto sy = __builtin_amdgcn_permlane16_swap(l4.y, l4.w, false, false);
                     rv[2 * jp] = uint2{sx[0], sy[0]};

@@ -43,9 +43,19 @@ __device__ __forceinline__ int swz2(int row, int chunk) { return row * (BK2 * 2)
 // k-tile rides along with unit UA1 (one more LDS-DMA by wave 0).  Weights: the decode stream's fp8 image (tiled8, common.h), whose
 // 2 KB per (16-row tile, 128 k) already IS two operand fragments; its per-output-channel float32 scale stays in the epilogue, the
 // block scale of the weight operand is 1 (e8m0 127).
+// -DSR_G256_TIMING (tools/probe_gemm256_timeline.py builds its own library with it; never the product build): wave 0 of every block
+// records the 100 MHz clock at entry / after the prologue / after the k loop / after the epilogue's stores have drained, and the CU it ran on
+#ifdef SR_G256_TIMING
+__device__ long long g_t256[16384 * 6];
+#define T256(slot, v) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_t256[blockIdx.x * 6 + (slot)] = (v); } while (0)
+#else
+#define T256(slot, v)
+#endif
 template <int EPI, bool MX>
 __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, int GROUP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // ONE array (a second __shared__ object de-pipelines)
+    T256(0, wall_clock64());
+    T256(4, ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
     {   // XCD-aware: block b runs on XCD b % 8 -> give every XCD a contiguous run of tiles (bijective for any grid size)
@@ -215,12 +225,20 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
     __builtin_amdgcn_s_barrier();                            \
     __builtin_amdgcn_sched_barrier(0);
 
+    // the lane's 16 bias values are fetched here, under the prologue's wait (8 registers through the k loop; the MX kernel has none to spare
+    // and fetches them at the head of its epilogue)
+    uint2 bia[4];
+    if constexpr (!MX) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bia[j] = p.bias ? *reinterpret_cast<const uint2*>(p.bias + n0 + wn * 64 + j * 16 + fg * 4) : uint2{0, 0};
+    }
     // ---- prologue: k-tile 0 completely, plus the two units of k-tile 1 the steady state has already issued by then
     stage_a(0, 0); stage_w(0, 0); stage_w(1, 0); stage_a(1, 0);
     if (nk > 1) { stage_a(0, 1); stage_w(MX ? 1 : 0, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();       // the second wave row runs half a phase behind the first
+    T256(1, wall_clock64());
 
     for (int t = 0; t < nk; ++t) {
         const unsigned char* buf = smem + (t & 1) * BUF_BYTES;
@@ -249,6 +267,7 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();       // balance the extra barrier of the other wave row
 #undef PHASE_SYNC_COMPUTE
+    T256(2, wall_clock64());
 
     // ---- epilogue (same rounding points as gemm.hip).  lane owns row m = .. + fr and columns n = .. + fg*4 + {0..3}.
     // Column-only operands (bias, fp8 scale) and the row map are fetched once, up front: no memory wait inside the store loop.
@@ -260,12 +279,11 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
         rok[i] = m < p.M;
         orow[i] = (rok[i] && p.rowmap) ? p.rowmap[m] : m;
     }
-    uint2 bia[4];
     float4 scl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + fg * 4;
-        bia[j] = p.bias ? *reinterpret_cast<const uint2*>(p.bias + n) : uint2{0, 0};
+        if constexpr (MX) bia[j] = p.bias ? *reinterpret_cast<const uint2*>(p.bias + n) : uint2{0, 0};
         scl[j] = p.w_scale ? *reinterpret_cast<const float4*>(p.w_scale + n) : float4{1.f, 1.f, 1.f, 1.f};
     }
     // 16-byte stores: a lane owns 4 consecutive columns (8 B) of a row in every 16-column tile; the lane 16 further on owns the next
@@ -460,6 +478,25 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
         return;
     }
     const int odd = fg & 1, half8 = (fg >> 1) * 8;            // which tile of a pair this lane stores, and its 8-column half
+    // EPI_RESID: ALL sixteen 16-byte residual loads of the lane go out before the first store.  The residual may alias the output (the
+    // engine adds in place), so the compiler must keep a load behind every earlier store: left inside the row loop that made eight
+    // load -> wait -> store round trips per tile (10-14 us of a 42-93 us ViT tile, tools/probe_gemm256_timeline.py).  Every 16 bytes
+    // are read and later written by the same lane only, so reading them all first is the same computation; the operand fragments are
+    // dead here and their 64 registers hold the values.
+    uint4 rl[8][2];
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp)
+                rl[i][jp] = rok[i] ? *reinterpret_cast<const uint4*>(p.resid + (size_t)orow[i] * p.ldo + n0 + wn * 64 + (2 * jp + odd) * 16 + half8)
+                                   : uint4{0, 0, 0, 0};
+    }
+    // The row loop is instantiated for the four (fp8 channel scale, bias) cases and picked by two block-uniform branches: left as run-time
+    // conditions inside the loop they became a multiply / add and a v_cndmask per accumulator (512 instructions of the ~2200 of the SwiGLU
+    // epilogue, which is VALU-bound: the two waves of a SIMD share it, tools/probe_gemm256_timeline.py).  Same arithmetic, same order.
+    auto rows = [&](auto hs_, auto hb_) {
+    constexpr bool HS = decltype(hs_)::value, HB = decltype(hb_)::value;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         // (no early exit on masked rows: the lane exchange needs every lane of the wave)
@@ -471,15 +508,20 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
                 const float us[4] = {scl[2 * jp + 1].x, scl[2 * jp + 1].y, scl[2 * jp + 1].z, scl[2 * jp + 1].w};
                 const float gb[4] = {lo16(bia[2 * jp].x), hi16(bia[2 * jp].x), lo16(bia[2 * jp].y), hi16(bia[2 * jp].y)};
                 const float ub[4] = {lo16(bia[2 * jp + 1].x), hi16(bia[2 * jp + 1].x), lo16(bia[2 * jp + 1].y), hi16(bia[2 * jp + 1].y)};
-                float o[4];
+                float o[4], uu[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float g = acc[i][2 * jp][r], u = acc[i][2 * jp + 1][r];
-                    if (p.w_scale) { g *= gs[r]; u *= us[r]; }
-                    if (p.bias) { g += gb[r]; u += ub[r]; }
-                    g = rbf(g); u = rbf(u);
-                    o[r] = rbf(silu_f(g)) * u;
+                    if constexpr (HS) { g *= gs[r]; u *= us[r]; }
+                    if constexpr (HB) { g += gb[r]; u += ub[r]; }
+                    rbf2(g, u);                                               // (two roundings per v_cvt_pk_bf16_f32)
+                    o[r] = silu_f(g);
+                    uu[r] = u;
                 }
+                rbf2(o[0], o[1]);
+                rbf2(o[2], o[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] *= uu[r];
                 t2[jp] = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
             }
             const uint4 v = widen(t2[0], t2[1]);
@@ -490,8 +532,8 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
             for (int j = 0; j < 4; ++j) {
                 const int n = n0 + wn * 64 + j * 16 + fg * 4;
                 float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (p.w_scale) { o[0] *= scl[j].x; o[1] *= scl[j].y; o[2] *= scl[j].z; o[3] *= scl[j].w; }
-                if (p.bias) { o[0] += bf2f(p.bias[n]); o[1] += bf2f(p.bias[n + 1]); o[2] += bf2f(p.bias[n + 2]); o[3] += bf2f(p.bias[n + 3]); }
+                if constexpr (HS) { o[0] *= scl[j].x; o[1] *= scl[j].y; o[2] *= scl[j].z; o[3] *= scl[j].w; }
+                if constexpr (HB) { o[0] += bf2f(p.bias[n]); o[1] += bf2f(p.bias[n + 1]); o[2] += bf2f(p.bias[n + 2]); o[3] += bf2f(p.bias[n + 3]); }
                 if (rok[i]) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow[i] * p.ldo + n) = float4{o[0], o[1], o[2], o[3]};
             }
         } else {
@@ -501,8 +543,7 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
                 // exchange hands every lane the 4 + 4 columns it accumulates (the swap is its own inverse on this layout)
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
-                    const uint4 l4 = rok[i] ? *reinterpret_cast<const uint4*>(p.resid + (size_t)orow[i] * p.ldo + n0 + wn * 64 + (2 * jp + odd) * 16 + half8)
-                                            : uint4{0, 0, 0, 0};
+                    const uint4 l4 = rl[i][jp];
                     const auto sx = __builtin_amdgcn_permlane16_swap(l4.x, l4.z, false, false);
                     const auto sy = __builtin_amdgcn_permlane16_swap(l4.y, l4.w, false, false);
                     rv[2 * jp] = uint2{sx[0], sy[0]};
@@ -512,8 +553,8 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (p.w_scale) { o[0] *= scl[j].x; o[1] *= scl[j].y; o[2] *= scl[j].z; o[3] *= scl[j].w; }
-                if (p.bias) { o[0] += lo16(bia[j].x); o[1] += hi16(bia[j].x); o[2] += lo16(bia[j].y); o[3] += hi16(bia[j].y); }
+                if constexpr (HS) { o[0] *= scl[j].x; o[1] *= scl[j].y; o[2] *= scl[j].z; o[3] *= scl[j].w; }
+                if constexpr (HB) { o[0] += lo16(bia[j].x); o[1] += hi16(bia[j].x); o[2] += lo16(bia[j].y); o[3] += hi16(bia[j].y); }
                 if constexpr (EPI == EPI_RESID) {
                     o[0] = lo16(rv[j].x) + rbf(o[0]); o[1] = hi16(rv[j].x) + rbf(o[1]);
                     o[2] = lo16(rv[j].y) + rbf(o[2]); o[3] = hi16(rv[j].y) + rbf(o[3]);
@@ -531,6 +572,14 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
             }
         }
     }
+    };
+    if (p.w_scale) { if (p.bias) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{}); }
+    else { if (p.bias) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{}); }
+#ifdef SR_G256_TIMING
+    T256(3, wall_clock64());                                   // stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    T256(5, wall_clock64());                                   // stores acknowledged
+#endif
 }
 
 template <int EPI, bool MX = false>
@@ -551,6 +600,12 @@ int launch256_t(hipStream_t s, const GemmArgs& a) {
 }
 
 }  // namespace
+
+#ifdef SR_G256_TIMING
+extern "C" int sr_dbg_g256_times(long long* host_out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_t256), (size_t)n_blocks * 6 * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // fused q/k/v epilogue: the q, k and v sections must start on 256-column tile boundaries (whole heads per tile, block-uniform role)
 bool lmqkv_ok(const GemmArgs& a) {
