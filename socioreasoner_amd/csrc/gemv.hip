@@ -27,6 +27,15 @@
 
 namespace {
 
+// -DSR_GEMV_TIMING (tools/probe_gemv_timeline.py builds its own library with it; never the product build): wave 0 of every block records the
+// 100 MHz clock at entry / when its ring is filled and the k loop starts / when the k loop is over / at the end
+#ifdef SR_GEMV_TIMING
+__device__ long long g_tgv[16384 * 4];
+#define TGV(slot) do { if (threadIdx.x == 0) { const int b_ = blockIdx.y * gridDim.x + blockIdx.x; if (b_ < 16384) g_tgv[b_ * 4 + (slot)] = wall_clock64(); } } while (0)
+#else
+#define TGV(slot)
+#endif
+
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 __device__ __forceinline__ u32x4 ldg_nt(const bf16_t* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
@@ -42,6 +51,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     constexpr int TPB = WAVES / KP;                    // wave-tiles per block
     constexpr int NT = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TGV(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int tp = wave / KP, kp = wave % KP;
@@ -106,7 +116,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
             }
         }
     }
-    if constexpr (!STAGE) first_fills();
 
     // ---------------------------------------------------------------- STAGE prologue: x -> LDS
     // layout: xn[m][K + 8] bf16 (row pad 16 B: conflict-free ds_read_b128 across rows); red[(K/512)][32] float after it.
@@ -244,10 +253,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
             }
         };
         if constexpr (!STAGE) {
+            // x BEFORE the weights: a wave's loads return in issue order, x comes from L2 (the previous launch wrote it) and W from HBM.
+            // Behind the weights the x loads of the first ring only started to arrive when ALL of it had landed (launches whose whole K
+            // fits the first ring -- qkv, o_proj: 3.2 us for W, then 1.3 us of x through the CU's load path, tools/probe_gemv_timeline.py);
+            // in front of them they travel during the HBM latency.
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (c0 + u < cend) fill_x(u, c0 + u);
         }
+        if constexpr (!STAGE) first_fills();
+        TGV(1);
         for (int c = c0; c < cend; c += U) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -285,6 +300,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
         }
     }
 
+    TGV(2);
     // ---------------------------------------------------------------- in-block K reduction (fixed order kp = 1, 2, 3)
     // reuses the staged-x region once every wave is done reading it
     f32x4* rbuf = reinterpret_cast<f32x4*>(STAGE ? smem : reinterpret_cast<unsigned char*>(red + 128));   // [TPB][KP-1][T*MT][64]
@@ -403,6 +419,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
             }
         }
     }
+    TGV(3);
 }
 
 // ---------------------------------------------------------------------------------------------- batches 17..32
@@ -417,6 +434,7 @@ template <int MODE, int KP>
 __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
     constexpr int WAVES = 4, TPB = WAVES / KP, U = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TGV(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, half = (lane >> 4) & 1, kg = lane >> 5, m = lane & 31;
     const int tp = wave / KP, kp = wave % KP;
@@ -438,20 +456,28 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
     const size_t x_c = p.x_tiled ? 1024 : 64, x_s = p.x_tiled ? 128 : 16;
 
     u32x4 w[U][4], xv[U][4];
-    auto fill = [&](int u, int c) {
+    auto fill_w = [&](int u, int c) {
 #pragma unroll
         for (int st = 0; st < 4; ++st) w[u][st] = ldg_nt(wbase + (size_t)c * w_c + st * w_s);
+    };
+    auto fill_x = [&](int u, int c) {
 #pragma unroll
         for (int st = 0; st < 4; ++st)
             xv[u][st] = (xok || p.x_tiled) ? *reinterpret_cast<const u32x4*>(xbase + (size_t)c * x_c + st * x_s) : u32x4{0, 0, 0, 0};
     };
+    auto fill = [&](int u, int c) { fill_w(u, c); fill_x(u, c); };
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     if (active) {
+        // first ring: x (L2) in front of the weights (HBM) -- loads return in issue order, see k_gemv
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (c0 + u < cend) fill(u, c0 + u);
+            if (c0 + u < cend) fill_x(u, c0 + u);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c0 + u < cend) fill_w(u, c0 + u);
+        TGV(1);
         for (int c = c0; c < cend; c += U) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -464,6 +490,7 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
             }
         }
     }
+    TGV(2);
     if constexpr (KP > 1) {
         f32x16* rbuf = reinterpret_cast<f32x16*>(smem);          // [TPB][KP-1][64]
         if (kp > 0) rbuf[(tp * (KP - 1) + (kp - 1)) * 64 + lane] = acc;
@@ -543,6 +570,7 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
             }
         }
     }
+    TGV(3);
 }
 
 // ---------------------------------------------------------------------------------------------- batches 33..128
@@ -578,9 +606,11 @@ __global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int
     const size_t x_c = p.x_tiled ? 1024 : 64, x_s = p.x_tiled ? 128 : 16, x_g = p.x_tiled ? (size_t)nchunks * 2048 : (size_t)32 * p.ldx;
     const int m_rd = p.x_tiled ? (p.M + 15) / 16 * 16 : p.M;
     u32x4 w[U][4], xv[U][G][4];
-    auto fill = [&](int u, int c) {
+    auto fill_w = [&](int u, int c) {
 #pragma unroll
         for (int st = 0; st < 4; ++st) w[u][st] = ldg_nt(wbase + (size_t)c * w_c + st * w_s);
+    };
+    auto fill_x = [&](int u, int c) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -588,15 +618,20 @@ __global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int
                 xv[u][g][st] = (m0 + 32 * g < m_rd) ? *reinterpret_cast<const u32x4*>(xbase + g * x_g + (size_t)c * x_c + st * x_s) : u32x4{0, 0, 0, 0};
         }
     };
+    auto fill = [&](int u, int c) { fill_w(u, c); fill_x(u, c); };
     f32x16 acc[G];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
     if (active) {
+        // first ring: x (L2) in front of the weights (HBM), see k_gemv
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (c0 + u < cend) fill(u, c0 + u);
+            if (c0 + u < cend) fill_x(u, c0 + u);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c0 + u < cend) fill_w(u, c0 + u);
         for (int c = c0; c < cend; c += U) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -795,6 +830,12 @@ int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
     return a.M <= 16 ? launch_k<MODE, 1, KP, false, 4, F8>(s, a) : launch_k<MODE, 2, KP, false, 4, F8>(s, a);
 }
 }  // namespace
+
+#ifdef SR_GEMV_TIMING
+extern "C" int sr_dbg_gemv_times(long long* host_out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tgv), (size_t)n_blocks * 4 * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // Also measured at M = 32: doubling the weight rows a wave owns per x fragment (half the x load instructions) is slower -- gate/up 25.5 vs
 // 22.7 us, qkv 11.1 vs 10.4 us: the halved wave count costs more than the saved L2 reads.
