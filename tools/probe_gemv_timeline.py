@@ -6,7 +6,7 @@ they END (tail), against the launch's span and the time the bytes would take at 
 import ctypes as C, json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-L = C.CDLL(os.path.join(ROOT, "socioreasoner_amd", "libsocior_timing.so"))
+L = C.CDLL(os.path.join(ROOT, "socioreasoner_amd", os.environ.get("SR_TIMING_LIB", "libsocior_timing.so")))
 vp, ci = C.c_void_p, C.c_int
 L.sr_op_gemv.argtypes = [vp, ci, vp, ci, ci, ci, vp, ci, ci, vp]
 L.sr_op_gemv_fused.argtypes = [vp, ci, vp, ci, ci, ci, vp, ci, ci, vp, vp, C.c_float, vp, ci, vp, vp, vp, vp]
