@@ -488,3 +488,33 @@ def test_rows_mode_above_32_rows_tiny_engine(B):
         cb.pump(lambda r, t: (None if r.aborted else done.__setitem__(r.tag, t)))
     assert victim.tag not in done and len(done) == B - 1
     e.close()
+
+
+# ------------------------------------------------------------------------------------------------ 256-tile GEMM: staging schedule
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,epi,tiled", [(32768, 1280, 1280, EPI_RESID, False), (14336, 2560, 2048, EPI_STORE, True), (8192, 6912, 1280, 2, False),
+                                              (2048, 2048, 128, EPI_STORE, False), (3000, 1024, 192, EPI_RESID, True), (14336, 2048, 11008, EPI_RESID, True)])
+def test_gemm256_schedule_race_screen_on_hot_shapes(L, M, N, K, epi, tiled):
+    """gemm256.hip keeps LDS-DMA units in flight across barriers and (round 4) reads the next k-tile's B0 fragments one phase after the
+    counted wait that retires their unit.  A read that beats its unit shows up as run-to-run differences or as a difference from the
+    128-tile kernel (same k order, LDS filled with drained waits): 12 launches per shape on the batch-32 shapes (every CU busy, several
+    rounds), the minimal k-tile counts (2 and 3: prologue and tail paths only) and the longest K."""
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.03).to(torch.bfloat16)
+    No = N // 2 if epi == 2 else N
+    res0 = torch.randn(M, No, device="cuda", generator=g).to(torch.bfloat16) if epi == EPI_RESID else None
+    fl = 0x100 if tiled else 0
+
+    def run(force):
+        out = torch.zeros(M, No, dtype=torch.bfloat16, device="cuda")
+        if epi == EPI_RESID:
+            out.copy_(res0)
+        assert L.sr_op_gemm(P(a), K, P(w), M, N, K, P(out), No, None, P(out) if epi == EPI_RESID else None, None, epi | force | fl, sp()) == 0
+        torch.cuda.synchronize()
+        return out
+
+    ref = run(0x400)
+    for it in range(12):
+        got = run(0x200)
+        assert torch.equal(got, ref), (it, M, N, K, float((got.float() - ref.float()).abs().max()))
