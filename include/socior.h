@@ -87,6 +87,10 @@ int sr_synth_fill(void* dev_out_bf16, int64_t n, const char* hf_name, uint32_t s
 /* K1 -- replaces the HF image processor's rescale/normalise/patchify (hf:models/qwen2_vl/
  * image_processing_pil_qwen2_vl.py:153-248, invoked at roll/datasets/collator.py:456-461): uint8 HWC image (h, w
  * multiples of patch*merge, already smart_resize'd) -> bf16 patch rows [N, sr_pixel_ld()], zero padded. */
+/* The attention plan of the last sr_vit_forward's grids: out4 = {window work items, full-attention work items, 1 when every window holds exactly 64
+ * tokens (the window blocks then run k_attn_win64), 1 when every image starts on a multiple of 8 patches (full attention through k_attn_prefill2)}.
+ * Lets tests assert WHICH kernel a geometry takes. */
+int sr_vit_plan(const sr_engine* e, int32_t* out4);
 int sr_pixel_ld(const sr_engine* e);
 int sr_patchify_u8(sr_engine* e, const uint8_t* dev_img_hwc, int h, int w, void* dev_pixels_bf16, void* stream);
 

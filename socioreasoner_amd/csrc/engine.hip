@@ -460,7 +460,8 @@ int vit_prepare(sr_engine* e, const int64_t* grid, int n_img, hipStream_t s, int
                         ++new_unit;
                     }
                 const int len = (new_unit - start_unit) * unit;
-                if (len != 64 || (start_unit * unit) % 4) all64 = false;
+                // (HF pads one whole extra window row / column when the grid IS a multiple of the window: those windows are empty and make no work item)
+                if (len != 0 && (len != 64 || (start_unit * unit) % 4)) all64 = false;
                 for (int q0 = 0; q0 < len; q0 += 64)
                     h_win[n_win++] = AttnWork{start_unit * unit + q0, len, q0, start_unit * unit, (long long)start_unit * unit};
             }
@@ -835,6 +836,11 @@ int sr_load_weight(sr_engine* e, const char* hf_name, const void* p, int dtype, 
     return 0;
 }
 
+int sr_vit_plan(const sr_engine* e, int32_t* out4) {
+    if (!e || !out4) return -22;
+    out4[0] = e->v_nwork_win; out4[1] = e->v_nwork_full; out4[2] = e->v_win_all64 ? 1 : 0; out4[3] = e->v_full_aligned ? 1 : 0;
+    return 0;
+}
 int sr_pixel_ld(const sr_engine* e) { return e->v_pd_pad; }
 
 int sr_patchify_u8(sr_engine* e, const uint8_t* img, int h, int w, void* out, void* stream) {

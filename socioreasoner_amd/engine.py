@@ -153,6 +153,12 @@ class Engine:
                                         C.c_void_p(out.data_ptr()), self._s()), self._h, "sr_vit_forward")
         return out
 
+    def vit_plan(self) -> dict:
+        """Which attention kernels the last vit_forward's grids take (sr_vit_plan)."""
+        out = np.zeros(4, dtype=np.int32)
+        L.check(self.lib.sr_vit_plan(self._h, out.ctypes.data_as(L._i32p)), self._h, "sr_vit_plan")
+        return {"window_items": int(out[0]), "full_items": int(out[1]), "windows_all_64": bool(out[2]), "full_aligned": bool(out[3])}
+
     # ------------------------------------------------------------------ LM
     def prefill(self, ids: Sequence[np.ndarray], pos3: Sequence[np.ndarray], image_embeds: torch.Tensor | None = None,
                 slots: Iterable[int] | None = None, return_logits: bool = False):

@@ -61,6 +61,7 @@ SIGNATURES = {
     "sr_rows_poll": (C.c_int, [_vp, _i32p, _i32p, _vp]),
     "sr_rows_read": (C.c_int, [_vp, _i, _vp, _i, _vp]),
     "sr_rows_abort": (C.c_int, [_vp, _i32p, _i, _vp]),
+    "sr_vit_plan": (C.c_int, [_vp, _i32p]),
     "sr_mask_union": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "sr_resize_nearest_u8": (C.c_int, [_vp, _i, _i, _vp, _i, _i, _vp]),
     "sr_iou_counts": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),

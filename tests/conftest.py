@@ -16,3 +16,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _release_device_objects(request):
+    """GPU tests build engines with multi-GB workspaces, hipGraphs and CU-masked streams; objects a test leaves to the cyclic garbage collector
+    (pipelines that own their strategies' engines) would otherwise be finalised -- device synchronize + sr_engine_destroy -- at an arbitrary
+    allocation inside a LATER test's launch sequence.  Finalise them here, between tests, with the device idle."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gc
+
+        import torch
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()

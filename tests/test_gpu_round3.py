@@ -252,5 +252,8 @@ def test_window_attention_without_lds_equals_the_staged_kernel_bit_for_bit(monke
         monkeypatch.setenv("SR_ATTN_WIN64", mode)
         out[mode] = e.vit_forward(pix, [grid] * n).clone()
         torch.cuda.synchronize()
+    # (round 4: 448- and 896-pixel tiles -- grids that ARE a multiple of the window, where HF pads an empty window row / column -- used to be
+    # refused the kernel because of those empty windows; the plan says which kernel a geometry takes)
+    assert e.vit_plan()["windows_all_64"] == (hw in (448, 896)), e.vit_plan()
     assert torch.equal(out["0"].view(torch.int16), out["1"].view(torch.int16))
     e.close()
