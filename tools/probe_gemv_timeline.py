@@ -30,7 +30,13 @@ cases = [
     ("down (partial, ksplit 4)", mk(H, I), H * I * 2, torch.zeros(4, B, H, device="cuda"),
      lambda w, o: L.sr_op_gemv(P(x), I, P(w), B, H, I, P(o), 4, 0 | WT | XT, s)),
 ]
+V = 151936
+nblk = 4096
+av = torch.zeros(32, nblk, device="cuda"); ai = torch.zeros(32, nblk, dtype=torch.int32, device="cuda")
+cases.append(("lm head (f32 + argmax)", (torch.randn(2, V, H, device="cuda") * 0.02).to(torch.bfloat16), V * H * 2, torch.zeros(B, V, device="cuda"),
+              lambda w, o: L.sr_op_gemv_fused(P(x), H, P(w), B, V, H, P(o), V, 2 | WT | XT, None, None, 0.0, None, 0, None, P(av), P(ai), s)))
 for name, W, nbytes, out, fn in cases:
+    R = W.shape[0]
     for it in range(3):
         for r in range(R):
             assert fn(W[r], out) == 0
@@ -46,7 +52,7 @@ for name, W, nbytes, out, fn in cases:
     assert L.sr_dbg_gemv_times(t.ctypes.data, 16384) == 0
     # blocks of the LAST launch: stamps newer than ... take all rows whose t0 is within 100 us of the newest stamp
     newest = t[:, 3].max()
-    live = (t[:, 0] > newest - 10000) & (t[:, 3] >= t[:, 0])
+    live = (t[:, 0] > newest - int(us_launch * 130)) & (t[:, 3] >= t[:, 0])
     tt = t[live].astype(np.float64) * 0.01
     t0 = tt[:, 0].min()
     q = lambda v, p_: round(float(np.percentile(v, p_)), 2)
