@@ -40,7 +40,7 @@ for name, c in fetch.items():
                  "avg_us_under_pmc": round(c["FETCH_SIZE"]["avg_us"], 1)}
     tot[B][0] += rd
     tot[B][1] += ALGO[launch]
-json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python tools/probe_r2.py gemv (separate passes: tools/gpu_r3_pmc_gemv.sh), round 3; "
+json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python tools/probe_r2.py gemv (separate passes: the script that wrote this file -- tools/gpu_r4_profiles.sh in round 4); "
                      "counter summed over its instances per dispatch, averaged over the dispatches (tools/rocpd_pmc.py, tools/gemv_traffic.py)",
            "correction": "FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 note in MI355X_MICROARCH.md).  traffic_over_algorithmic = HBM reads / weight bytes "
                          "(as in profiles/r02_pmc_gemv_traffic.json); the writes (float32 logits of the LM head, the down-projection's four float32 slabs) are listed beside it",
