@@ -11,6 +11,7 @@
 // 157 TF/s = 1/16 of the bf16 rate (MI355X_MICROARCH.md "Matrix cores"), each product and sum an exact float32 fmaf chain -- the
 // arithmetic torch's CPU float32 path performs, up to the order of the sums.
 #include "kernels.h"
+#include <type_traits>
 #include <math.h>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -92,34 +93,64 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmF32Args p, int n_tiles_
         if (kt + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
     }
-    // epilogue: D[n][m], lane (kg, col): m = col, n = 8 * (v / 4) + 4 * kg + v % 4
+    // epilogue: D[n][m], lane (kg, col): m = col, n = 8 * (v / 4) + 4 * kg + v % 4.
+    // Instantiated per (bias, residual, activation) case behind block-uniform branches.  The residual may alias the output (the blocks add
+    // in place), so inside one store loop every residual load waited for the previous store: the four float4s of a (row group, column
+    // half) are fetched together, ahead of its stores -- four round trips per tile instead of sixteen.  (All sixteen up front cost 86 more
+    // registers and two of the four blocks a CU holds: batched encoder 156 -> 164 ms.  With four blocks per CU the others' k loops hide what
+    // is left.)  Same arithmetic, same order.
+    auto epilogue = [&](auto hb_, auto hr_, auto act_) {
+        constexpr bool HB = decltype(hb_)::value, HR = decltype(hr_)::value;
+        constexpr int ACT = decltype(act_)::value;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + col;
-        if (m >= p.M) continue;
-        const size_t orow = (size_t)(p.rowmap ? p.rowmap[m] : m) * p.ldo;
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wm * 64 + i * 32 + col;
+            if (m >= p.M) continue;
+            const size_t orow = (size_t)(p.rowmap ? p.rowmap[m] : m) * p.ldo;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                float4 rv[4];
+                if constexpr (HR) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * kg;
-                if (n >= p.N) continue;
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = acc[j][i][4 * q + e];
-                    if (p.bias) x += p.bias[n + e];
-                    if (p.act == 1) x = gelu_f(x);
-                    else if (p.act == 2) x = fmaxf(x, 0.f);
-                    o[e] = x;
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * kg;
+                        rv[q] = n < p.N ? *reinterpret_cast<const float4*>(p.resid + orow + n) : float4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
-                if (p.resid) {
-                    const float4 r = *reinterpret_cast<const float4*>(p.resid + orow + n);
-                    o[0] = r.x + o[0]; o[1] = r.y + o[1]; o[2] = r.z + o[2]; o[3] = r.w + o[3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * kg;
+                    if (n >= p.N) continue;
+                    float o[4];
+                    float4 bq = float4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (HB) bq = *reinterpret_cast<const float4*>(p.bias + n);
+                    const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[j][i][4 * q + e];
+                        if constexpr (HB) x += bb[e];
+                        if constexpr (ACT == 1) x = gelu_f(x);
+                        else if constexpr (ACT == 2) x = fmaxf(x, 0.f);
+                        o[e] = x;
+                    }
+                    if constexpr (HR) {
+                        const float4 r = rv[q];
+                        o[0] = r.x + o[0]; o[1] = r.y + o[1]; o[2] = r.z + o[2]; o[3] = r.w + o[3];
+                    }
+                    *reinterpret_cast<float4*>(p.out + orow + n) = float4{o[0], o[1], o[2], o[3]};
                 }
-                *reinterpret_cast<float4*>(p.out + orow + n) = float4{o[0], o[1], o[2], o[3]};
             }
-    }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    auto by_act = [&](auto hb_, auto hr_) {
+        if (p.act == 1) epilogue(hb_, hr_, std::integral_constant<int, 1>{});
+        else if (p.act == 2) epilogue(hb_, hr_, std::integral_constant<int, 2>{});
+        else epilogue(hb_, hr_, std::integral_constant<int, 0>{});
+    };
+    if (p.bias) { if (p.resid) by_act(T_{}, T_{}); else by_act(T_{}, F_{}); }
+    else { if (p.resid) by_act(F_{}, T_{}); else by_act(F_{}, F_{}); }
 }
 
 // ------------------------------------------------------------------------------------------------ attention
@@ -225,7 +256,7 @@ __global__ __launch_bounds__(256) void k_attn_f32(AttnF32Args p) {
 
 int launch_gemm_f32(hipStream_t s, const GemmF32Args& a) {
     if (a.M <= 0 || a.N <= 0) return 0;
-    if (a.K % GK || a.N % 4 || a.ldo % 4 || a.lda % 4 || (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.out | (uintptr_t)a.resid) & 15)) return -22;
+    if (a.K % GK || a.N % 4 || a.ldo % 4 || a.lda % 4 || (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.out | (uintptr_t)a.resid | (uintptr_t)a.bias) & 15)) return -22;      // (bias is read 16 bytes at a time)
     const int tn = cdiv(a.N, GB), tm = cdiv(a.M, GB);
     hipLaunchKernelGGL(k_gemm_f32, dim3((unsigned)tn * (unsigned)tm), dim3(256), 0, s, a, tn);
     SR_CHECK_LAUNCH();
