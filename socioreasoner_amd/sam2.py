@@ -31,6 +31,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import gc
 import os
 from dataclasses import dataclass
 from collections import OrderedDict
@@ -547,8 +548,17 @@ class Sam2Engine:
             out = self._decode_launches(Ts, tok)     # eager once: allocates every buffer / work list, raises kernel attributes
             torch.cuda.synchronize(self.device)
             cg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cg, capture_error_mode="thread_local"):
-                out = self._decode_launches(Ts, tok)
+            # No Python garbage collection while the stream is capturing: a finaliser that touches the device (another engine's close(), a
+            # tensor freed on a different stream) is an illegal call inside a capture and takes the process down (seen once in the GPU suite:
+            # "Fatal Python error: Aborted ... Garbage-collecting" under this call).  torch.cuda.graph collects BEFORE it begins the capture.
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(cg, capture_error_mode="thread_local"):
+                    out = self._decode_launches(Ts, tok)
+            finally:
+                if gc_was_on:
+                    gc.enable()
             gr = self._graphs[Ts] = (cg, out)
         gr[0].replay()
         return gr[1]
