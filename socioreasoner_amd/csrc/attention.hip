@@ -29,6 +29,19 @@
 
 namespace {
 
+// the four scores of an accumulator: s = bf16(bf16(acc) * scale), two roundings per v_cvt_pk_bf16_f32 (rbf2, common.h) instead of one each --
+// the prefill attention kernels are bound by instruction issue; same values as rbf(rbf(x) * scale)
+__device__ __forceinline__ void scaled_scores4(const f32x4& acc, float scale, float (&v)[4]) {
+    float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+    rbf2(a0, a1);
+    rbf2(a2, a3);
+    a0 *= scale; a1 *= scale; a2 *= scale; a3 *= scale;
+    rbf2(a0, a1);
+    rbf2(a2, a3);
+    v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
+}
+
+
 constexpr int QT = 64;   // queries per block (4 waves x 16)
 constexpr int KT = 64;   // keys per staged tile
 constexpr int VT_RS = 136;  // V^T LDS row stride in bytes: 64 keys * 2 B + 8 B pad (conflict-free ds_read_b64)
@@ -111,12 +124,13 @@ __global__ __launch_bounds__(256) void k_attn_prefill(AttnArgs p) {
                 bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + (t * 16 + fr) * C::K_RS + (kk * 4 + fg) * 16);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
             }
+            float sv[4];
+            scaled_scores4(acc, p.scale, sv);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int kidx = kv0 + t * 16 + fg * 4 + r;
                 const bool ok = kidx < wk.seq_len && (!CAUSAL || kidx <= qpos);
-                const float v = rbf(rbf(acc[r]) * p.scale);
-                s[t][r] = ok ? v : -INFINITY;
+                s[t][r] = ok ? sv[r] : -INFINITY;
             }
         }
     };
@@ -239,8 +253,7 @@ __global__ __launch_bounds__(256) void k_attn_win64(AttnArgs p) {
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < C::KS; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][kk], qf[qs][kk], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[t][r] = rbf(rbf(acc[r]) * p.scale);
+            scaled_scores4(acc, p.scale, s[t]);
         }
         float m = -INFINITY;
 #pragma unroll
@@ -343,8 +356,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn_fewq(AttnArgs p) {
                 bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + (t * 16 + fr) * C::K_RS + (kk * 4 + fg) * 16);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
             }
+            float sv[4];
+            scaled_scores4(acc, p.scale, sv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[t][r] = (kv0 + t * 16 + fg * 4 + r < wk.seq_len) ? rbf(rbf(acc[r]) * p.scale) : -INFINITY;
+            for (int r = 0; r < 4; ++r) s[t][r] = (kv0 + t * 16 + fg * 4 + r < wk.seq_len) ? sv[r] : -INFINITY;
         }
     };
     // ---- pass 1 over this wave's tiles
@@ -570,16 +585,16 @@ __global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_unit
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
         }
         if (masked) {
+            float sv[4];
+            scaled_scores4(acc, p.scale, sv);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int kidx = kv0 + t * 16 + fg * 4 + r;
                 const bool ok = kidx < seq_len && (!CAUSAL || kidx <= qpos);
-                const float v = rbf(rbf(acc[r]) * p.scale);
-                s[r] = ok ? v : -INFINITY;
+                s[r] = ok ? sv[r] : -INFINITY;
             }
         } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[r] = rbf(rbf(acc[r]) * p.scale);
+            scaled_scores4(acc, p.scale, s);
         }
     };
     const int q_first = q_off + (wave % QW) * 16;       // first query position of this wave
