@@ -189,3 +189,19 @@ def test_checkpoint_directory_processor_equals_the_offline_stand_in(tmp_path):
     # stage-2 text goes through the same tokenizer: decode(encode(text)) round-trips, special tokens keep their ids
     text = P.format_prompt_2("school", '[{"bbox_2d": [1, 2, 3, 4]}]', hf)
     assert hf.tokenizer.encode(text, add_special_tokens=False) == st.tokenizer.encode(text) and hf.tokenizer.decode(st.tokenizer.encode(text)) == text
+
+
+def test_scheduler_share_model_picks_the_measured_splits():
+    """ContinuousBatcher._pick_share (the "auto" admission share of the chip): with the calibration the bench measures -- a 32-tile admission
+    122 ms on the whole chip, a decode step 2.5 ms -- it must pick 3 of 8 CUs per shader engine for 448-pixel tiles and 4 of 8 for the
+    reference's two-image samples (218 ms per admission), the splits the sweeps of DESIGN.md "Continuous batching" measured as best; a longer
+    admission never gets a smaller share, and when the running rows are about to finish anyway (nothing left to slow down) the largest share wins."""
+    from types import SimpleNamespace
+    from socioreasoner_amd.serving import ContinuousBatcher as CB
+    stub = SimpleNamespace(_step_ms=2.5, steps_per_poll=16, _ADM_EFF=CB._ADM_EFF, _DEC_SLOW=CB._DEC_SLOW)
+    pick = lambda a_ms, left: CB._pick_share(stub, a_ms, left)
+    assert pick(122.0, 112) == 3
+    assert pick(218.0, 112) == 4
+    shares = [pick(a, 112) for a in (40.0, 80.0, 122.0, 160.0, 218.0, 300.0, 500.0)]
+    assert shares == sorted(shares) and shares[0] >= 2 and shares[-1] <= 5, shares
+    assert pick(122.0, 1) == 5
