@@ -700,6 +700,14 @@ __global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_unit
 // but SLOWER -- 11.3 vs 9.9 us per layer at batch 1, 17.0 vs 11.7 us at batch 32: 147 KB of K per block costs two dependent
 // load rounds, more than the launch boundary it saves.
 constexpr int DEC_HD = 128;
+// -DSR_ATTN_TIMING (tools/probe_attn_decode_timeline.py builds its own library with it; never the product build): thread 0 of every block
+// stamps the 100 MHz clock at the phase boundaries of the two decode attention kernels
+#ifdef SR_ATTN_TIMING
+__device__ long long g_tad[2][8192 * 5];
+#define TAD(k, slot) do { if (threadIdx.x == 0) { const int b_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (b_ < 8192) g_tad[k][b_ * 5 + (slot)] = wall_clock64(); } } while (0)
+#else
+#define TAD(k, slot)
+#endif
 
 __device__ __forceinline__ void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2) {
     o1 = rbf(rbf(x1 * c) + rbf((-x2) * s));
@@ -711,6 +719,7 @@ __global__ __launch_bounds__(256) void k_attn_dec_scores(DecodeAttnArgs p) {
     __shared__ __attribute__((aligned(16))) bf16_t k_s[128];
     __shared__ float cs[64], sn[64];
     const int b = blockIdx.x, kvh = blockIdx.y, z = blockIdx.z;
+    TAD(0, 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int G = p.group, HQ = p.n_q_heads, HK = p.n_kv_heads;
@@ -773,6 +782,7 @@ __global__ __launch_bounds__(256) void k_attn_dec_scores(DecodeAttnArgs p) {
         sn[tid] = bf2f(p.rope_sin[(size_t)pos * 64 + tid]);
     }
     __syncthreads();
+    TAD(0, 1);                                    // state, q / k / v and the rotary row have arrived
     if (tid < 128) {
         const float x1[8] = {lo16(q1.x), hi16(q1.x), lo16(q1.y), hi16(q1.y), lo16(q1.z), hi16(q1.z), lo16(q1.w), hi16(q1.w)};
         const float x2[8] = {lo16(q2.x), hi16(q2.x), lo16(q2.y), hi16(q2.y), lo16(q2.z), hi16(q2.z), lo16(q2.w), hi16(q2.w)};
@@ -792,6 +802,7 @@ __global__ __launch_bounds__(256) void k_attn_dec_scores(DecodeAttnArgs p) {
         k_s[d + 64] = b2;
     }
     __syncthreads();
+    TAD(0, 2);                                    // q / k rotated
     if (t >= ntiles) return;
     if (key == idx) {                             // rows of (or clamped to) the new token come from LDS
 #pragma unroll
@@ -803,10 +814,12 @@ __global__ __launch_bounds__(256) void k_attn_dec_scores(DecodeAttnArgs p) {
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(q_s + fr * 136 + kk * 32 + fg * 8);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kk], qf, acc, 0, 0, 0);
     }
+    TAD(0, 3);                                    // K fragments arrived, MFMAs issued
     if (fr < G) {
         uint2 v = {pack2(rbf(acc[0]) * p.scale, rbf(acc[1]) * p.scale), pack2(rbf(acc[2]) * p.scale, rbf(acc[3]) * p.scale)};
         *reinterpret_cast<uint2*>(p.scores + ((size_t)(b * HK + kvh) * G + fr) * p.ctx_max + t * 16 + fg * 4) = v;
     }
+    TAD(0, 4);
 }
 
 // DT = 16-wide d-tiles per block: 1 at small batch (most blocks), 2 at batch >= 16 (the softmax of a (sequence, kv head) is then
@@ -818,6 +831,7 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
     f32x4* ored = reinterpret_cast<f32x4*>(dsm);
     bf16_t* sb = reinterpret_cast<bf16_t*>(ored + DT * 3 * 64);
     const int b = blockIdx.x, kvh = blockIdx.y, dt0 = blockIdx.z * DT;
+    TAD(1, 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int G = p.group, HK = p.n_kv_heads;
@@ -867,6 +881,7 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
         }
     }
     __syncthreads();
+    TAD(1, 1);                                    // state + score rows arrived, scores in LDS
     // softmax per head (float32), probabilities rounded to bf16 in place; tail zero-filled
     for (int hh = wave; hh < G; hh += 4) {
         bf16_t* srow = sb + hh * s_stride;
@@ -915,6 +930,7 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
         }
     }
     __syncthreads();
+    TAD(1, 2);                                    // softmax done
     // O^T[d][head] for the block's d-tiles; the 4 waves split the key blocks and reduce through LDS in fixed order
     f32x4 oacc[DT];
 #pragma unroll
@@ -943,6 +959,7 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
                 if (kb0 + 4 * i < nkb) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[i], pfrag(kb0 + 4 * i), oacc[d], 0, 0, 0);
         }
     }
+    TAD(1, 3);                                    // V^T arrived, MFMAs issued
     if (wave > 0) {
 #pragma unroll
         for (int d = 0; d < DT; ++d) ored[(d * 3 + wave - 1) * 64 + lane] = oacc[d];
@@ -961,6 +978,7 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
             *reinterpret_cast<uint2*>(p.out + (p.out_tiled ? tiled_offset((size_t)b, (size_t)col, (size_t)p.out_stride) : (size_t)b * p.out_stride + col)) = v;
         }
     }
+    TAD(1, 4);
 }
 
 
@@ -969,6 +987,12 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
 
 
 }  // namespace
+
+#ifdef SR_ATTN_TIMING
+extern "C" int sr_dbg_attn_dec_times(long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tad), sizeof(long long) * 2 * 8192 * 5, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 template <int HD, bool CAUSAL, int QW, int NS>
 static int launch_prefill2(hipStream_t s, const AttnArgs& a) {
