@@ -48,8 +48,12 @@ __device__ __forceinline__ int swz2(int row, int chunk) { return row * (BK2 * 2)
 #ifdef SR_G256_TIMING
 __device__ long long g_t256[16384 * 6];
 #define T256(slot, v) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_t256[blockIdx.x * 6 + (slot)] = (v); } while (0)
+// the phases of ONE steady-state k-tile (t == 5) in shader clocks (s_memtime), for the first wave of each wave row (threads 0 and 256)
+__device__ long long g_p256[1024 * 2 * 6];
+#define P256(slot) do { if (t == 5 && (threadIdx.x & 255) == 0 && blockIdx.x < 1024) g_p256[(blockIdx.x * 2 + (threadIdx.x >> 8)) * 6 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define T256(slot, v)
+#define P256(slot)
 #endif
 template <int EPI, bool MX>
 __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, int GROUP) {
@@ -242,21 +246,25 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
 
     for (int t = 0; t < nk; ++t) {
         const unsigned char* buf = smem + (t & 1) * BUF_BYTES;
+        P256(0);
         // p0
         read_w(buf, 0, wf0);
         read_a(buf, 0);
         read_scales(t, 0);
         if (t + 1 < nk) stage_a(1, t + 1);
         PHASE_SYNC_COMPUTE(0, 0, wf0)
+        P256(1);
         // p1
         read_w(buf, 1, wf1);
         if (t + 1 < nk) stage_w(MX ? 0 : 1, t + 1);       // MX re-reads UB0 in p3, so UB0 / UB1 trade places in the staging order
         PHASE_SYNC_COMPUTE(0, 1, wf1)
+        P256(2);
         // p2
         read_a(buf, 1);
         read_scales(t, 1);
         if (t + 2 < nk) stage_a(0, t + 2);
         PHASE_SYNC_COMPUTE(1, 1, wf1)
+        P256(3);
         // p3 (MX: the 8-register operands leave no room to keep B0 alive through p1 / p2 -- it is re-read here, like the guide's
         // template does.  UB0 is then busy until p3, so MX stages UA1(t+1) | UB0(t+1) | UA0(t+2) | UB1(t+2) in p0..p3: every unit is
         // still re-staged >= 2 phases after its last read, and vmcnt(4) at p3 still retires everything k-tile t + 1 needs)
@@ -264,6 +272,7 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
         if (t + 2 < nk) { stage_w(MX ? 1 : 0, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PHASE_SYNC_COMPUTE(1, 0, wf0)
+        P256(4);
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();       // balance the extra barrier of the other wave row
 #undef PHASE_SYNC_COMPUTE
@@ -604,6 +613,9 @@ int launch256_t(hipStream_t s, const GemmArgs& a) {
 #ifdef SR_G256_TIMING
 extern "C" int sr_dbg_g256_times(long long* host_out, int n_blocks) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_t256), (size_t)n_blocks * 6 * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+extern "C" int sr_dbg_g256_phases(long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_p256), sizeof(long long) * 1024 * 2 * 6, 0, hipMemcpyDeviceToHost);
 }
 #endif
 
