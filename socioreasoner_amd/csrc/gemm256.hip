@@ -49,11 +49,13 @@ __device__ __forceinline__ int swz2(int row, int chunk) { return row * (BK2 * 2)
 __device__ long long g_t256[16384 * 6];
 #define T256(slot, v) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_t256[blockIdx.x * 6 + (slot)] = (v); } while (0)
 // the phases of ONE steady-state k-tile (t == 5) in shader clocks (s_memtime), for the first wave of each wave row (threads 0 and 256)
-__device__ long long g_p256[1024 * 2 * 6];
+__device__ long long g_p256[1024 * 2 * 6 + 2048];      // (+ per block: s_memtime at the start and at the end of the k loop, next to T256's wall clock)
+#define C256(slot) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_p256[1024 * 2 * 6 + blockIdx.x * 2 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define P256(slot) do { if (t == 5 && (threadIdx.x & 255) == 0 && blockIdx.x < 1024) g_p256[(blockIdx.x * 2 + (threadIdx.x >> 8)) * 6 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define T256(slot, v)
 #define P256(slot)
+#define C256(slot)
 #endif
 template <int EPI, bool MX>
 __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, int GROUP) {
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();       // the second wave row runs half a phase behind the first
     T256(1, wall_clock64());
+    C256(0);
 
     for (int t = 0; t < nk; ++t) {
         const unsigned char* buf = smem + (t & 1) * BUF_BYTES;
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(512) void k_gemm256(GemmArgs p, int ntm, int ntn, i
     if (wm == 0) __builtin_amdgcn_s_barrier();       // balance the extra barrier of the other wave row
 #undef PHASE_SYNC_COMPUTE
     T256(2, wall_clock64());
+    C256(1);
 
     // ---- epilogue (same rounding points as gemm.hip).  lane owns row m = .. + fr and columns n = .. + fg*4 + {0..3}.
     // Column-only operands (bias, fp8 scale) and the row map are fetched once, up front: no memory wait inside the store loop.
@@ -615,7 +619,7 @@ extern "C" int sr_dbg_g256_times(long long* host_out, int n_blocks) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_t256), (size_t)n_blocks * 6 * sizeof(long long), 0, hipMemcpyDeviceToHost);
 }
 extern "C" int sr_dbg_g256_phases(long long* host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_p256), sizeof(long long) * 1024 * 2 * 6, 0, hipMemcpyDeviceToHost);
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_p256), sizeof(long long) * (1024 * 2 * 6 + 2048), 0, hipMemcpyDeviceToHost);
 }
 #endif
 
