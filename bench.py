@@ -423,9 +423,11 @@ def main():
         # invariance): one extra batch-1 step with it switched on, reported beside the default numbers
         sk_ms = {"vit": 0.0, "prefill": 0.0, "decode": 0.0, "raster": 0.0}
         os.environ["SR_SPLITK"] = "1"
+        L.reload_switches()            # the library reads its switches once, not per call
         step_static(1)
         step_static(1, sk_ms)
         os.environ.pop("SR_SPLITK")
+        L.reload_switches()
         latency = {"workload": "BASELINE.json configs[1]: batch 1, one tile per step", "tiles_per_s": round(ksteps / d1, 4),
                    "ms_per_tile": round(d1 / ksteps * 1e3, 3), "steps": ksteps,
                    "phase_ms": {k: round(v / ksteps, 3) for k, v in lat_ms.items()},

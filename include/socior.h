@@ -288,6 +288,15 @@ int sr_op_quant_f8(void* dev_w_tiled, int N, int K, void* dev_w8, float* dev_sca
 int sr_op_gemv_f8(const void* x, int ldx, const void* w8, const float* w_scale, int M, int N, int K, void* out, int ldo, int mode,
                   const void* bias, const void* norm_w, float eps, int ksplit, void* stream);
 int sr_version(void);
+/* The library's SR_* tuning / test switches ("Switches") are read from the environment once -- at the first call that
+ * needs one and again at every sr_engine_create -- never in per-call dispatch.  A caller that changes one of them inside a running process
+ * (the bit-identity tests do) calls this to have the environment read again.  No reference counterpart (vLLM reads its VLLM_* variables at
+ * import: roll/distributed/strategy/vllm_strategy.py:13-30). */
+int sr_switches_reload(void);
+/* Round 5: at 5..32 decode rows the RMSNorms of a layer run inside the o_proj / down-projection launches (their last-arriving blocks; hf
+ * modeling_qwen2_5_vl.py:65-79, 708-758).  A tail block that gives up waiting for the launch's other blocks counts here -- 0 in a healthy
+ * run (tests assert it); a negative value is an error. */
+int sr_tail_timeouts(sr_engine* e, void* stream);
 
 #ifdef __cplusplus
 }

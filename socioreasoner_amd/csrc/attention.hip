@@ -1012,10 +1012,9 @@ static int launch_prefill2(hipStream_t s, const AttnArgs& a) {
 
 // which kernel takes the launch: 2 = k_attn_prefill2 (8-wave blocks sharing LDS-DMA-staged tiles; needs a.v2_ok from the caller:
 // 16-byte aligned V^T key runs with finite contents, work items cut at a.q_tile queries), 1 = k_attn_prefill.  SR_ATTN2=0 forces the
-// round-2 kernel (read at every call: the bit-identity tests flip it).
+// round-2 kernel (the bit-identity tests flip it and call sr_switches_reload).
 int attn_prefill_variant(const AttnArgs& a, int head_dim) {
-    const char* env = getenv("SR_ATTN2");
-    if (env && atoi(env) == 0) return 1;
+    if (!sr_switches().attn2) return 1;
     if (!a.v2_ok) return 1;
     if (head_dim == 128 && a.causal && a.q_tile == 64 && a.group % 4 == 0 && a.n_heads % 4 == 0) return 2;
     if (head_dim == 80 && !a.causal && a.q_tile == 128 && a.group == 1) return 2;
@@ -1029,8 +1028,7 @@ int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim) {
         return launch_prefill2<80, false, 8, 3>(s, a);                            // 128 queries x 1 head, 3 x 26 KB ring
     }
     if (a.win64 && head_dim == 80 && !a.causal && a.n_heads % 4 == 0) {      // every item = one 64-token window starting at its first query (caller's promise)
-        const char* env = getenv("SR_ATTN_WIN64");
-        if (!(env && atoi(env) == 0)) {
+        if (sr_switches().attn_win64) {
             hipLaunchKernelGGL((k_attn_win64<80>), dim3(a.n_work, a.n_heads / 4), dim3(256), 0, s, a);
             SR_CHECK_LAUNCH();
             return 0;

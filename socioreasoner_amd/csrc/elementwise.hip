@@ -3,6 +3,7 @@
 // decode bookkeeping and the synthetic-weight generator.  All bf16 traffic is 8- or 16-byte vectorised.
 // Rounding points follow HF's bf16 eager path (hf: transformers/models/qwen2_5_vl/modeling_qwen2_5_vl.py).
 #include "kernels.h"
+#include "rownorm.h"
 #include <math.h>
 
 namespace {
@@ -63,52 +64,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm(bf16_t* x, const bf16_t* xin, c
 __global__ __launch_bounds__(256) void k_rmsnorm_row(bf16_t* x, const bf16_t* xin, const float* part, int ksplit,
                                                      const bf16_t* w, bf16_t* out, int rows, int H, float eps, int out_tiled) {
     __shared__ float wsum[4];
-    const int row = blockIdx.x, c = threadIdx.x, nch = H / 8;
-    const bool on = c < nch;
-    uint4 u = uint4{0, 0, 0, 0}, wu = uint4{0, 0, 0, 0};
-    float4 p0[4], p1[4];
-    if (on) {
-        u = *reinterpret_cast<const uint4*>(xin + (size_t)row * H + c * 8);
-        wu = *reinterpret_cast<const uint4*>(w + c * 8);
-        if (part) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                if (ks < ksplit) {
-                    const float4* pp = reinterpret_cast<const float4*>(part + ((size_t)ks * rows + row) * H + c * 8);
-                    p0[ks] = pp[0];
-                    p1[ks] = pp[1];
-                }
-        }
-    }
-    float v[8] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y), lo16(u.z), hi16(u.z), lo16(u.w), hi16(u.w)};
-    if (on && part) {
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            if (ks < ksplit) {
-                a[0] += p0[ks].x; a[1] += p0[ks].y; a[2] += p0[ks].z; a[3] += p0[ks].w;
-                a[4] += p1[ks].x; a[5] += p1[ks].y; a[6] += p1[ks].z; a[7] += p1[ks].w;
-            }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + rbf(a[e]));
-        *reinterpret_cast<uint4*>(x + (size_t)row * H + c * 8) = uint4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-    }
-    float ss = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
-    ss = wave_sum(ss);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    const float rs = 1.0f / sqrtf((wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)H + eps);
-    if (on) {
-        const float wv[8] = {lo16(wu.x), hi16(wu.x), lo16(wu.y), hi16(wu.y), lo16(wu.z), hi16(wu.z), lo16(wu.w), hi16(wu.w)};
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = wv[e] * rbf(v[e] * rs);
-        // fragment order: the 8 consecutive k of one row stay contiguous (16 B), see tiled_offset in common.h
-        bf16_t* dst = out + (out_tiled ? tiled_offset((size_t)row, (size_t)c * 8, (size_t)H) : (size_t)row * H + c * 8);
-        *reinterpret_cast<uint4*>(dst) = uint4{pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
-    }
+    rmsnorm_row_body<false>(x, xin, false, part, ksplit, w, out, rows, blockIdx.x, H, eps, out_tiled, wsum);     // rownorm.h (shared with the GEMV tails)
 }
 
 // ----------------------------------------------------------------------------------------------- ViT 2-D RoPE (hf:160-171)
@@ -351,6 +307,14 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
     for (int c = tid; c < a.H / 8; c += 256) {
         const bf16_t* from = a.table + (a.table_tiled ? tiled_offset(s_feed, (size_t)c * 8, a.H) : (size_t)s_feed * a.H + c * 8);
         reinterpret_cast<uint4*>(a.x + (size_t)b * a.H)[c] = *reinterpret_cast<const uint4*>(from);
+    }
+    if (a.norm_w) {
+        // round 5: the first layer's input RMSNorm of the row this block just gathered (H <= 2048: one 16-byte chunk per thread) -- with the GEMV
+        // tails (rownorm.h) a 5..32-row decode step then has no RMSNorm launch at all.  The row is re-read through the body shared with
+        // k_rmsnorm_row (the block's own stores, made visible to its other threads by the barrier): same bits as the separate launch.
+        __threadfence_block();
+        __syncthreads();
+        rmsnorm_row_body<false>(nullptr, a.x, false, nullptr, 0, a.norm_w, a.xn, a.B, b, a.H, a.eps, a.xn_tiled, sv);
     }
 }
 

@@ -72,6 +72,28 @@ bf16_t host_f2bf(float f) {
 
 }  // namespace
 
+// ---- SR_* switches: the environment is read here and nowhere else in the library
+static SrSwitches g_sw;
+static bool g_sw_loaded = false;
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
+static void load_switches() {
+    g_sw.splitk = env_int("SR_SPLITK", 0);
+    g_sw.gemm_bm = env_int("SR_GEMM_BM", 0);
+    g_sw.gemm_ring = env_int("SR_GEMM_RING", 1);
+    g_sw.gemm256 = env_int("SR_GEMM256", 1);
+    g_sw.fuse_qkv = env_int("SR_FUSE_QKV", 1);
+    g_sw.g256_group = env_int("SR_G256_GROUP", 4);
+    if (g_sw.g256_group < 1) g_sw.g256_group = 4;
+    g_sw.attn2 = env_int("SR_ATTN2", 1);
+    g_sw.attn_win64 = env_int("SR_ATTN_WIN64", 1);
+    g_sw.tail_norm = env_int("SR_TAIL_NORM", 1);
+    g_sw_loaded = true;
+}
+const SrSwitches& sr_switches() {
+    if (!g_sw_loaded) load_switches();
+    return g_sw;
+}
+
 struct sr_engine {
     sr_config c;
     // derived geometry
@@ -112,6 +134,8 @@ struct sr_engine {
     bf16_t *d_xa, *d_xb, *d_xn, *d_qkv, *d_attn, *d_act, *d_scores;    // d_xa / d_xb: residual stream ping-pong
     float *d_logits, *d_slabs, *d_amax_val;
     float* d_row_cs = nullptr;               // [MAXB][128] rotary cos | sin of every row's current position (k_step -> decode attention)
+    unsigned* d_tail = nullptr;              // [2 * layers] arrival tickets of the decode GEMV tails (rownorm.h) + [1] give-up count; zeroed at the head of every forward
+    int tail_norm = 1;                       // round 5: RMSNorm of a 5..32-row decode layer inside the o_proj / down-projection launches (SR_TAIL_NORM=0: the two launches)
     int *d_amax_idx, *d_cur_tok, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
     int n_part = 0;      // LM-head blocks = partial argmax entries per row
     // continuous batching (sr_rows_*): admission scratch so that a prefill never touches the pending tokens of running rows
@@ -322,6 +346,7 @@ void carve(sr_engine* e) {
     e->d_amax_idx_adm = ar.take<int>(B * e->n_part);
     e->d_row_limit = ar.take<int>(MAXB);
     e->d_row_cs = ar.take<float>(MAXB * 128);
+    e->d_tail = ar.take<unsigned>((size_t)2 * c.t_layers + 64);
     e->d_ngen = ar.take<int>(MAXB);
     e->d_adm = ar.take<int>(5 * MAXB);
     e->d_adm_slots = ar.take<int>(MAXB);
@@ -518,8 +543,7 @@ int gemm(sr_engine* e, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W,
 // through 36 layers of bf16 rounding that is a noise-floor-sized difference (rms 0.03 on the logits, test_small_prefill_split_k_*):
 // correct, but it gives up the batch invariance that the continuous-batching and data-parallel tests assert with torch.equal.
 bool prefill_splitk(const sr_engine* e, int n_tok) {
-    const char* env = getenv("SR_SPLITK");                     // read at every call
-    if (!(env && atoi(env) == 1)) return false;
+    if (sr_switches().splitk != 1) return false;
     return e->c.lm_weight_dtype != 2 && n_tok <= SPLITK_ROWS && e->c.t_hidden <= 2048 && e->c.t_hidden % 512 == 0;
 }
 
@@ -567,15 +591,33 @@ bool x_tiled_ok(const sr_engine* e) {
     return e->c.t_hidden % 64 == 0 && (e->c.t_heads * 128) % 64 == 0 && e->t_inter_pad % 64 == 0 && e->c.t_hidden <= 2048;
 }
 int ks_down(const sr_engine* e, int B) { return (B > 16 && e->t_inter_pad / 64 >= 32) ? 4 : e->ks_down; }
+// round 5: at 5..32 rows the o_proj and down-projection GEMVs finish their rows as the next launch's normalised x
+// (the last B blocks to arrive do residual add + RMSNorm, rownorm.h; the first layer's norm rides in k_step): no RMSNorm launch in the step
+bool tail_norms(const sr_engine* e, int B) {
+    if (!e->tail_norm || fused_norms(e, B) || B > 32 || !x_tiled_ok(e)) return false;
+    const int H = e->c.t_hidden, QD = e->c.t_heads * 128;
+    const bool f8 = e->c.lm_weight_dtype >= 1;
+    GemvArgs go = gv(nullptr, QD, nullptr, B, H, QD, nullptr, H), gd = gv(nullptr, e->t_inter_pad, nullptr, B, H, e->t_inter_pad, nullptr, H);
+    gd.ksplit = ks_down(e, B);
+    if (f8) go.W8 = gd.W8 = reinterpret_cast<const unsigned char*>(e);      // (only its null-ness matters)
+    return gemv_launch_blocks(go, GV_RESID) >= B && gemv_launch_blocks(gd, GV_PARTIAL) >= B;      // one tail block per row
+}
+GemvTail make_tail(sr_engine* e, int idx, const bf16_t* norm_w, bf16_t* x) {
+    GemvTail t{};
+    t.counter = e->d_tail + idx; t.timeout = e->d_tail + 2 * e->c.t_layers;
+    t.norm_w = norm_w; t.eps = e->c.t_rms_eps; t.xn = e->d_xn; t.xn_tiled = 1; t.x = x;
+    return t;
+}
 
 // LM head on B rows of `x` (+ optional pending slabs): float32 logits + per-block argmax partials.
 // Small batches fuse the final RMSNorm (and the pending residual) into the GEMV prologue.
-int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending, hipStream_t s, bool admission = false) {
+int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending, hipStream_t s, bool admission = false, bool normed = false) {
     const sr_config& c = e->c;
     const int H = c.t_hidden;
     GemvArgs g = gv(x, H, e->embed, B, c.t_vocab, H, admission ? e->d_logits_adm : e->d_logits, c.t_vocab);
     g.amax_val = admission ? e->d_amax_val_adm : e->d_amax_val; g.amax_idx = admission ? e->d_amax_idx_adm : e->d_amax_idx;
-    if (fused_norms(e, B)) {
+    if (normed) { g.x = e->d_xn; g.x_tiled = 1; }      // the last down-projection's tail already wrote final_norm(x) fragment-ordered
+    else if (fused_norms(e, B)) {
         g.norm_w = e->final_norm; g.eps = c.t_rms_eps;
         if (pending) { g.slabs = e->d_slabs; g.n_slabs = ks_down(e, B); g.x_out = x_alt; }
     } else {
@@ -600,6 +642,8 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
     bf16_t *x = e->d_xa, *x_alt = e->d_xb;      // k_step gathered the input embedding into d_xa
     bool pending = false;                       // down-projection slabs not yet added to the residual stream
     const float scale = (float)(1.0 / sqrt(128.0));
+    const bool tail = tail_norms(e, B);         // (k_step wrote ln1(x) of layer 0 into d_xn: enqueue_step)
+    if (tail) SR_TRY((int)hipMemsetAsync(e->d_tail, 0, (size_t)2 * c.t_layers * sizeof(unsigned), s));     // a memset node at the head of the captured step
     for (int l = 0; l < c.t_layers; ++l) {
         const LmLayerW& w = e->ll[l];
         bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
@@ -610,7 +654,8 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
             gq.norm_w = w.ln1; gq.eps = c.t_rms_eps;
             if (pending) { gq.slabs = e->d_slabs; gq.n_slabs = ks_down(e, B); gq.x_out = x_alt; }
         } else {
-            if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, ks_down(e, B), w.ln1, e->d_xn, B, H, c.t_rms_eps, xt));
+            if (tail) {}     // d_xn = ln1(x) is there: k_step (layer 0) or the previous down-projection's tail
+            else if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, ks_down(e, B), w.ln1, e->d_xn, B, H, c.t_rms_eps, xt));
             else SR_TRY(launch_rmsnorm(s, x, w.ln1, e->d_xn, B, H, c.t_rms_eps, xt));
             gq.x = e->d_xn; gq.x_tiled = xt;
         }
@@ -622,6 +667,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         SR_TRY(launch_attn_decode(s, da));
         GemvArgs go = gv(e->d_attn, QD, w.o_w, B, H, QD, x, H);
         go.W8 = w.o_w8; go.w_scale = w.o_s; go.x_tiled = xt;
+        if (tail) go.tail = make_tail(e, 2 * l, w.ln2, x);
         SR_TRY(launch_gemv(s, go, GV_RESID));
         GemvArgs gg = gv(x, H, w.gu_w, B, 2 * e->t_inter_pad, H, e->d_act, e->t_inter_pad);
         gg.W8 = w.gu_w8; gg.w_scale = w.gu_s;
@@ -637,21 +683,26 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
             SR_TRY(launch_gemm(s, ga, EPI_SWIGLU));
             gg.M = 0;       // (done)
         }
-        else { SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt)); gg.x = e->d_xn; gg.x_tiled = xt; gg.out_tiled = xt; }
+        else {
+            if (!tail) SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt));
+            gg.x = e->d_xn; gg.x_tiled = xt; gg.out_tiled = xt;
+        }
         if (gg.M > 0) SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
         GemvArgs gd = gv(e->d_act, e->t_inter_pad, w.down_w, B, H, e->t_inter_pad, e->d_slabs, H);
         gd.ksplit = ks_down(e, B);
         gd.W8 = w.down_w8; gd.w_scale = w.down_s; gd.x_tiled = xt;
+        if (tail) gd.tail = make_tail(e, 2 * l + 1, l + 1 < c.t_layers ? e->ll[l + 1].ln1 : e->final_norm, x);
         SR_TRY(launch_gemv(s, gd, GV_PARTIAL));
-        pending = true;
+        pending = !tail;        // with the tail the slabs are already in the residual stream and d_xn holds the next norm
     }
-    return enqueue_lm_head(e, B, x, x_alt, pending, s);
+    return enqueue_lm_head(e, B, x, x_alt, pending, s, false, tail);
 }
 
 int enqueue_step(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, hipStream_t s, const long long* chosen = nullptr) {
     StepArgs a{e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(e->c.t_vocab, B, e->c.t_hidden, fused_norms(e, B) ? 1 : 0), e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished,
                e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden, 1, chosen, e->d_row_limit, e->d_ngen,
                e->rope_cos, e->rope_sin, e->d_row_cs};
+    if (tail_norms(e, B)) { a.norm_w = e->ll[0].ln1; a.eps = e->c.t_rms_eps; a.xn = e->d_xn; a.xn_tiled = 1; }     // layer 0's input norm (see enqueue_decode_forward)
     SR_TRY(launch_step(s, a));
     return 0;
 }
@@ -662,6 +713,16 @@ int enqueue_step(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, 
 extern "C" {
 
 int sr_version(void) { return 1; }
+
+int sr_switches_reload(void) { load_switches(); return 0; }
+int sr_tail_timeouts(sr_engine* e, void* stream) {
+    if (!e) return -22;
+    enter(e);
+    unsigned v = 0;
+    if (hipMemcpyAsync(&v, e->d_tail + 2 * e->c.t_layers, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -5;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -5;
+    return (int)v;
+}
 
 const char* sr_last_error(const sr_engine* e) { return e ? e->err : g_err; }
 
@@ -679,6 +740,8 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
     if ((uintptr_t)workspace & 255) return fail(nullptr, -22, "workspace must be 256-byte aligned");
     sr_engine* e = new sr_engine();
     e->c = *cfg;
+    load_switches();                            // the environment is read here (and by sr_switches_reload), never in per-call dispatch
+    e->tail_norm = g_sw.tail_norm;
     snprintf(e->err, sizeof e->err, "ok");
     {   // the engine belongs to the device that owns the workspace, whatever the calling thread's current device is
         hipPointerAttribute_t pa{};
@@ -709,6 +772,7 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
     if (r == hipSuccess) r = hipMemset(e->vtcache, 0, e->kv_layer_elems * e->c.t_layers * sizeof(bf16_t));
     if (r == hipSuccess) r = hipMemset(e->d_cur_tok, 0, (char*)e->d_tokens - (char*)e->d_cur_tok);
     if (r == hipSuccess) r = hipMemset(e->v_vt, 0, (size_t)e->c.v_hidden * e->v_vt_stride * sizeof(bf16_t));
+    if (r == hipSuccess) r = hipMemset(e->d_tail, 0, ((size_t)2 * e->c.t_layers + 64) * sizeof(unsigned));
     // normalise LUT (hf image_transforms.py:89-124, 384-440) and rotary inverse frequencies (hf:506-523)
     std::vector<bf16_t> lut(768);
     const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f}, stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};

@@ -325,9 +325,9 @@ template <int EPI>
 int launch_e(hipStream_t s, const GemmArgs& a) {
     // 128-row tiles only when they still give every CU work; otherwise 64-row tiles double the block count
     long blocks128 = (long)cdiv(a.M, 128) * cdiv(a.N, BN);
-    static const char* bm_env = getenv("SR_GEMM_BM");          // tuning hook for tools/bench_gemm.py: 64 forces the 64-row tile
-    if (bm_env && atoi(bm_env) == 64) return launch_t<64, EPI>(s, a);
-    if (bm_env && atoi(bm_env) == 1288) return launch_t<128, EPI, 8>(s, a);      // 128-row tile, 8 waves (2 x 4) of 64 x 32
+    const int bm = sr_switches().gemm_bm;                      // tuning hook for tools/bench_gemm.py: 64 forces the 64-row tile
+    if (bm == 64) return launch_t<64, EPI>(s, a);
+    if (bm == 1288) return launch_t<128, EPI, 8>(s, a);      // 128-row tile, 8 waves (2 x 4) of 64 x 32
     if (blocks128 >= 512) {
         // 8 waves (2 x 4, 64 x 32 each; four waves per SIMD with two blocks per CU) measured +2..4 % on the SwiGLU / residual shapes
         // (lm gate/up 984 vs 943 TF/s, ViT gate/up 821 vs 797, ViT down 874 vs 856) and -5 % on the ViT qkv store shape
@@ -337,8 +337,7 @@ int launch_e(hipStream_t s, const GemmArgs& a) {
     // at most one block per CU, each walking the whole K: the 6-stage ring (5 k-tiles of LDS-DMA in flight; 144 KB of LDS).  With more
     // blocks than CUs the three co-resident blocks of the double-buffered loop cover each other better (ViT qkv at batch 1, 480 blocks:
     // 6.06 vs 6.47 ms per ViT pass)
-    const char* ring_env = getenv("SR_GEMM_RING");            // tuning / test hook (read at every call): 0 = never, 2 = whenever K allows
-    const int ring = ring_env ? atoi(ring_env) : 1;
+    const int ring = sr_switches().gemm_ring;                 // tuning / test hook: 0 = never, 2 = whenever K allows
     const long blocks64 = (long)cdiv(a.M, 64) * cdiv(a.N, BN);
     if (a.K / BK >= 8 && (ring == 2 || (ring == 1 && blocks64 <= 256))) return launch_t<64, EPI, 4, 6>(s, a);
     return launch_t<64, EPI>(s, a);
@@ -355,22 +354,19 @@ int gemm_prepare_decode() {
 
 // does the dispatch below send `a` to the 256-tile kernel?  (SR_GEMM256: 0 = never, 2 = whenever the shape is supported -- tuning hook)
 static bool picks_256(const GemmArgs& a) {
-    static const char* g256_env = getenv("SR_GEMM256");
-    const int g256 = g256_env ? atoi(g256_env) : 1;
+    const int g256 = sr_switches().gemm256;
     if (a.force_tile == 256) return true;
     return a.force_tile != 128 && g256 && gemm256_supports(a) && (g256 == 2 || (long)cdiv(a.M, 256) * (a.N / 256) >= 384);
 }
 bool lmqkv_ok(const GemmArgs& a);
 bool gemm_fuses_lmqkv(const GemmArgs& a) {
-    const char* env = getenv("SR_FUSE_QKV");                   // tuning / test hook (read at every call): 0 = separate rotary + cache-write launch as in round 1
-    if (env && atoi(env) == 0) return false;
+    if (!sr_switches().fuse_qkv) return false;                 // tuning / test hook: 0 = separate rotary + cache-write launch as in round 1
     return a.K % BK == 0 && picks_256(a) && gemm256_supports(a) && lmqkv_ok(a);
 }
 
 bool vitqkv_ok(const GemmArgs& a);
 bool gemm_fuses_vitqkv(const GemmArgs& a) {
-    const char* env = getenv("SR_FUSE_QKV");                   // the same hook as above
-    if (env && atoi(env) == 0) return false;
+    if (!sr_switches().fuse_qkv) return false;                 // the same hook as above
     return a.K % BK == 0 && picks_256(a) && gemm256_supports(a) && vitqkv_ok(a);
 }
 

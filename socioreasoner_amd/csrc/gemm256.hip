@@ -605,8 +605,7 @@ int launch256_t(hipStream_t s, const GemmArgs& a) {
         if (r != hipSuccess) return (int)r;
         attr_done = true;
     }
-    static const char* g_env = getenv("SR_G256_GROUP");        // tuning hook
-    const int group = g_env ? atoi(g_env) : 4;
+    const int group = sr_switches().g256_group;                // tuning hook (default 4)
     hipLaunchKernelGGL((k_gemm256<EPI, MX>), dim3(ntm * ntn), dim3(512), smem, s, a, ntm, ntn, group);
     SR_CHECK_LAUNCH();
     return 0;

@@ -18,6 +18,7 @@
 //   SWIGLU        : bf16(bf16(silu(bf16 g)) * bf16 u)   (hf:541-554)
 //   F32 + argmax  : float32 logits and a per-block (max, lowest index) pair for the greedy token (hf:1386-1387).
 #include "kernels.h"
+#include "rownorm.h"
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -374,11 +375,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                     o[0] = lo16(rv.x) + rbf(o[0]); o[1] = hi16(rv.x) + rbf(o[1]);
                     o[2] = lo16(rv.y) + rbf(o[2]); o[3] = hi16(rv.y) + rbf(o[3]);
                 }
-                *reinterpret_cast<uint2*>(optr) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                const uint2 ov = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                if (MODE == GV_RESID && p.tail.counter) st8_sc1(optr, ov);      // write-through: the tail blocks of THIS launch read the rows (rownorm.h)
+                else *reinterpret_cast<uint2*>(optr) = ov;
             } else {
                 const int n = tile * 16 + fg * 4;
-                float* o = reinterpret_cast<float*>(p.out) + ((size_t)(MODE == GV_PARTIAL ? blockIdx.y : 0) * p.M + m) * p.N + n;
-                *reinterpret_cast<float4*>(o) = float4{acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3]};
+                const size_t oi = ((size_t)(MODE == GV_PARTIAL ? blockIdx.y : 0) * p.M + m) * p.N + n;
+                const float4 ov = float4{acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3]};
+                if (MODE == GV_PARTIAL && p.tail.counter) st16_sc1(sr_rsrc(p.out, (unsigned)p.ksplit * p.M * p.N * 4), (unsigned)oi * 4, __builtin_bit_cast(sr_u32x4, ov));
+                else *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + oi) = ov;
                 if constexpr (MODE == GV_F32) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -420,6 +425,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
         }
     }
     TGV(3);
+    if constexpr ((MODE == GV_RESID || MODE == GV_PARTIAL) && WAVES == 4 && !STAGE) {
+        // round 5: the last p.M blocks to arrive finish the launch's rows as the NEXT launch's normalised x (residual add of the slabs + RMSNorm,
+        // rownorm.h) -- the RMSNorm launches of a 5..32-row decode layer are gone.  `red` (128 floats at the head of the LDS) is unused here.
+        if (p.tail.counter) gemv_tail_rmsnorm(p.tail, MODE == GV_PARTIAL ? reinterpret_cast<const float*>(p.out) : nullptr, MODE == GV_PARTIAL ? p.ksplit : 0, p.M, p.N, red);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- batches 17..32
@@ -535,11 +545,15 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
                     o[0] = lo16(rv.x) + rbf(o[0]); o[1] = hi16(rv.x) + rbf(o[1]);
                     o[2] = lo16(rv.y) + rbf(o[2]); o[3] = hi16(rv.y) + rbf(o[3]);
                 }
-                *reinterpret_cast<uint2*>(optr) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                const uint2 ov = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+                if (MODE == GV_RESID && p.tail.counter) st8_sc1(optr, ov);      // write-through for the tail blocks (rownorm.h)
+                else *reinterpret_cast<uint2*>(optr) = ov;
             } else {
                 const int n = tile * 32 + nl;
-                float* o = reinterpret_cast<float*>(p.out) + ((size_t)(MODE == GV_PARTIAL ? blockIdx.y : 0) * p.M + m) * p.N + n;
-                *reinterpret_cast<float4*>(o) = float4{acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
+                const size_t oi = ((size_t)(MODE == GV_PARTIAL ? blockIdx.y : 0) * p.M + m) * p.N + n;
+                const float4 ov = float4{acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
+                if (MODE == GV_PARTIAL && p.tail.counter) st16_sc1(sr_rsrc(p.out, (unsigned)p.ksplit * p.M * p.N * 4), (unsigned)oi * 4, __builtin_bit_cast(sr_u32x4, ov));
+                else *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + oi) = ov;
                 if constexpr (MODE == GV_F32) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -547,6 +561,11 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
                 }
             }
         }
+    }
+    if constexpr (MODE == GV_RESID || MODE == GV_PARTIAL) {
+        // round 5: tail RMSNorm of the launch's rows by its last-arriving blocks (see k_gemv); the reduction buffer at the head of the LDS is dead
+        // behind the tail's first barrier
+        if (p.tail.counter) gemv_tail_rmsnorm(p.tail, MODE == GV_PARTIAL ? reinterpret_cast<const float*>(p.out) : nullptr, MODE == GV_PARTIAL ? p.ksplit : 0, p.M, p.N, reinterpret_cast<float*>(smem));
     }
     if constexpr (MODE == GV_F32) {
         if (p.amax_val) {                                          // KP == 1: smem is free
@@ -870,11 +889,19 @@ int gemv_pick_kp(int K, int ksplit, int want) {
     return 1;
 }
 
+// blocks of the launch launch_gemv would make for a RESID / PARTIAL call at M <= 32 (what a tail needs to know: one block per output row)
+int gemv_launch_blocks(const GemvArgs& a, int mode) {
+    if (a.M <= 0 || a.M > 32 || !(mode == GV_RESID || mode == GV_PARTIAL)) return 0;
+    const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, 4);
+    const int rows_per_tile = (!a.W8 && use_32(a, mode)) ? 32 : 16;
+    return cdiv(a.N / rows_per_tile, 4 / kp) * (mode == GV_PARTIAL ? a.ksplit : 1);
+}
+
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     if (a.M <= 0) return 0;
     if (a.M > 128 || a.K % 64 != 0 || a.N % 16 != 0) return -22;
     if (a.M > 32) {      // 33..128 rows: the 32-row-tile kernel over 2 / 4 row groups per weight pass (bf16 stream, no fused norm)
-        if (a.N % 32 != 0 || a.norm_w || a.W8 || a.n_slabs) return -22;
+        if (a.N % 32 != 0 || a.norm_w || a.W8 || a.n_slabs || a.tail.counter) return -22;
         if (mode == GV_PARTIAL && (a.ksplit < 1 || a.ksplit > a.K / 64)) return -22;
         if (a.out_tiled && (mode != GV_SWIGLU || (a.N / 2) % 64 != 0)) return -22;
         const int kp32 = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, mode == GV_F32 ? 1 : 4);
@@ -894,6 +921,13 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     if (a.out_tiled && (mode != GV_SWIGLU || (a.N / 2) % 64 != 0)) return -22;
     int want = mode == GV_F32 ? 1 : 4;
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
+    if (a.tail.counter) {       // in-launch RMSNorm of the output rows by the last M blocks to arrive (rownorm.h): one 256-thread block per row
+        if (!(mode == GV_RESID || mode == GV_PARTIAL) || a.norm_w || a.N > 2048 || a.N % 8 != 0) return -22;
+        if (!a.tail.timeout || !a.tail.norm_w || !a.tail.xn || !a.tail.x) return -22;
+        if (mode == GV_RESID && (a.tail.x != a.out || a.ldo != a.N)) return -22;
+        if (a.tail.xn_tiled && a.N % 64 != 0) return -22;
+        if (gemv_launch_blocks(a, mode) < a.M) return -22;
+    }
     if (a.W8) {          // fp8 weight stream (decode of the quantised LM linears); the in-block K split is always 4 there
         if (!a.w_scale || mode == GV_F32) return -22;
         if (kp != 4) return -22;

@@ -3,6 +3,22 @@
 #pragma once
 #include "common.h"
 
+// ------------------------------------------------------------------ switches (engine.hip)
+// Every SR_* tuning / test switch of the library, read from the environment ONCE (first use, and again at every sr_engine_create and
+// sr_switches_reload) -- never in per-call dispatch (hygiene).  Defaults = the shipped behaviour.
+struct SrSwitches {
+    int splitk;         // SR_SPLITK      1: split-K residual GEMMs of a SMALL static prefill (gives up bit-exact batch invariance; default 0)
+    int gemm_bm;        // SR_GEMM_BM     64 / 1288: force a tile shape of the 128-tile GEMM (tools/bench_gemm.py); 0 = pick
+    int gemm_ring;      // SR_GEMM_RING   small-M 6-stage ring: 0 never, 1 when it pays (default), 2 whenever K allows
+    int gemm256;        // SR_GEMM256     256-tile GEMM: 0 never, 1 when it pays (default), 2 whenever the shape is supported
+    int fuse_qkv;       // SR_FUSE_QKV    0: separate rotary + cache-write launches instead of the fused q/k/v epilogues (default 1)
+    int g256_group;     // SR_G256_GROUP  m-tiles per W panel of the 256-tile GEMM (default 4)
+    int attn2;          // SR_ATTN2       0: round-2 prefill attention kernel (default 1)
+    int attn_win64;     // SR_ATTN_WIN64  0: no 64-token window kernel (default 1)
+    int tail_norm;      // SR_TAIL_NORM   0: RMSNorm launches instead of the GEMV tails at 5..32 decode rows (default 1; read at sr_engine_create)
+};
+const SrSwitches& sr_switches();
+
 // ------------------------------------------------------------------ gemm.hip (MFMA, M large)
 // out[M,N] = A[M,K] . W[N,K]^T, bf16 operands, float32 accumulate.  K % 64 == 0, N % 16 == 0.
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_F32 = 4,
@@ -65,6 +81,15 @@ int launch_quant_mx_act(hipStream_t s, const bf16_t* x, int ldx, int M, int K, u
 
 // ------------------------------------------------------------------ gemv.hip (weight streaming, M <= 32)
 enum { GV_PARTIAL = 0, GV_SWIGLU = 1, GV_F32 = 2, GV_BIAS = 3, GV_RESID = 4 };
+// what a GEMV launch needs to finish its output as a normalised activation (GemvArgs.tail, device side in rownorm.h; counter == null: no tail, plain stores)
+struct GemvTail {
+    unsigned* counter;          // arrival tickets of THIS launch; zero when the launch starts (memset node at the head of the decode forward)
+    unsigned* timeout;          // a tail block that gave up waiting adds 1 here (never in a healthy run; tests assert 0)
+    const bf16_t* norm_w; float eps;
+    bf16_t* xn; int xn_tiled;   // normalised rows out [M][H] (fragment-ordered when xn_tiled: the next GEMV's x)
+    bf16_t* x;                  // residual stream [M][H].  PARTIAL: read, h = r(x + r(sum slabs)) written back; RESID: the launch's own output
+};
+
 struct GemvArgs {
     const bf16_t* x; int ldx;   // [M, K] B operand; with norm_w: the residual stream the RMSNorm prologue reads
     const bf16_t* W;            // [N, K]
@@ -84,8 +109,10 @@ struct GemvArgs {
                                             // x load is 1 KB contiguous instead of 16 rows x 64 B (batches > 4, no fused norm)
     int out_tiled;                          // SWIGLU: write the activation fragment-ordered (it is the next GEMV's x)
     int force32;                            // always the 32-row MFMA variant (whatever M): a row's result then does not depend on how many rows share the launch
+    GemvTail tail;                          // RESID / PARTIAL at 5..32 rows, N <= 2048: the launch also normalises its rows (round 5); counter null = off
 };
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode);
+int gemv_launch_blocks(const GemvArgs& a, int mode);     // RESID / PARTIAL at M <= 32: blocks of that launch (a tail needs >= M)
 int gemv_f32_blocks(int N, int M, int K, int has_norm);
 int gemv_f32_block_rows(int N, int M, int K, int has_norm);   // vocabulary rows per block of that launch    // gridDim.x of the F32 launch (length of the amax rows)
 
@@ -179,6 +206,7 @@ struct StepArgs {
     const bf16_t* rope_cos; const bf16_t* rope_sin;     // optional LM rotary tables [pos][64] ...
     float* row_cs;              // ... and [B][128]: cos | sin of every row's NEW position, for the decode attention of this step (which then
                                 // does not have to chase pos[b] -> table row through two dependent loads in every layer)
+    const bf16_t* norm_w; float eps; bf16_t* xn; int xn_tiled;   // optional (round 5, H <= 2048): xn = RMSNorm(x row) * norm_w, the first layer's input norm
 };
 // fp8 quantisation of a fragment-ordered bf16 matrix [N, K]: scale[n] = amax_n / 448 (1 if the row is zero),
 // q = fp8(W / scale) -> W8 (tiled8); W itself is overwritten with q as bf16 (what the prefill GEMM multiplies, scaled in its epilogue)

@@ -97,6 +97,8 @@ SIGNATURES = {
     "sr_op_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i, _i, C.c_float, _vp]),
     "sr_op_resid_rmsnorm": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, C.c_float, _vp]),
     "sr_op_argmax": (C.c_int, [_vp, _i, _i, _vp, _vp]),
+    "sr_switches_reload": (C.c_int, []),
+    "sr_tail_timeouts": (C.c_int, [_vp, _vp]),
 }
 
 
@@ -124,3 +126,8 @@ def check(rc: int, engine=None, what: str = ""):
 def stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def reload_switches():
+    """The library reads its SR_* switches once (and at every engine creation); call this after changing one in ``os.environ``."""
+    return load().sr_switches_reload()

@@ -31,3 +31,15 @@ def _release_device_objects(request):
         gc.collect()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+
+
+@pytest.fixture(autouse=True)
+def _library_switches_follow_the_environment():
+    """libsocior.so reads its SR_* switches once (and at every engine creation), not per call (round 5).  A test that flips one with
+    ``switch(monkeypatch, name, value)`` has the library re-read it; this fixture is set up before ``monkeypatch`` and therefore torn down after
+    it has restored the environment, so the next test starts from the shipped defaults again."""
+    yield
+    from socioreasoner_amd import lib
+    if lib._lib is not None:
+        lib.reload_switches()
+

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_bf16_close, tile16x64
+from tests.util import assert_bf16_close, switch, tile16x64
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -108,7 +108,7 @@ def test_small_m_ring_gemm_equals_double_buffered_loop(L, monkeypatch):
         res0 = (torch.randn(M, No, device="cuda")).to(torch.bfloat16) if epi == EPI_RESID else None
         outs = []
         for ring in ("0", "2", "2", "2"):
-            monkeypatch.setenv("SR_GEMM_RING", ring)
+            switch(monkeypatch, "SR_GEMM_RING", ring)
             out = torch.zeros(M, No, dtype=torch.float32 if epi == EPI_F32 else torch.bfloat16, device="cuda")
             res = None
             if epi == EPI_RESID:
@@ -278,7 +278,7 @@ def test_fused_qkv_epilogue_equals_separate_rope_launch(mode, B, monkeypatch):
     pix = torch.cat([e.patchify(im) for im in imgs], dim=0)
     res = {}
     for fuse in ("0", "1"):
-        monkeypatch.setenv("SR_FUSE_QKV", fuse)
+        switch(monkeypatch, "SR_FUSE_QKV", fuse)
         emb = e.vit_forward(pix, [grid] * B).clone()      # 24 tiles: the ViT qkv GEMM takes the fused 2-D rotary + V^T epilogue as well
         first = e.prefill(ids, pos, emb, return_logits=True).clone()
         toks, tr = e.decode(4, trace=True)
@@ -309,7 +309,7 @@ def test_small_prefill_split_k_residual_gemms(monkeypatch):
     emb = e.vit_forward(torch.cat([e.patchify(im) for im in imgs], dim=0), [grid] * 2)
     out = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("SR_SPLITK", flag)
+        switch(monkeypatch, "SR_SPLITK", flag)
         lg = e.prefill(ids, pos, emb, return_logits=True).clone()
         toks, tr = e.decode(8, trace=True)
         out[flag] = (lg, toks.clone(), tr.clone())
@@ -322,7 +322,7 @@ def test_small_prefill_split_k_residual_gemms(monkeypatch):
             k = int(neq[0])
             top2 = out["0"][2][k, b].topk(2).values
             assert float(top2[0] - top2[1]) < 0.4, (b, k, float(top2[0] - top2[1]))
-    monkeypatch.delenv("SR_SPLITK")
+    switch(monkeypatch, "SR_SPLITK", None)
     alone = e.prefill(ids[:1], pos[:1], emb[:256], return_logits=True).clone()
     emb3 = torch.cat([emb, emb[:256]], dim=0)
     three = e.prefill([ids[0], ids[1], ids[0]], [pos[0], pos[1], pos[0]], emb3, return_logits=True)

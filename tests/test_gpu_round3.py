@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import bits_to_f32
+from tests.util import bits_to_f32, switch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -103,7 +103,7 @@ def test_full_depth_3b_distance_to_float32_truth(golden_dir, tag):
 
 def _run_prefill(e, geom, tiles, hw, monkeypatch, attn2):
     from socioreasoner_amd import hostops, synthetic
-    monkeypatch.setenv("SR_ATTN2", attn2)
+    switch(monkeypatch, "SR_ATTN2", attn2)
     grid = (1, hw // 14, hw // 14)
     pix = torch.cat([e.patchify(torch.from_numpy(synthetic.tile_pixels(i, hw, hw)).cuda()) for i in tiles], dim=0)
     emb = e.vit_forward(pix, [grid] * len(tiles))
@@ -249,7 +249,7 @@ def test_window_attention_without_lds_equals_the_staged_kernel_bit_for_bit(monke
     pix = torch.cat([e.patchify(torch.from_numpy(synthetic.tile_pixels(70 + i, hw, hw)).cuda()) for i in range(n)], dim=0)
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("SR_ATTN_WIN64", mode)
+        switch(monkeypatch, "SR_ATTN_WIN64", mode)
         out[mode] = e.vit_forward(pix, [grid] * n).clone()
         torch.cuda.synchronize()
     # (round 4: 448- and 896-pixel tiles -- grids that ARE a multiple of the window, where HF pads an empty window row / column -- used to be

@@ -45,3 +45,13 @@ def tile8(q: torch.Tensor) -> torch.Tensor:
     N, K = q.shape
     assert N % 16 == 0 and K % 64 == 0
     return q.reshape(N // 16, 16, K // 64, 4, 16).permute(0, 2, 3, 1, 4).contiguous().reshape(N, K)
+
+
+def switch(monkeypatch, name, value):
+    """Set (value=None: delete) an SR_* switch of the library for the rest of the test."""
+    from socioreasoner_amd import lib
+    if value is None:
+        monkeypatch.delenv(name, raising=False)
+    else:
+        monkeypatch.setenv(name, str(value))
+    lib.reload_switches()

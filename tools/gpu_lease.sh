@@ -1,0 +1,84 @@
+#!/bin/bash
+# ONE parametrised script for everything this repo runs on a leased MI355X (replaces the 35 one-off tools/gpu_r3_*.sh / gpu_r4_*.sh / _run_*.sh
+# lease scripts of rounds 1-4, which stay in the git history):
+#     gpurun --timeout 1500 -- 'bash tools/gpu_lease.sh <stage> [<stage> ...]'
+# Every stage writes under gpurun_out/ (merged back by gpurun); summaries worth judging are copied into profiles/ by hand afterwards.
+# Stages:
+#   tests5      tests/test_gpu_round5.py
+#   suite       the whole -m gpu suite
+#   tail_ab     static 32-row bench with SR_TAIL_NORM=0 / 1 (same box, interleaved twice), decode step ms of each
+#   trace_s32   rocprofv3 kernel trace of the static 32-row bench            -> gpurun_out/r05_bench_s32_kernel_stats.md
+#   trace_c32   ... of the headline (continuous) configuration               -> gpurun_out/r05_bench_c32_kernel_stats.md
+#   trace_b1    ... of batch 1                                               -> gpurun_out/r05_bench_b1_kernel_stats.md
+#   trace_fp8   ... of --fp8 static 32 rows                                  -> gpurun_out/r05_bench_fp8_s32_kernel_stats.md
+#   pmc_gemv    FETCH_SIZE / WRITE_SIZE passes of the decode weight stream (bf16 and fp8) -> gpurun_out/r05_pmc_gemv_traffic*.json
+#   bench       the driver's command (python bench.py)                       -> gpurun_out/r05_bench_default_line.json
+#   configs     the other configurations of README (pair, fp8, fp8-mx 896, 64 / 128 rows, no-overlap, batch 1), 2 steps each
+#   smoke       __graft_entry__.smoke()
+cd "$(dirname "$0")/.."
+R=$PWD
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+QUIET="--no-cpu-baseline --no-latency --no-sam --no-more-rows"
+
+line() { python - "$1" "$2" <<'EOF'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
+except Exception as e:
+    print(sys.argv[2], "NO JSON LINE", e); sys.exit(0)
+r, st = d.get("roofline") or {}, d.get("static_batch") or {}
+print(sys.argv[2], "value", d["value"], d["unit"], "| ms/step", d["ms_per_step"], "| decode step ms", r.get("decode_step_ms"), "| gemv frac", r.get("frac"),
+      "| phases", {k: v for k, v in d["phase_ms_per_step"].items() if not isinstance(v, dict)}, "| checksum", d["result_checksum"])
+EOF
+}
+
+trace() {   # trace <name> <bench args...>: kernel trace + stats summary
+  local n=$1; shift
+  rm -rf /tmp/prof5_$n
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof5_$n -o $n -- python $R/bench.py "$@" > $R/gpurun_out/r05_prof_$n.log 2>&1; echo "trace $n exit $?")
+  local DB=$(find /tmp/prof5_$n -name "${n}_results.db" | head -1)
+  rm -f gpurun_out/r05_bench_${n}_kernel_stats.md
+  [ -n "$DB" ] && python tools/rocpd_stats.py $DB gpurun_out/r05_bench_${n}_kernel_stats.md > /dev/null && head -16 gpurun_out/r05_bench_${n}_kernel_stats.md | cut -c1-170
+  [ -n "$DB" ] && python tools/rocpd_gaps.py $DB > gpurun_out/r05_gaps_$n.json 2>/dev/null
+  line gpurun_out/r05_prof_$n.log "traced $n:"
+  rm -rf /tmp/prof5_$n
+}
+
+for stage in "$@"; do
+  echo "================ stage $stage ($(date +%T))"
+  case $stage in
+    tests5) timeout 1500 python -m pytest tests/test_gpu_round5.py -x -q -m gpu 2>&1 | tail -15 ;;
+    suite)  timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 ;;
+    smoke)  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
+    tail_ab)
+      for rep in 1 2; do for t in 0 1; do
+        SR_TAIL_NORM=$t timeout 600 python bench.py --static --steps 3 --warmup 1 $QUIET > gpurun_out/r05_tail_${t}_$rep.log 2> gpurun_out/r05_tail_${t}_$rep.err
+        line gpurun_out/r05_tail_${t}_$rep.log "SR_TAIL_NORM=$t rep $rep:"
+      done; done ;;
+    trace_s32) trace s32 --static --steps 2 --warmup 1 $QUIET ;;
+    trace_c32) trace c32 --steps 2 --warmup 1 $QUIET ;;
+    trace_b1)  trace b1 --batch 1 --steps 3 --warmup 1 --no-cpu-baseline --no-sam ;;
+    trace_fp8) trace fp8_s32 --fp8 --static --steps 2 --warmup 1 $QUIET ;;
+    pmc_gemv)
+      mkdir -p gpurun_out/pmc_r5
+      for v in bf16 fp8; do for c in FETCH_SIZE WRITE_SIZE; do
+        rm -rf /tmp/pmc_$c
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o p -- python $R/tools/probe_r2.py gemv $v > $R/gpurun_out/pmc_r5/gemv_${v}_$c.log 2>&1)
+        python tools/rocpd_pmc.py "$(find /tmp/pmc_$c -name '*.db' | head -1)" gpurun_out/pmc_r5/gemv_${v}_$c.json > /dev/null 2>> gpurun_out/pmc_r5/gemv_${v}_$c.log
+      done
+      python tools/gemv_traffic.py gpurun_out/pmc_r5/gemv_${v}_FETCH_SIZE.json gpurun_out/pmc_r5/gemv_${v}_WRITE_SIZE.json gpurun_out/r05_pmc_gemv_traffic_$v.json $v | tail -6
+      done ;;
+    bench)
+      timeout 1500 python bench.py > gpurun_out/r05_bench_default.log 2> gpurun_out/r05_bench_default.err; echo "bench exit $?"
+      tail -n 1 gpurun_out/r05_bench_default.log > gpurun_out/r05_bench_default_line.json
+      line gpurun_out/r05_bench_default.log "default:" ;;
+    configs)
+      : > gpurun_out/r05_other_configs.txt
+      for cfg in "--pair" "--fp8" "--fp8 --batch 64" "--fp8 --batch 128" "--fp8-mx --tile 896 --batch 16 --static" "--no-overlap" "--drain" "--batch 64" "--batch 128" "--batch 1"; do
+        timeout 900 python bench.py $cfg --steps 2 --warmup 1 $QUIET > gpurun_out/r05_cfg.log 2> gpurun_out/r05_cfg.err
+        line gpurun_out/r05_cfg.log "bench.py $cfg:" | tee -a gpurun_out/r05_other_configs.txt
+      done ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
