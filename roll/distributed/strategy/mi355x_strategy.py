@@ -66,7 +66,11 @@ class Mi355xStrategy(InferenceStrategy):
         margs = _get(self.worker_config, "model_args")
         path = str(_get(margs, "model_name_or_path", "") or sc.get("model", "synthetic:3b"))
         import os
-        if os.path.isfile(os.path.join(path, "config.json")):    # a checkpoint directory brings its own geometry
+        from socioreasoner_amd import checkpoints
+        # the same policy as seg_infer's provider: synthetic:* | a directory | a hub id found in the local HF cache | else FileNotFoundError
+        # (SR_ALLOW_SYNTHETIC_WEIGHTS=1: loud fallback to random weights of the 3B geometry)
+        kind, path = checkpoints.resolve(path, "actor_infer (SocioReasoner LM)", "synthetic:3b")
+        if kind == "dir" and os.path.isfile(os.path.join(path, "config.json")):    # a checkpoint directory brings its own geometry
             import json
             from socioreasoner_amd.config import geometry_from_hf_config
             self.geom = geometry_from_hf_config(json.load(open(os.path.join(path, "config.json"))))
@@ -92,7 +96,7 @@ class Mi355xStrategy(InferenceStrategy):
                              max_batch=self.max_batch, max_ctx=max_ctx, max_new_tokens=min(resp_len, max_ctx - 1),
                              lm_fp8={"fp8": True, "fp8_e4m3": True, "fp8_mx": "mx"}.get(str(sc.get("quantization", "") or "").lower(), False),   # vLLM's knob name; fp8_mx: + MX fp8 activations in prefill
                              device=f"cuda:{int(_get(getattr(self.worker, 'rank_info', None), 'local_rank', 0) or 0)}")
-        if os.path.isdir(path):
+        if kind == "dir":
             self.engine.load_safetensors_dir(path)
             if any(os.path.exists(os.path.join(path, f)) for f in ("tokenizer.json", "tokenizer_config.json", "vocab.json")):
                 from transformers import AutoTokenizer       # (a checkpoint with tokenizer files that do not load is an error, not a stub)
@@ -101,7 +105,7 @@ class Mi355xStrategy(InferenceStrategy):
                 logger.warning("checkpoint directory %r has no tokenizer files: token ids in, token ids out only", path)
                 self.tokenizer = _StubTokenizer(self.geom)
         else:
-            logger.warning("no checkpoint directory at %r: using synthetic weights (seed 0)", path)
+            logger.warning("%s: using SYNTHETIC weights (seed %d)", path, int(sc.get("seed", 0)))
             self.engine.load_synthetic_weights(seed=int(sc.get("seed", 0)))
             self.tokenizer = _StubTokenizer(self.geom)
         self.command_queue = queue.Queue()

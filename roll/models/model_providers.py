@@ -12,8 +12,9 @@ Precision.  The reference's provider ignores ``model_args.dtype`` (the YAML's ``
 So does this one: float32 (socioreasoner_amd.sam2, csrc/sam_f32.hip) unless ``model_args.sam2_compute_dtype: bf16`` (or the environment
 variable SR_SAM2_DTYPE=bf16) opts into the bf16 kernels -- ~3x the throughput, masks equal to float32's only outside the bf16 noise band.
 
-A ``model_name_or_path`` that is neither ``synthetic:*`` nor an existing directory (a hub id with nothing on disk, a typo) RAISES, as the
-reference's ``build_sam2`` would; SR_ALLOW_SYNTHETIC_WEIGHTS=1 turns that into a loud fallback to random weights (offline demos and tests).
+A hub id (``facebook/sam2-hiera-large`` in the shipped YAML) is looked up in the local HuggingFace cache; a ``model_name_or_path`` that is neither
+``synthetic:*``, nor an existing directory, nor in that cache (a typo) RAISES, as the reference's ``build_sam2`` would;
+SR_ALLOW_SYNTHETIC_WEIGHTS=1 turns that into a loud fallback to random weights (socioreasoner_amd/checkpoints.py: one policy for both models).
 """
 from __future__ import annotations
 
@@ -38,26 +39,16 @@ def sam2_seg_model_provider(model_args=None, training_args=None, is_trainable: b
     if want not in ("float32", "fp32", "f32", "bf16", "bfloat16"):
         raise ValueError(f"sam2_compute_dtype {want!r}: float32 (the reference's precision) or bf16")
     dtype = torch.bfloat16 if want in ("bf16", "bfloat16") else torch.float32
-    if path.startswith("synthetic"):
+    from socioreasoner_amd import checkpoints
+    kind, path = checkpoints.resolve(path, "seg_infer (SAM2)", "synthetic:sam2-hiera-large")     # hub ids -> the local HF cache; else raises
+    if kind != "dir":
         tiny = path.endswith("tiny")
         g = sam2.Sam2Geometry(image_size=256, embed_dims=(32, 64, 128, 256), heads=(1, 2, 4, 8), blocks=(1, 2, 3, 2), windows=(8, 4, 8, 4),
                               global_blocks=(4,), dec_mlp=256) if tiny else sam2.Sam2Geometry()
         eng = sam2.Sam2Engine(g, dev, dtype=dtype)
         eng.load_state_dict(sam2.synthetic_state_dict(g, seed=0))
-        return sam2.Sam2Predictor(eng)
-    if not os.path.isdir(path):
-        # a hub id (facebook/sam2-hiera-large in the reference's YAML) with nothing on disk, or a typo in a real path: the reference fails
-        # to load here, and masks from random weights must never pass for results.  Offline runs opt in explicitly.
-        if os.environ.get("SR_ALLOW_SYNTHETIC_WEIGHTS") != "1":
-            raise FileNotFoundError(f"seg_infer: no SAM2 checkpoint directory at {path!r} (expected sam2_hiera_large.pt or *.safetensors inside); "
-                                    f"use 'synthetic:sam2-hiera-large' or set SR_ALLOW_SYNTHETIC_WEIGHTS=1 to run random weights on purpose")
-        import warnings
-        warnings.warn(f"seg_infer: no checkpoint directory at {path!r}; running SAM2 Hiera-L with SYNTHETIC weights (SR_ALLOW_SYNTHETIC_WEIGHTS=1)")
-        g = sam2.Sam2Geometry()
-        eng = sam2.Sam2Engine(g, dev, dtype=dtype)
-        eng.load_state_dict(sam2.synthetic_state_dict(g, seed=0))
         pred = sam2.Sam2Predictor(eng)
-        pred.synthetic_weights = True
+        pred.synthetic_weights = kind == "synthetic-fallback"
         return pred
     eng = sam2.Sam2Engine(sam2.Sam2Geometry(), dev, dtype=dtype)
     pt = os.path.join(path, "sam2_hiera_large.pt")

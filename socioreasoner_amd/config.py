@@ -125,10 +125,44 @@ def geometry_from_hf_config(cfg: dict) -> ModelGeometry:
                         mrope_section=tuple(rope.get("mrope_section") or dt.mrope_section))
     d = ModelGeometry()
     eos = cfg.get("eos_token_id", tc.get("eos_token_id", d.eos_token_id))
+    check_supported(ModelGeometry(vision=vision, text=text), tie_word_embeddings=t("tie_word_embeddings", True))
     return ModelGeometry(vision=vision, text=text, image_token_id=int(cfg.get("image_token_id", d.image_token_id)),
                          video_token_id=int(cfg.get("video_token_id", d.video_token_id)), vision_start_token_id=int(cfg.get("vision_start_token_id", d.vision_start_token_id)),
                          vision_end_token_id=int(cfg.get("vision_end_token_id", d.vision_end_token_id)),
                          eos_token_id=int(eos[0] if isinstance(eos, (list, tuple)) else eos), pad_token_id=int(cfg.get("pad_token_id", tc.get("pad_token_id", d.pad_token_id)) or d.pad_token_id))
+
+
+def check_supported(g: ModelGeometry, tie_word_embeddings=True) -> None:
+    """Refuses, by name, every checkpoint geometry the engine's kernels cannot run CORRECTLY (a ``config.json`` of another
+    Qwen2.5-VL size used to be accepted here and fail -- or, for an untied LM head, silently compute with the embedding matrix -- later).
+    The limits are those of libsocior.so as built for SocioReasoner-3B (csrc/engine.hip ``validate``; include/socior.h)."""
+    v, t = g.vision, g.text
+    why = []
+    if tie_word_embeddings is False:
+        why.append("tie_word_embeddings is false: the engine uses model.embed_tokens.weight as the LM head (sr_load_weight ignores lm_head.weight), "
+                   "an untied head would be replaced by the embedding matrix")
+    if t.head_dim != 128:
+        why.append(f"text head_dim {t.head_dim}: the attention and rotary kernels are built for 128")
+    if t.hidden_size > 2048 or t.hidden_size % 64:
+        why.append(f"text hidden_size {t.hidden_size}: the decode RMSNorm / fragment-ordered activation kernels take multiples of 64 up to 2048")
+    if t.num_attention_heads % max(t.num_key_value_heads, 1) or t.num_attention_heads // max(t.num_key_value_heads, 1) > 16:
+        why.append(f"GQA group {t.num_attention_heads} / {t.num_key_value_heads}: must divide, at most 16 query heads per KV head")
+    if sum(t.mrope_section) != 64:
+        why.append(f"mrope_section {tuple(t.mrope_section)} must sum to 64 (head_dim / 2)")
+    if t.vocab_size % 16:
+        why.append(f"vocab_size {t.vocab_size} must be a multiple of 16")
+    if v.hidden_size % v.num_heads or v.hidden_size // v.num_heads not in (80, 128):
+        why.append(f"vision head_dim {v.hidden_size}/{v.num_heads}: 80 or 128")
+    if v.hidden_size % 64:
+        why.append(f"vision hidden_size {v.hidden_size} must be a multiple of 64")
+    if v.spatial_merge_size != 2:
+        why.append(f"spatial_merge_size {v.spatial_merge_size}: 2")
+    if v.out_hidden_size != t.hidden_size:
+        why.append(f"vision out_hidden_size {v.out_hidden_size} != text hidden_size {t.hidden_size}")
+    if len(v.fullatt_block_indexes) > 16:
+        why.append("more than 16 full-attention blocks")
+    if why:
+        raise ValueError("this checkpoint geometry is not supported by the MI355X engine (built for SocioReasoner-3B = Qwen2.5-VL-3B):\n  - " + "\n  - ".join(why))
 
 
 def geometry_to_hf_config(g: ModelGeometry) -> dict:

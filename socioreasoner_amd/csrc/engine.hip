@@ -206,6 +206,7 @@ const char* validate(const sr_config& c) {
     if (c.v_out_hidden != c.t_hidden) return "v_out_hidden must equal t_hidden";
     if (c.t_head_dim != 128) return "t_head_dim must be 128";
     if (c.t_hidden % 64 || c.t_vocab % 16) return "t_hidden % 64, t_vocab % 16";
+    if (c.t_hidden > 2048) return "t_hidden must be <= 2048 (the decode RMSNorm and fragment-ordered activation kernels are sized for SocioReasoner-3B)";
     if (c.t_heads % c.t_kv_heads || c.t_heads / c.t_kv_heads > 16) return "GQA group must divide and be <= 16";
     if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] != 64) return "mrope_section must sum to 64";
     if (c.max_batch < 1 || c.max_batch > MAXB) return "max_batch in 1..128";

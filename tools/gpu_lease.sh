@@ -57,6 +57,7 @@ for stage in "$@"; do
         line gpurun_out/r05_tail_${t}_$rep.log "SR_TAIL_NORM=$t rep $rep:"
       done; done ;;
     trace_s32) trace s32 --static --steps 2 --warmup 1 $QUIET ;;
+    tail_trace) SR_TAIL_NORM=0 trace s32_tail0 --static --steps 2 --warmup 1 $QUIET; SR_TAIL_NORM=1 trace s32_tail1 --static --steps 2 --warmup 1 $QUIET ;;
     trace_c32) trace c32 --steps 2 --warmup 1 $QUIET ;;
     trace_b1)  trace b1 --batch 1 --steps 3 --warmup 1 --no-cpu-baseline --no-sam ;;
     trace_fp8) trace fp8_s32 --fp8 --static --steps 2 --warmup 1 $QUIET ;;
