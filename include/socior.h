@@ -237,8 +237,11 @@ int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void*
  * autocast (/root/reference/roll/models/model_providers.py:540-548, roll/distributed/strategy/seg_strategy.py:47-60): these are the
  * float32 forms of the entry points above (same argument meaning, float32 row-major matrices [rows][ld], ld % 4 == 0, 16-byte aligned)
  * that socioreasoner_amd/sam2.py drives when Sam2Engine(dtype=float32) -- the default behind seg_infer.
- *   sr_op_gemm_f32      : out = act(A . W^T + bias) (+ resid) on the f32-input MFMA (exact float32 fmaf chains); epilogue 0 store, 1 residual,
- *                         3 GELU (erf form; | 0x1000 = ReLU), 4 = 0; K % 16 == 0, N % 4 == 0.
+ *   sr_op_gemm_f32      : out = act(A . W^T + bias) (+ resid), float32 in and out; epilogue 0 store, 1 residual, 3 GELU (erf form; | 0x1000 =
+ *                         ReLU), 4 = 0; K % 16 == 0, N % 4 == 0.  Round 5: computed on the bf16 matrix pipe from an exact three-term bf16 split of
+ *                         every operand (six partial products, float32 accumulation: float32-grade results at 2-3 x the rate of the f32-input
+ *                         MFMA, which SR_SAM_F32_SPLIT=0 selects instead).  | 0x2000: `W` holds the weight ALREADY split, three bf16 planes
+ *                         [3][N][K] with W = hi + mid + lo (hi = bf16(W), mid = bf16(W - hi), lo = bf16(W - hi - mid)): weights are constants.
  *   sr_op_attention_f32 : softmax(q k^T * scale) v per work item (the struct of sr_op_attention, <= 64 queries per item; vt_off unused:
  *                         V is ROW-major, element (key j, head h, d) = v[(k_row0 + j) * v_stride + h * head_dim + d]); head_dim 16 / 32 / 80. */
 int sr_op_gemm_f32(const float* A, int lda, const float* W, int M, int N, int K, float* out, int ldo, const float* bias, const float* resid,

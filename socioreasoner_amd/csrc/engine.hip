@@ -86,7 +86,8 @@ static void load_switches() {
     if (g_sw.g256_group < 1) g_sw.g256_group = 4;
     g_sw.attn2 = env_int("SR_ATTN2", 1);
     g_sw.attn_win64 = env_int("SR_ATTN_WIN64", 1);
-    g_sw.tail_norm = env_int("SR_TAIL_NORM", 1);
+    g_sw.sam_f32_split = env_int("SR_SAM_F32_SPLIT", 1);
+    g_sw.tail_norm = env_int("SR_TAIL_NORM", 3);
     g_sw_loaded = true;
 }
 const SrSwitches& sr_switches() {
@@ -594,14 +595,15 @@ bool x_tiled_ok(const sr_engine* e) {
 int ks_down(const sr_engine* e, int B) { return (B > 16 && e->t_inter_pad / 64 >= 32) ? 4 : e->ks_down; }
 // round 5: at 5..32 rows the o_proj and down-projection GEMVs finish their rows as the next launch's normalised x
 // (the last B blocks to arrive do residual add + RMSNorm, rownorm.h; the first layer's norm rides in k_step): no RMSNorm launch in the step
-bool tail_norms(const sr_engine* e, int B) {
-    if (!e->tail_norm || fused_norms(e, B) || B > 32 || !x_tiled_ok(e)) return false;
+// (tail_norm is a bit mask for the A/B: 1 = o_proj's tail does ln2, 2 = the down-projection's tail does the next ln1 / the final norm and k_step layer 0's; 3 = both)
+int tail_norms(const sr_engine* e, int B) {
+    if (!e->tail_norm || fused_norms(e, B) || B > 32 || !x_tiled_ok(e)) return 0;
     const int H = e->c.t_hidden, QD = e->c.t_heads * 128;
     const bool f8 = e->c.lm_weight_dtype >= 1;
     GemvArgs go = gv(nullptr, QD, nullptr, B, H, QD, nullptr, H), gd = gv(nullptr, e->t_inter_pad, nullptr, B, H, e->t_inter_pad, nullptr, H);
     gd.ksplit = ks_down(e, B);
     if (f8) go.W8 = gd.W8 = reinterpret_cast<const unsigned char*>(e);      // (only its null-ness matters)
-    return gemv_launch_blocks(go, GV_RESID) >= B && gemv_launch_blocks(gd, GV_PARTIAL) >= B;      // one tail block per row
+    return (gemv_launch_blocks(go, GV_RESID) >= B && gemv_launch_blocks(gd, GV_PARTIAL) >= B) ? (e->tail_norm & 3) : 0;      // one tail block per row
 }
 GemvTail make_tail(sr_engine* e, int idx, const bf16_t* norm_w, bf16_t* x) {
     GemvTail t{};
@@ -643,8 +645,9 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
     bf16_t *x = e->d_xa, *x_alt = e->d_xb;      // k_step gathered the input embedding into d_xa
     bool pending = false;                       // down-projection slabs not yet added to the residual stream
     const float scale = (float)(1.0 / sqrt(128.0));
-    const bool tail = tail_norms(e, B);         // (k_step wrote ln1(x) of layer 0 into d_xn: enqueue_step)
-    if (tail) SR_TRY((int)hipMemsetAsync(e->d_tail, 0, (size_t)2 * c.t_layers * sizeof(unsigned), s));     // a memset node at the head of the captured step
+    const int tails = tail_norms(e, B);
+    const bool tail_o = tails & 1, tail_d = tails & 2;      // (tail_d: k_step wrote ln1(x) of layer 0 into d_xn, enqueue_step)
+    if (tails) SR_TRY((int)hipMemsetAsync(e->d_tail, 0, (size_t)2 * c.t_layers * sizeof(unsigned), s));     // a memset node at the head of the captured step
     for (int l = 0; l < c.t_layers; ++l) {
         const LmLayerW& w = e->ll[l];
         bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
@@ -655,7 +658,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
             gq.norm_w = w.ln1; gq.eps = c.t_rms_eps;
             if (pending) { gq.slabs = e->d_slabs; gq.n_slabs = ks_down(e, B); gq.x_out = x_alt; }
         } else {
-            if (tail) {}     // d_xn = ln1(x) is there: k_step (layer 0) or the previous down-projection's tail
+            if (tail_d) {}     // d_xn = ln1(x) is there: k_step (layer 0) or the previous down-projection's tail
             else if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, ks_down(e, B), w.ln1, e->d_xn, B, H, c.t_rms_eps, xt));
             else SR_TRY(launch_rmsnorm(s, x, w.ln1, e->d_xn, B, H, c.t_rms_eps, xt));
             gq.x = e->d_xn; gq.x_tiled = xt;
@@ -668,7 +671,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         SR_TRY(launch_attn_decode(s, da));
         GemvArgs go = gv(e->d_attn, QD, w.o_w, B, H, QD, x, H);
         go.W8 = w.o_w8; go.w_scale = w.o_s; go.x_tiled = xt;
-        if (tail) go.tail = make_tail(e, 2 * l, w.ln2, x);
+        if (tail_o) go.tail = make_tail(e, 2 * l, w.ln2, x);
         SR_TRY(launch_gemv(s, go, GV_RESID));
         GemvArgs gg = gv(x, H, w.gu_w, B, 2 * e->t_inter_pad, H, e->d_act, e->t_inter_pad);
         gg.W8 = w.gu_w8; gg.w_scale = w.gu_s;
@@ -685,25 +688,25 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
             gg.M = 0;       // (done)
         }
         else {
-            if (!tail) SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt));
+            if (!tail_o) SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt));
             gg.x = e->d_xn; gg.x_tiled = xt; gg.out_tiled = xt;
         }
         if (gg.M > 0) SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
         GemvArgs gd = gv(e->d_act, e->t_inter_pad, w.down_w, B, H, e->t_inter_pad, e->d_slabs, H);
         gd.ksplit = ks_down(e, B);
         gd.W8 = w.down_w8; gd.w_scale = w.down_s; gd.x_tiled = xt;
-        if (tail) gd.tail = make_tail(e, 2 * l + 1, l + 1 < c.t_layers ? e->ll[l + 1].ln1 : e->final_norm, x);
+        if (tail_d) gd.tail = make_tail(e, 2 * l + 1, l + 1 < c.t_layers ? e->ll[l + 1].ln1 : e->final_norm, x);
         SR_TRY(launch_gemv(s, gd, GV_PARTIAL));
-        pending = !tail;        // with the tail the slabs are already in the residual stream and d_xn holds the next norm
+        pending = !tail_d;      // with the tail the slabs are already in the residual stream and d_xn holds the next norm
     }
-    return enqueue_lm_head(e, B, x, x_alt, pending, s, false, tail);
+    return enqueue_lm_head(e, B, x, x_alt, pending, s, false, tail_d);
 }
 
 int enqueue_step(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, hipStream_t s, const long long* chosen = nullptr) {
     StepArgs a{e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(e->c.t_vocab, B, e->c.t_hidden, fused_norms(e, B) ? 1 : 0), e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished,
                e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden, 1, chosen, e->d_row_limit, e->d_ngen,
                e->rope_cos, e->rope_sin, e->d_row_cs};
-    if (tail_norms(e, B)) { a.norm_w = e->ll[0].ln1; a.eps = e->c.t_rms_eps; a.xn = e->d_xn; a.xn_tiled = 1; }     // layer 0's input norm (see enqueue_decode_forward)
+    if (tail_norms(e, B) & 2) { a.norm_w = e->ll[0].ln1; a.eps = e->c.t_rms_eps; a.xn = e->d_xn; a.xn_tiled = 1; }     // layer 0's input norm (see enqueue_decode_forward)
     SR_TRY(launch_step(s, a));
     return 0;
 }
@@ -1613,7 +1616,8 @@ int sr_op_gemm_f32(const float* A, int lda, const float* W, int M, int N, int K,
                    const int32_t* rowmap, int epilogue, void* stream) {
     const int e = epilogue & 0xff;
     if (e != EPI_STORE && e != EPI_RESID && e != EPI_GELU && e != EPI_F32) return -22;
-    GemmF32Args a{A, lda, W, M, N, K, out, ldo, bias, e == EPI_RESID ? resid : nullptr, rowmap, e == EPI_GELU ? ((epilogue & 0x1000) ? 2 : 1) : 0};
+    GemmF32Args a{A, lda, W, M, N, K, out, ldo, bias, e == EPI_RESID ? resid : nullptr, rowmap, e == EPI_GELU ? ((epilogue & 0x1000) ? 2 : 1) : 0, nullptr};
+    if (epilogue & 0x2000) { a.W3 = reinterpret_cast<const bf16_t*>(W); a.W = nullptr; }      // W = three bf16 planes [3][N][K] (hi, mid, lo)
     SR_WRAP(launch_gemm_f32((hipStream_t)stream, a));
 }
 int sr_op_attention_f32(const float* q, int q_stride, const float* k, int k_stride, const float* v, int v_stride, float* out, int out_stride,

@@ -15,6 +15,7 @@ struct SrSwitches {
     int g256_group;     // SR_G256_GROUP  m-tiles per W panel of the 256-tile GEMM (default 4)
     int attn2;          // SR_ATTN2       0: round-2 prefill attention kernel (default 1)
     int attn_win64;     // SR_ATTN_WIN64  0: no 64-token window kernel (default 1)
+    int sam_f32_split;  // SR_SAM_F32_SPLIT 0: SAM2's float32 GEMM on the f32-input MFMA (round 4) instead of the three-term bf16 split on the bf16 pipe (default 1)
     int tail_norm;      // SR_TAIL_NORM   0: RMSNorm launches instead of the GEMV tails at 5..32 decode rows (default 1; read at sr_engine_create)
 };
 const SrSwitches& sr_switches();
@@ -269,6 +270,7 @@ struct GemmF32Args {
     const float* resid;         // [*, ldo] indexed by DESTINATION row (may alias out) or null; added after the activation
     const int* rowmap;          // optional destination row per source row
     int act;                    // 0 none, 1 GELU (erf form), 2 ReLU
+    const bf16_t* W3;           // optional: W pre-split into three bf16 planes [3][N][K] (hi, mid, lo: W = hi + mid + lo exactly); W may then be null
 };
 int launch_gemm_f32(hipStream_t s, const GemmF32Args& a);
 // float32 attention over the same work items as launch_attn_prefill (q_tile 64); V is ROW-major here ([key][head * hd + d])

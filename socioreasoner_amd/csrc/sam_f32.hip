@@ -11,6 +11,7 @@
 // 157 TF/s = 1/16 of the bf16 rate (MI355X_MICROARCH.md "Matrix cores"), each product and sum an exact float32 fmaf chain -- the
 // arithmetic torch's CPU float32 path performs, up to the order of the sums.
 #include "kernels.h"
+#include "rownorm.h"     // (sr_rsrc: buffer descriptors)
 #include <type_traits>
 #include <math.h>
 
@@ -99,6 +100,217 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmF32Args p, int n_tiles_
     // half) are fetched together, ahead of its stores -- four round trips per tile instead of sixteen.  (All sixteen up front cost 86 more
     // registers and two of the four blocks a CU holds: batched encoder 156 -> 164 ms.  With four blocks per CU the others' k loops hide what
     // is left.)  Same arithmetic, same order.
+    auto epilogue = [&](auto hb_, auto hr_, auto act_) {
+        constexpr bool HB = decltype(hb_)::value, HR = decltype(hr_)::value;
+        constexpr int ACT = decltype(act_)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wm * 64 + i * 32 + col;
+            if (m >= p.M) continue;
+            const size_t orow = (size_t)(p.rowmap ? p.rowmap[m] : m) * p.ldo;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float4 rv[4];
+                if constexpr (HR) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * kg;
+                        rv[q] = n < p.N ? *reinterpret_cast<const float4*>(p.resid + orow + n) : float4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * kg;
+                    if (n >= p.N) continue;
+                    float o[4];
+                    float4 bq = float4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (HB) bq = *reinterpret_cast<const float4*>(p.bias + n);
+                    const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[j][i][4 * q + e];
+                        if constexpr (HB) x += bb[e];
+                        if constexpr (ACT == 1) x = gelu_f(x);
+                        else if constexpr (ACT == 2) x = fmaxf(x, 0.f);
+                        o[e] = x;
+                    }
+                    if constexpr (HR) {
+                        const float4 r = rv[q];
+                        o[0] = r.x + o[0]; o[1] = r.y + o[1]; o[2] = r.z + o[2]; o[3] = r.w + o[3];
+                    }
+                    *reinterpret_cast<float4*>(p.out + orow + n) = float4{o[0], o[1], o[2], o[3]};
+                }
+            }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    auto by_act = [&](auto hb_, auto hr_) {
+        if (p.act == 1) epilogue(hb_, hr_, std::integral_constant<int, 1>{});
+        else if (p.act == 2) epilogue(hb_, hr_, std::integral_constant<int, 2>{});
+        else epilogue(hb_, hr_, std::integral_constant<int, 0>{});
+    };
+    if (p.bias) { if (p.resid) by_act(T_{}, T_{}); else by_act(T_{}, F_{}); }
+    else { if (p.resid) by_act(F_{}, T_{}); else by_act(F_{}, F_{}); }
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM on the bf16 matrix pipe (round 5)
+// The same contract -- float32 operands in, float32 out, float32-grade results -- at the bf16 MFMA rate instead of the float32 one (1/16 of
+// it): every float32 operand is split EXACTLY into three bf16 terms, x = hi + mid + lo (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid);
+// 3 x 8 significand bits cover float32's 24, the two subtractions are exact), and a . w is formed from the six partial products whose
+// weight is >= 2^-16 of the leading one:
+//     hi.hi                                  -> accumulator `main`
+//     hi.mid + mid.hi + mid.mid + hi.lo + lo.hi   -> accumulator `corr`        (dropped: mid.lo, lo.mid, lo.lo, <= 3 x 2^-24 relative)
+// Each bf16 x bf16 product is exact in float32 (16 significand bits) and the MFMA sums them in float32; `corr` (2^-8 of `main`) is kept apart so
+// that `main` sees exactly as many float32 roundings as the f32-input MFMA chain does, and is added once at the end.  The dropped terms are of
+// the size of ONE float32 rounding of the product -- below the round-off of the K-term sum that any float32 GEMM (torch's CPU path included,
+// whose summation order differs from ours anyway) carries: tests/test_gpu_round4.py::test_gemm_f32_vs_float64 holds this kernel to the bound
+// it held the f32-input kernel to, and SAM2's masks keep their pixel-exactness against HF float32 (tests/test_gpu_sam2.py).
+// 6 x v_mfma_f32_32x32x16_bf16 (32 cycles each) replace 8 x v_mfma_f32_32x32x2_f32 (64 cycles each) per 16 k: 2.67 x fewer matrix-pipe cycles.
+// Tiles as above (128 x 128 x 16, 4 waves 2 x 2, D = W_frag x A_frag -> the same accumulator layout and epilogue).  The split happens on the
+// way from global memory to LDS: thread t owns 8 consecutive k of one row (row t / 2, k half t % 2) of each operand; LDS holds three bf16
+// planes per operand as [k half][row][8 k] (16 bytes per entry: fragment reads are conflict-free ds_read_b128, stores conflict-free
+// ds_write_b128 with the second k half displaced by 64 bytes).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
+constexpr int SP_HALF = 128 * 16 + 64;            // bytes between the two k halves of a plane
+constexpr int SP_PLANE = 2 * SP_HALF;             // bytes per plane
+constexpr int SP_OPER = 3 * SP_PLANE;             // bytes per operand (hi, mid, lo)
+
+// x = hi + mid + lo, two values per dword of each plane: one v_cvt_pk_bf16_f32 (round to nearest even) per pair and level, the bf16 terms
+// widened back by a shift / a mask, the remainders by one exact subtraction each -- 11 VALU instructions per pair of elements
+__device__ __forceinline__ uint32_t cvt_pk(float a, float b) {
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2_t{a, b}, bf2_t));
+}
+__device__ __forceinline__ void split3(const float (&x)[8], u32x4s& hi, u32x4s& mid, u32x4s& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = x[2 * e], b = x[2 * e + 1];
+        const uint32_t h = cvt_pk(a, b);
+        const float ra = a - lo16(h), rb = b - hi16(h);              // exact
+        const uint32_t m = cvt_pk(ra, rb);
+        const float sa = ra - lo16(m), sb = rb - hi16(m);            // exact
+        hi[e] = h; mid[e] = m; lo[e] = cvt_pk(sa, sb);
+    }
+}
+
+// W3: W arrives PRE-SPLIT (GemmF32Args.W3: three bf16 planes [3][N][K], what socioreasoner_amd/sam2.py builds once per weight at load time --
+// weights are constants) and goes from global memory to LDS as it is: only A is split in the kernel.
+template <bool W3>
+__global__ __launch_bounds__(256, 2) void k_gemm_f32s(GemmF32Args p, int n_tiles_n) {
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][SP_OPER];     // [buffer][A | W]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / n_tiles_n) * GB, n0 = (tile % n_tiles_n) * GB;
+    const int sr = tid >> 1, sk = tid & 1;                                       // staging: row sr, k half sk
+    // rows beyond M / N are read from the last valid row instead: an output element depends on ITS row of A and ITS row of W only, and the
+    // epilogue never stores rows >= M or columns >= N -- no zero fill, no conditional loads.  Buffer loads (descriptor + per-thread byte offset
+    // fixed for the whole k loop + the k-tile's offset in an SGPR): no per-iteration address arithmetic in VGPRs.
+    const __amdgpu_buffer_rsrc_t ra_ = sr_rsrc(p.A, (unsigned)(((size_t)(p.M - 1) * p.lda + p.K) * 4));
+    const __amdgpu_buffer_rsrc_t rw_ = W3 ? sr_rsrc(p.W3, (unsigned)((size_t)3 * p.N * p.K * 2)) : sr_rsrc(p.W, (unsigned)((size_t)p.N * p.K * 4));
+    const int arow_i = min(m0 + sr, p.M - 1), wrow_i = min(n0 + sr, p.N - 1);
+    const unsigned avo = ((unsigned)arow_i * p.lda + sk * 8) * 4;
+    const unsigned wvo = ((unsigned)wrow_i * p.K + sk * 8) * (W3 ? 2 : 4);
+    const unsigned w3pl = (unsigned)p.N * p.K * 2;                                // bytes per pre-split plane
+    // TWO k-tiles of global loads in flight per thread (register sets 0 / 1 alternate): with one, a k-tile lasted one memory round trip
+    // (~3 200 cycles against the 768 of its 24 MFMAs: 2 blocks per CU do not cover it the way the f32-input kernel's four do)
+    u32x4s ra[2][2], rw[2][2];
+    u32x4s rw3[2][3];
+    auto gload = [&](auto set_, int k0) {
+        constexpr int S = decltype(set_)::value;
+        ra[S][0] = __builtin_amdgcn_raw_buffer_load_b128(ra_, avo, k0 * 4, 0);
+        ra[S][1] = __builtin_amdgcn_raw_buffer_load_b128(ra_, avo + 16, k0 * 4, 0);
+        if constexpr (W3) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) rw3[S][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wvo, k0 * 2 + pl * w3pl, 0);
+        } else {
+            rw[S][0] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wvo, k0 * 4, 0);
+            rw[S][1] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wvo + 16, k0 * 4, 0);
+        }
+    };
+    const int soff = sk * SP_HALF + sr * 16;
+    auto lstore = [&](auto set_, int b) {
+        constexpr int S = decltype(set_)::value;
+        u32x4s h, m, l;
+        float xa[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xa[e] = __uint_as_float(ra[S][e >> 2][e & 3]);
+        split3(xa, h, m, l);
+        *reinterpret_cast<u32x4s*>(sm[b][0] + soff) = h;
+        *reinterpret_cast<u32x4s*>(sm[b][0] + SP_PLANE + soff) = m;
+        *reinterpret_cast<u32x4s*>(sm[b][0] + 2 * SP_PLANE + soff) = l;
+        if constexpr (W3) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4s*>(sm[b][1] + pl * SP_PLANE + soff) = rw3[S][pl];
+        } else {
+            float xw[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xw[e] = __uint_as_float(rw[S][e >> 2][e & 3]);
+            split3(xw, h, m, l);
+            *reinterpret_cast<u32x4s*>(sm[b][1] + soff) = h;
+            *reinterpret_cast<u32x4s*>(sm[b][1] + SP_PLANE + soff) = m;
+            *reinterpret_cast<u32x4s*>(sm[b][1] + 2 * SP_PLANE + soff) = l;
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    f32x16 acc[2][2], cor[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { acc[j][i][v] = 0.f; cor[j][i][v] = 0.f; }
+    const int nk = p.K / GK;
+    gload(S0{}, 0);
+    gload(S1{}, min(1, nk - 1) * GK);
+    lstore(S0{}, 0);
+    __syncthreads();
+    const int kg = lane >> 5, col = lane & 31;
+    const int roff = kg * SP_HALF + col * 16;                                     // fragment: row col of its 32-row tile, k half kg
+    // k-tile kt: LDS buffer kt & 1 holds it, register set (kt + 1) & 1 holds k-tile kt + 1 (loaded one iteration ago), set kt & 1 is free for kt + 2
+    auto ktile = [&](auto cur_, int kt) {
+        constexpr int cur = decltype(cur_)::value;
+        using NXT = std::integral_constant<int, cur ^ 1>;
+        gload(cur_, min(kt + 2, nk - 1) * GK);      // UNCONDITIONAL (past the end: the last k-tile again, never stored): behind a branch the compiler cannot count
+                                                    // these loads and makes the store of k-tile kt + 1 below wait for ALL of them (vmcnt(0) instead of vmcnt(5))
+        bf16x8 af[2][3], wf[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                af[t][pl] = *reinterpret_cast<const bf16x8*>(sm[cur][0] + pl * SP_PLANE + roff + (wm * 64 + t * 32) * 16);
+                wf[t][pl] = *reinterpret_cast<const bf16x8*>(sm[cur][1] + pl * SP_PLANE + roff + (wn * 64 + t * 32) * 16);
+            }
+        // six partial products, the smallest first; each pass runs over the four (j, i) accumulators, so an MFMA never waits for the one before it
+        // (back-to-back MFMAs on ONE accumulator issue at their 64-cycle latency instead of the pipe's 32-cycle rate)
+#define SR_PASS(ACC, WP, AP)                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                      \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                  \
+                ACC[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][WP], af[i][AP], ACC[j][i], 0, 0, 0);
+        SR_PASS(cor, 2, 0)
+        SR_PASS(cor, 0, 2)
+        SR_PASS(cor, 1, 1)
+        SR_PASS(cor, 1, 0)
+        SR_PASS(cor, 0, 1)
+        SR_PASS(acc, 0, 0)
+#undef SR_PASS
+        if (kt + 1 < nk) lstore(NXT{}, cur ^ 1);        // (waits for the loads of k-tile kt + 1 only: those of kt + 2 stay in flight)
+        __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        ktile(S0{}, kt);
+        if (kt + 1 < nk) ktile(S1{}, kt + 1);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[j][i][v] += cor[j][i][v];
+    // epilogue: identical to k_gemm_f32's (same accumulator layout)
     auto epilogue = [&](auto hb_, auto hr_, auto act_) {
         constexpr bool HB = decltype(hb_)::value, HR = decltype(hr_)::value;
         constexpr int ACT = decltype(act_)::value;
@@ -256,9 +468,16 @@ __global__ __launch_bounds__(256) void k_attn_f32(AttnF32Args p) {
 
 int launch_gemm_f32(hipStream_t s, const GemmF32Args& a) {
     if (a.M <= 0 || a.N <= 0) return 0;
-    if (a.K % GK || a.N % 4 || a.ldo % 4 || a.lda % 4 || (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.out | (uintptr_t)a.resid | (uintptr_t)a.bias) & 15)) return -22;      // (bias is read 16 bytes at a time)
+    if (a.K % GK || a.N % 4 || a.ldo % 4 || a.lda % 4 || (!a.W && !a.W3) || (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.out | (uintptr_t)a.resid | (uintptr_t)a.bias) & 15)) return -22;      // (bias is read 16 bytes at a time)
     const int tn = cdiv(a.N, GB), tm = cdiv(a.M, GB);
-    hipLaunchKernelGGL(k_gemm_f32, dim3((unsigned)tn * (unsigned)tm), dim3(256), 0, s, a, tn);
+    // default: the split-bf16 form on the bf16 matrix pipe (SR_SAM_F32_SPLIT=0: the f32-input MFMA of round 4); the row stride of A and the
+    // rows of W must keep the staging's 16-byte loads of 8 consecutive k aligned (lda % 4, K % 16: checked above)
+    const bool fits32 = ((size_t)a.M * a.lda + a.K) * 4 < (1ull << 32) && (size_t)3 * a.N * a.K * 4 < (1ull << 32);      // buffer descriptors address 4 GB
+    if (a.W3) {
+        if (a.K % 8 || ((uintptr_t)a.W3 & 15) || !fits32) return -22;
+        hipLaunchKernelGGL(k_gemm_f32s<true>, dim3((unsigned)tn * (unsigned)tm), dim3(256), 0, s, a, tn);
+    } else if (sr_switches().sam_f32_split && fits32) hipLaunchKernelGGL(k_gemm_f32s<false>, dim3((unsigned)tn * (unsigned)tm), dim3(256), 0, s, a, tn);
+    else hipLaunchKernelGGL(k_gemm_f32, dim3((unsigned)tn * (unsigned)tm), dim3(256), 0, s, a, tn);
     SR_CHECK_LAUNCH();
     return 0;
 }

@@ -123,6 +123,8 @@ class CrossRankDispatcher:
                     r = min(range(self.world), key=lambda k: (load[k], k))
                     if load[r] < self.cap:
                         break
+                    if self.aborted():                    # another rank failed: stop dealing at once instead of spinning into the timeout
+                        raise RuntimeError("dispatcher: another rank aborted the round")
                     if time.monotonic() > deadline:
                         raise TimeoutError("dispatcher: no worker below its request cap before the timeout")
                     time.sleep(self.poll_s)

@@ -3,7 +3,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from socioreasoner_amd import sam2, synthetic
 g = sam2.Sam2Geometry()
-e = sam2.Sam2Engine(g)
+e = sam2.Sam2Engine(g, dtype=__import__("torch").bfloat16)
 e.load_state_dict(sam2.synthetic_state_dict(g))
 img = torch.from_numpy(synthetic.tile_pixels(7, 756, 756)).cuda()
 acc = torch.zeros(756, 756, dtype=torch.uint8, device="cuda")

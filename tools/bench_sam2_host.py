@@ -5,7 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from socioreasoner_amd import sam2, synthetic
 g = sam2.Sam2Geometry()
-e = sam2.Sam2Engine(g)
+e = sam2.Sam2Engine(g, dtype=__import__("torch").bfloat16)
 e.load_state_dict(sam2.synthetic_state_dict(g))
 pr = sam2.Sam2Predictor(e)
 N = 32

@@ -50,9 +50,12 @@ for stage in "$@"; do
   case $stage in
     tests5) timeout 1500 python -m pytest tests/test_gpu_round5.py -x -q -m gpu 2>&1 | tail -15 ;;
     suite)  timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 ;;
+    gemm_f32) timeout 600 python tools/bench_gemm_f32.py | tee gpurun_out/r05_gemm_f32_split.jsonl ;;
+    sam2bench) timeout 900 python tools/bench_sam2_modes.py | tee gpurun_out/r05_sam2_modes.json ;;
+    sam2tests) timeout 1500 python -m pytest tests/test_gpu_sam2.py tests/test_gpu_round4.py -x -q -m gpu -k "sam2 or gemm_f32 or seg_infer" 2>&1 | tail -8 ;;
     smoke)  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
     tail_ab)
-      for rep in 1 2; do for t in 0 1; do
+      for rep in 1 2; do for t in 0 1 2 3; do
         SR_TAIL_NORM=$t timeout 600 python bench.py --static --steps 3 --warmup 1 $QUIET > gpurun_out/r05_tail_${t}_$rep.log 2> gpurun_out/r05_tail_${t}_$rep.err
         line gpurun_out/r05_tail_${t}_$rep.log "SR_TAIL_NORM=$t rep $rep:"
       done; done ;;

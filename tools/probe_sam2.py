@@ -8,7 +8,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "tiny"
 og = S.geometry_tiny() if tag == "tiny" else S.geometry_large()
 g = sam2.Sam2Geometry(**{k: getattr(og, k) for k in sam2.Sam2Geometry.__dataclass_fields__})
 W = S.synthetic_weights(og)
-e = sam2.Sam2Engine(g)
+e = sam2.Sam2Engine(g, dtype=__import__("torch").bfloat16)
 e.load_state_dict(W)
 hw = 189 if tag == "tiny" else 756
 img = synthetic.tile_pixels(7, hw, hw)
