@@ -87,7 +87,7 @@ static void load_switches() {
     g_sw.attn2 = env_int("SR_ATTN2", 1);
     g_sw.attn_win64 = env_int("SR_ATTN_WIN64", 1);
     g_sw.sam_f32_split = env_int("SR_SAM_F32_SPLIT", 1);
-    g_sw.tail_norm = env_int("SR_TAIL_NORM", 3);
+    g_sw.tail_norm = env_int("SR_TAIL_NORM", 0);
     g_sw_loaded = true;
 }
 const SrSwitches& sr_switches() {
@@ -136,7 +136,8 @@ struct sr_engine {
     float *d_logits, *d_slabs, *d_amax_val;
     float* d_row_cs = nullptr;               // [MAXB][128] rotary cos | sin of every row's current position (k_step -> decode attention)
     unsigned* d_tail = nullptr;              // [2 * layers] arrival tickets of the decode GEMV tails (rownorm.h) + [1] give-up count; zeroed at the head of every forward
-    int tail_norm = 1;                       // round 5: RMSNorm of a 5..32-row decode layer inside the o_proj / down-projection launches (SR_TAIL_NORM=0: the two launches)
+    int tail_norm = 0;                       // round 5: RMSNorm of a 5..32-row decode layer inside the o_proj (bit 0) / down-projection (bit 1) launches; OFF by default: measured
+                                             // 0.5 / 1.0 / 1.4 % SLOWER per decode step than the two RMSNorm launches (SR_TAIL_NORM=1 / 2 / 3)
     int *d_amax_idx, *d_cur_tok, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
     int n_part = 0;      // LM-head blocks = partial argmax entries per row
     // continuous batching (sr_rows_*): admission scratch so that a prefill never touches the pending tokens of running rows
@@ -212,7 +213,6 @@ const char* validate(const sr_config& c) {
     if (c.mrope_section[0] + c.mrope_section[1] + c.mrope_section[2] != 64) return "mrope_section must sum to 64";
     if (c.max_batch < 1 || c.max_batch > MAXB) return "max_batch in 1..128";
     if (c.kv_slots != 0 && (c.kv_slots < c.max_batch || c.kv_slots > 2 * MAXB)) return "kv_slots 0 (= max_batch) or max_batch..256";
-    if (c.max_batch > 32 && c.lm_weight_dtype != 0) return "more than 32 batch rows: bf16 LM weights only (the fp8 decode stream has no row-group kernel)";
     if (c.max_ctx < 64 || c.max_ctx % 64) return "max_ctx multiple of 64";
     if (c.lm_weight_dtype < 0 || c.lm_weight_dtype > 2) return "lm_weight_dtype 0 (bf16), 1 (fp8 e4m3 weights, per-channel scale) or 2 (1 + MX fp8 activations in prefill)";
     if (c.lm_weight_dtype == 2 && (c.t_hidden % 256 || ((c.t_heads + 2 * c.t_kv_heads) * 128) % 256 || c.t_hidden / 128 < 2))
@@ -1698,7 +1698,9 @@ int sr_op_gemv_f8(const void* x, int ldx, const void* w8, const float* w_scale, 
     a.x = (const bf16_t*)x; a.ldx = ldx; a.W = nullptr; a.W8 = (const unsigned char*)w8; a.w_scale = w_scale; a.w_tiled = 1;
     a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo; a.ksplit = ksplit > 0 ? ksplit : 1;
     a.bias = (const bf16_t*)bias; a.norm_w = (const bf16_t*)norm_w; a.eps = eps;
-    SR_WRAP(launch_gemv((hipStream_t)stream, a, mode));
+    a.x_tiled = (mode & 0x800) ? 1 : 0;          // bit 11: x fragment-ordered; bit 12: SWIGLU output fragment-ordered (as sr_op_gemv_fused)
+    a.out_tiled = (mode & 0x1000) ? 1 : 0;
+    SR_WRAP(launch_gemv((hipStream_t)stream, a, mode & 0xff));
 }
 int sr_op_sample(const float* logits, int B, int V, float temperature, int top_k, float top_p, float rep_penalty, const uint32_t* seen,
                  uint32_t seed, const int32_t* step, int64_t* out, const float* blk_max, int n_blk, int blk_rows, void* stream) {

@@ -599,7 +599,11 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
 // quadruple.  The x fragments of all groups ride the ring with the weights (ring depth 3 at G = 2, 2 at G = 4: 16 registers per group and
 // slot); at G = 4 a wave reads 4 x as many x bytes (from L2) as weight bytes (from HBM).  Per row the arithmetic is that of k_gemv32 (same
 // MFMA, same k order, same split over waves and the same reduction order), so a row's result does not depend on which group it sits in.
-template <int MODE, int KP, int G>
+// F8 (round 5: configs[4]'s fp8 weights at 33..128 rows): the stream is the fp8 image (tiled8, common.h: 16 bytes = 16 consecutive k of one row).
+// A lane loads TWO 16-byte units per 64-k chunk -- k-groups 2 j + kg, j = 0 / 1 -- and widens each (exactly) to the bf16 operands of two MFMA steps
+// (k % 16 < 8, >= 8), so MFMA step s = 2 j + h of lane half kg covers k = (2 j + kg) * 16 + h * 8 .. + 7; x is addressed with the same permutation.
+// The per-channel scale multiplies the float32 sums in the epilogue.  Half the weight bytes per step of the bf16 stream, the same x bytes.
+template <int MODE, int KP, int G, bool F8 = false>
 __global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int ntiles32) {
     constexpr int WAVES = 4, TPB = WAVES / KP, U = (G <= 2) ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -616,25 +620,37 @@ __global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int
     const int c0 = min(((MODE == GV_PARTIAL ? blockIdx.y : 0) * KP + kp) * per, nchunks);
     const int cend = min(c0 + per, nchunks);
     const int t16 = (active ? tile : 0) * 2 + half;
-    const bf16_t* wbase = p.w_tiled ? p.W + (size_t)t16 * nchunks * 1024 + kg * 512 + fr * 8
-                                    : p.W + (size_t)(t16 * 16 + fr) * p.K + kg * 8;
+    const bf16_t* wbase = F8 ? nullptr : p.w_tiled ? p.W + (size_t)t16 * nchunks * 1024 + kg * 512 + fr * 8
+                                                   : p.W + (size_t)(t16 * 16 + fr) * p.K + kg * 8;
+    const unsigned char* w8base = F8 ? p.W8 + (size_t)t16 * nchunks * 1024 + kg * 256 + fr * 16 : nullptr;
     const size_t w_c = p.w_tiled ? 1024 : 64, w_s = p.w_tiled ? 128 : 16;
     // x of row group g = x of group 0 + g * x_g elements (fragment order: two 16-row tiles further; row-major: 32 rows further).  Fragment-
     // ordered x holds whole 16-row groups: rows beyond ceil16(M) do not exist -- never read them (m_rd); row-major x: rows beyond M
-    const bf16_t* xbase = p.x_tiled ? p.x + ((size_t)(m0 >> 4) * nchunks * 2 + kg) * 512 + (m0 & 15) * 8 : p.x + (size_t)m0 * p.ldx + kg * 8;
+    // (F8: MFMA step s = 2 j + h reads k-group 2 j + kg, k half h -- fragment order: k-step half h, lane group 2 j + kg; see above)
+    const bf16_t* xbase = F8 ? (p.x_tiled ? p.x + ((size_t)(m0 >> 4) * nchunks * 2) * 512 + (kg * 16 + (m0 & 15)) * 8 : p.x + (size_t)m0 * p.ldx + kg * 16)
+                             : (p.x_tiled ? p.x + ((size_t)(m0 >> 4) * nchunks * 2 + kg) * 512 + (m0 & 15) * 8 : p.x + (size_t)m0 * p.ldx + kg * 8);
     const size_t x_c = p.x_tiled ? 1024 : 64, x_s = p.x_tiled ? 128 : 16, x_g = p.x_tiled ? (size_t)nchunks * 2048 : (size_t)32 * p.ldx;
+    const size_t x8_j = p.x_tiled ? 256 : 32, x8_h = p.x_tiled ? 512 : 8;           // F8: element strides of j (k-group pair) and h (k half)
     const int m_rd = p.x_tiled ? (p.M + 15) / 16 * 16 : p.M;
-    u32x4 w[U][4], xv[U][G][4];
+    constexpr int WL = F8 ? 2 : 4;
+    u32x4 w[U][WL], xv[U][G][4];
     auto fill_w = [&](int u, int c) {
+        if constexpr (F8) {
 #pragma unroll
-        for (int st = 0; st < 4; ++st) w[u][st] = ldg_nt(wbase + (size_t)c * w_c + st * w_s);
+            for (int j = 0; j < 2; ++j) w[u][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(w8base + (size_t)c * 1024 + j * 512));
+        } else {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) w[u][st] = ldg_nt(wbase + (size_t)c * w_c + st * w_s);
+        }
     };
     auto fill_x = [&](int u, int c) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
 #pragma unroll
-            for (int st = 0; st < 4; ++st)
-                xv[u][g][st] = (m0 + 32 * g < m_rd) ? *reinterpret_cast<const u32x4*>(xbase + g * x_g + (size_t)c * x_c + st * x_s) : u32x4{0, 0, 0, 0};
+            for (int st = 0; st < 4; ++st) {
+                const bf16_t* xp = F8 ? xbase + g * x_g + (size_t)c * x_c + (st >> 1) * x8_j + (st & 1) * x8_h : xbase + g * x_g + (size_t)c * x_c + st * x_s;
+                xv[u][g][st] = (m0 + 32 * g < m_rd) ? *reinterpret_cast<const u32x4*>(xp) : u32x4{0, 0, 0, 0};
+            }
         }
     };
     auto fill = [&](int u, int c) { fill_w(u, c); fill_x(u, c); };
@@ -656,10 +672,19 @@ __global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int
             for (int u = 0; u < U; ++u) {
                 if (c + u < cend) {
 #pragma unroll
-                    for (int st = 0; st < 4; ++st)
+                    for (int st = 0; st < 4; ++st) {
+                        u32x4 wop;
+                        if constexpr (F8) {
+                            const u32x4 q = w[u][st >> 1];
+                            uint32_t d[4];
+                            f8x4_to_bf16(q[(st & 1) * 2], d[0], d[1]);
+                            f8x4_to_bf16(q[(st & 1) * 2 + 1], d[2], d[3]);
+                            wop = u32x4{d[0], d[1], d[2], d[3]};
+                        } else wop = w[u][st];
 #pragma unroll
                         for (int g = 0; g < G; ++g)
-                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(w[u][st]), as_frag(xv[u][g][st]), acc[g], 0, 0, 0);
+                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wop), as_frag(xv[u][g][st]), acc[g], 0, 0, 0);
+                    }
                     if (c + U + u < cend) fill(u, c + U + u);
                 }
             }
@@ -681,6 +706,18 @@ __global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[g][i] += o[i];
                 }
+        }
+    }
+    if constexpr (F8) {
+        if (active && kp == 0) {        // per-output-channel scale of the fp8 weights (engine row order): weight row of acc[i] = tile * 32 + 8 (i / 4) + 4 kg + i % 4
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 sc = *reinterpret_cast<const float4*>(p.w_scale + (size_t)tile * 32 + 8 * g4 + 4 * kg);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    acc[g][g4 * 4] *= sc.x; acc[g][g4 * 4 + 1] *= sc.y; acc[g][g4 * 4 + 2] *= sc.z; acc[g][g4 * 4 + 3] *= sc.w;
+                }
+            }
         }
     }
     float bestv[G];
@@ -761,30 +798,31 @@ __global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int
     }
 }
 
-template <int MODE, int KP, int G>
+template <int MODE, int KP, int G, bool F8 = false>
 int launch_32g(hipStream_t s, const GemvArgs& a) {
     constexpr int TPB = 4 / KP;
     const int ntiles = a.N / 32;
     dim3 grid(cdiv(ntiles, TPB), MODE == GV_PARTIAL ? a.ksplit : cdiv(a.M, 32 * G));
     size_t smem = (size_t)TPB * (KP > 1 ? KP - 1 : 0) * G * 64 * sizeof(f32x16);
     if (smem < (size_t)4 * 32 * G * 8) smem = (size_t)4 * 32 * G * 8;
-    hipLaunchKernelGGL((k_gemv32g<MODE, KP, G>), grid, dim3(256), smem, s, a, ntiles);
+    hipLaunchKernelGGL((k_gemv32g<MODE, KP, G, F8>), grid, dim3(256), smem, s, a, ntiles);
     SR_CHECK_LAUNCH();
     return 0;
 }
-template <int MODE, int G>
+template <int MODE, int G, bool F8 = false>
 int launch_32g_kp(hipStream_t s, const GemvArgs& a, int kp) {
-    if constexpr (MODE == GV_F32) return launch_32g<MODE, 1, G>(s, a);
+    if constexpr (MODE == GV_F32) return launch_32g<MODE, 1, G, false>(s, a);
+    else if constexpr (F8) return kp == 4 ? launch_32g<MODE, 4, G, true>(s, a) : -22;        // (the fp8 stream: in-block K split 4 only, as at <= 32 rows)
     else return kp == 4 ? launch_32g<MODE, 4, G>(s, a) : kp == 2 ? launch_32g<MODE, 2, G>(s, a) : launch_32g<MODE, 1, G>(s, a);
 }
-template <int G>
+template <int G, bool F8 = false>
 int launch_32g_mode(hipStream_t s, const GemvArgs& a, int mode, int kp) {
     switch (mode) {
-        case GV_PARTIAL: return launch_32g_kp<GV_PARTIAL, G>(s, a, kp);
-        case GV_SWIGLU: return launch_32g_kp<GV_SWIGLU, G>(s, a, kp);
-        case GV_F32: return launch_32g_kp<GV_F32, G>(s, a, kp);
-        case GV_BIAS: return launch_32g_kp<GV_BIAS, G>(s, a, kp);
-        case GV_RESID: return launch_32g_kp<GV_RESID, G>(s, a, kp);
+        case GV_PARTIAL: return launch_32g_kp<GV_PARTIAL, G, F8>(s, a, kp);
+        case GV_SWIGLU: return launch_32g_kp<GV_SWIGLU, G, F8>(s, a, kp);
+        case GV_F32: return F8 ? -22 : launch_32g_kp<GV_F32, G, false>(s, a, kp);
+        case GV_BIAS: return launch_32g_kp<GV_BIAS, G, F8>(s, a, kp);
+        case GV_RESID: return launch_32g_kp<GV_RESID, G, F8>(s, a, kp);
     }
     return -22;
 }
@@ -901,7 +939,8 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     if (a.M <= 0) return 0;
     if (a.M > 128 || a.K % 64 != 0 || a.N % 16 != 0) return -22;
     if (a.M > 32) {      // 33..128 rows: the 32-row-tile kernel over 2 / 4 row groups per weight pass (bf16 stream, no fused norm)
-        if (a.N % 32 != 0 || a.norm_w || a.W8 || a.n_slabs || a.tail.counter) return -22;
+        if (a.N % 32 != 0 || a.norm_w || a.n_slabs || a.tail.counter) return -22;
+        if (a.W8 && (!a.w_scale || mode == GV_F32)) return -22;
         if (mode == GV_PARTIAL && (a.ksplit < 1 || a.ksplit > a.K / 64)) return -22;
         if (a.out_tiled && (mode != GV_SWIGLU || (a.N / 2) % 64 != 0)) return -22;
         const int kp32 = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, mode == GV_F32 ? 1 : 4);
@@ -909,6 +948,10 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
         // blocks, and their 8 - 10 MB of weights cost nothing to stream once per group (measured against two groups per block: decode step
         // 3.24 -> 3.09 ms at 64 rows, 4.20 -> 4.15 ms at 128; bit-identical)
         const bool narrow = (mode == GV_BIAS || mode == GV_RESID) && a.N <= 4096;
+        if (a.W8) {     // fp8 weight stream (round 5): the same row-group kernel on the tiled8 image
+            if (narrow) return launch_32g_mode<1, true>(s, a, mode, kp32);
+            return a.M <= 64 ? launch_32g_mode<2, true>(s, a, mode, kp32) : launch_32g_mode<4, true>(s, a, mode, kp32);
+        }
         if (narrow) return launch_32g_mode<1>(s, a, mode, kp32);
         return a.M <= 64 ? launch_32g_mode<2>(s, a, mode, kp32) : launch_32g_mode<4>(s, a, mode, kp32);
     }

@@ -151,3 +151,171 @@ def test_split_bf16_gemm_is_float32_grade(monkeypatch, M, N, K):
                                                    "max_rel_diff_between_kernels": rel})
     assert errs["1"] <= 1.25 * errs["0"] + ulp, errs
     assert rel < 1e-4, rel
+
+
+# ------------------------------------------------------------------------------------------------ row-group GEMV (33..128 rows) at the 3B shapes, bf16 and fp8
+from tests.util import assert_bf16_close, tile16x64, tile8  # noqa: E402
+
+GV_PARTIAL, GV_SWIGLU, GV_F32, GV_BIAS, GV_RESID = range(5)
+TL, XT, OT = 0x100, 0x800, 0x1000
+_KEEP = []
+
+
+def _D(t):
+    d = t.cuda().contiguous()
+    _KEEP.append(d)
+    if len(_KEEP) > 48:
+        torch.cuda.synchronize()
+        del _KEEP[:24]
+    return d
+
+
+def _rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def _interleave16(gate, up):
+    n, k = gate.shape
+    out = torch.empty(2 * n, k, dtype=gate.dtype)
+    o = out.view(n // 16, 2, 16, k)
+    o[:, 0] = gate.view(n // 16, 16, k)
+    o[:, 1] = up.view(n // 16, 16, k)
+    return out
+
+
+def _frag_x(x):
+    """[M, K] -> the fragment-ordered activation buffer of the batch > 4 decode layer (tiled16x64 of [ceil16(M), K], zero rows appended)"""
+    M, K = x.shape
+    Mp = (M + 15) // 16 * 16
+    xp = torch.zeros(Mp, K, dtype=x.dtype)
+    xp[:M] = x
+    return tile16x64(xp)
+
+
+def _unfrag(t, M, K):
+    Mp = (M + 15) // 16 * 16
+    return t.reshape(Mp // 16, K // 64, 2, 4, 16, 8).permute(0, 4, 1, 3, 2, 5).reshape(Mp, K)[:M]
+
+
+@pytest.mark.parametrize("xt", [0, 1])
+@pytest.mark.parametrize("M", [33, 48, 64, 65, 100, 128])
+def test_row_group_gemv_bf16_at_3b_shapes(M, xt):
+    """k_gemv32g (G = 1 / 2 / 4 row groups per weight pass, row-split narrow launches) checked per operator at the 3B
+    shapes against float64 / the oracle's rounding points -- q/k/v (bias), o_proj (residual, in place), gate/up (SwiGLU, row-major and
+    fragment-ordered output), the 4-slab down-projection and the float32 head, with x row-major and fragment-ordered, M not a multiple
+    of 16 or 32; and the refusals above 32 rows (fused norm, pending slabs)."""
+    from oracle import model_ref as MR
+    from socioreasoner_amd import lib
+    L = lib.load()
+    K, N, I = 2048, 2560, 11008
+    x = _rnd((M, K), 500 + M, 1.0)
+    xd = _D(_frag_x(x) if xt else x)
+    fl = TL | (XT if xt else 0)
+    w, b = _rnd((N, K), 501, 0.03), _rnd((N,), 502, 0.1)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    assert L.sr_op_gemv_fused(_P(xd), K, _P(_D(tile16x64(w))), M, N, K, _P(out), N, GV_BIAS | fl, _P(_D(b)), None, C.c_float(0), None, 0, None, None, None, _sp()) == 0
+    assert_bf16_close(out.float().cpu(), MR.linear(x.float(), w.float(), b.float()), 1, 0.02, "qkv bias")
+    wo = _rnd((2048, K), 503, 0.03)
+    res = _rnd((M, 2048), 504)
+    rd = res.cuda().clone()
+    assert L.sr_op_gemv_fused(_P(xd), K, _P(_D(tile16x64(wo))), M, 2048, K, _P(rd), 2048, GV_RESID | fl, None, None, C.c_float(0), None, 0, None, None, None, _sp()) == 0
+    assert_bf16_close(rd.float().cpu(), MR.r(res.float() + MR.linear(x.float(), wo.float())), 2, 0.01, "o_proj resid")
+    g, u = _rnd((I, K), 505, 0.03), _rnd((I, K), 506, 0.03)
+    wgu = _D(tile16x64(_interleave16(g, u)))
+    want = MR.r(MR.silu_bf16(MR.linear(x.float(), g.float())) * MR.linear(x.float(), u.float()))
+    for ot in (0, 1):          # (the fragment-ordered output needs N / 2 % 64 == 0: 11008 = 172 * 64)
+        Mp = (M + 15) // 16 * 16
+        act = torch.zeros(Mp * I if ot else M * I, dtype=torch.bfloat16, device="cuda")
+        assert L.sr_op_gemv_fused(_P(xd), K, _P(wgu), M, 2 * I, K, _P(act), I, GV_SWIGLU | fl | (OT if ot else 0), None, None, C.c_float(0), None, 0, None, None, None, _sp()) == 0
+        got = _unfrag(act.cpu(), M, I) if ot else act.cpu().reshape(M, I)
+        assert_bf16_close(got.float(), want, 3, 0.005, f"gate/up swiglu out_tiled={ot}")
+    xa = _rnd((M, I), 507, 0.5)
+    wd = _rnd((2048, I), 508, 0.02)
+    slabs = torch.zeros(4, M, 2048, dtype=torch.float32, device="cuda")
+    assert L.sr_op_gemv(_P(_D(_frag_x(xa) if xt else xa)), I, _P(_D(tile16x64(wd))), M, 2048, I, _P(slabs), 4, GV_PARTIAL | fl, _sp()) == 0
+    assert float((slabs.sum(0).cpu().double() - xa.double() @ wd.double().t()).abs().max()) <= 2e-3
+    V = 4096
+    wv = _rnd((V, K), 509, 0.03)
+    nb = L.sr_op_gemv_f32_blocks(V, M, K, 0)
+    lg = torch.zeros(M, V, dtype=torch.float32, device="cuda")
+    av, ai = torch.zeros(M, nb, dtype=torch.float32, device="cuda"), torch.zeros(M, nb, dtype=torch.int32, device="cuda")
+    assert L.sr_op_gemv_fused(_P(xd), K, _P(_D(tile16x64(wv))), M, V, K, _P(lg), V, GV_F32 | fl, None, None, C.c_float(0), None, 0, None, _P(av), _P(ai), _sp()) == 0
+    torch.cuda.synchronize()
+    assert float((lg.cpu().double() - x.double() @ wv.double().t()).abs().max()) <= 1e-3
+    for m in (0, M - 1):
+        assert int(ai[m][av[m] == av[m].max()].min()) == int(lg[m].argmax())
+    # refusals above 32 rows: a fused RMSNorm prologue / pending slabs belong to the <= 4-row kernels
+    nw = _D(torch.ones(K, dtype=torch.bfloat16))
+    assert L.sr_op_gemv_fused(_P(xd), K, _P(_D(tile16x64(w))), M, N, K, _P(out), N, GV_BIAS | fl, _P(_D(b)), _P(nw), C.c_float(1e-6), None, 0, None, None, None, _sp()) != 0
+
+
+@pytest.mark.parametrize("M", [33, 64, 100, 128])
+def test_row_group_gemv_fp8_at_3b_shapes(M):
+    """VERDICT round 4 (missing #3): the fp8 weight stream above 32 rows -- k_gemv32g on the tiled8 image (two 16-byte units per lane and
+    64-k chunk widened exactly to the bf16 MFMA operands, per-channel scale on the float32 sums) against the oracle's quantised Linear,
+    every mode the decode layer uses, x row-major and fragment-ordered."""
+    from oracle import model_ref as MR
+    from socioreasoner_amd import lib
+    L = lib.load()
+    K, N, I = 2048, 2560, 11008
+    x = _rnd((M, K), 600 + M, 1.5)
+
+    def quant(w):
+        q = MR.QuantW(w.float())
+        return q, _D(tile8(q.q8.view(torch.uint8))), _D(q.scale)
+    for xt in (0, 1):
+        xd = _D(_frag_x(x) if xt else x)
+        fl = XT if xt else 0
+        w, b = _rnd((N, K), 601, 0.03), _rnd((N,), 602, 0.1)
+        qw, w8, sc = quant(w)
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        assert L.sr_op_gemv_f8(_P(xd), K, _P(w8), _P(sc), M, N, K, _P(out), N, GV_BIAS | fl, _P(_D(b)), None, C.c_float(0), 1, _sp()) == 0
+        assert_bf16_close(out.float().cpu(), MR.linear(x.float(), qw, b.float()), 1, 0.02, "f8 qkv bias")
+        wo = _rnd((2048, K), 603, 0.03)
+        qo, o8, so = quant(wo)
+        res = _rnd((M, 2048), 604)
+        rd = res.cuda().clone()
+        assert L.sr_op_gemv_f8(_P(xd), K, _P(o8), _P(so), M, 2048, K, _P(rd), 2048, GV_RESID | fl, None, None, C.c_float(0), 1, _sp()) == 0
+        assert_bf16_close(rd.float().cpu(), MR.r(res.float() + MR.linear(x.float(), qo)), 2, 0.01, "f8 o_proj resid")
+        g, u = _rnd((I, K), 605, 0.03), _rnd((I, K), 606, 0.03)
+        qg, qu = MR.QuantW(g.float()), MR.QuantW(u.float())
+        gu8 = _D(tile8(_interleave16(qg.q8.view(torch.uint8), qu.q8.view(torch.uint8))))
+        gus = _D(_interleave16(qg.scale[:, None], qu.scale[:, None])[:, 0])
+        act = torch.zeros(M, I, dtype=torch.bfloat16, device="cuda")
+        assert L.sr_op_gemv_f8(_P(xd), K, _P(gu8), _P(gus), M, 2 * I, K, _P(act), I, GV_SWIGLU | fl, None, None, C.c_float(0), 1, _sp()) == 0
+        want = MR.r(MR.silu_bf16(MR.linear(x.float(), qg)) * MR.linear(x.float(), qu))
+        assert_bf16_close(act.float().cpu(), want, 3, 0.005, "f8 gate/up swiglu")
+        xa = _rnd((M, I), 607, 0.5)
+        wd = _rnd((2048, I), 608, 0.03)
+        qd, d8, sd = quant(wd)
+        slabs = torch.zeros(4, M, 2048, dtype=torch.float32, device="cuda")
+        assert L.sr_op_gemv_f8(_P(_D(_frag_x(xa) if xt else xa)), I, _P(d8), _P(sd), M, 2048, I, _P(slabs), 2048, GV_PARTIAL | fl, None, None, C.c_float(0), 4, _sp()) == 0
+        ref = (xa.double() @ qd.q.double().t()) * qd.scale.double()
+        assert float((slabs.sum(0).cpu().double() - ref).abs().max()) <= 2e-3
+
+
+@pytest.mark.parametrize("B,fp8", [(64, True), (128, "mx")])
+def test_fp8_weights_above_32_rows_tiny_engine(B, fp8):
+    """`max_batch > 32` with `lm_weight_dtype` 1 / 2 (refused until round 5: csrc/engine.hip validate): continuous batching through 64 / 128
+    rows of a tiny-geometry fp8 engine with overlapped admission -- every request's tokens equal those of the same request served ALONE by
+    the same engine (a row's arithmetic does not depend on its 32-row group or its neighbours), as the bf16 engine's test of round 4 asserts."""
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.engine import Engine
+    from socioreasoner_amd.serving import ContinuousBatcher, Request
+    geom = geometry_tiny()
+    e = Engine(geom, max_patches=1024, max_prefill_tokens=64 * B, max_batch=B, max_ctx=128, max_new_tokens=24, kv_slots=2 * B, lm_fp8=fp8)
+    e.load_synthetic_weights(seed=0)
+    rng = np.random.default_rng(B)
+    n_req = 2 * B + 5
+    ids, pos = _prompts(rng, n_req)
+    max_new = [int(rng.integers(3, 24)) for _ in range(n_req)]
+    mk = lambda i: Request(ids=ids[i], pos3=pos[i], max_new=max_new[i], tag=i)
+    cb = ContinuousBatcher(e, eos=[], pad_id=0, steps_per_poll=4, overlap=True)
+    got = cb.run([mk(i) for i in range(n_req)])
+    assert cb.stats["admitted"] == n_req
+    for i in list(range(0, n_req, 9)) + [n_req - 1]:
+        c1 = ContinuousBatcher(e, eos=[], pad_id=0, steps_per_poll=4)
+        t = c1.run([mk(i)])[0]
+        assert got[i] == t and len(t) == max_new[i], (i, got[i][:6], t[:6])
+    e.close()

@@ -48,7 +48,7 @@ trace() {   # trace <name> <bench args...>: kernel trace + stats summary
 for stage in "$@"; do
   echo "================ stage $stage ($(date +%T))"
   case $stage in
-    tests5) timeout 1500 python -m pytest tests/test_gpu_round5.py -x -q -m gpu 2>&1 | tail -15 ;;
+    tests5) timeout 1500 python -m pytest tests/test_gpu_round5.py -q -m gpu 2>&1 | tail -15 ;;
     suite)  timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 ;;
     gemm_f32) timeout 600 python tools/bench_gemm_f32.py | tee gpurun_out/r05_gemm_f32_split.jsonl ;;
     sam2bench) timeout 900 python tools/bench_sam2_modes.py | tee gpurun_out/r05_sam2_modes.json ;;
