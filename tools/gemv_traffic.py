@@ -8,11 +8,24 @@ import sys
 fetch, write, out = (json.load(open(p)) for p in sys.argv[1:3]), None, sys.argv[3]
 fetch = list(fetch)
 fetch, write = fetch[0], fetch[1]
+FP8 = len(sys.argv) > 4 and sys.argv[4] == "fp8"       # round 5: the fp8 image of the layer linears (1 byte per weight), tools/probe_r2.py gemv fp8
 H, I, V = 2048, 11008, 151936
-ALGO = {"gate/up": 2 * I * H * 2, "down": H * I * 2, "lm_head": V * H * 2}
+ALGO = {"gate/up": 2 * I * H * (1 if FP8 else 2), "down": H * I * (1 if FP8 else 2), "lm_head": V * H * 2}
 
 
 def kind(name):                # kernel symbol -> (launch, batch) by the template arguments the decode path dispatches
+    if FP8:                    # k_gemv<MODE, MT, KP = 4, STAGE, 4, F8 = true>: MT 2 = 17..32 rows, MT 1 = <= 16 rows
+        if "Lb1EEEv8GemvArgs" not in name:
+            return None, None
+        if "k_gemvILi1ELi2E" in name:
+            return "gate/up", 32
+        if "k_gemvILi0ELi2E" in name:
+            return "down", 32
+        if "k_gemvILi1ELi1E" in name:
+            return "gate/up", 1
+        if "k_gemvILi0ELi1E" in name:
+            return "down", 1
+        return None, None
     if "k_gemv32ILi2E" in name or "k_gemv32<2" in name:
         return "lm_head", 32
     if "k_gemv32ILi0E" in name or "k_gemv32<0" in name:
@@ -40,7 +53,7 @@ for name, c in fetch.items():
                  "avg_us_under_pmc": round(c["FETCH_SIZE"]["avg_us"], 1)}
     tot[B][0] += rd
     tot[B][1] += ALGO[launch]
-json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python tools/probe_r2.py gemv (separate passes: the script that wrote this file -- tools/gpu_r4_profiles.sh in round 4); "
+json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python tools/probe_r2.py gemv (separate passes: the script that wrote this file -- tools/gpu_lease.sh pmc_gemv in round 5); "
                      "counter summed over its instances per dispatch, averaged over the dispatches (tools/rocpd_pmc.py, tools/gemv_traffic.py)",
            "correction": "FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 note in MI355X_MICROARCH.md).  traffic_over_algorithmic = HBM reads / weight bytes "
                          "(as in profiles/r02_pmc_gemv_traffic.json); the writes (float32 logits of the LM head, the down-projection's four float32 slabs) are listed beside it",

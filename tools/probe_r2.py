@@ -17,6 +17,23 @@ if what == "gemm":
         for _ in range(4):
             assert L.sr_op_gemm(P(a), K, P(w), M, N, K, P(out), ldo, None, P(out) if epi == 1 else None, None, epi | tiled | 0x200, s) == 0
         torch.cuda.synchronize()
+elif len(sys.argv) > 2 and sys.argv[2] == "fp8":
+    # round 5: the fp8 weight stream of the same launches (BASELINE.json configs[4]; the LM head stays bf16): gate/up and the down-projection at 32 rows and at 1
+    H, I = 2048, 11008
+    g8 = torch.randint(0, 120, (2 * I * H,), dtype=torch.uint8, device="cuda")
+    d8 = torch.randint(0, 120, (H * I,), dtype=torch.uint8, device="cuda")
+    sc = torch.ones(2 * I, device="cuda")
+    for B in (32, 1):
+        XT, OT, ks = (0x800, 0x1000, 4) if B > 4 else (0, 0, 2)
+        x = torch.randn(32, I, device="cuda").to(torch.bfloat16)
+        act = torch.zeros(32, I, dtype=torch.bfloat16, device="cuda")
+        part = torch.zeros(4, B, H, device="cuda")
+        nw = torch.ones(H, dtype=torch.bfloat16, device="cuda")
+        eps = C.c_float(1e-6)
+        for _ in range(5):
+            assert L.sr_op_gemv_f8(P(x), H, P(g8), P(sc), B, 2 * I, H, P(act), I, 1 | XT | OT, None, P(nw) if B <= 4 else None, eps, 1, s) == 0     # 45.1 MB
+            assert L.sr_op_gemv_f8(P(act), I, P(d8), P(sc), B, H, I, P(part), H, 0 | XT, None, None, eps, ks, s) == 0                                # 22.5 MB
+        torch.cuda.synchronize()
 else:
     H, I, V = 2048, 11008, 151936
     wg = (torch.randn(2 * I, H, device="cuda") * 0.02).to(torch.bfloat16)
