@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sam", action="store_true", help="skip the SAM2 (seg_infer) timing")
     ap.add_argument("--no-more-rows", action="store_true", help="skip the 64- and 128-row points (child processes)")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the two-stage pipeline timing with SAM2 at work (a child process)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="BASELINE.json configs[4] weights: LM decoder linears fp8 e4m3, per-channel scale")
     ap.add_argument("--fp8-mx", action="store_true", help="--fp8 plus MX fp8 activations in the prefill linears (fp8 x fp8 block-scaled MFMA, lm_weight_dtype 2)")
@@ -198,7 +199,7 @@ def main():
             if phase_ms is not None:
                 for k, v in cb.phase_ms().items():
                     phase_ms[k] = phase_ms.get(k, 0.0) + v
-                for k in ("admitted", "staged_shared", "steps", "steps_shared"):
+                for k in ("admitted", "staged_shared", "steps", "steps_shared", "rounds", "host_ms", "poll_wait_ms"):
                     sched[k] = sched.get(k, 0) + cb.stats[k]
                 shares.extend(cb.stats["shares"])
                 phase_ms["raster"] += sum(a.elapsed_time(b_) for a, b_ in spans)
@@ -398,14 +399,33 @@ def main():
             return dict(t_, tiles_per_s_4_objects=round(1e3 / t_["tile_ms_4_objects"], 2), tiles_per_s_4_objects_batched=round(8e3 / t_["tiles8_ms_4_objects"], 2))
         # Hiera-L encoder: 1.57 TFLOP of Linear layers + 0.21 TFLOP of attention per 1024 x 1024 input
         f32 = sam_mode(torch.float32)
-        f32["dtype"] = "float32 (the reference's precision: seg_infer's default; v_mfma_f32_32x32x2_f32 / 16x16x4_f32, peak 157 TF/s)"
-        f32["encoder_mfma_f32_frac_batched"] = round(1.78e12 * 8 / (f32["set_images_8_ms"] * 1e-3) / 157.3e12, 4)
+        f32["dtype"] = ("float32 (the reference's precision: seg_infer's default).  Round 5: the Linear layers run on the bf16 matrix pipe from an exact three-term bf16 split of "
+                        "both operands (six partial products, float32 accumulation: csrc/sam_f32.hip k_gemm_f32s); attention on v_mfma_f32_16x16x4_f32")
+        f32["encoder_TFLOPs_batched"] = round(1.78e12 * 8 / (f32["set_images_8_ms"] * 1e-3) / 1e12, 1)
+        f32["encoder_vs_f32_mfma_peak_157TF"] = round(1.78e12 * 8 / (f32["set_images_8_ms"] * 1e-3) / 157.3e12, 4)
         b16 = sam_mode(torch.bfloat16)
         b16["dtype"] = "bf16 storage / float32 accumulation (opt-in: sam2_compute_dtype bf16; masks differ from float32's inside the bf16 noise band)"
         sam = {"workload": "SAM2 Hiera-L (216.9 M parameters, random init), 756 x 756 tiles -> 1024 x 1024 input, box + click prompts, 3 masks + scores per object, "
                            "best mask resized to 756 x 756 and OR-ed on the device; tile_ms = one tile and one object at a time (the reference's loop), "
                            "tiles8_ms = 8 tiles per encoder pass and a tile's 4 objects per decoder pass (what seg_infer runs)",
                "float32": f32, "bf16": b16}
+
+    # ---- the reference's own two-stage pipeline (examples/infer/rlvr_megatron.yaml through SocioSegInferPipeline: two generate calls on a
+    # (map, satellite) pair each, two segment calls, four PNGs + two text files per sample) with SAM2 DOING WORK: random weights emit no <answer>,
+    # so tools/run_example_small.py scripts the decoded answers (4 objects per stage; the LM still generates its 128 tokens per stage on the engine).
+    # A child process (own engines), after this process's side measurements; phase wall times from SocioSegInferPipeline.timing.
+    pipeline = None
+    if rank == 0 and world == 1 and continuous and B == 32 and args.tile == 448 and not args.pair and not args.fp8 and not args.no_latency and not args.no_pipeline:
+        import subprocess
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env.update(SCRIPTED_OBJECTS="4", SOCIOSEG_NUM_SAMPLES="64", NEW_TOKENS=str(N_NEW), OUT="/tmp/sr_bench_pipeline_out")
+        try:
+            r_ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_example_small.py")], capture_output=True, text=True, timeout=900, env=env)
+            pipeline = json.loads([ln for ln in r_.stdout.splitlines() if ln.startswith("{")][-1])
+            pipeline["workload"] = ("SocioSegInferPipeline.run() on 64 synthetic SocioSeg samples, the shipped YAML (3B LM + SAM2 Hiera-L float32, synthetic weights), 128 new tokens per "
+                                    "stage, decoded answers scripted to 4 objects per stage so that seg_infer encodes every satellite image and decodes 4 prompts per stage and sample")
+        except Exception as e_:  # noqa: BLE001
+            pipeline = {"error": f"{type(e_).__name__}: {e_}"[:300]}
 
     # ---- configs[1] beside it: one tile at a time on the same engine (batch-1 kernels, hipGraph decode), rank 0 only
     latency = None
@@ -521,18 +541,17 @@ def main():
         # HBM traffic per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950 note):
         # measured ratio traffic / algorithmic bytes of this kernel family x the algorithmic bytes of one launch
         traffic, pmc, insitu = None, None, None
-        PMC_FILE = "r04_pmc_gemv_traffic.json"
+        PMC_FILE = "r05_pmc_gemv_traffic_fp8.json" if args.fp8 else "r05_pmc_gemv_traffic_bf16.json"
         try:     # rocprofv3 kernel-trace average of the same kernels inside the full decode step (committed summary of the static-batch trace)
-            insitu = json.load(open(os.path.join(ROOT, "profiles", "r04_gemv_in_situ.json")))["batch32" if B > 4 else "batch1"] if B in (1, 32) else None
+            insitu = json.load(open(os.path.join(ROOT, "profiles", "r05_gemv_in_situ.json")))["batch32" if B > 4 else "batch1"] if (B in (1, 32) and not args.fp8) else None
         except Exception:  # noqa: BLE001
             pass
-        try:     # profiles/r04_pmc_gemv_traffic.json: FETCH_SIZE / WRITE_SIZE passes of this kernel family at batch 32 and batch 1 (tools/gpu_r4_profiles.sh)
+        try:     # FETCH_SIZE / WRITE_SIZE passes of this kernel family at 32 rows and at 1 (tools/gpu_lease.sh pmc_gemv; round 5: also on the fp8 stream,
+                 # whose file covers gate/up + the down-projection -- the layer linears that carry 88 % of the fp8 bytes; the bf16 LM head is in the other file)
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             traffic = round(pmc["traffic_over_algorithmic_weighted_batch32" if B > 4 else "traffic_over_algorithmic_weighted_batch1"] * bytes_per_launch)
         except Exception:  # noqa: BLE001
             pass
-        if args.fp8:
-            traffic = None       # the PMC calibration under profiles/ was taken on the bf16 stream
         roof = {"bound": "hbm", "kernel": f"k_gemv family at batch {B} (decode weight stream, all LM linears + LM head)" + (" [fp8 layer linears]" if args.fp8 else ""),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": (f"profiles/{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel family): measured "
@@ -555,7 +574,8 @@ def main():
         per = (sched["admitted"] - sched["staged_shared"]) / B if continuous else args.steps
         phases = {k: round(v / args.steps, 3) for k, v in phase_ms.items()}
         if continuous:
-            phases["scheduler"] = dict({k: v // args.steps for k, v in sched.items()}, overlap=overlap, admit_cus_per_se=shares,
+            phases["scheduler"] = dict({k: v // args.steps for k, v in sched.items() if k not in ("host_ms", "poll_wait_ms")}, overlap=overlap, admit_cus_per_se=shares,
+                                       host_ms_per_round=round(sched["host_ms"] / max(sched["rounds"], 1), 3), poll_wait_ms_per_round=round(sched["poll_wait_ms"] / max(sched["rounds"], 1), 3),
                                        decode_step_ms_shared=round(phase_ms.get("decode_shared", 0.0) / max(sched["steps_shared"], 1), 4),
                                        note=f"spans named *_shared ran concurrently on disjoint CU sets (admission share of the CUs: {args.admit_cus} of 8 per shader engine): they do not add up to ms_per_step" if overlap else None)
         vit_ms, pre_ms = phase_ms["vit"] / per, phase_ms["prefill"] / per
@@ -601,7 +621,7 @@ def main():
                        "parallelism": f"dp{world}", "decode": "hipGraph" if not args.no_graph else "eager",
                        "exchange": dict(exchange, payload="float32 logits all-gather per decode step (verification mode)" if args.gather_logits
                                         else "one all-gather of 1 KB result rows per tile and step")},
-            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_torch_bf16": cpu_hf, "phase_ms_per_step": phases, "static_batch": static_ref, "drained_step": drained, "more_rows_per_gpu": more_rows, "ragged": ragged, "sam2": sam, "latency_b1": latency,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_torch_bf16": cpu_hf, "phase_ms_per_step": phases, "static_batch": static_ref, "drained_step": drained, "more_rows_per_gpu": more_rows, "ragged": ragged, "sam2": sam, "pipeline_two_stage_with_sam2": pipeline, "latency_b1": latency,
             "weights_load_s": round(load_s, 1), "workspace_GB": round(eng.workspace_bytes / 1e9, 2),
             "result_checksum": int(res.sum().item()),
         }

@@ -63,7 +63,9 @@ class ContinuousBatcher:
         self.free = deque(range(engine.cfg.max_batch))
         self.active: Dict[int, Request] = {}
         self.pending: deque = deque()
-        self.stats = {"admitted": 0, "steps": 0, "admissions": 0, "staged_shared": 0, "steps_shared": 0, "shares": []}
+        # rounds / host_ms / poll_wait_ms (round 5): scheduling rounds, host time spent in them OUTSIDE the poll's wait for the device, and that wait --
+        # with N ranks on one node a flat 1 -> N curve shows here as host_ms per round growing with N (host contention) rather than poll_wait_ms
+        self.stats = {"admitted": 0, "steps": 0, "admissions": 0, "staged_shared": 0, "steps_shared": 0, "shares": [], "rounds": 0, "host_ms": 0.0, "poll_wait_ms": 0.0}
         engine.rows_begin()
         if sampling:
             engine.rows_sampling(float(sampling["temperature"]), int(sampling["top_k"]), float(sampling.get("top_p", 1.0)), int(sampling.get("seed", 0)))
@@ -318,7 +320,7 @@ class ContinuousBatcher:
         if self.staged is None and self.pending and self.free_slots:
             self._stage()                              # the host side of the next admission is prepared while the chunk above runs
         with torch.cuda.stream(s):
-            fin, cnt = self.engine.rows_poll()
+            fin, cnt = self._poll()
             self._cnt_last = {row: int(cnt[row]) for row in self.active}
             if self._auto:          # (the poll synchronised the decode stream: finished measurements can be read without waiting)
                 if self._cal_step is not None and self._cal_step[1].query():
@@ -336,8 +338,27 @@ class ContinuousBatcher:
                 self.free_slots.append(self.row_slot.pop(row))
                 on_complete(req, toks)
 
+    def _poll(self):
+        import time
+        t0 = time.perf_counter()
+        out = self.engine.rows_poll()
+        self._poll_wait += time.perf_counter() - t0
+        return out
+
     def pump(self, on_complete: Callable[[Request, List[int]], None]):
         """One scheduling round: admit what fits, decode `steps_per_poll` tokens, release finished rows."""
+        import time
+        t0 = time.perf_counter()
+        self._poll_wait = 0.0
+        try:
+            return self._pump(on_complete)
+        finally:
+            dt = time.perf_counter() - t0
+            self.stats["rounds"] += 1
+            self.stats["poll_wait_ms"] += self._poll_wait * 1e3
+            self.stats["host_ms"] += (dt - self._poll_wait) * 1e3
+
+    def _pump(self, on_complete):
         if self.overlap:
             return self._pump_overlap(on_complete)
         self._admit()
@@ -347,7 +368,7 @@ class ContinuousBatcher:
         self.engine.rows_step(self.steps_per_poll, self.eos, self.pad_id)
         self._span("decode", t0, self._mark())
         self.stats["steps"] += self.steps_per_poll
-        fin, cnt = self.engine.rows_poll()
+        fin, cnt = self._poll()
         for row in [r for r in self.active if fin[r]]:
             req = self.active.pop(row)
             toks = self.engine.row_tokens(row, int(cnt[row])).cpu().tolist()

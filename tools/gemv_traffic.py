@@ -14,16 +14,17 @@ ALGO = {"gate/up": 2 * I * H * (1 if FP8 else 2), "down": H * I * (1 if FP8 else
 
 
 def kind(name):                # kernel symbol -> (launch, batch) by the template arguments the decode path dispatches
-    if FP8:                    # k_gemv<MODE, MT, KP = 4, STAGE, 4, F8 = true>: MT 2 = 17..32 rows, MT 1 = <= 16 rows
-        if "Lb1EEEv8GemvArgs" not in name:
+    if FP8:                    # k_gemv<MODE, MT, KP = 4, STAGE, 4, F8 = true> (MT 2 = 17..32 rows, MT 1 = <= 16 rows); k_gemv32g<0, 4, 1, true> = the 4-slab down-projection at 17..32 rows
+        n = name.replace(" ", "")
+        if not (n.endswith(",true>") or "Lb1EEEv8GemvArgs" in n):
             return None, None
-        if "k_gemvILi1ELi2E" in name:
-            return "gate/up", 32
-        if "k_gemvILi0ELi2E" in name:
+        if "k_gemv32g<0,4,1" in n or "k_gemv32gILi0ELi4ELi1E" in n or "k_gemv<0,2," in n or "k_gemvILi0ELi2E" in n:
             return "down", 32
-        if "k_gemvILi1ELi1E" in name:
+        if "k_gemv<1,2," in n or "k_gemvILi1ELi2E" in n:
+            return "gate/up", 32
+        if "k_gemv<1,1," in n or "k_gemvILi1ELi1E" in n:
             return "gate/up", 1
-        if "k_gemvILi0ELi1E" in name:
+        if "k_gemv<0,1," in n or "k_gemvILi0ELi1E" in n:
             return "down", 1
         return None, None
     if "k_gemv32ILi2E" in name or "k_gemv32<2" in name:

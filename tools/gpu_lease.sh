@@ -51,6 +51,8 @@ for stage in "$@"; do
     tests5) timeout 1500 python -m pytest tests/test_gpu_round5.py -q -m gpu 2>&1 | tail -15 ;;
     suite)  timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 ;;
     fp8tests) timeout 1500 python -m pytest tests -q -m gpu -k "f8 or fp8" 2>&1 | tail -8 ;;
+    pipeline) for dt in float32 bf16; do SR_SAM2_DTYPE=$dt SCRIPTED_OBJECTS=4 OUT=/tmp/example_out SOCIOSEG_NUM_SAMPLES=64 timeout 900 python tools/run_example_small.py 2> gpurun_out/r05_pipeline_$dt.err | tail -1 | tee gpurun_out/r05_pipeline_$dt.json | cut -c1-900; done
+              SCRIPTED_OBJECTS=0 OUT=/tmp/example_out SOCIOSEG_NUM_SAMPLES=64 timeout 900 python tools/run_example_small.py 2>/dev/null | tail -1 | tee gpurun_out/r05_pipeline_noanswers.json | cut -c1-600 ;;
     gemm_f32) timeout 600 python tools/bench_gemm_f32.py | tee gpurun_out/r05_gemm_f32_split.jsonl ;;
     sam2bench) timeout 900 python tools/bench_sam2_modes.py | tee gpurun_out/r05_sam2_modes.json ;;
     sam2tests) timeout 1500 python -m pytest tests/test_gpu_sam2.py tests/test_gpu_round4.py -x -q -m gpu -k "sam2 or gemm_f32 or seg_infer" 2>&1 | tail -8 ;;
