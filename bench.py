@@ -65,6 +65,9 @@ def self_launch(args):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # N schedulers + N poll loops share this host: give every rank its share of the cores for its intra-op pool (torch.distributed.run would set
+    # OMP_NUM_THREADS=1; the collator and the PNG writers of the pipeline use a few threads), never more than 8
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or args.gpus) // args.gpus))))
     return subprocess.call(cmd, env=env)
 
 
@@ -123,6 +126,8 @@ def main():
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
         os.environ["SR_RCCL_LOG"] = os.environ["NCCL_DEBUG_FILE"] = f"/tmp/sr_rccl_{os.getpid()}_rank{os.environ.get('RANK', '0')}.log"
     rank, world, local = dp.init_distributed()      # RCCL when ranks > 1 (gloo only if SR_DIST_BACKEND=gloo asks for it)
+    if world > 1 and os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        torch.set_num_threads(max(1, int(os.environ["OMP_NUM_THREADS"])))      # the per-rank share of the host cores (self_launch)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s): launch `python bench.py --gpus N` (self-launching) or "
                          f"torchrun --nproc-per-node N bench.py --gpus N")
@@ -624,6 +629,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_torch_bf16": cpu_hf, "phase_ms_per_step": phases, "static_batch": static_ref, "drained_step": drained, "more_rows_per_gpu": more_rows, "ragged": ragged, "sam2": sam, "pipeline_two_stage_with_sam2": pipeline, "latency_b1": latency,
             "weights_load_s": round(load_s, 1), "workspace_GB": round(eng.workspace_bytes / 1e9, 2),
             "result_checksum": int(res.sum().item()),
+            "result_row_checksums": [int(v) for v in res.sum(dim=1).tolist()] if res.shape[0] <= 64 else None,      # one per tile of the last step, in tile order over all ranks
+            "host_threads_per_rank": torch.get_num_threads(),
         }
         def clean(o):       # NaN (fractions that are not quoted for this workload) -> null
             if isinstance(o, float) and o != o:

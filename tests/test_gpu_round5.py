@@ -319,3 +319,27 @@ def test_fp8_weights_above_32_rows_tiny_engine(B, fp8):
         t = c1.run([mk(i)])[0]
         assert got[i] == t and len(t) == max_new[i], (i, got[i][:6], t[:6])
     e.close()
+
+
+# ------------------------------------------------------------------------------------------------ multi-GPU readiness without the node
+def test_bench_self_launches_8_ranks_and_every_tile_equals_the_single_process_run():
+    """`python bench.py --gpus 8` with SR_DIST_BACKEND=gloo (8 ranks sharing this box's one device, host-staged exchange -- the development
+    layout; on an 8-GPU node the same command runs one rank per GPU over RCCL): 8 schedulers + 8 poll loops + 8 engines on one host.  The line
+    says n_gpus 8 / exchange.nranks 8 / dp8, every rank served its own tile (tile = rank), and the per-tile result rows (128 greedy tokens + the
+    two IoU counts) equal, tile by tile, those of ONE process serving the same 8 tiles through one batch row.  DP contract:
+    /root/reference/roll/distributed/scheduler/decorator.py:106-181 (dispatch_dp_mp_compute), protocol.py:550-617 (chunk / concat)."""
+    import subprocess
+    import sys
+    common = ["--batch", "1", "--continuous", "--no-overlap", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-latency", "--no-sam"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SR_DIST_BACKEND")}
+    r8 = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--waves", "1"] + common, cwd=ROOT, env=dict(env, SR_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=1500)
+    assert r8.returncode == 0, r8.stdout[-2000:] + r8.stderr[-3000:]
+    l8 = json.loads([ln for ln in r8.stdout.splitlines() if ln.startswith("{")][-1])
+    assert l8["n_gpus"] == 8 and l8["config"]["exchange"]["nranks"] == 8 and l8["config"]["parallelism"] == "dp8"
+    assert l8["host_threads_per_rank"] <= 8
+    r1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--waves", "8"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
+    l1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
+    assert len(l8["result_row_checksums"]) == 8 and l8["result_row_checksums"] == l1["result_row_checksums"], (l8["result_row_checksums"], l1["result_row_checksums"])
+    _record("r05_multi_rank.json", "8_gloo_ranks_one_device", {"tiles_per_s": l8["value"], "ms_per_step": l8["ms_per_step"], "host_threads_per_rank": l8["host_threads_per_rank"],
+                                                                "scheduler": l8["phase_ms_per_step"].get("scheduler"), "single_process_tiles_per_s": l1["value"]})

@@ -48,7 +48,7 @@ trace() {   # trace <name> <bench args...>: kernel trace + stats summary
 for stage in "$@"; do
   echo "================ stage $stage ($(date +%T))"
   case $stage in
-    tests5) timeout 1500 python -m pytest tests/test_gpu_round5.py -q -m gpu 2>&1 | tail -15 ;;
+    tests5) timeout 2400 python -m pytest tests/test_gpu_round5.py -q -m gpu ${TESTS5_K:+-k "$TESTS5_K"} 2>&1 | tail -15 ;;
     suite)  timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 ;;
     fp8tests) timeout 1500 python -m pytest tests -q -m gpu -k "f8 or fp8" 2>&1 | tail -8 ;;
     pipeline) for dt in float32 bf16; do SR_SAM2_DTYPE=$dt SCRIPTED_OBJECTS=4 OUT=/tmp/example_out SOCIOSEG_NUM_SAMPLES=64 timeout 900 python tools/run_example_small.py 2> gpurun_out/r05_pipeline_$dt.err | tail -1 | tee gpurun_out/r05_pipeline_$dt.json | cut -c1-900; done
