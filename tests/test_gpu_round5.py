@@ -343,3 +343,48 @@ def test_bench_self_launches_8_ranks_and_every_tile_equals_the_single_process_ru
     assert len(l8["result_row_checksums"]) == 8 and l8["result_row_checksums"] == l1["result_row_checksums"], (l8["result_row_checksums"], l1["result_row_checksums"])
     _record("r05_multi_rank.json", "8_gloo_ranks_one_device", {"tiles_per_s": l8["value"], "ms_per_step": l8["ms_per_step"], "host_threads_per_rank": l8["host_threads_per_rank"],
                                                                 "scheduler": l8["phase_ms_per_step"].get("scheduler"), "single_process_tiles_per_s": l1["value"]})
+
+
+# ------------------------------------------------------------------------------------------------ SAM2 float32 vs HF float32: more images, weights and prompts
+def test_sam2_float32_masks_on_more_images_weights_and_multi_point_prompts(golden_dir):
+    """VERDICT round 4 (weak #2): the exactness of the float32 SAM2 path was pinned on ONE image, ONE set of weights and three prompts.
+    tests/golden/sam2_more.npz (tools/make_golden_sam2_more.py: HF Sam2Model float32 at Hiera-L) adds two images, a second set of synthetic
+    weights and six prompts -- three clicks of mixed labels, box + three clicks, a small box in the image corner, a negative click in a box,
+    four clicks, a box at the lower right edge.  Same bar as test_sam2_float32_mode_equals_hf_float32: IoU scores to 1e-4, the same best
+    mask, its low-resolution logits to 1e-3, the 756 x 756 mask EXACT outside |logit| < 1e-3 and at most 10 pixels different inside."""
+    from oracle import sam2_ref as S
+    from socioreasoner_amd import sam2, synthetic
+    g = np.load(os.path.join(golden_dir, "sam2_more.npz"))
+    og = S.geometry_large()
+    sg = sam2.Sam2Geometry(**{k: getattr(og, k) for k in sam2.Sam2Geometry.__dataclass_fields__})
+    res, fails = {}, []
+    for ci in range(int(g["n_cases"][0])):
+        e = sam2.Sam2Engine(sg, dtype=torch.float32)
+        e.load_state_dict(S.synthetic_weights(og, seed=int(g[f"c{ci}_weight_seed"][0])))
+        e.set_image(torch.from_numpy(synthetic.tile_pixels(int(g[f"c{ci}_img_seed"][0]), 756, 756)).cuda())
+        for p in range(int(g[f"c{ci}_n_prompts"][0])):
+            k = f"c{ci}_p{p}"
+            box = g[k + "_box"].tolist() or None
+            pts = g[k + "_pts"]
+            labels = g[k + "_labels"] if len(pts) else None
+            logits, scores, low = e.predict(pts if len(pts) else None, labels, box, return_logits=True)
+            ref_iou, best = g[k + "_iou"], int(g[k + "_best"][0])
+            want = torch.from_numpy(np.unpackbits(g[k + "_mask_bits"])[: 756 * 756].reshape(756, 756).astype(bool))
+            mine = torch.from_numpy(logits[best] > 0)
+            d_low = float(np.abs(np.asarray(low)[best] - g[k + "_low_best"]).max())
+            # HF's resized logits of the best mask (the band is defined on them): from the stored low-resolution logits, the predictor's bilinear resize
+            ref3 = torch.zeros(3, *g[k + "_low_best"].shape)
+            ref3[best] = torch.from_numpy(g[k + "_low_best"])
+            _, _, up = S.postprocess(ref3, torch.from_numpy(ref_iou), (756, 756))
+            clear = up[best].abs() >= 1e-3
+            n_diff = int((mine != want).sum())
+            res[k] = {"iou_max_err": float(np.abs(scores - ref_iou).max()), "low_logits_max_err_best_mask": d_low, "mask_pixels_differing_from_hf_float32": n_diff,
+                      "pixels_with_abs_logit_below_1e-3": int((~clear).sum()), "mask_area": int(want.sum())}
+            for ok, what in ((np.abs(scores - ref_iou).max() <= 1e-4, "iou"), (int(np.argmax(scores)) == best, "best mask"), (d_low <= 1e-3, "low-resolution logits"),
+                             (bool((mine == want)[clear].all()), "mask differs outside the 1e-3 band"), (n_diff <= 10, "more than 10 pixels differ inside the band")):
+                if not ok:
+                    fails.append((k, what, res[k]))
+        del e
+        torch.cuda.empty_cache()
+    _record("r05_sam2_more_parity.json", "hiera_large_float32", res)
+    assert not fails, fails
