@@ -137,7 +137,8 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
 int sr_finalize_weights(sr_engine* e, void* stream);
 
 /* Sampled decode on the device -- replaces vllm.LLM.generate with the SamplingParams of vllm_strategy.py:289-309
- * (temperature > 0, 1 <= top_k <= 1024, 0 < top_p <= 1, repetition_penalty): as sr_decode, but every token is drawn by
+ * (temperature > 0, top_k <= 1024 with top_k <= 0 = no top-k bound [round 5: nucleus sampling over the whole vocabulary, k_sample_full], 0 < top_p <= 1,
+ * repetition_penalty): as sr_decode, but every token is drawn by
  * k_sample (exact top-k, temperature softmax, top-p, one categorical draw with a counter-based RNG keyed by
  * (seed, sequence, step)); with use_graph one captured graph per step includes the draw.  The stream of random numbers is
  * this library's own (vLLM's cannot be reproduced): top_k = 1 equals greedy decode exactly, everything else is pinned
@@ -166,7 +167,7 @@ int sr_decode_step(sr_engine* e, const int64_t* dev_last_ids, int B, float* dev_
  *                   nothing more is appended to their KV slot); the next sr_rows_poll reports them finished and the caller may
  *                   re-use row and slot at once -- what vLLM's abort_request does for the reference's ABORT command
  *                   (/root/reference/roll/distributed/strategy/vllm_strategy.py:188-193).
- *   sr_rows_sampling : (optional, after sr_rows_begin) all rows draw their tokens with k_sample (temperature > 0, 1 <= top_k <= 1024,
+ *   sr_rows_sampling : (optional, after sr_rows_begin) all rows draw their tokens with k_sample (temperature > 0, top_k <= 1024 -- <= 0: no top-k bound --,
  *                   0 < top_p <= 1) instead of the greedy arg-max; temperature 0 switches back. */
 int sr_rows_begin(sr_engine* e, void* stream);
 int sr_rows_sampling(sr_engine* e, float temperature, int top_k, float top_p, uint32_t seed);

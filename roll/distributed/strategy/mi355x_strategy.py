@@ -8,8 +8,8 @@ and of the raster half of ``seg_infer`` (roll/distributed/strategy/seg_strategy.
   out: LongTensor [B * n, P + max_response_len_in_batch]: the prompt columns verbatim, responses right-padded with pad.
 Greedy requests (temperature 0 or top_k 1 -- BASELINE.json's configurations) run the whole decode loop on the device
 (sr_decode, one hipGraph replay per token).  Sampling requests (the shipped YAML's temperature / top_p / top_k /
-repetition_penalty, vllm_strategy.py:289-309) also stay on the device when 1 <= top_k <= 1024 (sr_decode_sample: the draw
-is a kernel inside the captured step); without a top-k bound they run token by token through sr_decode_step with the draw
+repetition_penalty, vllm_strategy.py:289-309) also stay on the device when top_k <= 1024 -- including top_k <= 0, vLLM's "no bound" (sr_decode_sample: the draw
+is a kernel inside the captured step); only a top-k bound above 1024 still runs token by token through sr_decode_step with the draw
 made by socioreasoner_amd.sampling on the device-resident logits.
 """
 from __future__ import annotations
@@ -314,7 +314,9 @@ class Mi355xStrategy(InferenceStrategy):
             prepared.append(self._prepare(ids_i, imgs))
         i = 0
         tk = gc.get("top_k", -1)
-        on_device = not greedy and tk is not None and 1 <= int(tk) <= 1024 and float(gc.get("temperature", 1.0)) > 1e-5
+        # (round 5: top_k <= 0 / None = vLLM's "no top-k bound" is sampled on the device too -- k_sample_full, nucleus sampling over the whole vocabulary)
+        tk = -1 if tk is None else int(tk)
+        on_device = not greedy and tk <= 1024 and float(gc.get("temperature", 1.0)) > 1e-5
         rp1 = float(gc.get("repetition_penalty", 1.0) or 1.0) == 1.0
         if greedy or (on_device and rp1 and n == 1):
             # the stages are decoupled: the scheduler admits the prompts in capacity-sized groups (ViT + prefill into free KV rows)
@@ -429,7 +431,8 @@ class Mi355xStrategy(InferenceStrategy):
                 rp1 = float(gc.get("repetition_penalty", 1.0) or 1.0) == 1.0
                 greedy = sampling.is_greedy(gc)
                 tk = gc.get("top_k", -1)
-                dev_sampling = not greedy and tk is not None and 1 <= int(tk) <= 1024 and float(gc.get("temperature", 1.0)) > 1e-5
+                tk = -1 if tk is None else int(tk)
+                dev_sampling = not greedy and tk <= 1024 and float(gc.get("temperature", 1.0)) > 1e-5
                 rows_ok = hasattr(self.engine, "rows_begin") and rp1 and (greedy or dev_sampling) and int(gc.get("num_return_sequences", 1) or 1) == 1
                 if not rows_ok:
                     sampled.append(req)

@@ -1235,8 +1235,8 @@ int sr_rows_begin(sr_engine* e, void* stream) {
 
 int sr_rows_sampling(sr_engine* e, float temperature, int top_k, float top_p, uint32_t seed) {
     if (!e || !e->rows_mode) return fail(e, -22, "sr_rows_sampling: call sr_rows_begin first");
-    if (temperature > 0.f && (top_k < 1 || top_k > 1024 || !(top_p > 0.f) || top_p > 1.f))
-        return fail(e, -22, "sr_rows_sampling: 1 <= top_k <= 1024 and 0 < top_p <= 1 required");
+    if (temperature > 0.f && (top_k > 1024 || !(top_p > 0.f) || top_p > 1.f))
+        return fail(e, -22, "sr_rows_sampling: top_k <= 1024 (<= 0: no top-k bound) and 0 < top_p <= 1 required");
     e->rows_temp = temperature > 0.f ? temperature : 0.f;
     e->rows_topk = top_k; e->rows_topp = top_p; e->rows_seed = seed; e->adm_count = 0;
     return 0;
@@ -1381,8 +1381,8 @@ int sr_decode_sample(sr_engine* e, int B, int max_new, const int32_t* host_eos, 
     if (e->rows_mode) return fail(e, -22, "sr_decode_sample: the engine is in continuous-batching mode");
     if (B < 1 || B != e->prefilled_B || max_new < 1 || max_new > c.max_new_tokens || n_eos < 0 || n_eos > 32)
         return fail(e, -22, "sr_decode_sample: B=%d (prefilled %d) max_new=%d n_eos=%d out of range", B, e->prefilled_B, max_new, n_eos);
-    if (!(temperature > 0.f) || top_k < 1 || top_k > 1024 || !(top_p > 0.f) || top_p > 1.f || !(rep_penalty > 0.f))
-        return fail(e, -22, "sr_decode_sample: temperature > 0, 1 <= top_k <= 1024, 0 < top_p <= 1, repetition_penalty > 0 required");
+    if (!(temperature > 0.f) || top_k > 1024 || !(top_p > 0.f) || top_p > 1.f || !(rep_penalty > 0.f))
+        return fail(e, -22, "sr_decode_sample: temperature > 0, top_k <= 1024 (<= 0: no top-k bound), 0 < top_p <= 1, repetition_penalty > 0 required");
     if (e->h_ctx_hi + max_new > c.max_ctx)
         return fail(e, -22, "sr_decode_sample: context %d + %d new tokens exceeds max_ctx %d", e->h_ctx_hi, max_new, c.max_ctx);
     e->h_ctx_hi += max_new;

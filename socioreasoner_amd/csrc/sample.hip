@@ -246,6 +246,158 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// top_k <= 0: NO top-k bound (vLLM's top_k = -1, which /root/reference/roll/distributed/strategy/vllm_strategy.py:289-309 passes through when the
+// YAML does not set one) -- round 5; rounds 1-4 ran this case as a host loop over sr_decode_step.  Nucleus sampling over the whole vocabulary
+// without sorting it: with p_i = softmax(l_i / T), the kept set of the sorted definition above ("keep j while the mass in front of it is < top_p") is
+//     { i : M(key_i) < top_p },   M(t) = mass of the tokens with a key STRICTLY above t,
+// plus, among the tokens that tie at the smallest kept key tau, the lowest ids while the mass in front stays < top_p.  tau is found by the same
+// 12 + 12 + 8-bit radix descent as the top-k select, with histograms of MASS instead of counts -- in 2^-40 fixed point and 64-bit LDS atomics,
+// so the sums (and with them every decision) are independent of the order in which threads arrive.  The draw is one inverse-CDF pass in TOKEN-ID
+// order over the kept set (the distribution does not depend on the enumeration order): per-thread sums over contiguous id ranges, a fixed-order
+// scan over the 1024 threads, then the owning thread walks its range.
+constexpr int FX_SHIFT = 40;
+
+__global__ __launch_bounds__(NT) void k_sample_full(SampleArgs a) {
+    __shared__ unsigned long long mh[4096];        // mass histogram (fixed point)
+    __shared__ int ch[256];                        // count histogram of the last level (ties at tau)
+    __shared__ float s_red[16];
+    __shared__ unsigned long long s_u64[2];
+    __shared__ int s_i[4];
+    __shared__ float s_scan[NT];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = a.logits + (size_t)b * a.V;
+    const unsigned* seen = a.seen ? a.seen + (size_t)b * a.seen_words : nullptr;
+    auto adj = [&](int id) -> float {
+        float l = row[id];
+        if (seen && ((seen[id >> 5] >> (id & 31)) & 1u)) l = l > 0.f ? l / a.rep_penalty : l * a.rep_penalty;
+        return l;
+    };
+    // ---- max and partition function (fixed-order block reductions)
+    float mx = -INFINITY;
+    for (int i = tid; i < a.V; i += NT) mx = fmaxf(mx, adj(i));
+    mx = wave_max(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = s_red[0];
+    for (int w = 1; w < NT / 64; ++w) mx = fmaxf(mx, s_red[w]);
+    __syncthreads();
+    float z = 0.f;
+    for (int i = tid; i < a.V; i += NT) z += __expf((adj(i) - mx) * a.inv_temp);
+    z = wave_sum(z);
+    if (lane == 0) s_red[wave] = z;
+    __syncthreads();
+    float Z = 0.f;
+    for (int w = 0; w < NT / 64; ++w) Z += s_red[w];
+    const float inv_z = 1.0f / Z;
+    auto prob_fx = [&](float l) -> unsigned long long { return (unsigned long long)(__expf((l - mx) * a.inv_temp) * inv_z * (float)(1ull << FX_SHIFT)); };
+    const unsigned long long want = a.top_p >= 1.0f ? ~0ull : (unsigned long long)((double)a.top_p * (double)(1ull << FX_SHIFT));
+    // ---- radix descent on mass: tau = the smallest key whose strictly-above mass is < top_p
+    uint32_t prefix = 0;
+    unsigned long long above = 0;                   // mass of the keys above the current prefix range
+    const int shifts[3] = {20, 8, 0}, widths[3] = {12, 12, 8};
+#pragma unroll
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        const int nb = 1 << widths[lvl];
+        for (int i = tid; i < nb; i += NT) mh[i] = 0ull;
+        if (lvl == 2) for (int i = tid; i < 256; i += NT) ch[i] = 0;
+        __syncthreads();
+        const uint32_t himask = lvl == 0 ? 0u : (lvl == 1 ? 0xfff00000u : 0xffffff00u);
+        for (int i = tid; i < a.V; i += NT) {
+            const float l = adj(i);
+            const uint32_t k = fkey(l);
+            if ((k & himask) == prefix) {
+                atomicAdd(&mh[(k >> shifts[lvl]) & (nb - 1)], prob_fx(l));
+                if (lvl == 2) atomicAdd(&ch[k & 0xff], 1);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {      // bins from the top: the first bin whose inclusive mass reaches top_p holds tau (if none does -- rounding, top_p = 1 -- the lowest non-empty one)
+            unsigned long long run = above;
+            int bin = -1, last = 0;
+            for (int bb = nb - 1; bb >= 0; --bb) {
+                if (mh[bb] == 0ull && !(lvl == 2 && ch[bb])) continue;
+                last = bb;
+                if (run + mh[bb] >= want) { bin = bb; break; }
+                run += mh[bb];
+            }
+            if (bin < 0) { bin = last; run -= mh[last]; }
+            s_i[0] = bin;
+            s_u64[0] = run;
+        }
+        __syncthreads();
+        prefix |= (uint32_t)s_i[0] << shifts[lvl];
+        above = s_u64[0];
+        __syncthreads();
+    }
+    const uint32_t tau = prefix;
+    const int n_eq = ch[tau & 0xff];
+    // ties at tau: keep the r lowest ids, r = the smallest count with above + r p_tau >= top_p (at least one, at most all)
+    const unsigned long long p_tau = prob_fx(unkey(tau));
+    int r_keep = n_eq;
+    if (want != ~0ull && p_tau > 0ull && above < want) {
+        const unsigned long long need = want - above;
+        const unsigned long long r = (need + p_tau - 1) / p_tau;
+        if (r < (unsigned long long)n_eq) r_keep = (int)(r < 1 ? 1 : r);
+    }
+    // ---- inverse CDF in id order over the kept set.  Thread t owns ids [t * per, (t + 1) * per)
+    const int per = (a.V + NT - 1) / NT, i0 = tid * per, i1 = min(a.V, i0 + per);
+    float msum = 0.f;
+    int ties = 0;
+    for (int i = i0; i < i1; ++i) {
+        const uint32_t k = fkey(adj(i));
+        ties += k == tau;
+    }
+    // exclusive scan of the tie counts (fixed order) -> which ties of this range are among the first r_keep
+    s_scan[tid] = (float)ties;
+    __syncthreads();
+    int ties_before = 0;
+    for (int t = 0; t < tid; ++t) ties_before += (int)s_scan[t];
+    __syncthreads();
+    int seen_ties = ties_before;
+    for (int i = i0; i < i1; ++i) {
+        const float l = adj(i);
+        const uint32_t k = fkey(l);
+        const bool keep = k > tau || (k == tau && seen_ties++ < r_keep);
+        if (keep) msum += __expf((l - mx) * a.inv_temp) * inv_z;
+    }
+    s_scan[tid] = msum;
+    __syncthreads();
+    float before = 0.f, total = 0.f;
+    for (int t = 0; t < NT; ++t) {
+        if (t < tid) before += s_scan[t];
+        total += s_scan[t];
+    }
+    const int stp = a.step ? a.step[b] : 0;
+    const uint32_t h = hmix(a.seed ^ hmix((uint32_t)b * 0x9E3779B1u + (uint32_t)stp * 0x85EBCA77u + 0x1234567u));
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    const float target = u * total;
+    if (tid == 0) s_i[1] = -1;
+    __syncthreads();
+    // the owner: the thread whose [before, before + msum) contains the target (the last thread with kept mass takes a target that rounding pushed past the end)
+    const bool owner = msum > 0.f && target >= before && (target < before + msum);
+    if (owner) atomicMax(&s_i[1], tid);
+    __syncthreads();
+    if (s_i[1] < 0) {            // rounding: nobody's interval held the target -> the last thread with mass
+        if (msum > 0.f) atomicMax(&s_i[1], tid);
+        __syncthreads();
+    }
+    if (tid == s_i[1]) {
+        float run = before;
+        int st = ties_before, pick = -1, lastk = -1;
+        for (int i = i0; i < i1; ++i) {
+            const float l = adj(i);
+            const uint32_t k = fkey(l);
+            const bool keep = k > tau || (k == tau && st++ < r_keep);
+            if (!keep) continue;
+            lastk = i;
+            run += __expf((l - mx) * a.inv_temp) * inv_z;
+            if (target < run) { pick = i; break; }
+        }
+        a.out[b] = (long long)(pick >= 0 ? pick : lastk);
+    }
+}
+
 // continuous marking of emitted tokens + the prompt, for the repetition penalty
 __global__ void k_mark_prompt(const int* src, const int* lastrow, unsigned* seen, int seen_words) {
     const int b = blockIdx.x;
@@ -280,7 +432,13 @@ int launch_scatter_rows(hipStream_t s, const int* rows, const long long* src, lo
 }
 int launch_sample(hipStream_t s, const SampleArgs& a) {
     if (a.B <= 0) return 0;
-    if (a.top_k < 1 || a.top_k > KMAX || a.top_k > a.V || !(a.inv_temp > 0.f) || !(a.top_p > 0.f)) return -22;
+    if (!(a.inv_temp > 0.f) || !(a.top_p > 0.f)) return -22;
+    if (a.top_k <= 0 || a.top_k >= a.V) {            // no top-k bound (vLLM's -1): nucleus sampling over the whole vocabulary
+        hipLaunchKernelGGL(k_sample_full, dim3(a.B), dim3(NT), 0, s, a);
+        SR_CHECK_LAUNCH();
+        return 0;
+    }
+    if (a.top_k > KMAX) return -22;
     hipLaunchKernelGGL(k_sample, dim3(a.B), dim3(NT), 0, s, a);
     SR_CHECK_LAUNCH();
     return 0;

@@ -388,3 +388,87 @@ def test_sam2_float32_masks_on_more_images_weights_and_multi_point_prompts(golde
         torch.cuda.empty_cache()
     _record("r05_sam2_more_parity.json", "hiera_large_float32", res)
     assert not fails, fails
+
+
+# ------------------------------------------------------------------------------------------------ sampling without a top-k bound on the device (missing #5)
+def _nucleus_probs(logits, temperature, top_p):
+    """the sampler's rule without a top-k bound (socioreasoner_amd/sampling.py), float64"""
+    x = logits.double() / temperature
+    sx, si = torch.sort(x, descending=False)
+    cp = torch.softmax(sx, -1).cumsum(-1)
+    drop = cp <= (1.0 - top_p)
+    drop[-1] = False
+    sx = sx.masked_fill(drop, float("-inf"))
+    return torch.softmax(torch.empty_like(x).scatter_(-1, si, sx), -1)
+
+
+def test_sampling_without_top_k_bound_on_the_device():
+    """vLLM's top_k = -1 (vllm_strategy.py:289-309 passes it through) used to be a host loop over sr_decode_step; k_sample_full draws on the device:
+    nucleus sampling over the whole 151 936-entry vocabulary by a radix descent on probability MASS (no sort).  Checked: the support of 8192
+    draws is inside the nucleus of the float64 rule and their frequencies follow it; top_p = 1 covers the tail; a tiny top_p is the arg-max; ties at the
+    nucleus edge keep the lowest ids; the same (seed, row, step) gives the same token; the repetition penalty moves the choice."""
+    from socioreasoner_amd import lib
+    L = lib.load()
+    V = 151936
+    g = torch.Generator().manual_seed(9)
+    base = torch.randn(V, generator=g) * 3.0
+
+    def run(logits, B, temperature, top_p, rp=1.0, seen=None, seed=1, step=None):
+        out = torch.zeros(B, dtype=torch.int64, device="cuda")
+        lg = _D(logits)
+        st = _D(step) if step is not None else None
+        assert L.sr_op_sample(_P(lg), B, logits.shape[1], C.c_float(temperature), -1, C.c_float(top_p), C.c_float(rp), _P(_D(seen)) if seen is not None else None, seed, _P(st), _P(out),
+                              None, 0, 0, _sp()) == 0
+        torch.cuda.synchronize()
+        return out.cpu()
+    B = 8192
+    rows = base[None].repeat(B, 1).contiguous()
+    step = torch.arange(B, dtype=torch.int32)
+    for T, tp in ((1.0, 0.8), (0.7, 0.95), (1.5, 1.0)):
+        got = run(rows, B, T, tp, step=step)
+        want = _nucleus_probs(base, T, tp)
+        support = want > 0
+        assert bool(support[got].all()), (T, tp, "a draw outside the nucleus")
+        freq = torch.bincount(got, minlength=V).double() / B
+        top = torch.topk(want, 40).indices
+        err = (freq[top] - want[top]).abs()
+        sigma = (want[top] * (1 - want[top]) / B).sqrt()
+        assert bool((err <= 5 * sigma + 2e-4).all()), (T, tp, float((err / (sigma + 1e-12)).max()))
+        assert torch.equal(got, run(rows, B, T, tp, step=step))                      # same (seed, row, step): same tokens
+    assert bool((run(rows[:64], 64, 1.0, 1e-6, step=step[:64]) == int(base.argmax())).all())      # a nucleus of one token
+    # ties at the edge of the nucleus: four equal maxima, top_p covers two and a half of them -> ids 10, 20, 30 only
+    flat = torch.full((V,), -30.0)
+    flat[[10, 20, 30, 40]] = 5.0
+    got = run(flat[None].repeat(2048, 1).contiguous(), 2048, 1.0, 0.6, step=step[:2048])
+    assert set(got.tolist()) == {10, 20, 30}, sorted(set(got.tolist()))
+    # repetition penalty: the dominant token, once seen, loses its lead
+    dom = torch.full((V,), -20.0)
+    dom[7], dom[9] = 6.0, 5.5
+    seen = torch.zeros(1, (V + 31) // 32, dtype=torch.int32)
+    seen[0, 0] = 1 << 7
+    a = run(dom[None].repeat(1, 1), 1, 1e-3, 0.5)
+    b = run(dom[None].repeat(1, 1), 1, 1e-3, 0.5, rp=2.0, seen=seen)
+    assert int(a[0]) == 7 and int(b[0]) == 9
+
+
+def test_decode_sample_without_top_k_bound_tiny_engine():
+    """sr_decode_sample / the rows mode accept top_k <= 0: a whole sampled decode on the device (graph-replayed step with the draw inside), same tokens eager
+    and replayed, and with a vanishing top_p it is the greedy decode."""
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.engine import Engine
+    geom = geometry_tiny()
+    e = Engine(geom, max_patches=64, max_prefill_tokens=512, max_batch=4, max_ctx=128, max_new_tokens=16)
+    e.load_synthetic_weights(seed=0)
+    rng = np.random.default_rng(3)
+    ids, pos = _prompts(rng, 4)
+    e.prefill(ids, pos)
+    greedy = e.decode(12)
+    e.prefill(ids, pos)
+    a = e.decode_sample(12, 1.0, -1, top_p=1e-6, seed=5, use_graph=True)
+    assert torch.equal(a, greedy)
+    e.prefill(ids, pos)
+    s1 = e.decode_sample(12, 1.0, 0, top_p=0.9, seed=5, use_graph=True)
+    e.prefill(ids, pos)
+    s2 = e.decode_sample(12, 1.0, 0, top_p=0.9, seed=5, use_graph=False)
+    assert torch.equal(s1, s2) and not torch.equal(s1, greedy)
+    e.close()
