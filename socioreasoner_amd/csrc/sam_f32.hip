@@ -382,6 +382,7 @@ __global__ __launch_bounds__(256) void k_attn_f32(AttnF32Args p) {
     const int nq = min(64, (w.q_len ? w.q_len : w.seq_len) - w.q_off);
     const int qi = wave * 16 + c;                                   // this lane's query inside the tile
     const bool qok = qi < nq;
+    const bool wave_live = wave * 16 < nq;
     float qreg[NS];
     {
         const float* qp = p.q + (size_t)(w.q_row0 + (qok ? qi : 0)) * p.q_stride + h * HD + g;
@@ -409,15 +410,27 @@ __global__ __launch_bounds__(256) void k_attn_f32(AttnF32Args p) {
             *reinterpret_cast<float4*>(Vs + r * PV + d4) = vv;
         }
         __syncthreads();
+        if (!wave_live) continue;               // (round 5) a wave without a query keeps only the barriers: Hiera's 196-token windows leave 3 of a window's 16 waves empty
+        // live 16-key sub-tiles of this 64-key tile (round 5): a window of 196 keys ends in a tile of 4 -- its three dead sub-tiles used to cost as much
+        // as live ones (S = -inf, P = 0, 0 x V added: skipping them changes no bit)
+        const int nt = min(4, (w.seq_len - j0 + 15) >> 4);
         // S^T tile t: keys 16 t + 4 g + v (v = 0..3) of query c
         f32x4 sc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* kr = Ks + c * PK + g;
+        if (nt == 4) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s)            // four independent accumulator chains: the 40-cycle dependent latency of the 16x16x4 form stays hidden
+            for (int s = 0; s < NS; ++s)        // four independent accumulator chains: the 40-cycle dependent latency of the 16x16x4 form stays hidden
 #pragma unroll
-            for (int t = 0; t < 4; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[16 * t * PK + 4 * s], qreg[s], sc[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[16 * t * PK + 4 * s], qreg[s], sc[t], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (t < nt) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[16 * t * PK + 4 * s], qreg[s], sc[t], 0, 0, 0);
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -447,13 +460,15 @@ __global__ __launch_bounds__(256) void k_attn_f32(AttnF32Args p) {
         }
         // O^T[d][q] += sum_key V[key][d] P[key][q]: A = V^T fragment (row d = 16 dt + c, k = g -> key 16 t + 4 g + v), B = P^T (this lane's sc[t][v])
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+            if (t >= nt) continue;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const float* vr = Vs + (16 * t + 4 * g + v) * PV + c;
 #pragma unroll
                 for (int d = 0; d < ND; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[16 * d], sc[t][v], o[d], 0, 0, 0);
             }
+        }
     }
     lrun += __shfl_xor(lrun, 16, 64);
     lrun += __shfl_xor(lrun, 32, 64);

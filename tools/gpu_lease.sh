@@ -53,6 +53,9 @@ for stage in "$@"; do
     fp8tests) timeout 1500 python -m pytest tests -q -m gpu -k "f8 or fp8" 2>&1 | tail -8 ;;
     pipeline) for dt in float32 bf16; do SR_SAM2_DTYPE=$dt SCRIPTED_OBJECTS=4 OUT=/tmp/example_out SOCIOSEG_NUM_SAMPLES=64 timeout 900 python tools/run_example_small.py 2> gpurun_out/r05_pipeline_$dt.err | tail -1 | tee gpurun_out/r05_pipeline_$dt.json | cut -c1-900; done
               SCRIPTED_OBJECTS=0 OUT=/tmp/example_out SOCIOSEG_NUM_SAMPLES=64 timeout 900 python tools/run_example_small.py 2>/dev/null | tail -1 | tee gpurun_out/r05_pipeline_noanswers.json | cut -c1-600 ;;
+    trace_sam2) rm -rf /tmp/prof5_sam; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof5_sam -o sam -- python $R/tools/prof_sam2_encoder.py f32 > $R/gpurun_out/r05_prof_sam2.log 2>&1; echo "trace sam2 exit $?")
+                DB=$(find /tmp/prof5_sam -name "sam_results.db" | head -1); [ -n "$DB" ] && python tools/rocpd_stats.py $DB gpurun_out/r05_sam2_f32_encoder_kernel_stats.md > /dev/null && head -20 gpurun_out/r05_sam2_f32_encoder_kernel_stats.md | cut -c1-170
+                [ -n "$DB" ] && python tools/rocpd_by_grid.py $DB gpurun_out/r05_sam2_f32_by_grid.md 30 > /dev/null 2>&1 && head -36 gpurun_out/r05_sam2_f32_by_grid.md | cut -c1-200 ;;
     gemm_f32) timeout 600 python tools/bench_gemm_f32.py | tee gpurun_out/r05_gemm_f32_split.jsonl ;;
     sam2bench) timeout 900 python tools/bench_sam2_modes.py | tee gpurun_out/r05_sam2_modes.json ;;
     sam2tests) timeout 1500 python -m pytest tests/test_gpu_sam2.py tests/test_gpu_round4.py -x -q -m gpu -k "sam2 or gemm_f32 or seg_infer" 2>&1 | tail -8 ;;
