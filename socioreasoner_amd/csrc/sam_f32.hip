@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(GemmF32Args p, int n_tiles_
 // planes per operand as [k half][row][8 k] (16 bytes per entry: fragment reads are conflict-free ds_read_b128, stores conflict-free
 // ds_write_b128 with the second k half displaced by 64 bytes).
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
+constexpr int FGROUP = 8;                         // m-tiles that walk the n-tiles together (tile order below)
 constexpr int SP_HALF = 128 * 16 + 64;            // bytes between the two k halves of a plane
 constexpr int SP_PLANE = 2 * SP_HALF;             // bytes per plane
 constexpr int SP_OPER = 3 * SP_PLANE;             // bytes per operand (hi, mid, lo)
@@ -202,8 +203,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32s(GemmF32Args p, int n_tiles
     __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][SP_OPER];     // [buffer][A | W]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = blockIdx.x;
-    const int m0 = (tile / n_tiles_n) * GB, n0 = (tile % n_tiles_n) * GB;
+    // tile order (as gemm256.hip): block b runs on XCD b % 8 -> every XCD gets a contiguous run of tiles, and inside it FGROUP m-tiles walk the n-tiles
+    // together, so that the blocks in flight on an XCD share their W panels (and their A panels) in ITS L2.  With the plain m-major order the
+    // XCDs each streamed all of W once per m-tile from the memory side (1.4 GB for the 8192 x 4608 x 1152 launch against 59 MB of operands)
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ntm = gridDim.x / n_tiles_n, per_group = FGROUP * n_tiles_n;
+    const int gid = bid / per_group, first_m = gid * FGROUP, gsz = min(ntm - first_m, FGROUP);
+    const int m0 = (first_m + (bid % per_group) % gsz) * GB, n0 = ((bid % per_group) / gsz) * GB;
     const int sr = tid >> 1, sk = tid & 1;                                       // staging: row sr, k half sk
     // rows beyond M / N are read from the last valid row instead: an output element depends on ITS row of A and ITS row of W only, and the
     // epilogue never stores rows >= M or columns >= N -- no zero fill, no conditional loads.  Buffer loads (descriptor + per-thread byte offset
