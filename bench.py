@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--no-sam", action="store_true", help="skip the SAM2 (seg_infer) timing")
     ap.add_argument("--no-more-rows", action="store_true", help="skip the 64- and 128-row points (child processes)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the two-stage pipeline timing with SAM2 at work (a child process)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure the weight stream's HBM traffic with rocprofv3 in this run (two child passes); use the ratio committed under profiles/")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="BASELINE.json configs[4] weights: LM decoder linears fp8 e4m3, per-channel scale")
     ap.add_argument("--fp8-mx", action="store_true", help="--fp8 plus MX fp8 activations in the prefill linears (fp8 x fp8 block-scaled MFMA, lm_weight_dtype 2)")
@@ -557,10 +558,12 @@ def main():
             traffic = round(pmc["traffic_over_algorithmic_weighted_batch32" if B > 4 else "traffic_over_algorithmic_weighted_batch1"] * bytes_per_launch)
         except Exception:  # noqa: BLE001
             pass
+        traffic_source = (f"profiles/{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel family): measured "
+                          "traffic / algorithmic bytes ratio x the algorithmic bytes of one launch -- NOT measured in this run") if traffic else None
         roof = {"bound": "hbm", "kernel": f"k_gemv family at batch {B} (decode weight stream, all LM linears + LM head)" + (" [fp8 layer linears]" if args.fp8 else ""),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": (f"profiles/{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel family): measured "
-                                                       "traffic / algorithmic bytes ratio x the algorithmic bytes of one launch -- NOT measured in this run") if traffic else None,
+                "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_over_algorithmic": (pmc or {}).get("traffic_over_algorithmic_weighted_batch32" if B > 4 else "traffic_over_algorithmic_weighted_batch1"),
                 "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_ms * 1e3, 2),
                 "avg_launch_us_source": "HIP events around the 145-launch sequence replayed on weight-sized operands, in this run",
                 "avg_launch_us_in_situ_rocprof": insitu,
@@ -575,6 +578,19 @@ def main():
                                    "traffic": round(pmc["traffic_over_algorithmic_weighted_batch1"] * bytes_per_launch) if pmc else None,
                                    "decode_step_achieved_GBs": round((wl + wh + 36864.0 * (S_PROMPT + N_NEW / 2)) / (latency["decode_step_ms"] * 1e-3) / 1e9, 1)}
         del wq, wo, wg, wd, wv
+        # ---- the family's HBM traffic measured in THIS run (rocprofv3 child passes, the GPU otherwise idle); without rocprofv3 the committed ratio above stays
+        if world == 1 and not args.no_latency and not args.no_pmc:
+            torch.cuda.empty_cache()
+            live = measure_gemv_traffic(args.fp8)
+            if live is not None:
+                here = ("measured IN THIS RUN: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) over tools/probe_r2.py gemv on this box (FETCH_SIZE doubled per the "
+                        "gfx950 note of the MI355X guide): HBM reads / algorithmic weight bytes x the algorithmic bytes of one launch")
+                r32, r1 = live.get("traffic_over_algorithmic_weighted_batch32"), live.get("traffic_over_algorithmic_weighted_batch1")
+                ratio = r32 if B > 4 else r1
+                if ratio:
+                    roof["traffic"], roof["traffic_source"], roof["traffic_over_algorithmic"] = round(ratio * bytes_per_launch), here, ratio
+                if latency is not None and r1:
+                    latency["roofline"]["traffic"], latency["roofline"]["traffic_over_algorithmic"] = round(r1 * bytes_per_launch), r1
         # batches of B tiles inside the timed region whose admission had the whole chip (the MFMA fractions are quoted on those)
         per = (sched["admitted"] - sched["staged_shared"]) / B if continuous else args.steps
         phases = {k: round(v / args.steps, 3) for k, v in phase_ms.items()}
@@ -643,6 +659,42 @@ def main():
         print(json.dumps(clean(out)), flush=True)
     dp.barrier()
     eng.close()
+
+
+def measure_gemv_traffic(fp8: bool, timeout_s: int = 240):
+    """HBM bytes of the decode weight-stream launches measured IN THIS RUN, on this box (hygiene: the line used to carry a
+    profile-file ratio): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (kernel trace only beside them, as gpurun
+    requires) over tools/probe_r2.py -- the batch-32 and batch-1 launches of this kernel family on weight-sized operands -- reduced by
+    tools/rocpd_pmc.py / tools/gemv_traffic.py (FETCH_SIZE doubled per the gfx950 note of the MI355X guide).  Child processes, the GPU otherwise
+    idle.  Returns the ratio dict, or None (no rocprofv3 on the box, a failed pass): the caller then falls back to the committed file."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TMPDIR"] = "/tmp"
+    tag = "fp8" if fp8 else "bf16"
+    try:
+        with tempfile.TemporaryDirectory(prefix="sr_pmc_", dir="/tmp") as td:
+            outs = {}
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(td, c)
+                cmd = ["rocprofv3", "--kernel-trace", "--pmc", c, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "probe_r2.py"), "gemv"] + (["fp8"] if fp8 else [])
+                subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+                dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+                if not dbs:
+                    return None
+                outs[c] = os.path.join(td, c + ".json")
+                subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_pmc.py"), dbs[0], outs[c]], capture_output=True, text=True, timeout=120, check=True)
+            res = os.path.join(td, "traffic.json")
+            subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemv_traffic.py"), outs["FETCH_SIZE"], outs["WRITE_SIZE"], res] + ([tag] if fp8 else []),
+                           capture_output=True, text=True, timeout=120, check=True)
+            j = json.load(open(res))
+            return j if j.get("traffic_over_algorithmic_weighted_batch32") else None
+    except Exception:  # noqa: BLE001  (a profiler that is missing, crashes or times out must never take the bench line with it)
+        return None
 
 
 def cpu_baseline(weight_source=None):

@@ -56,6 +56,8 @@ for stage in "$@"; do
     trace_sam2) rm -rf /tmp/prof5_sam; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof5_sam -o sam -- python $R/tools/prof_sam2_encoder.py f32 > $R/gpurun_out/r05_prof_sam2.log 2>&1; echo "trace sam2 exit $?")
                 DB=$(find /tmp/prof5_sam -name "sam_results.db" | head -1); [ -n "$DB" ] && python tools/rocpd_stats.py $DB gpurun_out/r05_sam2_f32_encoder_kernel_stats.md > /dev/null && head -20 gpurun_out/r05_sam2_f32_encoder_kernel_stats.md | cut -c1-170
                 [ -n "$DB" ] && python tools/rocpd_by_grid.py $DB gpurun_out/r05_sam2_f32_by_grid.md 30 > /dev/null 2>&1 && head -36 gpurun_out/r05_sam2_f32_by_grid.md | cut -c1-200 ;;
+    bench_pmc) timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-sam --no-more-rows --no-pipeline > gpurun_out/r05_bench_pmc.log 2> gpurun_out/r05_bench_pmc.err; python -c "
+import json; d=json.loads([l for l in open('gpurun_out/r05_bench_pmc.log') if l.startswith('{')][-1]); r=d['roofline']; print({k: r[k] for k in ('frac','traffic','traffic_over_algorithmic','bytes_per_launch')}); print(r['traffic_source'][:160]); print(d['latency_b1']['roofline'])" ;;
     gemm_f32) timeout 600 python tools/bench_gemm_f32.py | tee gpurun_out/r05_gemm_f32_split.jsonl ;;
     sam2bench) timeout 900 python tools/bench_sam2_modes.py | tee gpurun_out/r05_sam2_modes.json ;;
     sam2tests) timeout 1500 python -m pytest tests/test_gpu_sam2.py tests/test_gpu_round4.py -x -q -m gpu -k "sam2 or gemm_f32 or seg_infer" 2>&1 | tail -8 ;;
