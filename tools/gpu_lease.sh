@@ -58,6 +58,7 @@ for stage in "$@"; do
                 [ -n "$DB" ] && python tools/rocpd_by_grid.py $DB gpurun_out/r05_sam2_f32_by_grid.md 30 > /dev/null 2>&1 && head -36 gpurun_out/r05_sam2_f32_by_grid.md | cut -c1-200 ;;
     bench_pmc) timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-sam --no-more-rows --no-pipeline > gpurun_out/r05_bench_pmc.log 2> gpurun_out/r05_bench_pmc.err; python -c "
 import json; d=json.loads([l for l in open('gpurun_out/r05_bench_pmc.log') if l.startswith('{')][-1]); r=d['roofline']; print({k: r[k] for k in ('frac','traffic','traffic_over_algorithmic','bytes_per_launch')}); print(r['traffic_source'][:160]); print(d['latency_b1']['roofline'])" ;;
+    tail_headline) for rep in 1 2; do for t in 0 1 3; do SR_TAIL_NORM=$t timeout 600 python bench.py --steps 3 --warmup 1 $QUIET > gpurun_out/r05_tailh_$t.log 2>&1; line gpurun_out/r05_tailh_$t.log "headline SR_TAIL_NORM=$t rep $rep:"; done; done ;;
     gemm_f32) timeout 600 python tools/bench_gemm_f32.py | tee gpurun_out/r05_gemm_f32_split.jsonl ;;
     sam2bench) timeout 900 python tools/bench_sam2_modes.py | tee gpurun_out/r05_sam2_modes.json ;;
     sam2tests) timeout 1500 python -m pytest tests/test_gpu_sam2.py tests/test_gpu_round4.py -x -q -m gpu -k "sam2 or gemm_f32 or seg_infer" 2>&1 | tail -8 ;;
