@@ -292,14 +292,15 @@ def main():
     drained = None
     if rank == 0 and world == 1 and continuous and not args.drain and not args.no_latency:
         args.drain = True
+        n_dr = 2                               # (the engine, its graphs and the scheduler's calibration are warm from the timed region above)
         torch.cuda.synchronize(dev)
         t_ = time.perf_counter()
-        steps_continuous(1)
+        steps_continuous(n_dr)
         torch.cuda.synchronize(dev)
-        d_ = time.perf_counter() - t_
+        d_ = (time.perf_counter() - t_) / n_dr
         args.drain = False
-        drained = {"workload": "ONE step on an idle engine: its first admission is exposed, its last rows decode with nothing staged under them", "tiles_per_s": round(n_req / d_, 3),
-                   "ms_per_step": round(d_ * 1e3, 2)}
+        drained = {"workload": f"rounds 1-3's definition of a step, {n_dr} of them back to back: every step starts on an idle engine (its first admission is exposed) and its last rows "
+                               "decode with nothing staged under them", "steps": n_dr, "tiles_per_s": round(n_req / d_, 3), "ms_per_step": round(d_ * 1e3, 2)}
 
     # ---- beyond the headline's 32 rows (not the headline: BASELINE.json configs[2] says batch = 32): the same workload through 64 and 128 batch
     # rows per GPU (the reference's request-level mode keeps up to 128 requests in flight per worker, generate_scheduler.py:57).  The decode
