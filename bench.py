@@ -662,7 +662,7 @@ def main():
     eng.close()
 
 
-def measure_gemv_traffic(fp8: bool, timeout_s: int = 240):
+def measure_gemv_traffic(fp8: bool, timeout_s: int = 120):
     """HBM bytes of the decode weight-stream launches measured IN THIS RUN, on this box (hygiene: the line used to carry a
     profile-file ratio): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (kernel trace only beside them, as gpurun
     requires) over tools/probe_r2.py -- the batch-32 and batch-1 launches of this kernel family on weight-sized operands -- reduced by
