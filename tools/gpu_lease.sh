@@ -59,6 +59,20 @@ for stage in "$@"; do
     bench_pmc) timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-sam --no-more-rows --no-pipeline > gpurun_out/r05_bench_pmc.log 2> gpurun_out/r05_bench_pmc.err; python -c "
 import json; d=json.loads([l for l in open('gpurun_out/r05_bench_pmc.log') if l.startswith('{')][-1]); r=d['roofline']; print({k: r[k] for k in ('frac','traffic','traffic_over_algorithmic','bytes_per_launch')}); print(r['traffic_source'][:160]); print(d['latency_b1']['roofline'])" ;;
     tail_headline) for rep in 1 2; do for t in 0 1 3; do SR_TAIL_NORM=$t timeout 600 python bench.py --steps 3 --warmup 1 $QUIET > gpurun_out/r05_tailh_$t.log 2>&1; line gpurun_out/r05_tailh_$t.log "headline SR_TAIL_NORM=$t rep $rep:"; done; done ;;
+    host_scaling) : > gpurun_out/r05_host_scaling.jsonl
+      for n in 1 2 4 8; do
+        SR_DIST_BACKEND=gloo timeout 900 python bench.py --gpus $n --batch 8 --waves 2 --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-sam --no-more-rows > gpurun_out/r05_hs.log 2> gpurun_out/r05_hs.err
+        python - $n <<'PY' | tee -a gpurun_out/r05_host_scaling.jsonl
+import json, sys
+try:
+    d = json.loads([l for l in open("gpurun_out/r05_hs.log") if l.startswith("{")][-1])
+    sc = d["phase_ms_per_step"]["scheduler"]
+    print(json.dumps({"ranks_on_one_device": int(sys.argv[1]), "n_gpus": d["n_gpus"], "nranks": d["config"]["exchange"]["nranks"], "tiles_per_s_all_ranks": d["value"], "ms_per_step": d["ms_per_step"],
+                      "host_threads_per_rank": d["host_threads_per_rank"], "rounds_per_step": sc["rounds"], "host_ms_per_round": sc["host_ms_per_round"], "poll_wait_ms_per_round": sc["poll_wait_ms_per_round"]}))
+except Exception as e:
+    print(json.dumps({"ranks_on_one_device": int(sys.argv[1]), "error": str(e)[:200]}))
+PY
+      done ;;
     gemm_f32) timeout 600 python tools/bench_gemm_f32.py | tee gpurun_out/r05_gemm_f32_split.jsonl ;;
     sam2bench) timeout 900 python tools/bench_sam2_modes.py | tee gpurun_out/r05_sam2_modes.json ;;
     sam2tests) timeout 1500 python -m pytest tests/test_gpu_sam2.py tests/test_gpu_round4.py -x -q -m gpu -k "sam2 or gemm_f32 or seg_infer" 2>&1 | tail -8 ;;
