@@ -208,6 +208,7 @@ def main():
                 for k in ("admitted", "staged_shared", "steps", "steps_shared", "rounds", "host_ms", "poll_wait_ms"):
                     sched[k] = sched.get(k, 0) + cb.stats[k]
                 shares.extend(cb.stats["shares"])
+                sched["share_model"] = cb.stats.get("share_model")
                 phase_ms["raster"] += sum(a.elapsed_time(b_) for a, b_ in spans)
         return res
 
@@ -596,7 +597,8 @@ def main():
         per = (sched["admitted"] - sched["staged_shared"]) / B if continuous else args.steps
         phases = {k: round(v / args.steps, 3) for k, v in phase_ms.items()}
         if continuous:
-            phases["scheduler"] = dict({k: v // args.steps for k, v in sched.items() if k not in ("host_ms", "poll_wait_ms")}, overlap=overlap, admit_cus_per_se=shares,
+            phases["scheduler"] = dict({k: v // args.steps for k, v in sched.items() if k not in ("host_ms", "poll_wait_ms", "share_model")}, overlap=overlap, admit_cus_per_se=shares,
+                                       share_model=sched.get("share_model"),
                                        host_ms_per_round=round(sched["host_ms"] / max(sched["rounds"], 1), 3), poll_wait_ms_per_round=round(sched["poll_wait_ms"] / max(sched["rounds"], 1), 3),
                                        decode_step_ms_shared=round(phase_ms.get("decode_shared", 0.0) / max(sched["steps_shared"], 1), 4),
                                        note=f"spans named *_shared ran concurrently on disjoint CU sets (admission share of the CUs: {args.admit_cus} of 8 per shader engine): they do not add up to ms_per_step" if overlap else None)

@@ -53,6 +53,15 @@ class ContinuousBatcher:
         # the engine, so that the next scheduler on it (one per generate call) starts calibrated
         self._adm_rate, self._step_ms = getattr(engine, "_sched_cal", (None, None))
         self._cal_adm = self._cal_step = None      # (start event, end event, units / steps) of a measurement in flight
+        # round 5: the cost of SHARING the chip depends on the rows per step (a 128-row decode step is 2.1 x as long next to an
+        # admission, a 32-row one 1.27 x), so the two tables below are only the prior: every shared decode chunk and every shared admission is timed and the
+        # measured slow-down of the share in use replaces the table's entry (other shares keep the table's shape, scaled by what was measured).  Kept on the
+        # engine like the unshared calibration.
+        self._dec_meas, self._adm_meas = getattr(engine, "_sched_cal_shared", ({}, {}))
+        self._cal_dec_sh = self._cal_adm_sh = None
+        self._cal_seen = engine.__dict__.setdefault("_sched_cal_seen", {})      # ("dec" | "adm", share) -> samples taken: 8 per share, then the timed events stop
+        import os
+        self._online = os.environ.get("SR_SCHED_ONLINE", "1") != "0"      # 0: the 32-row tables only (A/B hook of tools/gpu_lease.sh sched_ab)
         self._cnt_last: Dict[int, int] = {}
         if self.overlap:
             from .streams import overlap_streams
@@ -186,20 +195,46 @@ class ContinuousBatcher:
     _ADM_EFF = {2: 0.86, 3: 0.886, 4: 0.913, 5: 0.94}
     _DEC_SLOW = {2: 1.20, 3: 1.265, 4: 1.36, 5: 1.55}
 
+    def _dec_factor(self, c: int) -> float:
+        """decode step time on the 8 - c CUs per shader engine next to an admission, relative to the whole chip"""
+        if c in self._dec_meas:
+            return self._dec_meas[c]
+        if self._dec_meas:       # the table's shape, scaled by the measured excess of the shares that were seen
+            k = sum((v - 1.0) / (self._DEC_SLOW[m] - 1.0) for m, v in self._dec_meas.items()) / len(self._dec_meas)
+            return 1.0 + (self._DEC_SLOW[c] - 1.0) * max(k, 0.25)
+        return self._DEC_SLOW[c]
+
+    def _adm_factor(self, c: int) -> float:
+        """admission time on c of the 8 CUs per shader engine under decode, relative to the whole chip"""
+        if c in self._adm_meas:
+            return self._adm_meas[c]
+        base = (8.0 / c) * self._ADM_EFF[c]
+        if self._adm_meas:
+            k = sum(v / ((8.0 / m) * self._ADM_EFF[m]) for m, v in self._adm_meas.items()) / len(self._adm_meas)
+            return base * min(max(k, 0.5), 2.0)
+        return base
+
+    @staticmethod
+    def _ema(table: dict, key: int, value: float):
+        table[key] = value if key not in table else 0.5 * table[key] + 0.5 * value
+
     def _pick_share(self, a_ms: float, steps_left: float) -> int:
         """CUs per shader engine for an admission that takes a_ms on the whole chip while the running rows still have steps_left decode
         steps in front of them: the share with the shortest predicted time until those rows are done AND the admission has landed
-        (decode runs on the small CU set until the poll after the admission ends, on the whole chip afterwards).  Among the shares predicted within 4 % of the
-        best the smallest is taken: the model is good to a few per cent, neighbouring shares often are that close (448-pixel tiles: 3 vs
-        4 CUs differ by 2 % measured), and the smaller share leaves decode more of the chip."""
+        (decode runs on the small CU set until the poll after the admission ends, on the whole chip afterwards).  Among the shares predicted within 1.5 % of the
+        best the smallest is taken (it leaves decode more of the chip); the band was 4 % while the costs came from the 32-row table alone -- with
+        the costs measured on the engine itself the prediction is trusted further (64 rows: 3 CUs predicted 2 % behind 4, measured 1.4 % behind)."""
         t = {}
         for c in (2, 3, 4, 5):
-            ta = a_ms * (8.0 / c) * self._ADM_EFF[c]
-            sc = self._step_ms * self._DEC_SLOW[c]
+            ta = a_ms * self._adm_factor(c)
+            sc = self._step_ms * self._dec_factor(c)
             shared = -(-(ta / sc) // self.steps_per_poll) * self.steps_per_poll      # steps decoded next to the admission (whole chunks)
-            t[c] = ta if shared >= steps_left else shared * sc + (steps_left - shared) * self._step_ms
+            # an admission that outlasts the running rows leaves the rest of the chip idle beside its CU mask until it lands: such a plan is
+            # charged 5 % more than its own length (64 rows: share 3 predicted 467 ms against 471 ms for share 4, measured 1.4 % SLOWER --
+            # the admission was the critical path, and every per cent it overran its estimate was a per cent of idle decode)
+            t[c] = 1.05 * ta if shared >= steps_left else shared * sc + (steps_left - shared) * self._step_ms
         t_min = min(t.values())
-        return min(c for c in t if t[c] <= 1.04 * t_min)
+        return min(c for c in t if t[c] <= 1.015 * t_min)
 
     # Measured and dropped (round 3): cutting a staged group to the rows that are idle or about to finish (so that they wait for a short
     # admission instead of a full one; the next group cannot be staged before this one is fully installed) -- ragged phase of bench.py,
@@ -230,8 +265,12 @@ class ContinuousBatcher:
         else:
             s = self._use_decode_stream(self.streams.decode_full)
         cal = self._auto and not shared and self._adm_rate is None and self._cal_adm is None
+        cal_sh = bool(self._online and self._auto and shared and self._adm_rate is not None and self._cal_adm_sh is None
+                      and self._cal_seen.get(("adm", self._share), 0) < 8)
         try:
-            self._stage_on(s, grp, slots, shared, cal, units)
+            self._stage_on(s, grp, slots, shared, cal or cal_sh, units)
+            if cal_sh and self._cal_adm is not None:          # (_stage_on left the event pair in _cal_adm: this one measures a SHARED admission)
+                self._cal_adm_sh, self._cal_adm = self._cal_adm + (self._share,), None
         except BaseException:
             self.free_slots.extendleft(reversed(slots))          # the group is lost to its caller (the exception says so), the slots are not
             raise
@@ -304,17 +343,22 @@ class ContinuousBatcher:
         # (step-time calibration: a chunk with the chip to itself -- no admission in flight and none about to be staged under it)
         cal = (self._auto and not busy and not (self.staged is None and self.pending and self.free_slots)
                and self._step_ms is None and self._cal_step is None)
+        cal_sh = bool(self._online and self._auto and busy and self._step_ms is not None and self._cal_dec_sh is None       # a chunk on the decode CU set next to the admission
+                      and self._cal_seen.get(("dec", self._share), 0) < 8)
         with torch.cuda.stream(s):
-            if cal:
+            if cal or cal_sh:
                 c0 = torch.cuda.Event(enable_timing=True)
                 c0.record(s)
             t0 = self._mark()
             self.engine.rows_step(self.steps_per_poll, self.eos, self.pad_id)
             self._span("decode_shared" if shares else "decode", t0, self._mark())
-            if cal:
+            if cal or cal_sh:
                 c1 = torch.cuda.Event(enable_timing=True)
                 c1.record(s)
-                self._cal_step = (c0, c1, self.steps_per_poll)
+                if cal:
+                    self._cal_step = (c0, c1, self.steps_per_poll)
+                else:
+                    self._cal_dec_sh = (c0, c1, self.steps_per_poll, self._share, self.staged[2])
         self.stats["steps"] += self.steps_per_poll
         self.stats["steps_shared"] += self.steps_per_poll if shares else 0
         if self.staged is None and self.pending and self.free_slots:
@@ -331,6 +375,22 @@ class ContinuousBatcher:
                     self._adm_rate = self._cal_adm[0].elapsed_time(self._cal_adm[1]) / max(self._cal_adm[2], 1)
                     self._cal_adm = None
                     self.engine._sched_cal = (self._adm_rate, self._step_ms)
+                if self._cal_dec_sh is not None and self._cal_dec_sh[1].query():
+                    c0, c1, n_st, share, adm_ev = self._cal_dec_sh
+                    if not adm_ev.query():          # the admission outlasted the chunk: every one of its steps shared the chip
+                        self._ema(self._dec_meas, share, max(c0.elapsed_time(c1) / n_st / self._step_ms, 1.0))
+                        self._cal_seen[("dec", share)] = self._cal_seen.get(("dec", share), 0) + 1
+                        self.engine._sched_cal_shared = (self._dec_meas, self._adm_meas)
+                    self._cal_dec_sh = None
+                if self._cal_adm_sh is not None and self._cal_adm_sh[1].query():
+                    c0, ev, units, share = self._cal_adm_sh
+                    self._ema(self._adm_meas, share, max(c0.elapsed_time(ev) / max(units * self._adm_rate, 1e-6), 1.0))
+                    self._cal_seen[("adm", share)] = self._cal_seen.get(("adm", share), 0) + 1
+                    self.engine._sched_cal_shared = (self._dec_meas, self._adm_meas)
+                    self._cal_adm_sh = None
+                self.stats["share_model"] = {"decode_slowdown_measured": {k: round(v, 3) for k, v in self._dec_meas.items()},
+                                             "admission_slowdown_measured": {k: round(v, 3) for k, v in self._adm_meas.items()},
+                                             "step_ms": self._step_ms, "admission_ms_per_unit": self._adm_rate}
             for row in [r for r in self.active if fin[r]]:
                 req = self.active.pop(row)
                 toks = self.engine.row_tokens(row, int(cnt[row])).cpu().tolist()

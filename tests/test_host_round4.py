@@ -198,10 +198,30 @@ def test_scheduler_share_model_picks_the_measured_splits():
     admission never gets a smaller share, and when the running rows are about to finish anyway (nothing left to slow down) the largest share wins."""
     from types import SimpleNamespace
     from socioreasoner_amd.serving import ContinuousBatcher as CB
-    stub = SimpleNamespace(_step_ms=2.5, steps_per_poll=16, _ADM_EFF=CB._ADM_EFF, _DEC_SLOW=CB._DEC_SLOW)
+    stub = SimpleNamespace(_step_ms=2.5, steps_per_poll=16, _ADM_EFF=CB._ADM_EFF, _DEC_SLOW=CB._DEC_SLOW, _dec_meas={}, _adm_meas={})
+    stub._dec_factor, stub._adm_factor = (lambda c: CB._dec_factor(stub, c)), (lambda c: CB._adm_factor(stub, c))
     pick = lambda a_ms, left: CB._pick_share(stub, a_ms, left)
     assert pick(122.0, 112) == 3
     assert pick(218.0, 112) == 4
     shares = [pick(a, 112) for a in (40.0, 80.0, 122.0, 160.0, 218.0, 300.0, 500.0)]
     assert shares == sorted(shares) and shares[0] >= 2 and shares[-1] <= 5, shares
     assert pick(122.0, 1) == 5
+    # round 5: the cost of sharing is MEASURED per engine (rows per step) and replaces the 32-row table; shares it has not seen keep the table's
+    # shape scaled by what was measured.  The numbers are the bench's (profiles/r05_sched_online_ab.txt).
+    def engine(step_ms, dec, adm):
+        st = SimpleNamespace(_step_ms=step_ms, steps_per_poll=16, _ADM_EFF=CB._ADM_EFF, _DEC_SLOW=CB._DEC_SLOW, _dec_meas=dict(dec), _adm_meas=dict(adm))
+        st._dec_factor, st._adm_factor = (lambda c: CB._dec_factor(st, c)), (lambda c: CB._adm_factor(st, c))
+        return st
+    # 128 rows: the table alone starts at 5 CUs; measured there a step is 2.25 x slower, on 4 CUs 1.62 x -> 4 (measured +7 % tiles/s)
+    stub128 = engine(4.10, {}, {})
+    assert CB._pick_share(stub128, 412.0, 112) == 5
+    stub128 = engine(4.10, {5: 2.251, 4: 1.618}, {3: 2.142, 4: 1.713, 5: 1.423})
+    assert CB._pick_share(stub128, 412.0, 112) == 4
+    # 64 rows: 3 CUs would make the admission (457 ms) as long as the rows' decode (467 ms) -- the critical path, with the rest of the chip idle
+    # for every per cent it overruns (measured 1.4 % slower than 4 CUs): such plans carry a 5 % margin -> 4
+    stub64 = engine(3.03, {4: 1.545, 3: 1.379}, {3: 2.126, 4: 1.615})
+    assert CB._pick_share(stub64, 215.0, 112) == 4
+    stub128 = engine(4.18, {3: 2.1}, {})
+    assert CB._dec_factor(stub128, 3) == 2.1 and CB._dec_factor(stub128, 4) > 2.1 > CB._dec_factor(stub128, 2) > CB._DEC_SLOW[2]
+    stub128._adm_meas[3] = (8.0 / 3) * CB._ADM_EFF[3] * 1.2          # the admission, too, ran 20 % slower than the table says
+    assert abs(CB._adm_factor(stub128, 4) - (8.0 / 4) * CB._ADM_EFF[4] * 1.2) < 1e-9

@@ -73,6 +73,14 @@ except Exception as e:
     print(json.dumps({"ranks_on_one_device": int(sys.argv[1]), "error": str(e)[:200]}))
 PY
       done ;;
+    sched_ab) for cfg in "--batch 32" "--batch 64" "--batch 128"; do for rep in 1 2; do for v in 0 1; do
+        SR_SCHED_ONLINE=$v timeout 900 python bench.py $cfg --steps 3 --warmup 1 $QUIET > gpurun_out/r05_cfg.log 2> gpurun_out/r05_cfg.err
+        python - "$cfg online=$v rep $rep" <<'PY'
+import json, sys
+d = json.loads([l for l in open("gpurun_out/r05_cfg.log") if l.startswith("{")][-1]); sc = d["phase_ms_per_step"]["scheduler"]
+print(sys.argv[1], "|", d["value"], "tiles/s | ms/step", d["ms_per_step"], "| shares", sc["admit_cus_per_se"], "| decode step shared", sc["decode_step_ms_shared"])
+PY
+      done; done; done ;;
     gemm_f32) timeout 600 python tools/bench_gemm_f32.py | tee gpurun_out/r05_gemm_f32_split.jsonl ;;
     sam2bench) timeout 900 python tools/bench_sam2_modes.py | tee gpurun_out/r05_sam2_modes.json ;;
     sam2tests) timeout 1500 python -m pytest tests/test_gpu_sam2.py tests/test_gpu_round4.py -x -q -m gpu -k "sam2 or gemm_f32 or seg_infer" 2>&1 | tail -8 ;;
