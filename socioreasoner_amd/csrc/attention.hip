@@ -492,7 +492,46 @@ __device__ __forceinline__ void wait_vmcnt(int n) {      // immediate operand: o
     }
 }
 
-template <int HD, bool CAUSAL, int QW, int NS>
+// V^T fragment reads of pass 2, issued by hand (round 5).  Written as two uint2 loads per d-tile, hipcc pairs the loads of NEIGHBOURING d-tiles (rows
+// 16 apart = 2048 B, a multiple of the 512-B stride unit) into `ds_read2st64_b64`.  That instruction is serviced as two accesses of four CONTIGUOUS 16-lane
+// groups with 32-bank addressing and half the bytes per clock of `ds_read_b64` (MI355X guide, LDS table) -- under that rule lanes fr and fr ^ 1 of a group
+// (same chunk, rows 128 B apart) share a bank: 2-way conflicts on a layout that is conflict-free for `ds_read_b64` (two 32-lane groups, 64 banks).  This was
+// the "unexplained" SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.32 (LM) / 0.255 (ViT) of profiles/r03_pmc_attn_prefill.json: per wave and 64-key tile
+// 128 cycles of K reads + 128 of V^T reads + 128 of conflicts, against 128 + 64 + 0 for the instruction the layout was designed for.  The pairs also
+// came back as (d-tile i, d-tile i + 1) tuples that had to be re-assembled into MFMA operands with v_mov.  Inline asm keeps `ds_read_b64`; the results are
+// handed to the compiler through the operands of the counted `s_waitcnt lgkmcnt` that covers them (LDS operations return in order, so every count the
+// compiler derives for its own K reads stays conservative).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// group G = d-tiles 2G and 2G + 1: four reads, 8 registers
+template <int DT, int G>
+__device__ __forceinline__ void vt_issue(unsigned a0, unsigned a1, u32x2 (&v0)[DT], u32x2 (&v1)[DT]) {
+    if constexpr (2 * G < DT) {
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v0[2 * G]) : "v"(a0), "n"(2 * G * 2048));
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v1[2 * G]) : "v"(a1), "n"(2 * G * 2048));
+    }
+    if constexpr (2 * G + 1 < DT) {
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v0[2 * G + 1]) : "v"(a0), "n"((2 * G + 1) * 2048));
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v1[2 * G + 1]) : "v"(a1), "n"((2 * G + 1) * 2048));
+    }
+}
+// group G has landed once only the reads of group G + 1 (issued behind it) can still be outstanding; then its MFMAs
+template <int DT, int G>
+__device__ __forceinline__ void vt_consume(u32x2 (&v0)[DT], u32x2 (&v1)[DT], const bf16x8& pf, f32x4 (&oacc)[DT]) {
+    if constexpr (2 * G < DT) {
+        constexpr int LEFT = 2 * ((2 * G + 2 < DT) + (2 * G + 3 < DT));
+        constexpr int I0 = 2 * G, I1 = 2 * G + 1 < DT ? 2 * G + 1 : 2 * G;
+        // (a group of ONE d-tile -- head_dim 80 has five -- must not name its registers twice: the second copy of an in-out operand is made BEFORE the
+        // wait, from a register the read has not reached yet)
+        if constexpr (I1 != I0) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(v0[I0]), "+v"(v1[I0]), "+v"(v0[I1]), "+v"(v1[I1]) : "n"(LEFT));
+        else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v0[I0]), "+v"(v1[I0]) : "n"(LEFT));
+        oacc[I0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, uint4{v0[I0].x, v0[I0].y, v1[I0].x, v1[I0].y}), pf, oacc[I0], 0, 0, 0);
+        if constexpr (I1 != I0)
+            oacc[I1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, uint4{v0[I1].x, v0[I1].y, v1[I1].x, v1[I1].y}), pf, oacc[I1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);      // the next group's reads are issued BEHIND these MFMAs (8 + 8 registers of fragments live, not 32)
+    }
+}
+
+template <int HD, bool CAUSAL, int QW, int NS, bool VASM>
 __global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_units, int Y, int subs) {
     using C = PrefillCfg<HD>;
     constexpr int NH = 8 / QW;                  // heads per block
@@ -598,6 +637,13 @@ __global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_unit
         }
     };
     const int q_first = q_off + (wave % QW) * 16;       // first query position of this wave
+    // VASM: byte offset of this lane's 8-byte V^T piece inside a stage for (key block kb, half j): row fr of a d-tile (d-tile i adds i * 2048 in the
+    // instruction's offset field; vt_swz(i * 16 + fr) == vt_swz(fr))
+    unsigned vo[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) vo[kb][j] = (unsigned)(K_BYTES + fr * 128 + (fg & 1) * 8 + (((kb * 4 + (fg >> 1) + 2 * j) ^ vt_swz(fr)) << 4));
 
     float m = -INFINITY, l = 0.f, inv_l = 0.f;
     f32x4 oacc[C::DT];
@@ -660,6 +706,19 @@ __global__ __launch_bounds__(512, 4) void k_attn_prefill2(AttnArgs p, int n_unit
                 pv.z = pack2(__expf(s1[0] - m) * inv_l, __expf(s1[1] - m) * inv_l);
                 pv.w = pack2(__expf(s1[2] - m) * inv_l, __expf(s1[3] - m) * inv_l);
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, pv);
+                if constexpr (VASM) {
+                    const unsigned a0 = lds0 + buf * ST_BYTES + vo[kb][0], a1 = lds0 + buf * ST_BYTES + vo[kb][1];
+                    u32x2 v0[C::DT], v1[C::DT];
+                    vt_issue<C::DT, 0>(a0, a1, v0, v1);
+                    vt_issue<C::DT, 1>(a0, a1, v0, v1);
+                    vt_consume<C::DT, 0>(v0, v1, pf, oacc);
+                    vt_issue<C::DT, 2>(a0, a1, v0, v1);
+                    vt_consume<C::DT, 1>(v0, v1, pf, oacc);
+                    vt_issue<C::DT, 3>(a0, a1, v0, v1);
+                    vt_consume<C::DT, 2>(v0, v1, pf, oacc);
+                    vt_consume<C::DT, 3>(v0, v1, pf, oacc);
+                    static_assert(C::DT <= 8, "four groups of two d-tiles");
+                } else
 #pragma unroll
                 for (int dt = 0; dt < C::DT; ++dt) {
                     const int d = dt * 16 + fr;
@@ -994,18 +1053,18 @@ extern "C" int sr_dbg_attn_dec_times(long long* host_out) {
 }
 #endif
 
-template <int HD, bool CAUSAL, int QW, int NS>
+template <int HD, bool CAUSAL, int QW, int NS, bool VASM>
 static int launch_prefill2(hipStream_t s, const AttnArgs& a) {
     constexpr int NH = 8 / QW, QTB = QW * 16;
     constexpr int smem = NS * (KT * 256 + HD * 128);
     static bool attr = false;
     if (!attr) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_prefill2<HD, CAUSAL, QW, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_prefill2<HD, CAUSAL, QW, NS, VASM>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (r != hipSuccess) return (int)r;
         attr = true;
     }
     const int Y = a.n_heads / NH, subs = a.q_tile / QTB, n_units = a.n_work * Y * subs;
-    hipLaunchKernelGGL((k_attn_prefill2<HD, CAUSAL, QW, NS>), dim3(n_units), dim3(512), smem, s, a, n_units, Y, subs);
+    hipLaunchKernelGGL((k_attn_prefill2<HD, CAUSAL, QW, NS, VASM>), dim3(n_units), dim3(512), smem, s, a, n_units, Y, subs);
     SR_CHECK_LAUNCH();
     return 0;
 }
@@ -1024,8 +1083,9 @@ int attn_prefill_variant(const AttnArgs& a, int head_dim) {
 int launch_attn_prefill(hipStream_t s, const AttnArgs& a, int head_dim) {
     if (a.n_work <= 0) return 0;
     if (attn_prefill_variant(a, head_dim) == 2) {
-        if (head_dim == 128) return launch_prefill2<128, true, 2, 2>(s, a);       // 32 queries x 4 heads, 2 x 32 KB ring
-        return launch_prefill2<80, false, 8, 3>(s, a);                            // 128 queries x 1 head, 3 x 26 KB ring
+        const bool vasm = sr_switches().attn_vasm;          // hand-issued ds_read_b64 for V^T (bit-identical; SR_ATTN_VASM=0: the compiler's ds_read2st64_b64)
+        if (head_dim == 128) return vasm ? launch_prefill2<128, true, 2, 2, true>(s, a) : launch_prefill2<128, true, 2, 2, false>(s, a);       // 32 queries x 4 heads, 2 x 32 KB ring
+        return vasm ? launch_prefill2<80, false, 8, 3, true>(s, a) : launch_prefill2<80, false, 8, 3, false>(s, a);                            // 128 queries x 1 head, 3 x 26 KB ring
     }
     if (a.win64 && head_dim == 80 && !a.causal && a.n_heads % 4 == 0) {      // every item = one 64-token window starting at its first query (caller's promise)
         if (sr_switches().attn_win64) {

@@ -86,6 +86,7 @@ static void load_switches() {
     if (g_sw.g256_group < 1) g_sw.g256_group = 4;
     g_sw.attn2 = env_int("SR_ATTN2", 1);
     g_sw.attn_win64 = env_int("SR_ATTN_WIN64", 1);
+    g_sw.attn_vasm = env_int("SR_ATTN_VASM", 1);
     g_sw.sam_f32_split = env_int("SR_SAM_F32_SPLIT", 1);
     g_sw.tail_norm = env_int("SR_TAIL_NORM", 0);
     g_sw_loaded = true;

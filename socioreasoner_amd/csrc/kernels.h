@@ -15,6 +15,7 @@ struct SrSwitches {
     int g256_group;     // SR_G256_GROUP  m-tiles per W panel of the 256-tile GEMM (default 4)
     int attn2;          // SR_ATTN2       0: round-2 prefill attention kernel (default 1)
     int attn_win64;     // SR_ATTN_WIN64  0: no 64-token window kernel (default 1)
+    int attn_vasm;      // SR_ATTN_VASM   0: V^T fragment reads of k_attn_prefill2 left to the compiler (ds_read2st64_b64, 2-way bank conflicts; default 1: hand-issued ds_read_b64)
     int sam_f32_split;  // SR_SAM_F32_SPLIT 0: SAM2's float32 GEMM on the f32-input MFMA (round 4) instead of the three-term bf16 split on the bf16 pipe (default 1)
     int tail_norm;      // SR_TAIL_NORM   bit 0 / bit 1: the RMSNorm after o_proj / after the down-projection of a 5..32-row decode layer runs INSIDE that GEMV launch
                         //                (its last-arriving blocks, rownorm.h) instead of as a launch of its own.  Default 0: bit-identical, measured slower.

@@ -472,3 +472,45 @@ def test_decode_sample_without_top_k_bound_tiny_engine():
     s2 = e.decode_sample(12, 1.0, 0, top_p=0.9, seed=5, use_graph=False)
     assert torch.equal(s1, s2) and not torch.equal(s1, greedy)
     e.close()
+
+
+@pytest.mark.parametrize("hw", [448, 756])
+def test_prefill_attention_hand_issued_vt_reads_are_bit_identical(monkeypatch, hw):
+    """k_attn_prefill2 with its V^T fragment reads issued by hand as ds_read_b64 (default) against the same kernel with the reads left to the
+    compiler (SR_ATTN_VASM=0: ds_read2st64_b64 pairs, 2-way bank conflicts): same data, same MFMA order -- ViT pooler (hd 80, full-attention block),
+    causal GQA prefill logits (hd 128) and the first decoded tokens are equal bit for bit.  448: four tiles, ragged prompts, partial key tiles;
+    756: an image that is not a multiple of 64 patches."""
+    from socioreasoner_amd import hostops, synthetic
+    from socioreasoner_amd.config import geometry_3b
+    from socioreasoner_amd.engine import Engine
+    geom = geometry_3b()
+    geom.vision.depth, geom.text.num_hidden_layers = 8, 3
+    geom.vision.fullatt_block_indexes = (7,)
+    tiles = {448: [0, 1, 2, 3], 756: [0]}[hw]
+    n = (hw // 14) ** 2
+    e = Engine(geom, max_patches=len(tiles) * n, max_prefill_tokens=len(tiles) * (n // 4 + 64), max_batch=len(tiles),
+               max_ctx=(n // 4 + 64 + 63) // 64 * 64 + 64, max_new_tokens=4)
+    e.load_synthetic_weights(seed=0)
+    grid = (1, hw // 14, hw // 14)
+
+    def run(vasm):
+        switch(monkeypatch, "SR_ATTN_VASM", vasm)
+        pix = torch.cat([e.patchify(torch.from_numpy(synthetic.tile_pixels(i, hw, hw)).cuda()) for i in tiles], dim=0)
+        emb = e.vit_forward(pix, [grid] * len(tiles))
+        ids, p3 = [], []
+        for i in tiles:
+            x = synthetic.tile_prompt(geom, i, grid, n_pre=9 + 5 * i, n_post=4 + 3 * i)
+            pos3, _ = hostops.get_rope_index(torch.from_numpy(x)[None], [grid], None, image_token_id=geom.image_token_id,
+                                             vision_start_token_id=geom.vision_start_token_id)
+            ids.append(x)
+            p3.append(pos3[:, 0].numpy())
+        logits = e.prefill(ids, p3, emb, return_logits=True)
+        toks = e.decode(4)
+        torch.cuda.synchronize()
+        return emb.clone(), logits.clone(), toks.clone()
+
+    a, b = run("0"), run("1")
+    for x, y, what in zip(a, b, ("pooler", "prefill logits", "tokens")):
+        assert torch.equal(x, y), (what, float((x.float() - y.float()).abs().max()))
+    assert torch.isfinite(b[1]).all()
+    e.close()

@@ -11,6 +11,7 @@
 #   trace_c32   ... of the headline (continuous) configuration               -> gpurun_out/r05_bench_c32_kernel_stats.md
 #   trace_b1    ... of batch 1                                               -> gpurun_out/r05_bench_b1_kernel_stats.md
 #   trace_fp8   ... of --fp8 static 32 rows                                  -> gpurun_out/r05_bench_fp8_s32_kernel_stats.md
+#   pmc_gemm / pmc_attn   SQ + FETCH_SIZE passes of the GEMM / prefill-attention kernels -> gpurun_out/r05_pmc_gemm256.json / r05_pmc_attn_prefill.json
 #   pmc_gemv    FETCH_SIZE / WRITE_SIZE passes of the decode weight stream (bf16 and fp8) -> gpurun_out/r05_pmc_gemv_traffic*.json
 #   bench       the driver's command (python bench.py)                       -> gpurun_out/r05_bench_default_line.json
 #   configs     the other configurations of README (pair, fp8, fp8-mx 896, 64 / 128 rows, no-overlap, batch 1), 2 steps each
@@ -95,6 +96,52 @@ PY
     trace_c32) trace c32 --steps 2 --warmup 1 $QUIET ;;
     trace_b1)  trace b1 --batch 1 --steps 3 --warmup 1 --no-cpu-baseline --no-sam ;;
     trace_fp8) trace fp8_s32 --fp8 --static --steps 2 --warmup 1 $QUIET ;;
+    attn_ab)   # prefill attention with the V^T reads issued by hand (default) / left to the compiler, kernel trace of tools/probe_attn.py, twice each
+      for rep in 1 2; do for v in 0 1; do rm -rf /tmp/attn_ab
+        (cd /tmp && SR_ATTN_VASM=$v timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/attn_ab -o ab -- python $R/tools/probe_attn.py > $R/gpurun_out/r05_attn_ab.log 2>&1)
+        DB=$(find /tmp/attn_ab -name "ab_results.db" | head -1)
+        [ -n "$DB" ] && python tools/rocpd_stats.py $DB /tmp/attn_ab/stats.md > /dev/null && grep "attn" /tmp/attn_ab/stats.md | sed "s/^/SR_ATTN_VASM=$v rep $rep /" | cut -c1-200
+      done; done | tee gpurun_out/r05_attn_vasm_ab.txt ;;
+    pmc_gemm|pmc_attn)   # SQ / fetch counters of the GEMM (tools/probe_r2.py gemm) or prefill-attention (tools/probe_attn.py) kernels: one pass per group
+      if [ $stage = pmc_gemm ]; then PROBE="tools/probe_r2.py gemm"; OUT=r05_pmc_gemm256${PMC_TAG}.json; MATCH="gemm"
+        CGRP="FETCH_SIZE|SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES|SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY|SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16"
+      else PROBE="tools/probe_attn.py"; OUT=r05_pmc_attn_prefill${PMC_TAG}.json; MATCH="attn"
+        CGRP="FETCH_SIZE|SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY|SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVES|SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU|SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE|SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"
+      fi
+      rm -rf gpurun_out/pmc_r5_$stage; mkdir -p gpurun_out/pmc_r5_$stage
+      i=0; IFS='|'; for g in $CGRP; do unset IFS; i=$((i+1)); rm -rf /tmp/pmc_g$i
+        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $g -d /tmp/pmc_g$i -o p -- python $R/$PROBE > $R/gpurun_out/pmc_r5_$stage/pass$i.log 2>&1)
+        db=$(find /tmp/pmc_g$i -name "*.db" | head -1)
+        [ -n "$db" ] && python tools/rocpd_pmc.py "$db" gpurun_out/pmc_r5_$stage/pass$i.json > /dev/null 2>> gpurun_out/pmc_r5_$stage/pass$i.log
+        rm -rf /tmp/pmc_g$i; IFS='|'; done; unset IFS
+      python - gpurun_out/pmc_r5_$stage gpurun_out/$OUT $MATCH "$PROBE" <<'PY'
+import glob, json, sys
+out = {}
+for f in sorted(glob.glob(sys.argv[1] + "/pass*.json")):
+    for k, v in json.load(open(f)).items():
+        if sys.argv[3] not in k:
+            continue
+        o = out.setdefault(k, {})
+        for c, x in v.items():
+            o[c] = round(x["per_dispatch"])
+            o.setdefault("avg_us_under_pmc", round(x["avg_us"], 1))
+for k, o in out.items():
+    d = o.setdefault("derived", {})
+    if o.get("SQ_LDS_IDX_ACTIVE"):
+        d["lds_bank_conflict_over_idx_active"] = round(o.get("SQ_LDS_BANK_CONFLICT", 0) / o["SQ_LDS_IDX_ACTIVE"], 4)
+    if o.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in o:
+        d["mfma_busy_over_sq_busy_x_simds(note: counters are summed over their instances)"] = round(o["SQ_VALU_MFMA_BUSY_CYCLES"] / o["SQ_BUSY_CYCLES"], 3)
+    if o.get("SQ_WAVE_CYCLES"):
+        d["waves_issuing_frac"] = round(o.get("SQ_ACTIVE_INST_ANY", 0) / o["SQ_WAVE_CYCLES"], 3)
+        d["waves_issue_stalled_frac"] = round(o.get("SQ_WAIT_INST_ANY", 0) / o["SQ_WAVE_CYCLES"], 3)
+    if "FETCH_SIZE" in o:
+        d["fabric_read_bytes(FETCH_SIZE KiB x2, gfx950 note)"] = o["FETCH_SIZE"] * 2048
+json.dump({"source": f"rocprofv3 --kernel-trace --pmc <group> -- python {sys.argv[4]} (one pass per counter group: tools/gpu_lease.sh); counter summed over its instances per dispatch, averaged over the dispatches (tools/rocpd_pmc.py)",
+           "kernels": out}, open(sys.argv[2], "w"), indent=1)
+for k, o in out.items():
+    print(k[:70], o.get("avg_us_under_pmc"), o["derived"])
+PY
+      ;;
     pmc_gemv)
       mkdir -p gpurun_out/pmc_r5
       for v in bf16 fp8; do for c in FETCH_SIZE WRITE_SIZE; do
