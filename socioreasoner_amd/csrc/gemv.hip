@@ -440,6 +440,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
 // register quad, and with the gate/up interleave rows r and r + 16 (gate / up of one column) sit in the same lane.
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// cross-wave reduction buffer of the 32-row-tile kernels: a lane's 16 accumulators as four 16-byte quads, quad-major ([slot][quad][lane]) -- with
+// the lane-major f32x16 layout of rounds 2-4 (64 B per lane) every fourth lane of a ds_write_b128 / ds_read_b128 group shared its banks: PMC round 5,
+// SQ_LDS_BANK_CONFLICT = 0.75 of the LDS-array cycles of the 32-row down-projection (profiles/r05_pmc_lds_all.txt).  Same values, same sum order.
+__device__ __forceinline__ void rb_store(unsigned char* smem, int slot, int lane, const f32x16& a) {
+    float4* b = reinterpret_cast<float4*>(smem) + (size_t)slot * 256 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q * 64] = float4{a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+}
+__device__ __forceinline__ void rb_add(const unsigned char* smem, int slot, int lane, f32x16& a) {
+    const float4* b = reinterpret_cast<const float4*>(smem) + (size_t)slot * 256 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 o = b[q * 64];
+        a[4 * q] += o.x; a[4 * q + 1] += o.y; a[4 * q + 2] += o.z; a[4 * q + 3] += o.w;
+    }
+}
+
 template <int MODE, int KP>
 __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
     constexpr int WAVES = 4, TPB = WAVES / KP, U = 4;
@@ -502,16 +519,11 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
     }
     TGV(2);
     if constexpr (KP > 1) {
-        f32x16* rbuf = reinterpret_cast<f32x16*>(smem);          // [TPB][KP-1][64]
-        if (kp > 0) rbuf[(tp * (KP - 1) + (kp - 1)) * 64 + lane] = acc;
+        if (kp > 0) rb_store(smem, tp * (KP - 1) + (kp - 1), lane, acc);          // [TPB][KP-1] slots
         __syncthreads();
         if (kp == 0) {
 #pragma unroll
-            for (int k = 1; k < KP; ++k) {
-                const f32x16 o = rbuf[(tp * (KP - 1) + (k - 1)) * 64 + lane];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] += o[i];
-            }
+            for (int k = 1; k < KP; ++k) rb_add(smem, tp * (KP - 1) + (k - 1), lane, acc);
         }
     }
     float bestv = -INFINITY;
@@ -691,21 +703,16 @@ __global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int
         }
     }
     if constexpr (KP > 1) {
-        f32x16* rbuf = reinterpret_cast<f32x16*>(smem);          // [TPB][KP-1][G][64]
-        if (kp > 0) {
+        if (kp > 0) {                                             // [TPB][KP-1][G] slots, quad-major (rb_store)
 #pragma unroll
-            for (int g = 0; g < G; ++g) rbuf[((tp * (KP - 1) + (kp - 1)) * G + g) * 64 + lane] = acc[g];
+            for (int g = 0; g < G; ++g) rb_store(smem, (tp * (KP - 1) + (kp - 1)) * G + g, lane, acc[g]);
         }
         __syncthreads();
         if (kp == 0) {
 #pragma unroll
             for (int k = 1; k < KP; ++k)
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const f32x16 o = rbuf[((tp * (KP - 1) + (k - 1)) * G + g) * 64 + lane];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[g][i] += o[i];
-                }
+                for (int g = 0; g < G; ++g) rb_add(smem, (tp * (KP - 1) + (k - 1)) * G + g, lane, acc[g]);
         }
     }
     if constexpr (F8) {

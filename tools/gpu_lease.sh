@@ -102,6 +102,25 @@ PY
         DB=$(find /tmp/attn_ab -name "ab_results.db" | head -1)
         [ -n "$DB" ] && python tools/rocpd_stats.py $DB /tmp/attn_ab/stats.md > /dev/null && grep "attn" /tmp/attn_ab/stats.md | sed "s/^/SR_ATTN_VASM=$v rep $rep /" | cut -c1-200
       done; done | tee gpurun_out/r05_attn_vasm_ab.txt ;;
+    pmc_lds_all)   # LDS bank conflicts of EVERY kernel of the headline bench and of the SAM2 float32 encoder: which ones have any
+      for w in bench sam2; do rm -rf /tmp/pmc_lds
+        if [ $w = bench ]; then CMD="python $R/bench.py --steps 1 --warmup 1 $QUIET --no-pmc --no-pipeline"; else CMD="python $R/tools/prof_sam2_encoder.py f32"; fi
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -d /tmp/pmc_lds -o p -- $CMD > $R/gpurun_out/r05_pmc_lds_$w.log 2>&1)
+        db=$(find /tmp/pmc_lds -name "*.db" | head -1)
+        [ -n "$db" ] && python tools/rocpd_pmc.py "$db" gpurun_out/r05_pmc_lds_$w.json > /dev/null
+        python - gpurun_out/r05_pmc_lds_$w.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+rows = []
+for k, v in d.items():
+    a = v.get("SQ_LDS_IDX_ACTIVE", {}).get("per_dispatch", 0)
+    if a > 0:
+        c = v.get("SQ_LDS_BANK_CONFLICT", {}).get("per_dispatch", 0)
+        rows.append((c / a, k[:90], round(a), round(c), round(v["SQ_LDS_IDX_ACTIVE"]["avg_us"], 1), v["SQ_LDS_IDX_ACTIVE"].get("dispatches")))
+for r in sorted(rows, reverse=True):
+    print("%.3f" % r[0], *r[1:])
+PY
+      done | tee gpurun_out/r05_pmc_lds_all.txt ;;
     pmc_gemm|pmc_attn)   # SQ / fetch counters of the GEMM (tools/probe_r2.py gemm) or prefill-attention (tools/probe_attn.py) kernels: one pass per group
       if [ $stage = pmc_gemm ]; then PROBE="tools/probe_r2.py gemm"; OUT=r05_pmc_gemm256${PMC_TAG}.json; MATCH="gemm"
         CGRP="FETCH_SIZE|SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES|SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY|SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16"
