@@ -96,3 +96,24 @@ def test_round5_entry_points_are_declared_and_bound():
         assert name in hdr and name in lib.SIGNATURES
     L = lib.load()
     assert L.sr_switches_reload() == 0      # (no GPU needed: it only reads the environment)
+
+
+def test_gpu_lease_script_parses_and_documents_its_stages():
+    """tools/gpu_lease.sh is the one script behind every number under profiles/r05_*: it must parse, and every stage it can run is named in its header
+    (and the other way round) so that the list a reader sees is the list that exists."""
+    import re
+    import subprocess
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_lease.sh")
+    assert subprocess.run(["bash", "-n", path]).returncode == 0
+    text = open(path).read()
+    head = text.split('cd "$(dirname "$0")/.."')[0]
+    documented = set()
+    for line in head.splitlines():
+        m = re.match(r"#\s{3}([a-z0-9_/ |]+?)\s{2,}\S", line)
+        if m:
+            documented.update(s for s in re.split(r"[\s/|]+", m.group(1)) if s)
+    stages = set()
+    for m in re.finditer(r"^\s{4}([a-z0-9_|]+)\)", text, re.M):
+        stages.update(m.group(1).split("|"))
+    assert stages, "no stages found"
+    assert stages <= documented, sorted(stages - documented)

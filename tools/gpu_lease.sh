@@ -16,6 +16,19 @@
 #   bench       the driver's command (python bench.py)                       -> gpurun_out/r05_bench_default_line.json
 #   configs     the other configurations of README (pair, fp8, fp8-mx 896, 64 / 128 rows, no-overlap, batch 1), 2 steps each
 #   smoke       __graft_entry__.smoke()
+#   fp8tests    the fp8 GPU tests only
+#   sam2tests   the SAM2 / float32 GEMM GPU tests only
+#   tail_trace  kernel traces of the static bench with SR_TAIL_NORM=0 and 1   -> gpurun_out/r05_bench_s32_tail{0,1}_kernel_stats.md
+#   tail_headline   the headline with SR_TAIL_NORM=0 / 1 / 3, twice
+#   trace_sam2  kernel trace of the SAM2 float32 encoder (tools/prof_sam2_encoder.py) -> gpurun_out/r05_sam2_f32_*.md
+#   bench_pmc   one bench step with the in-run rocprofv3 PMC passes (roofline.traffic measured, not a file ratio)
+#   pipeline    tools/run_example_small.py with 4 scripted objects per stage, SAM2 float32 / bf16 / no answers -> gpurun_out/r05_pipeline_*.json
+#   gemm_f32    tools/bench_gemm_f32.py: the split-bf16 float32 GEMM against the f32-input MFMA kernel  -> gpurun_out/r05_gemm_f32_split.jsonl
+#   sam2bench   tools/bench_sam2_modes.py (float32 split / f32-input / bf16)  -> gpurun_out/r05_sam2_modes.json
+#   host_scaling    1 / 2 / 4 / 8 gloo ranks on the one device: host ms per scheduling round -> gpurun_out/r05_host_scaling.jsonl
+#   sched_ab    admission share from measured costs (default) against the 32-row table (SR_SCHED_ONLINE=0) at 32 / 64 / 128 rows, twice each
+#   attn_ab     prefill attention with hand-issued V^T reads (default) against SR_ATTN_VASM=0, kernel trace, twice each -> gpurun_out/r05_attn_vasm_ab.txt
+#   pmc_lds_all     LDS bank conflicts of every kernel of the bench and of the SAM2 float32 encoder -> gpurun_out/r05_pmc_lds_all.txt
 cd "$(dirname "$0")/.."
 R=$PWD
 mkdir -p gpurun_out
