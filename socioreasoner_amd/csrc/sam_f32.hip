@@ -383,7 +383,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32s(GemmF32Args p, int n_tiles
 // permutation the V^T fragment reads follow, so P never moves between lanes.  K rows have pitch HD + 2 and V rows HD + 4 floats: both
 // fragment reads are conflict-free ds_read_b32.
 template <int HD>
-__global__ __launch_bounds__(256) void k_attn_f32(AttnF32Args p) {
+// Registers: 196 at head_dim 80 with the next tile's 40 in flight = 2 blocks per CU instead of the 3 the LDS would allow.  Measured (SAM2 encoder, 8 tiles, same box):
+// 98.2 ms of attention without the prefetch, 98.1 with it at 3 blocks per CU (28 dwords spilled), 106.9 with the prefetch issued behind the S^T MFMAs, **91.5** like this.
+__global__ __launch_bounds__(256, 2) void k_attn_f32(AttnF32Args p) {
     constexpr int PK = HD + 2, PV = HD + 4, NS = HD / 4, ND = HD / 16;
     __shared__ __attribute__((aligned(16))) float Ks[64 * PK];
     __shared__ __attribute__((aligned(16))) float Vs[64 * PV];
@@ -405,21 +407,35 @@ __global__ __launch_bounds__(256) void k_attn_f32(AttnF32Args p) {
     float mrun = -INFINITY, lrun = 0.f;
     const float* kbase = p.k + (size_t)w.k_row0 * p.k_stride + h * HD;
     const float* vbase = p.v + (size_t)w.k_row0 * p.v_stride + h * HD;
+    // the K / V rows of a tile travel through registers into LDS; the NEXT tile's loads are issued right behind the barrier that publishes the current
+    // one (round 5: they used to be issued, waited for and stored between the two barriers -- a memory round trip per tile with nothing under it)
+    constexpr int NL = HD / 16;                                     // float4 per thread, tile and operand (64 keys x HD / 4 chunks over 256 threads)
+    float4 kreg[NL], vreg[NL];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 256, r = e / (HD / 4), d4 = (e % (HD / 4)) * 4;
+            kreg[i] = float4{0.f, 0.f, 0.f, 0.f};
+            vreg[i] = kreg[i];
+            if (j0 + r < w.seq_len) {
+                kreg[i] = *reinterpret_cast<const float4*>(kbase + (size_t)(j0 + r) * p.k_stride + d4);
+                vreg[i] = *reinterpret_cast<const float4*>(vbase + (size_t)(j0 + r) * p.v_stride + d4);
+            }
+        }
+    };
+    fetch(0);
     for (int j0 = 0; j0 < w.seq_len; j0 += 64) {
         __syncthreads();                                            // the previous tile's fragment reads are done
-        for (int e = tid; e < 64 * (HD / 4); e += 256) {
-            const int r = e / (HD / 4), d4 = (e % (HD / 4)) * 4;
-            float4 kv = float4{0.f, 0.f, 0.f, 0.f}, vv = kv;
-            if (j0 + r < w.seq_len) {
-                kv = *reinterpret_cast<const float4*>(kbase + (size_t)(j0 + r) * p.k_stride + d4);
-                vv = *reinterpret_cast<const float4*>(vbase + (size_t)(j0 + r) * p.v_stride + d4);
-            }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 256, r = e / (HD / 4), d4 = (e % (HD / 4)) * 4;
             float2* kd = reinterpret_cast<float2*>(Ks + r * PK + d4);          // (pitch HD + 2: rows are 8-byte aligned)
-            kd[0] = float2{kv.x, kv.y};
-            kd[1] = float2{kv.z, kv.w};
-            *reinterpret_cast<float4*>(Vs + r * PV + d4) = vv;
+            kd[0] = float2{kreg[i].x, kreg[i].y};
+            kd[1] = float2{kreg[i].z, kreg[i].w};
+            *reinterpret_cast<float4*>(Vs + r * PV + d4) = vreg[i];
         }
         __syncthreads();
+        if (j0 + 64 < w.seq_len) fetch(j0 + 64);
         if (!wave_live) continue;               // (round 5) a wave without a query keeps only the barriers: Hiera's 196-token windows leave 3 of a window's 16 waves empty
         // live 16-key sub-tiles of this 64-key tile (round 5): a window of 196 keys ends in a tile of 4 -- its three dead sub-tiles used to cost as much
         // as live ones (S = -inf, P = 0, 0 x V added: skipping them changes no bit)
