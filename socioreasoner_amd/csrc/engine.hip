@@ -89,6 +89,7 @@ static void load_switches() {
     g_sw.attn_vasm = env_int("SR_ATTN_VASM", 1);
     g_sw.sam_f32_split = env_int("SR_SAM_F32_SPLIT", 1);
     g_sw.tail_norm = env_int("SR_TAIL_NORM", 0);
+    g_sw.head_norm = env_int("SR_HEAD_NORM", 0);
     g_sw_loaded = true;
 }
 const SrSwitches& sr_switches() {
@@ -137,6 +138,7 @@ struct sr_engine {
     float *d_logits, *d_slabs, *d_amax_val;
     float* d_row_cs = nullptr;               // [MAXB][128] rotary cos | sin of every row's current position (k_step -> decode attention)
     unsigned* d_tail = nullptr;              // [2 * layers] arrival tickets of the decode GEMV tails (rownorm.h) + [1] give-up count; zeroed at the head of every forward
+    int head_norm = 0;                       // round 5: RMSNorm in front of q/k/v (bit 0) / gate/up (bit 1) of a 5..32-row decode layer as the first blocks of that GEMV launch (GemvHead)
     int tail_norm = 0;                       // round 5: RMSNorm of a 5..32-row decode layer inside the o_proj (bit 0) / down-projection (bit 1) launches; OFF by default: measured
                                              // 0.5 / 1.0 / 1.4 % SLOWER per decode step than the two RMSNorm launches (SR_TAIL_NORM=1 / 2 / 3)
     int *d_amax_idx, *d_cur_tok, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
@@ -349,7 +351,7 @@ void carve(sr_engine* e) {
     e->d_amax_idx_adm = ar.take<int>(B * e->n_part);
     e->d_row_limit = ar.take<int>(MAXB);
     e->d_row_cs = ar.take<float>(MAXB * 128);
-    e->d_tail = ar.take<unsigned>((size_t)2 * c.t_layers + 64);
+    e->d_tail = ar.take<unsigned>((size_t)4 * c.t_layers + 64);      // [2L] head counters | [2L] tail tickets | give-up count
     e->d_ngen = ar.take<int>(MAXB);
     e->d_adm = ar.take<int>(5 * MAXB);
     e->d_adm_slots = ar.take<int>(MAXB);
@@ -606,9 +608,21 @@ int tail_norms(const sr_engine* e, int B) {
     if (f8) go.W8 = gd.W8 = reinterpret_cast<const unsigned char*>(e);      // (only its null-ness matters)
     return (gemv_launch_blocks(go, GV_RESID) >= B && gemv_launch_blocks(gd, GV_PARTIAL) >= B) ? (e->tail_norm & 3) : 0;      // one tail block per row
 }
+// round 5: the RMSNorm launches in front of q/k/v (bit 0) and gate/up (bit 1) of a 5..32-row decode layer become the FIRST blocks of those GEMV launches
+// (GemvHead: the GEMV blocks stream their first weight ring while the rows are normalised).  bf16 weight stream only; a norm a tail already does is not a head.
+int head_norms(const sr_engine* e, int B) {
+    if (!e->head_norm || fused_norms(e, B) || B > 32 || B < 5 || !x_tiled_ok(e) || e->c.lm_weight_dtype != 0) return 0;
+    return e->head_norm & 3 & ~((tail_norms(e, B) & 2 ? 1 : 0) | (tail_norms(e, B) & 1 ? 2 : 0));
+}
+GemvHead make_head(sr_engine* e, int idx, const bf16_t* norm_w, bf16_t* x, const float* part, int ksplit, int rows) {
+    GemvHead h{};
+    h.counter = e->d_tail + idx; h.timeout = e->d_tail + 4 * e->c.t_layers;
+    h.x = x; h.part = part; h.ksplit = ksplit; h.norm_w = norm_w; h.eps = e->c.t_rms_eps; h.rows = rows;
+    return h;
+}
 GemvTail make_tail(sr_engine* e, int idx, const bf16_t* norm_w, bf16_t* x) {
     GemvTail t{};
-    t.counter = e->d_tail + idx; t.timeout = e->d_tail + 2 * e->c.t_layers;
+    t.counter = e->d_tail + 2 * e->c.t_layers + idx; t.timeout = e->d_tail + 4 * e->c.t_layers;
     t.norm_w = norm_w; t.eps = e->c.t_rms_eps; t.xn = e->d_xn; t.xn_tiled = 1; t.x = x;
     return t;
 }
@@ -648,7 +662,9 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
     const float scale = (float)(1.0 / sqrt(128.0));
     const int tails = tail_norms(e, B);
     const bool tail_o = tails & 1, tail_d = tails & 2;      // (tail_d: k_step wrote ln1(x) of layer 0 into d_xn, enqueue_step)
-    if (tails) SR_TRY((int)hipMemsetAsync(e->d_tail, 0, (size_t)2 * c.t_layers * sizeof(unsigned), s));     // a memset node at the head of the captured step
+    const int heads = head_norms(e, B);
+    const bool head_q = heads & 1, head_g = heads & 2;
+    if (tails || heads) SR_TRY((int)hipMemsetAsync(e->d_tail, 0, (size_t)4 * c.t_layers * sizeof(unsigned), s));     // a memset node at the head of the captured step
     for (int l = 0; l < c.t_layers; ++l) {
         const LmLayerW& w = e->ll[l];
         bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
@@ -660,6 +676,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
             if (pending) { gq.slabs = e->d_slabs; gq.n_slabs = ks_down(e, B); gq.x_out = x_alt; }
         } else {
             if (tail_d) {}     // d_xn = ln1(x) is there: k_step (layer 0) or the previous down-projection's tail
+            else if (head_q) gq.head = make_head(e, 2 * l, w.ln1, x, pending ? e->d_slabs : nullptr, pending ? ks_down(e, B) : 0, B);
             else if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, ks_down(e, B), w.ln1, e->d_xn, B, H, c.t_rms_eps, xt));
             else SR_TRY(launch_rmsnorm(s, x, w.ln1, e->d_xn, B, H, c.t_rms_eps, xt));
             gq.x = e->d_xn; gq.x_tiled = xt;
@@ -689,7 +706,9 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
             gg.M = 0;       // (done)
         }
         else {
-            if (!tail_o) SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt));
+            if (tail_o) {}
+            else if (head_g) gg.head = make_head(e, 2 * l + 1, w.ln2, x, nullptr, 0, B);
+            else SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt));
             gg.x = e->d_xn; gg.x_tiled = xt; gg.out_tiled = xt;
         }
         if (gg.M > 0) SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
@@ -724,7 +743,7 @@ int sr_tail_timeouts(sr_engine* e, void* stream) {
     if (!e) return -22;
     enter(e);
     unsigned v = 0;
-    if (hipMemcpyAsync(&v, e->d_tail + 2 * e->c.t_layers, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -5;
+    if (hipMemcpyAsync(&v, e->d_tail + 4 * e->c.t_layers, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -5;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -5;
     return (int)v;
 }
@@ -747,6 +766,7 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
     e->c = *cfg;
     load_switches();                            // the environment is read here (and by sr_switches_reload), never in per-call dispatch
     e->tail_norm = g_sw.tail_norm;
+    e->head_norm = g_sw.head_norm;
     snprintf(e->err, sizeof e->err, "ok");
     {   // the engine belongs to the device that owns the workspace, whatever the calling thread's current device is
         hipPointerAttribute_t pa{};
@@ -777,7 +797,7 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
     if (r == hipSuccess) r = hipMemset(e->vtcache, 0, e->kv_layer_elems * e->c.t_layers * sizeof(bf16_t));
     if (r == hipSuccess) r = hipMemset(e->d_cur_tok, 0, (char*)e->d_tokens - (char*)e->d_cur_tok);
     if (r == hipSuccess) r = hipMemset(e->v_vt, 0, (size_t)e->c.v_hidden * e->v_vt_stride * sizeof(bf16_t));
-    if (r == hipSuccess) r = hipMemset(e->d_tail, 0, ((size_t)2 * e->c.t_layers + 64) * sizeof(unsigned));
+    if (r == hipSuccess) r = hipMemset(e->d_tail, 0, ((size_t)4 * e->c.t_layers + 64) * sizeof(unsigned));
     // normalise LUT (hf image_transforms.py:89-124, 384-440) and rotary inverse frequencies (hf:506-523)
     std::vector<bf16_t> lut(768);
     const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f}, stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};

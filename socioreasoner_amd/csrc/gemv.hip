@@ -56,7 +56,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int tp = wave / KP, kp = wave % KP;
-    const int tile = blockIdx.x * TPB + tp;            // in units of T tiles
+    // round 5, GemvHead: the first nh blocks of the launch are one RMSNorm row each (they produce this launch's x); the GEMV blocks behind them
+    // stream their first weight ring, then wait for the nh arrivals.  Block dispatch is in index order and the whole grid is resident at once
+    // (<= 720 blocks of 256 threads), so a waiting block never keeps a head block off the chip.
+    constexpr bool HEAD_OK = !STAGE && !F8 && WAVES == 4 && (MODE == GV_BIAS || MODE == GV_SWIGLU);
+    int nh = 0;
+    if constexpr (HEAD_OK) nh = p.head.counter ? p.head.rows : 0;
+    if constexpr (HEAD_OK) {
+        if ((int)blockIdx.x < nh) {
+            rmsnorm_row_body<false>(p.head.x, p.head.x, false, p.head.part, p.head.ksplit, p.head.norm_w, const_cast<bf16_t*>(p.x), nh, (int)blockIdx.x, p.K,
+                                    p.head.eps, p.x_tiled, reinterpret_cast<float*>(smem), true);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have left
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(p.head.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+    const int tile = ((int)blockIdx.x - nh) * TPB + tp;            // in units of T tiles
     const bool active = tile < ntiles;
     const int nchunks = p.K / 64;
     const int ks = (MODE == GV_PARTIAL) ? p.ksplit : 1;
@@ -258,11 +274,30 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
             // Behind the weights the x loads of the first ring only started to arrive when ALL of it had landed (launches whose whole K
             // fits the first ring -- qkv, o_proj: 3.2 us for W, then 1.3 us of x through the CU's load path, tools/probe_gemv_timeline.py);
             // in front of them they travel during the HBM latency.
+            if (nh == 0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (c0 + u < cend) fill_x(u, c0 + u);
+                for (int u = 0; u < U; ++u)
+                    if (c0 + u < cend) fill_x(u, c0 + u);
+            }
         }
         if constexpr (!STAGE) first_fills();
+        if constexpr (HEAD_OK) {
+            if (nh) {       // the weights are on their way; x exists once every head block has arrived (their rows were written through: first touch here
+                            // misses this CU's L1 and -- the launch started with its non-coherent lines invalidated -- this XCD's L2)
+                if (tid == 0) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(p.head.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nh) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1u << 22)) { atomicAdd(p.head.timeout, 1u); break; }     // never hang the GPU
+                    }
+                }
+                __syncthreads();
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (c0 + u < cend) fill_x(u, c0 + u);
+            }
+        }
         TGV(1);
         for (int c = c0; c < cend; c += U) {
 #pragma unroll
@@ -858,7 +893,7 @@ int launch_k(hipStream_t s, const GemvArgs& a) {
     constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;
     constexpr int TPB = WAVES / KP;
     const int ntiles = a.N / (16 * T);
-    dim3 grid(cdiv(ntiles, TPB), MODE == GV_PARTIAL ? a.ksplit : 1);
+    dim3 grid(cdiv(ntiles, TPB) + (a.head.counter ? a.head.rows : 0), MODE == GV_PARTIAL ? a.ksplit : 1);
     size_t red = (size_t)TPB * (KP > 1 ? KP - 1 : 0) * T * MT * 64 * sizeof(f32x4);
     if (MODE == GV_F32) red = red > (size_t)WAVES * 32 * 8 ? red : (size_t)WAVES * 32 * 8;
     size_t smem;
@@ -946,7 +981,7 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     if (a.M <= 0) return 0;
     if (a.M > 128 || a.K % 64 != 0 || a.N % 16 != 0) return -22;
     if (a.M > 32) {      // 33..128 rows: the 32-row-tile kernel over 2 / 4 row groups per weight pass (bf16 stream, no fused norm)
-        if (a.N % 32 != 0 || a.norm_w || a.n_slabs || a.tail.counter) return -22;
+        if (a.N % 32 != 0 || a.norm_w || a.n_slabs || a.tail.counter || a.head.counter) return -22;
         if (a.W8 && (!a.w_scale || mode == GV_F32)) return -22;
         if (mode == GV_PARTIAL && (a.ksplit < 1 || a.ksplit > a.K / 64)) return -22;
         if (a.out_tiled && (mode != GV_SWIGLU || (a.N / 2) % 64 != 0)) return -22;
@@ -971,6 +1006,11 @@ int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
     if (a.out_tiled && (mode != GV_SWIGLU || (a.N / 2) % 64 != 0)) return -22;
     int want = mode == GV_F32 ? 1 : 4;
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
+    if (a.head.counter) {       // in-launch RMSNorm of the INPUT rows by the first M blocks (GemvHead): the un-staged bf16 16-row-tile kernel only
+        if (!(mode == GV_BIAS || mode == GV_SWIGLU) || a.norm_w || a.W8 || a.M < 5 || use_32(a, mode) || kp != 4) return -22;
+        if (!a.head.timeout || !a.head.norm_w || !a.head.x || a.head.rows != a.M || a.K > 2048 || a.K % 64 != 0 || !a.x_tiled) return -22;
+        if (a.head.part && (a.head.ksplit < 1 || a.head.ksplit > 4)) return -22;
+    }
     if (a.tail.counter) {       // in-launch RMSNorm of the output rows by the last M blocks to arrive (rownorm.h): one 256-thread block per row
         if (!(mode == GV_RESID || mode == GV_PARTIAL) || a.norm_w || a.N > 2048 || a.N % 8 != 0) return -22;
         if (!a.tail.timeout || !a.tail.norm_w || !a.tail.xn || !a.tail.x) return -22;

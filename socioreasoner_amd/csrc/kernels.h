@@ -17,6 +17,7 @@ struct SrSwitches {
     int attn_win64;     // SR_ATTN_WIN64  0: no 64-token window kernel (default 1)
     int attn_vasm;      // SR_ATTN_VASM   0: V^T fragment reads of k_attn_prefill2 left to the compiler (ds_read2st64_b64, 2-way bank conflicts; default 1: hand-issued ds_read_b64)
     int sam_f32_split;  // SR_SAM_F32_SPLIT 0: SAM2's float32 GEMM on the f32-input MFMA (round 4) instead of the three-term bf16 split on the bf16 pipe (default 1)
+    int head_norm;      // SR_HEAD_NORM   bit 0 / bit 1: the RMSNorm in front of q/k/v / of gate/up of a 5..32-row decode layer runs as the first blocks of that GEMV launch (default 0)
     int tail_norm;      // SR_TAIL_NORM   bit 0 / bit 1: the RMSNorm after o_proj / after the down-projection of a 5..32-row decode layer runs INSIDE that GEMV launch
                         //                (its last-arriving blocks, rownorm.h) instead of as a launch of its own.  Default 0: bit-identical, measured slower.
                         //                Read at sr_engine_create.
@@ -94,6 +95,17 @@ struct GemvTail {
     bf16_t* x;                  // residual stream [M][H].  PARTIAL: read, h = r(x + r(sum slabs)) written back; RESID: the launch's own output
 };
 
+// what a GEMV launch needs to PRODUCE its own normalised x (GemvArgs.head, round 5): the first `rows` blocks of the launch are one RMSNorm row each
+// (rmsnorm_row_body, rownorm.h), the GEMV blocks behind them stream their first weight ring and then wait for `rows` arrivals on `counter`
+struct GemvHead {
+    unsigned* counter;          // zero when the launch starts (memset node at the head of the decode forward); null: no head
+    unsigned* timeout;          // a GEMV block that gave up waiting adds 1 here (never in a healthy run)
+    bf16_t* x;                  // residual stream [rows][K] (updated in place when part != null)
+    const float* part; int ksplit;      // pending float32 slabs of the previous down-projection (another launch), or null
+    const bf16_t* norm_w; float eps;
+    int rows;
+};
+
 struct GemvArgs {
     const bf16_t* x; int ldx;   // [M, K] B operand; with norm_w: the residual stream the RMSNorm prologue reads
     const bf16_t* W;            // [N, K]
@@ -113,6 +125,7 @@ struct GemvArgs {
                                             // x load is 1 KB contiguous instead of 16 rows x 64 B (batches > 4, no fused norm)
     int out_tiled;                          // SWIGLU: write the activation fragment-ordered (it is the next GEMV's x)
     int force32;                            // always the 32-row MFMA variant (whatever M): a row's result then does not depend on how many rows share the launch
+    GemvHead head;                          // BIAS / SWIGLU at 5..32 rows on the un-staged 16-row-tile kernel: the launch normalises its own x first (x = the fragment-ordered buffer the head writes)
     GemvTail tail;                          // RESID / PARTIAL at 5..32 rows, N <= 2048: the launch also normalises its rows (round 5); counter null = off
 };
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode);

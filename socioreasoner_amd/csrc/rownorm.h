@@ -31,7 +31,7 @@ __device__ __forceinline__ void st8_sc1(void* p, uint2 v) {     // global_store_
 // COH: `part` (and xin when coh_x) were written by other blocks of this launch -- sc1 loads.  wsum: 4 floats of LDS.
 template <bool COH>
 __device__ __forceinline__ void rmsnorm_row_body(bf16_t* x, const bf16_t* xin, bool coh_x, const float* part, int ksplit, const bf16_t* w,
-                                                 bf16_t* out, int rows, int row, int H, float eps, int out_tiled, float* wsum) {
+                                                 bf16_t* out, int rows, int row, int H, float eps, int out_tiled, float* wsum, bool wt_out = false) {
     const int c = threadIdx.x, nch = H / 8;
     const bool on = c < nch;
     uint4 u = uint4{0, 0, 0, 0}, wu = uint4{0, 0, 0, 0};
@@ -89,8 +89,11 @@ __device__ __forceinline__ void rmsnorm_row_body(bf16_t* x, const bf16_t* xin, b
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = wv[e] * rbf(v[e] * rs);
         // fragment order: the 8 consecutive k of one row stay contiguous (16 B), see tiled_offset in common.h
-        bf16_t* dst = out + (out_tiled ? tiled_offset((size_t)row, (size_t)c * 8, (size_t)H) : (size_t)row * H + c * 8);
-        *reinterpret_cast<uint4*>(dst) = uint4{pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+        const size_t di = out_tiled ? tiled_offset((size_t)row, (size_t)c * 8, (size_t)H) : (size_t)row * H + c * 8;
+        const uint4 ov = uint4{pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+        // wt_out: other blocks of THIS launch read the row (GemvHead): write-through.  (Fragment order pads the rows to a multiple of 16.)
+        if (wt_out) st16_sc1(sr_rsrc(out, (unsigned)((rows + 15) / 16 * 16) * H * 2), (unsigned)di * 2, sr_u32x4{ov.x, ov.y, ov.z, ov.w});
+        else *reinterpret_cast<uint4*>(out + di) = ov;
     }
 }
 

@@ -6,6 +6,7 @@
 # Stages:
 #   tests5      tests/test_gpu_round5.py
 #   suite       the whole -m gpu suite
+#   head_ab     static 32-row bench with SR_HEAD_NORM=0 / 1 / 2 / 3 (RMSNorm rows as the first blocks of the consuming GEMV launch), twice
 #   tail_ab     static 32-row bench with SR_TAIL_NORM=0 / 1 (same box, interleaved twice), decode step ms of each
 #   trace_s32   rocprofv3 kernel trace of the static 32-row bench            -> gpurun_out/r05_bench_s32_kernel_stats.md
 #   trace_c32   ... of the headline (continuous) configuration               -> gpurun_out/r05_bench_c32_kernel_stats.md
@@ -99,6 +100,11 @@ PY
     sam2bench) timeout 900 python tools/bench_sam2_modes.py | tee gpurun_out/r05_sam2_modes.json ;;
     sam2tests) timeout 1500 python -m pytest tests/test_gpu_sam2.py tests/test_gpu_round4.py -x -q -m gpu -k "sam2 or gemm_f32 or seg_infer" 2>&1 | tail -8 ;;
     smoke)  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
+    head_ab)   # RMSNorms as the first blocks of the q/k/v / gate/up launches (SR_HEAD_NORM bit mask) against the launches, static 32-row bench, twice
+      for rep in 1 2; do for t in 0 1 2 3; do
+        SR_HEAD_NORM=$t timeout 600 python bench.py --static --steps 3 --warmup 1 $QUIET > gpurun_out/r05_head_${t}.log 2> gpurun_out/r05_head_${t}.err
+        line gpurun_out/r05_head_${t}.log "SR_HEAD_NORM=$t rep $rep:"
+      done; done | tee gpurun_out/r05_head_norm_ab.txt ;;
     tail_ab)
       for rep in 1 2; do for t in 0 1 2 3; do
         SR_TAIL_NORM=$t timeout 600 python bench.py --static --steps 3 --warmup 1 $QUIET > gpurun_out/r05_tail_${t}_$rep.log 2> gpurun_out/r05_tail_${t}_$rep.err
