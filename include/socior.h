@@ -297,9 +297,10 @@ int sr_version(void);
  * (the bit-identity tests do) calls this to have the environment read again.  No reference counterpart (vLLM reads its VLLM_* variables at
  * import: roll/distributed/strategy/vllm_strategy.py:13-30). */
 int sr_switches_reload(void);
-/* Round 5: at 5..32 decode rows the RMSNorms of a layer run inside the o_proj / down-projection launches (their last-arriving blocks; hf
- * modeling_qwen2_5_vl.py:65-79, 708-758).  A tail block that gives up waiting for the launch's other blocks counts here -- 0 in a healthy
- * run (tests assert it); a negative value is an error. */
+/* Round 5: at 5..32 decode rows the RMSNorms of a layer CAN run inside their neighbouring GEMV launches (hf modeling_qwen2_5_vl.py:65-79, 708-758):
+ * as the last-arriving blocks of the o_proj / down-projection launch (SR_TAIL_NORM) or as the first blocks of the q/k/v / gate/up launch
+ * (SR_HEAD_NORM); both are bit-identical to the RMSNorm launches, measured slower, and off by default.  A block that gives up waiting for the
+ * launch's other blocks counts here -- 0 in a healthy run (tests assert it); a negative value is an error. */
 int sr_tail_timeouts(sr_engine* e, void* stream);
 
 #ifdef __cplusplus
