@@ -12,7 +12,7 @@
 #   trace_c32   ... of the headline (continuous) configuration               -> gpurun_out/r05_bench_c32_kernel_stats.md
 #   trace_b1    ... of batch 1                                               -> gpurun_out/r05_bench_b1_kernel_stats.md
 #   trace_fp8   ... of --fp8 static 32 rows                                  -> gpurun_out/r05_bench_fp8_s32_kernel_stats.md
-#   pmc_gemm / pmc_attn   SQ + FETCH_SIZE passes of the GEMM / prefill-attention kernels -> gpurun_out/r05_pmc_gemm256.json / r05_pmc_attn_prefill.json
+#   pmc_gemm / pmc_attn / pmc_sam2   SQ (+ FETCH_SIZE) passes of the GEMM / prefill-attention / SAM2 float32 kernels -> gpurun_out/r05_pmc_gemm256.json / r05_pmc_attn_prefill.json / r05_pmc_sam2_f32.json
 #   pmc_gemv    FETCH_SIZE / WRITE_SIZE passes of the decode weight stream (bf16 and fp8) -> gpurun_out/r05_pmc_gemv_traffic*.json
 #   bench       the driver's command (python bench.py)                       -> gpurun_out/r05_bench_default_line.json
 #   configs     the other configurations of README (pair, fp8, fp8-mx 896, 64 / 128 rows, no-overlap, batch 1), 2 steps each
@@ -140,9 +140,11 @@ for r in sorted(rows, reverse=True):
     print("%.3f" % r[0], *r[1:])
 PY
       done | tee gpurun_out/r05_pmc_lds_all.txt ;;
-    pmc_gemm|pmc_attn)   # SQ / fetch counters of the GEMM (tools/probe_r2.py gemm) or prefill-attention (tools/probe_attn.py) kernels: one pass per group
+    pmc_gemm|pmc_attn|pmc_sam2)   # SQ / fetch counters of the GEMM (tools/probe_r2.py gemm) or prefill-attention (tools/probe_attn.py) kernels: one pass per group
       if [ $stage = pmc_gemm ]; then PROBE="tools/probe_r2.py gemm"; OUT=r05_pmc_gemm256${PMC_TAG}.json; MATCH="gemm"
         CGRP="FETCH_SIZE|SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES|SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY|SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16"
+      elif [ $stage = pmc_sam2 ]; then PROBE="tools/prof_sam2_encoder.py f32"; OUT=r05_pmc_sam2_f32${PMC_TAG}.json; MATCH="f32"
+        CGRP="SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES|SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY|SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS|SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"
       else PROBE="tools/probe_attn.py"; OUT=r05_pmc_attn_prefill${PMC_TAG}.json; MATCH="attn"
         CGRP="FETCH_SIZE|SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY|SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVES|SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU|SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE|SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"
       fi
