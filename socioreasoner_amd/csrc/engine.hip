@@ -90,6 +90,7 @@ static void load_switches() {
     g_sw.sam_f32_split = env_int("SR_SAM_F32_SPLIT", 1);
     g_sw.tail_norm = env_int("SR_TAIL_NORM", 0);
     g_sw.head_norm = env_int("SR_HEAD_NORM", 0);
+    g_sw.gemv_counted = env_int("SR_GEMV_COUNTED", 1);
     g_sw_loaded = true;
 }
 const SrSwitches& sr_switches() {

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     constexpr int NT = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TGV(0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform for the compiler too: scalar branches)
     const int fr = lane & 15, fg = lane >> 4;
     const int tp = wave / KP, kp = wave % KP;
     // round 5, GemvHead: the first nh blocks of the launch are one RMSNorm row each (they produce this launch's x); the GEMV blocks behind them
@@ -269,6 +269,74 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                 }
             }
         };
+        // round 5, counted path (fragment-ordered x, no head): every fill is UNCONDITIONAL -- the chunk index is clamped to the wave's last chunk (at most
+        // U - 1 redundant chunk loads per wave, L2 hits), the steady rounds refill every slot and only the peeled last round asks whether a chunk
+        // exists.  With a load behind `if (chunk exists)` hipcc's vmcnt bookkeeping collapses to `vmcnt(0)` at the top of every round (see k_gemv32).
+        bool counted = false;
+        if constexpr (!STAGE) counted = p.counted && p.x_tiled && nh == 0 && cend > c0;
+        if constexpr (!STAGE) {
+            if (counted) {
+                auto fill_c = [&](int u, int c) {
+                    c = min(c, cend - 1);
+                    fill_w(u, c);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const bf16_t* xt = p.x + ((size_t)(mt * nchunks + c) * 2) * 512 + lane * 8;
+                        xv[u][mt][0] = *reinterpret_cast<const u32x4*>(xt);
+                        xv[u][mt][1] = *reinterpret_cast<const u32x4*>(xt + 512);
+                    }
+                };
+                auto consume = [&](int u) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        u32x4 w0, w1;
+                        if constexpr (F8) {
+                            const u32x4 q = w[u][t][0];
+                            uint32_t d[8];
+                            f8x4_to_bf16(q[0], d[0], d[1]); f8x4_to_bf16(q[1], d[2], d[3]);
+                            f8x4_to_bf16(q[2], d[4], d[5]); f8x4_to_bf16(q[3], d[6], d[7]);
+                            w0 = u32x4{d[0], d[1], d[2], d[3]};
+                            w1 = u32x4{d[4], d[5], d[6], d[7]};
+                        } else {
+                            w0 = w[u][t][0];
+                            w1 = w[u][t][WL - 1];
+                        }
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w0), as_frag(xv[u][mt][0]), acc[t][mt], 0, 0, 0);
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w1), as_frag(xv[u][mt][1]), acc[t][mt], 0, 0, 0);
+                        }
+                    }
+                };
+                const int rounds = (cend - c0 + U - 1) / U;
+                // x in front of the weights in the first ring (in-order return: x comes from L2, W from HBM -- see below)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int c = min(c0 + u, cend - 1);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const bf16_t* xt = p.x + ((size_t)(mt * nchunks + c) * 2) * 512 + lane * 8;
+                        xv[u][mt][0] = *reinterpret_cast<const u32x4*>(xt);
+                        xv[u][mt][1] = *reinterpret_cast<const u32x4*>(xt + 512);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) fill_w(u, min(c0 + u, cend - 1));
+                TGV(1);
+                for (int r = 0; r + 1 < rounds; ++r) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        consume(u);
+                        fill_c(u, c0 + (r + 1) * U + u);
+                    }
+                }
+                const int last = c0 + (rounds - 1) * U;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (last + u < cend) consume(u);
+            }
+        }
+        if (!counted) {
         if constexpr (!STAGE) {
             // x BEFORE the weights: a wave's loads return in issue order, x comes from L2 (the previous launch wrote it) and W from HBM.
             // Behind the weights the x loads of the first ring only started to arrive when ALL of it had landed (launches whose whole K
@@ -334,6 +402,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                 }
             }
         }
+        }      // !counted
     }
 
     TGV(2);
@@ -492,12 +561,17 @@ __device__ __forceinline__ void rb_add(const unsigned char* smem, int slot, int 
     }
 }
 
-template <int MODE, int KP>
+// AW (round 5, "all refills unconditional"): hipcc's vmcnt bookkeeping gives up on the ring loop as written below -- every refill sits behind `if (chunk
+// exists)`, and at the loop header the counts of the entry edge and the back edge merge to "unknown": the generated code waits for vmcnt(0) at the top of
+// every round (disassembly, round 5), i.e. the whole ring lands before the first MFMA of a round and the refills of a round only start to arrive when the
+// round is over -- a ring in name only.  Here the steady rounds refill EVERY slot (chunk index clamped to the wave's last chunk: at most U - 1 redundant
+// 1-KB loads per wave, L2 hits) and only the peeled last round asks whether a chunk exists -- no load sits behind a condition, the waits are counted.
+template <int MODE, int KP, bool AW>
 __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
     constexpr int WAVES = 4, TPB = WAVES / KP, U = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TGV(0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = AW ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;      // (AW: the chunk range must be wave-uniform for the compiler too)
     const int fr = lane & 15, half = (lane >> 4) & 1, kg = lane >> 5, m = lane & 31;
     const int tp = wave / KP, kp = wave % KP;
     const int tile = blockIdx.x * TPB + tp;
@@ -531,6 +605,41 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if constexpr (AW) {
+        const int n = cend - c0;
+        if (active && n > 0) {
+            // (rows >= M of an un-tiled x read row 0 -- valid memory; their output columns are never stored)
+            auto fill_a = [&](int u, int c) {
+                c = min(c, cend - 1);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) xv[u][st] = *reinterpret_cast<const u32x4*>(xbase + (size_t)c * x_c + st * x_s);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) w[u][st] = ldg_nt(wbase + (size_t)c * w_c + st * w_s);
+            };
+            const int rounds = (n + U - 1) / U;
+#pragma unroll
+            for (int u = 0; u < U; ++u) fill_a(u, c0 + u);
+            TGV(1);
+            for (int r = 0; r + 1 < rounds; ++r) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(w[u][st]), as_frag(xv[u][st]), acc, 0, 0, 0);
+                    fill_a(u, c0 + (r + 1) * U + u);
+                }
+            }
+            const int last = c0 + (rounds - 1) * U;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (last + u < cend) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(w[u][st]), as_frag(xv[u][st]), acc, 0, 0, 0);
+                }
+            }
+        }
+    } else
     if (active) {
         // first ring: x (L2) in front of the weights (HBM) -- loads return in issue order, see k_gemv
 #pragma unroll
@@ -881,7 +990,8 @@ int launch_32(hipStream_t s, const GemvArgs& a) {
     dim3 grid(cdiv(ntiles, TPB), MODE == GV_PARTIAL ? a.ksplit : 1);
     size_t smem = (size_t)TPB * (KP > 1 ? KP - 1 : 0) * 64 * sizeof(f32x16);
     if (smem < 4 * 32 * 8) smem = 4 * 32 * 8;
-    hipLaunchKernelGGL((k_gemv32<MODE, KP>), grid, dim3(256), smem, s, a, ntiles);
+    if (sr_switches().gemv_counted) hipLaunchKernelGGL((k_gemv32<MODE, KP, true>), grid, dim3(256), smem, s, a, ntiles);
+    else hipLaunchKernelGGL((k_gemv32<MODE, KP, false>), grid, dim3(256), smem, s, a, ntiles);
     SR_CHECK_LAUNCH();
     return 0;
 }
@@ -977,7 +1087,9 @@ int gemv_launch_blocks(const GemvArgs& a, int mode) {
     return cdiv(a.N / rows_per_tile, 4 / kp) * (mode == GV_PARTIAL ? a.ksplit : 1);
 }
 
-int launch_gemv(hipStream_t s, const GemvArgs& a, int mode) {
+int launch_gemv(hipStream_t s, const GemvArgs& a_, int mode) {
+    GemvArgs a = a_;
+    a.counted = sr_switches().gemv_counted;      // (SR_GEMV_COUNTED: the loops whose refills are all unconditional)
     if (a.M <= 0) return 0;
     if (a.M > 128 || a.K % 64 != 0 || a.N % 16 != 0) return -22;
     if (a.M > 32) {      // 33..128 rows: the 32-row-tile kernel over 2 / 4 row groups per weight pass (bf16 stream, no fused norm)

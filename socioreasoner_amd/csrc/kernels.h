@@ -17,6 +17,7 @@ struct SrSwitches {
     int attn_win64;     // SR_ATTN_WIN64  0: no 64-token window kernel (default 1)
     int attn_vasm;      // SR_ATTN_VASM   0: V^T fragment reads of k_attn_prefill2 left to the compiler (ds_read2st64_b64, 2-way bank conflicts; default 1: hand-issued ds_read_b64)
     int sam_f32_split;  // SR_SAM_F32_SPLIT 0: SAM2's float32 GEMM on the f32-input MFMA (round 4) instead of the three-term bf16 split on the bf16 pipe (default 1)
+    int gemv_counted;   // SR_GEMV_COUNTED 0: the decode GEMVs' ring loops with a refill behind `if (chunk exists)` (rounds 1-4: hipcc then waits vmcnt(0) every round); default 1: every refill unconditional, counted waits
     int head_norm;      // SR_HEAD_NORM   bit 0 / bit 1: the RMSNorm in front of q/k/v / of gate/up of a 5..32-row decode layer runs as the first blocks of that GEMV launch (default 0)
     int tail_norm;      // SR_TAIL_NORM   bit 0 / bit 1: the RMSNorm after o_proj / after the down-projection of a 5..32-row decode layer runs INSIDE that GEMV launch
                         //                (its last-arriving blocks, rownorm.h) instead of as a launch of its own.  Default 0: bit-identical, measured slower.
@@ -125,6 +126,7 @@ struct GemvArgs {
                                             // x load is 1 KB contiguous instead of 16 rows x 64 B (batches > 4, no fused norm)
     int out_tiled;                          // SWIGLU: write the activation fragment-ordered (it is the next GEMV's x)
     int force32;                            // always the 32-row MFMA variant (whatever M): a row's result then does not depend on how many rows share the launch
+    int counted;                            // set by launch_gemv from SR_GEMV_COUNTED: un-staged launches with fragment-ordered x use the loop whose refills are all unconditional (counted vmcnt waits)
     GemvHead head;                          // BIAS / SWIGLU at 5..32 rows on the un-staged 16-row-tile kernel: the launch normalises its own x first (x = the fragment-ordered buffer the head writes)
     GemvTail tail;                          // RESID / PARTIAL at 5..32 rows, N <= 2048: the launch also normalises its rows (round 5); counter null = off
 };
