@@ -273,7 +273,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
         // U - 1 redundant chunk loads per wave, L2 hits), the steady rounds refill every slot and only the peeled last round asks whether a chunk
         // exists.  With a load behind `if (chunk exists)` hipcc's vmcnt bookkeeping collapses to `vmcnt(0)` at the top of every round (see k_gemv32).
         bool counted = false;
-        if constexpr (!STAGE) counted = p.counted && p.x_tiled && nh == 0 && cend > c0;
+        if constexpr (!STAGE) counted = (p.counted & 1) && p.x_tiled && nh == 0 && cend > c0;
         if constexpr (!STAGE) {
             if (counted) {
                 auto fill_c = [&](int u, int c) {
@@ -763,7 +763,7 @@ template <int MODE, int KP, int G, bool F8 = false>
 __global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int ntiles32) {
     constexpr int WAVES = 4, TPB = WAVES / KP, U = (G <= 2) ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // BIAS / RESID / SWIGLU launches may split the ROWS over gridDim.y (32 G rows per y): the narrow matrices (N = 2048 / 2560: 64 / 80 tiles)
     // otherwise leave three quarters of the CUs without a block, and their few MB of weights cost nothing to stream twice
     const int fr = lane & 15, half = (lane >> 4) & 1, kg = lane >> 5, m0 = (lane & 31) + (MODE != GV_PARTIAL ? (int)blockIdx.y * 32 * G : 0);
@@ -815,7 +815,59 @@ __global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
-    if (active) {
+    auto consume = [&](int u) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            u32x4 wop;
+            if constexpr (F8) {
+                const u32x4 q = w[u][st >> 1];
+                uint32_t d[4];
+                f8x4_to_bf16(q[(st & 1) * 2], d[0], d[1]);
+                f8x4_to_bf16(q[(st & 1) * 2 + 1], d[2], d[3]);
+                wop = u32x4{d[0], d[1], d[2], d[3]};
+            } else wop = w[u][st];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wop), as_frag(xv[u][g][st]), acc[g], 0, 0, 0);
+        }
+    };
+    // round 5, counted form (GemvArgs.counted bit 1; see k_gemv32): every fill unconditional -- chunk index clamped to the wave's last chunk, rows that do
+    // not exist read the last row that does (their output rows are never stored) -- so that hipcc counts the waits instead of `vmcnt(0)` every round
+    const bool counted = (p.counted & 2) && cend > c0;
+    if (active && counted) {
+        const bf16_t* xg[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int mm = min(m0 + 32 * g, m_rd - 1);
+            xg[g] = F8 ? (p.x_tiled ? p.x + ((size_t)(mm >> 4) * nchunks * 2) * 512 + (kg * 16 + (mm & 15)) * 8 : p.x + (size_t)mm * p.ldx + kg * 16)
+                       : (p.x_tiled ? p.x + ((size_t)(mm >> 4) * nchunks * 2 + kg) * 512 + (mm & 15) * 8 : p.x + (size_t)mm * p.ldx + kg * 8);
+        }
+        auto fill_xc = [&](int u, int c) {
+            c = min(c, cend - 1);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    xv[u][g][st] = *reinterpret_cast<const u32x4*>(xg[g] + (size_t)c * x_c + (F8 ? (st >> 1) * x8_j + (st & 1) * x8_h : st * x_s));
+        };
+        const int rounds = (cend - c0 + U - 1) / U;
+#pragma unroll
+        for (int u = 0; u < U; ++u) fill_xc(u, c0 + u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) fill_w(u, min(c0 + u, cend - 1));
+        for (int r = 0; r + 1 < rounds; ++r) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                consume(u);
+                fill_w(u, min(c0 + (r + 1) * U + u, cend - 1));
+                fill_xc(u, c0 + (r + 1) * U + u);
+            }
+        }
+        const int last = c0 + (rounds - 1) * U;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (last + u < cend) consume(u);
+    } else if (active) {
         // first ring: x (L2) in front of the weights (HBM), see k_gemv
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -827,20 +879,7 @@ __global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (c + u < cend) {
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-                        u32x4 wop;
-                        if constexpr (F8) {
-                            const u32x4 q = w[u][st >> 1];
-                            uint32_t d[4];
-                            f8x4_to_bf16(q[(st & 1) * 2], d[0], d[1]);
-                            f8x4_to_bf16(q[(st & 1) * 2 + 1], d[2], d[3]);
-                            wop = u32x4{d[0], d[1], d[2], d[3]};
-                        } else wop = w[u][st];
-#pragma unroll
-                        for (int g = 0; g < G; ++g)
-                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wop), as_frag(xv[u][g][st]), acc[g], 0, 0, 0);
-                    }
+                    consume(u);
                     if (c + U + u < cend) fill(u, c + U + u);
                 }
             }
@@ -990,7 +1029,7 @@ int launch_32(hipStream_t s, const GemvArgs& a) {
     dim3 grid(cdiv(ntiles, TPB), MODE == GV_PARTIAL ? a.ksplit : 1);
     size_t smem = (size_t)TPB * (KP > 1 ? KP - 1 : 0) * 64 * sizeof(f32x16);
     if (smem < 4 * 32 * 8) smem = 4 * 32 * 8;
-    if (sr_switches().gemv_counted) hipLaunchKernelGGL((k_gemv32<MODE, KP, true>), grid, dim3(256), smem, s, a, ntiles);
+    if (sr_switches().gemv_counted & 1) hipLaunchKernelGGL((k_gemv32<MODE, KP, true>), grid, dim3(256), smem, s, a, ntiles);
     else hipLaunchKernelGGL((k_gemv32<MODE, KP, false>), grid, dim3(256), smem, s, a, ntiles);
     SR_CHECK_LAUNCH();
     return 0;
@@ -1089,7 +1128,7 @@ int gemv_launch_blocks(const GemvArgs& a, int mode) {
 
 int launch_gemv(hipStream_t s, const GemvArgs& a_, int mode) {
     GemvArgs a = a_;
-    a.counted = sr_switches().gemv_counted;      // (SR_GEMV_COUNTED: the loops whose refills are all unconditional)
+    a.counted = sr_switches().gemv_counted;      // (SR_GEMV_COUNTED: the loops whose refills are all unconditional; bit 0: <= 32 rows, bit 1: the row-group kernel of 33..128 rows)
     if (a.M <= 0) return 0;
     if (a.M > 128 || a.K % 64 != 0 || a.N % 16 != 0) return -22;
     if (a.M > 32) {      // 33..128 rows: the 32-row-tile kernel over 2 / 4 row groups per weight pass (bf16 stream, no fused norm)

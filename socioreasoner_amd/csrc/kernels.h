@@ -17,7 +17,7 @@ struct SrSwitches {
     int attn_win64;     // SR_ATTN_WIN64  0: no 64-token window kernel (default 1)
     int attn_vasm;      // SR_ATTN_VASM   0: V^T fragment reads of k_attn_prefill2 left to the compiler (ds_read2st64_b64, 2-way bank conflicts; default 1: hand-issued ds_read_b64)
     int sam_f32_split;  // SR_SAM_F32_SPLIT 0: SAM2's float32 GEMM on the f32-input MFMA (round 4) instead of the three-term bf16 split on the bf16 pipe (default 1)
-    int gemv_counted;   // SR_GEMV_COUNTED 0: the decode GEMVs' ring loops with a refill behind `if (chunk exists)` (rounds 1-4: hipcc then waits vmcnt(0) every round); default 1: every refill unconditional, counted waits
+    int gemv_counted;   // SR_GEMV_COUNTED bit 0 (default on): <= 32-row decode GEMVs refill their ring unconditionally -> counted vmcnt waits (rounds 1-4: vmcnt(0) every round); bit 1 (default off: measured slower at 128 rows): the same for k_gemv32g
     int head_norm;      // SR_HEAD_NORM   bit 0 / bit 1: the RMSNorm in front of q/k/v / of gate/up of a 5..32-row decode layer runs as the first blocks of that GEMV launch (default 0)
     int tail_norm;      // SR_TAIL_NORM   bit 0 / bit 1: the RMSNorm after o_proj / after the down-projection of a 5..32-row decode layer runs INSIDE that GEMV launch
                         //                (its last-arriving blocks, rownorm.h) instead of as a launch of its own.  Default 0: bit-identical, measured slower.
