@@ -117,3 +117,77 @@ def test_gpu_lease_script_parses_and_documents_its_stages():
         stages.update(m.group(1).split("|"))
     assert stages, "no stages found"
     assert stages <= documented, sorted(stages - documented)
+
+
+def _device_disassembly():
+    """disassembly of every gfx950 code object bundled into libsocior.so, keyed by kernel symbol (llvm-objcopy / clang-offload-bundler / llvm-objdump of the
+    ROCm toolchain; the .hip_fatbin section is a sequence of offload bundles, one per translation unit)"""
+    import re
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "socioreasoner_amd", "libsocior.so")
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not os.path.exists(so) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("needs the built libsocior.so and the ROCm LLVM tools")
+    funcs = {}
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", so, os.path.join(td, "copy.so")], check=True)
+        data = open(fat, "rb").read()
+        idx = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data)]
+        for i, a in enumerate(idx):
+            b = idx[i + 1] if i + 1 < len(idx) else len(data)
+            piece, co = os.path.join(td, f"b{i}.bin"), os.path.join(td, f"d{i}.co")
+            open(piece, "wb").write(data[a:b])
+            subprocess.run([tools[1], "--unbundle", "--type=o", f"--input={piece}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True, capture_output=True)
+            name = None
+            for line in subprocess.run([tools[2], "-d", co], check=True, capture_output=True, text=True).stdout.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
+                if m:
+                    name = m.group(1)
+                    funcs[name] = []
+                elif name and line.strip():
+                    funcs[name].append(line.split("//")[0].strip())
+    return funcs
+
+
+def test_built_library_keeps_the_two_compiler_findings_of_round_5():
+    """Round 5 found two places where hipcc's code was not what the source promised; both fixes live in how the source is WRITTEN, so a toolchain or source
+    change could silently undo them.  This reads the ISA of the built library:
+      * k_attn_prefill2 (hand-issued V^T reads): plain ds_read_b64, never the paired ds_read2st64_b64 (half rate, 32-bank rule: 2-way conflicts), and no
+        instruction touches a read's destination registers between the read and the counted lgkmcnt wait that covers it (a copy there would copy stale data);
+      * the decode GEMVs' ring loops (k_gemv32 / k_gemv at <= 32 rows): counted `s_waitcnt vmcnt(N)` between the MFMAs -- with a refill behind a condition
+        hipcc waits vmcnt(0) at the top of every round."""
+    import re
+    funcs = _device_disassembly()
+
+    def one(pattern):
+        names = [n for n in funcs if re.search(pattern, n)]
+        assert len(names) == 1, (pattern, names)
+        return funcs[names[0]]
+
+    for pat in (r"k_attn_prefill2ILi128ELb1ELi2ELi2ELb1E", r"k_attn_prefill2ILi80ELb0ELi8ELi3ELb1E"):
+        body = one(pat)
+        text = "\n".join(body)
+        assert "ds_read2st64_b64" not in text and "ds_read2_b64" not in text, pat
+        reads = [i for i, l in enumerate(body) if l.startswith("ds_read_b64 ")]
+        assert len(reads) >= 20, (pat, len(reads))
+        for i in reads:
+            m = re.match(r"ds_read_b64 v\[(\d+):(\d+)\]", body[i])
+            regs = {int(m.group(1)), int(m.group(2))}
+            for l in body[i + 1:]:
+                if l.startswith("s_waitcnt") and "lgkmcnt" in l:
+                    break
+                used = set()
+                for a, b in re.findall(r"v\[(\d+):(\d+)\]", l):
+                    used.update(range(int(a), int(b) + 1))
+                used.update(int(x) for x in re.findall(r"\bv(\d+)\b", l))
+                if l.startswith("ds_read_b64 "):      # another hand-issued read: only its ADDRESS register may coincide (never with a pending destination)
+                    addr = re.match(r"ds_read_b64 v\[\d+:\d+\], v(\d+)", l)
+                    used = {int(addr.group(1))}
+                assert not (used & regs), (pat, body[i], l)
+    for pat, floor in ((r"k_gemv32ILi0ELi4ELb1E", 16), (r"k_gemv32ILi2ELi1ELb1E", 16), (r"k_gemvILi1ELi2ELi4ELb0ELi4ELb0E", 16), (r"k_gemvILi3ELi2ELi4ELb0ELi4ELb0E", 16)):
+        body = one(pat)
+        counts = {int(x) for l in body for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", l)}
+        assert len([c for c in counts if c >= 8]) >= 4 and max(counts) >= floor, (pat, sorted(counts))
