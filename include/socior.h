@@ -22,6 +22,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libsocior.so is built with -fvisibility=hidden: the declarations between this push and the pop at the end of the file are the library's
+ * whole dynamic symbol table (tests/test_host_round6.py checks `nm -D` against this header). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct sr_engine sr_engine;
 
@@ -241,8 +246,8 @@ int sr_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, void*
  *   sr_op_gemm_f32      : out = act(A . W^T + bias) (+ resid), float32 in and out; epilogue 0 store, 1 residual, 3 GELU (erf form; | 0x1000 =
  *                         ReLU), 4 = 0; K % 16 == 0, N % 4 == 0.  Round 5: computed on the bf16 matrix pipe from an exact three-term bf16 split of
  *                         every operand (six partial products, float32 accumulation: float32-grade results at 2-3 x the rate of the f32-input
- *                         MFMA, which SR_SAM_F32_SPLIT=0 selects instead).  | 0x2000: `W` holds the weight ALREADY split, three bf16 planes
- *                         [3][N][K] with W = hi + mid + lo (hi = bf16(W), mid = bf16(W - hi), lo = bf16(W - hi - mid)): weights are constants.
+ *                         MFMA, which SR_SAM_F32_SPLIT=0 selects instead).  The split is exact for finite operands inside bf16's range (|x| < 3.39e38):
+ *                         beyond it, and for +-inf, hi rounds to inf and the remainders turn NaN where the f32-input kernel returns inf.
  *   sr_op_attention_f32 : softmax(q k^T * scale) v per work item (the struct of sr_op_attention, <= 64 queries per item; vt_off unused:
  *                         V is ROW-major, element (key j, head h, d) = v[(k_row0 + j) * v_stride + h * head_dim + d]); head_dim 16 / 32 / 80. */
 int sr_op_gemm_f32(const float* A, int lda, const float* W, int M, int N, int K, float* out, int ldo, const float* bias, const float* resid,
@@ -297,12 +302,10 @@ int sr_version(void);
  * (the bit-identity tests do) calls this to have the environment read again.  No reference counterpart (vLLM reads its VLLM_* variables at
  * import: roll/distributed/strategy/vllm_strategy.py:13-30). */
 int sr_switches_reload(void);
-/* Round 5: at 5..32 decode rows the RMSNorms of a layer CAN run inside their neighbouring GEMV launches (hf modeling_qwen2_5_vl.py:65-79, 708-758):
- * as the last-arriving blocks of the o_proj / down-projection launch (SR_TAIL_NORM) or as the first blocks of the q/k/v / gate/up launch
- * (SR_HEAD_NORM); both are bit-identical to the RMSNorm launches, measured slower, and off by default.  A block that gives up waiting for the
- * launch's other blocks counts here -- 0 in a healthy run (tests assert it); a negative value is an error. */
-int sr_tail_timeouts(sr_engine* e, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm(bf16_t* x, const bf16_t* xin, c
 __global__ __launch_bounds__(256) void k_rmsnorm_row(bf16_t* x, const bf16_t* xin, const float* part, int ksplit,
                                                      const bf16_t* w, bf16_t* out, int rows, int H, float eps, int out_tiled) {
     __shared__ float wsum[4];
-    rmsnorm_row_body<false>(x, xin, false, part, ksplit, w, out, rows, blockIdx.x, H, eps, out_tiled, wsum);     // rownorm.h (shared with the GEMV tails)
+    rmsnorm_row_body(x, xin, part, ksplit, w, out, rows, blockIdx.x, H, eps, out_tiled, wsum);     // rownorm.h
 }
 
 // ----------------------------------------------------------------------------------------------- ViT 2-D RoPE (hf:160-171)
@@ -307,14 +307,6 @@ __global__ __launch_bounds__(256) void k_step(StepArgs a) {
     for (int c = tid; c < a.H / 8; c += 256) {
         const bf16_t* from = a.table + (a.table_tiled ? tiled_offset(s_feed, (size_t)c * 8, a.H) : (size_t)s_feed * a.H + c * 8);
         reinterpret_cast<uint4*>(a.x + (size_t)b * a.H)[c] = *reinterpret_cast<const uint4*>(from);
-    }
-    if (a.norm_w) {
-        // round 5: the first layer's input RMSNorm of the row this block just gathered (H <= 2048: one 16-byte chunk per thread) -- with the GEMV
-        // tails (rownorm.h) a 5..32-row decode step then has no RMSNorm launch at all.  The row is re-read through the body shared with
-        // k_rmsnorm_row (the block's own stores, made visible to its other threads by the barrier): same bits as the separate launch.
-        __threadfence_block();
-        __syncthreads();
-        rmsnorm_row_body<false>(nullptr, a.x, false, nullptr, 0, a.norm_w, a.xn, a.B, b, a.H, a.eps, a.xn_tiled, sv);
     }
 }
 

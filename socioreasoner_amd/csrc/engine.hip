@@ -88,8 +88,6 @@ static void load_switches() {
     g_sw.attn_win64 = env_int("SR_ATTN_WIN64", 1);
     g_sw.attn_vasm = env_int("SR_ATTN_VASM", 1);
     g_sw.sam_f32_split = env_int("SR_SAM_F32_SPLIT", 1);
-    g_sw.tail_norm = env_int("SR_TAIL_NORM", 0);
-    g_sw.head_norm = env_int("SR_HEAD_NORM", 0);
     g_sw.gemv_counted = env_int("SR_GEMV_COUNTED", 1);
     g_sw_loaded = true;
 }
@@ -138,10 +136,6 @@ struct sr_engine {
     bf16_t *d_xa, *d_xb, *d_xn, *d_qkv, *d_attn, *d_act, *d_scores;    // d_xa / d_xb: residual stream ping-pong
     float *d_logits, *d_slabs, *d_amax_val;
     float* d_row_cs = nullptr;               // [MAXB][128] rotary cos | sin of every row's current position (k_step -> decode attention)
-    unsigned* d_tail = nullptr;              // [2 * layers] arrival tickets of the decode GEMV tails (rownorm.h) + [1] give-up count; zeroed at the head of every forward
-    int head_norm = 0;                       // round 5: RMSNorm in front of q/k/v (bit 0) / gate/up (bit 1) of a 5..32-row decode layer as the first blocks of that GEMV launch (GemvHead)
-    int tail_norm = 0;                       // round 5: RMSNorm of a 5..32-row decode layer inside the o_proj (bit 0) / down-projection (bit 1) launches; OFF by default: measured
-                                             // 0.5 / 1.0 / 1.4 % SLOWER per decode step than the two RMSNorm launches (SR_TAIL_NORM=1 / 2 / 3)
     int *d_amax_idx, *d_cur_tok, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
     int n_part = 0;      // LM-head blocks = partial argmax entries per row
     // continuous batching (sr_rows_*): admission scratch so that a prefill never touches the pending tokens of running rows
@@ -352,7 +346,6 @@ void carve(sr_engine* e) {
     e->d_amax_idx_adm = ar.take<int>(B * e->n_part);
     e->d_row_limit = ar.take<int>(MAXB);
     e->d_row_cs = ar.take<float>(MAXB * 128);
-    e->d_tail = ar.take<unsigned>((size_t)4 * c.t_layers + 64);      // [2L] head counters | [2L] tail tickets | give-up count
     e->d_ngen = ar.take<int>(MAXB);
     e->d_adm = ar.take<int>(5 * MAXB);
     e->d_adm_slots = ar.take<int>(MAXB);
@@ -597,46 +590,15 @@ bool x_tiled_ok(const sr_engine* e) {
     return e->c.t_hidden % 64 == 0 && (e->c.t_heads * 128) % 64 == 0 && e->t_inter_pad % 64 == 0 && e->c.t_hidden <= 2048;
 }
 int ks_down(const sr_engine* e, int B) { return (B > 16 && e->t_inter_pad / 64 >= 32) ? 4 : e->ks_down; }
-// round 5: at 5..32 rows the o_proj and down-projection GEMVs finish their rows as the next launch's normalised x
-// (the last B blocks to arrive do residual add + RMSNorm, rownorm.h; the first layer's norm rides in k_step): no RMSNorm launch in the step
-// (tail_norm is a bit mask for the A/B: 1 = o_proj's tail does ln2, 2 = the down-projection's tail does the next ln1 / the final norm and k_step layer 0's; 3 = both)
-int tail_norms(const sr_engine* e, int B) {
-    if (!e->tail_norm || fused_norms(e, B) || B > 32 || !x_tiled_ok(e)) return 0;
-    const int H = e->c.t_hidden, QD = e->c.t_heads * 128;
-    const bool f8 = e->c.lm_weight_dtype >= 1;
-    GemvArgs go = gv(nullptr, QD, nullptr, B, H, QD, nullptr, H), gd = gv(nullptr, e->t_inter_pad, nullptr, B, H, e->t_inter_pad, nullptr, H);
-    gd.ksplit = ks_down(e, B);
-    if (f8) go.W8 = gd.W8 = reinterpret_cast<const unsigned char*>(e);      // (only its null-ness matters)
-    return (gemv_launch_blocks(go, GV_RESID) >= B && gemv_launch_blocks(gd, GV_PARTIAL) >= B) ? (e->tail_norm & 3) : 0;      // one tail block per row
-}
-// round 5: the RMSNorm launches in front of q/k/v (bit 0) and gate/up (bit 1) of a 5..32-row decode layer become the FIRST blocks of those GEMV launches
-// (GemvHead: the GEMV blocks stream their first weight ring while the rows are normalised).  bf16 weight stream only; a norm a tail already does is not a head.
-int head_norms(const sr_engine* e, int B) {
-    if (!e->head_norm || fused_norms(e, B) || B > 32 || B < 5 || !x_tiled_ok(e) || e->c.lm_weight_dtype != 0) return 0;
-    return e->head_norm & 3 & ~((tail_norms(e, B) & 2 ? 1 : 0) | (tail_norms(e, B) & 1 ? 2 : 0));
-}
-GemvHead make_head(sr_engine* e, int idx, const bf16_t* norm_w, bf16_t* x, const float* part, int ksplit, int rows) {
-    GemvHead h{};
-    h.counter = e->d_tail + idx; h.timeout = e->d_tail + 4 * e->c.t_layers;
-    h.x = x; h.part = part; h.ksplit = ksplit; h.norm_w = norm_w; h.eps = e->c.t_rms_eps; h.rows = rows;
-    return h;
-}
-GemvTail make_tail(sr_engine* e, int idx, const bf16_t* norm_w, bf16_t* x) {
-    GemvTail t{};
-    t.counter = e->d_tail + 2 * e->c.t_layers + idx; t.timeout = e->d_tail + 4 * e->c.t_layers;
-    t.norm_w = norm_w; t.eps = e->c.t_rms_eps; t.xn = e->d_xn; t.xn_tiled = 1; t.x = x;
-    return t;
-}
 
 // LM head on B rows of `x` (+ optional pending slabs): float32 logits + per-block argmax partials.
 // Small batches fuse the final RMSNorm (and the pending residual) into the GEMV prologue.
-int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending, hipStream_t s, bool admission = false, bool normed = false) {
+int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending, hipStream_t s, bool admission = false) {
     const sr_config& c = e->c;
     const int H = c.t_hidden;
     GemvArgs g = gv(x, H, e->embed, B, c.t_vocab, H, admission ? e->d_logits_adm : e->d_logits, c.t_vocab);
     g.amax_val = admission ? e->d_amax_val_adm : e->d_amax_val; g.amax_idx = admission ? e->d_amax_idx_adm : e->d_amax_idx;
-    if (normed) { g.x = e->d_xn; g.x_tiled = 1; }      // the last down-projection's tail already wrote final_norm(x) fragment-ordered
-    else if (fused_norms(e, B)) {
+    if (fused_norms(e, B)) {
         g.norm_w = e->final_norm; g.eps = c.t_rms_eps;
         if (pending) { g.slabs = e->d_slabs; g.n_slabs = ks_down(e, B); g.x_out = x_alt; }
     } else {
@@ -661,11 +623,6 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
     bf16_t *x = e->d_xa, *x_alt = e->d_xb;      // k_step gathered the input embedding into d_xa
     bool pending = false;                       // down-projection slabs not yet added to the residual stream
     const float scale = (float)(1.0 / sqrt(128.0));
-    const int tails = tail_norms(e, B);
-    const bool tail_o = tails & 1, tail_d = tails & 2;      // (tail_d: k_step wrote ln1(x) of layer 0 into d_xn, enqueue_step)
-    const int heads = head_norms(e, B);
-    const bool head_q = heads & 1, head_g = heads & 2;
-    if (tails || heads) SR_TRY((int)hipMemsetAsync(e->d_tail, 0, (size_t)4 * c.t_layers * sizeof(unsigned), s));     // a memset node at the head of the captured step
     for (int l = 0; l < c.t_layers; ++l) {
         const LmLayerW& w = e->ll[l];
         bf16_t* kc = e->kcache + (size_t)l * e->kv_layer_elems;
@@ -676,9 +633,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
             gq.norm_w = w.ln1; gq.eps = c.t_rms_eps;
             if (pending) { gq.slabs = e->d_slabs; gq.n_slabs = ks_down(e, B); gq.x_out = x_alt; }
         } else {
-            if (tail_d) {}     // d_xn = ln1(x) is there: k_step (layer 0) or the previous down-projection's tail
-            else if (head_q) gq.head = make_head(e, 2 * l, w.ln1, x, pending ? e->d_slabs : nullptr, pending ? ks_down(e, B) : 0, B);
-            else if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, ks_down(e, B), w.ln1, e->d_xn, B, H, c.t_rms_eps, xt));
+            if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, ks_down(e, B), w.ln1, e->d_xn, B, H, c.t_rms_eps, xt));
             else SR_TRY(launch_rmsnorm(s, x, w.ln1, e->d_xn, B, H, c.t_rms_eps, xt));
             gq.x = e->d_xn; gq.x_tiled = xt;
         }
@@ -690,7 +645,6 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         SR_TRY(launch_attn_decode(s, da));
         GemvArgs go = gv(e->d_attn, QD, w.o_w, B, H, QD, x, H);
         go.W8 = w.o_w8; go.w_scale = w.o_s; go.x_tiled = xt;
-        if (tail_o) go.tail = make_tail(e, 2 * l, w.ln2, x);
         SR_TRY(launch_gemv(s, go, GV_RESID));
         GemvArgs gg = gv(x, H, w.gu_w, B, 2 * e->t_inter_pad, H, e->d_act, e->t_inter_pad);
         gg.W8 = w.gu_w8; gg.w_scale = w.gu_s;
@@ -707,27 +661,23 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
             gg.M = 0;       // (done)
         }
         else {
-            if (tail_o) {}
-            else if (head_g) gg.head = make_head(e, 2 * l + 1, w.ln2, x, nullptr, 0, B);
-            else SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt));
+            SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt));
             gg.x = e->d_xn; gg.x_tiled = xt; gg.out_tiled = xt;
         }
         if (gg.M > 0) SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
         GemvArgs gd = gv(e->d_act, e->t_inter_pad, w.down_w, B, H, e->t_inter_pad, e->d_slabs, H);
         gd.ksplit = ks_down(e, B);
         gd.W8 = w.down_w8; gd.w_scale = w.down_s; gd.x_tiled = xt;
-        if (tail_d) gd.tail = make_tail(e, 2 * l + 1, l + 1 < c.t_layers ? e->ll[l + 1].ln1 : e->final_norm, x);
         SR_TRY(launch_gemv(s, gd, GV_PARTIAL));
-        pending = !tail_d;      // with the tail the slabs are already in the residual stream and d_xn holds the next norm
+        pending = true;
     }
-    return enqueue_lm_head(e, B, x, x_alt, pending, s, false, tail_d);
+    return enqueue_lm_head(e, B, x, x_alt, pending, s, false);
 }
 
 int enqueue_step(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, hipStream_t s, const long long* chosen = nullptr) {
     StepArgs a{e->d_amax_val, e->d_amax_idx, gemv_f32_blocks(e->c.t_vocab, B, e->c.t_hidden, fused_norms(e, B) ? 1 : 0), e->d_cur_tok, e->d_ctx_len, e->d_pos, e->d_step, e->d_finished,
                e->d_tokens, e->c.max_new_tokens, e->d_eos, n_eos, pad_id, B, forced, e->embed, e->d_xa, e->c.t_hidden, 1, chosen, e->d_row_limit, e->d_ngen,
                e->rope_cos, e->rope_sin, e->d_row_cs};
-    if (tail_norms(e, B) & 2) { a.norm_w = e->ll[0].ln1; a.eps = e->c.t_rms_eps; a.xn = e->d_xn; a.xn_tiled = 1; }     // layer 0's input norm (see enqueue_decode_forward)
     SR_TRY(launch_step(s, a));
     return 0;
 }
@@ -740,14 +690,6 @@ extern "C" {
 int sr_version(void) { return 1; }
 
 int sr_switches_reload(void) { load_switches(); return 0; }
-int sr_tail_timeouts(sr_engine* e, void* stream) {
-    if (!e) return -22;
-    enter(e);
-    unsigned v = 0;
-    if (hipMemcpyAsync(&v, e->d_tail + 4 * e->c.t_layers, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -5;
-    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -5;
-    return (int)v;
-}
 
 const char* sr_last_error(const sr_engine* e) { return e ? e->err : g_err; }
 
@@ -766,8 +708,6 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
     sr_engine* e = new sr_engine();
     e->c = *cfg;
     load_switches();                            // the environment is read here (and by sr_switches_reload), never in per-call dispatch
-    e->tail_norm = g_sw.tail_norm;
-    e->head_norm = g_sw.head_norm;
     snprintf(e->err, sizeof e->err, "ok");
     {   // the engine belongs to the device that owns the workspace, whatever the calling thread's current device is
         hipPointerAttribute_t pa{};
@@ -798,7 +738,6 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
     if (r == hipSuccess) r = hipMemset(e->vtcache, 0, e->kv_layer_elems * e->c.t_layers * sizeof(bf16_t));
     if (r == hipSuccess) r = hipMemset(e->d_cur_tok, 0, (char*)e->d_tokens - (char*)e->d_cur_tok);
     if (r == hipSuccess) r = hipMemset(e->v_vt, 0, (size_t)e->c.v_hidden * e->v_vt_stride * sizeof(bf16_t));
-    if (r == hipSuccess) r = hipMemset(e->d_tail, 0, ((size_t)4 * e->c.t_layers + 64) * sizeof(unsigned));
     // normalise LUT (hf image_transforms.py:89-124, 384-440) and rotary inverse frequencies (hf:506-523)
     std::vector<bf16_t> lut(768);
     const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f}, stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
@@ -1638,8 +1577,8 @@ int sr_op_gemm_f32(const float* A, int lda, const float* W, int M, int N, int K,
                    const int32_t* rowmap, int epilogue, void* stream) {
     const int e = epilogue & 0xff;
     if (e != EPI_STORE && e != EPI_RESID && e != EPI_GELU && e != EPI_F32) return -22;
-    GemmF32Args a{A, lda, W, M, N, K, out, ldo, bias, e == EPI_RESID ? resid : nullptr, rowmap, e == EPI_GELU ? ((epilogue & 0x1000) ? 2 : 1) : 0, nullptr};
-    if (epilogue & 0x2000) { a.W3 = reinterpret_cast<const bf16_t*>(W); a.W = nullptr; }      // W = three bf16 planes [3][N][K] (hi, mid, lo)
+    GemmF32Args a{A, lda, W, M, N, K, out, ldo, bias, e == EPI_RESID ? resid : nullptr, rowmap, e == EPI_GELU ? ((epilogue & 0x1000) ? 2 : 1) : 0};
+    if (epilogue & 0x2000) return -22;      // (round 5's pre-split weight planes: measured slower, left the library in round 6)
     SR_WRAP(launch_gemm_f32((hipStream_t)stream, a));
 }
 int sr_op_attention_f32(const float* q, int q_stride, const float* k, int k_stride, const float* v, int v_stride, float* out, int out_stride,

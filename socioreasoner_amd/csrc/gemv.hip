@@ -56,23 +56,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform for the compiler too: scalar branches)
     const int fr = lane & 15, fg = lane >> 4;
     const int tp = wave / KP, kp = wave % KP;
-    // round 5, GemvHead: the first nh blocks of the launch are one RMSNorm row each (they produce this launch's x); the GEMV blocks behind them
-    // stream their first weight ring, then wait for the nh arrivals.  Block dispatch is in index order and the whole grid is resident at once
-    // (<= 720 blocks of 256 threads), so a waiting block never keeps a head block off the chip.
-    constexpr bool HEAD_OK = !STAGE && !F8 && WAVES == 4 && (MODE == GV_BIAS || MODE == GV_SWIGLU);
-    int nh = 0;
-    if constexpr (HEAD_OK) nh = p.head.counter ? p.head.rows : 0;
-    if constexpr (HEAD_OK) {
-        if ((int)blockIdx.x < nh) {
-            rmsnorm_row_body<false>(p.head.x, p.head.x, false, p.head.part, p.head.ksplit, p.head.norm_w, const_cast<bf16_t*>(p.x), nh, (int)blockIdx.x, p.K,
-                                    p.head.eps, p.x_tiled, reinterpret_cast<float*>(smem), true);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have left
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(p.head.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-    }
-    const int tile = ((int)blockIdx.x - nh) * TPB + tp;            // in units of T tiles
+    const int tile = (int)blockIdx.x * TPB + tp;            // in units of T tiles
     const bool active = tile < ntiles;
     const int nchunks = p.K / 64;
     const int ks = (MODE == GV_PARTIAL) ? p.ksplit : 1;
@@ -111,8 +95,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
             }
         }
     };
+    // counted form (round 5: fragment-ordered x at 5..32 rows; round 6: every launch of this kernel, the LDS-staged ones of <= 4 rows included): every fill of the ring is
+    // UNCONDITIONAL -- the chunk index is clamped to the wave's last chunk (at most U - 1 redundant 1-KB loads per wave, L2 hits), the steady
+    // rounds refill every slot and only the peeled last round asks whether a chunk exists.  With a load behind `if (chunk exists)` hipcc's vmcnt
+    // bookkeeping collapses to `vmcnt(0)` at the top of every round (see k_gemv32): the whole ring landed before a round's first MFMA.
+    const bool counted = p.counted && active && cend > c0;
     auto first_fills = [&]() {
-        if (active) {
+        if (counted) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) fill_w(u, min(c0 + u, cend - 1));
+        } else if (active) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (c0 + u < cend) fill_w(u, c0 + u);
@@ -269,72 +261,67 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                 }
             }
         };
-        // round 5, counted path (fragment-ordered x, no head): every fill is UNCONDITIONAL -- the chunk index is clamped to the wave's last chunk (at most
-        // U - 1 redundant chunk loads per wave, L2 hits), the steady rounds refill every slot and only the peeled last round asks whether a chunk
-        // exists.  With a load behind `if (chunk exists)` hipcc's vmcnt bookkeeping collapses to `vmcnt(0)` at the top of every round (see k_gemv32).
-        bool counted = false;
-        if constexpr (!STAGE) counted = (p.counted & 1) && p.x_tiled && nh == 0 && cend > c0;
-        if constexpr (!STAGE) {
-            if (counted) {
-                auto fill_c = [&](int u, int c) {
-                    c = min(c, cend - 1);
-                    fill_w(u, c);
+        auto mfmas = [&](int u, int xs_) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const bf16_t* xt = p.x + ((size_t)(mt * nchunks + c) * 2) * 512 + lane * 8;
-                        xv[u][mt][0] = *reinterpret_cast<const u32x4*>(xt);
-                        xv[u][mt][1] = *reinterpret_cast<const u32x4*>(xt + 512);
-                    }
-                };
-                auto consume = [&](int u) {
+            for (int t = 0; t < T; ++t) {
+                u32x4 w0, w1;
+                if constexpr (F8) {
+                    const u32x4 q = w[u][t][0];
+                    uint32_t d[8];
+                    f8x4_to_bf16(q[0], d[0], d[1]); f8x4_to_bf16(q[1], d[2], d[3]);
+                    f8x4_to_bf16(q[2], d[4], d[5]); f8x4_to_bf16(q[3], d[6], d[7]);
+                    w0 = u32x4{d[0], d[1], d[2], d[3]};
+                    w1 = u32x4{d[4], d[5], d[6], d[7]};
+                } else {
+                    w0 = w[u][t][0];
+                    w1 = w[u][t][WL - 1];
+                }
 #pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        u32x4 w0, w1;
-                        if constexpr (F8) {
-                            const u32x4 q = w[u][t][0];
-                            uint32_t d[8];
-                            f8x4_to_bf16(q[0], d[0], d[1]); f8x4_to_bf16(q[1], d[2], d[3]);
-                            f8x4_to_bf16(q[2], d[4], d[5]); f8x4_to_bf16(q[3], d[6], d[7]);
-                            w0 = u32x4{d[0], d[1], d[2], d[3]};
-                            w1 = u32x4{d[4], d[5], d[6], d[7]};
-                        } else {
-                            w0 = w[u][t][0];
-                            w1 = w[u][t][WL - 1];
-                        }
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w0), as_frag(xv[xs_][mt][0]), acc[t][mt], 0, 0, 0);
+                    acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w1), as_frag(xv[xs_][mt][1]), acc[t][mt], 0, 0, 0);
+                }
+            }
+        };
+        if (counted) {
+            const int rounds = (cend - c0 + U - 1) / U;
+            // x without a condition around the loads: both layouts through one base pointer + two strides (fragment-ordered: 1 KB per 16-row group and
+            // chunk, halves 512 elements apart; row-major: rows >= M read row 0 -- valid memory, their output columns are never stored)
+            const bf16_t* xb[MT];
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w0), as_frag(xv[u][mt][0]), acc[t][mt], 0, 0, 0);
-                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w1), as_frag(xv[u][mt][1]), acc[t][mt], 0, 0, 0);
-                        }
-                    }
-                };
-                const int rounds = (cend - c0 + U - 1) / U;
+            for (int mt = 0; mt < MT; ++mt) xb[mt] = p.x_tiled ? p.x + (size_t)mt * nchunks * 1024 + lane * 8 : xrow[mt];
+            const size_t x_cs = p.x_tiled ? 1024 : 64, x_h = p.x_tiled ? 512 : 8;
+            auto fill_xt = [&](int u, int c) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    xv[STAGE ? 0 : u][mt][0] = *reinterpret_cast<const u32x4*>(xb[mt] + (size_t)c * x_cs);
+                    xv[STAGE ? 0 : u][mt][1] = *reinterpret_cast<const u32x4*>(xb[mt] + (size_t)c * x_cs + x_h);
+                }
+            };
+            if constexpr (!STAGE) {
                 // x in front of the weights in the first ring (in-order return: x comes from L2, W from HBM -- see below)
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int c = min(c0 + u, cend - 1);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const bf16_t* xt = p.x + ((size_t)(mt * nchunks + c) * 2) * 512 + lane * 8;
-                        xv[u][mt][0] = *reinterpret_cast<const u32x4*>(xt);
-                        xv[u][mt][1] = *reinterpret_cast<const u32x4*>(xt + 512);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) fill_w(u, min(c0 + u, cend - 1));
-                TGV(1);
-                for (int r = 0; r + 1 < rounds; ++r) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        consume(u);
-                        fill_c(u, c0 + (r + 1) * U + u);
-                    }
-                }
-                const int last = c0 + (rounds - 1) * U;
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (last + u < cend) consume(u);
+                for (int u = 0; u < U; ++u) fill_xt(u, min(c0 + u, cend - 1));
+                first_fills();
             }
+            TGV(1);
+            for (int r = 0; r + 1 < rounds; ++r) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int cn = min(c0 + (r + 1) * U + u, cend - 1);
+                    if constexpr (STAGE) fill_x(0, c0 + r * U + u);      // (x fragments from LDS at consume time)
+                    mfmas(u, STAGE ? 0 : u);
+                    fill_w(u, cn);
+                    if constexpr (!STAGE) fill_xt(u, cn);
+                }
+            }
+            const int last = c0 + (rounds - 1) * U;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (last + u < cend) {
+                    if constexpr (STAGE) fill_x(0, last + u);
+                    mfmas(u, STAGE ? 0 : u);
+                }
         }
         if (!counted) {
         if constexpr (!STAGE) {
@@ -342,30 +329,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
             // Behind the weights the x loads of the first ring only started to arrive when ALL of it had landed (launches whose whole K
             // fits the first ring -- qkv, o_proj: 3.2 us for W, then 1.3 us of x through the CU's load path, tools/probe_gemv_timeline.py);
             // in front of them they travel during the HBM latency.
-            if (nh == 0) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (c0 + u < cend) fill_x(u, c0 + u);
-            }
+            for (int u = 0; u < U; ++u)
+                if (c0 + u < cend) fill_x(u, c0 + u);
         }
         if constexpr (!STAGE) first_fills();
-        if constexpr (HEAD_OK) {
-            if (nh) {       // the weights are on their way; x exists once every head block has arrived (their rows were written through: first touch here
-                            // misses this CU's L1 and -- the launch started with its non-coherent lines invalidated -- this XCD's L2)
-                if (tid == 0) {
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(p.head.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nh) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > (1u << 22)) { atomicAdd(p.head.timeout, 1u); break; }     // never hang the GPU
-                    }
-                }
-                __syncthreads();
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (c0 + u < cend) fill_x(u, c0 + u);
-            }
-        }
         TGV(1);
         for (int c = c0; c < cend; c += U) {
 #pragma unroll
@@ -480,14 +448,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
                     o[2] = lo16(rv.y) + rbf(o[2]); o[3] = hi16(rv.y) + rbf(o[3]);
                 }
                 const uint2 ov = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
-                if (MODE == GV_RESID && p.tail.counter) st8_sc1(optr, ov);      // write-through: the tail blocks of THIS launch read the rows (rownorm.h)
-                else *reinterpret_cast<uint2*>(optr) = ov;
+                *reinterpret_cast<uint2*>(optr) = ov;
             } else {
                 const int n = tile * 16 + fg * 4;
                 const size_t oi = ((size_t)(MODE == GV_PARTIAL ? blockIdx.y : 0) * p.M + m) * p.N + n;
                 const float4 ov = float4{acc[0][mt][0], acc[0][mt][1], acc[0][mt][2], acc[0][mt][3]};
-                if (MODE == GV_PARTIAL && p.tail.counter) st16_sc1(sr_rsrc(p.out, (unsigned)p.ksplit * p.M * p.N * 4), (unsigned)oi * 4, __builtin_bit_cast(sr_u32x4, ov));
-                else *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + oi) = ov;
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + oi) = ov;
                 if constexpr (MODE == GV_F32) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -529,11 +495,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
         }
     }
     TGV(3);
-    if constexpr ((MODE == GV_RESID || MODE == GV_PARTIAL) && WAVES == 4 && !STAGE) {
-        // round 5: the last p.M blocks to arrive finish the launch's rows as the NEXT launch's normalised x (residual add of the slabs + RMSNorm,
-        // rownorm.h) -- the RMSNorm launches of a 5..32-row decode layer are gone.  `red` (128 floats at the head of the LDS) is unused here.
-        if (p.tail.counter) gemv_tail_rmsnorm(p.tail, MODE == GV_PARTIAL ? reinterpret_cast<const float*>(p.out) : nullptr, MODE == GV_PARTIAL ? p.ksplit : 0, p.M, p.N, red);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------- batches 17..32
@@ -702,14 +663,12 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
                     o[2] = lo16(rv.y) + rbf(o[2]); o[3] = hi16(rv.y) + rbf(o[3]);
                 }
                 const uint2 ov = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
-                if (MODE == GV_RESID && p.tail.counter) st8_sc1(optr, ov);      // write-through for the tail blocks (rownorm.h)
-                else *reinterpret_cast<uint2*>(optr) = ov;
+                *reinterpret_cast<uint2*>(optr) = ov;
             } else {
                 const int n = tile * 32 + nl;
                 const size_t oi = ((size_t)(MODE == GV_PARTIAL ? blockIdx.y : 0) * p.M + m) * p.N + n;
                 const float4 ov = float4{acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
-                if (MODE == GV_PARTIAL && p.tail.counter) st16_sc1(sr_rsrc(p.out, (unsigned)p.ksplit * p.M * p.N * 4), (unsigned)oi * 4, __builtin_bit_cast(sr_u32x4, ov));
-                else *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + oi) = ov;
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + oi) = ov;
                 if constexpr (MODE == GV_F32) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -717,11 +676,6 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
                 }
             }
         }
-    }
-    if constexpr (MODE == GV_RESID || MODE == GV_PARTIAL) {
-        // round 5: tail RMSNorm of the launch's rows by its last-arriving blocks (see k_gemv); the reduction buffer at the head of the LDS is dead
-        // behind the tail's first barrier
-        if (p.tail.counter) gemv_tail_rmsnorm(p.tail, MODE == GV_PARTIAL ? reinterpret_cast<const float*>(p.out) : nullptr, MODE == GV_PARTIAL ? p.ksplit : 0, p.M, p.N, reinterpret_cast<float*>(smem));
     }
     if constexpr (MODE == GV_F32) {
         if (p.amax_val) {                                          // KP == 1: smem is free
@@ -831,43 +785,7 @@ __global__ __launch_bounds__(256, G <= 2 ? 2 : 1) void k_gemv32g(GemvArgs p, int
                 acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wop), as_frag(xv[u][g][st]), acc[g], 0, 0, 0);
         }
     };
-    // round 5, counted form (GemvArgs.counted bit 1; see k_gemv32): every fill unconditional -- chunk index clamped to the wave's last chunk, rows that do
-    // not exist read the last row that does (their output rows are never stored) -- so that hipcc counts the waits instead of `vmcnt(0)` every round
-    const bool counted = (p.counted & 2) && cend > c0;
-    if (active && counted) {
-        const bf16_t* xg[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int mm = min(m0 + 32 * g, m_rd - 1);
-            xg[g] = F8 ? (p.x_tiled ? p.x + ((size_t)(mm >> 4) * nchunks * 2) * 512 + (kg * 16 + (mm & 15)) * 8 : p.x + (size_t)mm * p.ldx + kg * 16)
-                       : (p.x_tiled ? p.x + ((size_t)(mm >> 4) * nchunks * 2 + kg) * 512 + (mm & 15) * 8 : p.x + (size_t)mm * p.ldx + kg * 8);
-        }
-        auto fill_xc = [&](int u, int c) {
-            c = min(c, cend - 1);
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-                for (int st = 0; st < 4; ++st)
-                    xv[u][g][st] = *reinterpret_cast<const u32x4*>(xg[g] + (size_t)c * x_c + (F8 ? (st >> 1) * x8_j + (st & 1) * x8_h : st * x_s));
-        };
-        const int rounds = (cend - c0 + U - 1) / U;
-#pragma unroll
-        for (int u = 0; u < U; ++u) fill_xc(u, c0 + u);
-#pragma unroll
-        for (int u = 0; u < U; ++u) fill_w(u, min(c0 + u, cend - 1));
-        for (int r = 0; r + 1 < rounds; ++r) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                consume(u);
-                fill_w(u, min(c0 + (r + 1) * U + u, cend - 1));
-                fill_xc(u, c0 + (r + 1) * U + u);
-            }
-        }
-        const int last = c0 + (rounds - 1) * U;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (last + u < cend) consume(u);
-    } else if (active) {
+    if (active) {
         // first ring: x (L2) in front of the weights (HBM), see k_gemv
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -1029,7 +947,7 @@ int launch_32(hipStream_t s, const GemvArgs& a) {
     dim3 grid(cdiv(ntiles, TPB), MODE == GV_PARTIAL ? a.ksplit : 1);
     size_t smem = (size_t)TPB * (KP > 1 ? KP - 1 : 0) * 64 * sizeof(f32x16);
     if (smem < 4 * 32 * 8) smem = 4 * 32 * 8;
-    if (sr_switches().gemv_counted & 1) hipLaunchKernelGGL((k_gemv32<MODE, KP, true>), grid, dim3(256), smem, s, a, ntiles);
+    if (sr_switches().gemv_counted) hipLaunchKernelGGL((k_gemv32<MODE, KP, true>), grid, dim3(256), smem, s, a, ntiles);
     else hipLaunchKernelGGL((k_gemv32<MODE, KP, false>), grid, dim3(256), smem, s, a, ntiles);
     SR_CHECK_LAUNCH();
     return 0;
@@ -1042,7 +960,7 @@ int launch_k(hipStream_t s, const GemvArgs& a) {
     constexpr int T = (MODE == GV_SWIGLU) ? 2 : 1;
     constexpr int TPB = WAVES / KP;
     const int ntiles = a.N / (16 * T);
-    dim3 grid(cdiv(ntiles, TPB) + (a.head.counter ? a.head.rows : 0), MODE == GV_PARTIAL ? a.ksplit : 1);
+    dim3 grid(cdiv(ntiles, TPB), MODE == GV_PARTIAL ? a.ksplit : 1);
     size_t red = (size_t)TPB * (KP > 1 ? KP - 1 : 0) * T * MT * 64 * sizeof(f32x4);
     if (MODE == GV_F32) red = red > (size_t)WAVES * 32 * 8 ? red : (size_t)WAVES * 32 * 8;
     size_t smem;
@@ -1118,21 +1036,13 @@ int gemv_pick_kp(int K, int ksplit, int want) {
     return 1;
 }
 
-// blocks of the launch launch_gemv would make for a RESID / PARTIAL call at M <= 32 (what a tail needs to know: one block per output row)
-int gemv_launch_blocks(const GemvArgs& a, int mode) {
-    if (a.M <= 0 || a.M > 32 || !(mode == GV_RESID || mode == GV_PARTIAL)) return 0;
-    const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, 4);
-    const int rows_per_tile = (!a.W8 && use_32(a, mode)) ? 32 : 16;
-    return cdiv(a.N / rows_per_tile, 4 / kp) * (mode == GV_PARTIAL ? a.ksplit : 1);
-}
-
 int launch_gemv(hipStream_t s, const GemvArgs& a_, int mode) {
     GemvArgs a = a_;
-    a.counted = sr_switches().gemv_counted;      // (SR_GEMV_COUNTED: the loops whose refills are all unconditional; bit 0: <= 32 rows, bit 1: the row-group kernel of 33..128 rows)
+    a.counted = sr_switches().gemv_counted;      // (SR_GEMV_COUNTED=0: the conditional-refill loops of rounds 1-4, A/B and bit-identity hook)
     if (a.M <= 0) return 0;
     if (a.M > 128 || a.K % 64 != 0 || a.N % 16 != 0) return -22;
     if (a.M > 32) {      // 33..128 rows: the 32-row-tile kernel over 2 / 4 row groups per weight pass (bf16 stream, no fused norm)
-        if (a.N % 32 != 0 || a.norm_w || a.n_slabs || a.tail.counter || a.head.counter) return -22;
+        if (a.N % 32 != 0 || a.norm_w || a.n_slabs) return -22;
         if (a.W8 && (!a.w_scale || mode == GV_F32)) return -22;
         if (mode == GV_PARTIAL && (a.ksplit < 1 || a.ksplit > a.K / 64)) return -22;
         if (a.out_tiled && (mode != GV_SWIGLU || (a.N / 2) % 64 != 0)) return -22;
@@ -1157,24 +1067,12 @@ int launch_gemv(hipStream_t s, const GemvArgs& a_, int mode) {
     if (a.out_tiled && (mode != GV_SWIGLU || (a.N / 2) % 64 != 0)) return -22;
     int want = mode == GV_F32 ? 1 : 4;
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
-    if (a.head.counter) {       // in-launch RMSNorm of the INPUT rows by the first M blocks (GemvHead): the un-staged bf16 16-row-tile kernel only
-        if (!(mode == GV_BIAS || mode == GV_SWIGLU) || a.norm_w || a.W8 || a.M < 5 || use_32(a, mode) || kp != 4) return -22;
-        if (!a.head.timeout || !a.head.norm_w || !a.head.x || a.head.rows != a.M || a.K > 2048 || a.K % 64 != 0 || !a.x_tiled) return -22;
-        if (a.head.part && (a.head.ksplit < 1 || a.head.ksplit > 4)) return -22;
-    }
-    if (a.tail.counter) {       // in-launch RMSNorm of the output rows by the last M blocks to arrive (rownorm.h): one 256-thread block per row
-        if (!(mode == GV_RESID || mode == GV_PARTIAL) || a.norm_w || a.N > 2048 || a.N % 8 != 0) return -22;
-        if (!a.tail.timeout || !a.tail.norm_w || !a.tail.xn || !a.tail.x) return -22;
-        if (mode == GV_RESID && (a.tail.x != a.out || a.ldo != a.N)) return -22;
-        if (a.tail.xn_tiled && a.N % 64 != 0) return -22;
-        if (gemv_launch_blocks(a, mode) < a.M) return -22;
-    }
     if (a.W8) {          // fp8 weight stream (decode of the quantised LM linears); the in-block K split is always 4 there
         if (!a.w_scale || mode == GV_F32) return -22;
         if (kp != 4) return -22;
         // 17..32 rows, 4-slab down-projection: the 32-row-tile kernel (x read once per 32 weight rows), as for the bf16 stream -- measured on the fp8
         // stream at 32 rows: decode step 2.211 -> 2.180 ms; gate/up unchanged (2.216), q/k/v + o_proj slower (2.323) and therefore left on 16-row tiles
-        if (mode == GV_PARTIAL && a.M > 16 && a.ksplit >= 4 && a.N % 32 == 0 && !a.norm_w && !a.tail.counter) return launch_32g_mode<1, true>(s, a, mode, kp);
+        if (mode == GV_PARTIAL && a.M > 16 && a.ksplit >= 4 && a.N % 32 == 0 && !a.norm_w) return launch_32g_mode<1, true>(s, a, mode, kp);
         switch (mode) {
             case GV_PARTIAL: return launch_small<GV_PARTIAL, 4, true>(s, a);
             case GV_SWIGLU: return launch_small<GV_SWIGLU, 4, true>(s, a);

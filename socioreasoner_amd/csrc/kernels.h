@@ -17,11 +17,8 @@ struct SrSwitches {
     int attn_win64;     // SR_ATTN_WIN64  0: no 64-token window kernel (default 1)
     int attn_vasm;      // SR_ATTN_VASM   0: V^T fragment reads of k_attn_prefill2 left to the compiler (ds_read2st64_b64, 2-way bank conflicts; default 1: hand-issued ds_read_b64)
     int sam_f32_split;  // SR_SAM_F32_SPLIT 0: SAM2's float32 GEMM on the f32-input MFMA (round 4) instead of the three-term bf16 split on the bf16 pipe (default 1)
-    int gemv_counted;   // SR_GEMV_COUNTED bit 0 (default on): <= 32-row decode GEMVs refill their ring unconditionally -> counted vmcnt waits (rounds 1-4: vmcnt(0) every round); bit 1 (default off: measured slower at 128 rows): the same for k_gemv32g
-    int head_norm;      // SR_HEAD_NORM   bit 0 / bit 1: the RMSNorm in front of q/k/v / of gate/up of a 5..32-row decode layer runs as the first blocks of that GEMV launch (default 0)
-    int tail_norm;      // SR_TAIL_NORM   bit 0 / bit 1: the RMSNorm after o_proj / after the down-projection of a 5..32-row decode layer runs INSIDE that GEMV launch
-                        //                (its last-arriving blocks, rownorm.h) instead of as a launch of its own.  Default 0: bit-identical, measured slower.
-                        //                Read at sr_engine_create.
+    int gemv_counted;   // SR_GEMV_COUNTED 0: the <= 32-row decode GEMVs use the conditional-refill ring loops of rounds 1-4 (vmcnt(0) every round) instead of the
+                        //                 unconditional refills with counted vmcnt waits (default 1; bit-identical: A/B + test hook)
 };
 const SrSwitches& sr_switches();
 
@@ -87,25 +84,6 @@ int launch_quant_mx_act(hipStream_t s, const bf16_t* x, int ldx, int M, int K, u
 
 // ------------------------------------------------------------------ gemv.hip (weight streaming, M <= 32)
 enum { GV_PARTIAL = 0, GV_SWIGLU = 1, GV_F32 = 2, GV_BIAS = 3, GV_RESID = 4 };
-// what a GEMV launch needs to finish its output as a normalised activation (GemvArgs.tail, device side in rownorm.h; counter == null: no tail, plain stores)
-struct GemvTail {
-    unsigned* counter;          // arrival tickets of THIS launch; zero when the launch starts (memset node at the head of the decode forward)
-    unsigned* timeout;          // a tail block that gave up waiting adds 1 here (never in a healthy run; tests assert 0)
-    const bf16_t* norm_w; float eps;
-    bf16_t* xn; int xn_tiled;   // normalised rows out [M][H] (fragment-ordered when xn_tiled: the next GEMV's x)
-    bf16_t* x;                  // residual stream [M][H].  PARTIAL: read, h = r(x + r(sum slabs)) written back; RESID: the launch's own output
-};
-
-// what a GEMV launch needs to PRODUCE its own normalised x (GemvArgs.head, round 5): the first `rows` blocks of the launch are one RMSNorm row each
-// (rmsnorm_row_body, rownorm.h), the GEMV blocks behind them stream their first weight ring and then wait for `rows` arrivals on `counter`
-struct GemvHead {
-    unsigned* counter;          // zero when the launch starts (memset node at the head of the decode forward); null: no head
-    unsigned* timeout;          // a GEMV block that gave up waiting adds 1 here (never in a healthy run)
-    bf16_t* x;                  // residual stream [rows][K] (updated in place when part != null)
-    const float* part; int ksplit;      // pending float32 slabs of the previous down-projection (another launch), or null
-    const bf16_t* norm_w; float eps;
-    int rows;
-};
 
 struct GemvArgs {
     const bf16_t* x; int ldx;   // [M, K] B operand; with norm_w: the residual stream the RMSNorm prologue reads
@@ -127,11 +105,8 @@ struct GemvArgs {
     int out_tiled;                          // SWIGLU: write the activation fragment-ordered (it is the next GEMV's x)
     int force32;                            // always the 32-row MFMA variant (whatever M): a row's result then does not depend on how many rows share the launch
     int counted;                            // set by launch_gemv from SR_GEMV_COUNTED: un-staged launches with fragment-ordered x use the loop whose refills are all unconditional (counted vmcnt waits)
-    GemvHead head;                          // BIAS / SWIGLU at 5..32 rows on the un-staged 16-row-tile kernel: the launch normalises its own x first (x = the fragment-ordered buffer the head writes)
-    GemvTail tail;                          // RESID / PARTIAL at 5..32 rows, N <= 2048: the launch also normalises its rows (round 5); counter null = off
 };
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode);
-int gemv_launch_blocks(const GemvArgs& a, int mode);     // RESID / PARTIAL at M <= 32: blocks of that launch (a tail needs >= M)
 int gemv_f32_blocks(int N, int M, int K, int has_norm);
 int gemv_f32_block_rows(int N, int M, int K, int has_norm);   // vocabulary rows per block of that launch    // gridDim.x of the F32 launch (length of the amax rows)
 
@@ -225,7 +200,6 @@ struct StepArgs {
     const bf16_t* rope_cos; const bf16_t* rope_sin;     // optional LM rotary tables [pos][64] ...
     float* row_cs;              // ... and [B][128]: cos | sin of every row's NEW position, for the decode attention of this step (which then
                                 // does not have to chase pos[b] -> table row through two dependent loads in every layer)
-    const bf16_t* norm_w; float eps; bf16_t* xn; int xn_tiled;   // optional (round 5, H <= 2048): xn = RMSNorm(x row) * norm_w, the first layer's input norm
 };
 // fp8 quantisation of a fragment-ordered bf16 matrix [N, K]: scale[n] = amax_n / 448 (1 if the row is zero),
 // q = fp8(W / scale) -> W8 (tiled8); W itself is overwritten with q as bf16 (what the prefill GEMM multiplies, scaled in its epilogue)
@@ -288,7 +262,6 @@ struct GemmF32Args {
     const float* resid;         // [*, ldo] indexed by DESTINATION row (may alias out) or null; added after the activation
     const int* rowmap;          // optional destination row per source row
     int act;                    // 0 none, 1 GELU (erf form), 2 ReLU
-    const bf16_t* W3;           // optional: W pre-split into three bf16 planes [3][N][K] (hi, mid, lo: W = hi + mid + lo exactly); W may then be null
 };
 int launch_gemm_f32(hipStream_t s, const GemmF32Args& a);
 // float32 attention over the same work items as launch_attn_prefill (q_tile 64); V is ROW-major here ([key][head * hd + d])

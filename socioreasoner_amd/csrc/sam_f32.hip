@@ -196,9 +196,6 @@ __device__ __forceinline__ void split3(const float (&x)[8], u32x4s& hi, u32x4s& 
     }
 }
 
-// W3: W arrives PRE-SPLIT (GemmF32Args.W3: three bf16 planes [3][N][K], what socioreasoner_amd/sam2.py builds once per weight at load time --
-// weights are constants) and goes from global memory to LDS as it is: only A is split in the kernel.
-template <bool W3>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32s(GemmF32Args p, int n_tiles_n) {
     __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][SP_OPER];     // [buffer][A | W]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -219,26 +216,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32s(GemmF32Args p, int n_tiles
     // epilogue never stores rows >= M or columns >= N -- no zero fill, no conditional loads.  Buffer loads (descriptor + per-thread byte offset
     // fixed for the whole k loop + the k-tile's offset in an SGPR): no per-iteration address arithmetic in VGPRs.
     const __amdgpu_buffer_rsrc_t ra_ = sr_rsrc(p.A, (unsigned)(((size_t)(p.M - 1) * p.lda + p.K) * 4));
-    const __amdgpu_buffer_rsrc_t rw_ = W3 ? sr_rsrc(p.W3, (unsigned)((size_t)3 * p.N * p.K * 2)) : sr_rsrc(p.W, (unsigned)((size_t)p.N * p.K * 4));
+    const __amdgpu_buffer_rsrc_t rw_ = sr_rsrc(p.W, (unsigned)((size_t)p.N * p.K * 4));
     const int arow_i = min(m0 + sr, p.M - 1), wrow_i = min(n0 + sr, p.N - 1);
     const unsigned avo = ((unsigned)arow_i * p.lda + sk * 8) * 4;
-    const unsigned wvo = ((unsigned)wrow_i * p.K + sk * 8) * (W3 ? 2 : 4);
-    const unsigned w3pl = (unsigned)p.N * p.K * 2;                                // bytes per pre-split plane
+    const unsigned wvo = ((unsigned)wrow_i * p.K + sk * 8) * 4;
     // TWO k-tiles of global loads in flight per thread (register sets 0 / 1 alternate): with one, a k-tile lasted one memory round trip
     // (~3 200 cycles against the 768 of its 24 MFMAs: 2 blocks per CU do not cover it the way the f32-input kernel's four do)
     u32x4s ra[2][2], rw[2][2];
-    u32x4s rw3[2][3];
     auto gload = [&](auto set_, int k0) {
         constexpr int S = decltype(set_)::value;
         ra[S][0] = __builtin_amdgcn_raw_buffer_load_b128(ra_, avo, k0 * 4, 0);
         ra[S][1] = __builtin_amdgcn_raw_buffer_load_b128(ra_, avo + 16, k0 * 4, 0);
-        if constexpr (W3) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) rw3[S][pl] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wvo, k0 * 2 + pl * w3pl, 0);
-        } else {
-            rw[S][0] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wvo, k0 * 4, 0);
-            rw[S][1] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wvo + 16, k0 * 4, 0);
-        }
+        rw[S][0] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wvo, k0 * 4, 0);
+        rw[S][1] = __builtin_amdgcn_raw_buffer_load_b128(rw_, wvo + 16, k0 * 4, 0);
     };
     const int soff = sk * SP_HALF + sr * 16;
     auto lstore = [&](auto set_, int b) {
@@ -251,18 +241,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32s(GemmF32Args p, int n_tiles
         *reinterpret_cast<u32x4s*>(sm[b][0] + soff) = h;
         *reinterpret_cast<u32x4s*>(sm[b][0] + SP_PLANE + soff) = m;
         *reinterpret_cast<u32x4s*>(sm[b][0] + 2 * SP_PLANE + soff) = l;
-        if constexpr (W3) {
+        float xw[8];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4s*>(sm[b][1] + pl * SP_PLANE + soff) = rw3[S][pl];
-        } else {
-            float xw[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xw[e] = __uint_as_float(rw[S][e >> 2][e & 3]);
-            split3(xw, h, m, l);
-            *reinterpret_cast<u32x4s*>(sm[b][1] + soff) = h;
-            *reinterpret_cast<u32x4s*>(sm[b][1] + SP_PLANE + soff) = m;
-            *reinterpret_cast<u32x4s*>(sm[b][1] + 2 * SP_PLANE + soff) = l;
-        }
+        for (int e = 0; e < 8; ++e) xw[e] = __uint_as_float(rw[S][e >> 2][e & 3]);
+        split3(xw, h, m, l);
+        *reinterpret_cast<u32x4s*>(sm[b][1] + soff) = h;
+        *reinterpret_cast<u32x4s*>(sm[b][1] + SP_PLANE + soff) = m;
+        *reinterpret_cast<u32x4s*>(sm[b][1] + 2 * SP_PLANE + soff) = l;
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -509,15 +494,12 @@ __global__ __launch_bounds__(256, 2) void k_attn_f32(AttnF32Args p) {
 
 int launch_gemm_f32(hipStream_t s, const GemmF32Args& a) {
     if (a.M <= 0 || a.N <= 0) return 0;
-    if (a.K % GK || a.N % 4 || a.ldo % 4 || a.lda % 4 || (!a.W && !a.W3) || (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.out | (uintptr_t)a.resid | (uintptr_t)a.bias) & 15)) return -22;      // (bias is read 16 bytes at a time)
+    if (a.K % GK || a.N % 4 || a.ldo % 4 || a.lda % 4 || !a.W || (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.out | (uintptr_t)a.resid | (uintptr_t)a.bias) & 15)) return -22;      // (bias is read 16 bytes at a time)
     const int tn = cdiv(a.N, GB), tm = cdiv(a.M, GB);
     // default: the split-bf16 form on the bf16 matrix pipe (SR_SAM_F32_SPLIT=0: the f32-input MFMA of round 4); the row stride of A and the
     // rows of W must keep the staging's 16-byte loads of 8 consecutive k aligned (lda % 4, K % 16: checked above)
     const bool fits32 = ((size_t)a.M * a.lda + a.K) * 4 < (1ull << 32) && (size_t)3 * a.N * a.K * 4 < (1ull << 32);      // buffer descriptors address 4 GB
-    if (a.W3) {
-        if (a.K % 8 || ((uintptr_t)a.W3 & 15) || !fits32) return -22;
-        hipLaunchKernelGGL(k_gemm_f32s<true>, dim3((unsigned)tn * (unsigned)tm), dim3(256), 0, s, a, tn);
-    } else if (sr_switches().sam_f32_split && fits32) hipLaunchKernelGGL(k_gemm_f32s<false>, dim3((unsigned)tn * (unsigned)tm), dim3(256), 0, s, a, tn);
+    if (sr_switches().sam_f32_split && fits32) hipLaunchKernelGGL(k_gemm_f32s, dim3((unsigned)tn * (unsigned)tm), dim3(256), 0, s, a, tn);
     else hipLaunchKernelGGL(k_gemm_f32, dim3((unsigned)tn * (unsigned)tm), dim3(256), 0, s, a, tn);
     SR_CHECK_LAUNCH();
     return 0;

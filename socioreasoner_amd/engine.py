@@ -72,13 +72,6 @@ class Engine:
     def _s(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def tail_timeouts(self) -> int:
-        """Tail blocks of the decode GEMVs (in-launch RMSNorm at 5..32 rows, csrc/rownorm.h) that gave up waiting: 0 in a healthy run."""
-        n = self.lib.sr_tail_timeouts(self._h, self._s())
-        if n < 0:
-            raise L.SocioRError(f"sr_tail_timeouts failed ({n})")
-        return n
-
     # ------------------------------------------------------------------ weights
     def load_weight(self, name: str, tensor: torch.Tensor):
         t = tensor.detach()

@@ -98,7 +98,6 @@ SIGNATURES = {
     "sr_op_resid_rmsnorm": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, C.c_float, _vp]),
     "sr_op_argmax": (C.c_int, [_vp, _i, _i, _vp, _vp]),
     "sr_switches_reload": (C.c_int, []),
-    "sr_tail_timeouts": (C.c_int, [_vp, _vp]),
 }
 
 

@@ -116,12 +116,6 @@ class Sam2Engine:
             if self.grid[s] % g.windows[s] or (s and self.grid[s - 1] % g.windows[s - 1]) or g.windows[s] % 2:
                 raise ValueError("window sizes must divide the stage grids (true for Hiera-L at 1024)")
         self.W: Dict[str, torch.Tensor] = {}
-        # float32 mode (round 5): every Linear weight also as three bf16 planes [3][N][K] with W = hi + mid + lo exactly -- what the float32 GEMM's
-        # split-bf16 form (csrc/sam_f32.hip k_gemm_f32s) multiplies on the bf16 matrix pipe; SR_SAM_F32_SPLIT=0 keeps the f32-input MFMA of round 4
-        self.W3: Dict[str, torch.Tensor] = {}
-        # (measured, tools/bench_gemm_f32.py: handing the kernel pre-split weights is 3-6 % SLOWER than letting it split both operands -- 48
-        # instead of 32 bytes per thread and k-tile through a memory system the kernel already leans on -- so the planes are an opt-in)
-        self.presplit = self.f32 and os.environ.get("SR_SAM_F32_SPLIT", "1") != "0" and os.environ.get("SR_SAM_PRESPLIT", "0") == "1"
         self._bufs: Dict[str, torch.Tensor] = {}
         self._work: Dict[tuple, tuple] = {}
         self._idx: Dict[str, torch.Tensor] = {}
@@ -154,9 +148,6 @@ class Sam2Engine:
         w = self.W[Wn + ".weight"]
         N, K = w.shape
         b = self.W.get(Wn + ".bias") if bias else None
-        w3 = self.W3.get(Wn + ".weight") if self.presplit else None
-        if w3 is not None:
-            w, epi = w3, epi | 0x2000          # the weight pre-split into bf16 planes (sr_op_gemm_f32, include/socior.h)
         self._ck(self._fn("sr_op_gemm")(self._p(A, a_off), lda, self._p(w), M, N, K, self._p(out, out_off), ldo, self._p(b), self._p(resid, out_off if resid is out else 0),
                                         self._p(rowmap), epi, self._s()), f"gemm {Wn}")
 
@@ -202,13 +193,6 @@ class Sam2Engine:
             out = torch.zeros(Np, rup(K), dtype=torch.float32)
             out[:N, :K] = w2d
             self.W[name + ".weight"] = out.to(self.dt).to(dev).contiguous()
-            if self.presplit:
-                w32 = self.W[name + ".weight"]
-                hi = w32.to(torch.bfloat16)
-                r1 = w32 - hi.float()                                  # exact
-                mid = r1.to(torch.bfloat16)
-                lo = (r1 - mid.float()).to(torch.bfloat16)            # (the subtraction is exact; lo's own rounding error is < 2^-25 |w|)
-                self.W3[name + ".weight"] = torch.stack([hi, mid, lo]).contiguous()
             if bias is not None:
                 bb = torch.zeros(Np, dtype=torch.float32)
                 bb[:N] = bias

@@ -4,8 +4,8 @@ roll/pipeline/rlvr/rlvr_socioseg_vlm_pipeline_infer.py:146-184 ground-truth help
 A sample is ``{"id", "problem", "map_image", "sat_image", "mask_label"}`` with PIL images (or paths).  The reference
 pulls ``vvangfaye/SocioSeg`` from the hub; offline the pipeline reads the same folder layout from disk or falls back to
 synthetic tiles (BASELINE.json: data = synthetic).  cv2 is not available here: connected components / bounding boxes
-are restated with scipy.ndimage (8-connectivity like the reference's connectedComponentsWithStats; the box filter is
-component pixel area > 10, the reference filters on polygon contourArea > 10 -- differs only for thread-like blobs).
+are restated with scipy.ndimage (8-connectivity like the reference's connectedComponentsWithStats) and, for the box filter, a restated
+Suzuki-Abe outer-border trace + shoelace area (= cv2.findContours(RETR_EXTERNAL) + cv2.contourArea > 10; round 6).
 """
 from __future__ import annotations
 
@@ -90,15 +90,77 @@ def count_components(image_list) -> List[int]:
     return [int(ndimage.label(_binary(im), structure=np.ones((3, 3)))[1]) for im in image_list]
 
 
+# clockwise order of the 8 neighbours (dy, dx) of a pixel in image coordinates (y down), starting at the west neighbour
+_NB8 = [(0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1), (1, 0), (1, -1)]
+
+
+def outer_border(mask: np.ndarray, y0: int, x0: int) -> List[tuple]:
+    """The outer border of the 8-connected component of `mask` whose raster-first pixel is (y0, x0) -- the pixel sequence cv2.findContours
+    follows (Suzuki & Abe 1985, algorithm 1, steps 3.1-3.5, restated: cv2 is not installed here): start with the west neighbour as the
+    "previous" pixel, find the first foreground neighbour clockwise, then walk counter-clockwise around every border pixel until the start
+    pixel is re-entered from the same predecessor.  Pixels of one-pixel-wide parts are visited twice (out and back), which is what makes
+    cv2.contourArea of a line zero.  Returns [(x, y), ...] (CHAIN_APPROX_SIMPLE only drops collinear points: same polygon, same area)."""
+    H, W = mask.shape
+    on = lambda y, x: 0 <= y < H and 0 <= x < W and bool(mask[y, x])      # noqa: E731
+    first = None
+    for k in range(8):                      # clockwise from the west neighbour
+        dy, dx = _NB8[k]
+        if on(y0 + dy, x0 + dx):
+            first = (y0 + dy, x0 + dx)
+            break
+    if first is None:
+        return [(x0, y0)]
+    pts = []
+    prev, cur = first, (y0, x0)
+    while True:
+        pts.append((cur[1], cur[0]))
+        k0 = _NB8.index((prev[0] - cur[0], prev[1] - cur[1]))
+        nxt = None
+        for s_ in range(1, 9):              # counter-clockwise, starting with the neighbour after `prev`
+            dy, dx = _NB8[(k0 - s_) % 8]
+            if on(cur[0] + dy, cur[1] + dx):
+                nxt = (cur[0] + dy, cur[1] + dx)
+                break
+        if nxt == (y0, x0) and cur == first:
+            return pts
+        prev, cur = cur, nxt
+
+
+def contour_area(pts: List[tuple]) -> float:
+    """cv2.contourArea: half the absolute shoelace sum over the contour's vertices (pixel CENTRES: a filled w x h rectangle has area (w - 1)(h - 1))."""
+    a = 0.0
+    for (xa, ya), (xb, yb) in zip(pts, pts[1:] + pts[:1]):
+        a += xa * yb - xb * ya
+    return abs(a) * 0.5
+
+
 def get_bboxes(image_list) -> List[str]:
-    """JSON list of {"bbox_2d": [x0, y0, x1, y1]} (exclusive max, like cv2.boundingRect's x + w) per image."""
+    """JSON list of {"bbox_2d": [x0, y0, x1, y1]} (exclusive max, like cv2.boundingRect's x + w) per image -- reference
+    rlvr_socioseg_vlm_pipeline_infer.py:156-184: cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE), boxes of the contours whose
+    cv2.contourArea exceeds 10.  Restated without cv2 (round 6; rounds 1-5 filtered on the component's pixel count, which keeps 4 x 4 blobs and
+    long one-pixel lines the reference drops):
+      * RETR_EXTERNAL: only components that touch the OUTER background (a blob inside another blob's hole has no external contour);
+      * the filter is the polygon area of the traced outer border (`outer_border`, `contour_area`), holes do not count;
+      * order: OpenCV links every new contour in FRONT of its siblings (cvInsertNodeIntoTree), so the list comes back in REVERSE discovery
+        order -- discovery is the raster order of each component's first pixel, which is scipy.ndimage.label's numbering too.
+    Unpinned (cv2 absent): checked against hand-computed cases in tests/test_host_round6.py."""
     from scipy import ndimage
     out = []
     for im in image_list:
-        lab, n = ndimage.label(_binary(im), structure=np.ones((3, 3)))
+        fg = _binary(im)
+        lab, n = ndimage.label(fg, structure=np.ones((3, 3)))
+        # outer background: the 4-connected background component that contains the frame around the image
+        bg, _ = ndimage.label(np.pad(~fg, 1, constant_values=True))
+        outer = bg == bg[0, 0]
+        touch = ndimage.binary_dilation(outer, structure=ndimage.generate_binary_structure(2, 1))[1:-1, 1:-1]
+        external = set(np.unique(lab[touch & fg]).tolist())
         boxes = []
-        for k, sl in enumerate(ndimage.find_objects(lab), start=1):
-            if sl is None or int((lab[sl] == k).sum()) <= 10:
+        for k, sl in reversed(list(enumerate(ndimage.find_objects(lab), start=1))):
+            if sl is None or k not in external:
+                continue
+            comp = lab[sl] == k
+            x0 = int(np.argmax(comp[0]))                         # raster-first pixel of the component: first row of its box, left-most
+            if contour_area(outer_border(comp, 0, x0)) <= 10:
                 continue
             boxes.append({"bbox_2d": [int(sl[1].start), int(sl[0].start), int(sl[1].stop), int(sl[0].stop)]})
         out.append(json.dumps(boxes))

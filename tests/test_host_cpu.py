@@ -313,7 +313,8 @@ def test_gt_components_and_boxes():
     from PIL import Image
     im = Image.fromarray(m, mode="L")
     assert D.count_components([im, im.convert("RGB")]) == [3, 3]
-    assert json.loads(D.get_bboxes([im])[0]) == [{"bbox_2d": [3, 2, 22, 12]}, {"bbox_2d": [40, 40, 60, 50]}]
+    # (cv2.findContours returns its contours in reverse discovery order: the lower blob first)
+    assert json.loads(D.get_bboxes([im])[0]) == [{"bbox_2d": [40, 40, 60, 50]}, {"bbox_2d": [3, 2, 22, 12]}]
 
 
 def test_actor_worker_and_scheduler_with_fake_strategy(tmp_path):

@@ -1,0 +1,89 @@
+"""Round 6 CPU tests: the library's dynamic symbol table, the lost experiments are out of the product library, bench/ modules."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "socioreasoner_amd", "libsocior.so")
+
+
+def _header_symbols():
+    hdr = open(os.path.join(ROOT, "include", "socior.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)                      # (comments mention entry points of other rounds)
+    return set(re.findall(r"\b(sr_[a-z0-9_]+)\s*\(", hdr))
+
+
+def test_library_exports_exactly_the_header():
+    """A C ABI exports its header and nothing else (~70 mangled internals sat next to the sr_* symbols): the library is
+    built with -fvisibility=hidden + a linker version script (csrc/exports.map), and `nm -D` must list exactly the functions include/socior.h declares."""
+    out = subprocess.run(["nm", "-D", "--defined-only", SO], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    declared = _header_symbols()
+    assert exported == declared, {"exported but not declared": sorted(exported - declared), "declared but not exported": sorted(declared - exported)}
+    assert all(s.startswith("sr_") for s in exported)
+
+
+def test_lost_experiments_are_not_in_the_product_library():
+    """Round 5 re-grew what round 4 had removed: kernels and switches of experiments that were measured slower (in-launch RMSNorm heads / tails of the
+    decode GEMVs, the counted form of the row-group GEMV, pre-split float32 weight planes).  They live as patches under tools/experiments/ now; neither
+    the sources nor the built library may name them."""
+    src = ""
+    for d, _, files in os.walk(os.path.join(ROOT, "socioreasoner_amd")):
+        for f in files:
+            if f.endswith((".hip", ".h", ".py")):
+                src += open(os.path.join(d, f), errors="replace").read()
+    src += open(os.path.join(ROOT, "include", "socior.h")).read()
+    for name in ("SR_TAIL_NORM", "SR_HEAD_NORM", "SR_SAM_PRESPLIT", "GemvTail", "GemvHead", "gemv_tail_rmsnorm", "sr_tail_timeouts"):
+        assert name not in src, name
+    blob = open(SO, "rb").read()
+    for name in (b"SR_TAIL_NORM", b"SR_HEAD_NORM", b"gemv_tail_rmsnorm"):
+        assert name not in blob, name
+    for patch in ("gemv_tail_head_rmsnorm.patch",):
+        assert os.path.exists(os.path.join(ROOT, "tools", "experiments", patch)), patch
+
+
+# ------------------------------------------------------------------------------------------------ N2: the ground-truth box filter is cv2.contourArea, not the pixel count
+def test_gt_boxes_follow_cv2_contour_area_on_hand_computed_cases():
+    """Reference rlvr_socioseg_vlm_pipeline_infer.py:156-184 keeps a ground-truth blob when cv2.contourArea(outer contour) > 10 -- the polygon through
+    the border pixels' CENTRES -- not when it has more than 10 pixels (rounds 1-5).  cv2 is not installed: the cases are computed by hand.
+      filled w x h rectangle            -> (w - 1)(h - 1)            4 x 4: 9 (dropped, 16 pixels), 5 x 4: 12 (kept), 12 x 2: 11 (kept), 11 x 2: 10 (dropped)
+      one-pixel line of any length      -> 0 (traced out and back)   40 pixels: dropped
+      diamond |x| + |y| <= r            -> 2 r^2                     r = 2 (13 pixels): 8 dropped, r = 3 (25 pixels): 18 kept
+      ring (a hole inside)              -> the OUTER polygon only    7 x 7 frame of width 1 (24 pixels): 36 kept
+      a blob inside a ring's hole       -> no external contour (RETR_EXTERNAL): dropped whatever its size
+      L of width 1 (two lines)          -> 0.5: on the way back the 8-connected trace cuts the corner pixel diagonally (one half-pixel triangle): dropped"""
+    import json
+    import numpy as np
+    from socioreasoner_amd import socioseg_data as D
+    rect = lambda w, h: np.ones((h, w), bool)      # noqa: E731
+    for w, h, want in ((4, 4, 9.0), (5, 4, 12.0), (12, 2, 11.0), (11, 2, 10.0), (40, 1, 0.0), (1, 1, 0.0), (2, 1, 0.0)):
+        assert D.contour_area(D.outer_border(rect(w, h), 0, 0)) == want, (w, h)
+
+    def diamond(r):
+        yy, xx = np.mgrid[-r:r + 1, -r:r + 1]
+        return (abs(yy) + abs(xx)) <= r
+    for r in (1, 2, 3, 5):
+        d = diamond(r)
+        assert D.contour_area(D.outer_border(d, 0, r)) == 2.0 * r * r, r
+    ell = np.zeros((9, 9), bool)
+    ell[0:9, 0] = True
+    ell[8, 0:9] = True
+    assert D.contour_area(D.outer_border(ell, 0, 0)) == 0.5
+    m = np.zeros((96, 96), np.uint8)
+    m[2:6, 2:6] = 255             # 4 x 4: area 9 -> dropped (16 pixels: rounds 1-5 kept it)
+    m[2:6, 10:15] = 255           # 5 x 4: area 12 -> kept
+    m[10, 2:42] = 255             # 40-pixel line -> dropped (rounds 1-5 kept it)
+    m[20:27, 20:27] = 255         # ring ...
+    m[21:26, 21:26] = 0
+    m[23, 23] = 255               # ... with a pixel in its hole
+    m[40:60, 40:70] = 255         # big block with a big hole that holds a 6 x 6 blob: the blob has no external contour
+    m[44:56, 44:66] = 0
+    m[47:53, 50:56] = 255
+    yy, xx = np.mgrid[0:96, 0:96]
+    m[(abs(yy - 80) + abs(xx - 12)) <= 2] = 255       # diamond r = 2: 8 -> dropped
+    m[(abs(yy - 80) + abs(xx - 30)) <= 3] = 255       # diamond r = 3: 18 -> kept
+    from PIL import Image
+    got = json.loads(D.get_bboxes([Image.fromarray(m, mode="L")])[0])
+    # reverse raster order of each kept component's first pixel (OpenCV links new contours in front)
+    assert got == [{"bbox_2d": [27, 77, 34, 84]}, {"bbox_2d": [40, 40, 70, 60]}, {"bbox_2d": [20, 20, 27, 27]}, {"bbox_2d": [10, 2, 15, 6]}], got
+    assert D.count_components([Image.fromarray(m, mode="L")]) == [9]          # connectedComponentsWithStats counts every blob, holes' contents included

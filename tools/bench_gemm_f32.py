@@ -22,15 +22,10 @@ for M, N, K in SHAPES:
     a = torch.randn(M, K, device="cuda")
     w = torch.randn(N, K, device="cuda") / K ** 0.5
     o = torch.empty(M, N, device="cuda")
-    hi = w.to(torch.bfloat16)
-    r1 = w - hi.float()
-    mid = r1.to(torch.bfloat16)
-    w3 = torch.stack([hi, mid, (r1 - mid.float()).to(torch.bfloat16)]).contiguous()
-    for flag, name in (("0", "f32-input MFMA"), ("1", "split-bf16 x3, both operands split in the kernel"), ("1", "split-bf16 x3, W pre-split (what sam2.py runs)")):
+    for flag, name in (("0", "f32-input MFMA"), ("1", "split-bf16 x3, both operands split in the kernel")):
         os.environ["SR_SAM_F32_SPLIT"] = flag
         lib.reload_switches()
-        pre = "pre-split" in name
-        call = lambda: L.sr_op_gemm_f32(P(a), K, P(w3 if pre else w), M, N, K, P(o), N, None, None, None, 0x2000 if pre else 0, s)
+        call = lambda: L.sr_op_gemm_f32(P(a), K, P(w), M, N, K, P(o), N, None, None, None, 0, s)
         for _ in range(2):
             assert call() == 0
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,4 +37,4 @@ for M, N, K in SHAPES:
         us = e0.elapsed_time(e1) / 5 * 1e3
         tf = 2.0 * M * N * K / us / 1e6
         print(json.dumps({"M": M, "N": N, "K": K, "kernel": name, "us": round(us, 1), "TFLOPs": round(tf, 1), "frac_of_f32_mfma_peak": round(tf / 157.3, 3)}), flush=True)
-    del a, w, o, w3
+    del a, w, o

@@ -6,34 +6,31 @@
 # Stages:
 #   tests5      tests/test_gpu_round5.py
 #   suite       the whole -m gpu suite
-#   head_ab     static 32-row bench with SR_HEAD_NORM=0 / 1 / 2 / 3 (RMSNorm rows as the first blocks of the consuming GEMV launch), twice
-#   tail_ab     static 32-row bench with SR_TAIL_NORM=0 / 1 (same box, interleaved twice), decode step ms of each
-#   trace_s32   rocprofv3 kernel trace of the static 32-row bench            -> gpurun_out/r05_bench_s32_kernel_stats.md
-#   trace_c32   ... of the headline (continuous) configuration               -> gpurun_out/r05_bench_c32_kernel_stats.md
-#   trace_b1    ... of batch 1                                               -> gpurun_out/r05_bench_b1_kernel_stats.md
-#   trace_fp8   ... of --fp8 static 32 rows                                  -> gpurun_out/r05_bench_fp8_s32_kernel_stats.md
-#   pmc_gemm / pmc_attn / pmc_sam2   SQ (+ FETCH_SIZE) passes of the GEMM / prefill-attention / SAM2 float32 kernels -> gpurun_out/r05_pmc_gemm256.json / r05_pmc_attn_prefill.json / r05_pmc_sam2_f32.json
-#   pmc_gemv    FETCH_SIZE / WRITE_SIZE passes of the decode weight stream (bf16 and fp8) -> gpurun_out/r05_pmc_gemv_traffic*.json
-#   bench       the driver's command (python bench.py)                       -> gpurun_out/r05_bench_default_line.json
+#   trace_s32   rocprofv3 kernel trace of the static 32-row bench            -> gpurun_out/${RT}_bench_s32_kernel_stats.md
+#   trace_c32   ... of the headline (continuous) configuration               -> gpurun_out/${RT}_bench_c32_kernel_stats.md
+#   trace_b1    ... of batch 1                                               -> gpurun_out/${RT}_bench_b1_kernel_stats.md
+#   trace_fp8   ... of --fp8 static 32 rows                                  -> gpurun_out/${RT}_bench_fp8_s32_kernel_stats.md
+#   pmc_gemm / pmc_attn / pmc_sam2   SQ (+ FETCH_SIZE) passes of the GEMM / prefill-attention / SAM2 float32 kernels -> gpurun_out/${RT}_pmc_gemm256.json / ${RT}_pmc_attn_prefill.json / ${RT}_pmc_sam2_f32.json
+#   pmc_gemv    FETCH_SIZE / WRITE_SIZE passes of the decode weight stream (bf16 and fp8) -> gpurun_out/${RT}_pmc_gemv_traffic*.json
+#   bench       the driver's command (python bench.py)                       -> gpurun_out/${RT}_bench_default_line.json
 #   configs     the other configurations of README (pair, fp8, fp8-mx 896, 64 / 128 rows, no-overlap, batch 1), 2 steps each
 #   smoke       __graft_entry__.smoke()
 #   fp8tests    the fp8 GPU tests only
 #   sam2tests   the SAM2 / float32 GEMM GPU tests only
-#   tail_trace  kernel traces of the static bench with SR_TAIL_NORM=0 and 1   -> gpurun_out/r05_bench_s32_tail{0,1}_kernel_stats.md
-#   tail_headline   the headline with SR_TAIL_NORM=0 / 1 / 3, twice
-#   trace_sam2  kernel trace of the SAM2 float32 encoder (tools/prof_sam2_encoder.py) -> gpurun_out/r05_sam2_f32_*.md
+#   trace_sam2  kernel trace of the SAM2 float32 encoder (tools/prof_sam2_encoder.py) -> gpurun_out/${RT}_sam2_f32_*.md
 #   bench_pmc   one bench step with the in-run rocprofv3 PMC passes (roofline.traffic measured, not a file ratio)
-#   pipeline    tools/run_example_small.py with 4 scripted objects per stage, SAM2 float32 / bf16 / no answers -> gpurun_out/r05_pipeline_*.json
-#   gemm_f32    tools/bench_gemm_f32.py: the split-bf16 float32 GEMM against the f32-input MFMA kernel  -> gpurun_out/r05_gemm_f32_split.jsonl
-#   sam2bench   tools/bench_sam2_modes.py (float32 split / f32-input / bf16)  -> gpurun_out/r05_sam2_modes.json
-#   host_scaling    1 / 2 / 4 / 8 gloo ranks on the one device: host ms per scheduling round -> gpurun_out/r05_host_scaling.jsonl
+#   pipeline    tools/run_example_small.py with 4 scripted objects per stage, SAM2 float32 / bf16 / no answers -> gpurun_out/${RT}_pipeline_*.json
+#   gemm_f32    tools/bench_gemm_f32.py: the split-bf16 float32 GEMM against the f32-input MFMA kernel  -> gpurun_out/${RT}_gemm_f32_split.jsonl
+#   sam2bench   tools/bench_sam2_modes.py (float32 split / f32-input / bf16)  -> gpurun_out/${RT}_sam2_modes.json
+#   host_scaling    1 / 2 / 4 / 8 gloo ranks on the one device: host ms per scheduling round -> gpurun_out/${RT}_host_scaling.jsonl
 #   sched_ab    admission share from measured costs (default) against the 32-row table (SR_SCHED_ONLINE=0) at 32 / 64 / 128 rows, twice each
-#   attn_ab     prefill attention with hand-issued V^T reads (default) against SR_ATTN_VASM=0, kernel trace, twice each -> gpurun_out/r05_attn_vasm_ab.txt
-#   pmc_lds_all     LDS bank conflicts of every kernel of the bench and of the SAM2 float32 encoder -> gpurun_out/r05_pmc_lds_all.txt
+#   attn_ab     prefill attention with hand-issued V^T reads (default) against SR_ATTN_VASM=0, kernel trace, twice each -> gpurun_out/${RT}_attn_vasm_ab.txt
+#   pmc_lds_all     LDS bank conflicts of every kernel of the bench and of the SAM2 float32 encoder -> gpurun_out/${RT}_pmc_lds_all.txt
 cd "$(dirname "$0")/.."
 R=$PWD
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+RT=${RT:-r06}      # round tag of every output file (profiles/r06_*)
 QUIET="--no-cpu-baseline --no-latency --no-sam --no-more-rows"
 
 line() { python - "$1" "$2" <<'EOF'
@@ -50,14 +47,14 @@ EOF
 
 trace() {   # trace <name> <bench args...>: kernel trace + stats summary
   local n=$1; shift
-  rm -rf /tmp/prof5_$n
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof5_$n -o $n -- python $R/bench.py "$@" > $R/gpurun_out/r05_prof_$n.log 2>&1; echo "trace $n exit $?")
-  local DB=$(find /tmp/prof5_$n -name "${n}_results.db" | head -1)
-  rm -f gpurun_out/r05_bench_${n}_kernel_stats.md
-  [ -n "$DB" ] && python tools/rocpd_stats.py $DB gpurun_out/r05_bench_${n}_kernel_stats.md > /dev/null && head -16 gpurun_out/r05_bench_${n}_kernel_stats.md | cut -c1-170
-  [ -n "$DB" ] && python tools/rocpd_gaps.py $DB > gpurun_out/r05_gaps_$n.json 2>/dev/null
-  line gpurun_out/r05_prof_$n.log "traced $n:"
-  rm -rf /tmp/prof5_$n
+  rm -rf /tmp/prof_${RT}_$n
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_${RT}_$n -o $n -- python $R/bench.py "$@" > $R/gpurun_out/${RT}_prof_$n.log 2>&1; echo "trace $n exit $?")
+  local DB=$(find /tmp/prof_${RT}_$n -name "${n}_results.db" | head -1)
+  rm -f gpurun_out/${RT}_bench_${n}_kernel_stats.md
+  [ -n "$DB" ] && python tools/rocpd_stats.py $DB gpurun_out/${RT}_bench_${n}_kernel_stats.md > /dev/null && head -16 gpurun_out/${RT}_bench_${n}_kernel_stats.md | cut -c1-170
+  [ -n "$DB" ] && python tools/rocpd_gaps.py $DB > gpurun_out/${RT}_gaps_$n.json 2>/dev/null
+  line gpurun_out/${RT}_prof_$n.log "traced $n:"
+  rm -rf /tmp/prof_${RT}_$n
 }
 
 for stage in "$@"; do
@@ -66,21 +63,20 @@ for stage in "$@"; do
     tests5) timeout 2400 python -m pytest tests/test_gpu_round5.py -q -m gpu ${TESTS5_K:+-k "$TESTS5_K"} 2>&1 | tail -15 ;;
     suite)  timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 ;;
     fp8tests) timeout 1500 python -m pytest tests -q -m gpu -k "f8 or fp8" 2>&1 | tail -8 ;;
-    pipeline) for dt in float32 bf16; do SR_SAM2_DTYPE=$dt SCRIPTED_OBJECTS=4 OUT=/tmp/example_out SOCIOSEG_NUM_SAMPLES=64 timeout 900 python tools/run_example_small.py 2> gpurun_out/r05_pipeline_$dt.err | tail -1 | tee gpurun_out/r05_pipeline_$dt.json | cut -c1-900; done
-              SCRIPTED_OBJECTS=0 OUT=/tmp/example_out SOCIOSEG_NUM_SAMPLES=64 timeout 900 python tools/run_example_small.py 2>/dev/null | tail -1 | tee gpurun_out/r05_pipeline_noanswers.json | cut -c1-600 ;;
-    trace_sam2) rm -rf /tmp/prof5_sam; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof5_sam -o sam -- python $R/tools/prof_sam2_encoder.py f32 > $R/gpurun_out/r05_prof_sam2.log 2>&1; echo "trace sam2 exit $?")
-                DB=$(find /tmp/prof5_sam -name "sam_results.db" | head -1); [ -n "$DB" ] && python tools/rocpd_stats.py $DB gpurun_out/r05_sam2_f32_encoder_kernel_stats.md > /dev/null && head -20 gpurun_out/r05_sam2_f32_encoder_kernel_stats.md | cut -c1-170
-                [ -n "$DB" ] && python tools/rocpd_by_grid.py $DB gpurun_out/r05_sam2_f32_by_grid.md 30 > /dev/null 2>&1 && head -36 gpurun_out/r05_sam2_f32_by_grid.md | cut -c1-200 ;;
-    bench_pmc) timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-sam --no-more-rows --no-pipeline > gpurun_out/r05_bench_pmc.log 2> gpurun_out/r05_bench_pmc.err; python -c "
-import json; d=json.loads([l for l in open('gpurun_out/r05_bench_pmc.log') if l.startswith('{')][-1]); r=d['roofline']; print({k: r[k] for k in ('frac','traffic','traffic_over_algorithmic','bytes_per_launch')}); print(r['traffic_source'][:160]); print(d['latency_b1']['roofline'])" ;;
-    tail_headline) for rep in 1 2; do for t in 0 1 3; do SR_TAIL_NORM=$t timeout 600 python bench.py --steps 3 --warmup 1 $QUIET > gpurun_out/r05_tailh_$t.log 2>&1; line gpurun_out/r05_tailh_$t.log "headline SR_TAIL_NORM=$t rep $rep:"; done; done ;;
-    host_scaling) : > gpurun_out/r05_host_scaling.jsonl
+    pipeline) for dt in float32 bf16; do SR_SAM2_DTYPE=$dt SCRIPTED_OBJECTS=4 OUT=/tmp/example_out SOCIOSEG_NUM_SAMPLES=64 timeout 900 python tools/run_example_small.py 2> gpurun_out/${RT}_pipeline_$dt.err | tail -1 | tee gpurun_out/${RT}_pipeline_$dt.json | cut -c1-900; done
+              SCRIPTED_OBJECTS=0 OUT=/tmp/example_out SOCIOSEG_NUM_SAMPLES=64 timeout 900 python tools/run_example_small.py 2>/dev/null | tail -1 | tee gpurun_out/${RT}_pipeline_noanswers.json | cut -c1-600 ;;
+    trace_sam2) rm -rf /tmp/prof_${RT}_sam; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_${RT}_sam -o sam -- python $R/tools/prof_sam2_encoder.py f32 > $R/gpurun_out/${RT}_prof_sam2.log 2>&1; echo "trace sam2 exit $?")
+                DB=$(find /tmp/prof_${RT}_sam -name "sam_results.db" | head -1); [ -n "$DB" ] && python tools/rocpd_stats.py $DB gpurun_out/${RT}_sam2_f32_encoder_kernel_stats.md > /dev/null && head -20 gpurun_out/${RT}_sam2_f32_encoder_kernel_stats.md | cut -c1-170
+                [ -n "$DB" ] && python tools/rocpd_by_grid.py $DB gpurun_out/${RT}_sam2_f32_by_grid.md 30 > /dev/null 2>&1 && head -36 gpurun_out/${RT}_sam2_f32_by_grid.md | cut -c1-200 ;;
+    bench_pmc) timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-sam --no-more-rows --no-pipeline > gpurun_out/${RT}_bench_pmc.log 2> gpurun_out/${RT}_bench_pmc.err; python -c "
+import json; d=json.loads([l for l in open('gpurun_out/${RT}_bench_pmc.log') if l.startswith('{')][-1]); r=d['roofline']; print({k: r[k] for k in ('frac','traffic','traffic_over_algorithmic','bytes_per_launch')}); print(r['traffic_source'][:160]); print(d['latency_b1']['roofline'])" ;;
+    host_scaling) : > gpurun_out/${RT}_host_scaling.jsonl
       for n in 1 2 4 8; do
-        SR_DIST_BACKEND=gloo timeout 900 python bench.py --gpus $n --batch 8 --waves 2 --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-sam --no-more-rows > gpurun_out/r05_hs.log 2> gpurun_out/r05_hs.err
-        python - $n <<'PY' | tee -a gpurun_out/r05_host_scaling.jsonl
+        SR_DIST_BACKEND=gloo timeout 900 python bench.py --gpus $n --batch 8 --waves 2 --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-sam --no-more-rows > gpurun_out/${RT}_hs.log 2> gpurun_out/${RT}_hs.err
+        python - $n <<'PY' | tee -a gpurun_out/${RT}_host_scaling.jsonl
 import json, sys
 try:
-    d = json.loads([l for l in open("gpurun_out/r05_hs.log") if l.startswith("{")][-1])
+    d = json.loads([l for l in open("gpurun_out/${RT}_hs.log") if l.startswith("{")][-1])
     sc = d["phase_ms_per_step"]["scheduler"]
     print(json.dumps({"ranks_on_one_device": int(sys.argv[1]), "n_gpus": d["n_gpus"], "nranks": d["config"]["exchange"]["nranks"], "tiles_per_s_all_ranks": d["value"], "ms_per_step": d["ms_per_step"],
                       "host_threads_per_rank": d["host_threads_per_rank"], "rounds_per_step": sc["rounds"], "host_ms_per_round": sc["host_ms_per_round"], "poll_wait_ms_per_round": sc["poll_wait_ms_per_round"]}))
@@ -89,45 +85,34 @@ except Exception as e:
 PY
       done ;;
     sched_ab) for cfg in "--batch 32" "--batch 64" "--batch 128"; do for rep in 1 2; do for v in 0 1; do
-        SR_SCHED_ONLINE=$v timeout 900 python bench.py $cfg --steps 3 --warmup 1 $QUIET > gpurun_out/r05_cfg.log 2> gpurun_out/r05_cfg.err
+        SR_SCHED_ONLINE=$v timeout 900 python bench.py $cfg --steps 3 --warmup 1 $QUIET > gpurun_out/${RT}_cfg.log 2> gpurun_out/${RT}_cfg.err
         python - "$cfg online=$v rep $rep" <<'PY'
 import json, sys
-d = json.loads([l for l in open("gpurun_out/r05_cfg.log") if l.startswith("{")][-1]); sc = d["phase_ms_per_step"]["scheduler"]
+d = json.loads([l for l in open("gpurun_out/${RT}_cfg.log") if l.startswith("{")][-1]); sc = d["phase_ms_per_step"]["scheduler"]
 print(sys.argv[1], "|", d["value"], "tiles/s | ms/step", d["ms_per_step"], "| shares", sc["admit_cus_per_se"], "| decode step shared", sc["decode_step_ms_shared"])
 PY
       done; done; done ;;
-    gemm_f32) timeout 600 python tools/bench_gemm_f32.py | tee gpurun_out/r05_gemm_f32_split.jsonl ;;
-    sam2bench) timeout 900 python tools/bench_sam2_modes.py | tee gpurun_out/r05_sam2_modes.json ;;
+    gemm_f32) timeout 600 python tools/bench_gemm_f32.py | tee gpurun_out/${RT}_gemm_f32_split.jsonl ;;
+    sam2bench) timeout 900 python tools/bench_sam2_modes.py | tee gpurun_out/${RT}_sam2_modes.json ;;
     sam2tests) timeout 1500 python -m pytest tests/test_gpu_sam2.py tests/test_gpu_round4.py -x -q -m gpu -k "sam2 or gemm_f32 or seg_infer" 2>&1 | tail -8 ;;
     smoke)  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
-    head_ab)   # RMSNorms as the first blocks of the q/k/v / gate/up launches (SR_HEAD_NORM bit mask) against the launches, static 32-row bench, twice
-      for rep in 1 2; do for t in 0 1 2 3; do
-        SR_HEAD_NORM=$t timeout 600 python bench.py --static --steps 3 --warmup 1 $QUIET > gpurun_out/r05_head_${t}.log 2> gpurun_out/r05_head_${t}.err
-        line gpurun_out/r05_head_${t}.log "SR_HEAD_NORM=$t rep $rep:"
-      done; done | tee gpurun_out/r05_head_norm_ab.txt ;;
-    tail_ab)
-      for rep in 1 2; do for t in 0 1 2 3; do
-        SR_TAIL_NORM=$t timeout 600 python bench.py --static --steps 3 --warmup 1 $QUIET > gpurun_out/r05_tail_${t}_$rep.log 2> gpurun_out/r05_tail_${t}_$rep.err
-        line gpurun_out/r05_tail_${t}_$rep.log "SR_TAIL_NORM=$t rep $rep:"
-      done; done ;;
     trace_s32) trace s32 --static --steps 2 --warmup 1 $QUIET ;;
-    tail_trace) SR_TAIL_NORM=0 trace s32_tail0 --static --steps 2 --warmup 1 $QUIET; SR_TAIL_NORM=1 trace s32_tail1 --static --steps 2 --warmup 1 $QUIET ;;
     trace_c32) trace c32 --steps 2 --warmup 1 $QUIET ;;
     trace_b1)  trace b1 --batch 1 --steps 3 --warmup 1 --no-cpu-baseline --no-sam ;;
     trace_fp8) trace fp8_s32 --fp8 --static --steps 2 --warmup 1 $QUIET ;;
     attn_ab)   # prefill attention with the V^T reads issued by hand (default) / left to the compiler, kernel trace of tools/probe_attn.py, twice each
       for rep in 1 2; do for v in 0 1; do rm -rf /tmp/attn_ab
-        (cd /tmp && SR_ATTN_VASM=$v timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/attn_ab -o ab -- python $R/tools/probe_attn.py > $R/gpurun_out/r05_attn_ab.log 2>&1)
+        (cd /tmp && SR_ATTN_VASM=$v timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/attn_ab -o ab -- python $R/tools/probe_attn.py > $R/gpurun_out/${RT}_attn_ab.log 2>&1)
         DB=$(find /tmp/attn_ab -name "ab_results.db" | head -1)
         [ -n "$DB" ] && python tools/rocpd_stats.py $DB /tmp/attn_ab/stats.md > /dev/null && grep "attn" /tmp/attn_ab/stats.md | sed "s/^/SR_ATTN_VASM=$v rep $rep /" | cut -c1-200
-      done; done | tee gpurun_out/r05_attn_vasm_ab.txt ;;
+      done; done | tee gpurun_out/${RT}_attn_vasm_ab.txt ;;
     pmc_lds_all)   # LDS bank conflicts of EVERY kernel of the headline bench and of the SAM2 float32 encoder: which ones have any
       for w in bench sam2; do rm -rf /tmp/pmc_lds
         if [ $w = bench ]; then CMD="python $R/bench.py --steps 1 --warmup 1 $QUIET --no-pmc --no-pipeline"; else CMD="python $R/tools/prof_sam2_encoder.py f32"; fi
-        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -d /tmp/pmc_lds -o p -- $CMD > $R/gpurun_out/r05_pmc_lds_$w.log 2>&1)
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -d /tmp/pmc_lds -o p -- $CMD > $R/gpurun_out/${RT}_pmc_lds_$w.log 2>&1)
         db=$(find /tmp/pmc_lds -name "*.db" | head -1)
-        [ -n "$db" ] && python tools/rocpd_pmc.py "$db" gpurun_out/r05_pmc_lds_$w.json > /dev/null
-        python - gpurun_out/r05_pmc_lds_$w.json <<'PY'
+        [ -n "$db" ] && python tools/rocpd_pmc.py "$db" gpurun_out/${RT}_pmc_lds_$w.json > /dev/null
+        python - gpurun_out/${RT}_pmc_lds_$w.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
 rows = []
@@ -139,22 +124,22 @@ for k, v in d.items():
 for r in sorted(rows, reverse=True):
     print("%.3f" % r[0], *r[1:])
 PY
-      done | tee gpurun_out/r05_pmc_lds_all.txt ;;
+      done | tee gpurun_out/${RT}_pmc_lds_all.txt ;;
     pmc_gemm|pmc_attn|pmc_sam2)   # SQ / fetch counters of the GEMM (tools/probe_r2.py gemm) or prefill-attention (tools/probe_attn.py) kernels: one pass per group
-      if [ $stage = pmc_gemm ]; then PROBE="tools/probe_r2.py gemm"; OUT=r05_pmc_gemm256${PMC_TAG}.json; MATCH="gemm"
+      if [ $stage = pmc_gemm ]; then PROBE="tools/probe_r2.py gemm"; OUT=${RT}_pmc_gemm256${PMC_TAG}.json; MATCH="gemm"
         CGRP="FETCH_SIZE|SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES|SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY|SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16"
-      elif [ $stage = pmc_sam2 ]; then PROBE="tools/prof_sam2_encoder.py f32"; OUT=r05_pmc_sam2_f32${PMC_TAG}.json; MATCH="f32"
+      elif [ $stage = pmc_sam2 ]; then PROBE="tools/prof_sam2_encoder.py f32"; OUT=${RT}_pmc_sam2_f32${PMC_TAG}.json; MATCH="f32"
         CGRP="SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES|SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY|SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS|SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"
-      else PROBE="tools/probe_attn.py"; OUT=r05_pmc_attn_prefill${PMC_TAG}.json; MATCH="attn"
+      else PROBE="tools/probe_attn.py"; OUT=${RT}_pmc_attn_prefill${PMC_TAG}.json; MATCH="attn"
         CGRP="FETCH_SIZE|SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY|SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVES|SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU|SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE|SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"
       fi
-      rm -rf gpurun_out/pmc_r5_$stage; mkdir -p gpurun_out/pmc_r5_$stage
+      rm -rf gpurun_out/pmc_${RT}_$stage; mkdir -p gpurun_out/pmc_${RT}_$stage
       i=0; IFS='|'; for g in $CGRP; do unset IFS; i=$((i+1)); rm -rf /tmp/pmc_g$i
-        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $g -d /tmp/pmc_g$i -o p -- python $R/$PROBE > $R/gpurun_out/pmc_r5_$stage/pass$i.log 2>&1)
+        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $g -d /tmp/pmc_g$i -o p -- python $R/$PROBE > $R/gpurun_out/pmc_${RT}_$stage/pass$i.log 2>&1)
         db=$(find /tmp/pmc_g$i -name "*.db" | head -1)
-        [ -n "$db" ] && python tools/rocpd_pmc.py "$db" gpurun_out/pmc_r5_$stage/pass$i.json > /dev/null 2>> gpurun_out/pmc_r5_$stage/pass$i.log
+        [ -n "$db" ] && python tools/rocpd_pmc.py "$db" gpurun_out/pmc_${RT}_$stage/pass$i.json > /dev/null 2>> gpurun_out/pmc_${RT}_$stage/pass$i.log
         rm -rf /tmp/pmc_g$i; IFS='|'; done; unset IFS
-      python - gpurun_out/pmc_r5_$stage gpurun_out/$OUT $MATCH "$PROBE" <<'PY'
+      python - gpurun_out/pmc_${RT}_$stage gpurun_out/$OUT $MATCH "$PROBE" <<'PY'
 import glob, json, sys
 out = {}
 for f in sorted(glob.glob(sys.argv[1] + "/pass*.json")):
@@ -183,23 +168,23 @@ for k, o in out.items():
 PY
       ;;
     pmc_gemv)
-      mkdir -p gpurun_out/pmc_r5
+      mkdir -p gpurun_out/pmc_${RT}
       for v in bf16 fp8; do for c in FETCH_SIZE WRITE_SIZE; do
         rm -rf /tmp/pmc_$c
-        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o p -- python $R/tools/probe_r2.py gemv $v > $R/gpurun_out/pmc_r5/gemv_${v}_$c.log 2>&1)
-        python tools/rocpd_pmc.py "$(find /tmp/pmc_$c -name '*.db' | head -1)" gpurun_out/pmc_r5/gemv_${v}_$c.json > /dev/null 2>> gpurun_out/pmc_r5/gemv_${v}_$c.log
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o p -- python $R/tools/probe_r2.py gemv $v > $R/gpurun_out/pmc_${RT}/gemv_${v}_$c.log 2>&1)
+        python tools/rocpd_pmc.py "$(find /tmp/pmc_$c -name '*.db' | head -1)" gpurun_out/pmc_${RT}/gemv_${v}_$c.json > /dev/null 2>> gpurun_out/pmc_${RT}/gemv_${v}_$c.log
       done
-      python tools/gemv_traffic.py gpurun_out/pmc_r5/gemv_${v}_FETCH_SIZE.json gpurun_out/pmc_r5/gemv_${v}_WRITE_SIZE.json gpurun_out/r05_pmc_gemv_traffic_$v.json $v | tail -6
+      python tools/gemv_traffic.py gpurun_out/pmc_${RT}/gemv_${v}_FETCH_SIZE.json gpurun_out/pmc_${RT}/gemv_${v}_WRITE_SIZE.json gpurun_out/${RT}_pmc_gemv_traffic_$v.json $v | tail -6
       done ;;
     bench)
-      timeout 1500 python bench.py > gpurun_out/r05_bench_default.log 2> gpurun_out/r05_bench_default.err; echo "bench exit $?"
-      tail -n 1 gpurun_out/r05_bench_default.log > gpurun_out/r05_bench_default_line.json
-      line gpurun_out/r05_bench_default.log "default:" ;;
+      timeout 1500 python bench.py > gpurun_out/${RT}_bench_default.log 2> gpurun_out/${RT}_bench_default.err; echo "bench exit $?"
+      tail -n 1 gpurun_out/${RT}_bench_default.log > gpurun_out/${RT}_bench_default_line.json
+      line gpurun_out/${RT}_bench_default.log "default:" ;;
     configs)
-      : > gpurun_out/r05_other_configs.txt
+      : > gpurun_out/${RT}_other_configs.txt
       for cfg in "--pair" "--fp8" "--fp8 --batch 64" "--fp8 --batch 128" "--fp8-mx --tile 896 --batch 16 --static" "--no-overlap" "--drain" "--batch 64" "--batch 128" "--batch 1"; do
-        timeout 900 python bench.py $cfg --steps 2 --warmup 1 $QUIET > gpurun_out/r05_cfg.log 2> gpurun_out/r05_cfg.err
-        line gpurun_out/r05_cfg.log "bench.py $cfg:" | tee -a gpurun_out/r05_other_configs.txt
+        timeout 900 python bench.py $cfg --steps 2 --warmup 1 $QUIET > gpurun_out/${RT}_cfg.log 2> gpurun_out/${RT}_cfg.err
+        line gpurun_out/${RT}_cfg.log "bench.py $cfg:" | tee -a gpurun_out/${RT}_other_configs.txt
       done ;;
     *) echo "unknown stage $stage" ;;
   esac
