@@ -187,7 +187,9 @@ def test_built_library_keeps_the_two_compiler_findings_of_round_5():
                     addr = re.match(r"ds_read_b64 v\[\d+:\d+\], v(\d+)", l)
                     used = {int(addr.group(1))}
                 assert not (used & regs), (pat, body[i], l)
-    for pat, floor in ((r"k_gemv32ILi0ELi4ELb1E", 16), (r"k_gemv32ILi2ELi1ELb1E", 16), (r"k_gemvILi1ELi2ELi4ELb0ELi4ELb0E", 16), (r"k_gemvILi3ELi2ELi4ELb0ELi4ELb0E", 16)):
+    # round 6: the LDS-staged launches of <= 4 rows too (gate/up with its RMSNorm prologue, the LM head) and the row-major down-projection at batch 1
+    for pat, floor in ((r"k_gemv32ILi0ELi4ELb1E", 16), (r"k_gemv32ILi2ELi1ELb1E", 16), (r"k_gemvILi1ELi2ELi4ELb0ELi4ELb0E", 16), (r"k_gemvILi3ELi2ELi4ELb0ELi4ELb0E", 16),
+                       (r"k_gemvILi1ELi1ELi4ELb1ELi4ELb0E", 12), (r"k_gemvILi2ELi1ELi1ELb1ELi4ELb0E", 12), (r"k_gemvILi0ELi1ELi4ELb0ELi4ELb0E", 16)):
         body = one(pat)
         counts = {int(x) for l in body for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", l)}
-        assert len([c for c in counts if c >= 8]) >= 4 and max(counts) >= floor, (pat, sorted(counts))
+        assert len([c for c in counts if c >= 8]) >= 3 and max(counts) >= floor, (pat, sorted(counts))

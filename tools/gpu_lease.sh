@@ -24,6 +24,8 @@
 #   sam2bench   tools/bench_sam2_modes.py (float32 split / f32-input / bf16)  -> gpurun_out/${RT}_sam2_modes.json
 #   host_scaling    1 / 2 / 4 / 8 gloo ranks on the one device: host ms per scheduling round -> gpurun_out/${RT}_host_scaling.jsonl
 #   sched_ab    admission share from measured costs (default) against the 32-row table (SR_SCHED_ONLINE=0) at 32 / 64 / 128 rows, twice each
+#   counted_ab  batch-1 and static 32-row bench with SR_GEMV_COUNTED=0 / 1, alternating twice (round 6: counted loops for the staged <= 4-row GEMVs)
+#   tests6      tests/test_gpu_round6.py
 #   attn_ab     prefill attention with hand-issued V^T reads (default) against SR_ATTN_VASM=0, kernel trace, twice each -> gpurun_out/${RT}_attn_vasm_ab.txt
 #   pmc_lds_all     LDS bank conflicts of every kernel of the bench and of the SAM2 float32 encoder -> gpurun_out/${RT}_pmc_lds_all.txt
 cd "$(dirname "$0")/.."
@@ -60,6 +62,11 @@ trace() {   # trace <name> <bench args...>: kernel trace + stats summary
 for stage in "$@"; do
   echo "================ stage $stage ($(date +%T))"
   case $stage in
+    tests6) timeout 2400 python -m pytest tests/test_gpu_round6.py -q -m gpu ${TESTS6_K:+-k "$TESTS6_K"} 2>&1 | tail -15 ;;
+    counted_ab) for rep in 1 2; do for v in 0 1; do
+        SR_GEMV_COUNTED=$v timeout 600 python bench.py --batch 1 --steps 3 --warmup 1 --no-cpu-baseline --no-sam --no-pmc > gpurun_out/${RT}_cnt_b1_$v.log 2>&1; line gpurun_out/${RT}_cnt_b1_$v.log "batch 1 SR_GEMV_COUNTED=$v rep $rep:"
+        SR_GEMV_COUNTED=$v timeout 600 python bench.py --static --steps 3 --warmup 1 $QUIET --no-pmc > gpurun_out/${RT}_cnt_s32_$v.log 2>&1; line gpurun_out/${RT}_cnt_s32_$v.log "static 32 SR_GEMV_COUNTED=$v rep $rep:"
+      done; done | tee gpurun_out/${RT}_gemv_counted_ab.txt ;;
     tests5) timeout 2400 python -m pytest tests/test_gpu_round5.py -q -m gpu ${TESTS5_K:+-k "$TESTS5_K"} 2>&1 | tail -15 ;;
     suite)  timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 ;;
     fp8tests) timeout 1500 python -m pytest tests -q -m gpu -k "f8 or fp8" 2>&1 | tail -8 ;;
