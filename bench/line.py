@@ -95,6 +95,6 @@ def assemble(wl, dt, res, roof, cpu, cpu_hf, side):
     out.update({"weights_load_s": round(wl.load_s, 1), "workspace_GB": round(wl.eng.workspace_bytes / 1e9, 2),
                 "result_checksum": int(res.sum().item()),
                 # one per tile of the last step, in tile order over all ranks
-                "result_row_checksums": [int(v) for v in res.sum(dim=1).tolist()] if res.shape[0] <= 64 else None,
+                "result_row_checksums": [int(v) for v in res.sum(dim=1).tolist()] if res.shape[0] <= 256 else None,
                 "host_threads_per_rank": torch.get_num_threads()})
     return out

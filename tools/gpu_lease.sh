@@ -25,7 +25,7 @@
 #   host_scaling    1 / 2 / 4 / 8 gloo ranks on the one device: host ms per scheduling round -> gpurun_out/${RT}_host_scaling.jsonl
 #   sched_ab    admission share from measured costs (default) against the 32-row table (SR_SCHED_ONLINE=0) at 32 / 64 / 128 rows, twice each
 #   counted_ab  batch-1 and static 32-row bench with SR_GEMV_COUNTED=0 / 1, alternating twice (round 6: counted loops for the staged <= 4-row GEMVs)
-#   tests6      tests/test_gpu_round6.py
+#   tests6      tests/test_gpu_round6.py (TESTS6_K selects)
 #   attn_ab     prefill attention with hand-issued V^T reads (default) against SR_ATTN_VASM=0, kernel trace, twice each -> gpurun_out/${RT}_attn_vasm_ab.txt
 #   pmc_lds_all     LDS bank conflicts of every kernel of the bench and of the SAM2 float32 encoder -> gpurun_out/${RT}_pmc_lds_all.txt
 cd "$(dirname "$0")/.."
