@@ -284,10 +284,9 @@ class Mi355xStrategy(InferenceStrategy):
             ids = np.asarray(out, dtype=np.int64)
         elif grids and n_pad != sum(toks):
             raise ValueError(f"Image features and image tokens do not match: tokens: {n_pad}, features {sum(toks)}")
-        pos3, _ = hostops.get_rope_index(torch.from_numpy(ids)[None], grids or None, None,
-                                         spatial_merge_size=g.vision.spatial_merge_size, image_token_id=g.image_token_id,
-                                         vision_start_token_id=g.vision_start_token_id)
-        return ids, pos3[:, 0].numpy(), ims, grids
+        pos3 = hostops.rope_index_1d(ids, grids or None, spatial_merge_size=g.vision.spatial_merge_size, image_token_id=g.image_token_id,
+                                     vision_start_token_id=g.vision_start_token_id)      # (= get_rope_index of this one sequence, without torch's per-op cost)
+        return ids, pos3, ims, grids
 
     @torch.no_grad()
     def generate(self, batch: DataProto, generation_config) -> torch.Tensor:
@@ -509,6 +508,27 @@ class SegRasterStrategy(InferenceStrategy):
     def offload_states(self, *args, **kwargs):
         return None
 
+    def _resized(self, image):
+        """image.resize((756, 756)) (seg_strategy.py:44), remembered per image OBJECT: the second stage segments the image the first stage did
+        (3.7 ms of PIL bicubic per call)."""
+        from collections import OrderedDict
+        memo = self.__dict__.setdefault("_r756", OrderedDict())
+        hit = memo.get(id(image))
+        if hit is not None and hit[0] is image:
+            memo.move_to_end(id(image))
+            return hit[1]
+        r = image.resize((756, 756))
+        memo[id(image)] = (image, r)
+        while len(memo) > 1024:
+            memo.popitem(last=False)
+        return r
+
+    def prefetch(self, images) -> None:
+        """Round 6: start SAM2's image encoder on these images in the background (socioreasoner_amd.sam2.Sam2Predictor.prefetch); `segment` later finds
+        the embeddings cached.  Predictors without `prefetch` (the reference's SAM2ImagePredictor) ignore the hint."""
+        if self.model is not None and hasattr(self.model, "prefetch"):
+            self.model.prefetch([self._resized(im) for im in images])
+
     def segment(self, batch: DataProto) -> dict:
         images, prompts = list(batch.non_tensor_batch["seg_image"]), list(batch.non_tensor_batch["visual_prompt"])
         masks: list = [None] * len(images)
@@ -521,7 +541,7 @@ class SegRasterStrategy(InferenceStrategy):
         if live and hasattr(self.model, "segment_batch"):
             # socioreasoner_amd.sam2: the encoder runs over several images per pass (and not at all for an image it has seen: stage 2
             # segments stage 1's image), decode / arg-max / resize / threshold / OR stay on the device
-            accs = self.model.segment_batch([images[i].resize((756, 756)) for i in live], [prompts[i] for i in live])
+            accs = self.model.segment_batch([self._resized(images[i]) for i in live], [prompts[i] for i in live])
             for i, acc in zip(live, accs):
                 masks[i] = raster.resize_nearest(acc, 768, 768).cpu().numpy()
             live = []

@@ -378,6 +378,9 @@ class SocioSegInferPipeline(BasePipeline):
             gen_batch = batch.pop(batch_keys=["map_input_ids", "map_attention_mask", "map_position_ids"], non_tensor_batch_keys=["multi_modal_map_data"])
             gen_batch.rename(["map_input_ids", "map_attention_mask", "map_position_ids"], ["input_ids", "attention_mask", "position_ids"])
             gen_batch.non_tensor_batch["multi_modal_data"] = gen_batch.non_tensor_batch.pop("multi_modal_map_data")
+            if os.environ.get("SOCIOSEG_SAM_PREFETCH", "1") != "0" and hasattr(self.seg_infer, "prefetch_images"):
+                # SAM2's set_image needs only the pixels (seg_strategy.py:47-58): its encoder starts now, under the LM's stage-1 generation
+                self.seg_infer.prefetch_images(list(batch.non_tensor_batch["seg_image"]))
             out = self._generate(gen_batch, global_step)
             lap("generate_stage1")
             out.rename(["input_ids", "attention_mask", "position_ids", "responses", "response_mask", "prompts", "prompt_mask"],
@@ -397,6 +400,20 @@ class SocioSegInferPipeline(BasePipeline):
             # ---- stage 2: render stage 1 onto both images, re-prompt with the boxes found
             map_response_list = self.tokenizer.batch_decode(batch.batch["map_responses"], skip_special_tokens=False)
             bboxs_text_list = [parse_points_text_from_content(r) for r in map_response_list]
+            # stage 1's files exist from here on: they are rendered (device overlay, this thread) and handed to the writer pool NOW, so that their PNG
+            # encoding runs under stage 2's generation instead of after it (same files, same contents as the reference's write at the end of the batch)
+            from PIL import Image
+            nt1 = batch.non_tensor_batch
+            for i in range(len(batch)):
+                vp1 = nt1["map_visual_prompt"][i][0] if len(nt1["map_visual_prompt"][i]) else {}
+                r1 = draw_visual_prompt(nt1["seg_image"][i], nt1["map_mask"][i], vp1)
+
+                def write1(sid=nt1["id"][i], m1=nt1["map_mask"][i], r1=r1, t1=map_response_list[i]):
+                    Image.fromarray(m1.astype(np.uint8) * 255).save(os.path.join(dirs["stage1"], f"{sid}.png"))
+                    r1.save(os.path.join(dirs["render1"], f"{sid}.png"))
+                    with open(os.path.join(dirs["stage1"], f"{sid}.txt"), "w") as f:
+                        f.write(t1)
+                pending.append(writers.submit(write1))
             batch = batch.union(self._stage2_batch(batch, bboxs_text_list))
             gen_batch = batch.pop(batch_keys=["input_ids", "attention_mask", "position_ids"], non_tensor_batch_keys=["multi_modal_sat_data"])
             gen_batch.non_tensor_batch["multi_modal_data"] = gen_batch.non_tensor_batch.pop("multi_modal_sat_data")
@@ -423,21 +440,14 @@ class SocioSegInferPipeline(BasePipeline):
             for i in range(len(batch)):
                 gt_mask = np.array(nt["gt_mask"][i].convert("L"))
                 giou_list.append(compute_giou(nt["sat_mask"][i], gt_mask))
-                vp1 = nt["map_visual_prompt"][i][0] if len(nt["map_visual_prompt"][i]) else {}
                 vp2 = nt["sat_visual_prompt"][i][0] if len(nt["sat_visual_prompt"][i]) else {}
                 sid = nt["id"][i]
-                from PIL import Image
-
                 # the overlays run on the device from THIS thread (the HIP current device is per thread); the pool only encodes and writes
-                r1, r2 = draw_visual_prompt(nt["seg_image"][i], nt["map_mask"][i], vp1), draw_visual_prompt(nt["seg_image"][i], nt["sat_mask"][i], vp2)
+                r2 = draw_visual_prompt(nt["seg_image"][i], nt["sat_mask"][i], vp2)
 
-                def write(sid=sid, m1=nt["map_mask"][i], m2=nt["sat_mask"][i], r1=r1, r2=r2, t1=map_response_list[i], t2=sat_response_list[i]):
-                    Image.fromarray(m1.astype(np.uint8) * 255).save(os.path.join(dirs["stage1"], f"{sid}.png"))
+                def write(sid=sid, m2=nt["sat_mask"][i], r2=r2, t2=sat_response_list[i]):
                     Image.fromarray(m2.astype(np.uint8) * 255).save(os.path.join(dirs["stage2"], f"{sid}.png"))
-                    r1.save(os.path.join(dirs["render1"], f"{sid}.png"))
                     r2.save(os.path.join(dirs["render2"], f"{sid}.png"))
-                    with open(os.path.join(dirs["stage1"], f"{sid}.txt"), "w") as f:
-                        f.write(t1)
                     with open(os.path.join(dirs["stage2"], f"{sid}.txt"), "w") as f:
                         f.write(t2)
                 pending.append(writers.submit(write))

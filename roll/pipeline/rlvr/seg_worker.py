@@ -48,6 +48,11 @@ class SegWorker(Worker):
         data.meta_info = {"metrics": {}}
         return data
 
+    def prefetch_images(self, images) -> None:
+        """hint: these images will be segmented soon (the strategy may start SAM2's image encoder now; no reference counterpart)"""
+        if hasattr(self.strategy, "prefetch"):
+            self.strategy.prefetch(images)
+
     @torch.no_grad()
     def segment_v4_map(self, data: DataProto) -> DataProto:
         return self._segment(data, "map_responses")

@@ -820,6 +820,13 @@ class Sam2Predictor:
         self._cache: "OrderedDict[bytes, dict]" = OrderedDict()
         self.stats = {"images": 0, "encoded": 0, "cache_hits": 0, "encoder_passes": 0}
         self._upload = None                           # side stream of the image uploads (embed)
+        # round 6: `prefetch` encodes images on a thread of its own (side stream) while the caller generates; the engine has ONE set of buffers,
+        # so every user of it -- a prefetch chunk, embed, segment_batch -- holds this lock and leaves its stream drained when it lets go
+        import threading
+        self._lock = threading.RLock()
+        self._pf_thread = None
+        self._pf_stream = None
+        self._pf_error = None
 
     @staticmethod
     def _host_u8(image) -> np.ndarray:
@@ -837,6 +844,10 @@ class Sam2Predictor:
         """image embeddings of a list of host images: the ones seen before come from the cache (keyed by a hash of the pixels), the rest go
         through the encoder ``batch`` at a time.  Same numbers either way: the encoder is deterministic and images do not interact."""
         import xxhash
+        with self._lock:
+            return self._embed_locked(images, xxhash)
+
+    def _embed_locked(self, images, xxhash):
         arrs = [self._host_u8(im) for im in images]
         keys = [xxhash.xxh3_128_digest(a.data) + bytes(str(a.shape), "ascii") for a in arrs]
         feats: Dict[bytes, dict] = {}
@@ -878,12 +889,46 @@ class Sam2Predictor:
         self.stats["images"] += len(arrs)
         return [feats[k] for k in keys]
 
+    def prefetch(self, images: Sequence) -> None:
+        """Start encoding `images` (host images, as `segment_batch` will receive them) on a background thread and a stream of its own; returns at once.
+        `set_images` needs nothing but the pixels (seg_strategy.py:47-58), so the pipeline calls this before stage-1 generation: the encoder runs under
+        the LM's generate call and `segment_batch` finds the embeddings in the cache (its own `embed` encodes whatever is still missing).  One chunk of
+        `batch` images per lock hold, the side stream drained before the lock is released."""
+        import threading
+        self.wait_prefetch()
+        images = list(images)
+        dev = self.engine.device
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                if self._pf_stream is None:
+                    self._pf_stream = torch.cuda.Stream(dev)
+                for i in range(0, len(images), self.batch):
+                    with self._lock, torch.cuda.stream(self._pf_stream):
+                        self.embed(images[i:i + self.batch])
+                        self._pf_stream.synchronize()
+            except Exception as e:  # noqa: BLE001  (reported by wait_prefetch / the next segment_batch; the embeddings it missed are encoded there)
+                self._pf_error = e
+        self._pf_thread = threading.Thread(target=work, name="sam2-prefetch", daemon=True)
+        self._pf_thread.start()
+
+    def wait_prefetch(self) -> None:
+        t, self._pf_thread = self._pf_thread, None
+        if t is not None:
+            t.join()
+        if self._pf_error is not None:
+            e, self._pf_error = self._pf_error, None
+            raise RuntimeError("SAM2 prefetch failed") from e
+
     def segment_batch(self, images: Sequence, prompts: Sequence[Sequence[dict]]) -> List[torch.Tensor]:
         """seg_strategy.py:40-66 over a whole batch: embeddings (batched / cached), then the object loop of every sample on the device"""
+        self.wait_prefetch()
         out = []
-        for ft, vps in zip(self.embed(images), prompts):
-            self.engine.use_features(ft)
-            out.append(self.segment_objects(vps))
+        with self._lock:
+            for ft, vps in zip(self.embed(images), prompts):
+                self.engine.use_features(ft)
+                out.append(self.segment_objects(vps))
         return out
 
     def segment_objects(self, prompts: Sequence[dict]) -> torch.Tensor:

@@ -87,3 +87,29 @@ def test_gt_boxes_follow_cv2_contour_area_on_hand_computed_cases():
     # reverse raster order of each kept component's first pixel (OpenCV links new contours in front)
     assert got == [{"bbox_2d": [27, 77, 34, 84]}, {"bbox_2d": [40, 40, 70, 60]}, {"bbox_2d": [20, 20, 27, 27]}, {"bbox_2d": [10, 2, 15, 6]}], got
     assert D.count_components([Image.fromarray(m, mode="L")]) == [9]          # connectedComponentsWithStats counts every blob, holes' contents included
+
+
+def test_rope_index_1d_equals_get_rope_index_on_random_prompt_structures():
+    """hostops.rope_index_1d (numpy, one unpadded sequence: what Mi355xStrategy._prepare calls per request) against hostops.get_rope_index (the torch form that is
+    pinned to the reference's own function by tests/golden/index.npz): text-only, one / two / three images of different grids, images back to back, an image
+    token run that is NOT preceded by <vision_start> (plain text to both), text after the last image."""
+    import numpy as np
+    import torch
+    from socioreasoner_amd import hostops
+    IMG, VS = 151655, 151652
+    rng = np.random.default_rng(7)
+    for case in range(60):
+        n_img = int(rng.integers(0, 4))
+        grids, ids = [], []
+        for k in range(n_img):
+            ids += rng.integers(0, 1000, int(rng.integers(0 if k else 1, 12))).tolist()
+            t, h, w = 1, 2 * int(rng.integers(1, 9)), 2 * int(rng.integers(1, 9))
+            grids.append((t, h, w))
+            ids += [VS] + [IMG] * (t * h * w // 4) + [151653]
+        ids += rng.integers(0, 1000, int(rng.integers(0, 20))).tolist()
+        if case % 7 == 3:
+            ids += [5, IMG, IMG, 6]                      # a stray run without <vision_start>: the rule treats it as text
+        ids = np.asarray(ids or [1], dtype=np.int64)
+        want, _ = hostops.get_rope_index(torch.from_numpy(ids)[None], grids or None, None, image_token_id=IMG, vision_start_token_id=VS)
+        got = hostops.rope_index_1d(ids, grids or None, image_token_id=IMG, vision_start_token_id=VS)
+        assert got.dtype == np.int64 and np.array_equal(got, want[:, 0].numpy()), case

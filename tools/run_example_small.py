@@ -24,7 +24,7 @@ os.environ.setdefault("SR_ALLOW_SYNTHETIC_WEIGHTS", "1")       # no SAM2 checkpo
 cfg = load_yaml_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "infer"), "rlvr_megatron")
 cfg["response_length"] = new
 cfg["actor_infer"]["generating_args"]["max_new_tokens"] = new
-cfg["rollout_batch_size"] = min(n, 32)
+cfg["rollout_batch_size"] = int(os.environ.get("ROLLOUT_BATCH", min(n, 32)))      # (the reference YAML: 250 -- ROLLOUT_BATCH=250)
 cfg["output_dir"] = out
 cfg["logging_dir"] = os.path.join(out, "logs")
 t0 = time.time()
