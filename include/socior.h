@@ -254,6 +254,21 @@ int sr_op_gemm_f32(const float* A, int lda, const float* W, int M, int N, int K,
                    const int32_t* rowmap, int epilogue, void* stream);
 int sr_op_attention_f32(const float* q, int q_stride, const float* k, int k_stride, const float* v, int v_stride, float* out, int out_stride,
                         const void* dev_work, int n_work, int n_heads, float scale, int head_dim, void* stream);
+/* ---- float32 VERIFICATION path (round 6).  north_star asks for logits "within 1e-3 of the reference's eager path"; with bf16 activations no implementation,
+ * HF against itself included, meets that.  These entry points complete the float32 ops above to the whole Qwen2.5-VL forward -- ViT,
+ * merger, LM prefill and KV-cache decode with float32 activations on the same bf16-representable weights -- so that tests/f32_path.py can hold the arithmetic
+ * this library implements (RMSNorm eps and form, softmax scale, rotary angles, SiLU / GELU forms, GQA mapping, causal mask) to max |dlogit| <= 1e-3 against HF
+ * run in float32 (/root/reference/roll/distributed/strategy/hf_strategy.py:49-94 with torch_dtype float32; tests/golden/hf_truth3b.npz).  Not a serving path.
+ *   sr_op_attention_f32_causal : sr_op_attention_f32 with the causal mask (query i of an item sees keys 0 .. seq_len - queries + q_off + i); head_dim 128 too.
+ *   sr_op_rmsnorm_f32          : out = w * x * rsqrt(mean(x^2) + eps) per row (hf:65-79 without the bf16 roundings), C <= 8192.
+ *   sr_op_rope_table_f32       : cos | sin [n_pos][n_freq] of pos[i] * inv_freq[f] -- the device cosf / sinf the engine's bf16 rotary tables are rounded from.
+ *   sr_op_rope_f32             : x <- x * cos + rotate_half(x) * sin in place for n_heads heads of head_dim columns; cos / sin rows [rows][ldc >= head_dim].
+ *   sr_op_ew_f32 mode 4        : silu(a) * b with the engine's own silu_f. */
+int sr_op_attention_f32_causal(const float* q, int q_stride, const float* k, int k_stride, const float* v, int v_stride, float* out, int out_stride,
+                               const void* dev_work, int n_work, int n_heads, float scale, int head_dim, void* stream);
+int sr_op_rmsnorm_f32(const float* x, int ldx, const float* w, float* out, int ldo, int rows, int C, float eps, void* stream);
+int sr_op_rope_f32(float* x, int ld, const float* cos_t, const float* sin_t, int ldc, int rows, int n_heads, int head_dim, void* stream);
+int sr_op_rope_table_f32(const float* inv_freq, int n_freq, const int32_t* pos, int n_pos, float* cos_t, float* sin_t, void* stream);
 int sr_op_sam_preprocess_f32(const uint8_t* img, int h, int w, float* out_chw, int S, void* stream);
 int sr_op_im2col_f32(const float* chw, int S, int k, int stride, int pad, float* out, int ld, const int32_t* rowmap, void* stream);
 int sr_op_layernorm_f32(const float* x, int ldx, const float* w, const float* b, float* out, int ldo, int rows, int C, float eps, void* stream);

@@ -1583,8 +1583,22 @@ int sr_op_gemm_f32(const float* A, int lda, const float* W, int M, int N, int K,
 }
 int sr_op_attention_f32(const float* q, int q_stride, const float* k, int k_stride, const float* v, int v_stride, float* out, int out_stride,
                         const void* dev_work, int n_work, int n_heads, float scale, int head_dim, void* stream) {
-    AttnF32Args a{q, q_stride, k, k_stride, v, v_stride, out, out_stride, (const AttnWork*)dev_work, n_work, n_heads, scale};
+    AttnF32Args a{q, q_stride, k, k_stride, v, v_stride, out, out_stride, (const AttnWork*)dev_work, n_work, n_heads, scale, 0};
     SR_WRAP(launch_attn_f32((hipStream_t)stream, a, head_dim));
+}
+int sr_op_attention_f32_causal(const float* q, int q_stride, const float* k, int k_stride, const float* v, int v_stride, float* out, int out_stride,
+                               const void* dev_work, int n_work, int n_heads, float scale, int head_dim, void* stream) {
+    AttnF32Args a{q, q_stride, k, k_stride, v, v_stride, out, out_stride, (const AttnWork*)dev_work, n_work, n_heads, scale, 1};
+    SR_WRAP(launch_attn_f32((hipStream_t)stream, a, head_dim));
+}
+int sr_op_rmsnorm_f32(const float* x, int ldx, const float* w, float* out, int ldo, int rows, int C, float eps, void* stream) {
+    SR_WRAP(launch_rmsnorm_f32((hipStream_t)stream, x, ldx, w, out, ldo, rows, C, eps));
+}
+int sr_op_rope_f32(float* x, int ld, const float* cos_t, const float* sin_t, int ldc, int rows, int n_heads, int head_dim, void* stream) {
+    SR_WRAP(launch_rope_f32((hipStream_t)stream, x, ld, cos_t, sin_t, ldc, rows, n_heads, head_dim));
+}
+int sr_op_rope_table_f32(const float* inv_freq, int n_freq, const int32_t* pos, int n_pos, float* cos_t, float* sin_t, void* stream) {
+    SR_WRAP(launch_rope_table_f32((hipStream_t)stream, inv_freq, n_freq, pos, n_pos, cos_t, sin_t));
 }
 int sr_op_sam_preprocess_f32(const uint8_t* img, int h, int w, float* out_chw, int S, void* stream) {
     SR_WRAP(launch_sam_preprocess_f32((hipStream_t)stream, img, h, w, out_chw, S));

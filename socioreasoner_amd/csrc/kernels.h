@@ -273,7 +273,12 @@ struct AttnF32Args {
     const AttnWork* work; int n_work;
     int n_heads;
     float scale;
+    int causal;                 // 1: query i of an item sees keys 0 .. (seq_len - queries of the sequence + q_off + i)  (the LM; head_dim 128)
 };
+// float32 row ops of the verification path (f32_ops.hip): RMSNorm (hf:65-79 without the bf16 roundings) and rotate-half rotary with per-row cos | sin
+int launch_rmsnorm_f32(hipStream_t s, const float* x, int ldx, const float* w, float* out, int ldo, int rows, int C, float eps);
+int launch_rope_f32(hipStream_t s, float* x, int ld, const float* cos_t, const float* sin_t, int ldc, int rows, int n_heads, int head_dim);
+int launch_rope_table_f32(hipStream_t s, const float* inv_freq, int n_freq, const int* pos, int n_pos, float* cos_t, float* sin_t);
 int launch_attn_f32(hipStream_t s, const AttnF32Args& a, int head_dim);
 
 // ------------------------------------------------------------------ raster.hip

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void k_maxpool_win(const E* in, int ld_in, int
     }
 }
 
-// ---- elementwise, row-major [rows][ld] with C live columns: mode 0 out = a + b, 1 out = a + vec (row vector), 2 relu(a), 3 gelu(a) (erf form)
+// ---- elementwise, row-major [rows][ld] with C live columns: mode 0 out = a + b, 1 out = a + vec (row vector), 2 relu(a), 3 gelu(a) (erf form),
+// 4 silu(a) * b (the LM's / ViT's gated MLP with the product's own silu_f: the float32 verification path, tests/f32_path.py)
 template <typename E>
 __global__ __launch_bounds__(256) void k_ew(const E* a, int lda, const E* b, int ldb, E* out, int ldo, int rows, int C, int mode) {
     const long long i = blockIdx.x * 256ll + threadIdx.x;
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(256) void k_ew(const E* a, int lda, const E* b, int
     if (mode == 0) y = x + ldf(b + (size_t)r * ldb + c);
     else if (mode == 1) y = x + ldf(b + c);
     else if (mode == 2) y = fmaxf(x, 0.f);
+    else if (mode == 4) y = silu_f(x) * ldf(b + (size_t)r * ldb + c);
     else y = gelu_f(x);
     stf(out + (size_t)r * ldo + c, y);
 }

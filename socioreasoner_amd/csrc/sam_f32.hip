@@ -378,6 +378,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_f32(AttnF32Args p) {
     const int h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int nq = min(64, (w.q_len ? w.q_len : w.seq_len) - w.q_off);
     const int qi = wave * 16 + c;                                   // this lane's query inside the tile
+    // causal (the LM of the float32 verification path): the item's queries are the LAST (q_len or seq_len) positions of its keys; query q_off + qi
+    // sees keys 0 .. its own position.  Key 0 is visible to every query, so the running maximum is finite from the first tile on.
+    const int kmax = p.causal ? w.seq_len - (w.q_len ? w.q_len : w.seq_len) + w.q_off + qi : 0x7fffffff;
     const bool qok = qi < nq;
     const bool wave_live = wave * 16 < nq;
     float qreg[NS];
@@ -447,7 +450,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_f32(AttnF32Args p) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const bool live = j0 + 16 * t + 4 * g + v < w.seq_len;
+                const int key = j0 + 16 * t + 4 * g + v;
+                const bool live = key < w.seq_len && key <= kmax;
                 sc[t][v] = live ? sc[t][v] * p.scale : -INFINITY;
                 mx = fmaxf(mx, sc[t][v]);
             }
@@ -513,6 +517,7 @@ int launch_attn_f32(hipStream_t s, const AttnF32Args& a, int head_dim) {
         case 16: hipLaunchKernelGGL(k_attn_f32<16>, grid, dim3(256), 0, s, a); break;
         case 32: hipLaunchKernelGGL(k_attn_f32<32>, grid, dim3(256), 0, s, a); break;
         case 80: hipLaunchKernelGGL(k_attn_f32<80>, grid, dim3(256), 0, s, a); break;
+        case 128: hipLaunchKernelGGL(k_attn_f32<128>, grid, dim3(256), 0, s, a); break;      // (the LM's heads: float32 verification path only)
         default: return -22;
     }
     SR_CHECK_LAUNCH();

@@ -87,6 +87,10 @@ SIGNATURES = {
     "sr_op_gather_rows": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
     "sr_op_gemm_f32": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "sr_op_attention_f32": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, C.c_float, _i, _vp]),
+    "sr_op_attention_f32_causal": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, C.c_float, _i, _vp]),
+    "sr_op_rmsnorm_f32": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, C.c_float, _vp]),
+    "sr_op_rope_f32": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sr_op_rope_table_f32": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "sr_op_sam_preprocess_f32": (C.c_int, [_vp, _i, _i, _vp, _i, _vp]),
     "sr_op_im2col_f32": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "sr_op_layernorm_f32": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, C.c_float, _vp]),

@@ -87,3 +87,55 @@ def test_configs3_eight_ranks_of_32_rows_equal_the_single_process_run():
                "tiles_per_s_all_ranks_one_device": l8["value"], "ms_per_step": l8["ms_per_step"], "host_threads_per_rank": l8["host_threads_per_rank"],
                "host_ms_per_round_rank0": sc.get("host_ms_per_round"), "poll_wait_ms_per_round_rank0": sc.get("poll_wait_ms_per_round"),
                "rows_equal_single_process": True, "single_process_tiles_per_s": l1["value"]}, open(os.path.join(out, "r06_configs3_gloo.json"), "w"), indent=1)
+
+
+# ------------------------------------------------------------------------------------------------ north_star's literal tolerance
+@pytest.mark.parametrize("tag", ["tile448", "pair448", "tile756", "tile896"])
+def test_float32_path_meets_1e3_on_logits_against_hf_float32_at_full_depth(golden_dir, tag):
+    """"Outputs match the reference CPU/eager path within 1e-3 on logits": with bf16 activations no implementation can (HF against itself with another
+    summation order is 0.04 rms apart at this depth) -- the bf16 engine is held to HF-bf16's own distance from float32 instead
+    (tests/test_gpu_round3.py).  A band of that width cannot see a SYSTEMATIC error of 1e-3, so this test closes the clause literally where it can be closed:
+    the same forward with float32 activations, every FLOP through the library's float32 C-ABI entry points (tests/f32_path.py), on the same
+    bf16-representable weights, at FULL depth (32 ViT blocks, 36 LM layers, vocabulary 151 936), against HF `Qwen2_5_VLForConditionalGeneration` run in float32
+    (tests/golden/hf_truth3b.npz; the reference's eager caller is /root/reference/roll/distributed/strategy/hf_strategy.py:49-94):
+        max |ViT + merger output - HF|, max |prefill logits - HF|, max |logits of 15 KV-cache decode steps - HF|  <=  1e-3   (|logit| up to ~4).
+    What that pins to 1e-3: RMSNorm form and eps, softmax scale, rotary angles (the device cosf / sinf the engine's bf16 tables are rounded from) and the
+    2-D / mRoPE channel layouts, SiLU / GELU forms (the engine's own silu_f / gelu_f), GQA mapping, causal mask, window order, merger order, KV-cache decode."""
+    import json
+    import os
+    from oracle import host_ref as H
+    from oracle import model_ref as MR
+    from socioreasoner_amd import synthetic
+    from tests.f32_path import F32Path
+    g = np.load(os.path.join(golden_dir, "hf_truth3b.npz"))
+    G, stride, ps, ls = int(g["g_new"][0]), int(g["stride"][0]), int(g["pool_stride"][0]), int(g["last_f32_stride"][0])
+    cfg = MR.config_3b()
+    tiles, hw = g[f"{tag}_tiles"].tolist(), int(g[f"{tag}_hw"][0])
+    grid = (1, hw // 14, hw // 14)
+    ids, pos3 = g[f"{tag}_ids"], g[f"{tag}_pos3"]
+    f = F32Path(cfg, "cuda:0", seed=0)
+    pv = torch.from_numpy(np.concatenate([H.patchify(synthetic.tile_pixels(i, hw, hw))[0] for i in tiles], axis=0)).to(torch.bfloat16).float()   # (as the fixture's runs saw them)
+    emb = f.vit(pv, [grid] * len(tiles))
+    res = {}
+    d = (emb[:, :cfg.vision.out_hidden_size].flatten()[::ps].cpu() - torch.from_numpy(g[f"{tag}_pooler_f32"])).abs()
+    res["vit_merger_max_abs_err"] = float(d.max())
+    assert float(d.max()) <= 1e-3, ("ViT + merger", float(d.max()))
+    logits = f.lm(f.embed(ids, emb), pos3).cpu()
+    d = (logits[::ls] - torch.from_numpy(g[f"{tag}_logits_last_f32"])).abs()
+    res["prefill_logits_max_abs_err"], res["logit_abs_max"] = float(d.max()), float(logits.abs().max())
+    assert float(d.max()) <= 1e-3, ("prefill logits", float(d.max()))
+    toks, base, worst = g[f"{tag}_tokens"].tolist(), int(pos3.max()) + 1, 0.0
+    for k in range(G - 1):          # teacher-forced on the fixture's tokens, through the KV cache (hf_run in tools/make_golden_truth.py)
+        lg = f.lm(f.embed([toks[k]]), np.full((3, 1), base + k)).cpu()
+        e1 = float((lg[::stride] - torch.from_numpy(g[f"{tag}_sample_f32"][k])).abs().max())
+        e2 = float((lg[torch.from_numpy(g[f"{tag}_top_idx"][k]).long()] - torch.from_numpy(g[f"{tag}_top_val_f32"][k])).abs().max())
+        worst = max(worst, e1, e2)
+        assert max(e1, e2) <= 1e-3, (k, e1, e2)
+    res["decode_steps_max_abs_err"] = worst
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "r06_f32_path_vs_hf_float32.json")
+    cur = json.load(open(path)) if os.path.exists(path) else {}
+    cur[tag] = res
+    json.dump(cur, open(path, "w"), indent=1)
+    print(tag, res)
