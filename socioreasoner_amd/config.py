@@ -125,7 +125,11 @@ def geometry_from_hf_config(cfg: dict) -> ModelGeometry:
                         mrope_section=tuple(rope.get("mrope_section") or dt.mrope_section))
     d = ModelGeometry()
     eos = cfg.get("eos_token_id", tc.get("eos_token_id", d.eos_token_id))
-    check_supported(ModelGeometry(vision=vision, text=text), tie_word_embeddings=t("tie_word_embeddings", True))
+    # HF ties the weights from the TOP-LEVEL flag (PreTrainedModel.tie_weights reads config.tie_word_embeddings); a re-saved config can carry a sub-config
+    # default that differs, so the top level wins when it is there; checkpoints.py / load_safetensors_dir additionally refuse a checkpoint
+    # whose index holds an lm_head.weight
+    tie = cfg["tie_word_embeddings"] if "tie_word_embeddings" in cfg else tc.get("tie_word_embeddings", True)
+    check_supported(ModelGeometry(vision=vision, text=text), tie_word_embeddings=tie)
     return ModelGeometry(vision=vision, text=text, image_token_id=int(cfg.get("image_token_id", d.image_token_id)),
                          video_token_id=int(cfg.get("video_token_id", d.video_token_id)), vision_start_token_id=int(cfg.get("vision_start_token_id", d.vision_start_token_id)),
                          vision_end_token_id=int(cfg.get("vision_end_token_id", d.vision_end_token_id)),

@@ -258,6 +258,29 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs a) {
 // scan over the 1024 threads, then the owning thread walks its range.
 constexpr int FX_SHIFT = 40;
 
+
+// exclusive prefix sum of one value per thread over the block (NT threads) in a FIXED association: Hillis-Steele inside each wave (shuffles), then the wave
+// totals in wave order.  sw: >= NT / 64 floats of LDS nobody else uses across the call.  total = the block's sum (same association for every thread).
+__device__ __forceinline__ float block_excl_scan(int tid, float v, float* sw, float& total) {
+    const int lane = tid & 63, wave = tid >> 6;
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();                 // (sw may still be read by an earlier call)
+    if (lane == 63) sw[wave] = inc;
+    __syncthreads();
+    float base = 0.f, tot = 0.f;
+    for (int w = 0; w < NT / 64; ++w) {
+        if (w < wave) base += sw[w];
+        tot += sw[w];
+    }
+    total = tot;
+    const float excl = __shfl_up(inc, 1, 64);         // the wave-inclusive sum of the lane before (every lane executes the shuffle)
+    return base + (lane ? excl : 0.f);
+}
 __global__ __launch_bounds__(NT) void k_sample_full(SampleArgs a) {
     __shared__ unsigned long long mh[4096];        // mass histogram (fixed point)
     __shared__ int ch[256];                        // count histogram of the last level (ties at tau)
@@ -348,12 +371,10 @@ __global__ __launch_bounds__(NT) void k_sample_full(SampleArgs a) {
         const uint32_t k = fkey(adj(i));
         ties += k == tau;
     }
-    // exclusive scan of the tie counts (fixed order) -> which ties of this range are among the first r_keep
-    s_scan[tid] = (float)ties;
-    __syncthreads();
-    int ties_before = 0;
-    for (int t = 0; t < tid; ++t) ties_before += (int)s_scan[t];
-    __syncthreads();
+    // exclusive scan of the tie counts -> which ties of this range are among the first r_keep.  Round 6: a wave-level shuffle scan + a
+    // 16-entry cross-wave pass in fixed order instead of every thread walking s_scan[0 .. tid) (O(NT^2) LDS reads inside the captured decode step)
+    float tie_total;
+    const int ties_before = (int)block_excl_scan(tid, (float)ties, s_scan, tie_total);        // (counts <= 149: exact in float32)
     int seen_ties = ties_before;
     for (int i = i0; i < i1; ++i) {
         const float l = adj(i);
@@ -361,13 +382,8 @@ __global__ __launch_bounds__(NT) void k_sample_full(SampleArgs a) {
         const bool keep = k > tau || (k == tau && seen_ties++ < r_keep);
         if (keep) msum += __expf((l - mx) * a.inv_temp) * inv_z;
     }
-    s_scan[tid] = msum;
-    __syncthreads();
-    float before = 0.f, total = 0.f;
-    for (int t = 0; t < NT; ++t) {
-        if (t < tid) before += s_scan[t];
-        total += s_scan[t];
-    }
+    float total;
+    const float before = block_excl_scan(tid, msum, s_scan, total);          // fixed association: lanes inside a wave, then the waves in order -> run-to-run identical
     const int stp = a.step ? a.step[b] : 0;
     const uint32_t h = hmix(a.seed ^ hmix((uint32_t)b * 0x9E3779B1u + (uint32_t)stp * 0x85EBCA77u + 0x1234567u));
     const float u = (float)(h >> 8) * (1.0f / 16777216.0f);

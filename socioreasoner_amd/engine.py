@@ -95,10 +95,21 @@ class Engine:
         files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
         if not files:
             raise L.SocioRError(f"no *.safetensors under {path}")
+        head = emb = None
         for f in files:
             with safe_open(f, framework="pt") as sf:
                 for k in sf.keys():
-                    self.load_weight(k, sf.get_tensor(k))
+                    t = sf.get_tensor(k)
+                    if k.endswith("lm_head.weight"):
+                        head = t                        # (the engine's LM head IS the embedding matrix: checked below, never loaded)
+                        continue
+                    if k.endswith("embed_tokens.weight"):
+                        emb = t
+                    self.load_weight(k, t)
+        # decided from the checkpoint itself, whatever config.json says: an lm_head.weight that differs from the embedding is an UNTIED head
+        if head is not None and emb is not None and (head.shape != emb.shape or not torch.equal(head, emb)):
+            raise L.SocioRError("this checkpoint has an untied LM head (lm_head.weight differs from model.embed_tokens.weight): the engine uses the "
+                                "embedding matrix as the head and would compute different logits")
         self.assert_ready()
 
     def load_synthetic_weights(self, seed: int = 0):

@@ -59,7 +59,8 @@ class ContinuousBatcher:
         # engine like the unshared calibration.
         self._dec_meas, self._adm_meas = getattr(engine, "_sched_cal_shared", ({}, {}))
         self._cal_dec_sh = self._cal_adm_sh = None
-        self._cal_seen = engine.__dict__.setdefault("_sched_cal_seen", {})      # ("dec" | "adm", share) -> samples taken: 8 per share, then the timed events stop
+        self._cal_seen = engine.__dict__.setdefault("_sched_cal_seen", {})      # ("dec" | "adm", share) -> samples taken (8 fast ones per share, then every 8th opportunity)
+        self._cal_opp: Dict[tuple, int] = {}
         import os
         self._online = os.environ.get("SR_SCHED_ONLINE", "1") != "0"      # 0: the 32-row tables only (A/B hook of tools/gpu_lease.sh sched_ab)
         self._cnt_last: Dict[int, int] = {}
@@ -214,9 +215,20 @@ class ContinuousBatcher:
             return base * min(max(k, 0.5), 2.0)
         return base
 
-    @staticmethod
-    def _ema(table: dict, key: int, value: float):
-        table[key] = value if key not in table else 0.5 * table[key] + 0.5 * value
+    def _ema(self, table: dict, key: int, value: float):
+        """fast while a share is new (the first 8 samples), slow afterwards: the measurement never stops (a table frozen after 8 samples keeps
+        a stale factor when the workload on a long-lived engine changes -- prompt lengths, context, rows per step)"""
+        kind = "dec" if table is self._dec_meas else "adm"
+        a = 0.5 if self._cal_seen.get((kind, key), 0) < 8 else 0.125
+        table[key] = value if key not in table else (1.0 - a) * table[key] + a * value
+
+    def _sample_due(self, kind: str) -> bool:
+        """every opportunity for a share's first 8 samples, every 8th afterwards (two timed events per sample)"""
+        n = self._cal_seen.get((kind, self._share), 0)
+        if n < 8:
+            return True
+        k = self._cal_opp[(kind, self._share)] = self._cal_opp.get((kind, self._share), 0) + 1
+        return k % 8 == 0
 
     def _pick_share(self, a_ms: float, steps_left: float) -> int:
         """CUs per shader engine for an admission that takes a_ms on the whole chip while the running rows still have steps_left decode
@@ -266,7 +278,7 @@ class ContinuousBatcher:
             s = self._use_decode_stream(self.streams.decode_full)
         cal = self._auto and not shared and self._adm_rate is None and self._cal_adm is None
         cal_sh = bool(self._online and self._auto and shared and self._adm_rate is not None and self._cal_adm_sh is None
-                      and self._cal_seen.get(("adm", self._share), 0) < 8)
+                      and self._sample_due("adm"))
         try:
             self._stage_on(s, grp, slots, shared, cal or cal_sh, units)
             if cal_sh and self._cal_adm is not None:          # (_stage_on left the event pair in _cal_adm: this one measures a SHARED admission)
@@ -344,7 +356,7 @@ class ContinuousBatcher:
         cal = (self._auto and not busy and not (self.staged is None and self.pending and self.free_slots)
                and self._step_ms is None and self._cal_step is None)
         cal_sh = bool(self._online and self._auto and busy and self._step_ms is not None and self._cal_dec_sh is None       # a chunk on the decode CU set next to the admission
-                      and self._cal_seen.get(("dec", self._share), 0) < 8)
+                      and self._sample_due("dec"))
         with torch.cuda.stream(s):
             if cal or cal_sh:
                 c0 = torch.cuda.Event(enable_timing=True)
