@@ -59,7 +59,7 @@ __device__ __forceinline__ void spin_until(unsigned* p, unsigned target, unsigne
     unsigned it = 0;
     while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++it > (1u << 22)) { atomicAdd(err, 1u); break; }      // never hang the GPU
+        if (++it > (1u << 18)) { atomicAdd(err, 1u); break; }      // never hang the GPU
     }
 }
 
@@ -130,6 +130,78 @@ __global__ __launch_bounds__(256) void k_persistent(Args p) {
         const __amdgpu_buffer_rsrc_t rn = rsrc(p.edge[(ph + 1) & 1], (unsigned)p.edge_bytes);
         for (int i = tid * 16; i < slice; i += 256 * 16)
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{(unsigned)(ph + 1), acc, (unsigned)b, acc}, rn, b * slice + i, 0, SC1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0 && ph >= p.stamp_from) {
+            long long* s = p.stamps + ((size_t)(ph - p.stamp_from) * G + b) * 3;
+            s[0] = t0; s[1] = t1; s[2] = t2;
+        }
+    }
+    if (acc == 0x12345678u) p.sink[0] = acc;
+}
+
+// XCD-LOCAL variant (round 6): the edge is produced REDUNDANTLY inside every XCD (8 copies, one per XCD: what a per-XCD recomputation of an RMSNorm would
+// be), so the hand-off never leaves the XCD's L2: plain stores (L1 is write-through) + vmcnt(0) + an L2 atomic (no sc bits: atomics always execute at L2) as the
+// arrival, polled with an L2 atomic, then sc0 loads (L1 bypass, L2 hit) for the payload.  Every chunk's tag is checked like above.
+enum { SC0 = 1 };
+__global__ __launch_bounds__(256) void k_persistent_xcd(Args p, unsigned char* xedge /* [2][8][edge_bytes] */) {
+    __shared__ unsigned s_n[2];
+    const int tid = threadIdx.x, b = blockIdx.x, G = gridDim.x;
+    const unsigned x = xcc_id();
+    if (tid == 0) {
+        const unsigned mine = __hip_atomic_fetch_add(&p.bar->census[x * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&p.bar->flat[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        spin_until(&p.bar->flat[0], (unsigned)G, &p.bar->err[0]);
+        s_n[0] = __hip_atomic_load(&p.bar->census[x * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_n[1] = mine;                                            // this block's index inside its XCD
+    }
+    __syncthreads();
+    const unsigned n_mine = s_n[0], idx = s_n[1];
+    const int per_thread = p.edge_bytes / (256 * 16);
+    const int slice = p.edge_bytes / (int)n_mine / 16 * 16;     // this block's share of ITS XCD's copy (the last block takes the remainder)
+    const int s0 = (int)idx * slice, s1 = idx + 1 == n_mine ? p.edge_bytes : s0 + slice;
+    unsigned acc = 0;
+    for (int ph = 0; ph < p.n_phases; ++ph) {
+        const long long t0 = wall_clock64();
+        u32x4 w[16];
+        const unsigned char* wp = p.wts + ((size_t)ph * G + b) * (size_t)p.pf_loads * 256 * 16 + tid * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < p.pf_loads) w[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)i * 256 * 16));
+        if (ph > 0) {
+            if (tid == 0) {
+                unsigned* c = &p.bar->xcd_cnt[x * 32];
+                // (workgroup-scope atomics were tried first: the pollers never saw the other CUs' arrivals -- every spin gave up and every chunk read stale;
+                // the counter needs agent scope even when all its users share one L2)
+                __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned it = 0;
+                while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_mine * (unsigned)ph) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++it > (1u << 16)) { atomicAdd(&p.bar->err[0], 1u); break; }
+                }
+            }
+            __syncthreads();
+        }
+        const long long t1 = wall_clock64();
+        unsigned char* mine_r = xedge + ((size_t)(ph & 1) * 8 + x) * p.edge_bytes;
+        const __amdgpu_buffer_rsrc_t re = rsrc(mine_r, (unsigned)p.edge_bytes);
+        unsigned stale = 0;
+        for (int c0 = 0; c0 < per_thread; c0 += 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (c0 + i < per_thread) v[i] = __builtin_amdgcn_raw_buffer_load_b128(re, ((c0 + i) * 256 + tid) * 16, 0, SC0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (c0 + i < per_thread) { stale += v[i][0] != (unsigned)ph; acc += v[i][1] ^ v[i][3]; }
+        }
+        const long long t2 = wall_clock64();
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < p.pf_loads) acc += w[i][0] ^ w[i][2];
+        if (stale) atomicAdd(&p.bar->err[1], stale);
+        u32x4* o = reinterpret_cast<u32x4*>(xedge + ((size_t)((ph + 1) & 1) * 8 + x) * p.edge_bytes);
+        for (int i = s0 / 16 + tid; i < s1 / 16; i += 256) o[i] = u32x4{(unsigned)(ph + 1), acc, (unsigned)b, acc};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0 && ph >= p.stamp_from) {
@@ -221,6 +293,37 @@ int main(int argc, char** argv) {
             for (int b = 0; b < G; ++b) prev_first0 = std::min(prev_first0, n0[b * 3]);
             span.push_back((first0 - prev_first0) * 0.01);
         }
+        // XCD-local hand-off (8 redundant copies of the edge, nothing leaves an XCD's L2)
+        double xcd_us = 0, xcd_wait = 0, xcd_gather = 0;
+        unsigned xcd_err[2] = {0, 0};
+        if (mode == 0) {
+            static unsigned char* xedge = nullptr;
+            if (!xedge) CK(hipMalloc(&xedge, (size_t)2 * 8 * (1 << 20)));
+            double bx = 1e30;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipMemsetAsync(bar, 0, sizeof(Bar), s));
+                CK(hipMemsetAsync(xedge, 0, (size_t)2 * 8 * (1 << 20), s));
+                hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
+                CK(hipEventRecord(a0, s));
+                hipLaunchKernelGGL(k_persistent_xcd, dim3(G), dim3(256), 0, s, a, xedge);
+                CK(hipEventRecord(a1, s));
+                CK(hipStreamSynchronize(s));
+                float ms; CK(hipEventElapsedTime(&ms, a0, a1));
+                bx = std::min(bx, (double)ms);
+                unsigned e3[2];
+                CK(hipMemcpy(e3, bar->err, 8, hipMemcpyDeviceToHost));
+                xcd_err[0] += e3[0]; xcd_err[1] += e3[1];
+            }
+            xcd_us = bx * 1e3 / NPH;
+            CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> w_, g_;
+            for (int ph = 1; ph < STAMP; ++ph)
+                for (int b = 0; b < G; ++b) {
+                    const long long* q = &hs[((size_t)ph * G + b) * 3];
+                    w_.push_back((q[1] - q[0]) * 0.01); g_.push_back((q[2] - q[1]) * 0.01);
+                }
+            xcd_wait = med(w_); xcd_gather = med(g_);
+        }
         // the same phases as graph-captured launches
         double launches_us = 0;
         if (mode == 0) {
@@ -249,9 +352,10 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(e2, bar->err, 8, hipMemcpyDeviceToHost));
         printf("{\"edge_KB\": %d, \"weight_prefetch_KB_per_block_and_phase\": %d, \"barrier\": \"%s\", \"persistent_us_per_phase\": %.2f, "
                "\"phase_span_us_median\": %.2f, \"wait_us_median_block\": %.2f, \"last_arrival_to_last_release_us\": %.2f, \"gather_us_median_block\": %.2f, "
-               "\"launches_us_per_phase\": %.2f, \"spins_given_up\": %u, \"stale_chunks_persistent\": %u, \"stale_chunks_launches\": %u}\n",
+               "\"launches_us_per_phase\": %.2f, \"spins_given_up\": %u, \"stale_chunks_persistent\": %u, \"stale_chunks_launches\": %u, "
+               "\"xcd_local_us_per_phase\": %.2f, \"xcd_local_wait_us\": %.2f, \"xcd_local_gather_us\": %.2f, \"xcd_local_spins_given_up\": %u, \"xcd_local_stale_chunks\": %u}\n",
                edge_kb, pf * 4, mode ? "flat counter" : "xcd-hierarchical", best * 1e3 / NPH, med(span), med(wait_med), med(wait_last), med(gather),
-               launches_us, herr[0], herr[1], e2[1]);
+               launches_us, herr[0], herr[1], e2[1], xcd_us, xcd_wait, xcd_gather, xcd_err[0], xcd_err[1]);
         fflush(stdout);
     }
     return 0;
