@@ -161,12 +161,19 @@ def pipeline(n_samples):
     (rollout_batch_size 250, temperature 1 / top_p 0.8 / top_k 100: rlvr_megatron.yaml:89-95) with SAM2 DOING WORK: random weights emit no
     <answer>, so tools/run_example_small.py scripts the decoded answers (4 objects per stage; the LM still generates its 128 tokens per stage on
     the engine).  A child process (own engines); phase wall times from SocioSegInferPipeline.timing."""
-    env = child_env(SCRIPTED_OBJECTS="4", SOCIOSEG_NUM_SAMPLES=str(n_samples), NEW_TOKENS=str(N_NEW), OUT="/tmp/sr_bench_pipeline_out", YAML_SAMPLING="1")
+    env = child_env(SCRIPTED_OBJECTS="4", SOCIOSEG_NUM_SAMPLES=str(n_samples), NEW_TOKENS=str(N_NEW), OUT="/tmp/sr_bench_pipeline_out",
+                    ROLLOUT_BATCH=str(n_samples))
+    script = [PYTHON, os.path.join(ROOT, "tools", "run_example_small.py")]
     try:
-        r_ = subprocess.run([PYTHON, os.path.join(ROOT, "tools", "run_example_small.py")], capture_output=True, text=True, timeout=900, env=env)
+        r_ = subprocess.run(script, capture_output=True, text=True, timeout=900, env=env)
         p = last_json_line(r_.stdout)
+        try:      # the same run with 128 LM batch rows instead of the example YAML's 32 (the reference's scheduler keeps up to 128 requests in flight)
+            q = last_json_line(subprocess.run(script, capture_output=True, text=True, timeout=900, env=dict(env, MAX_BATCH="128")).stdout)
+            p["with_128_lm_batch_rows"] = {k: q[k] for k in ("samples_per_s", "run_s", "wall_s_by_phase")}
+        except Exception as e_:  # noqa: BLE001
+            p["with_128_lm_batch_rows"] = {"error": f"{type(e_).__name__}: {e_}"[:200]}
         p["workload"] = (f"SocioSegInferPipeline.run() on {n_samples} synthetic SocioSeg samples, the shipped YAML (3B LM + SAM2 Hiera-L float32, synthetic "
-                         "weights; "
+                         "weights; rollout_batch_size = the sample count as in the reference YAML; "
                          "the YAML's sampling parameters), 128 new tokens per stage, decoded answers scripted to 4 objects per stage so that seg_infer encodes "
                          "every satellite image and decodes 4 prompts per stage and sample")
         return p

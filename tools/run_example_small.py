@@ -24,6 +24,8 @@ os.environ.setdefault("SR_ALLOW_SYNTHETIC_WEIGHTS", "1")       # no SAM2 checkpo
 cfg = load_yaml_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "infer"), "rlvr_megatron")
 cfg["response_length"] = new
 cfg["actor_infer"]["generating_args"]["max_new_tokens"] = new
+if os.environ.get("MAX_BATCH"):      # batch rows of the LM engine (the example YAML says 32 = BASELINE.json configs[2]; vLLM's own default admits 256 sequences, the reference's scheduler 128)
+    cfg["actor_infer"]["strategy_args"]["strategy_config"]["max_batch"] = int(os.environ["MAX_BATCH"])
 cfg["rollout_batch_size"] = int(os.environ.get("ROLLOUT_BATCH", min(n, 32)))      # (the reference YAML: 250 -- ROLLOUT_BATCH=250)
 cfg["output_dir"] = out
 cfg["logging_dir"] = os.path.join(out, "logs")
