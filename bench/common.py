@@ -42,8 +42,9 @@ def parse_args(argv=None):
                     "staging the next admission on a CU-masked stream under the running rows' decode")
     ap.add_argument("--drain", action="store_true", help="continuous mode: drain the batch rows between steps (every step starts with an exposed admission "
                     "on an idle engine, rounds 1-3) instead of serving the steps' requests as ONE stream")
-    ap.add_argument("--poll", type=int, default=16, help="continuous mode: decode steps queued per scheduling round (rows are released / admitted between "
-                    "rounds)")
+    ap.add_argument("--poll", type=int, default=8, help="continuous mode: decode steps queued per scheduling round (rows are released / admitted between "
+                    "rounds; 8 = ContinuousBatcher's own default.  Round 6, same box, alternating: 82.3-83.0 tiles/s at 16, 83.0 at 8, 82.8 at 4 -- the rows "
+                    "return to the whole chip at the first poll after an admission has landed)")
     ap.add_argument("--poll-ragged", type=int, default=4, help="the same for the ragged phase (0 = --poll): rows that end on different steps are refilled "
                     "sooner "
                     "with short rounds -- measured 59.8 / 60.8 / 62.1 tiles/s at 16 / 8 / 4")
