@@ -37,6 +37,13 @@ __device__ long long g_tgv[16384 * 4];
 #define TGV(slot)
 #endif
 
+// -DSR_EXP_NOX (tools/probe_gemv_masked.py builds its own library with it; never the product build): every x fragment load of the counted loops reads
+// chunk 0 again -- L1 hits, WRONG results, the same instruction stream: what would a launch cost if the activations cost no L2 traffic?
+#ifdef SR_EXP_NOX
+#define SR_XC(c) 0
+#else
+#define SR_XC(c) (c)
+#endif
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 __device__ __forceinline__ u32x4 ldg_nt(const bf16_t* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
@@ -294,8 +301,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
             auto fill_xt = [&](int u, int c) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    xv[STAGE ? 0 : u][mt][0] = *reinterpret_cast<const u32x4*>(xb[mt] + (size_t)c * x_cs);
-                    xv[STAGE ? 0 : u][mt][1] = *reinterpret_cast<const u32x4*>(xb[mt] + (size_t)c * x_cs + x_h);
+                    xv[STAGE ? 0 : u][mt][0] = *reinterpret_cast<const u32x4*>(xb[mt] + (size_t)SR_XC(c) * x_cs);
+                    xv[STAGE ? 0 : u][mt][1] = *reinterpret_cast<const u32x4*>(xb[mt] + (size_t)SR_XC(c) * x_cs + x_h);
                 }
             };
             if constexpr (!STAGE) {
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
             auto fill_a = [&](int u, int c) {
                 c = min(c, cend - 1);
 #pragma unroll
-                for (int st = 0; st < 4; ++st) xv[u][st] = *reinterpret_cast<const u32x4*>(xbase + (size_t)c * x_c + st * x_s);
+                for (int st = 0; st < 4; ++st) xv[u][st] = *reinterpret_cast<const u32x4*>(xbase + (size_t)SR_XC(c) * x_c + st * x_s);
 #pragma unroll
                 for (int st = 0; st < 4; ++st) w[u][st] = ldg_nt(wbase + (size_t)c * w_c + st * w_s);
             };

@@ -54,8 +54,12 @@ def main():
     s3 = streams.overlap_streams("cuda:0", 3)
     s4 = streams.overlap_streams("cuda:0", 4)
     s2 = streams.overlap_streams("cuda:0", 2)
+    full_mask = streams.masked_stream("cuda:0", 0, 8)          # round 6: a stream created WITH a CU mask that enables every CU -- is there a cost of the masked queue itself?
+    m7 = streams.masked_stream("cuda:0", 0, 7)
     for _ in range(2):
         run("(a) ordinary stream, alone", plain)
+        run("(a') masked stream with ALL 8/8 CUs enabled, alone", full_mask)
+        run("(a'') masked stream 7/8 CUs, alone", m7)
         run("(b) masked decode stream 5/8 CUs, alone", s3.decode)
         run("(d) masked decode stream 4/8 CUs, alone", s4.decode)
         run("(d) masked decode stream 6/8 CUs, alone", s2.decode)
