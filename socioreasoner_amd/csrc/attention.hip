@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(256) void k_attn_dec_pv(DecodeAttnArgs p, int s_str
 }  // namespace
 
 #ifdef SR_ATTN_TIMING
-extern "C" int sr_dbg_attn_dec_times(long long* host_out) {
+extern "C" __attribute__((visibility("default"))) int sr_dbg_attn_dec_times(long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tad), sizeof(long long) * 2 * 8192 * 5, 0, hipMemcpyDeviceToHost);
 }
 #endif

@@ -89,6 +89,7 @@ static void load_switches() {
     g_sw.attn_vasm = env_int("SR_ATTN_VASM", 1);
     g_sw.sam_f32_split = env_int("SR_SAM_F32_SPLIT", 1);
     g_sw.gemv_counted = env_int("SR_GEMV_COUNTED", 1);
+    g_sw.gemv_xlds = env_int("SR_GEMV_XLDS", 1);
     g_sw_loaded = true;
 }
 const SrSwitches& sr_switches() {
@@ -136,6 +137,7 @@ struct sr_engine {
     bf16_t *d_xa, *d_xb, *d_xn, *d_qkv, *d_attn, *d_act, *d_scores;    // d_xa / d_xb: residual stream ping-pong
     float *d_logits, *d_slabs, *d_amax_val;
     float* d_row_cs = nullptr;               // [MAXB][128] rotary cos | sin of every row's current position (k_step -> decode attention)
+    unsigned* d_px = nullptr;                // [256] 8 ticket shards + done count of the persistent x-resident GEMV (k_gemv_px): zero between launches
     int *d_amax_idx, *d_cur_tok, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
     int n_part = 0;      // LM-head blocks = partial argmax entries per row
     // continuous batching (sr_rows_*): admission scratch so that a prefill never touches the pending tokens of running rows
@@ -346,6 +348,7 @@ void carve(sr_engine* e) {
     e->d_amax_idx_adm = ar.take<int>(B * e->n_part);
     e->d_row_limit = ar.take<int>(MAXB);
     e->d_row_cs = ar.take<float>(MAXB * 128);
+    e->d_px = ar.take<unsigned>(256);
     e->d_ngen = ar.take<int>(MAXB);
     e->d_adm = ar.take<int>(5 * MAXB);
     e->d_adm_slots = ar.take<int>(MAXB);
@@ -663,6 +666,7 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         else {
             SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt));
             gg.x = e->d_xn; gg.x_tiled = xt; gg.out_tiled = xt;
+            gg.px_counter = e->d_px;        // 17..32 rows: launch_gemv may take the persistent x-resident kernel (same bits)
         }
         if (gg.M > 0) SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
         GemvArgs gd = gv(e->d_act, e->t_inter_pad, w.down_w, B, H, e->t_inter_pad, e->d_slabs, H);
@@ -737,6 +741,7 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
     if (r == hipSuccess) r = hipMemset(e->kcache, 0, e->kv_layer_elems * e->c.t_layers * sizeof(bf16_t));
     if (r == hipSuccess) r = hipMemset(e->vtcache, 0, e->kv_layer_elems * e->c.t_layers * sizeof(bf16_t));
     if (r == hipSuccess) r = hipMemset(e->d_cur_tok, 0, (char*)e->d_tokens - (char*)e->d_cur_tok);
+    if (r == hipSuccess) r = hipMemset(e->d_px, 0, 256 * sizeof(unsigned));
     if (r == hipSuccess) r = hipMemset(e->v_vt, 0, (size_t)e->c.v_hidden * e->v_vt_stride * sizeof(bf16_t));
     // normalise LUT (hf image_transforms.py:89-124, 384-440) and rotary inverse frequencies (hf:506-523)
     std::vector<bf16_t> lut(768);
@@ -754,6 +759,7 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
     if (r == hipSuccess) r = hipDeviceSynchronize();
     if (r == hipSuccess) r = (hipError_t)attn_decode_prepare(e->c.max_ctx, e->t_group);
     if (r == hipSuccess && e->c.max_batch > 64) r = (hipError_t)gemm_prepare_decode();
+    if (r == hipSuccess) r = (hipError_t)gemv_prepare_px();
     if (r != hipSuccess) {
         int rc = fail(nullptr, (int)r, "engine init: %s", hipGetErrorString(r));
         sr_engine_destroy(e);
@@ -1646,6 +1652,12 @@ int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K,
     a.w_tiled = (mode & 0x100) ? 1 : 0;
     a.x_tiled = (mode & 0x800) ? 1 : 0;          // bit 11: x fragment-ordered; bit 12: SWIGLU output fragment-ordered
     a.out_tiled = (mode & 0x1000) ? 1 : 0;
+    // the op-level callers (tests, probes; one stream at a time) share one process-wide ticket pair for the persistent x-resident kernel
+    static unsigned* g_px = nullptr;
+    if (!g_px && (mode & 0xff) == GV_SWIGLU && M > 16) {
+        if (hipMalloc(&g_px, 256 * sizeof(unsigned)) != hipSuccess || hipMemset(g_px, 0, 256 * sizeof(unsigned)) != hipSuccess) return -12;
+    }
+    a.px_counter = g_px;
     SR_WRAP(launch_gemv((hipStream_t)stream, a, mode & 0xff));
 }
 int sr_op_gemv_f32_blocks(int N, int M, int K, int has_norm) { return gemv_f32_blocks(N, M, K, has_norm); }

@@ -614,10 +614,10 @@ int launch256_t(hipStream_t s, const GemmArgs& a) {
 }  // namespace
 
 #ifdef SR_G256_TIMING
-extern "C" int sr_dbg_g256_times(long long* host_out, int n_blocks) {
+extern "C" __attribute__((visibility("default"))) int sr_dbg_g256_times(long long* host_out, int n_blocks) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_t256), (size_t)n_blocks * 6 * sizeof(long long), 0, hipMemcpyDeviceToHost);
 }
-extern "C" int sr_dbg_g256_phases(long long* host_out) {
+extern "C" __attribute__((visibility("default"))) int sr_dbg_g256_phases(long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_p256), sizeof(long long) * (1024 * 2 * 6 + 2048), 0, hipMemcpyDeviceToHost);
 }
 #endif

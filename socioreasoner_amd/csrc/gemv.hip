@@ -26,6 +26,8 @@
 // (Measured dead ends of round 3 -- RMSNorm folded into / deferred behind the consuming GEMV, 8- and 16-wave blocks, a 3-deep gate/up ring --
 // are no longer compiled into the library: tools/experiments/README.md.)
 
+int gemv_prepare_px();
+
 namespace {
 
 // -DSR_GEMV_TIMING (tools/probe_gemv_timeline.py builds its own library with it; never the product build): wave 0 of every block records the
@@ -504,6 +506,177 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
     TGV(3);
 }
 
+// ---------------------------------------------------------------------------------------------- 17..32 rows, x STATIONARY in registers (round 6)
+// Why: at 32 rows every wave of k_gemv re-reads as many bytes of x from L2 as it streams weights from HBM, and a CU's load path carries both.  On the whole chip
+// that costs the gate/up launch ~2 us of 19; on the scheduler's 160-CU decode stream (5 of 8 CUs per shader engine while an admission is staged: 63 % of the
+// headline's decode steps) it is THE limit -- tools/probe_gemv_masked.py, profiles/r06_probe_gemv_masked.jsonl: gate/up 24.9 us with the x loads, 18.0 with them
+// pinned to L1.  A wave of this launch only ever needs ITS K quarter of x (32 rows x K / 4 bf16 <= 32 KB = 128 registers per lane): here it loads that quarter ONCE,
+// keeps it in registers, and walks weight tiles it pulls from a ticket counter (persistent: one block per CU -- ~300 registers per wave --, blocks that find the
+// counter exhausted leave: the launch balances itself on any CU count).  Per tile the arithmetic is k_gemv<SWIGLU, 2, 4, false, 4>'s -- the same 4 waves = 4 K
+// quarters, the same chunk order and MFMA order per wave, the same in-block reduction order, the same epilogue -- so the result is bit-identical
+// (tests/test_gpu_round6.py).  The ring holds a wave's WHOLE K slice (U = PER chunks): a slot is refilled with the NEXT tile's chunk right after it is consumed,
+// so the weight stream never ramps between tiles.  (A first version kept x in LDS, 128 KB per block by LDS-DMA: its up-front copy made the first tile cost twice
+// a tile's bytes per CU -- 7.6 us of prologue -- and lost to the streaming kernel on the whole chip.)
+// Tickets: ONE counter word saturates at ~88 dequeues per microsecond on this chip (MI355X guide, "dequeue") -- 944 tickets would cost the launch 10 us.  The
+// counter is sharded 8 ways: block b draws from shard b % 8 (its XCD under round-robin dispatch; nothing depends on that being true), whose k-th ticket is tile
+// 8 k + shard.  A shard is served by every 8th block, on the whole chip and on a CU-masked stream alike (the first blocks dispatched are 0 .. n - 1), so the
+// shards stay balanced without stealing; a block leaves when its shard is exhausted.
+template <bool F8, int PER>
+__global__ __launch_bounds__(256) void k_gemv_px(GemvArgs p, int ntiles) {
+    constexpr int T = 2, MT = 2, KP = 4, U = PER;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TGV(0);
+    const int tid = threadIdx.x, lane = tid & 63, kp = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nchunks = p.K / 64;                          // = 4 PER (K = 256 PER <= 2048, checked by the launcher): every wave owns PER chunks = its whole ring
+    constexpr int per = PER;
+    const int c0 = kp * per;
+    unsigned* shard = p.px_counter + (blockIdx.x & 7) * 16;                                  // (64 bytes apart)
+    const int sh = blockIdx.x & 7;
+    f32x4* rbuf = reinterpret_cast<f32x4*>(smem);                                            // [2 parities][KP - 1][T * MT][64]
+    int* s_tile = reinterpret_cast<int*>(smem + 2 * (KP - 1) * T * MT * 64 * 16);            // [4]: tile of iteration i at s_tile[i & 3]
+    // this wave's K quarter of x: chunk c0 + u, 16-row group mt, k-step half h -- loaded once, kept for every tile (rows >= M of the second group only feed output
+    // columns that are never stored)
+    u32x4 xr[U][MT][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bf16_t* xt = p.x + ((size_t)(mt * nchunks + c0 + u) * 2) * 512 + lane * 8;
+            xr[u][mt][0] = *reinterpret_cast<const u32x4*>(xt);
+            xr[u][mt][1] = *reinterpret_cast<const u32x4*>(xt + 512);
+        }
+    // tickets of iterations 0 and 1 (wave 0), published through LDS
+    if (tid == 0) {
+        const unsigned k0 = atomicAdd(shard, 2u);
+        s_tile[0] = (int)(k0 * 8u) + sh;
+        s_tile[1] = (int)((k0 + 1u) * 8u) + sh;
+    }
+    __syncthreads();
+    int tile = s_tile[0];
+    u32x4 w[U][T][F8 ? 1 : 2];
+    auto fill_w = [&](int u, int tile, int c) {           // weight chunk c of `tile` into ring slot u (fragment-ordered weights only)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if constexpr (F8) {
+                w[u][t][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.W8 + (size_t)(tile * T + t) * 16 * p.K + lane * 16 + (size_t)c * 1024));
+            } else {
+                const bf16_t* wr = p.W + (size_t)(tile * T + t) * 16 * p.K + lane * 8 + (size_t)c * 1024;
+                w[u][t][0] = ldg_nt(wr);
+                w[u][t][1] = ldg_nt(wr + 512);
+            }
+        }
+    };
+    if (tile < ntiles) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) fill_w(u, tile, c0 + u);
+    }
+    TGV(1);
+    // one tile: consume the ring slot by slot (x from this wave's registers), refilling every slot with the SAME chunk of tile `nxt` when REFILL.  Two straight-line
+    // instantiations (steady state / last tile of the block) instead of a refill behind a condition: hipcc then counts its vmcnt waits (see k_gemv32)
+    auto run_tile = [&](auto refill_, int nxt, f32x4 (&acc)[T][MT]) {
+        constexpr bool REFILL = decltype(refill_)::value;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u < per) {
+                const int c = c0 + u;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    u32x4 w0, w1;
+                    if constexpr (F8) {
+                        const u32x4 q = w[u][t][0];
+                        uint32_t d[8];
+                        f8x4_to_bf16(q[0], d[0], d[1]); f8x4_to_bf16(q[1], d[2], d[3]);
+                        f8x4_to_bf16(q[2], d[4], d[5]); f8x4_to_bf16(q[3], d[6], d[7]);
+                        w0 = u32x4{d[0], d[1], d[2], d[3]};
+                        w1 = u32x4{d[4], d[5], d[6], d[7]};
+                    } else {
+                        w0 = w[u][t][0];
+                        w1 = w[u][t][F8 ? 0 : 1];
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w0), as_frag(xr[u][mt][0]), acc[t][mt], 0, 0, 0);
+                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(w1), as_frag(xr[u][mt][1]), acc[t][mt], 0, 0, 0);
+                    }
+                }
+                if constexpr (REFILL) fill_w(u, nxt, c);
+            }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    for (int it = 0;; ++it) {
+        if (tile >= ntiles) break;                        // (block-uniform: every wave read the same s_tile word)
+        unsigned ticket = 0;
+        if (tid == 0) ticket = atomicAdd(shard, 1u) * 8u + (unsigned)sh;      // the tile of iteration it + 2: requested now, stored behind the k loop, published by the barrier
+        const int next = s_tile[(it + 1) & 3];
+        f32x4 acc[T][MT];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (next < ntiles) run_tile(T_{}, next, acc);
+        else run_tile(F_{}, 0, acc);
+        if (tid == 0) s_tile[(it + 2) & 3] = (int)ticket;
+        // in-block K reduction, fixed order kp = 1, 2, 3 (k_gemv's); the buffer alternates so that a fast wave's partials of the next tile never meet a slow reader
+        f32x4* rb = rbuf + (size_t)(it & 1) * (KP - 1) * T * MT * 64;
+        if (kp > 0) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) rb[((kp - 1) * (T * MT) + t * MT + mt) * 64 + lane] = acc[t][mt];
+        }
+        __syncthreads();
+        if (kp == 0) {
+#pragma unroll
+            for (int k = 1; k < KP; ++k)
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const f32x4 o = rb[((k - 1) * (T * MT) + t * MT + mt) * 64 + lane];
+                        acc[t][mt][0] += o[0]; acc[t][mt][1] += o[1]; acc[t][mt][2] += o[2]; acc[t][mt][3] += o[3];
+                    }
+            if constexpr (F8) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float4 sc = *reinterpret_cast<const float4*>(p.w_scale + (size_t)(tile * T + t) * 16 + fg * 4);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc[t][mt][0] *= sc.x; acc[t][mt][1] *= sc.y; acc[t][mt][2] *= sc.z; acc[t][mt][3] *= sc.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mt * 16 + fr;
+                if (m >= p.M) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float g = rbf(acc[0][mt][r]), u = rbf(acc[1][mt][r]);
+                    o[r] = rbf(silu_f(g)) * u;
+                }
+                bf16_t* ob = reinterpret_cast<bf16_t*>(p.out);
+                *reinterpret_cast<uint2*>(ob + (p.out_tiled ? tiled_offset((size_t)m, (size_t)(tile * 16 + fg * 4), (size_t)(p.N / 2))
+                                                            : (size_t)m * (p.N / 2) + tile * 16 + fg * 4)) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+            }
+        }
+        tile = next;
+    }
+    TGV(2);
+    // the last block out re-arms the counters for the next launch (stream order makes the zeros visible to it)
+    __syncthreads();
+    if (tid == 0) {
+        if (atomicAdd(p.px_counter + 8 * 16, 1u) == gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i <= 8; ++i) p.px_counter[i * 16] = 0u;
+        }
+    }
+    TGV(3);
+}
+
 // ---------------------------------------------------------------------------------------------- batches 17..32
 // 32x32x16 MFMA variant: a wave owns a 32-row weight tile (two 16-row tiles of the fragment-ordered layout) and all
 // 32 batch rows are ONE B operand, so x is read once per 32 weight rows instead of once per 16 (at M = 32 the x
@@ -960,6 +1133,35 @@ int launch_32(hipStream_t s, const GemvArgs& a) {
     return 0;
 }
 
+int g_px_cus = 0;
+// the persistent x-stationary launch (SWIGLU, 17..32 rows, fragment-ordered x and weights, K = 256 / 512 / 1024 / 2048)
+bool px_ok(const GemvArgs& a, int mode) {
+    return a.px_counter && sr_switches().gemv_xlds && mode == GV_SWIGLU && a.M > 16 && a.M <= 32 && a.x_tiled && a.w_tiled && !a.norm_w && (a.K == 256 || a.K == 512 || a.K == 1024 || a.K == 2048)
+           && a.N % 32 == 0 && (!a.W8 || a.w_scale);
+}
+template <bool F8, int PER>
+int launch_px_per(hipStream_t s, const GemvArgs& a, int grid, size_t smem, int ntiles) {
+    hipLaunchKernelGGL((k_gemv_px<F8, PER>), dim3(grid), dim3(256), smem, s, a, ntiles);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+template <bool F8>
+int launch_px(hipStream_t s, const GemvArgs& a) {
+    const int ntiles = a.N / 32;
+    const size_t smem = (size_t)2 * 3 * 4 * 64 * 16 + 64;
+    if (!g_px_cus) { if (int rc = gemv_prepare_px()) return rc; }      // (engines call it at sr_engine_create: a decode step is a stream capture)
+    if (smem > 160 * 1024 - 64) return -12;
+    const int n_cu = g_px_cus;
+    int grid = ntiles < n_cu ? ntiles : n_cu;      // one block per CU (~300 registers per wave); on a CU-masked stream the surplus blocks start late, find no ticket and leave
+    switch (a.K / 256) {
+        case 8: return launch_px_per<F8, 8>(s, a, grid, smem, ntiles);
+        case 4: return launch_px_per<F8, 4>(s, a, grid, smem, ntiles);
+        case 2: return launch_px_per<F8, 2>(s, a, grid, smem, ntiles);
+        case 1: return launch_px_per<F8, 1>(s, a, grid, smem, ntiles);
+    }
+    return -22;
+}
+
 size_t stage_bytes(const GemvArgs& a) { return ((size_t)a.M * (a.K + 8) * 2 + 15) / 16 * 16; }
 
 template <int MODE, int MT, int KP, bool STAGE, int WAVES, bool F8 = false>
@@ -1004,8 +1206,24 @@ int launch_small(hipStream_t s, const GemvArgs& a) {      // 4-wave blocks
 }
 }  // namespace
 
+// attribute + CU count of the persistent x-resident kernel, outside of any stream capture (sr_engine_create; the op-level entry points call it lazily)
+int gemv_prepare_px() {
+    for (const void* f : {reinterpret_cast<const void*>(k_gemv_px<false, 8>), reinterpret_cast<const void*>(k_gemv_px<true, 8>),
+                          reinterpret_cast<const void*>(k_gemv_px<false, 4>), reinterpret_cast<const void*>(k_gemv_px<true, 4>),
+                          reinterpret_cast<const void*>(k_gemv_px<false, 2>), reinterpret_cast<const void*>(k_gemv_px<true, 2>),
+                          reinterpret_cast<const void*>(k_gemv_px<false, 1>), reinterpret_cast<const void*>(k_gemv_px<true, 1>)}) {
+        hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (r != hipSuccess) return (int)r;
+    }
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return -5;
+    g_px_cus = pr.multiProcessorCount;
+    return 0;
+}
+
 #ifdef SR_GEMV_TIMING
-extern "C" int sr_dbg_gemv_times(long long* host_out, int n_blocks) {
+extern "C" __attribute__((visibility("default"))) int sr_dbg_gemv_times(long long* host_out, int n_blocks) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tgv), (size_t)n_blocks * 4 * sizeof(long long), 0, hipMemcpyDeviceToHost);
 }
 #endif
@@ -1074,6 +1292,7 @@ int launch_gemv(hipStream_t s, const GemvArgs& a_, int mode) {
     if (a.out_tiled && (mode != GV_SWIGLU || (a.N / 2) % 64 != 0)) return -22;
     int want = mode == GV_F32 ? 1 : 4;
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
+    if (kp == 4 && px_ok(a, mode)) return a.W8 ? launch_px<true>(s, a) : launch_px<false>(s, a);
     if (a.W8) {          // fp8 weight stream (decode of the quantised LM linears); the in-block K split is always 4 there
         if (!a.w_scale || mode == GV_F32) return -22;
         if (kp != 4) return -22;

@@ -139,3 +139,82 @@ def test_float32_path_meets_1e3_on_logits_against_hf_float32_at_full_depth(golde
     cur[tag] = res
     json.dump(cur, open(path, "w"), indent=1)
     print(tag, res)
+
+
+# ------------------------------------------------------------------------------------------------ gate/up GEMV with x resident in LDS (persistent launch)
+def _tile16x64(t):
+    from tests.util import tile16x64
+    return tile16x64(t)
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 22016, 2048), (17, 22016, 2048), (24, 4096, 1024), (32, 64, 512), (31, 96, 256)])
+def test_x_resident_gate_up_gemv_equals_the_streaming_kernel(monkeypatch, M, N, K):
+    """k_gemv_px (round 6): the 17..32-row gate/up GEMV as a persistent launch that stages the fragment-ordered activations into LDS once and pulls weight tiles
+    from a ticket counter.  Per tile its arithmetic is k_gemv<SWIGLU>'s (same K quarters per wave, chunk order, MFMA order, reduction order, epilogue): the output
+    equals SR_GEMV_XLDS=0 bit for bit -- at the 3B shapes, with fewer tiles than CUs, ragged row counts, fragment-ordered and row-major outputs, launch after
+    launch (the last block re-arms the ticket counter) and on a CU-masked stream (surplus blocks find no ticket)."""
+    import ctypes as C
+    from socioreasoner_amd import lib, streams
+    L = lib.load()
+    P = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    Mp = (M + 15) // 16 * 16
+    x = torch.randn(Mp, K, generator=g).to(torch.bfloat16)
+    x[M:] = 0
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    xt, wt = _tile16x64(x).cuda().contiguous(), _tile16x64(w).cuda().contiguous()
+    outs = {}
+    for flag in ("0", "1"):
+        switch(monkeypatch, "SR_GEMV_XLDS", flag)
+        res = []
+        for out_tiled in (0x1000, 0):
+            if out_tiled and (N // 2) % 64:
+                continue
+            for stream in (torch.cuda.current_stream(), streams.masked_stream("cuda:0", 0, 5)):
+                with torch.cuda.stream(stream):
+                    sp = C.c_void_p(stream.cuda_stream)
+                    for _ in range(3):
+                        o = torch.zeros(Mp, N // 2, dtype=torch.bfloat16, device="cuda")
+                        assert L.sr_op_gemv_fused(P(xt), K, P(wt), M, N, K, P(o), N // 2, 1 | 0x100 | 0x800 | out_tiled, None, None, C.c_float(0), None, 0, None,
+                                                  None, None, sp) == 0
+                        stream.synchronize()
+                        res.append(o.cpu().clone())
+        outs[flag] = res
+    assert len(outs["0"]) == len(outs["1"]) > 0
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+    assert float(outs["1"][0].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("size,fp8", [("tiny", False), ("tiny", True), ("3b", False), ("3b", True)])
+def test_x_resident_gate_up_in_the_decode_step(monkeypatch, size, fp8):
+    """The same switch inside the engine's captured decode step: every logit of every step at 17 / 32 rows equals SR_GEMV_XLDS=0 (bf16 and fp8 weight streams,
+    eager and graph-replayed; 5 / 16 rows keep the streaming kernel either way)."""
+    from socioreasoner_amd.config import geometry_3b, geometry_tiny
+    from socioreasoner_amd.engine import Engine
+    if size == "tiny":
+        geom, vocab = geometry_tiny(), 2000
+    else:
+        geom = geometry_3b()
+        geom = replace(geom, text=replace(geom.text, num_hidden_layers=4), vision=replace(geom.vision, depth=2, fullatt_block_indexes=(1,)))
+        vocab = 150000
+    rng = np.random.default_rng(67)
+    ids, pos = _prompts(rng, 32, vocab=vocab)
+    out = {}
+    for flag in ("0", "1"):
+        switch(monkeypatch, "SR_GEMV_XLDS", flag)
+        e = Engine(geom, max_patches=64, max_prefill_tokens=64 * 32, max_batch=32, max_ctx=128, max_new_tokens=16, lm_fp8=fp8)
+        e.load_synthetic_weights(seed=0)
+        res = []
+        for B in (16, 17, 32):
+            e.prefill(ids[:B], pos[:B])
+            toks, tr = e.decode(10, trace=True, use_graph=False)
+            e.prefill(ids[:B], pos[:B])
+            toks_g, tr_g = e.decode(10, trace=True, use_graph=True)
+            assert torch.equal(toks, toks_g) and torch.equal(tr, tr_g), (flag, B)
+            res.append((toks.clone(), tr.clone()))
+        out[flag] = res
+        e.close()
+    for (t0, r0), (t1, r1) in zip(out["0"], out["1"]):
+        assert torch.equal(t0, t1)
+        assert torch.equal(r0, r1), float((r0 - r1).abs().max())
