@@ -172,6 +172,12 @@ int sr_decode_step(sr_engine* e, const int64_t* dev_last_ids, int B, float* dev_
  *                   nothing more is appended to their KV slot); the next sr_rows_poll reports them finished and the caller may
  *                   re-use row and slot at once -- what vLLM's abort_request does for the reference's ABORT command
  *                   (/root/reference/roll/distributed/strategy/vllm_strategy.py:188-193).
+ *   sr_rows_set_cus : a HINT for the decode steps queued on `stream` after it (sr_rows_step, sr_decode, sr_decode_step): they will run on
+ *                   n_cus compute units -- a CU-masked stream next to an overlapped admission; 0 = the whole chip, the state after
+ *                   sr_engine_create.  With n_cus > 0 the engine replays a second captured form of the step whose gate/up and
+ *                   down-projection GEMVs at 17..32 rows keep their activations in registers and walk the weight tiles (the
+ *                   down-projection deals them to n_cus blocks): 4.6 % more tiles/s on the headline, 1 % slower on the whole chip.
+ *                   Results do not depend on it, bit for bit.
  *   sr_rows_sampling : (optional, after sr_rows_begin) all rows draw their tokens with k_sample (temperature > 0, top_k <= 1024 -- <= 0: no top-k bound --,
  *                   0 < top_p <= 1) instead of the greedy arg-max; temperature 0 switches back. */
 int sr_rows_begin(sr_engine* e, void* stream);
@@ -193,6 +199,7 @@ int sr_rows_step(sr_engine* e, int n_steps, const int32_t* host_eos, int n_eos, 
 int sr_rows_poll(sr_engine* e, int32_t* host_finished, int32_t* host_steps, void* stream);
 int sr_rows_read(sr_engine* e, int row, int32_t* dev_tokens_out, int n, void* stream);
 int sr_rows_abort(sr_engine* e, const int32_t* host_rows, int n, void* stream);
+int sr_rows_set_cus(sr_engine* e, int n_cus, void* stream);
 
 /* K19-K22 raster tail -- replaces seg_strategy.py:58-65 (union, cv2.INTER_NEAREST resize),
  * rlvr_socioseg_vlm_pipeline_infer.py:45-58 (IoU counts) and :383-452 (render).  No engine needed. */
@@ -289,6 +296,9 @@ int sr_op_gemv(const void* x, int ldx, const void* W, int M, int N, int K, void*
 int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ldo, int mode, const void* bias,
                      const void* norm_w, float eps, const float* slabs, int n_slabs, void* x_out, float* amax_val,
                      int32_t* amax_idx, void* stream);
+/* the CU-count hint of sr_rows_set_cus for the op-level GEMVs (sr_op_gemv / sr_op_gemv_fused at 17..32 rows; process-wide, one stream at a time): 0 = the whole
+ * chip = the streaming kernels, n > 0 = the x-stationary forms dealt to n blocks (n >= the device's CU count: one block per CU) */
+int sr_op_gemv_set_cus(int n_cus, void* stream);
 int sr_op_gemv_f32_blocks(int N, int M, int K, int has_norm);
 /* fused decode attention: qkv rows (bias applied, pre-rope) -> mRoPE -> KV-cache append -> attention; slots = identity.
  * kcache [B][kvh][ctx_max][128], vtcache [B][kvh][128][ctx_max]; ctx_len counts the new token; rope_cos/sin: bf16 [max_pos+1][64] tables; scores_scratch: bf16 [B][heads][ctx_max] */

@@ -89,7 +89,7 @@ static void load_switches() {
     g_sw.attn_vasm = env_int("SR_ATTN_VASM", 1);
     g_sw.sam_f32_split = env_int("SR_SAM_F32_SPLIT", 1);
     g_sw.gemv_counted = env_int("SR_GEMV_COUNTED", 1);
-    g_sw.gemv_xlds = env_int("SR_GEMV_XLDS", 1);
+    g_sw.gemv_xlds = env_int("SR_GEMV_XLDS", 3);
     g_sw_loaded = true;
 }
 const SrSwitches& sr_switches() {
@@ -137,7 +137,7 @@ struct sr_engine {
     bf16_t *d_xa, *d_xb, *d_xn, *d_qkv, *d_attn, *d_act, *d_scores;    // d_xa / d_xb: residual stream ping-pong
     float *d_logits, *d_slabs, *d_amax_val;
     float* d_row_cs = nullptr;               // [MAXB][128] rotary cos | sin of every row's current position (k_step -> decode attention)
-    unsigned* d_px = nullptr;                // [256] 8 ticket shards + done count of the persistent x-resident GEMV (k_gemv_px): zero between launches
+    unsigned* d_px = nullptr;                // [256] x-stationary GEMVs: 8 ticket shards + done count (k_gemv_px; zero between launches), word 160 = CU limit (sr_rows_set_cus)
     int *d_amax_idx, *d_cur_tok, *d_ctx_len, *d_pos, *d_finished, *d_step, *d_slots, *d_eos, *d_tokens;
     int n_part = 0;      // LM-head blocks = partial argmax entries per row
     // continuous batching (sr_rows_*): admission scratch so that a prefill never touches the pending tokens of running rows
@@ -154,21 +154,22 @@ struct sr_engine {
     hipEvent_t ev_copy = nullptr;
     bool copy_pending = false;
     // ---- decode graph cache
-    hipGraphExec_t graph = nullptr;
+    hipGraphExec_t graph[2] = {nullptr, nullptr};     // [px_mode]: the decode step on the whole chip / on a CU-limited stream (x-stationary GEMVs, sr_rows_set_cus)
+    int px_mode = 0;
     int device = 0;                     // the GPU the workspace lives on: every C-ABI entry makes it current (per-thread HIP state)
     hipStream_t cap_stream = nullptr;   // used only to CAPTURE the decode step (the caller's stream may be the null stream)
-    int graph_B = -1, graph_neos = -1, graph_pad = 0;
+    int graph_B[2] = {-1, -1}, graph_neos[2] = {-1, -1}, graph_pad[2] = {0, 0};
     hipGraphExec_t step_graph[2] = {nullptr, nullptr};   // sr_decode_step: [0] engine-greedy token, [1] caller-chosen token
-    int step_graph_B[2] = {-1, -1};
+    int step_graph_B[2] = {-1, -1}, step_graph_px[2] = {0, 0};
     long long *d_chosen = nullptr, *d_next = nullptr, *d_sampled = nullptr;
     unsigned* d_seen = nullptr;    // [MAXB][seen_words] token bitmask for the repetition penalty
     int seen_words = 0;
     // continuous batching with sampling (sr_rows_sampling): parameters shared by all rows; 0 temperature = greedy
     float rows_temp = 0.f, rows_topp = 1.f; int rows_topk = 0; unsigned rows_seed = 0, adm_count = 0;
     long long* d_adm_pick = nullptr;
-    hipGraphExec_t rgraph = nullptr; int rg_neos = -1, rg_pad = 0, rg_topk = 0; float rg_it = 0.f, rg_topp = 0.f; unsigned rg_seed = 0;
+    struct RowsGraph { hipGraphExec_t g = nullptr; int neos = -1, pad = 0, topk = 0; float it = 0.f, topp = 0.f; unsigned seed = 0; } rgraph[2];      // [px_mode]
     hipGraphExec_t sgraph = nullptr;      // sampled decode step: bookkeeping + forward + k_sample
-    int sg_B = -1, sg_neos = -1, sg_pad = 0, sg_topk = 0; float sg_it = 0.f, sg_topp = 0.f, sg_rp = 0.f; unsigned sg_seed = 0;
+    int sg_B = -1, sg_neos = -1, sg_pad = 0, sg_topk = 0, sg_px = 0; float sg_it = 0.f, sg_topp = 0.f, sg_rp = 0.f; unsigned sg_seed = 0;
     int prefilled_B = 0;
     int h_ctx_hi = 0;              // longest context any slot can have reached (prefill length + decode steps issued)
     // ---- bookkeeping
@@ -623,6 +624,9 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
     const int H = c.t_hidden, QD = c.t_heads * 128;
     const bool fused = fused_norms(e, B);
     const int xt = (!fused && x_tiled_ok(e)) ? 1 : 0;      // activations handed from launch to launch in fragment order
+    // the x-stationary gate/up and down GEMVs (17..32 rows): on a CU-limited stream (sr_rows_set_cus) -- on the whole chip the streaming kernels are 1 % faster per step;
+    // bit 2 of SR_GEMV_XLDS: everywhere (A/B and test hook)
+    const bool px = e->px_mode || (sr_switches().gemv_xlds & 4);
     bf16_t *x = e->d_xa, *x_alt = e->d_xb;      // k_step gathered the input embedding into d_xa
     bool pending = false;                       // down-projection slabs not yet added to the residual stream
     const float scale = (float)(1.0 / sqrt(128.0));
@@ -666,12 +670,13 @@ int enqueue_decode_forward(sr_engine* e, int B, hipStream_t s) {
         else {
             SR_TRY(launch_rmsnorm(s, x, w.ln2, e->d_xn, B, H, c.t_rms_eps, xt));
             gg.x = e->d_xn; gg.x_tiled = xt; gg.out_tiled = xt;
-            gg.px_counter = e->d_px;        // 17..32 rows: launch_gemv may take the persistent x-resident kernel (same bits)
+            gg.px_counter = px ? e->d_px : nullptr;        // 17..32 rows: launch_gemv may take the persistent x-resident kernel (same bits)
         }
         if (gg.M > 0) SR_TRY(launch_gemv(s, gg, GV_SWIGLU));
         GemvArgs gd = gv(e->d_act, e->t_inter_pad, w.down_w, B, H, e->t_inter_pad, e->d_slabs, H);
         gd.ksplit = ks_down(e, B);
         gd.W8 = w.down_w8; gd.w_scale = w.down_s; gd.x_tiled = xt;
+        gd.px_counter = px ? e->d_px : nullptr;            // 17..32 rows, bf16: the x-stationary split-K kernel (same bits)
         SR_TRY(launch_gemv(s, gd, GV_PARTIAL));
         pending = true;
     }
@@ -687,6 +692,15 @@ int enqueue_step(sr_engine* e, int B, int n_eos, int pad_id, const int* forced, 
 }
 
 }  // namespace
+
+// counter block of the x-stationary GEMVs for the op-level entry points (engines own theirs): 8 ticket shards + done count + the CU limit, 64 B apart
+static unsigned* g_op_px = nullptr;
+static int g_op_px_mode = 0;         // as sr_engine::px_mode: the x-stationary forms after sr_op_gemv_set_cus(n > 0) (or bit 2 of SR_GEMV_XLDS)
+static int op_px() {
+    if (g_op_px) return 0;
+    if (hipMalloc(&g_op_px, 256 * sizeof(unsigned)) != hipSuccess || hipMemset(g_op_px, 0, 256 * sizeof(unsigned)) != hipSuccess) return -12;
+    return 0;
+}
 
 // =================================================================================================== C ABI
 extern "C" {
@@ -772,10 +786,10 @@ int sr_engine_create(const sr_config* cfg, void* workspace, size_t workspace_byt
 int sr_engine_destroy(sr_engine* e) {
     enter(e);
     if (!e) return 0;
-    if (e->graph) (void)hipGraphExecDestroy(e->graph);
+    for (auto g : e->graph) if (g) (void)hipGraphExecDestroy(g);
     for (auto g : e->step_graph) if (g) (void)hipGraphExecDestroy(g);
     if (e->sgraph) (void)hipGraphExecDestroy(e->sgraph);
-    if (e->rgraph) (void)hipGraphExecDestroy(e->rgraph);
+    for (auto& r : e->rgraph) if (r.g) (void)hipGraphExecDestroy(r.g);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     if (e->ev_copy) (void)hipEventDestroy(e->ev_copy);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -1258,8 +1272,9 @@ int sr_admit_commit(sr_engine* e, const int32_t* rows, int n, void* stream) {
 
 // one decode step (bookkeeping kernel + forward) captured once per (B, eos count, pad) and replayed
 static int ensure_decode_graph(sr_engine* e, int B, int n_eos, int pad_id) {
-    if (e->graph != nullptr && e->graph_B == B && e->graph_neos == n_eos && e->graph_pad == pad_id) return 0;
-    if (e->graph) { (void)hipGraphExecDestroy(e->graph); e->graph = nullptr; }
+    const int m = e->px_mode;
+    if (e->graph[m] != nullptr && e->graph_B[m] == B && e->graph_neos[m] == n_eos && e->graph_pad[m] == pad_id) return 0;
+    if (e->graph[m]) { (void)hipGraphExecDestroy(e->graph[m]); e->graph[m] = nullptr; }
     hipGraph_t g = nullptr;
     SR_TRY((int)hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
     int rc = enqueue_step(e, B, n_eos, pad_id, nullptr, e->cap_stream);
@@ -1267,10 +1282,10 @@ static int ensure_decode_graph(sr_engine* e, int B, int n_eos, int pad_id) {
     hipError_t er = hipStreamEndCapture(e->cap_stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     SR_TRY((int)er);
-    er = hipGraphInstantiate(&e->graph, g, nullptr, nullptr, 0);
+    er = hipGraphInstantiate(&e->graph[m], g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     SR_TRY((int)er);
-    e->graph_B = B; e->graph_neos = n_eos; e->graph_pad = pad_id;
+    e->graph_B[m] = B; e->graph_neos[m] = n_eos; e->graph_pad[m] = pad_id;
     return 0;
 }
 
@@ -1307,7 +1322,7 @@ int sr_decode(sr_engine* e, const int32_t* host_slots, int B, int max_new, const
             done = max_new;
             break;
         }
-        if (graph_ok) SR_TRY((int)hipGraphLaunch(e->graph, s));
+        if (graph_ok) SR_TRY((int)hipGraphLaunch(e->graph[e->px_mode], s));
         else {
             if (int rc = enqueue_step(e, B, n_eos, pad_id, forced_dev, s)) return rc;
             if (int rc = enqueue_decode_forward(e, B, s)) return rc;
@@ -1369,7 +1384,7 @@ int sr_decode_sample(sr_engine* e, int B, int max_new, const int32_t* host_eos, 
         return launch_sample(q, sa);
     };
     if (use_graph && (e->sgraph == nullptr || e->sg_B != B || e->sg_neos != n_eos || e->sg_pad != pad_id || e->sg_topk != top_k ||
-                      e->sg_it != it || e->sg_topp != top_p || e->sg_rp != rep_penalty || e->sg_seed != seed)) {
+                      e->sg_it != it || e->sg_topp != top_p || e->sg_rp != rep_penalty || e->sg_seed != seed || e->sg_px != e->px_mode)) {
         if (e->sgraph) { (void)hipGraphExecDestroy(e->sgraph); e->sgraph = nullptr; }
         hipGraph_t g = nullptr;
         SR_TRY((int)hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
@@ -1380,7 +1395,7 @@ int sr_decode_sample(sr_engine* e, int B, int max_new, const int32_t* host_eos, 
         er = hipGraphInstantiate(&e->sgraph, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         SR_TRY((int)er);
-        e->sg_B = B; e->sg_neos = n_eos; e->sg_pad = pad_id; e->sg_topk = top_k; e->sg_it = it; e->sg_topp = top_p; e->sg_rp = rep_penalty; e->sg_seed = seed;
+        e->sg_B = B; e->sg_neos = n_eos; e->sg_pad = pad_id; e->sg_topk = top_k; e->sg_it = it; e->sg_topp = top_p; e->sg_rp = rep_penalty; e->sg_seed = seed; e->sg_px = e->px_mode;
     }
     int done = 0;
     std::vector<int> fin(B);
@@ -1424,9 +1439,9 @@ int sr_rows_step(sr_engine* e, int n_steps, const int32_t* host_eos, int n_eos, 
     if (e->rows_temp > 0.f) {      // sampled step: consume the drawn tokens, forward, draw the next ones for every row
         const sr_config& c = e->c;
         const float it = 1.0f / e->rows_temp;
-        if (e->rgraph == nullptr || e->rg_neos != n_eos || e->rg_pad != pad_id || e->rg_topk != e->rows_topk || e->rg_it != it ||
-            e->rg_topp != e->rows_topp || e->rg_seed != e->rows_seed) {
-            if (e->rgraph) { (void)hipGraphExecDestroy(e->rgraph); e->rgraph = nullptr; }
+        auto& rg = e->rgraph[e->px_mode];
+        if (rg.g == nullptr || rg.neos != n_eos || rg.pad != pad_id || rg.topk != e->rows_topk || rg.it != it || rg.topp != e->rows_topp || rg.seed != e->rows_seed) {
+            if (rg.g) { (void)hipGraphExecDestroy(rg.g); rg.g = nullptr; }
             const int hn = fused_norms(e, B) ? 1 : 0;
             SampleArgs sa{e->d_logits, c.t_vocab, B, it, e->rows_topk, e->rows_topp, 1.0f, nullptr, e->seen_words, e->rows_seed, e->d_step, e->d_sampled,
                           e->d_amax_val, gemv_f32_blocks(c.t_vocab, B, c.t_hidden, hn), gemv_f32_block_rows(c.t_vocab, B, c.t_hidden, hn)};
@@ -1438,16 +1453,16 @@ int sr_rows_step(sr_engine* e, int n_steps, const int32_t* host_eos, int n_eos, 
             hipError_t er = hipStreamEndCapture(e->cap_stream, &g);
             if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
             SR_TRY((int)er);
-            er = hipGraphInstantiate(&e->rgraph, g, nullptr, nullptr, 0);
+            er = hipGraphInstantiate(&rg.g, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
             SR_TRY((int)er);
-            e->rg_neos = n_eos; e->rg_pad = pad_id; e->rg_topk = e->rows_topk; e->rg_it = it; e->rg_topp = e->rows_topp; e->rg_seed = e->rows_seed;
+            rg.neos = n_eos; rg.pad = pad_id; rg.topk = e->rows_topk; rg.it = it; rg.topp = e->rows_topp; rg.seed = e->rows_seed;
         }
-        for (int i = 0; i < n_steps; ++i) SR_TRY((int)hipGraphLaunch(e->rgraph, s));
+        for (int i = 0; i < n_steps; ++i) SR_TRY((int)hipGraphLaunch(rg.g, s));
         return 0;
     }
     if (int rc = ensure_decode_graph(e, B, n_eos, pad_id)) return rc;
-    for (int i = 0; i < n_steps; ++i) SR_TRY((int)hipGraphLaunch(e->graph, s));
+    for (int i = 0; i < n_steps; ++i) SR_TRY((int)hipGraphLaunch(e->graph[e->px_mode], s));
     return 0;
 }
 
@@ -1466,6 +1481,15 @@ int sr_rows_read(sr_engine* e, int row, int32_t* dev_tokens_out, int n, void* st
     if (!e || !e->rows_mode || row < 0 || row >= e->c.max_batch || n < 0 || n > e->c.max_new_tokens)
         return fail(e, -22, "sr_rows_read: bad argument / not in rows mode");
     SR_TRY((int)hipMemcpyAsync(dev_tokens_out, e->d_tokens + (size_t)row * e->c.max_new_tokens, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int sr_rows_set_cus(sr_engine* e, int n_cus, void* stream) {
+    enter(e);
+    if (!e || n_cus < 0) return fail(e, -22, "sr_rows_set_cus: bad argument");
+    hipError_t r = hipMemsetD32Async((hipDeviceptr_t)(e->d_px + 10 * 16), n_cus, 1, (hipStream_t)stream);
+    if (r != hipSuccess) return fail(e, (int)r, "sr_rows_set_cus: %s", hipGetErrorString(r));
+    e->px_mode = n_cus > 0 ? 1 : 0;         // the decode step has two captured forms: the next steps replay the one for this stream
     return 0;
 }
 
@@ -1494,7 +1518,7 @@ int sr_decode_step(sr_engine* e, const int64_t* dev_last_ids, int B, float* dev_
     // One captured graph per (token source, B): step bookkeeping + forward + greedy ids, replayed from engine-owned buffers.
     const int kind = dev_last_ids ? 1 : 0;
     const int n_part = gemv_f32_blocks(c.t_vocab, B, c.t_hidden, fused_norms(e, B) ? 1 : 0);
-    if (e->step_graph[kind] == nullptr || e->step_graph_B[kind] != B) {
+    if (e->step_graph[kind] == nullptr || e->step_graph_B[kind] != B || e->step_graph_px[kind] != e->px_mode) {
         if (e->step_graph[kind]) { (void)hipGraphExecDestroy(e->step_graph[kind]); e->step_graph[kind] = nullptr; }
         hipGraph_t g = nullptr;
         SR_TRY((int)hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
@@ -1507,7 +1531,7 @@ int sr_decode_step(sr_engine* e, const int64_t* dev_last_ids, int B, float* dev_
         er = hipGraphInstantiate(&e->step_graph[kind], g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         SR_TRY((int)er);
-        e->step_graph_B[kind] = B;
+        e->step_graph_B[kind] = B; e->step_graph_px[kind] = e->px_mode;
     }
     if (kind) SR_TRY((int)hipMemcpyAsync(e->d_chosen, dev_last_ids, (size_t)B * 8, hipMemcpyDeviceToDevice, s));
     SR_TRY((int)hipGraphLaunch(e->step_graph[kind], s));
@@ -1641,6 +1665,8 @@ int sr_op_gemv(const void* x, int ldx, const void* W, int M, int N, int K, void*
     a.ksplit = ksplit;
     a.w_tiled = (mode & 0x100) ? 1 : 0;          // bit 8 of `mode`: W is fragment-ordered (tiled16x64)
     a.x_tiled = (mode & 0x800) ? 1 : 0;          // bit 11: x is fragment-ordered (tiled16x64 of [ceil16(M), K])
+    if (M > 16) { if (int rc = op_px()) return rc; }
+    a.px_counter = (g_op_px_mode || (sr_switches().gemv_xlds & 4)) ? g_op_px : nullptr;
     SR_WRAP(launch_gemv((hipStream_t)stream, a, mode & 0xff));
 }
 int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K, void* out, int ldo, int mode, const void* bias,
@@ -1652,13 +1678,16 @@ int sr_op_gemv_fused(const void* x, int ldx, const void* W, int M, int N, int K,
     a.w_tiled = (mode & 0x100) ? 1 : 0;
     a.x_tiled = (mode & 0x800) ? 1 : 0;          // bit 11: x fragment-ordered; bit 12: SWIGLU output fragment-ordered
     a.out_tiled = (mode & 0x1000) ? 1 : 0;
-    // the op-level callers (tests, probes; one stream at a time) share one process-wide ticket pair for the persistent x-resident kernel
-    static unsigned* g_px = nullptr;
-    if (!g_px && (mode & 0xff) == GV_SWIGLU && M > 16) {
-        if (hipMalloc(&g_px, 256 * sizeof(unsigned)) != hipSuccess || hipMemset(g_px, 0, 256 * sizeof(unsigned)) != hipSuccess) return -12;
-    }
-    a.px_counter = g_px;
+    // the op-level callers (tests, probes; one stream at a time) share one process-wide counter block for the x-stationary kernels
+    if (M > 16) { if (int rc = op_px()) return rc; }
+    a.px_counter = (g_op_px_mode || (sr_switches().gemv_xlds & 4)) ? g_op_px : nullptr;
     SR_WRAP(launch_gemv((hipStream_t)stream, a, mode & 0xff));
+}
+int sr_op_gemv_set_cus(int n_cus, void* stream) {
+    if (n_cus < 0) return fail(nullptr, -22, "sr_op_gemv_set_cus: negative CU count");
+    if (int rc = op_px()) return rc;
+    g_op_px_mode = n_cus > 0 ? 1 : 0;
+    SR_WRAP((int)hipMemsetD32Async((hipDeviceptr_t)(g_op_px + 10 * 16), n_cus, 1, (hipStream_t)stream));
 }
 int sr_op_gemv_f32_blocks(int N, int M, int K, int has_norm) { return gemv_f32_blocks(N, M, K, has_norm); }
 int sr_op_attn_decode(const void* qkv, int qkv_stride, const int32_t* pos, const int32_t* ctx_len, const void* rope_cos,

@@ -882,6 +882,90 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
     TGV(3);
 }
 
+// ---------------------------------------------------------------------------------------------- 17..32 rows, split-K down-projection with x STATIONARY (round 6)
+// The same idea for the 32-row-tile split-K launch (k_gemv32<GV_PARTIAL, 4>: grid = 64 tiles x 4 K slabs, every wave reads 44 KB of weights and 44 KB of x): a
+// block is pinned to ONE K slab, its 4 waves keep their K sixteenth of x (<= PER chunks x 4 k-steps = 176 registers per lane at K = 11008) for every tile they
+// walk, and the ring holds a wave's whole slice of a tile (PER slots), refilled with the next tile's chunks as they are consumed.  With one tile per block (the
+// whole chip: 256 blocks, 64 tiles x 4 slabs) this is the streaming kernel with a deeper ring; with fewer CUs than units -- the scheduler's CU-masked decode
+// stream, 160 CUs -- a block's second tile costs only its weights.  The tiles are dealt STATICALLY: blocks 0 .. L - 1 take part (L = the CU count the host wrote
+// to px_counter[160] -- sr_rows_set_cus --, 0 = the grid), block b owns slab b % ksplit and tiles b / ksplit, + L / ksplit, ...; the other blocks leave at once.
+// (Tickets, as in k_gemv_px, cannot serve a launch with about one unit per block: a block has to hold the NEXT tile while it works, and the early blocks would
+// take every tile.)  Any L gives the same bits: per tile the chunk order, the MFMA order, the in-block reduction order and the slab stores are k_gemv32's.
+template <int PER>
+__global__ __launch_bounds__(256) void k_gemv32_px(GemvArgs p, int ntiles32) {
+    constexpr int KP = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TGV(0);
+    const int tid = threadIdx.x, lane = tid & 63, kp = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, half = (lane >> 4) & 1, kg = lane >> 5, m = lane & 31;
+    const int nchunks = p.K / 64, ks = p.ksplit;
+    const int per = (nchunks + ks * KP - 1) / (ks * KP);                 // <= PER, and every wave owns >= 1 chunk (launcher)
+    const unsigned lim = p.px_counter[10 * 16];
+    const int nb = (lim != 0u && lim < gridDim.x) ? max((int)lim, ks) : (int)gridDim.x;        // (the grid is a multiple of ksplit, >= ksplit)
+    const int per_slab = nb / ks;
+    const int slab = blockIdx.x % ks;
+    int tile = blockIdx.x / ks;
+    if ((int)blockIdx.x >= per_slab * ks || tile >= ntiles32) return;
+    const int c0 = (slab * KP + kp) * per, cend = min(c0 + per, nchunks), n = cend - c0;
+    // this wave's K sixteenth of x, fragment order (see k_gemv32): loaded once.  Slots u >= n hold a copy of the last chunk and are never multiplied
+    const bf16_t* xbase = p.x + ((size_t)(m >> 4) * nchunks * 2 + kg) * 512 + (m & 15) * 8;
+    u32x4 xr[PER][4], w[PER][4];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int c = min(c0 + u, cend - 1);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) xr[u][st] = *reinterpret_cast<const u32x4*>(xbase + (size_t)c * 1024 + st * 128);
+    }
+    auto fill_w = [&](int u, int tile, int c) {            // no load behind a condition: the chunk index is clamped instead (counted vmcnt waits, see k_gemv32)
+        c = min(c, cend - 1);
+        const bf16_t* wb = p.W + ((size_t)(tile * 2 + half) * nchunks + c) * 1024 + kg * 512 + fr * 8;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) w[u][st] = ldg_nt(wb + st * 128);
+    };
+#pragma unroll
+    for (int u = 0; u < PER; ++u) fill_w(u, tile, c0 + u);
+    TGV(1);
+    auto run_tile = [&](auto refill_, int nxt, f32x16& acc) {
+        constexpr bool REFILL = decltype(refill_)::value;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (u < n) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(w[u][st]), as_frag(xr[u][st]), acc, 0, 0, 0);
+            }
+            if constexpr (REFILL) fill_w(u, nxt, c0 + u);
+        }
+    };
+    const bool xok = m < p.M;
+    for (int it = 0;; ++it) {
+        const int next = tile + per_slab;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        if (next < ntiles32) run_tile(std::true_type{}, next, acc);
+        else run_tile(std::false_type{}, 0, acc);
+        // in-block K reduction, fixed order kp = 1, 2, 3; the buffer alternates (a fast wave's partials of the next tile never meet a slow reader)
+        unsigned char* rb = smem + (size_t)(it & 1) * (KP - 1) * 64 * sizeof(f32x16);
+        if (kp > 0) rb_store(rb, kp - 1, lane, acc);
+        __syncthreads();
+        if (kp == 0) {
+#pragma unroll
+            for (int k = 1; k < KP; ++k) rb_add(rb, k - 1, lane, acc);
+            if (xok) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const size_t oi = ((size_t)slab * p.M + m) * p.N + tile * 32 + 8 * g4 + 4 * kg;
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + oi) = float4{acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
+                }
+            }
+        }
+        if (next >= ntiles32) break;
+        tile = next;
+    }
+    TGV(3);
+}
+
 // ---------------------------------------------------------------------------------------------- batches 33..128
 // The same 32-row-tile kernel for G groups of 32 batch rows (round 4: the reference's request-level mode keeps up to 128 requests in flight
 // per worker, /root/reference/roll/distributed/scheduler/generate_scheduler.py:57): a wave streams its weight tile ONCE and multiplies it with
@@ -1136,7 +1220,7 @@ int launch_32(hipStream_t s, const GemvArgs& a) {
 int g_px_cus = 0;
 // the persistent x-stationary launch (SWIGLU, 17..32 rows, fragment-ordered x and weights, K = 256 / 512 / 1024 / 2048)
 bool px_ok(const GemvArgs& a, int mode) {
-    return a.px_counter && sr_switches().gemv_xlds && mode == GV_SWIGLU && a.M > 16 && a.M <= 32 && a.x_tiled && a.w_tiled && !a.norm_w && (a.K == 256 || a.K == 512 || a.K == 1024 || a.K == 2048)
+    return a.px_counter && (sr_switches().gemv_xlds & 1) && mode == GV_SWIGLU && a.M > 16 && a.M <= 32 && a.x_tiled && a.w_tiled && !a.norm_w && (a.K == 256 || a.K == 512 || a.K == 1024 || a.K == 2048)
            && a.N % 32 == 0 && (!a.W8 || a.w_scale);
 }
 template <bool F8, int PER>
@@ -1145,21 +1229,41 @@ int launch_px_per(hipStream_t s, const GemvArgs& a, int grid, size_t smem, int n
     SR_CHECK_LAUNCH();
     return 0;
 }
+constexpr size_t kPxSmem = (size_t)2 * 3 * 4 * 64 * 16 + 64;     // reduction buffers (2 parities) + tile slots
 template <bool F8>
 int launch_px(hipStream_t s, const GemvArgs& a) {
     const int ntiles = a.N / 32;
-    const size_t smem = (size_t)2 * 3 * 4 * 64 * 16 + 64;
     if (!g_px_cus) { if (int rc = gemv_prepare_px()) return rc; }      // (engines call it at sr_engine_create: a decode step is a stream capture)
-    if (smem > 160 * 1024 - 64) return -12;
     const int n_cu = g_px_cus;
     int grid = ntiles < n_cu ? ntiles : n_cu;      // one block per CU (~300 registers per wave); on a CU-masked stream the surplus blocks start late, find no ticket and leave
     switch (a.K / 256) {
-        case 8: return launch_px_per<F8, 8>(s, a, grid, smem, ntiles);
-        case 4: return launch_px_per<F8, 4>(s, a, grid, smem, ntiles);
-        case 2: return launch_px_per<F8, 2>(s, a, grid, smem, ntiles);
-        case 1: return launch_px_per<F8, 1>(s, a, grid, smem, ntiles);
+        case 8: return launch_px_per<F8, 8>(s, a, grid, kPxSmem, ntiles);
+        case 4: return launch_px_per<F8, 4>(s, a, grid, kPxSmem, ntiles);
+        case 2: return launch_px_per<F8, 2>(s, a, grid, kPxSmem, ntiles);
+        case 1: return launch_px_per<F8, 1>(s, a, grid, kPxSmem, ntiles);
     }
     return -22;
+}
+
+// the x-stationary split-K launch (PARTIAL, 17..32 rows, bf16 fragment-ordered x and weights, 4 waves = 4 in-block K parts, <= 11 chunks per wave)
+bool px32_ok(const GemvArgs& a, int mode) {
+    if (!(a.px_counter && (sr_switches().gemv_xlds & 2) && mode == GV_PARTIAL && a.M > 16 && a.M <= 32 && a.x_tiled && a.w_tiled && !a.norm_w && !a.W8
+          && a.N % 32 == 0 && a.ksplit >= 4 && a.ksplit <= 8)) return false;          // (ksplit >= 4: where the streaming path runs the 32-row-tile kernel, use_32)
+    const int nch = a.K / 64, per = (nch + a.ksplit * 4 - 1) / (a.ksplit * 4);
+    return per >= 3 && per <= 11 && (a.ksplit * 4 - 1) * per < nch;
+}
+int launch_px32(hipStream_t s, const GemvArgs& a) {
+    const int ntiles = a.N / 32;
+    const size_t smem = (size_t)2 * 3 * 64 * sizeof(f32x16);
+    if (!g_px_cus) { if (int rc = gemv_prepare_px()) return rc; }
+    int grid = g_px_cus / a.ksplit * a.ksplit;           // one block per CU (~400 registers per wave)
+    if (grid > ntiles * a.ksplit) grid = ntiles * a.ksplit;
+    const int nch = a.K / 64, per = (nch + a.ksplit * 4 - 1) / (a.ksplit * 4);
+    if (per <= 4) hipLaunchKernelGGL((k_gemv32_px<4>), dim3(grid), dim3(256), smem, s, a, ntiles);
+    else if (per <= 8) hipLaunchKernelGGL((k_gemv32_px<8>), dim3(grid), dim3(256), smem, s, a, ntiles);
+    else hipLaunchKernelGGL((k_gemv32_px<11>), dim3(grid), dim3(256), smem, s, a, ntiles);
+    SR_CHECK_LAUNCH();
+    return 0;
 }
 
 size_t stage_bytes(const GemvArgs& a) { return ((size_t)a.M * (a.K + 8) * 2 + 15) / 16 * 16; }
@@ -1293,6 +1397,7 @@ int launch_gemv(hipStream_t s, const GemvArgs& a_, int mode) {
     int want = mode == GV_F32 ? 1 : 4;
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
     if (kp == 4 && px_ok(a, mode)) return a.W8 ? launch_px<true>(s, a) : launch_px<false>(s, a);
+    if (kp == 4 && px32_ok(a, mode)) return launch_px32(s, a);
     if (a.W8) {          // fp8 weight stream (decode of the quantised LM linears); the in-block K split is always 4 there
         if (!a.w_scale || mode == GV_F32) return -22;
         if (kp != 4) return -22;

@@ -17,8 +17,9 @@ struct SrSwitches {
     int attn_win64;     // SR_ATTN_WIN64  0: no 64-token window kernel (default 1)
     int attn_vasm;      // SR_ATTN_VASM   0: V^T fragment reads of k_attn_prefill2 left to the compiler (ds_read2st64_b64, 2-way bank conflicts; default 1: hand-issued ds_read_b64)
     int sam_f32_split;  // SR_SAM_F32_SPLIT 0: SAM2's float32 GEMM on the f32-input MFMA (round 4) instead of the three-term bf16 split on the bf16 pipe (default 1)
-    int gemv_xlds;      // SR_GEMV_XLDS   0: the 17..32-row gate/up GEMV re-reads its activations from L2 in every wave (rounds 2-5) instead of keeping them resident in LDS in a
-                        //                 persistent launch (round 6, default 1; bit-identical: A/B + test hook)
+    int gemv_xlds;      // SR_GEMV_XLDS   bit 0: the 17..32-row gate/up GEMV keeps its activations in registers in a persistent launch (k_gemv_px), bit 1: so does the split-K
+                        //                 down-projection (k_gemv32_px) -- in the engine's decode step on a CU-limited stream only (sr_rows_set_cus), bit 2: on the whole chip too;
+                        //                 0: both re-read x from L2 in every wave (rounds 2-5).  Round 6, default 3; bit-identical: A/B + test hook
     int gemv_counted;   // SR_GEMV_COUNTED 0: the <= 32-row decode GEMVs use the conditional-refill ring loops of rounds 1-4 (vmcnt(0) every round) instead of the
                         //                 unconditional refills with counted vmcnt waits (default 1; bit-identical: A/B + test hook)
 };
@@ -107,8 +108,9 @@ struct GemvArgs {
     int out_tiled;                          // SWIGLU: write the activation fragment-ordered (it is the next GEMV's x)
     int force32;                            // always the 32-row MFMA variant (whatever M): a row's result then does not depend on how many rows share the launch
     int counted;                            // set by launch_gemv from SR_GEMV_COUNTED: un-staged launches with fragment-ordered x use the loop whose refills are all unconditional (counted vmcnt waits)
-    unsigned* px_counter;                   // round 6, non-null: 9 words 64 bytes apart (8 ticket shards + blocks done; zero between launches; 576 bytes) -- SWIGLU / PARTIAL at 17..32 rows with fragment-ordered x may
-                                            // run as the PERSISTENT kernel that keeps x resident in LDS (k_gemv_px: same per-tile arithmetic, same bits)
+    unsigned* px_counter;                   // round 6, non-null: 11 words 64 bytes apart (8 ticket shards + blocks done: zero between launches; word 160 = CU limit of the static
+                                            // deal, 0 = the grid) -- SWIGLU / PARTIAL at 17..32 rows with fragment-ordered x and weights may run as the PERSISTENT kernels that
+                                            // keep x in registers (k_gemv_px / k_gemv32_px: same per-tile arithmetic, same bits)
 };
 int launch_gemv(hipStream_t s, const GemvArgs& a, int mode);
 int gemv_prepare_px();     // attribute call of the persistent x-resident kernel (outside stream capture: sr_engine_create)

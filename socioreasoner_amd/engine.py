@@ -298,6 +298,10 @@ class Engine:
         L.check(self.lib.sr_rows_step(self._h, n_steps, eos_a.ctypes.data_as(L._i32p) if len(eos_a) else None, len(eos_a), pad_id, self._s()),
                 self._h, "sr_rows_step")
 
+    def rows_set_cus(self, n_cus: int):
+        """hint: the decode steps queued after this on the current stream run on n_cus compute units (0 = the whole chip); results do not depend on it"""
+        L.check(self.lib.sr_rows_set_cus(self._h, int(n_cus), self._s()), self._h, "sr_rows_set_cus")
+
     def rows_poll(self):
         """-> (finished flags, generated-token counts), numpy int32 [max_batch]; synchronises."""
         fin = np.zeros(self.cfg.max_batch, dtype=np.int32)

@@ -58,6 +58,8 @@ SIGNATURES = {
     "sr_admit_stage": (C.c_int, [_vp, _i64p, _i64p, _i32p, _i32p, _i32p, _i, _vp, _i, _vp, _vp]),
     "sr_admit_commit": (C.c_int, [_vp, _i32p, _i, _vp]),
     "sr_rows_step": (C.c_int, [_vp, _i, _i32p, _i, C.c_int32, _vp]),
+    "sr_rows_set_cus": (C.c_int, [_vp, _i, _vp]),
+    "sr_op_gemv_set_cus": (C.c_int, [_i, _vp]),
     "sr_rows_poll": (C.c_int, [_vp, _i32p, _i32p, _vp]),
     "sr_rows_read": (C.c_int, [_vp, _i, _vp, _i, _vp]),
     "sr_rows_abort": (C.c_int, [_vp, _i32p, _i, _vp]),

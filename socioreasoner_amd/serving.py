@@ -182,6 +182,13 @@ class ContinuousBatcher:
             npatch += np_r
         return grp
 
+    def _set_cus(self, n):
+        """tell the engine how many CUs the decode steps queued next (on the current stream) will find: its x-stationary down-projection deals
+        its weight tiles to that many blocks (sr_rows_set_cus; a hint -- the tokens do not depend on it)"""
+        if getattr(self.engine, "_decode_cus", 0) != n:
+            self.engine.rows_set_cus(n)
+            self.engine._decode_cus = n
+
     def _use_decode_stream(self, s):
         """decode moves between the unmasked stream and the masked one; the new stream waits for what the old one has queued"""
         if self._dec_last is None:                   # first use: whatever the caller queued (weights, inputs) comes first
@@ -362,6 +369,7 @@ class ContinuousBatcher:
                 c0 = torch.cuda.Event(enable_timing=True)
                 c0.record(s)
             t0 = self._mark()
+            self._set_cus(self.streams.decode_cus if s is self.streams.decode else 0)
             self.engine.rows_step(self.steps_per_poll, self.eos, self.pad_id)
             self._span("decode_shared" if shares else "decode", t0, self._mark())
             if cal or cal_sh:
@@ -447,6 +455,12 @@ class ContinuousBatcher:
             self.free.append(row)
             on_complete(req, toks)
 
+    def _hand_back(self):
+        """back to the caller's stream, the engine's CU hint back to the whole chip"""
+        if self.overlap and self._dec_last is not None:
+            torch.cuda.current_stream(self.engine.device).wait_stream(self._dec_last)
+            self._set_cus(0)
+
     def run_stream(self, requests: Sequence[Request], on_complete: Callable[[Request, List[int]], None]) -> None:
         """Serve a stream of requests, reporting each as it completes (in completion order): what a server does -- the next requests'
         admission is staged under the running rows' last decode steps instead of after them."""
@@ -454,8 +468,7 @@ class ContinuousBatcher:
             self.submit(r)
         while not self.idle():
             self.pump(on_complete)
-        if self.overlap and self._dec_last is not None:      # hand back to the caller's stream
-            torch.cuda.current_stream(self.engine.device).wait_stream(self._dec_last)
+        self._hand_back()
 
     def run(self, requests: Sequence[Request]) -> List[List[int]]:
         """Serve a fixed list of requests; returns their token lists in request order."""
@@ -465,6 +478,5 @@ class ContinuousBatcher:
             self.submit(r)
         while not self.idle():
             self.pump(lambda req, toks: out.__setitem__(order[id(req)], toks))
-        if self.overlap and self._dec_last is not None:      # hand back to the caller's stream
-            torch.cuda.current_stream(self.engine.device).wait_stream(self._dec_last)
+        self._hand_back()
         return out

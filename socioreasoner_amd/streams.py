@@ -84,3 +84,4 @@ class OverlapStreams:
         self.decode_full = torch.cuda.Stream(dev)
         self.admit = _stream_with_mask(dev, adm)
         self.decode = _stream_with_mask(dev, dec)
+        self.decode_cus = sum(bin(w).count("1") for w in dec)          # CUs of the decode half (the engine's sr_rows_set_cus hint)

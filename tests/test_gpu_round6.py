@@ -173,6 +173,7 @@ def test_x_resident_gate_up_gemv_equals_the_streaming_kernel(monkeypatch, M, N, 
             for stream in (torch.cuda.current_stream(), streams.masked_stream("cuda:0", 0, 5)):
                 with torch.cuda.stream(stream):
                     sp = C.c_void_p(stream.cuda_stream)
+                    assert L.sr_op_gemv_set_cus(1000 if flag == "1" else 0, sp) == 0          # (n > 0 selects the x-stationary form at the op level, as sr_rows_set_cus in an engine)
                     for _ in range(3):
                         o = torch.zeros(Mp, N // 2, dtype=torch.bfloat16, device="cuda")
                         assert L.sr_op_gemv_fused(P(xt), K, P(wt), M, N, K, P(o), N // 2, 1 | 0x100 | 0x800 | out_tiled, None, None, C.c_float(0), None, 0, None,
@@ -180,6 +181,7 @@ def test_x_resident_gate_up_gemv_equals_the_streaming_kernel(monkeypatch, M, N, 
                         stream.synchronize()
                         res.append(o.cpu().clone())
         outs[flag] = res
+    assert L.sr_op_gemv_set_cus(0, None) == 0
     assert len(outs["0"]) == len(outs["1"]) > 0
     for a, b in zip(outs["0"], outs["1"]):
         assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
@@ -189,7 +191,8 @@ def test_x_resident_gate_up_gemv_equals_the_streaming_kernel(monkeypatch, M, N, 
 @pytest.mark.parametrize("size,fp8", [("tiny", False), ("tiny", True), ("3b", False), ("3b", True)])
 def test_x_resident_gate_up_in_the_decode_step(monkeypatch, size, fp8):
     """The same switch inside the engine's captured decode step: every logit of every step at 17 / 32 rows equals SR_GEMV_XLDS=0 (bf16 and fp8 weight streams,
-    eager and graph-replayed; 5 / 16 rows keep the streaming kernel either way)."""
+    eager and graph-replayed; 16 rows keep the streaming kernel either way).  The engine keeps TWO captured forms of the step -- whole chip (streaming GEMVs) and
+    CU-limited stream (x-stationary GEMVs, after sr_rows_set_cus(n > 0)) -- and moves between them call by call."""
     from socioreasoner_amd.config import geometry_3b, geometry_tiny
     from socioreasoner_amd.engine import Engine
     if size == "tiny":
@@ -201,20 +204,66 @@ def test_x_resident_gate_up_in_the_decode_step(monkeypatch, size, fp8):
     rng = np.random.default_rng(67)
     ids, pos = _prompts(rng, 32, vocab=vocab)
     out = {}
-    for flag in ("0", "1"):
+    for flag in ("0", "1", "3", "7"):
         switch(monkeypatch, "SR_GEMV_XLDS", flag)
         e = Engine(geom, max_patches=64, max_prefill_tokens=64 * 32, max_batch=32, max_ctx=128, max_new_tokens=16, lm_fp8=fp8)
         e.load_synthetic_weights(seed=0)
         res = []
         for B in (16, 17, 32):
-            e.prefill(ids[:B], pos[:B])
-            toks, tr = e.decode(10, trace=True, use_graph=False)
-            e.prefill(ids[:B], pos[:B])
-            toks_g, tr_g = e.decode(10, trace=True, use_graph=True)
-            assert torch.equal(toks, toks_g) and torch.equal(tr, tr_g), (flag, B)
-            res.append((toks.clone(), tr.clone()))
+            # the CU hint switches the step to its x-stationary form (bits 0 / 1: gate/up / down-projection; bit 2: that form on the whole chip too) and sets the deal
+            # of the down-projection's tiles -- never a bit of the result
+            for cus in {"0": (0,), "1": (0, 160), "3": (0, 160, 37), "7": (0,)}[flag]:
+                e.rows_set_cus(cus)
+                e.prefill(ids[:B], pos[:B])
+                toks, tr = e.decode(10, trace=True, use_graph=False)
+                e.prefill(ids[:B], pos[:B])
+                toks_g, tr_g = e.decode(10, trace=True, use_graph=True)
+                assert torch.equal(toks, toks_g) and torch.equal(tr, tr_g), (flag, B)
+                if cus:
+                    assert torch.equal(toks, res[-1][0]) and torch.equal(tr, res[-1][1]), (flag, B, cus)
+                else:
+                    res.append((toks.clone(), tr.clone()))
         out[flag] = res
         e.close()
-    for (t0, r0), (t1, r1) in zip(out["0"], out["1"]):
-        assert torch.equal(t0, t1)
-        assert torch.equal(r0, r1), float((r0 - r1).abs().max())
+    for flag in ("1", "3", "7"):
+        for (t0, r0), (t1, r1) in zip(out["0"], out[flag]):
+            assert torch.equal(t0, t1)
+            assert torch.equal(r0, r1), float((r0 - r1).abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,ks", [(32, 2048, 11008, 4), (17, 2048, 11008, 4), (24, 256, 11008, 4), (32, 2048, 4096, 4), (31, 128, 7168, 4), (32, 512, 8192, 4),
+                                      (32, 256, 22528, 8)])
+def test_x_stationary_split_k_gemv_equals_the_streaming_kernel(monkeypatch, M, N, K, ks):
+    """k_gemv32_px (round 6): the 17..32-row split-K down-projection with a block pinned to one K slab, its waves' x slice in registers and the weight tiles dealt
+    statically to the first L blocks (L = sr_op_gemv_set_cus; 0 = one block per CU).  Per tile the arithmetic is k_gemv32<PARTIAL, 4>'s: the float32 slabs equal
+    SR_GEMV_XLDS=0 bit for bit -- the 3B shape, ragged rows, fewer tiles than blocks, 4 / 8 / 11 chunks per wave (incl. a short last wave: 172 chunks over 16), 4 / 8
+    slabs, every L (incl. L < ksplit and L > the grid), on the whole chip and on a CU-masked stream."""
+    import ctypes as C
+    from socioreasoner_amd import lib, streams
+    L = lib.load()
+    P = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+    g = torch.Generator().manual_seed(M * 7 + N + K + ks)
+    x = torch.randn(32, K, generator=g).to(torch.bfloat16)
+    x[M:] = 0
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    xt, wt = _tile16x64(x).cuda().contiguous(), _tile16x64(w).cuda().contiguous()
+    outs = {}
+    for flag in ("0", "3"):
+        switch(monkeypatch, "SR_GEMV_XLDS", flag)
+        res = []
+        for stream in (torch.cuda.current_stream(), streams.masked_stream("cuda:0", 0, 5)):
+            with torch.cuda.stream(stream):
+                sp = C.c_void_p(stream.cuda_stream)
+                for cus in (0, 160, 96, 7, 1, 1000):
+                    assert L.sr_op_gemv_set_cus(cus, sp) == 0
+                    o = torch.full((ks, M, N), float("nan"), dtype=torch.float32, device="cuda")
+                    assert L.sr_op_gemv(P(xt), K, P(wt), M, N, K, P(o), ks, 0 | 0x100 | 0x800, sp) == 0
+                    stream.synchronize()
+                    res.append(o.cpu().clone())
+                assert L.sr_op_gemv_set_cus(0, sp) == 0
+        outs[flag] = res
+    for a, b in zip(outs["0"], outs["3"]):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    ref = x[:M].float() @ w.float().T
+    got = outs["3"][0].sum(0)
+    assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())

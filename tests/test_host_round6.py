@@ -38,7 +38,11 @@ def test_lost_experiments_are_not_in_the_product_library():
     blob = open(SO, "rb").read()
     for name in (b"SR_TAIL_NORM", b"SR_HEAD_NORM", b"gemv_tail_rmsnorm"):
         assert name not in blob, name
-    for patch in ("gemv_tail_head_rmsnorm.patch",):
+    # round 6's own lost experiment: the RMSNorm inside the x-stationary gate/up launch (k_gemv_px<.., NORM>, bits 3 / 4 of SR_GEMV_XLDS)
+    for name in ("ln2_px", "rms_ss8", "bool NORM"):
+        assert name not in src, name
+    assert not any(b"k_gemv_pxILb" in blob and tag in blob for tag in (b"k_gemv_pxILb0ELi8ELb1", b"k_gemv_pxILb1ELi8ELb1")), "k_gemv_px<.., NORM> is in the library"
+    for patch in ("gemv_tail_head_rmsnorm.patch", "gemv_px_norm_prologue.patch"):
         assert os.path.exists(os.path.join(ROOT, "tools", "experiments", patch)), patch
 
 

@@ -26,7 +26,9 @@
 #   sched_ab    admission share from measured costs (default) against the 32-row table (SR_SCHED_ONLINE=0) at 32 / 64 / 128 rows, twice each
 #   counted_ab  batch-1 and static 32-row bench with SR_GEMV_COUNTED=0 / 1, alternating twice (round 6: counted loops for the staged <= 4-row GEMVs)
 #   tests6      tests/test_gpu_round6.py (TESTS6_K selects)
+#   xlds_ab     the headline and the static 32-row bench with SR_GEMV_XLDS=0 / 1 / 3 (XLDS_SET selects; x-stationary gate/up and down-projection GEMVs, + 8 / 16: ln2 inside the gate/up launch), alternating twice -> gpurun_out/${RT}_gemv_xlds_ab.txt
 #   masked_trace  kernel traces of 63 decode steps on the ordinary stream and on CU-masked streams (8 / 7 / 5 of 8 CUs per shader engine) -> gpurun_out/${RT}_masked_trace.txt
+#   masked_trace_px  the 7 / 5-of-8 traces again with the scheduler's CU hint (sr_rows_set_cus: x-stationary gate/up and down GEMVs) -> gpurun_out/${RT}_masked_trace_px.txt
 #   attn_ab     prefill attention with hand-issued V^T reads (default) against SR_ATTN_VASM=0, kernel trace, twice each -> gpurun_out/${RT}_attn_vasm_ab.txt
 #   pmc_lds_all     LDS bank conflicts of every kernel of the bench and of the SAM2 float32 encoder -> gpurun_out/${RT}_pmc_lds_all.txt
 cd "$(dirname "$0")/.."
@@ -64,16 +66,22 @@ for stage in "$@"; do
   echo "================ stage $stage ($(date +%T))"
   case $stage in
     tests6) timeout 2400 python -m pytest tests/test_gpu_round6.py -q -m gpu ${TESTS6_K:+-k "$TESTS6_K"} 2>&1 | tail -15 ;;
+    xlds_ab) for rep in 1 2; do for v in ${XLDS_SET:-0 1 3}; do
+        SR_GEMV_XLDS=$v timeout 600 python bench.py --steps 3 --warmup 1 $QUIET --no-pmc > gpurun_out/${RT}_xl_c32_$v.log 2>&1; line gpurun_out/${RT}_xl_c32_$v.log "headline SR_GEMV_XLDS=$v rep $rep:"
+        SR_GEMV_XLDS=$v timeout 600 python bench.py --static --steps 3 --warmup 1 $QUIET --no-pmc > gpurun_out/${RT}_xl_s32_$v.log 2>&1; line gpurun_out/${RT}_xl_s32_$v.log "static 32 SR_GEMV_XLDS=$v rep $rep:"
+      done; done | tee gpurun_out/${RT}_gemv_xlds_ab.txt ;;
     counted_ab) for rep in 1 2; do for v in 0 1; do
         SR_GEMV_COUNTED=$v timeout 600 python bench.py --batch 1 --steps 3 --warmup 1 --no-cpu-baseline --no-sam --no-pmc > gpurun_out/${RT}_cnt_b1_$v.log 2>&1; line gpurun_out/${RT}_cnt_b1_$v.log "batch 1 SR_GEMV_COUNTED=$v rep $rep:"
         SR_GEMV_COUNTED=$v timeout 600 python bench.py --static --steps 3 --warmup 1 $QUIET --no-pmc > gpurun_out/${RT}_cnt_s32_$v.log 2>&1; line gpurun_out/${RT}_cnt_s32_$v.log "static 32 SR_GEMV_COUNTED=$v rep $rep:"
       done; done | tee gpurun_out/${RT}_gemv_counted_ab.txt ;;
-    masked_trace) for w in plain m8 m7 m5; do rm -rf /tmp/mt_$w
+    masked_trace|masked_trace_px)      # (masked_trace: the streaming GEMVs on every stream; masked_trace_px: the scheduler's CU hint on the masked ones -> the x-stationary GEMVs)
+      [ $stage = masked_trace ] && export PROBE_NO_HINT=1 || export PROBE_NO_HINT=0
+      for w in $([ $stage = masked_trace ] && echo plain m8 m7 m5 || echo m7 m5); do rm -rf /tmp/mt_$w
         (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/mt_$w -o t -- python $R/tools/probe_masked_trace.py $w 2>/dev/null | grep "decode ms")
         DB=$(find /tmp/mt_$w -name "t_results.db" | head -1)
         [ -n "$DB" ] && python tools/rocpd_stats.py $DB /tmp/mt_$w/stats.md > /dev/null && grep "k_gemv\|k_rmsnorm_row\|k_attn_dec\|k_step" /tmp/mt_$w/stats.md | awk -F"|" -v w=$w '{printf "%s %s calls %s avg_us %s\n", w, substr($2,1,60), $3, $5}'
         [ -n "$DB" ] && python tools/rocpd_gaps.py $DB 2>/dev/null | head -c 600; echo
-      done | tee gpurun_out/${RT}_masked_trace.txt ;;
+      done | tee gpurun_out/${RT}_${stage}.txt ;;
     tests5) timeout 2400 python -m pytest tests/test_gpu_round5.py -q -m gpu ${TESTS5_K:+-k "$TESTS5_K"} 2>&1 | tail -15 ;;
     suite)  timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 ;;
     fp8tests) timeout 1500 python -m pytest tests -q -m gpu -k "f8 or fp8" 2>&1 | tail -8 ;;

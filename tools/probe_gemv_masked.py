@@ -1,7 +1,7 @@
 """The five weight-streaming launches of a 32-row decode layer (+ LM head), each timed back to back over distinct weight copies, on the ORDINARY stream and on
 CU-masked streams (7 / 5 of the 8 CUs of every shader engine: the scheduler's decode stream is 5 / 8 while an admission is staged) -- and the same with a library
 built with -DSR_EXP_NOX (activation loads pinned to chunk 0: no L2 traffic for x, wrong results): is a launch on 160 CUs slower because a CU cannot pull more
-HBM-missing bytes, or because half of what it pulls is x from L2?  (round 6; SR_LIB_PATH selects the library)"""
+HBM-missing bytes, or because half of what it pulls is x from L2?  (round 6; SR_LIB_PATH selects the library; PROBE_HINT=1: what the x-stationary kernels make of the masked streams)"""
 import ctypes as C, json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from socioreasoner_amd import lib, streams
@@ -24,12 +24,14 @@ cases = [
     ("down (4 slabs)", mk(H, I), lambda w, o, s: L.sr_op_gemv(P(x), I, P(w), B, H, I, P(o), 4, 0 | TL | XT, s), torch.zeros(4, B, H, device="cuda")),
     ("LM head", mk(V, H, 2), lambda w, o, s: L.sr_op_gemv_fused(P(x), I, P(w), B, V, H, P(o), V, 2 | TL | XT, None, None, eps, None, 0, None, P(av), P(ai), s), torch.zeros(B, V, device="cuda")),
 ]
-strs = {"ordinary": torch.cuda.Stream(), "7 of 8 CUs": streams.masked_stream("cuda:0", 0, 7), "5 of 8 CUs": streams.masked_stream("cuda:0", 0, 5)}
+strs = {"ordinary": (torch.cuda.Stream(), 0), "7 of 8 CUs": (streams.masked_stream("cuda:0", 0, 7), 224), "5 of 8 CUs": (streams.masked_stream("cuda:0", 0, 5), 160)}
+HINT = os.environ.get("PROBE_HINT", "0") == "1"      # PROBE_HINT=1: the masked streams get the scheduler's CU hint (sr_op_gemv_set_cus: x-stationary gate/up and down)
 out = {}
 for name, W, fn, o in cases:
-    for sn, st in strs.items():
+    for sn, (st, cus) in strs.items():
         sp = C.c_void_p(st.cuda_stream)
         with torch.cuda.stream(st):
+            assert L.sr_op_gemv_set_cus(cus if HINT else 0, sp) == 0
             for r in range(W.shape[0]):
                 assert fn(W[r], o, sp) == 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -40,4 +42,4 @@ for name, W, fn, o in cases:
             e1.record()
         torch.cuda.synchronize()
         out.setdefault(name, {})[sn] = round(e0.elapsed_time(e1) * 1e3 / (5 * W.shape[0]), 2)
-print(json.dumps({"library": os.path.basename(lib.LIB_PATH), "us_per_launch": out}))
+print(json.dumps({"library": os.path.basename(lib.LIB_PATH), "cu_hint_on_masked_streams": HINT, "us_per_launch": out}))

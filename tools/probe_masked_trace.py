@@ -1,7 +1,8 @@
 """Kernel trace of the same 63 decode steps of a 32-row engine on ONE chosen stream -- `plain` (ordinary), `m8` (CU mask with every CU enabled), `m7` .. `m3` (7 .. 3 of the 8 CUs
 of every shader engine) -- so that rocprofv3's per-kernel durations and the gaps between them can be compared stream by stream:
     rocprofv3 --kernel-trace --stats -d out -o t -- python tools/probe_masked_trace.py m5
-Is a decode step on the scheduler's 160-CU stream slower because its kernels are longer, or because the launches are further apart?  (round 6)"""
+Is a decode step on the scheduler's 160-CU stream slower because its kernels are longer, or because the launches are further apart?  (round 6)
+On the m7 .. m3 streams the engine gets the scheduler's CU hint (sr_rows_set_cus) unless PROBE_NO_HINT=1."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,6 +26,8 @@ with torch.cuda.stream(plain):
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 with torch.cuda.stream(s):
+    if which[0] == "m" and which != "m8" and os.environ.get("PROBE_NO_HINT") != "1":
+        e.rows_set_cus(int(which[1:]) * 32)          # the scheduler's hint: the step's x-stationary form (sr_rows_set_cus; PROBE_NO_HINT=1: the streaming kernels)
     a.record()
     e.decode(G)
     b.record()
