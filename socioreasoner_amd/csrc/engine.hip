@@ -1716,6 +1716,8 @@ int sr_op_gemv_f8(const void* x, int ldx, const void* w8, const float* w_scale, 
     a.bias = (const bf16_t*)bias; a.norm_w = (const bf16_t*)norm_w; a.eps = eps;
     a.x_tiled = (mode & 0x800) ? 1 : 0;          // bit 11: x fragment-ordered; bit 12: SWIGLU output fragment-ordered (as sr_op_gemv_fused)
     a.out_tiled = (mode & 0x1000) ? 1 : 0;
+    if (M > 16) { if (int rc = op_px()) return rc; }
+    a.px_counter = (g_op_px_mode || (sr_switches().gemv_xlds & 4)) ? g_op_px : nullptr;
     SR_WRAP(launch_gemv((hipStream_t)stream, a, mode & 0xff));
 }
 int sr_op_sample(const float* logits, int B, int V, float temperature, int top_k, float top_p, float rep_penalty, const uint32_t* seen,

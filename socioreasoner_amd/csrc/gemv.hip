@@ -891,9 +891,9 @@ __global__ __launch_bounds__(256) void k_gemv32(GemvArgs p, int ntiles32) {
 // to px_counter[160] -- sr_rows_set_cus --, 0 = the grid), block b owns slab b % ksplit and tiles b / ksplit, + L / ksplit, ...; the other blocks leave at once.
 // (Tickets, as in k_gemv_px, cannot serve a launch with about one unit per block: a block has to hold the NEXT tile while it works, and the early blocks would
 // take every tile.)  Any L gives the same bits: per tile the chunk order, the MFMA order, the in-block reduction order and the slab stores are k_gemv32's.
-template <int PER>
+template <int PER, bool F8 = false>
 __global__ __launch_bounds__(256) void k_gemv32_px(GemvArgs p, int ntiles32) {
-    constexpr int KP = 4;
+    constexpr int KP = 4, WL = F8 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TGV(0);
     const int tid = threadIdx.x, lane = tid & 63, kp = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -907,20 +907,29 @@ __global__ __launch_bounds__(256) void k_gemv32_px(GemvArgs p, int ntiles32) {
     int tile = blockIdx.x / ks;
     if ((int)blockIdx.x >= per_slab * ks || tile >= ntiles32) return;
     const int c0 = (slab * KP + kp) * per, cend = min(c0 + per, nchunks), n = cend - c0;
-    // this wave's K sixteenth of x, fragment order (see k_gemv32): loaded once.  Slots u >= n hold a copy of the last chunk and are never multiplied
-    const bf16_t* xbase = p.x + ((size_t)(m >> 4) * nchunks * 2 + kg) * 512 + (m & 15) * 8;
-    u32x4 xr[PER][4], w[PER][4];
+    // this wave's K sixteenth of x, fragment order (k_gemv32; F8: k_gemv32g's operand order, MFMA step st = 2 j + h reads lane group 2 j + kg of k-step half h):
+    // loaded once.  Slots u >= n hold a copy of the last chunk and are never multiplied
+    const bf16_t* xbase = F8 ? p.x + ((size_t)(m >> 4) * nchunks * 2) * 512 + (kg * 16 + (m & 15)) * 8
+                             : p.x + ((size_t)(m >> 4) * nchunks * 2 + kg) * 512 + (m & 15) * 8;
+    u32x4 xr[PER][4], w[PER][WL];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const int c = min(c0 + u, cend - 1);
 #pragma unroll
-        for (int st = 0; st < 4; ++st) xr[u][st] = *reinterpret_cast<const u32x4*>(xbase + (size_t)c * 1024 + st * 128);
+        for (int st = 0; st < 4; ++st)
+            xr[u][st] = *reinterpret_cast<const u32x4*>(xbase + (size_t)c * 1024 + (F8 ? (st >> 1) * 256 + (st & 1) * 512 : st * 128));
     }
     auto fill_w = [&](int u, int tile, int c) {            // no load behind a condition: the chunk index is clamped instead (counted vmcnt waits, see k_gemv32)
         c = min(c, cend - 1);
-        const bf16_t* wb = p.W + ((size_t)(tile * 2 + half) * nchunks + c) * 1024 + kg * 512 + fr * 8;
+        if constexpr (F8) {
+            const unsigned char* wb = p.W8 + ((size_t)(tile * 2 + half) * nchunks + c) * 1024 + kg * 256 + fr * 16;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) w[u][st] = ldg_nt(wb + st * 128);
+            for (int j = 0; j < 2; ++j) w[u][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wb + j * 512));
+        } else {
+            const bf16_t* wb = p.W + ((size_t)(tile * 2 + half) * nchunks + c) * 1024 + kg * 512 + fr * 8;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) w[u][st] = ldg_nt(wb + st * 128);
+        }
     };
 #pragma unroll
     for (int u = 0; u < PER; ++u) fill_w(u, tile, c0 + u);
@@ -931,8 +940,17 @@ __global__ __launch_bounds__(256) void k_gemv32_px(GemvArgs p, int ntiles32) {
         for (int u = 0; u < PER; ++u) {
             if (u < n) {
 #pragma unroll
-                for (int st = 0; st < 4; ++st)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(w[u][st]), as_frag(xr[u][st]), acc, 0, 0, 0);
+                for (int st = 0; st < 4; ++st) {
+                    u32x4 wop;
+                    if constexpr (F8) {
+                        const u32x4 q = w[u][st >> 1];
+                        uint32_t d[4];
+                        f8x4_to_bf16(q[(st & 1) * 2], d[0], d[1]);
+                        f8x4_to_bf16(q[(st & 1) * 2 + 1], d[2], d[3]);
+                        wop = u32x4{d[0], d[1], d[2], d[3]};
+                    } else wop = w[u][st];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(wop), as_frag(xr[u][st]), acc, 0, 0, 0);
+                }
             }
             if constexpr (REFILL) fill_w(u, nxt, c0 + u);
         }
@@ -955,8 +973,13 @@ __global__ __launch_bounds__(256) void k_gemv32_px(GemvArgs p, int ntiles32) {
             if (xok) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
+                    float4 o = float4{acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
+                    if constexpr (F8) {        // per-output-channel scale of the fp8 weights
+                        const float4 sc = *reinterpret_cast<const float4*>(p.w_scale + (size_t)tile * 32 + 8 * g4 + 4 * kg);
+                        o.x *= sc.x; o.y *= sc.y; o.z *= sc.z; o.w *= sc.w;
+                    }
                     const size_t oi = ((size_t)slab * p.M + m) * p.N + tile * 32 + 8 * g4 + 4 * kg;
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + oi) = float4{acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + oi) = o;
                 }
             }
         }
@@ -1247,11 +1270,12 @@ int launch_px(hipStream_t s, const GemvArgs& a) {
 
 // the x-stationary split-K launch (PARTIAL, 17..32 rows, bf16 fragment-ordered x and weights, 4 waves = 4 in-block K parts, <= 11 chunks per wave)
 bool px32_ok(const GemvArgs& a, int mode) {
-    if (!(a.px_counter && (sr_switches().gemv_xlds & 2) && mode == GV_PARTIAL && a.M > 16 && a.M <= 32 && a.x_tiled && a.w_tiled && !a.norm_w && !a.W8
-          && a.N % 32 == 0 && a.ksplit >= 4 && a.ksplit <= 8)) return false;          // (ksplit >= 4: where the streaming path runs the 32-row-tile kernel, use_32)
+    if (!(a.px_counter && (sr_switches().gemv_xlds & 2) && mode == GV_PARTIAL && a.M > 16 && a.M <= 32 && a.x_tiled && a.w_tiled && !a.norm_w && (!a.W8 || a.w_scale)
+          && a.N % 32 == 0 && a.ksplit >= 4 && a.ksplit <= 8)) return false;          // (ksplit >= 4: where the streaming path runs the 32-row-tile kernels, use_32 / the fp8 branch of launch_gemv)
     const int nch = a.K / 64, per = (nch + a.ksplit * 4 - 1) / (a.ksplit * 4);
     return per >= 3 && per <= 11 && (a.ksplit * 4 - 1) * per < nch;
 }
+template <bool F8>
 int launch_px32(hipStream_t s, const GemvArgs& a) {
     const int ntiles = a.N / 32;
     const size_t smem = (size_t)2 * 3 * 64 * sizeof(f32x16);
@@ -1259,9 +1283,9 @@ int launch_px32(hipStream_t s, const GemvArgs& a) {
     int grid = g_px_cus / a.ksplit * a.ksplit;           // one block per CU (~400 registers per wave)
     if (grid > ntiles * a.ksplit) grid = ntiles * a.ksplit;
     const int nch = a.K / 64, per = (nch + a.ksplit * 4 - 1) / (a.ksplit * 4);
-    if (per <= 4) hipLaunchKernelGGL((k_gemv32_px<4>), dim3(grid), dim3(256), smem, s, a, ntiles);
-    else if (per <= 8) hipLaunchKernelGGL((k_gemv32_px<8>), dim3(grid), dim3(256), smem, s, a, ntiles);
-    else hipLaunchKernelGGL((k_gemv32_px<11>), dim3(grid), dim3(256), smem, s, a, ntiles);
+    if (per <= 4) hipLaunchKernelGGL((k_gemv32_px<4, F8>), dim3(grid), dim3(256), smem, s, a, ntiles);
+    else if (per <= 8) hipLaunchKernelGGL((k_gemv32_px<8, F8>), dim3(grid), dim3(256), smem, s, a, ntiles);
+    else hipLaunchKernelGGL((k_gemv32_px<11, F8>), dim3(grid), dim3(256), smem, s, a, ntiles);
     SR_CHECK_LAUNCH();
     return 0;
 }
@@ -1397,7 +1421,7 @@ int launch_gemv(hipStream_t s, const GemvArgs& a_, int mode) {
     int want = mode == GV_F32 ? 1 : 4;
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
     if (kp == 4 && px_ok(a, mode)) return a.W8 ? launch_px<true>(s, a) : launch_px<false>(s, a);
-    if (kp == 4 && px32_ok(a, mode)) return launch_px32(s, a);
+    if (kp == 4 && px32_ok(a, mode)) return a.W8 ? launch_px32<true>(s, a) : launch_px32<false>(s, a);
     if (a.W8) {          // fp8 weight stream (decode of the quantised LM linears); the in-block K split is always 4 there
         if (!a.w_scale || mode == GV_F32) return -22;
         if (kp != 4) return -22;

@@ -267,3 +267,26 @@ def test_x_stationary_split_k_gemv_equals_the_streaming_kernel(monkeypatch, M, N
     ref = x[:M].float() @ w.float().T
     got = outs["3"][0].sum(0)
     assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    # the fp8 weight stream (k_gemv32_px<.., F8> against k_gemv32g<PARTIAL, 4, 1, F8>)
+    w8 = torch.zeros(N * K, dtype=torch.uint8, device="cuda")
+    sc = torch.zeros(N, dtype=torch.float32, device="cuda")
+    assert L.sr_op_quant_f8(P(wt), N, K, P(w8), P(sc), None) == 0
+    torch.cuda.synchronize()
+    outs8 = {}
+    for flag in ("0", "3"):
+        switch(monkeypatch, "SR_GEMV_XLDS", flag)
+        res = []
+        for stream in (torch.cuda.current_stream(), streams.masked_stream("cuda:0", 0, 5)):
+            with torch.cuda.stream(stream):
+                sp = C.c_void_p(stream.cuda_stream)
+                for cus in (0, 160, 7, 1000):
+                    assert L.sr_op_gemv_set_cus(cus, sp) == 0
+                    o = torch.full((ks, M, N), float("nan"), dtype=torch.float32, device="cuda")
+                    assert L.sr_op_gemv_f8(P(xt), K, P(w8), P(sc), M, N, K, P(o), N, 0 | 0x800, None, None, C.c_float(0), ks, sp) == 0
+                    stream.synchronize()
+                    res.append(o.cpu().clone())
+                assert L.sr_op_gemv_set_cus(0, sp) == 0
+        outs8[flag] = res
+    for a, b in zip(outs8["0"], outs8["3"]):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    assert float((outs8["3"][0].sum(0) - ref).abs().max()) <= 8e-2 * float(ref.abs().max())
