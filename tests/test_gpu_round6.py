@@ -1,5 +1,6 @@
 """Round 6 GPU tests (through the C ABI): the counted ring loops of EVERY decode GEMV launch (LDS-staged <= 4-row launches and row-major x included)
-give the bits of the conditional-refill loops of rounds 1-4."""
+give the bits of the conditional-refill loops of rounds 1-4; configs[3] as 8 gloo ranks x 32 rows; the float32 verification path against HF float32 at 1e-3;
+the x-stationary persistent gate/up and down-projection GEMVs of the CU-limited decode stream give the bits of the streaming kernels."""
 from dataclasses import replace
 
 import numpy as np
@@ -141,7 +142,7 @@ def test_float32_path_meets_1e3_on_logits_against_hf_float32_at_full_depth(golde
     print(tag, res)
 
 
-# ------------------------------------------------------------------------------------------------ gate/up GEMV with x resident in LDS (persistent launch)
+# ------------------------------------------------------------------------------------------------ x-stationary persistent GEMVs of the CU-limited decode stream
 def _tile16x64(t):
     from tests.util import tile16x64
     return tile16x64(t)
@@ -149,10 +150,10 @@ def _tile16x64(t):
 
 @pytest.mark.parametrize("M,N,K", [(32, 22016, 2048), (17, 22016, 2048), (24, 4096, 1024), (32, 64, 512), (31, 96, 256)])
 def test_x_resident_gate_up_gemv_equals_the_streaming_kernel(monkeypatch, M, N, K):
-    """k_gemv_px (round 6): the 17..32-row gate/up GEMV as a persistent launch that stages the fragment-ordered activations into LDS once and pulls weight tiles
-    from a ticket counter.  Per tile its arithmetic is k_gemv<SWIGLU>'s (same K quarters per wave, chunk order, MFMA order, reduction order, epilogue): the output
-    equals SR_GEMV_XLDS=0 bit for bit -- at the 3B shapes, with fewer tiles than CUs, ragged row counts, fragment-ordered and row-major outputs, launch after
-    launch (the last block re-arms the ticket counter) and on a CU-masked stream (surplus blocks find no ticket)."""
+    """k_gemv_px (round 6): the 17..32-row gate/up GEMV as a persistent launch whose waves keep their K quarter of the fragment-ordered activations in registers and
+    pull weight tiles from sharded ticket counters.  Per tile its arithmetic is k_gemv<SWIGLU>'s (same K quarters per wave, chunk order, MFMA order, reduction order,
+    epilogue): the output equals the streaming kernel's bit for bit -- at the 3B shapes, with fewer tiles than CUs, ragged row counts, fragment-ordered and row-major
+    outputs, launch after launch (the last block re-arms the ticket counters) and on a CU-masked stream (surplus blocks find no ticket)."""
     import ctypes as C
     from socioreasoner_amd import lib, streams
     L = lib.load()

@@ -117,3 +117,34 @@ def test_rope_index_1d_equals_get_rope_index_on_random_prompt_structures():
         want, _ = hostops.get_rope_index(torch.from_numpy(ids)[None], grids or None, None, image_token_id=IMG, vision_start_token_id=VS)
         got = hostops.rope_index_1d(ids, grids or None, image_token_id=IMG, vision_start_token_id=VS)
         assert got.dtype == np.int64 and np.array_equal(got, want[:, 0].numpy()), case
+
+
+# ------------------------------------------------------------------------------------------------ the scheduler's CU hint (sr_rows_set_cus)
+def test_scheduler_tells_the_engine_the_cu_count_only_when_it_changes():
+    """ContinuousBatcher._set_cus / _hand_back (socioreasoner_amd/serving.py): the engine hears about the decode stream's CU count when decode moves between the unmasked
+    and the masked stream -- not per chunk -- and is told "whole chip" again when the scheduler hands the stream back (the engine then replays the whole-chip form of
+    its decode step for whoever calls next)."""
+    from socioreasoner_amd.serving import ContinuousBatcher
+
+    class Eng:
+        def __init__(self):
+            self.calls = []
+
+        def rows_set_cus(self, n):
+            self.calls.append(n)
+
+    cb = ContinuousBatcher.__new__(ContinuousBatcher)
+    cb.engine = Eng()
+    for n in (0, 0, 160, 160, 160, 0, 176, 176):
+        cb._set_cus(n)
+    assert cb.engine.calls == [160, 0, 176]
+    assert cb.engine._decode_cus == 176
+    # hand-back: only an overlapped scheduler that decoded on its own streams has anything to undo
+    cb.overlap, cb._dec_last = False, None
+    cb._hand_back()
+    assert cb.engine.calls == [160, 0, 176]
+    # the decode CU count of a split = the complement of the admission mask
+    from socioreasoner_amd.streams import split_masks
+    for share, want in ((3, 160), (2, 192), (2.5, 176), (4, 128)):
+        _, dec = split_masks(8, share)
+        assert sum(bin(w).count("1") for w in dec) == want
