@@ -90,6 +90,7 @@ class Mi355xStrategy(InferenceStrategy):
         # spare KV slots (default: as many again as rows) let the scheduler prefill the next requests on a CU-masked stream while the
         # running rows decode (socioreasoner_amd/serving.py overlap); strategy_config overlap_admission: false = one stream as before
         self.overlap = bool(sc.get("overlap_admission", True))
+        self.gen_stats = []          # one entry per generate call served by the scheduler (host preparation / run wall time, scheduler counters)
         kv_slots = int(sc.get("kv_slots", 2 * self.max_batch if self.overlap else 0))
         self.engine = Engine(self.geom, max_patches=int(sc.get("max_patches", self.max_batch * 2 * 2916)), kv_slots=kv_slots,
                              max_prefill_tokens=int(sc.get("max_prefill_tokens", min(prompt_len, 2048) * self.max_batch)),
@@ -307,6 +308,8 @@ class Mi355xStrategy(InferenceStrategy):
         B = len(prompts)
         results: List[List[List[int]]] = [None] * B          # per prompt: n responses
         prepared = []
+        import time as _time
+        t_gen0 = _time.perf_counter()
         for i in range(B):
             ids_i = mm[i]["prompt_token_ids"] if mm is not None and mm[i].get("prompt_token_ids") else prompts[i]
             imgs = (mm[i].get("multi_modal_data") or {}).get("image") if mm is not None else None
@@ -331,7 +334,13 @@ class Mi355xStrategy(InferenceStrategy):
                 if room < 1:
                     raise ValueError(f"prompt of {len(ids_k)} tokens leaves no room in max_ctx {self.engine.cfg.max_ctx}")
                 reqs.append(Request(ids=ids_k, pos3=pos_k, max_new=max(1, min(max_new, room)), images=ims_k, grids=grids_k))
-            outs = ContinuousBatcher(self.engine, eos, pad, sampling=smp, overlap=self.overlap).run(reqs)
+            t_run0 = _time.perf_counter()
+            cb = ContinuousBatcher(self.engine, eos, pad, sampling=smp, overlap=self.overlap)
+            outs = cb.run(reqs)
+            # where a generate call's wall time went (tools/run_example_small.py prints it): host preparation of the requests, then the scheduler's run
+            self.gen_stats.append({"requests": B, "prepare_s": round(t_run0 - t_gen0, 3), "run_s": round(_time.perf_counter() - t_run0, 3),
+                                   **{k: (round(v, 1) if isinstance(v, float) else v) for k, v in cb.stats.items()
+                                      if k in ("steps", "steps_shared", "admissions", "rounds", "host_ms", "poll_wait_ms", "shares", "share_model")}})
             for k in range(B):
                 row = [int(t) for t in outs[k]]
                 cut = next((j + 1 for j, t in enumerate(row) if t in eos), len(row))

@@ -900,6 +900,8 @@ class Sam2Predictor:
         dev = self.engine.device
 
         def work():
+            from .serving import foreign_gpu_load
+            foreign_gpu_load(True)           # the LM scheduler of this process takes no cost measurements next to this (serving.py)
             try:
                 torch.cuda.set_device(dev)
                 if self._pf_stream is None:
@@ -910,6 +912,8 @@ class Sam2Predictor:
                         self._pf_stream.synchronize()
             except Exception as e:  # noqa: BLE001  (reported by wait_prefetch / the next segment_batch; the embeddings it missed are encoded there)
                 self._pf_error = e
+            finally:
+                foreign_gpu_load(False)
         self._pf_thread = threading.Thread(target=work, name="sam2-prefetch", daemon=True)
         self._pf_thread.start()
 

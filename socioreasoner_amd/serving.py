@@ -16,6 +16,19 @@ import numpy as np
 import torch
 
 
+# Other GPU work of the same process that the scheduler does not schedule (SAM2's image encoder prefetched on a side stream under stage-1 generation,
+# socioreasoner_amd/sam2.py) announces itself here: a cost measurement that overlaps it says nothing about the scheduler's own two streams -- taken anyway, it made
+# the share model flip between 4 and 5 CUs per shader engine from run to run of the two-stage pipeline (stage 2: 4.7 s or 5.9 s) -- so none is started while such
+# work is running and one in flight when it starts or ends is dropped.
+_FOREIGN = {"active": 0, "epoch": 0}
+
+
+def foreign_gpu_load(begin: bool) -> None:
+    """bracket GPU work outside the scheduler's streams: foreign_gpu_load(True) ... foreign_gpu_load(False) (any thread)"""
+    _FOREIGN["active"] += 1 if begin else -1
+    _FOREIGN["epoch"] += 1
+
+
 @dataclass
 class Request:
     ids: np.ndarray                       # int64 [S], image placeholders already expanded
@@ -59,6 +72,7 @@ class ContinuousBatcher:
         # engine like the unshared calibration.
         self._dec_meas, self._adm_meas = getattr(engine, "_sched_cal_shared", ({}, {}))
         self._cal_dec_sh = self._cal_adm_sh = None
+        self._meas_epoch: Dict[str, int] = {}      # measurement in flight -> _FOREIGN epoch at its start (see foreign_gpu_load)
         self._cal_seen = engine.__dict__.setdefault("_sched_cal_seen", {})      # ("dec" | "adm", share) -> samples taken (8 fast ones per share, then every 8th opportunity)
         self._cal_opp: Dict[tuple, int] = {}
         import os
@@ -222,6 +236,17 @@ class ContinuousBatcher:
             return base * min(max(k, 0.5), 2.0)
         return base
 
+    def _meas_begin(self, key: str) -> bool:
+        """may a cost measurement start now?  Not next to GPU work the scheduler does not own."""
+        if _FOREIGN["active"] > 0:
+            return False
+        self._meas_epoch[key] = _FOREIGN["epoch"]
+        return True
+
+    def _meas_clean(self, key: str) -> bool:
+        """did the measurement run without such work starting or ending under it?"""
+        return self._meas_epoch.pop(key, None) == _FOREIGN["epoch"]
+
     def _ema(self, table: dict, key: int, value: float):
         """fast while a share is new (the first 8 samples), slow afterwards: the measurement never stops (a table frozen after 8 samples keeps
         a stale factor when the workload on a long-lived engine changes -- prompt lengths, context, rows per step)"""
@@ -283,9 +308,9 @@ class ContinuousBatcher:
                 s.wait_event(self._commit_ev)          # the previous group's last commit reads the engine's admission scratch
         else:
             s = self._use_decode_stream(self.streams.decode_full)
-        cal = self._auto and not shared and self._adm_rate is None and self._cal_adm is None
+        cal = bool(self._auto and not shared and self._adm_rate is None and self._cal_adm is None and self._meas_begin("adm"))
         cal_sh = bool(self._online and self._auto and shared and self._adm_rate is not None and self._cal_adm_sh is None
-                      and self._sample_due("adm"))
+                      and self._sample_due("adm") and self._meas_begin("adm_sh"))
         try:
             self._stage_on(s, grp, slots, shared, cal or cal_sh, units)
             if cal_sh and self._cal_adm is not None:          # (_stage_on left the event pair in _cal_adm: this one measures a SHARED admission)
@@ -361,9 +386,9 @@ class ContinuousBatcher:
         shares = busy or (self.staged is None and bool(self.pending) and bool(self.free_slots))
         # (step-time calibration: a chunk with the chip to itself -- no admission in flight and none about to be staged under it)
         cal = (self._auto and not busy and not (self.staged is None and self.pending and self.free_slots)
-               and self._step_ms is None and self._cal_step is None)
+               and self._step_ms is None and self._cal_step is None and self._meas_begin("step"))
         cal_sh = bool(self._online and self._auto and busy and self._step_ms is not None and self._cal_dec_sh is None       # a chunk on the decode CU set next to the admission
-                      and self._sample_due("dec"))
+                      and self._sample_due("dec") and self._meas_begin("dec_sh"))
         with torch.cuda.stream(s):
             if cal or cal_sh:
                 c0 = torch.cuda.Event(enable_timing=True)
@@ -388,25 +413,28 @@ class ContinuousBatcher:
             self._cnt_last = {row: int(cnt[row]) for row in self.active}
             if self._auto:          # (the poll synchronised the decode stream: finished measurements can be read without waiting)
                 if self._cal_step is not None and self._cal_step[1].query():
-                    self._step_ms = self._cal_step[0].elapsed_time(self._cal_step[1]) / self._cal_step[2]
+                    if self._meas_clean("step"):
+                        self._step_ms = self._cal_step[0].elapsed_time(self._cal_step[1]) / self._cal_step[2]
+                        self.engine._sched_cal = (self._adm_rate, self._step_ms)
                     self._cal_step = None
-                    self.engine._sched_cal = (self._adm_rate, self._step_ms)
                 if self._cal_adm is not None and self._cal_adm[1].query():
-                    self._adm_rate = self._cal_adm[0].elapsed_time(self._cal_adm[1]) / max(self._cal_adm[2], 1)
+                    if self._meas_clean("adm"):
+                        self._adm_rate = self._cal_adm[0].elapsed_time(self._cal_adm[1]) / max(self._cal_adm[2], 1)
+                        self.engine._sched_cal = (self._adm_rate, self._step_ms)
                     self._cal_adm = None
-                    self.engine._sched_cal = (self._adm_rate, self._step_ms)
                 if self._cal_dec_sh is not None and self._cal_dec_sh[1].query():
                     c0, c1, n_st, share, adm_ev = self._cal_dec_sh
-                    if not adm_ev.query():          # the admission outlasted the chunk: every one of its steps shared the chip
+                    if not adm_ev.query() and self._meas_clean("dec_sh"):          # the admission outlasted the chunk: every one of its steps shared the chip
                         self._ema(self._dec_meas, share, max(c0.elapsed_time(c1) / n_st / self._step_ms, 1.0))
                         self._cal_seen[("dec", share)] = self._cal_seen.get(("dec", share), 0) + 1
                         self.engine._sched_cal_shared = (self._dec_meas, self._adm_meas)
                     self._cal_dec_sh = None
                 if self._cal_adm_sh is not None and self._cal_adm_sh[1].query():
                     c0, ev, units, share = self._cal_adm_sh
-                    self._ema(self._adm_meas, share, max(c0.elapsed_time(ev) / max(units * self._adm_rate, 1e-6), 1.0))
-                    self._cal_seen[("adm", share)] = self._cal_seen.get(("adm", share), 0) + 1
-                    self.engine._sched_cal_shared = (self._dec_meas, self._adm_meas)
+                    if self._meas_clean("adm_sh"):
+                        self._ema(self._adm_meas, share, max(c0.elapsed_time(ev) / max(units * self._adm_rate, 1e-6), 1.0))
+                        self._cal_seen[("adm", share)] = self._cal_seen.get(("adm", share), 0) + 1
+                        self.engine._sched_cal_shared = (self._dec_meas, self._adm_meas)
                     self._cal_adm_sh = None
                 self.stats["share_model"] = {"decode_slowdown_measured": {k: round(v, 3) for k, v in self._dec_meas.items()},
                                              "admission_slowdown_measured": {k: round(v, 3) for k, v in self._adm_meas.items()},

@@ -42,7 +42,9 @@ def test_lost_experiments_are_not_in_the_product_library():
     for name in ("ln2_px", "rms_ss8", "bool NORM"):
         assert name not in src, name
     assert not any(b"k_gemv_pxILb" in blob and tag in blob for tag in (b"k_gemv_pxILb0ELi8ELb1", b"k_gemv_pxILb1ELi8ELb1")), "k_gemv_px<.., NORM> is in the library"
-    for patch in ("gemv_tail_head_rmsnorm.patch", "gemv_px_norm_prologue.patch"):
+    for name in ("ctx_grid", "SR_ATTN_CTX_GRID"):
+        assert name not in src, name
+    for patch in ("gemv_tail_head_rmsnorm.patch", "gemv_px_norm_prologue.patch", "attn_decode_ctx_grid.patch"):
         assert os.path.exists(os.path.join(ROOT, "tools", "experiments", patch)), patch
 
 
@@ -148,3 +150,25 @@ def test_scheduler_tells_the_engine_the_cu_count_only_when_it_changes():
     for share, want in ((3, 160), (2, 192), (2.5, 176), (4, 128)):
         _, dec = split_masks(8, share)
         assert sum(bin(w).count("1") for w in dec) == want
+
+
+def test_scheduler_takes_no_cost_measurement_next_to_foreign_gpu_work():
+    """serving.foreign_gpu_load brackets GPU work the scheduler does not own (SAM2's prefetched encoder): no measurement starts inside the bracket, one in flight
+    when the bracket opens or closes is dropped, and afterwards measurements are taken again."""
+    from socioreasoner_amd import serving
+    cb = serving.ContinuousBatcher.__new__(serving.ContinuousBatcher)
+    cb._meas_epoch = {}
+    assert cb._meas_begin("step") and cb._meas_clean("step")
+    assert cb._meas_begin("adm")
+    serving.foreign_gpu_load(True)
+    try:
+        assert not cb._meas_clean("adm")            # foreign work started under it
+        assert not cb._meas_begin("dec_sh")         # none starts next to it
+    finally:
+        serving.foreign_gpu_load(False)
+    assert cb._meas_begin("dec_sh") and cb._meas_clean("dec_sh")
+    assert cb._meas_begin("adm_sh")
+    serving.foreign_gpu_load(True)
+    serving.foreign_gpu_load(False)
+    assert not cb._meas_clean("adm_sh")             # ... or started AND ended under it
+    assert serving._FOREIGN["active"] == 0

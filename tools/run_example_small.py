@@ -72,4 +72,5 @@ pred = getattr(pipe.seg_infer.strategy, "model", None)
 print(json.dumps({"samples": n, "new_tokens_per_stage": new, "scripted_objects_per_stage": n_obj, "sam2_stats": getattr(pred, "stats", None),
                   "sam2_dtype": str(getattr(getattr(pred, "engine", None), "dt", None)), "build_s": round(t1 - t0, 1), "run_s": round(t2 - t1, 1), "samples_per_s": round(n / (t2 - t1), 2),
                   "giou_acc": acc, "files": files, "sam": type(pipe.seg_infer.strategy.model).__name__,
-                  "wall_s_by_phase": {k: round(v, 2) for k, v in pipe.timing.items()}}))
+                  "wall_s_by_phase": {k: round(v, 2) for k, v in pipe.timing.items()},
+                  "generate_calls": getattr(getattr(pipe.actor_infer, "strategy", None), "gen_stats", None)}))
