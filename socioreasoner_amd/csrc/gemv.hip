@@ -508,7 +508,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
 
 // ---------------------------------------------------------------------------------------------- 17..32 rows, x STATIONARY in registers (round 6)
 // Why: at 32 rows every wave of k_gemv re-reads as many bytes of x from L2 as it streams weights from HBM, and a CU's load path carries both.  On the whole chip
-// that costs the gate/up launch ~2 us of 19; on the scheduler's 160-CU decode stream (5 of 8 CUs per shader engine while an admission is staged: 63 % of the
+// that costs the gate/up launch ~2 us of 19; on the scheduler's 160-CU decode stream (5 of 8 CUs per shader engine while an admission is staged: two thirds of the
 // headline's decode steps) it is THE limit -- tools/probe_gemv_masked.py, profiles/r06_probe_gemv_masked.jsonl: gate/up 24.9 us with the x loads, 18.0 with them
 // pinned to L1.  A wave of this launch only ever needs ITS K quarter of x (32 rows x K / 4 bf16 <= 32 KB = 128 registers per lane): here it loads that quarter ONCE,
 // keeps it in registers, and walks weight tiles it pulls from a ticket counter (persistent: one block per CU -- ~300 registers per wave --, blocks that find the
@@ -516,7 +516,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv(GemvArgs p, int ntiles) {
 // quarters, the same chunk order and MFMA order per wave, the same in-block reduction order, the same epilogue -- so the result is bit-identical
 // (tests/test_gpu_round6.py).  The ring holds a wave's WHOLE K slice (U = PER chunks): a slot is refilled with the NEXT tile's chunk right after it is consumed,
 // so the weight stream never ramps between tiles.  (A first version kept x in LDS, 128 KB per block by LDS-DMA: its up-front copy made the first tile cost twice
-// a tile's bytes per CU -- 7.6 us of prologue -- and lost to the streaming kernel on the whole chip.)
+// a tile's bytes per CU -- 7.6 us of prologue -- and lost to the streaming kernel on the whole chip.)  On the whole chip even this form is 1 % slower per step
+// than the streaming kernel (688 tiles over 256 persistent blocks are 2.7 rounds that quantise to 3): the engine takes it on a CU-limited stream only
+// (sr_rows_set_cus; bit 2 of SR_GEMV_XLDS forces it everywhere).
 // Tickets: ONE counter word saturates at ~88 dequeues per microsecond on this chip (MI355X guide, "dequeue") -- 944 tickets would cost the launch 10 us.  The
 // counter is sharded 8 ways: block b draws from shard b % 8 (its XCD under round-robin dispatch; nothing depends on that being true), whose k-th ticket is tile
 // 8 k + shard.  A shard is served by every 8th block, on the whole chip and on a CU-masked stream alike (the first blocks dispatched are 0 .. n - 1), so the
