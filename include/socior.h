@@ -175,8 +175,8 @@ int sr_decode_step(sr_engine* e, const int64_t* dev_last_ids, int B, float* dev_
  *   sr_rows_set_cus : a HINT for the decode steps queued on `stream` after it (sr_rows_step, sr_decode, sr_decode_step): they will run on
  *                   n_cus compute units -- a CU-masked stream next to an overlapped admission; 0 = the whole chip, the state after
  *                   sr_engine_create.  With n_cus > 0 the engine replays a second captured form of the step whose gate/up and
- *                   down-projection GEMVs at 17..32 rows keep their activations in registers and walk the weight tiles (the
- *                   down-projection deals them to n_cus blocks): 4.6 % more tiles/s on the headline, 1 % slower on the whole chip.
+ *                   down-projection GEMVs and LM head at 17..32 rows keep their activations in registers / LDS and walk the weight
+ *                   tiles (dealt to n_cus blocks): 4.6 % more tiles/s on the headline, 1 % slower on the whole chip.
  *                   Results do not depend on it, bit for bit.
  *   sr_rows_sampling : (optional, after sr_rows_begin) all rows draw their tokens with k_sample (temperature > 0, top_k <= 1024 -- <= 0: no top-k bound --,
  *                   0 < top_p <= 1) instead of the greedy arg-max; temperature 0 switches back. */

@@ -89,7 +89,7 @@ static void load_switches() {
     g_sw.attn_vasm = env_int("SR_ATTN_VASM", 1);
     g_sw.sam_f32_split = env_int("SR_SAM_F32_SPLIT", 1);
     g_sw.gemv_counted = env_int("SR_GEMV_COUNTED", 1);
-    g_sw.gemv_xlds = env_int("SR_GEMV_XLDS", 3);
+    g_sw.gemv_xlds = env_int("SR_GEMV_XLDS", 11);
     g_sw_loaded = true;
 }
 const SrSwitches& sr_switches() {
@@ -611,6 +611,8 @@ int enqueue_lm_head(sr_engine* e, int B, bf16_t* x, bf16_t* x_alt, bool pending,
         if (pending) SR_TRY(launch_resid_rmsnorm(s, x, e->d_slabs, ks_down(e, B), e->final_norm, e->d_xn, B, H, c.t_rms_eps, xt));
         else SR_TRY(launch_rmsnorm(s, x, e->final_norm, e->d_xn, B, H, c.t_rms_eps, xt));
         g.x = e->d_xn; g.x_tiled = xt;
+        // on a CU-limited stream the decode step's head keeps x in LDS (k_gemv32_hpx: same bits; the admission's own head stays the streaming kernel)
+        if (!admission && (e->px_mode || (sr_switches().gemv_xlds & 4))) g.px_counter = e->d_px;
     }
     SR_TRY(launch_gemv(s, g, GV_F32));
     return 0;

@@ -991,6 +991,116 @@ __global__ __launch_bounds__(256) void k_gemv32_px(GemvArgs p, int ntiles32) {
     TGV(3);
 }
 
+// ---------------------------------------------------------------------------------------------- 17..32 rows, LM head with x resident in LDS (round 6)
+// The head keeps its summation order -- ONE wave per 32-row vocabulary tile, all 32 chunks of K = 2048 in sequence (k_gemv32<GV_F32, 1>) -- so a wave needs ALL of x
+// (128 KB), which no register file holds: here the block copies x to LDS once and its 4 waves walk (groups of 4) vocabulary tiles, reading the activation fragments
+// with ds_read_b128 (conflict-free: 16 lanes read 256 contiguous bytes) while the weights stream through an 8-slot ring that is refilled across tile boundaries.  On
+// 160 CUs the streaming head is bound by the CUs' load path, half of which carries x re-reads from L2 (152 us against 113 on the whole chip); the whole chip is
+// HBM-bound either way, so this form is used on a CU-limited stream only (sr_rows_set_cus).  Groups are dealt statically to the first L blocks (L = the hinted CU
+// count).  Logits and the per-group arg-max partials are the streaming kernel's, bit for bit.
+template <int U>
+__global__ __launch_bounds__(256) void k_gemv32_hpx(GemvArgs p, int ntiles32, int ngroups) {
+    constexpr int NCH = 32;                     // K = 2048 (launcher)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                               // [2 row groups][32 chunks][2 halves][64 lanes][8]: x as it lies in memory
+    float* av = reinterpret_cast<float*>(smem + (size_t)32 * 2048 * 2);        // [4 waves][32 rows]
+    int* ai = reinterpret_cast<int*>(av + 4 * 32);
+    TGV(0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, half = (lane >> 4) & 1, kg = lane >> 5, m = lane & 31;
+    const unsigned lim = p.px_counter[10 * 16];
+    const int nb = (lim != 0u && lim < gridDim.x) ? (int)lim : (int)gridDim.x;
+    int g = blockIdx.x;
+    if (g >= nb || g >= ngroups) return;
+    u32x4 w[U][4];
+    auto wptr = [&](int tile, int c) { return p.W + ((size_t)(tile * 2 + half) * NCH + c) * 1024 + kg * 512 + fr * 8; };
+    auto fill_w = [&](int u, int tile, int c) {
+        const bf16_t* wb = wptr(tile, c);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) w[u][st] = ldg_nt(wb + st * 128);
+    };
+    int tile = min(g * 4 + wave, ntiles32 - 1);           // (a wave past the last tile repeats it and stores nothing)
+#pragma unroll
+    for (int u = 0; u < U; ++u) fill_w(u, tile, u);
+    // x -> LDS by LDS-DMA (one wave instruction = 1 KB, no register round trip), 32 KB per wave, behind the first ring of weights; the barrier drains it
+    {
+        typedef __attribute__((address_space(1))) const void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int kb = wave * 32 + i;
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.x + (size_t)kb * 512 + lane * 8), (lptr_t)(xs + kb * 512), 16, 0, 0);
+        }
+    }
+    __syncthreads();
+    TGV(1);
+    const bf16_t* xl = xs + ((size_t)(m >> 4) * NCH * 2 + kg) * 512 + (m & 15) * 8;
+    auto run_tile = [&](auto refill_, int cur, int nxt, f32x16& acc) {
+        constexpr bool REFILL = decltype(refill_)::value;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int u = c % U;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const u32x4 xv = *reinterpret_cast<const u32x4*>(xl + (size_t)c * 1024 + st * 128);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(w[u][st]), as_frag(xv), acc, 0, 0, 0);
+            }
+            if (c + U < NCH) fill_w(u, cur, c + U);
+            else if constexpr (REFILL) fill_w(u, nxt, c + U - NCH);
+            // hipcc otherwise sinks every refill down to its use eight chunks later (one fully unrolled basic block, "fewer live registers"): the ring
+            // would be one slot deep -- vmcnt(0) in front of every MFMA (disassembly)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const bool xok = m < p.M;
+    for (;;) {
+        const int gnext = g + nb;
+        const bool more = gnext < ngroups;
+        const int tnext = min(gnext * 4 + wave, ntiles32 - 1);
+        const bool active = g * 4 + wave < ntiles32;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        if (more) run_tile(std::true_type{}, tile, tnext, acc);
+        else run_tile(std::false_type{}, tile, 0, acc);
+        float bestv = -INFINITY;
+        int besti = 0x7fffffff;
+        if (active && xok) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = tile * 32 + 8 * g4 + 4 * kg;
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.N + n) = float4{acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (acc[g4 * 4 + r] > bestv || (acc[g4 * 4 + r] == bestv && n + r < besti)) { bestv = acc[g4 * 4 + r]; besti = n + r; }
+            }
+        }
+        if (p.amax_val) {        // the group's arg-max partial, as one block of the streaming launch computes it
+            const float ov = __shfl_xor(bestv, 32, 64);
+            const int oi = __shfl_xor(besti, 32, 64);
+            if (ov > bestv || (ov == bestv && oi < besti)) { bestv = ov; besti = oi; }
+            if (kg == 0) { av[wave * 32 + m] = bestv; ai[wave * 32 + m] = besti; }
+            __syncthreads();
+            if (tid < p.M) {
+                float bv = av[tid];
+                int bi = ai[tid];
+                for (int w2 = 1; w2 < 4; ++w2) {
+                    const float v2 = av[w2 * 32 + tid];
+                    const int i2 = ai[w2 * 32 + tid];
+                    if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+                }
+                p.amax_val[(size_t)tid * ngroups + g] = bv;
+                p.amax_idx[(size_t)tid * ngroups + g] = bi;
+            }
+            __syncthreads();
+        }
+        if (!more) break;
+        g = gnext;
+        tile = tnext;
+    }
+    TGV(3);
+}
+
 // ---------------------------------------------------------------------------------------------- batches 33..128
 // The same 32-row-tile kernel for G groups of 32 batch rows (round 4: the reference's request-level mode keeps up to 128 requests in flight
 // per worker, /root/reference/roll/distributed/scheduler/generate_scheduler.py:57): a wave streams its weight tile ONCE and multiplies it with
@@ -1292,6 +1402,21 @@ int launch_px32(hipStream_t s, const GemvArgs& a) {
     return 0;
 }
 
+// the LM head with x resident in LDS (F32, 17..32 rows, bf16 fragment-ordered x and weights, K = 2048, whole groups of 4 tiles)
+bool hpx_ok(const GemvArgs& a, int mode) {
+    return a.px_counter && (sr_switches().gemv_xlds & 8) && mode == GV_F32 && a.M > 16 && a.M <= 32 && a.x_tiled && a.w_tiled && !a.norm_w && !a.W8 && a.K == 2048
+           && a.N % 32 == 0 && (a.amax_val == nullptr) == (a.amax_idx == nullptr);
+}
+int launch_hpx(hipStream_t s, const GemvArgs& a) {
+    const int ntiles = a.N / 32, ngroups = cdiv(ntiles, 4);
+    const size_t smem = (size_t)32 * 2048 * 2 + 4 * 32 * 8;
+    if (!g_px_cus) { if (int rc = gemv_prepare_px()) return rc; }
+    const int grid = ngroups < g_px_cus ? ngroups : g_px_cus;
+    hipLaunchKernelGGL((k_gemv32_hpx<8>), dim3(grid), dim3(256), smem, s, a, ntiles, ngroups);
+    SR_CHECK_LAUNCH();
+    return 0;
+}
+
 size_t stage_bytes(const GemvArgs& a) { return ((size_t)a.M * (a.K + 8) * 2 + 15) / 16 * 16; }
 
 template <int MODE, int MT, int KP, bool STAGE, int WAVES, bool F8 = false>
@@ -1343,6 +1468,10 @@ int gemv_prepare_px() {
                           reinterpret_cast<const void*>(k_gemv_px<false, 2>), reinterpret_cast<const void*>(k_gemv_px<true, 2>),
                           reinterpret_cast<const void*>(k_gemv_px<false, 1>), reinterpret_cast<const void*>(k_gemv_px<true, 1>)}) {
         hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (r != hipSuccess) return (int)r;
+    }
+    {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemv32_hpx<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         if (r != hipSuccess) return (int)r;
     }
     int dev = 0;
@@ -1424,6 +1553,7 @@ int launch_gemv(hipStream_t s, const GemvArgs& a_, int mode) {
     const int kp = gemv_pick_kp(a.K, mode == GV_PARTIAL ? a.ksplit : 1, want);
     if (kp == 4 && px_ok(a, mode)) return a.W8 ? launch_px<true>(s, a) : launch_px<false>(s, a);
     if (kp == 4 && px32_ok(a, mode)) return a.W8 ? launch_px32<true>(s, a) : launch_px32<false>(s, a);
+    if (hpx_ok(a, mode)) return launch_hpx(s, a);
     if (a.W8) {          // fp8 weight stream (decode of the quantised LM linears); the in-block K split is always 4 there
         if (!a.w_scale || mode == GV_F32) return -22;
         if (kp != 4) return -22;

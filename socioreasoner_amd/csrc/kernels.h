@@ -18,8 +18,9 @@ struct SrSwitches {
     int attn_vasm;      // SR_ATTN_VASM   0: V^T fragment reads of k_attn_prefill2 left to the compiler (ds_read2st64_b64, 2-way bank conflicts; default 1: hand-issued ds_read_b64)
     int sam_f32_split;  // SR_SAM_F32_SPLIT 0: SAM2's float32 GEMM on the f32-input MFMA (round 4) instead of the three-term bf16 split on the bf16 pipe (default 1)
     int gemv_xlds;      // SR_GEMV_XLDS   bit 0: the 17..32-row gate/up GEMV keeps its activations in registers in a persistent launch (k_gemv_px), bit 1: so does the split-K
-                        //                 down-projection (k_gemv32_px) -- in the engine's decode step on a CU-limited stream only (sr_rows_set_cus), bit 2: on the whole chip too;
-                        //                 0: both re-read x from L2 in every wave (rounds 2-5).  Round 6, default 3; bit-identical: A/B + test hook
+                        //                 down-projection (k_gemv32_px), bit 3: the LM head keeps them in LDS (k_gemv32_hpx) -- in the engine's decode step on a CU-limited stream
+                        //                 only (sr_rows_set_cus), bit 2: on the whole chip too; 0: all re-read x from L2 in every wave (rounds 2-5).  Round 6, default 11;
+                        //                 bit-identical: A/B + test hook
     int gemv_counted;   // SR_GEMV_COUNTED 0: the <= 32-row decode GEMVs use the conditional-refill ring loops of rounds 1-4 (vmcnt(0) every round) instead of the
                         //                 unconditional refills with counted vmcnt waits (default 1; bit-identical: A/B + test hook)
 };

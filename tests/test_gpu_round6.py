@@ -205,7 +205,7 @@ def test_x_resident_gate_up_in_the_decode_step(monkeypatch, size, fp8):
     rng = np.random.default_rng(67)
     ids, pos = _prompts(rng, 32, vocab=vocab)
     out = {}
-    for flag in ("0", "1", "3", "7"):
+    for flag in ("0", "1", "3", "7", "11", "15"):
         switch(monkeypatch, "SR_GEMV_XLDS", flag)
         e = Engine(geom, max_patches=64, max_prefill_tokens=64 * 32, max_batch=32, max_ctx=128, max_new_tokens=16, lm_fp8=fp8)
         e.load_synthetic_weights(seed=0)
@@ -213,7 +213,8 @@ def test_x_resident_gate_up_in_the_decode_step(monkeypatch, size, fp8):
         for B in (16, 17, 32):
             # the CU hint switches the step to its x-stationary form (bits 0 / 1: gate/up / down-projection; bit 2: that form on the whole chip too) and sets the deal
             # of the down-projection's tiles -- never a bit of the result
-            for cus in {"0": (0,), "1": (0, 160), "3": (0, 160, 37), "7": (0,)}[flag]:
+            # bit 3: the LM head with x resident in LDS (hidden size 2048 only: the "3b" cases)
+            for cus in {"0": (0,), "1": (0, 160), "3": (0, 160, 37), "7": (0,), "11": (0, 160, 37), "15": (0,)}[flag]:
                 e.rows_set_cus(cus)
                 e.prefill(ids[:B], pos[:B])
                 toks, tr = e.decode(10, trace=True, use_graph=False)
@@ -226,7 +227,7 @@ def test_x_resident_gate_up_in_the_decode_step(monkeypatch, size, fp8):
                     res.append((toks.clone(), tr.clone()))
         out[flag] = res
         e.close()
-    for flag in ("1", "3", "7"):
+    for flag in ("1", "3", "7", "11", "15"):
         for (t0, r0), (t1, r1) in zip(out["0"], out[flag]):
             assert torch.equal(t0, t1)
             assert torch.equal(r0, r1), float((r0 - r1).abs().max())
@@ -291,3 +292,44 @@ def test_x_stationary_split_k_gemv_equals_the_streaming_kernel(monkeypatch, M, N
     for a, b in zip(outs8["0"], outs8["3"]):
         assert torch.equal(a, b), float((a - b).abs().max())
     assert float((outs8["3"][0].sum(0) - ref).abs().max()) <= 8e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N", [(32, 151936), (17, 151936), (25, 4096 + 96)])
+def test_lm_head_with_x_in_lds_equals_the_streaming_kernel(monkeypatch, M, N):
+    """k_gemv32_hpx (round 6): the 17..32-row LM head on a CU-limited stream -- x copied to LDS once per block (LDS-DMA), 4 waves walking groups of 4 vocabulary tiles,
+    the weights through an 8-slot ring refilled across tile boundaries, groups dealt statically to the hinted CU count.  One wave still sums all 32 chunks of a tile in
+    order, so the float32 logits AND the per-group arg-max partials equal the streaming kernel's bit for bit -- the full vocabulary, a vocabulary whose last group is
+    partial (131 tiles), ragged rows, every CU hint, ordinary and CU-masked streams."""
+    import ctypes as C
+    from socioreasoner_amd import lib, streams
+    L = lib.load()
+    P = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+    K = 2048
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(32, K, generator=g).to(torch.bfloat16)
+    x[M:] = 0
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    xt, wt = _tile16x64(x).cuda().contiguous(), _tile16x64(w).cuda().contiguous()
+    nb = L.sr_op_gemv_f32_blocks(N, M, K, 0)
+    outs = {}
+    for flag in ("0", "11"):
+        switch(monkeypatch, "SR_GEMV_XLDS", flag)
+        res = []
+        for stream in (torch.cuda.current_stream(), streams.masked_stream("cuda:0", 0, 5)):
+            with torch.cuda.stream(stream):
+                sp = C.c_void_p(stream.cuda_stream)
+                for cus in (0, 160, 7, 1000):
+                    assert L.sr_op_gemv_set_cus(cus, sp) == 0
+                    o = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+                    av = torch.full((M, nb), float("nan"), dtype=torch.float32, device="cuda")
+                    ai = torch.full((M, nb), -1, dtype=torch.int32, device="cuda")
+                    assert L.sr_op_gemv_fused(P(xt), K, P(wt), M, N, K, P(o), N, 2 | 0x100 | 0x800, None, None, C.c_float(0), None, 0, None, P(av), P(ai), sp) == 0
+                    stream.synchronize()
+                    res += [o.cpu().clone(), av.cpu().clone(), ai.cpu().clone()]
+                assert L.sr_op_gemv_set_cus(0, sp) == 0
+        outs[flag] = res
+    for a, b in zip(outs["0"], outs["11"]):
+        assert torch.equal(a, b)
+    ref = x[:M].float() @ w.float().T
+    assert float((outs["11"][0] - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    assert torch.equal(outs["11"][2].long().gather(1, outs["11"][1].argmax(1, keepdim=True)).squeeze(1), outs["11"][0].argmax(1))
