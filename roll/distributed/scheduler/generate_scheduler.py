@@ -118,11 +118,79 @@ class GenerateScheduler:
                     worker.stop_server()
                     raise TimeoutError(f"{B - len(self.results)} of {B} generation requests did not complete")
             worker.stop_server()
-        pad = worker.tokenizer.pad_token_id
         rows = [self.results[i] for i in range(B)]                      # re-sorted by prompt id (reference :293-294)
-        output_ids = hostops.gather_outputs_to_pad_tensor(rows, pad, device=data.batch["input_ids"].device)
-        seq = hostops.concatenate_input_and_output(data.batch["input_ids"], output_ids, 1)
-        out = hostops.postprocess_generate(prompts=data.batch, output=seq, num_return_sequences=1,
-                                           sequence_length=int(pipeline_config.sequence_length),
-                                           eos_token_id=worker.tokenizer.eos_token_id, pad_token_id=pad)
-        return DataProto(batch=out, meta_info={"metrics": {}})
+        return assemble_responses(data, rows, worker, pipeline_config)
+
+    def open_stream(self, actor_cluster, pipeline_config) -> "RequestStream":
+        """The request loop of level 1 kept OPEN across several batches of prompts (round 6; no reference counterpart -- the reference's two stages are
+        two generate calls with the host flow between them): the two-stage pipeline adds stage-2 prompts while stage-1 prompts of other samples are
+        still decoding, so the engine's rows never drain between the stages and the host flow runs under generation."""
+        worker = actor_cluster
+        gc = dict(worker.worker_config.generating_args or {})
+        gc["num_return_sequences"] = 1
+        gc.setdefault("max_new_tokens", int(pipeline_config.response_length))
+        self.round += 1
+        return RequestStream(worker, gc, float(pipeline_config.get("rpc_timeout") or 3600))
+
+
+def assemble_responses(data: DataProto, rows: List[List[int]], worker, pipeline_config) -> DataProto:
+    """token lists of the prompts of `data` (in its row order) -> the reference's 7 output tensors (postprocess_generate, reference :293-334)"""
+    pad = worker.tokenizer.pad_token_id
+    output_ids = hostops.gather_outputs_to_pad_tensor(rows, pad, device=data.batch["input_ids"].device)
+    seq = hostops.concatenate_input_and_output(data.batch["input_ids"], output_ids, 1)
+    out = hostops.postprocess_generate(prompts=data.batch, output=seq, num_return_sequences=1,
+                                       sequence_length=int(pipeline_config.sequence_length),
+                                       eos_token_id=worker.tokenizer.eos_token_id, pad_token_id=pad)
+    return DataProto(batch=out, meta_info={"metrics": {}})
+
+
+class RequestStream:
+    """One generation server (ActorWorker.start_server: the strategy's request loop on its own thread) with requests added and answers collected while
+    it runs.  `add` hands it one prompt row under a caller-chosen id, `collect` blocks for the next finished request(s)."""
+
+    def __init__(self, worker, gc: Dict, timeout_s: float):
+        import queue
+        import time
+        self.worker, self.gc = worker, gc
+        self.answers: "queue.Queue" = queue.Queue()
+        self.in_flight = 0
+        self.deadline = time.monotonic() + timeout_s
+        worker.start_server(DataProto(meta_info={}), request_complete_callback=self._report)
+
+    def _report(self, data: DataProto):
+        self.answers.put((int(data.meta_info["request_id"]), data.meta_info["output_token_ids"][0]))
+
+    def add(self, request_ids: List[int], data: DataProto) -> None:
+        """the rows of `data` as one request each.  The requests are built first and queued in one go: the server thread takes commands as fast as
+        they arrive and starts its first admission when it finds the queue empty -- a producer slower than that would split its burst over several
+        small admissions"""
+        reqs = [DataProto(batch={k: v[i:i + 1] for k, v in data.batch.items()}, non_tensor_batch={k: v[i:i + 1] for k, v in data.non_tensor_batch.items()},
+                          meta_info={"request_id": int(rid), "generation_config": dict(self.gc)}) for i, rid in enumerate(request_ids)]
+        self.in_flight += len(reqs)
+        for req in reqs:
+            self.worker.add_request(GenerateRequestType.ADD, req)
+
+    def collect(self, linger_s: float = 0.003) -> List[tuple]:
+        """[(request id, tokens)] of the requests that have finished: waits for the first, then takes what arrives within `linger_s` of each other
+        (rows that end in the same decode step are reported one after the other by the server thread)"""
+        import queue
+        import time
+        got = []
+        while not got:
+            try:
+                got.append(self.answers.get(timeout=0.2))
+            except queue.Empty:
+                self.worker.add_request(GenerateRequestType.ALIVE_CHECK)         # raises if the server thread died
+                if time.monotonic() > self.deadline:
+                    self.close()
+                    raise TimeoutError(f"{self.in_flight} generation requests did not complete")
+        while True:
+            try:
+                got.append(self.answers.get(timeout=linger_s))
+            except queue.Empty:
+                break
+        self.in_flight -= len(got)
+        return got
+
+    def close(self) -> None:
+        self.worker.stop_server()

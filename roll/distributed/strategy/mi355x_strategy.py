@@ -14,8 +14,10 @@ made by socioreasoner_amd.sampling on the device-resident logits.
 """
 from __future__ import annotations
 
+import contextlib
 import logging
 import queue
+import time
 from typing import Dict, List
 
 import numpy as np
@@ -51,6 +53,7 @@ def _get(obj, name, default=None):
 
 class Mi355xStrategy(InferenceStrategy):
     strategy_name = "mi355x"
+    request_stream = True      # start_server may stay open while prompts keep arriving (GenerateScheduler.open_stream; the two-stage pipeline's streamed mode)
 
     def __init__(self, worker):
         super().__init__(worker)
@@ -249,9 +252,16 @@ class Mi355xStrategy(InferenceStrategy):
         return collate_fn_to_dict_list(results)
 
     # ------------------------------------------------------------------ generate
-    def _prepare(self, ids: List[int], images) -> tuple:
-        """-> (expanded ids np.int64, pos3 [3,S], list of uint8 HWC cuda images, grids)"""
+    def _prepare(self, ids: List[int], images, side_stream: bool = False) -> tuple:
+        """-> (expanded ids np.int64, pos3 [3,S], list of uint8 HWC cuda images, grids).  side_stream: host images are uploaded on a stream of their
+        own instead of the caller's current (usually the null) stream -- next to a running request loop a null-stream copy would wait for everything the
+        scheduler's CU-masked streams have queued (they are blocking streams); the copy is synchronous for the host either way."""
         g = self.geom
+        up = contextlib.nullcontext()
+        if side_stream and torch.cuda.is_available():
+            if getattr(self, "_upload_stream", None) is None:
+                self._upload_stream = torch.cuda.Stream(self.engine.device if getattr(self, "engine", None) is not None else None)
+            up = torch.cuda.stream(self._upload_stream)
         f = g.vision.patch_size * g.vision.spatial_merge_size
         ims, grids = [], []
         for im in images or []:
@@ -269,7 +279,8 @@ class Mi355xStrategy(InferenceStrategy):
             if (rh, rw) != (h, w):
                 from PIL import Image
                 arr = np.asarray(Image.fromarray(arr).resize((rw, rh), resample=Image.BICUBIC))
-            ims.append(torch.from_numpy(np.array(arr, dtype=np.uint8, order="C")).cuda())
+            with up:
+                ims.append(torch.from_numpy(np.array(arr, dtype=np.uint8, order="C")).cuda())
             grids.append((1, rh // g.vision.patch_size, rw // g.vision.patch_size))
         ids = np.asarray(ids, dtype=np.int64)
         n_pad = int((ids == g.image_token_id).sum())
@@ -414,6 +425,19 @@ class Mi355xStrategy(InferenceStrategy):
 
     # ------------------------------------------------------------------ request-level serving (generate_opt_level 1)
     def add_request(self, command, data: DataProto):
+        if getattr(command, "name", command) == "ADD" and data is not None and data.batch is not None and getattr(self, "engine", None) is not None:
+            # the host side of a request (image resize + upload, placeholder expansion, rope index: ~1 ms) is done HERE, on the caller's thread, not
+            # between two scheduling rounds of the request loop
+            try:
+                mm = data.non_tensor_batch.get("multi_modal_data") if data.non_tensor_batch else None
+                ids_in = hostops.gather_unpadded_input_ids(data.batch["input_ids"].cpu(), data.batch["attention_mask"].cpu())[0]
+                if mm is not None and mm[0].get("prompt_token_ids"):
+                    ids_in = mm[0]["prompt_token_ids"]
+                imgs = (mm[0].get("multi_modal_data") or {}).get("image") if mm is not None else None
+                data.meta_info["_prepared"] = self._prepare(ids_in, imgs, side_stream=True)
+            except Exception as e:  # noqa: BLE001  (the request loop prepares it again and raises where the reference's loop would)
+                data.meta_info.pop("_prepared", None)
+                logger.debug("request preparation deferred to the request loop: %s", e)
         self.command_queue.put((command, data))
 
     def start_server(self, data: DataProto, request_complete_callback):
@@ -427,54 +451,76 @@ class Mi355xStrategy(InferenceStrategy):
         batcher, bkey = None, None
         sampled: List[DataProto] = []
         stop = False
+        last_cmd = 0.0
         while True:
             busy = batcher is not None and not batcher.idle()
             try:
                 command, req = self.command_queue.get(timeout=0.0005 if busy or sampled else 0.01)
             except queue.Empty:
                 command, req = None, None
-            name = getattr(command, "name", command)
-            if name == "ADD":
-                gc = dict(req.meta_info.get("generation_config") or {})
-                rp1 = float(gc.get("repetition_penalty", 1.0) or 1.0) == 1.0
-                greedy = sampling.is_greedy(gc)
-                tk = gc.get("top_k", -1)
-                tk = -1 if tk is None else int(tk)
-                dev_sampling = not greedy and tk <= 1024 and float(gc.get("temperature", 1.0)) > 1e-5
-                rows_ok = hasattr(self.engine, "rows_begin") and rp1 and (greedy or dev_sampling) and int(gc.get("num_return_sequences", 1) or 1) == 1
-                if not rows_ok:
-                    sampled.append(req)
-                else:
-                    eos = gc.get("eos_token_id") or [self.tokenizer.eos_token_id]
-                    eos = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos])]
-                    pad = int(gc.get("pad_token_id", self.tokenizer.pad_token_id))
-                    smp = None if greedy else {"temperature": float(gc.get("temperature", 1.0)), "top_k": int(tk),
-                                               "top_p": float(gc.get("top_p", 1.0) or 1.0), "seed": int(gc.get("seed", 0) or 0)}
-                    key = (tuple(eos), pad, None if smp is None else tuple(sorted(smp.items())))
-                    if batcher is None or (key != bkey and batcher.idle()):
-                        batcher, bkey = ContinuousBatcher(self.engine, eos, pad, sampling=smp, overlap=self.overlap), key
-                    if key != bkey:
-                        sampled.append(req)          # different stop set / sampling parameters while rows are running: static path
+            # every queued command is taken before the next scheduling round: at one command per round a burst of ADDs -- the two-stage pipeline's
+            # stage-2 prompts of a wave that has just finished -- would trickle into the scheduler one request per steps_per_poll decode steps
+            taken = 0
+            while command is not None or taken == 0:
+                taken += 1
+                name = getattr(command, "name", command)
+                if name == "ADD":
+                    gc = dict(req.meta_info.get("generation_config") or {})
+                    rp1 = float(gc.get("repetition_penalty", 1.0) or 1.0) == 1.0
+                    greedy = sampling.is_greedy(gc)
+                    tk = gc.get("top_k", -1)
+                    tk = -1 if tk is None else int(tk)
+                    dev_sampling = not greedy and tk <= 1024 and float(gc.get("temperature", 1.0)) > 1e-5
+                    rows_ok = hasattr(self.engine, "rows_begin") and rp1 and (greedy or dev_sampling) and int(gc.get("num_return_sequences", 1) or 1) == 1
+                    if not rows_ok:
+                        sampled.append(req)
                     else:
-                        mm = req.non_tensor_batch.get("multi_modal_data") if req.non_tensor_batch else None
-                        ids_in = hostops.gather_unpadded_input_ids(req.batch["input_ids"].cpu(), req.batch["attention_mask"].cpu())[0]
-                        if mm is not None and mm[0].get("prompt_token_ids"):
-                            ids_in = mm[0]["prompt_token_ids"]
-                        imgs = (mm[0].get("multi_modal_data") or {}).get("image") if mm is not None else None
-                        ids, pos3, ims, grids = self._prepare(ids_in, imgs)
-                        room = self.engine.cfg.max_ctx - len(ids)
-                        if room < 1:
-                            raise ValueError(f"prompt of {len(ids)} tokens leaves no room in max_ctx {self.engine.cfg.max_ctx}")
-                        max_new = max(1, min(int(gc["max_new_tokens"]), self.engine.cfg.max_new_tokens, room))
-                        batcher.submit(Request(ids=ids, pos3=pos3, max_new=max_new, images=ims, grids=grids, tag=req))
-            elif name == "ABORT":
-                rid = req.meta_info["request_id"]
-                sampled = [p for p in sampled if p.meta_info.get("request_id") != rid]
-                if batcher is not None:      # queued requests are dropped, running rows stop now and free row + KV slot at the next poll
-                    batcher.abort(lambda r: r.tag.meta_info.get("request_id") == rid)
-            elif name == "STOP":
-                stop = True
-            if batcher is not None and not batcher.idle() and (self.command_queue.empty() or len(batcher.active) > 0):
+                        eos = gc.get("eos_token_id") or [self.tokenizer.eos_token_id]
+                        eos = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos])]
+                        pad = int(gc.get("pad_token_id", self.tokenizer.pad_token_id))
+                        smp = None if greedy else {"temperature": float(gc.get("temperature", 1.0)), "top_k": int(tk),
+                                                   "top_p": float(gc.get("top_p", 1.0) or 1.0),
+                                                   "seed": int(gc.get("seed", 0) or 0) * 1000003 + 7919 * int(getattr(self.worker, "rank", 0) or 0)}      # (as generate())
+                        key = (tuple(eos), pad, None if smp is None else tuple(sorted(smp.items())))
+                        if batcher is None or (key != bkey and batcher.idle()):
+                            batcher, bkey = ContinuousBatcher(self.engine, eos, pad, sampling=smp, overlap=self.overlap), key
+                        if key != bkey:
+                            sampled.append(req)          # different stop set / sampling parameters while rows are running: static path
+                        else:
+                            if req.meta_info.get("_prepared") is not None:          # done by add_request on the caller's thread
+                                ids, pos3, ims, grids = req.meta_info.pop("_prepared")
+                            else:
+                                mm = req.non_tensor_batch.get("multi_modal_data") if req.non_tensor_batch else None
+                                ids_in = hostops.gather_unpadded_input_ids(req.batch["input_ids"].cpu(), req.batch["attention_mask"].cpu())[0]
+                                if mm is not None and mm[0].get("prompt_token_ids"):
+                                    ids_in = mm[0]["prompt_token_ids"]
+                                imgs = (mm[0].get("multi_modal_data") or {}).get("image") if mm is not None else None
+                                ids, pos3, ims, grids = self._prepare(ids_in, imgs)
+                            room = self.engine.cfg.max_ctx - len(ids)
+                            if room < 1:
+                                raise ValueError(f"prompt of {len(ids)} tokens leaves no room in max_ctx {self.engine.cfg.max_ctx}")
+                            max_new = max(1, min(int(gc["max_new_tokens"]), self.engine.cfg.max_new_tokens, room))
+                            batcher.submit(Request(ids=ids, pos3=pos3, max_new=max_new, images=ims, grids=grids, tag=req))
+                elif name == "ABORT":
+                    rid = req.meta_info["request_id"]
+                    sampled = [p for p in sampled if p.meta_info.get("request_id") != rid]
+                    if batcher is not None:      # queued requests are dropped, running rows stop now and free row + KV slot at the next poll
+                        batcher.abort(lambda r: r.tag.meta_info.get("request_id") == rid)
+                elif name == "STOP":
+                    stop = True
+                if command is None or taken >= 1024:
+                    break
+                try:
+                    command, req = self.command_queue.get_nowait()
+                except queue.Empty:
+                    break
+            if taken > 1 or command is not None:
+                last_cmd = time.monotonic()
+            # with no rows running, a first admission of a few requests would leave the rest of a burst that is still arriving (one ADD per ~1 ms of the
+            # producer's preparation) waiting for a whole admission: the loop waits until a full group is pending or nothing has arrived for 5 ms
+            filling = (batcher is not None and not batcher.active and batcher.staged is None and 0 < len(batcher.pending) < self.max_batch
+                       and not stop and time.monotonic() - last_cmd < 0.005)
+            if batcher is not None and not batcher.idle() and not filling and (self.command_queue.empty() or len(batcher.active) > 0):
                 def done(r, toks):
                     if r.aborted:
                         return
@@ -498,6 +544,10 @@ class Mi355xStrategy(InferenceStrategy):
                         request_complete_callback(data=res)
             if stop and (batcher is None or batcher.idle()) and not sampled:
                 self.running = False
+                if batcher is not None and hasattr(self, "gen_stats"):      # (as generate(): what the scheduler did while this server was open)
+                    self.gen_stats.append({"requests": batcher.stats["admitted"], "served_as": "request stream",
+                                           **{k: (round(v, 1) if isinstance(v, float) else v) for k, v in batcher.stats.items()
+                                              if k in ("steps", "steps_shared", "admissions", "rounds", "host_ms", "poll_wait_ms", "shares", "share_model")}})
                 return
 
 
@@ -521,22 +571,26 @@ class SegRasterStrategy(InferenceStrategy):
         """image.resize((756, 756)) (seg_strategy.py:44), remembered per image OBJECT: the second stage segments the image the first stage did
         (3.7 ms of PIL bicubic per call)."""
         from collections import OrderedDict
+        import threading
         memo = self.__dict__.setdefault("_r756", OrderedDict())
-        hit = memo.get(id(image))
-        if hit is not None and hit[0] is image:
-            memo.move_to_end(id(image))
-            return hit[1]
+        lock = self.__dict__.setdefault("_r756_lock", threading.Lock())      # (the prefetch thread resizes too)
+        with lock:
+            hit = memo.get(id(image))
+            if hit is not None and hit[0] is image:
+                memo.move_to_end(id(image))
+                return hit[1]
         r = image.resize((756, 756))
-        memo[id(image)] = (image, r)
-        while len(memo) > 1024:
-            memo.popitem(last=False)
+        with lock:
+            memo[id(image)] = (image, r)
+            while len(memo) > 1024:
+                memo.popitem(last=False)
         return r
 
-    def prefetch(self, images) -> None:
+    def prefetch(self, images, chunk=None) -> None:
         """Round 6: start SAM2's image encoder on these images in the background (socioreasoner_amd.sam2.Sam2Predictor.prefetch); `segment` later finds
         the embeddings cached.  Predictors without `prefetch` (the reference's SAM2ImagePredictor) ignore the hint."""
         if self.model is not None and hasattr(self.model, "prefetch"):
-            self.model.prefetch([self._resized(im) for im in images])
+            self.model.prefetch(list(images), prepare=self._resized, chunk=chunk)      # (the 756 x 756 resize, 3.7 ms per image, on the prefetch thread as well)
 
     def segment(self, batch: DataProto) -> dict:
         images, prompts = list(batch.non_tensor_batch["seg_image"]), list(batch.non_tensor_batch["visual_prompt"])

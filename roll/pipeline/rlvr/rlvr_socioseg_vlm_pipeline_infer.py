@@ -18,6 +18,7 @@ The batch keys, the order of operations and the files written follow the referen
 """
 from __future__ import annotations
 
+import contextlib
 import json
 import os
 from collections import defaultdict
@@ -346,6 +347,148 @@ class SocioSegInferPipeline(BasePipeline):
         sat["bboxs_text"] = _obj(bboxs_text_list)
         return DataProto.from_single_dict(sat)
 
+    # ---- the host flow behind the two generations, for any set of samples: a whole rollout batch, or -- streamed mode -- the samples whose requests
+    #      have just finished
+    def _after_stage1(self, batch: DataProto, out: DataProto, n_ret: int, lap, dirs, writers, pending) -> DataProto:
+        """stage-1 responses -> masks -> stage-1 files -> the stage-2 generation batch (reference :645-836).  `batch` is updated in place."""
+        out.rename(["input_ids", "attention_mask", "position_ids", "responses", "response_mask", "prompts", "prompt_mask"],
+                   ["map_input_ids", "map_attention_mask", "map_position_ids", "map_responses", "map_response_mask", "map_prompts", "map_prompt_mask"])
+        out.batch.pop("prompt_id", None)
+        for k, v in batch.non_tensor_batch.items():
+            batch.non_tensor_batch[k] = np.repeat(v, n_ret)
+        batch.batch = out.batch
+        # ---- stage-1 masks: responses -> SAM prompts -> union / nearest resize on the device
+        seg_batch = batch.pop(batch_keys=["map_responses", "map_prompts"], non_tensor_batch_keys=["seg_image"])
+        seg_out = self.seg_infer.segment_v4_map(seg_batch)
+        lap("segment_stage1")
+        batch = batch.union(seg_out)
+        batch.non_tensor_batch["map_mask"] = batch.non_tensor_batch.pop("mask")
+        batch.non_tensor_batch["map_visual_prompt"] = batch.non_tensor_batch.pop("visual_prompt")
+        batch.non_tensor_batch.pop("response_text")
+        # ---- stage 2: render stage 1 onto both images, re-prompt with the boxes found
+        map_response_list = self.tokenizer.batch_decode(batch.batch["map_responses"], skip_special_tokens=False)
+        bboxs_text_list = [parse_points_text_from_content(r) for r in map_response_list]
+        # stage 1's files exist from here on: they are rendered (device overlay, this thread) and handed to the writer pool NOW, so that their PNG
+        # encoding runs under stage 2's generation instead of after it (same files, same contents as the reference's write at the end of the batch)
+        from PIL import Image
+        nt1 = batch.non_tensor_batch
+        for i in range(len(batch)):
+            vp1 = nt1["map_visual_prompt"][i][0] if len(nt1["map_visual_prompt"][i]) else {}
+            r1 = draw_visual_prompt(nt1["seg_image"][i], nt1["map_mask"][i], vp1)
+
+            def write1(sid=nt1["id"][i], m1=nt1["map_mask"][i], r1=r1, t1=map_response_list[i]):
+                Image.fromarray(m1.astype(np.uint8) * 255).save(os.path.join(dirs["stage1"], f"{sid}.png"))
+                r1.save(os.path.join(dirs["render1"], f"{sid}.png"))
+                with open(os.path.join(dirs["stage1"], f"{sid}.txt"), "w") as f:
+                    f.write(t1)
+            pending.append(writers.submit(write1))
+        batch = batch.union(self._stage2_batch(batch, bboxs_text_list))
+        gen_batch = batch.pop(batch_keys=["input_ids", "attention_mask", "position_ids"], non_tensor_batch_keys=["multi_modal_sat_data"])
+        gen_batch.non_tensor_batch["multi_modal_data"] = gen_batch.non_tensor_batch.pop("multi_modal_sat_data")
+        lap("stage2_prompts")
+        return gen_batch
+
+    def _after_stage2(self, batch: DataProto, out: DataProto, lap, dirs, writers, pending) -> List[float]:
+        """stage-2 responses -> masks -> IoU against the ground truth, stage-2 files (reference :853-905)"""
+        from PIL import Image
+        out.batch.pop("prompt_id", None)
+        batch = batch.union(out)
+        seg_batch = batch.pop(batch_keys=["responses", "prompts"], non_tensor_batch_keys=["seg_image"])
+        seg_out = self.seg_infer.segment_v4_sat(seg_batch)
+        lap("segment_stage2")
+        seg_out.meta_info.pop("metrics", None)
+        batch = batch.union(seg_out)
+        batch.non_tensor_batch["sat_mask"] = batch.non_tensor_batch.pop("mask")
+        batch.non_tensor_batch["sat_visual_prompt"] = batch.non_tensor_batch.pop("visual_prompt")
+        # ---- score and write
+        sat_response_list = self.tokenizer.batch_decode(batch.batch["responses"], skip_special_tokens=False)
+        nt = batch.non_tensor_batch
+        giou_list = []
+        for i in range(len(batch)):
+            gt_mask = np.array(nt["gt_mask"][i].convert("L"))
+            giou_list.append(compute_giou(nt["sat_mask"][i], gt_mask))
+            vp2 = nt["sat_visual_prompt"][i][0] if len(nt["sat_visual_prompt"][i]) else {}
+            sid = nt["id"][i]
+            # the overlays run on the device from THIS thread (the HIP current device is per thread); the pool only encodes and writes
+            r2 = draw_visual_prompt(nt["seg_image"][i], nt["sat_mask"][i], vp2)
+
+            def write(sid=sid, m2=nt["sat_mask"][i], r2=r2, t2=sat_response_list[i]):
+                Image.fromarray(m2.astype(np.uint8) * 255).save(os.path.join(dirs["stage2"], f"{sid}.png"))
+                r2.save(os.path.join(dirs["render2"], f"{sid}.png"))
+                with open(os.path.join(dirs["stage2"], f"{sid}.txt"), "w") as f:
+                    f.write(t2)
+            pending.append(writers.submit(write))
+        lap("score_and_write")
+        return giou_list
+
+    def _streamed(self, n_ret: int) -> bool:
+        """Streamed mode (round 6): the two stages of a rollout batch share ONE open request stream on the engine -- a sample's stage-2 prompt is
+        added as soon as ITS stage-1 answer has been segmented and rendered, while other samples are still in stage 1 -- so the engine's batch rows
+        never drain between the stages and the host flow (SAM2 decoding, rendering, prompt building, scoring, file encoding) runs under generation
+        instead of between the two generate calls.  Per sample the operations, their order and the files are those of the batch flow.
+        Needs a strategy whose request loop can stay open (`request_stream`); SOCIOSEG_STREAM=0 restores the reference's batch-by-batch order.
+        Not with n > 1 sequences per prompt, nor with request-level dispatch across ranks (generate_opt_level >= 1 and more than one rank: that exchange
+        is collective per generate call)."""
+        if os.environ.get("SOCIOSEG_STREAM", "1") == "0" or n_ret != 1:
+            return False
+        if int(self.pipeline_config.get("generate_opt_level") or 0) >= 1 and self.world > 1:
+            return False
+        st = getattr(self.actor_infer, "strategy", None)
+        return bool(getattr(st, "request_stream", False)) and hasattr(self.actor_infer, "start_server")
+
+    @staticmethod
+    def _rows(data: DataProto, idx: List[int]) -> DataProto:
+        ix = np.asarray(idx, dtype=np.int64)
+        return DataProto(batch={k: v[torch.from_numpy(ix)] for k, v in (data.batch or {}).items()},
+                         non_tensor_batch={k: v[ix] for k, v in data.non_tensor_batch.items()}, meta_info=dict(data.meta_info))
+
+    def _run_batch_streamed(self, batch: DataProto, gen_batch: DataProto, lap, dirs, writers, pending) -> List[float]:
+        from roll.distributed.scheduler.generate_scheduler import assemble_responses
+        B = len(batch)
+        host_stream = None
+        if torch.cuda.is_available():
+            # this thread's device work (SAM2 decoder, raster kernels, render) runs next to the engine's: on a stream of its own, not on the null
+            # stream, which would serialise with the scheduler's CU-masked (blocking) streams
+            # -- a HIGH-PRIORITY one: SAM2's decoder is ~110 dependent launches of a few microseconds per sample, and behind the engine's GEMM grids
+            # each of them would wait for a free CU at normal priority (measured: 18 ms per sample instead of 2.6 ms on an idle GPU)
+            if getattr(self, "_host_stream", None) is None:
+                self._host_stream = torch.cuda.Stream(priority=-1)
+            host_stream = self._host_stream
+        stream = self.generate_scheduler.open_stream(self.actor_infer, self.pipeline_config)
+        try:
+            stream.add(list(range(B)), gen_batch)                     # request ids 0 .. B - 1: stage 1; B .. 2B - 1: stage 2 of sample id - B
+            lap("generate_stage1")
+            state: Dict[int, DataProto] = {}                             # sample -> its one-row batch after stage 1
+            gen2_rows: Dict[int, DataProto] = {}                         # sample -> its stage-2 prompt row
+            giou: Dict[int, float] = {}
+            while len(giou) < B:
+                got = stream.collect()
+                lap("generate_wait")
+                s1 = sorted((rid, toks) for rid, toks in got if rid < B)
+                s2 = sorted((rid - B, toks) for rid, toks in got if rid >= B)
+                with (torch.cuda.stream(host_stream) if host_stream is not None else contextlib.nullcontext()):
+                    if s1:
+                        idx = [i for i, _ in s1]
+                        sub, gsub = self._rows(batch, idx), self._rows(gen_batch, idx)
+                        out = assemble_responses(gsub, [t for _, t in s1], self.actor_infer, self.pipeline_config)
+                        gen2 = self._after_stage1(sub, out, 1, lap, dirs, writers, pending)
+                        if host_stream is not None:
+                            host_stream.synchronize()                    # the rendered pairs are read by the engine's streams (another thread)
+                        stream.add([B + i for i in idx], gen2)
+                        for k, i in enumerate(idx):
+                            state[i], gen2_rows[i] = self._rows(sub, [k]), self._rows(gen2, [k])
+                        lap("stage2_prompts")
+                    if s2:
+                        idx = [i for i, _ in s2]
+                        sub = DataProto.concat([state.pop(i) for i in idx])
+                        gsub = DataProto.concat([gen2_rows.pop(i) for i in idx])
+                        out = assemble_responses(gsub, [t for _, t in s2], self.actor_infer, self.pipeline_config)
+                        for i, g_ in zip(idx, self._after_stage2(sub, out, lap, dirs, writers, pending)):
+                            giou[i] = g_
+        finally:
+            stream.close()
+        return [giou[i] for i in range(B)]
+
     @torch.no_grad()
     def run(self):
         cfg = self.pipeline_config
@@ -358,7 +501,10 @@ class SocioSegInferPipeline(BasePipeline):
         global_step = 0
         import time as _time
         from concurrent.futures import ThreadPoolExecutor
+        self.streamed = self._streamed(n_ret)
         self.timing = {k: 0.0 for k in ("collate", "generate_stage1", "segment_stage1", "stage2_prompts", "generate_stage2", "segment_stage2", "score_and_write")}
+        if self.streamed:       # the generations run under the other phases: what is left of them on this thread is the wait for the next finished request
+            self.timing["generate_wait"] = 0.0
         clock = [_time.perf_counter()]
 
         def lap(name):          # wall time since the previous lap (the reference times generate / seg with _Timer: ...infer.py:625-704)
@@ -369,7 +515,20 @@ class SocioSegInferPipeline(BasePipeline):
         # the files are written by a small pool while the next batch generates; run() returns after the last one is on disk
         writers = ThreadPoolExecutor(max_workers=int(os.environ.get("SOCIOSEG_WRITERS", 8)))
         pending = []
-        for batch_dict in get_dataloader(self.dataset, self.batch_size, self.data_collator):
+        prefetch = os.environ.get("SOCIOSEG_SAM_PREFETCH", "1") != "0" and hasattr(self.seg_infer, "prefetch_images")
+        loader = get_dataloader(self.dataset, self.batch_size, self.data_collator)          # (in dataset order: batch k = samples k * batch_size ...)
+        import sys
+        switch = sys.getswitchinterval()
+        if self.streamed:
+            # three Python threads share the interpreter in streamed mode (this one, the request loop, SAM2's prefetch): the request loop needs it for
+            # ~1.5 ms between two chunks of decode steps, and every 5 ms (the default switch interval) it waits for it is a chunk the GPU starts late
+            sys.setswitchinterval(0.0005)
+        for b0 in range(0, len(self.dataset["id"]), self.batch_size):
+            if prefetch:
+                # SAM2's set_image needs only the pixels (seg_strategy.py:47-58): its encoder starts now, under the collation of the batch and the
+                # LM's stage-1 generation
+                self.seg_infer.prefetch_images(list(self.dataset["seg_image"][b0:b0 + self.batch_size]))
+            batch_dict = next(loader)
             lap("collate")
             self.model_update(global_step)
             batch = DataProto.from_single_dict(batch_dict)
@@ -378,83 +537,25 @@ class SocioSegInferPipeline(BasePipeline):
             gen_batch = batch.pop(batch_keys=["map_input_ids", "map_attention_mask", "map_position_ids"], non_tensor_batch_keys=["multi_modal_map_data"])
             gen_batch.rename(["map_input_ids", "map_attention_mask", "map_position_ids"], ["input_ids", "attention_mask", "position_ids"])
             gen_batch.non_tensor_batch["multi_modal_data"] = gen_batch.non_tensor_batch.pop("multi_modal_map_data")
-            if os.environ.get("SOCIOSEG_SAM_PREFETCH", "1") != "0" and hasattr(self.seg_infer, "prefetch_images"):
-                # SAM2's set_image needs only the pixels (seg_strategy.py:47-58): its encoder starts now, under the LM's stage-1 generation
-                self.seg_infer.prefetch_images(list(batch.non_tensor_batch["seg_image"]))
-            out = self._generate(gen_batch, global_step)
-            lap("generate_stage1")
-            out.rename(["input_ids", "attention_mask", "position_ids", "responses", "response_mask", "prompts", "prompt_mask"],
-                       ["map_input_ids", "map_attention_mask", "map_position_ids", "map_responses", "map_response_mask", "map_prompts", "map_prompt_mask"])
-            out.batch.pop("prompt_id", None)
-            for k, v in batch.non_tensor_batch.items():
-                batch.non_tensor_batch[k] = np.repeat(v, n_ret)
-            batch.batch = out.batch
-            # ---- stage-1 masks: responses -> SAM prompts -> union / nearest resize on the device
-            seg_batch = batch.pop(batch_keys=["map_responses", "map_prompts"], non_tensor_batch_keys=["seg_image"])
-            seg_out = self.seg_infer.segment_v4_map(seg_batch)
-            lap("segment_stage1")
-            batch = batch.union(seg_out)
-            batch.non_tensor_batch["map_mask"] = batch.non_tensor_batch.pop("mask")
-            batch.non_tensor_batch["map_visual_prompt"] = batch.non_tensor_batch.pop("visual_prompt")
-            batch.non_tensor_batch.pop("response_text")
-            # ---- stage 2: render stage 1 onto both images, re-prompt with the boxes found
-            map_response_list = self.tokenizer.batch_decode(batch.batch["map_responses"], skip_special_tokens=False)
-            bboxs_text_list = [parse_points_text_from_content(r) for r in map_response_list]
-            # stage 1's files exist from here on: they are rendered (device overlay, this thread) and handed to the writer pool NOW, so that their PNG
-            # encoding runs under stage 2's generation instead of after it (same files, same contents as the reference's write at the end of the batch)
-            from PIL import Image
-            nt1 = batch.non_tensor_batch
-            for i in range(len(batch)):
-                vp1 = nt1["map_visual_prompt"][i][0] if len(nt1["map_visual_prompt"][i]) else {}
-                r1 = draw_visual_prompt(nt1["seg_image"][i], nt1["map_mask"][i], vp1)
-
-                def write1(sid=nt1["id"][i], m1=nt1["map_mask"][i], r1=r1, t1=map_response_list[i]):
-                    Image.fromarray(m1.astype(np.uint8) * 255).save(os.path.join(dirs["stage1"], f"{sid}.png"))
-                    r1.save(os.path.join(dirs["render1"], f"{sid}.png"))
-                    with open(os.path.join(dirs["stage1"], f"{sid}.txt"), "w") as f:
-                        f.write(t1)
-                pending.append(writers.submit(write1))
-            batch = batch.union(self._stage2_batch(batch, bboxs_text_list))
-            gen_batch = batch.pop(batch_keys=["input_ids", "attention_mask", "position_ids"], non_tensor_batch_keys=["multi_modal_sat_data"])
-            gen_batch.non_tensor_batch["multi_modal_data"] = gen_batch.non_tensor_batch.pop("multi_modal_sat_data")
-            ga = cfg.actor_infer.generating_args or {}
-            keep = ga.get("num_return_sequences", 1)
-            ga["num_return_sequences"] = 1                      # stage 2 never fans out (reference :838-852)
-            lap("stage2_prompts")
-            out = self._generate(gen_batch, global_step)
-            lap("generate_stage2")
-            ga["num_return_sequences"] = keep
-            out.batch.pop("prompt_id", None)
-            batch = batch.union(out)
-            seg_batch = batch.pop(batch_keys=["responses", "prompts"], non_tensor_batch_keys=["seg_image"])
-            seg_out = self.seg_infer.segment_v4_sat(seg_batch)
-            lap("segment_stage2")
-            seg_out.meta_info.pop("metrics", None)
-            batch = batch.union(seg_out)
-            batch.non_tensor_batch["sat_mask"] = batch.non_tensor_batch.pop("mask")
-            batch.non_tensor_batch["sat_visual_prompt"] = batch.non_tensor_batch.pop("visual_prompt")
-            # ---- score and write
-            sat_response_list = self.tokenizer.batch_decode(batch.batch["responses"], skip_special_tokens=False)
-            nt = batch.non_tensor_batch
-            giou_list = []
-            for i in range(len(batch)):
-                gt_mask = np.array(nt["gt_mask"][i].convert("L"))
-                giou_list.append(compute_giou(nt["sat_mask"][i], gt_mask))
-                vp2 = nt["sat_visual_prompt"][i][0] if len(nt["sat_visual_prompt"][i]) else {}
-                sid = nt["id"][i]
-                # the overlays run on the device from THIS thread (the HIP current device is per thread); the pool only encodes and writes
-                r2 = draw_visual_prompt(nt["seg_image"][i], nt["sat_mask"][i], vp2)
-
-                def write(sid=sid, m2=nt["sat_mask"][i], r2=r2, t2=sat_response_list[i]):
-                    Image.fromarray(m2.astype(np.uint8) * 255).save(os.path.join(dirs["stage2"], f"{sid}.png"))
-                    r2.save(os.path.join(dirs["render2"], f"{sid}.png"))
-                    with open(os.path.join(dirs["stage2"], f"{sid}.txt"), "w") as f:
-                        f.write(t2)
-                pending.append(writers.submit(write))
+            if self.streamed:
+                giou_list = self._run_batch_streamed(batch, gen_batch, lap, dirs, writers, pending)
+            else:
+                out = self._generate(gen_batch, global_step)
+                lap("generate_stage1")
+                gen_batch = self._after_stage1(batch, out, n_ret, lap, dirs, writers, pending)
+                ga = cfg.actor_infer.generating_args or {}
+                keep = ga.get("num_return_sequences", 1)
+                ga["num_return_sequences"] = 1                      # stage 2 never fans out (reference :838-852)
+                lap("stage2_prompts")
+                out = self._generate(gen_batch, global_step)
+                lap("generate_stage2")
+                ga["num_return_sequences"] = keep
+                giou_list = self._after_stage2(batch, out, lap, dirs, writers, pending)
             print(f"giou_acc: {np.mean(giou_list)}")
             all_giou.extend(giou_list)
             global_step += 1
             lap("score_and_write")
+        sys.setswitchinterval(switch)
         # request-level dispatch across ranks is collective: a rank whose shard had fewer batches than the largest shard joins the
         # other ranks' remaining rounds (two generate calls per batch) with no requests of its own
         most = max(-(-s_ // self.batch_size) for s_ in dp.split_sizes(self.n_samples, self.world))

@@ -48,10 +48,11 @@ class SegWorker(Worker):
         data.meta_info = {"metrics": {}}
         return data
 
-    def prefetch_images(self, images) -> None:
-        """hint: these images will be segmented soon (the strategy may start SAM2's image encoder now; no reference counterpart)"""
+    def prefetch_images(self, images, chunk=None) -> None:
+        """hint: these images will be segmented soon (the strategy may start SAM2's image encoder now; no reference counterpart).  chunk: images per
+        encoder pass of the background work (a segment call that arrives meanwhile waits for at most one pass)"""
         if hasattr(self.strategy, "prefetch"):
-            self.strategy.prefetch(images)
+            self.strategy.prefetch(images, chunk=chunk)
 
     @torch.no_grad()
     def segment_v4_map(self, data: DataProto) -> DataProto:

@@ -38,6 +38,7 @@ class Engine:
                  max_new_tokens=128, device="cuda:0", lm_fp8=False, kv_slots: int = 0):
         """kv_slots: KV-cache slots (0 = max_batch); spare slots let the scheduler prefill the next requests while all rows decode"""
         self.lib = L.load()
+        self.lib_held = L.load_held()          # the scheduler's queue-only calls, made without releasing the interpreter lock (lib.load_held)
         if not torch.cuda.is_available():
             raise L.SocioRError("no GPU visible: the product path has no CPU fallback")
         self.geom = geometry
@@ -291,16 +292,16 @@ class Engine:
     def admit_commit(self, rows: Sequence[int]):
         """Second half, on the decode stream between two steps: batch row rows[i] takes over the i-th staged sequence (and its KV slot)."""
         rw = np.asarray(list(rows), dtype=np.int32)
-        L.check(self.lib.sr_admit_commit(self._h, rw.ctypes.data_as(L._i32p), len(rw), self._s()), self._h, "sr_admit_commit")
+        L.check(self.lib_held.sr_admit_commit(self._h, rw.ctypes.data_as(L._i32p), len(rw), self._s()), self._h, "sr_admit_commit")
 
     def rows_step(self, n_steps: int, eos: Sequence[int] = (), pad_id: int = 0):
         eos_a = np.asarray(list(eos), dtype=np.int32)
-        L.check(self.lib.sr_rows_step(self._h, n_steps, eos_a.ctypes.data_as(L._i32p) if len(eos_a) else None, len(eos_a), pad_id, self._s()),
+        L.check(self.lib_held.sr_rows_step(self._h, n_steps, eos_a.ctypes.data_as(L._i32p) if len(eos_a) else None, len(eos_a), pad_id, self._s()),
                 self._h, "sr_rows_step")
 
     def rows_set_cus(self, n_cus: int):
         """hint: the decode steps queued after this on the current stream run on n_cus compute units (0 = the whole chip); results do not depend on it"""
-        L.check(self.lib.sr_rows_set_cus(self._h, int(n_cus), self._s()), self._h, "sr_rows_set_cus")
+        L.check(self.lib_held.sr_rows_set_cus(self._h, int(n_cus), self._s()), self._h, "sr_rows_set_cus")
 
     def rows_poll(self):
         """-> (finished flags, generated-token counts), numpy int32 [max_batch]; synchronises."""
@@ -316,7 +317,15 @@ class Engine:
 
     def row_tokens(self, row: int, n: int) -> torch.Tensor:
         out = torch.empty(n, dtype=torch.int32, device=self.device)
-        L.check(self.lib.sr_rows_read(self._h, row, C.c_void_p(out.data_ptr()), n, self._s()), self._h, "sr_rows_read")
+        L.check(self.lib_held.sr_rows_read(self._h, row, C.c_void_p(out.data_ptr()), n, self._s()), self._h, "sr_rows_read")
+        return out
+
+    def rows_tokens(self, rows: Sequence[int], counts: Sequence[int]) -> torch.Tensor:
+        """the generated tokens of several rows as ONE device tensor int32 [len(rows), max(counts)] (row i valid up to counts[i]): stream-ordered
+        device-to-device copies, so a row may be re-used by a later call on the same stream before the host has looked at the result"""
+        out = torch.empty(len(rows), max(max(counts, default=0), 1), dtype=torch.int32, device=self.device)
+        for i, (row, n) in enumerate(zip(rows, counts)):
+            L.check(self.lib_held.sr_rows_read(self._h, int(row), C.c_void_p(out[i].data_ptr()), int(n), self._s()), self._h, "sr_rows_read")
         return out
 
     def decode_step(self, last_ids: torch.Tensor | None = None, return_logits: bool = True):

@@ -122,6 +122,26 @@ def load():
     return _lib
 
 
+_lib_held = None
+# the scheduler's per-round calls that only QUEUE work (no wait inside): see load_held
+HELD = ("sr_rows_step", "sr_rows_set_cus", "sr_rows_read", "sr_admit_commit")
+
+
+def load_held():
+    """The same library through ctypes.PyDLL, for the few calls of a scheduling round that only queue work: a CDLL call releases the interpreter
+    lock and has to win it back afterwards -- with other Python threads busy (the streamed two-stage pipeline: host flow, SAM2 prefetch) that is up to
+    one switch interval per call, five calls per round, between two chunks of decode steps.  Never used for a call that waits for the device."""
+    global _lib_held
+    if _lib_held is None:
+        load()
+        lib = C.PyDLL(LIB_PATH)
+        for name in HELD:
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = SIGNATURES[name]
+        _lib_held = lib
+    return _lib_held
+
+
 def check(rc: int, engine=None, what: str = ""):
     if rc != 0:
         msg = load().sr_last_error(engine).decode("utf-8", "replace")

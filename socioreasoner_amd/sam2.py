@@ -827,6 +827,7 @@ class Sam2Predictor:
         self._pf_thread = None
         self._pf_stream = None
         self._pf_error = None
+        self._want = 0                                # foreground callers waiting for the lock (the prefetch loop yields to them)
 
     @staticmethod
     def _host_u8(image) -> np.ndarray:
@@ -889,11 +890,12 @@ class Sam2Predictor:
         self.stats["images"] += len(arrs)
         return [feats[k] for k in keys]
 
-    def prefetch(self, images: Sequence) -> None:
+    def prefetch(self, images: Sequence, prepare=None, chunk: Optional[int] = None) -> None:
         """Start encoding `images` (host images, as `segment_batch` will receive them) on a background thread and a stream of its own; returns at once.
         `set_images` needs nothing but the pixels (seg_strategy.py:47-58), so the pipeline calls this before stage-1 generation: the encoder runs under
         the LM's generate call and `segment_batch` finds the embeddings in the cache (its own `embed` encodes whatever is still missing).  One chunk of
-        `batch` images per lock hold, the side stream drained before the lock is released."""
+        `batch` images per lock hold, the side stream drained before the lock is released.  `prepare(image)` -- the caller's host-side preparation of one
+        image, e.g. seg_infer's 756 x 756 resize -- runs on the thread too, chunk by chunk."""
         import threading
         self.wait_prefetch()
         images = list(images)
@@ -906,9 +908,14 @@ class Sam2Predictor:
                 torch.cuda.set_device(dev)
                 if self._pf_stream is None:
                     self._pf_stream = torch.cuda.Stream(dev)
-                for i in range(0, len(images), self.batch):
+                import time
+                step = max(1, min(self.batch, int(chunk or self.batch)))      # images per lock hold (a foreground caller waits for at most one)
+                for i in range(0, len(images), step):
+                    while self._want > 0:            # a caller is waiting for the engine (segment_batch): a released threading lock goes to whoever asks
+                        time.sleep(0.0005)           # first, which would be this loop again -- the foreground goes first
+                    part = images[i:i + step] if prepare is None else [prepare(im) for im in images[i:i + step]]      # (host preparation outside the lock)
                     with self._lock, torch.cuda.stream(self._pf_stream):
-                        self.embed(images[i:i + self.batch])
+                        self.embed(part)
                         self._pf_stream.synchronize()
             except Exception as e:  # noqa: BLE001  (reported by wait_prefetch / the next segment_batch; the embeddings it missed are encoded there)
                 self._pf_error = e
@@ -926,13 +933,22 @@ class Sam2Predictor:
             raise RuntimeError("SAM2 prefetch failed") from e
 
     def segment_batch(self, images: Sequence, prompts: Sequence[Sequence[dict]]) -> List[torch.Tensor]:
-        """seg_strategy.py:40-66 over a whole batch: embeddings (batched / cached), then the object loop of every sample on the device"""
-        self.wait_prefetch()
+        """seg_strategy.py:40-66 over a whole batch: embeddings (batched / cached), then the object loop of every sample on the device.
+        A prefetch that is still running is not waited for (the streamed two-stage pipeline segments its first samples while later ones are still being
+        encoded): this call goes ahead of the prefetch loop's next chunk, encodes what it misses itself, and the loop finds those in the cache."""
+        if self._pf_error is not None:
+            self.wait_prefetch()
         out = []
-        with self._lock:
-            for ft, vps in zip(self.embed(images), prompts):
-                self.engine.use_features(ft)
-                out.append(self.segment_objects(vps))
+        self._want += 1
+        try:
+            with self._lock:
+                for ft, vps in zip(self.embed(images), prompts):
+                    self.engine.use_features(ft)
+                    out.append(self.segment_objects(vps))
+                if self._pf_thread is not None:      # the prefetch loop may take the engine next, on another stream: leave this one drained (as it does)
+                    torch.cuda.current_stream(self.engine.device).synchronize()
+        finally:
+            self._want -= 1
         return out
 
     def segment_objects(self, prompts: Sequence[dict]) -> torch.Tensor:

@@ -150,16 +150,36 @@ def _scripted_worker(cfg, geom, proc, seen):
             out = hostops.gather_outputs_to_pad_tensor(rows, generation_config["pad_token_id"], device=ids.device)
             return hostops.concatenate_input_and_output(ids, out, 1)
 
+        def start_server(self, data, request_complete_callback):
+            """the request loop of the streamed pipeline (GenerateScheduler.open_stream): every ADD is answered from the same script"""
+            from roll.distributed.scheduler.protocol import DataProto
+            while True:
+                command, req = self.command_queue.get()
+                name = getattr(command, "name", command)
+                if name == "STOP":
+                    return
+                if name == "ADD":
+                    gc = req.meta_info["generation_config"]
+                    row = self.generate(req, gc)[0, req.batch["input_ids"].shape[1]:].tolist()
+                    res = DataProto(meta_info=dict(req.meta_info))
+                    res.meta_info["output_token_ids"] = [[int(t) for t in row if int(t) != int(gc["pad_token_id"])]]
+                    seen.setdefault("streamed_requests", []).append(int(req.meta_info["request_id"]))
+                    request_complete_callback(data=res)
+
     w = ActorWorker(cfg.actor_infer, cfg, 0, 1, 0, "actor_infer")
     w.strategy = Scripted(w)
     w.strategy.initialize()
     return w
 
 
-def test_pipeline_two_stage_flow_against_oracle(tmp_path):
+@pytest.mark.parametrize("streamed", [True, False])
+def test_pipeline_two_stage_flow_against_oracle(tmp_path, monkeypatch, streamed):
     """The reference's run() sequence with a scripted LM (answers are a function of the prompt text): parsing, SAM-prompt
     construction, union / nearest resize, render onto both images, stage-2 prompt construction and IoU are compared with
-    the oracle restatements step by step (device raster kernels vs numpy / C)."""
+    the oracle restatements step by step (device raster kernels vs numpy / C).  Both orders of the host flow: the reference's
+    (two generate calls per batch, SOCIOSEG_STREAM=0) and the streamed one (one open request stream, a sample's stage-2 prompt
+    added as soon as its stage-1 answer is segmented) must write the same files and the same score."""
+    monkeypatch.setenv("SOCIOSEG_STREAM", "1" if streamed else "0")
     import json
     import queue
     import re
@@ -220,6 +240,12 @@ def test_pipeline_two_stage_flow_against_oracle(tmp_path):
         assert "<answer>" in open(os.path.join(res, "stage2", s["id"] + ".txt")).read()
     assert abs(acc - float(np.mean(want_iou))) < 1e-12 and acc > 0
     assert open(os.path.join(res, "iou_acc.txt")).read() == f"giou_acc: {acc}"
+    assert pipe.streamed == streamed
+    if streamed:       # every sample went through the open stream twice: ids 0..3 (stage 1), 4..7 (stage 2), a sample's stage 2 after its stage 1
+        order = seen["streamed_requests"]
+        assert sorted(order) == list(range(8)) and all(order.index(i) < order.index(4 + i) for i in range(4)), order
+    else:
+        assert "streamed_requests" not in seen
 
 
 def test_checkpoint_loader_safetensors_both_namings(tmp_path):

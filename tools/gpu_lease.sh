@@ -20,6 +20,8 @@
 #   trace_sam2  kernel trace of the SAM2 float32 encoder (tools/prof_sam2_encoder.py) -> gpurun_out/${RT}_sam2_f32_*.md
 #   bench_pmc   one bench step with the in-run rocprofv3 PMC passes (roofline.traffic measured, not a file ratio)
 #   pipeline    tools/run_example_small.py with 4 scripted objects per stage, SAM2 float32 / bf16 / no answers -> gpurun_out/${RT}_pipeline_*.json
+#   pipeline250 the two-stage pipeline at the reference's scale, streamed (default) against SOCIOSEG_STREAM=0, twice each -> gpurun_out/${RT}_pipeline250_ab.txt
+#   pipetests   the GPU tests that run the pipeline / the request loop
 #   gemm_f32    tools/bench_gemm_f32.py: the split-bf16 float32 GEMM against the f32-input MFMA kernel  -> gpurun_out/${RT}_gemm_f32_split.jsonl
 #   sam2bench   tools/bench_sam2_modes.py (float32 split / f32-input / bf16)  -> gpurun_out/${RT}_sam2_modes.json
 #   host_scaling    1 / 2 / 4 / 8 gloo ranks on the one device: host ms per scheduling round -> gpurun_out/${RT}_host_scaling.jsonl
@@ -87,6 +89,18 @@ for stage in "$@"; do
     fp8tests) timeout 1500 python -m pytest tests -q -m gpu -k "f8 or fp8" 2>&1 | tail -8 ;;
     pipeline) for dt in float32 bf16; do SR_SAM2_DTYPE=$dt SCRIPTED_OBJECTS=4 OUT=/tmp/example_out SOCIOSEG_NUM_SAMPLES=64 timeout 900 python tools/run_example_small.py 2> gpurun_out/${RT}_pipeline_$dt.err | tail -1 | tee gpurun_out/${RT}_pipeline_$dt.json | cut -c1-900; done
               SCRIPTED_OBJECTS=0 OUT=/tmp/example_out SOCIOSEG_NUM_SAMPLES=64 timeout 900 python tools/run_example_small.py 2>/dev/null | tail -1 | tee gpurun_out/${RT}_pipeline_noanswers.json | cut -c1-600 ;;
+    pipeline250)   # the two-stage pipeline at the reference's scale (250 samples, rollout_batch_size 250, YAML sampling, 4 scripted objects per stage): streamed against the batch order, twice each
+      for rep in 1 2; do for st in 1 0; do
+        SOCIOSEG_STREAM=$st SCRIPTED_OBJECTS=4 OUT=/tmp/example_out SOCIOSEG_NUM_SAMPLES=250 ROLLOUT_BATCH=250 timeout 900 python tools/run_example_small.py 2> gpurun_out/${RT}_pipeline250_s$st.err | tail -1 > gpurun_out/${RT}_pipeline250_s$st.json
+        python -c "
+import json,sys
+try:
+    d=json.load(open('gpurun_out/${RT}_pipeline250_s$st.json')); print('SOCIOSEG_STREAM=$st rep $rep', {k: d[k] for k in ('streamed','samples_per_s','run_s','giou_acc','files','wall_s_by_phase')}); print('   ', [{k: g.get(k) for k in ('requests','served_as','steps','steps_shared','admissions','rounds','host_ms','poll_wait_ms')} for g in d['generate_calls']])
+except Exception as e:
+    print('SOCIOSEG_STREAM=$st rep $rep FAILED', e); print(open('gpurun_out/${RT}_pipeline250_s$st.err').read()[-3000:])
+"
+      done; done | tee gpurun_out/${RT}_pipeline250_ab.txt ;;
+    pipetests) timeout 1500 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_sam2.py tests/test_gpu_round4.py -q -m gpu -x -k "pipeline or serving or request or level" 2>&1 | tail -15 ;;
     trace_sam2) rm -rf /tmp/prof_${RT}_sam; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_${RT}_sam -o sam -- python $R/tools/prof_sam2_encoder.py f32 > $R/gpurun_out/${RT}_prof_sam2.log 2>&1; echo "trace sam2 exit $?")
                 DB=$(find /tmp/prof_${RT}_sam -name "sam_results.db" | head -1); [ -n "$DB" ] && python tools/rocpd_stats.py $DB gpurun_out/${RT}_sam2_f32_encoder_kernel_stats.md > /dev/null && head -20 gpurun_out/${RT}_sam2_f32_encoder_kernel_stats.md | cut -c1-170
                 [ -n "$DB" ] && python tools/rocpd_by_grid.py $DB gpurun_out/${RT}_sam2_f32_by_grid.md 30 > /dev/null 2>&1 && head -36 gpurun_out/${RT}_sam2_f32_by_grid.md | cut -c1-200 ;;

@@ -69,7 +69,7 @@ acc = pipe.run()
 t2 = time.time()
 files = {d: len(os.listdir(os.path.join(out, "result", d))) for d in ("stage1", "stage2", "render1", "render2") if os.path.isdir(os.path.join(out, "result", d))}
 pred = getattr(pipe.seg_infer.strategy, "model", None)
-print(json.dumps({"samples": n, "new_tokens_per_stage": new, "scripted_objects_per_stage": n_obj, "sam2_stats": getattr(pred, "stats", None),
+print(json.dumps({"samples": n, "new_tokens_per_stage": new, "scripted_objects_per_stage": n_obj, "sam2_stats": getattr(pred, "stats", None), "streamed": getattr(pipe, "streamed", None),
                   "sam2_dtype": str(getattr(getattr(pred, "engine", None), "dt", None)), "build_s": round(t1 - t0, 1), "run_s": round(t2 - t1, 1), "samples_per_s": round(n / (t2 - t1), 2),
                   "giou_acc": acc, "files": files, "sam": type(pipe.seg_infer.strategy.model).__name__,
                   "wall_s_by_phase": {k: round(v, 2) for k, v in pipe.timing.items()},
