@@ -172,3 +172,84 @@ def test_scheduler_takes_no_cost_measurement_next_to_foreign_gpu_work():
     serving.foreign_gpu_load(False)
     assert not cb._meas_clean("adm_sh")             # ... or started AND ended under it
     assert serving._FOREIGN["active"] == 0
+
+
+def test_request_stream_serves_two_waves_of_prompts_on_one_open_server(tmp_path):
+    """GenerateScheduler.open_stream (the streamed two-stage pipeline's generation interface): ONE start_server / stop_server pair, prompts added under
+    caller-chosen ids in two waves -- the second while answers of the first are being collected -- and every answer equals what a level-0 generate call
+    returns for that prompt.  The request loop takes a burst of queued commands in one round (an ADD burst followed by STOP still answers every ADD)."""
+    import numpy as np
+    import torch
+    from roll.distributed.scheduler.generate_scheduler import GenerateScheduler, assemble_responses
+    from roll.distributed.scheduler.protocol import DataProto
+    from roll.distributed.strategy.mi355x_strategy import Mi355xStrategy
+    from roll.pipeline.base_worker import ActorWorker
+    from socioreasoner_amd import hostops
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.textproc import ByteTokenizer
+    from tests.test_host_cpu import _tiny_cfg
+    cfg = _tiny_cfg(tmp_path, prompt_length=12, response_length=6)
+    tok = ByteTokenizer(geometry_tiny())
+    servers = []
+
+    class Fake(Mi355xStrategy):          # the real request loop (start_server / add_request) over a scripted generate
+        max_batch = 2
+
+        def initialize(self, model_provider=None):
+            import queue
+            self.command_queue, self.tokenizer = queue.Queue(), tok
+
+        def start_server(self, data, request_complete_callback):
+            servers.append(1)
+            return super().start_server(data, request_complete_callback)
+
+        def generate(self, batch, generation_config):
+            ids, mask = batch.batch["input_ids"], batch.batch["attention_mask"]
+            rows = []
+            for r, m in zip(ids, mask):
+                p = r[m.bool()].tolist()
+                rows.append(list(reversed(p))[: 1 + len(p) % 4] + [tok.eos_token_id])
+            out = hostops.gather_outputs_to_pad_tensor(rows, generation_config["pad_token_id"], device=ids.device)
+            return hostops.concatenate_input_and_output(ids, out, 1)
+
+    assert Fake.request_stream
+    w = ActorWorker(cfg.actor_infer, cfg, 0, 1, 0, "actor_infer")
+    w.strategy = Fake(w)
+    w.strategy.initialize()
+    w.tokenizer = tok
+    rng = np.random.default_rng(1)
+
+    def prompts(lengths):
+        ids = torch.full((len(lengths), 12), tok.pad_token_id, dtype=torch.long)
+        mask = torch.zeros(len(lengths), 12, dtype=torch.long)
+        for i, n in enumerate(lengths):
+            ids[i, 12 - n:] = torch.from_numpy(rng.integers(0, 250, n))
+            mask[i, 12 - n:] = 1
+        pos = (mask.cumsum(-1) - 1).clamp(min=0)[:, None, :].repeat(1, 3, 1)
+        return DataProto(batch={"input_ids": ids, "attention_mask": mask, "position_ids": pos}, non_tensor_batch={})
+    a, b = prompts([12, 7, 9, 3, 10]), prompts([5, 11, 2])
+    sched = GenerateScheduler()
+    want_a = sched.generate(DataProto(batch={k: v.clone() for k, v in a.batch.items()}, non_tensor_batch={}), w, cfg)
+    want_b = sched.generate(DataProto(batch={k: v.clone() for k, v in b.batch.items()}, non_tensor_batch={}), w, cfg)
+    st = sched.open_stream(w, cfg)
+    st.add(list(range(5)), a)
+    got = dict(st.collect())
+    st.add([100, 101, 102], b)                         # second wave, same server
+    while len(got) < 8:
+        got.update(dict(st.collect()))
+    st.close()
+    assert servers == [1] and st.in_flight == 0 and sorted(got) == [0, 1, 2, 3, 4, 100, 101, 102]
+    out_a = assemble_responses(a, [got[i] for i in range(5)], w, cfg)
+    out_b = assemble_responses(b, [got[100 + i] for i in range(3)], w, cfg)
+    for k in want_a.batch:
+        if k != "prompt_id":
+            assert torch.equal(out_a.batch[k], want_a.batch[k]) and torch.equal(out_b.batch[k], want_b.batch[k]), k
+    # a burst: three ADDs and the STOP queued before the loop has started -- every ADD is answered before the loop ends
+    from roll.utils.functionals import GenerateRequestType
+    answers = []
+    for i in range(3):
+        w.strategy.add_request(GenerateRequestType.ADD, DataProto(batch={k: v[i:i + 1] for k, v in b.batch.items()}, non_tensor_batch={},
+                                                                  meta_info={"request_id": i, "generation_config": dict(st.gc, eos_token_id=[tok.eos_token_id], pad_token_id=tok.pad_token_id)}))
+    w.strategy.add_request(GenerateRequestType.STOP, None)
+    w.strategy.start_server(DataProto(meta_info={}), lambda data: answers.append((data.meta_info["request_id"], data.meta_info["output_token_ids"][0])))
+    assert dict(answers) == {i: got[100 + i] for i in range(3)}
