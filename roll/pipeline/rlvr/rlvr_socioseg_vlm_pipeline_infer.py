@@ -449,10 +449,10 @@ class SocioSegInferPipeline(BasePipeline):
         if torch.cuda.is_available():
             # this thread's device work (SAM2 decoder, raster kernels, render) runs next to the engine's: on a stream of its own, not on the null
             # stream, which would serialise with the scheduler's CU-masked (blocking) streams
-            # -- a HIGH-PRIORITY one: SAM2's decoder is ~110 dependent launches of a few microseconds per sample, and behind the engine's GEMM grids
-            # each of them would wait for a free CU at normal priority (measured: 18 ms per sample instead of 2.6 ms on an idle GPU)
+            # (a high-priority stream was measured too and changes nothing: a segment call next to the engine waits for SAM2 ENCODER passes -- its own
+            # or the prefetch thread's -- not for launch slots)
             if getattr(self, "_host_stream", None) is None:
-                self._host_stream = torch.cuda.Stream(priority=-1)
+                self._host_stream = torch.cuda.Stream()
             host_stream = self._host_stream
         stream = self.generate_scheduler.open_stream(self.actor_infer, self.pipeline_config)
         try:
