@@ -20,7 +20,7 @@
 #   trace_sam2  kernel trace of the SAM2 float32 encoder (tools/prof_sam2_encoder.py) -> gpurun_out/${RT}_sam2_f32_*.md
 #   bench_pmc   one bench step with the in-run rocprofv3 PMC passes (roofline.traffic measured, not a file ratio)
 #   pipeline    tools/run_example_small.py with 4 scripted objects per stage, SAM2 float32 / bf16 / no answers -> gpurun_out/${RT}_pipeline_*.json
-#   pipeline250 the two-stage pipeline at the reference's scale, streamed (default) against SOCIOSEG_STREAM=0, twice each -> gpurun_out/${RT}_pipeline250_ab.txt
+#   pipeline250  the two-stage pipeline at the reference's scale, streamed (default) against SOCIOSEG_STREAM=0, twice each -> gpurun_out/${RT}_pipeline250_ab.txt
 #   pipetests   the GPU tests that run the pipeline / the request loop
 #   gemm_f32    tools/bench_gemm_f32.py: the split-bf16 float32 GEMM against the f32-input MFMA kernel  -> gpurun_out/${RT}_gemm_f32_split.jsonl
 #   sam2bench   tools/bench_sam2_modes.py (float32 split / f32-input / bf16)  -> gpurun_out/${RT}_sam2_modes.json
