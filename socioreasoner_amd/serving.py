@@ -8,6 +8,7 @@ the batch with it (per-row arithmetic is independent of the other rows).
 """
 from __future__ import annotations
 
+import contextlib
 from collections import deque
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence
@@ -471,8 +472,12 @@ class ContinuousBatcher:
                 self._copy_stream.wait_event(ev)
                 buf.record_stream(self._copy_stream)
                 host = buf.cpu().numpy()
-            for req, n, toks in zip(reqs, counts, host):
-                on_complete(req, toks[:n].tolist())
+            # the callbacks run with the rows' stream current, as they did when they were called from the poll: device work they queue (the bench's
+            # raster tail and result exchange) is ordered behind the decode steps and never lands on the null stream, which would synchronise with the
+            # CU-masked (blocking) streams -- i.e. wait for a staged admission and hold every later decode chunk behind itself
+            with (torch.cuda.stream(self._dec_last) if (self.overlap and self._dec_last is not None) else contextlib.nullcontext()):
+                for req, n, toks in zip(reqs, counts, host):
+                    on_complete(req, toks[:n].tolist())
 
     def _poll(self):
         import time
