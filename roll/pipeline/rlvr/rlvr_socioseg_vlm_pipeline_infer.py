@@ -442,9 +442,10 @@ class SocioSegInferPipeline(BasePipeline):
         return DataProto(batch={k: v[torch.from_numpy(ix)] for k, v in (data.batch or {}).items()},
                          non_tensor_batch={k: v[ix] for k, v in data.non_tensor_batch.items()}, meta_info=dict(data.meta_info))
 
-    def _run_batch_streamed(self, batch: DataProto, gen_batch: DataProto, lap, dirs, writers, pending) -> List[float]:
+    def _run_batch_streamed(self, parts, B: int, lap, dirs, writers, pending) -> List[float]:
+        """parts: the rollout batch of B samples as an iterator of (batch, stage-1 generation batch) pieces in sample order -- the first piece's prompts
+        are on the engine while the later pieces are still being collated"""
         from roll.distributed.scheduler.generate_scheduler import assemble_responses
-        B = len(batch)
         host_stream = None
         if torch.cuda.is_available():
             # this thread's device work (SAM2 decoder, raster kernels, render) runs next to the engine's: on a stream of its own, not on the null
@@ -456,8 +457,17 @@ class SocioSegInferPipeline(BasePipeline):
             host_stream = self._host_stream
         stream = self.generate_scheduler.open_stream(self.actor_infer, self.pipeline_config)
         try:
-            stream.add(list(range(B)), gen_batch)                     # request ids 0 .. B - 1: stage 1; B .. 2B - 1: stage 2 of sample id - B
-            lap("generate_stage1")
+            pieces, n0 = [], 0
+            for part, gen_part in parts:
+                lap("collate")
+                stream.add(list(range(n0, n0 + len(part))), gen_part)       # request ids 0 .. B - 1: stage 1; B .. 2B - 1: stage 2 of sample id - B
+                lap("generate_stage1")
+                pieces.append((part, gen_part))
+                n0 += len(part)
+            assert n0 == B, (n0, B)
+            batch = pieces[0][0] if len(pieces) == 1 else DataProto.concat([p_ for p_, _ in pieces])
+            gen_batch = pieces[0][1] if len(pieces) == 1 else DataProto.concat([g_ for _, g_ in pieces])
+            lap("collate")
             state: Dict[int, DataProto] = {}                             # sample -> its one-row batch after stage 1
             gen2_rows: Dict[int, DataProto] = {}                         # sample -> its stage-2 prompt row
             giou: Dict[int, float] = {}
@@ -516,7 +526,8 @@ class SocioSegInferPipeline(BasePipeline):
         writers = ThreadPoolExecutor(max_workers=int(os.environ.get("SOCIOSEG_WRITERS", 8)))
         pending = []
         prefetch = os.environ.get("SOCIOSEG_SAM_PREFETCH", "1") != "0" and hasattr(self.seg_infer, "prefetch_images")
-        loader = get_dataloader(self.dataset, self.batch_size, self.data_collator)          # (in dataset order: batch k = samples k * batch_size ...)
+        # (in dataset order: batch k = samples k * batch_size ...; the streamed mode collates the same rows itself, in pieces)
+        loader = None if self.streamed else get_dataloader(self.dataset, self.batch_size, self.data_collator)
         import sys
         switch = sys.getswitchinterval()
         if self.streamed:
@@ -528,18 +539,28 @@ class SocioSegInferPipeline(BasePipeline):
                 # SAM2's set_image needs only the pixels (seg_strategy.py:47-58): its encoder starts now, under the collation of the batch and the
                 # LM's stage-1 generation
                 self.seg_infer.prefetch_images(list(self.dataset["seg_image"][b0:b0 + self.batch_size]))
-            batch_dict = next(loader)
-            lap("collate")
-            self.model_update(global_step)
-            batch = DataProto.from_single_dict(batch_dict)
-            batch.meta_info = {"global_step": global_step}
-            # ---- stage 1: generate on the (map, satellite) pair
-            gen_batch = batch.pop(batch_keys=["map_input_ids", "map_attention_mask", "map_position_ids"], non_tensor_batch_keys=["multi_modal_map_data"])
-            gen_batch.rename(["map_input_ids", "map_attention_mask", "map_position_ids"], ["input_ids", "attention_mask", "position_ids"])
-            gen_batch.non_tensor_batch["multi_modal_data"] = gen_batch.non_tensor_batch.pop("multi_modal_map_data")
+            def stage1_batches(batch_dict, step=global_step):
+                batch = DataProto.from_single_dict(batch_dict)
+                batch.meta_info = {"global_step": step}
+                # ---- stage 1: generate on the (map, satellite) pair
+                gen_batch = batch.pop(batch_keys=["map_input_ids", "map_attention_mask", "map_position_ids"], non_tensor_batch_keys=["multi_modal_map_data"])
+                gen_batch.rename(["map_input_ids", "map_attention_mask", "map_position_ids"], ["input_ids", "attention_mask", "position_ids"])
+                gen_batch.non_tensor_batch["multi_modal_data"] = gen_batch.non_tensor_batch.pop("multi_modal_map_data")
+                return batch, gen_batch
             if self.streamed:
-                giou_list = self._run_batch_streamed(batch, gen_batch, lap, dirs, writers, pending)
+                # the rollout batch is collated in pieces (every row is padded to prompt_length and indexed on its own, so the pieces ARE the rows of the
+                # whole batch's collation): the first piece's prompts are being prefilled while the rest is collated
+                self.model_update(global_step)
+                hi = min(b0 + self.batch_size, len(self.dataset["id"]))
+                piece = max(1, int(os.environ.get("SOCIOSEG_COLLATE_CHUNK", 32)))
+                parts = (stage1_batches(self.data_collator([{k: v[i] for k, v in self.dataset.items()} for i in range(c0, min(c0 + piece, hi))]))
+                         for c0 in range(b0, hi, piece))
+                giou_list = self._run_batch_streamed(parts, hi - b0, lap, dirs, writers, pending)
             else:
+                batch_dict = next(loader)
+                lap("collate")
+                self.model_update(global_step)
+                batch, gen_batch = stage1_batches(batch_dict)
                 out = self._generate(gen_batch, global_step)
                 lap("generate_stage1")
                 gen_batch = self._after_stage1(batch, out, n_ret, lap, dirs, writers, pending)

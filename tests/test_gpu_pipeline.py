@@ -180,6 +180,7 @@ def test_pipeline_two_stage_flow_against_oracle(tmp_path, monkeypatch, streamed)
     (two generate calls per batch, SOCIOSEG_STREAM=0) and the streamed one (one open request stream, a sample's stage-2 prompt
     added as soon as its stage-1 answer is segmented) must write the same files and the same score."""
     monkeypatch.setenv("SOCIOSEG_STREAM", "1" if streamed else "0")
+    monkeypatch.setenv("SOCIOSEG_COLLATE_CHUNK", "3")          # streamed: the batch of 4 is collated as 3 + 1 rows, the first piece on the engine before the second exists
     import json
     import queue
     import re

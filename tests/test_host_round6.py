@@ -253,3 +253,38 @@ def test_request_stream_serves_two_waves_of_prompts_on_one_open_server(tmp_path)
     w.strategy.add_request(GenerateRequestType.STOP, None)
     w.strategy.start_server(DataProto(meta_info={}), lambda data: answers.append((data.meta_info["request_id"], data.meta_info["output_token_ids"][0])))
     assert dict(answers) == {i: got[100 + i] for i in range(3)}
+
+
+def test_collating_a_batch_in_pieces_gives_the_rows_of_the_whole_batch():
+    """The streamed pipeline collates a rollout batch in pieces (the first piece's prompts are prefilled while the rest is collated): with padding to
+    max_length every row is padded and indexed on its own, so the concatenated pieces must BE the whole batch's collation -- ragged image sizes included."""
+    import numpy as np
+    import torch
+    from roll.datasets.collator import DataCollatorWithPaddingForMultiSeg
+    from roll.distributed.scheduler.protocol import DataProto
+    from roll.pipeline.rlvr import rlvr_socioseg_vlm_pipeline_infer as P
+    from socioreasoner_amd import socioseg_data
+    from socioreasoner_amd.config import geometry_tiny
+    from socioreasoner_amd.textproc import SyntheticProcessor
+    proc = SyntheticProcessor(geometry_tiny())
+    proc.image_processor.max_pixels, proc.image_processor.min_pixels = 768 * 768, 56 * 56
+    samples = socioseg_data.synthetic_socioseg(5, size=112)
+    samples[1]["sat_image"] = samples[1]["sat_image"].resize((150, 100))
+    samples[3]["map_image"] = samples[3]["map_image"].resize((84, 140))
+    enc = P.encode_function({k: [s[k] for s in samples] for k in samples[0]}, proc)
+    coll = DataCollatorWithPaddingForMultiSeg(tokenizer=proc.tokenizer, processor=proc, extra_data_provider=P.get_extra_data_provider(processor=proc),
+                                              max_length=900, image_key="image", padding="max_length", gt_object_key="gt_object", gt_bbox_key="gt_bbox")
+    rows = [{k: v[i] for k, v in enc.items()} for i in range(5)]
+    whole = DataProto.from_single_dict(coll(rows))
+    pieces = DataProto.concat([DataProto.from_single_dict(coll(rows[:3])), DataProto.from_single_dict(coll(rows[3:]))])
+    assert set(whole.batch) == set(pieces.batch) and set(whole.non_tensor_batch) == set(pieces.non_tensor_batch)
+    for k in whole.batch:
+        assert torch.equal(whole.batch[k], pieces.batch[k]), k
+    for k, v in whole.non_tensor_batch.items():
+        w = pieces.non_tensor_batch[k]
+        assert w.dtype == object and w.shape == v.shape == (5,), k
+    for i in range(5):
+        assert whole.non_tensor_batch["id"][i] == pieces.non_tensor_batch["id"][i]
+        assert whole.non_tensor_batch["multi_modal_map_data"][i]["prompt_token_ids"] == pieces.non_tensor_batch["multi_modal_map_data"][i]["prompt_token_ids"]
+        assert torch.equal(whole.non_tensor_batch["multi_modal_map_inputs"][i]["image_grid_thw"], pieces.non_tensor_batch["multi_modal_map_inputs"][i]["image_grid_thw"])
+        assert whole.non_tensor_batch["seg_image"][i] is pieces.non_tensor_batch["seg_image"][i]      # the dataset's own objects (the 756-resize memo is keyed by them)
