@@ -72,7 +72,8 @@ def main():
               "more_rows_per_gpu": side.more_rows() if extras and wl.continuous and plain and not args.no_more_rows else None,
               "ragged": side.ragged(wl) if extras and wl.continuous else None,
               "sam2": side.sam2(dev) if extras and not args.no_sam else None,
-              "pipeline_two_stage_with_sam2": side.pipeline(args.pipeline_samples) if extras and wl.continuous and plain and not args.no_pipeline else None,
+              "pipeline_two_stage_with_sam2": (side.pipeline(args.pipeline_samples, batch_order_too=args.pipeline_ab)
+                                               if extras and wl.continuous and plain and not args.no_pipeline else None),
               "latency_b1": side.latency_b1(wl) if extras and B > 1 and not args.fp8 else None}
         roof = roofline.build(wl, line.decode_step_alone_ms(wl), sd["latency_b1"], measure=extras and not args.no_pmc)
         cpu = cpu_hf = None

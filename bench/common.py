@@ -53,6 +53,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-sam", action="store_true", help="skip the SAM2 (seg_infer) timing")
     ap.add_argument("--no-more-rows", action="store_true", help="skip the 64- and 128-row points (child processes)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the two-stage pipeline timing with SAM2 at work (a child process)")
+    ap.add_argument("--pipeline-ab", action="store_true",
+                    help="also time the pipeline in the reference's batch order (SOCIOSEG_STREAM=0): one more child process, ~35 s")
     ap.add_argument("--no-pmc", action="store_true", help="no rocprofv3 child passes in this run: neither the in-situ kernel trace of the decode weight stream "
                     "(roofline.avg_launch_us then comes from the launch-only replay, and says so) nor the FETCH_SIZE / WRITE_SIZE passes")
     ap.add_argument("--no-graph", action="store_true")

@@ -155,7 +155,7 @@ def sam2(dev):
             "float32": f32, "bf16": b16}
 
 
-def pipeline(n_samples):
+def pipeline(n_samples, batch_order_too=False):
     """The reference's own two-stage pipeline (examples/infer/rlvr_megatron.yaml through SocioSegInferPipeline: two generate calls on a (map,
     satellite) pair each, two segment calls, four PNGs + two text files per sample) at the reference's scale and sampling parameters
     (rollout_batch_size 250, temperature 1 / top_p 0.8 / top_k 100: rlvr_megatron.yaml:89-95) with SAM2 DOING WORK: random weights emit no
@@ -172,15 +172,19 @@ def pipeline(n_samples):
             p["with_128_lm_batch_rows"] = {k: q[k] for k in ("samples_per_s", "run_s", "wall_s_by_phase")}
         except Exception as e_:  # noqa: BLE001
             p["with_128_lm_batch_rows"] = {"error": f"{type(e_).__name__}: {e_}"[:200]}
-        try:      # the reference's order of the host flow (two generate calls per batch, the host work between them) instead of the streamed one
-            q = last_json_line(subprocess.run(script, capture_output=True, text=True, timeout=900, env=dict(env, SOCIOSEG_STREAM="0")).stdout)
-            p["batch_order_SOCIOSEG_STREAM_0"] = {k: q[k] for k in ("samples_per_s", "run_s", "wall_s_by_phase")}
-        except Exception as e_:  # noqa: BLE001
-            p["batch_order_SOCIOSEG_STREAM_0"] = {"error": f"{type(e_).__name__}: {e_}"[:200]}
+        # --pipeline-ab: the reference's order of the host flow (two generate calls per batch, the host work between them) instead of the streamed
+        # one.  Not in the default run, which has to stay within minutes: profiles/r06_pipeline250_ab.txt holds the A/B (tools/gpu_lease.sh pipeline250)
+        if batch_order_too:
+            try:
+                q = last_json_line(subprocess.run(script, capture_output=True, text=True, timeout=900, env=dict(env, SOCIOSEG_STREAM="0")).stdout)
+                p["batch_order_SOCIOSEG_STREAM_0"] = {k: q[k] for k in ("samples_per_s", "run_s", "wall_s_by_phase")}
+            except Exception as e_:  # noqa: BLE001
+                p["batch_order_SOCIOSEG_STREAM_0"] = {"error": f"{type(e_).__name__}: {e_}"[:200]}
         p["workload"] = (f"SocioSegInferPipeline.run() on {n_samples} synthetic SocioSeg samples, the shipped YAML (3B LM + SAM2 Hiera-L float32, synthetic "
                          "weights; rollout_batch_size = the sample count as in the reference YAML; "
                          "the YAML's sampling parameters), 128 new tokens per stage, decoded answers scripted to 4 objects per stage so that seg_infer encodes "
-                         "every satellite image and decodes 4 prompts per stage and sample; streamed mode (one open request stream for both stages, the host flow "
+                         "every satellite image and decodes 4 prompts per stage and sample; streamed mode (one open request stream for both "
+                         "stages, the host flow "
                          "under generation) unless the entry says otherwise")
         return p
     except Exception as e_:  # noqa: BLE001
