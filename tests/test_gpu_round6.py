@@ -333,3 +333,38 @@ def test_lm_head_with_x_in_lds_equals_the_streaming_kernel(monkeypatch, M, N):
     ref = x[:M].float() @ w.float().T
     assert float((outs["11"][0] - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
     assert torch.equal(outs["11"][2].long().gather(1, outs["11"][1].argmax(1, keepdim=True)).squeeze(1), outs["11"][0].argmax(1))
+
+
+def test_streamed_and_batch_order_of_the_pipeline_write_the_same_files_on_the_real_engine(tmp_path, monkeypatch):
+    """SocioSegInferPipeline.run() on the real engine (tiny synthetic weights, GREEDY decoding, so a prompt's tokens do not depend on how the scheduler grouped it):
+    the streamed order -- one open request stream for both stages, 7 samples through 4 batch rows, the batch collated as 3 + 3 + 1 rows, stage-2 prompts added while
+    stage-1 prompts of other samples are still waiting -- must write byte-for-byte the response texts and masks of the reference's batch order (SOCIOSEG_STREAM=0),
+    and the same score."""
+    import hashlib
+    import os
+    from roll.pipeline.rlvr.rlvr_socioseg_vlm_pipeline_infer import SocioSegInferPipeline
+    from tests.test_gpu_pipeline import _cfg
+    monkeypatch.setenv("SOCIOSEG_NUM_SAMPLES", "7")
+    monkeypatch.setenv("SOCIOSEG_COLLATE_CHUNK", "3")
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SOCIOSEG_STREAM", mode)
+        d = tmp_path / f"stream{mode}"
+        cfg = _cfg(d, resp=12, prompt=1600)
+        cfg["rollout_batch_size"] = 7
+        cfg.actor_infer.generating_args["temperature"] = 0
+        pipe = SocioSegInferPipeline(cfg)
+        acc = pipe.run()
+        assert pipe.streamed == (mode == "1")
+        res = os.path.join(str(d), "result")
+        files = {}
+        for sub in ("stage1", "stage2", "render1", "render2"):
+            names = sorted(os.listdir(os.path.join(res, sub)))
+            assert len([n for n in names if n.endswith(".png")]) == 7, (mode, sub, names)
+            for n in names:
+                files[f"{sub}/{n}"] = hashlib.sha256(open(os.path.join(res, sub, n), "rb").read()).hexdigest()
+        out[mode] = (acc, files, [g.get("served_as") for g in pipe.actor_infer.strategy.gen_stats])
+        pipe.actor_infer.strategy.engine.close()
+    assert out["1"][2] == ["request stream"] and out["0"][2] == [None, None]          # one open server against two generate calls
+    assert out["1"][0] == out["0"][0]
+    assert out["1"][1] == out["0"][1], sorted(k for k in out["1"][1] if out["1"][1][k] != out["0"][1].get(k))
