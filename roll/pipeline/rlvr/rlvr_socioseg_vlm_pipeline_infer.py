@@ -577,6 +577,8 @@ class SocioSegInferPipeline(BasePipeline):
             global_step += 1
             lap("score_and_write")
         sys.setswitchinterval(switch)
+        if prefetch and hasattr(self.seg_infer, "wait_prefetch"):
+            self.seg_infer.wait_prefetch()          # (segment calls no longer join the prefetch thread: nothing of it may outlive run() -- the caller may close the engines next)
         # request-level dispatch across ranks is collective: a rank whose shard had fewer batches than the largest shard joins the
         # other ranks' remaining rounds (two generate calls per batch) with no requests of its own
         most = max(-(-s_ // self.batch_size) for s_ in dp.split_sizes(self.n_samples, self.world))

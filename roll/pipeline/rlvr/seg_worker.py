@@ -54,6 +54,11 @@ class SegWorker(Worker):
         if hasattr(self.strategy, "prefetch"):
             self.strategy.prefetch(images, chunk=chunk)
 
+    def wait_prefetch(self) -> None:
+        """returns when the background work started by prefetch_images has ended (raises what it raised)"""
+        if hasattr(self.strategy, "wait_prefetch"):
+            self.strategy.wait_prefetch()
+
     @torch.no_grad()
     def segment_v4_map(self, data: DataProto) -> DataProto:
         return self._segment(data, "map_responses")
