@@ -217,8 +217,10 @@ class ContinuousBatcher:
 
     # measured on MI355X (bench.py --admit-cus 2 / 3 / 4): an admission confined to c of the 8 CUs of every shader engine takes
     # (8 / c) x _ADM_EFF[c] as long as on the whole chip, a decode step on the other 8 - c CUs _DEC_SLOW[c] as long
-    _ADM_EFF = {2: 0.86, 3: 0.886, 4: 0.913, 5: 0.94}
-    _DEC_SLOW = {2: 1.20, 3: 1.265, 4: 1.36, 5: 1.55}
+    # (6 of 8: round 6, `bench.py --pair --tile 896 --admit-cus 6` -- admissions of 822 ms on the whole chip against 421 ms of decode per wave: 29.9 samples/s
+    # against 27.4 on 5 CUs, profiles/r06_pair896_share_sweep.txt; the decode step on the remaining 64 CUs is 2.2 x as long)
+    _ADM_EFF = {2: 0.86, 3: 0.886, 4: 0.913, 5: 0.94, 6: 0.955}
+    _DEC_SLOW = {2: 1.20, 3: 1.265, 4: 1.36, 5: 1.55, 6: 2.2}
 
     def _dec_factor(self, c: int) -> float:
         """decode step time on the 8 - c CUs per shader engine next to an admission, relative to the whole chip"""
@@ -272,7 +274,7 @@ class ContinuousBatcher:
         best the smallest is taken (it leaves decode more of the chip); the band was 4 % while the costs came from the 32-row table alone -- with
         the costs measured on the engine itself the prediction is trusted further (64 rows: 3 CUs predicted 2 % behind 4, measured 1.4 % behind)."""
         t = {}
-        for c in (2, 3, 4, 5):
+        for c in (2, 3, 4, 5, 6):
             ta = a_ms * self._adm_factor(c)
             sc = self._step_ms * self._dec_factor(c)
             shared = -(-(ta / sc) // self.steps_per_poll) * self.steps_per_poll      # steps decoded next to the admission (whole chunks)

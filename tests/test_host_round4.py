@@ -204,8 +204,15 @@ def test_scheduler_share_model_picks_the_measured_splits():
     assert pick(122.0, 112) == 3
     assert pick(218.0, 112) == 4
     shares = [pick(a, 112) for a in (40.0, 80.0, 122.0, 160.0, 218.0, 300.0, 500.0)]
-    assert shares == sorted(shares) and shares[0] >= 2 and shares[-1] <= 5, shares
-    assert pick(122.0, 1) == 5
+    assert shares == sorted(shares) and shares[0] >= 2 and shares[-1] <= 6, shares
+    assert pick(122.0, 1) == 6
+    # round 6: 6 of 8 CUs is a candidate too.  Two-image samples at 896 x 896 (822 ms of admission against 128 x 3.29 ms of decode per wave) take it -- measured
+    # 29.9 samples/s against 27.4 on 5 CUs (profiles/r06_pair896_share_sweep.txt)
+    def engine0(step_ms):
+        st = SimpleNamespace(_step_ms=step_ms, steps_per_poll=8, _ADM_EFF=CB._ADM_EFF, _DEC_SLOW=CB._DEC_SLOW, _dec_meas={}, _adm_meas={})
+        st._dec_factor, st._adm_factor = (lambda c: CB._dec_factor(st, c)), (lambda c: CB._adm_factor(st, c))
+        return st
+    assert CB._pick_share(engine0(3.29), 822.0, 128) == 6
     # round 5: the cost of sharing is MEASURED per engine (rows per step) and replaces the 32-row table; shares it has not seen keep the table's
     # shape scaled by what was measured.  The numbers are the bench's (profiles/r05_sched_online_ab.txt).
     def engine(step_ms, dec, adm):
