@@ -63,6 +63,9 @@ class ContinuousBatcher:
         self._commit_ev = None
         self._deferred: list = []               # (requests, token counts, device token rows, event) of rows that finished, not yet reported (_deliver)
         self._copy_stream = None
+        import os
+        if admit_cus_per_se == "auto" and os.environ.get("SR_ADMIT_CUS"):       # deployment / experiment override of the automatic share (2 .. 6, fractions allowed)
+            admit_cus_per_se = float(os.environ["SR_ADMIT_CUS"])
         self._auto = admit_cus_per_se == "auto"
         self._share = 3 if self._auto else admit_cus_per_se
         # calibration of the "auto" share: ms per work unit of an unshared admission, ms per decode step with the chip to itself.  Kept on
