@@ -442,10 +442,16 @@ class SocioSegInferPipeline(BasePipeline):
         return DataProto(batch={k: v[torch.from_numpy(ix)] for k, v in (data.batch or {}).items()},
                          non_tensor_batch={k: v[ix] for k, v in data.non_tensor_batch.items()}, meta_info=dict(data.meta_info))
 
-    def _run_batch_streamed(self, parts, B: int, lap, dirs, writers, pending) -> List[float]:
-        """parts: the rollout batch of B samples as an iterator of (batch, stage-1 generation batch) pieces in sample order -- the first piece's prompts
-        are on the engine while the later pieces are still being collated"""
+    def _run_streamed(self, batches, make_parts, lap, dirs, writers, pending, on_batch_start=None) -> List[List[float]]:
+        """The streamed flow over ALL rollout batches on one open request stream.
+        batches: [(first sample, one past the last)] in dataset order; make_parts(k) -> iterator of (batch, stage-1 generation batch) pieces of batch k in
+        sample order (the first piece's prompts are on the engine while the later pieces are still being collated).  Request ids: batch k owns
+        base_k .. base_k + 2 B_k - 1 -- first its B_k stage-1 prompts, then the stage-2 prompt of sample id - base_k - B_k.  Batch k + 1 is STARTED (collated, its
+        stage-1 prompts added behind whatever is queued) as soon as every stage-1 answer of batch k has been turned into a stage-2 prompt: the engine goes from
+        batch k's stage 2 into batch k + 1's stage 1 without draining, and the next batch is collated under generation.  Per-batch scores come back in batch order."""
         from roll.distributed.scheduler.generate_scheduler import assemble_responses
+        if not batches:
+            return []
         host_stream = None
         if torch.cuda.is_available():
             # this thread's device work (SAM2 decoder, raster kernels, render) runs next to the engine's: on a stream of its own, not on the null
@@ -456,48 +462,73 @@ class SocioSegInferPipeline(BasePipeline):
                 self._host_stream = torch.cuda.Stream()
             host_stream = self._host_stream
         stream = self.generate_scheduler.open_stream(self.actor_infer, self.pipeline_config)
-        try:
+        live: Dict[int, dict] = {}          # batch index -> its state while any of its samples is in flight
+        bases = []
+        for lo, hi in batches:
+            bases.append(2 * lo)            # (ids of batch k: 2 lo_k .. 2 hi_k - 1)
+        results: Dict[int, List[float]] = {}
+        started = 0
+
+        def start(k):
+            lo, hi = batches[k]
+            B = hi - lo
+            if on_batch_start is not None:
+                on_batch_start(k)
             pieces, n0 = [], 0
-            for part, gen_part in parts:
+            for part, gen_part in make_parts(k):
                 lap("collate")
-                stream.add(list(range(n0, n0 + len(part))), gen_part)       # request ids 0 .. B - 1: stage 1; B .. 2B - 1: stage 2 of sample id - B
+                stream.add(list(range(bases[k] + n0, bases[k] + n0 + len(part))), gen_part)
                 lap("generate_stage1")
                 pieces.append((part, gen_part))
                 n0 += len(part)
             assert n0 == B, (n0, B)
-            batch = pieces[0][0] if len(pieces) == 1 else DataProto.concat([p_ for p_, _ in pieces])
-            gen_batch = pieces[0][1] if len(pieces) == 1 else DataProto.concat([g_ for _, g_ in pieces])
+            live[k] = {"B": B, "s1_left": B,
+                       "batch": pieces[0][0] if len(pieces) == 1 else DataProto.concat([p_ for p_, _ in pieces]),
+                       "gen_batch": pieces[0][1] if len(pieces) == 1 else DataProto.concat([g_ for _, g_ in pieces]),
+                       "state": {}, "gen2": {}, "giou": {}}       # state / gen2: sample -> its one-row batch after stage 1 / its stage-2 prompt row
             lap("collate")
-            state: Dict[int, DataProto] = {}                             # sample -> its one-row batch after stage 1
-            gen2_rows: Dict[int, DataProto] = {}                         # sample -> its stage-2 prompt row
-            giou: Dict[int, float] = {}
-            while len(giou) < B:
+
+        try:
+            start(0)
+            started = 1
+            while len(results) < len(batches):
                 got = stream.collect()
                 lap("generate_wait")
-                s1 = sorted((rid, toks) for rid, toks in got if rid < B)
-                s2 = sorted((rid - B, toks) for rid, toks in got if rid >= B)
-                with (torch.cuda.stream(host_stream) if host_stream is not None else contextlib.nullcontext()):
-                    if s1:
-                        idx = [i for i, _ in s1]
-                        sub, gsub = self._rows(batch, idx), self._rows(gen_batch, idx)
-                        out = assemble_responses(gsub, [t for _, t in s1], self.actor_infer, self.pipeline_config)
-                        gen2 = self._after_stage1(sub, out, 1, lap, dirs, writers, pending)
-                        if host_stream is not None:
-                            host_stream.synchronize()                    # the rendered pairs are read by the engine's streams (another thread)
-                        stream.add([B + i for i in idx], gen2)
-                        for k, i in enumerate(idx):
-                            state[i], gen2_rows[i] = self._rows(sub, [k]), self._rows(gen2, [k])
-                        lap("stage2_prompts")
-                    if s2:
-                        idx = [i for i, _ in s2]
-                        sub = DataProto.concat([state.pop(i) for i in idx])
-                        gsub = DataProto.concat([gen2_rows.pop(i) for i in idx])
-                        out = assemble_responses(gsub, [t for _, t in s2], self.actor_infer, self.pipeline_config)
-                        for i, g_ in zip(idx, self._after_stage2(sub, out, lap, dirs, writers, pending)):
-                            giou[i] = g_
+                for k in sorted(live):
+                    b, B, base = live[k], live[k]["B"], bases[k]
+                    mine = [(rid - base, toks) for rid, toks in got if base <= rid < base + 2 * B]
+                    s1 = sorted((i, t) for i, t in mine if i < B)
+                    s2 = sorted((i - B, t) for i, t in mine if i >= B)
+                    with (torch.cuda.stream(host_stream) if host_stream is not None else contextlib.nullcontext()):
+                        if s1:
+                            idx = [i for i, _ in s1]
+                            sub, gsub = self._rows(b["batch"], idx), self._rows(b["gen_batch"], idx)
+                            out = assemble_responses(gsub, [t for _, t in s1], self.actor_infer, self.pipeline_config)
+                            gen2 = self._after_stage1(sub, out, 1, lap, dirs, writers, pending)
+                            if host_stream is not None:
+                                host_stream.synchronize()                # the rendered pairs are read by the engine's streams (another thread)
+                            stream.add([base + B + i for i in idx], gen2)
+                            for j, i in enumerate(idx):
+                                b["state"][i], b["gen2"][i] = self._rows(sub, [j]), self._rows(gen2, [j])
+                            b["s1_left"] -= len(idx)
+                            lap("stage2_prompts")
+                        if s2:
+                            idx = [i for i, _ in s2]
+                            sub = DataProto.concat([b["state"].pop(i) for i in idx])
+                            gsub = DataProto.concat([b["gen2"].pop(i) for i in idx])
+                            out = assemble_responses(gsub, [t for _, t in s2], self.actor_infer, self.pipeline_config)
+                            for i, g_ in zip(idx, self._after_stage2(sub, out, lap, dirs, writers, pending)):
+                                b["giou"][i] = g_
+                for k in sorted(live):
+                    if len(live[k]["giou"]) == live[k]["B"]:
+                        results[k] = [live[k]["giou"][i] for i in range(live[k]["B"])]
+                        del live[k]
+                if started < len(batches) and (started - 1 not in live or live[started - 1]["s1_left"] == 0):
+                    start(started)
+                    started += 1
         finally:
             stream.close()
-        return [giou[i] for i in range(B)]
+        return [results[k] for k in range(len(batches))]
 
     @torch.no_grad()
     def run(self):
@@ -526,41 +557,61 @@ class SocioSegInferPipeline(BasePipeline):
         writers = ThreadPoolExecutor(max_workers=int(os.environ.get("SOCIOSEG_WRITERS", 8)))
         pending = []
         prefetch = os.environ.get("SOCIOSEG_SAM_PREFETCH", "1") != "0" and hasattr(self.seg_infer, "prefetch_images")
-        # (in dataset order: batch k = samples k * batch_size ...; the streamed mode collates the same rows itself, in pieces)
-        loader = None if self.streamed else get_dataloader(self.dataset, self.batch_size, self.data_collator)
         import sys
         switch = sys.getswitchinterval()
+        n_all = len(self.dataset["id"])
+        spans = [(b0, min(b0 + self.batch_size, n_all)) for b0 in range(0, n_all, self.batch_size)]       # (in dataset order: batch k = samples k * batch_size ...)
+
+        def stage1_batches(batch_dict, step):
+            batch = DataProto.from_single_dict(batch_dict)
+            batch.meta_info = {"global_step": step}
+            # ---- stage 1: generate on the (map, satellite) pair
+            gen_batch = batch.pop(batch_keys=["map_input_ids", "map_attention_mask", "map_position_ids"], non_tensor_batch_keys=["multi_modal_map_data"])
+            gen_batch.rename(["map_input_ids", "map_attention_mask", "map_position_ids"], ["input_ids", "attention_mask", "position_ids"])
+            gen_batch.non_tensor_batch["multi_modal_data"] = gen_batch.non_tensor_batch.pop("multi_modal_map_data")
+            return batch, gen_batch
+
+        def start_prefetch(k):
+            if prefetch:
+                # SAM2's set_image needs only the pixels (seg_strategy.py:47-58): its encoder starts now, under the collation of the batch and the
+                # LM's stage-1 generation
+                self.seg_infer.prefetch_images(list(self.dataset["seg_image"][spans[k][0]:spans[k][1]]))
+
         if self.streamed:
             # three Python threads share the interpreter in streamed mode (this one, the request loop, SAM2's prefetch): the request loop needs it for
             # ~1.5 ms between two chunks of decode steps, and every 5 ms (the default switch interval) it waits for it is a chunk the GPU starts late
             sys.setswitchinterval(0.0005)
-        for b0 in range(0, len(self.dataset["id"]), self.batch_size):
-            if prefetch:
-                # SAM2's set_image needs only the pixels (seg_strategy.py:47-58): its encoder starts now, under the collation of the batch and the
-                # LM's stage-1 generation
-                self.seg_infer.prefetch_images(list(self.dataset["seg_image"][b0:b0 + self.batch_size]))
-            def stage1_batches(batch_dict, step=global_step):
-                batch = DataProto.from_single_dict(batch_dict)
-                batch.meta_info = {"global_step": step}
-                # ---- stage 1: generate on the (map, satellite) pair
-                gen_batch = batch.pop(batch_keys=["map_input_ids", "map_attention_mask", "map_position_ids"], non_tensor_batch_keys=["multi_modal_map_data"])
-                gen_batch.rename(["map_input_ids", "map_attention_mask", "map_position_ids"], ["input_ids", "attention_mask", "position_ids"])
-                gen_batch.non_tensor_batch["multi_modal_data"] = gen_batch.non_tensor_batch.pop("multi_modal_map_data")
-                return batch, gen_batch
-            if self.streamed:
+            piece = max(1, int(os.environ.get("SOCIOSEG_COLLATE_CHUNK", 32)))
+            model = getattr(getattr(self.seg_infer, "strategy", None), "model", None)
+            if hasattr(model, "cache_images"):      # two rollout batches are in flight at a batch boundary: batch k's stage 2 still needs its embeddings while batch k + 1's arrive
+                model.cache_images = max(int(model.cache_images), 2 * self.batch_size + 32)
+
+            def make_parts(k):
                 # the rollout batch is collated in pieces (every row is padded to prompt_length and indexed on its own, so the pieces ARE the rows of the
                 # whole batch's collation): the first piece's prompts are being prefilled while the rest is collated
-                self.model_update(global_step)
-                hi = min(b0 + self.batch_size, len(self.dataset["id"]))
-                piece = max(1, int(os.environ.get("SOCIOSEG_COLLATE_CHUNK", 32)))
-                parts = (stage1_batches(self.data_collator([{k: v[i] for k, v in self.dataset.items()} for i in range(c0, min(c0 + piece, hi))]))
-                         for c0 in range(b0, hi, piece))
-                giou_list = self._run_batch_streamed(parts, hi - b0, lap, dirs, writers, pending)
-            else:
+                lo, hi = spans[k]
+                return (stage1_batches(self.data_collator([{key: v[i] for key, v in self.dataset.items()} for i in range(c0, min(c0 + piece, hi))]), k)
+                        for c0 in range(lo, hi, piece))
+
+            def on_batch_start(k):
+                self.model_update(k)
+                start_prefetch(k)
+            try:
+                for giou_list in self._run_streamed(spans, make_parts, lap, dirs, writers, pending, on_batch_start):
+                    print(f"giou_acc: {np.mean(giou_list)}")
+                    all_giou.extend(giou_list)
+                    global_step += 1
+            finally:
+                sys.setswitchinterval(switch)
+            lap("score_and_write")
+        else:
+            loader = get_dataloader(self.dataset, self.batch_size, self.data_collator)
+            for k in range(len(spans)):
+                start_prefetch(k)
                 batch_dict = next(loader)
                 lap("collate")
                 self.model_update(global_step)
-                batch, gen_batch = stage1_batches(batch_dict)
+                batch, gen_batch = stage1_batches(batch_dict, global_step)
                 out = self._generate(gen_batch, global_step)
                 lap("generate_stage1")
                 gen_batch = self._after_stage1(batch, out, n_ret, lap, dirs, writers, pending)
@@ -572,11 +623,10 @@ class SocioSegInferPipeline(BasePipeline):
                 lap("generate_stage2")
                 ga["num_return_sequences"] = keep
                 giou_list = self._after_stage2(batch, out, lap, dirs, writers, pending)
-            print(f"giou_acc: {np.mean(giou_list)}")
-            all_giou.extend(giou_list)
-            global_step += 1
-            lap("score_and_write")
-        sys.setswitchinterval(switch)
+                print(f"giou_acc: {np.mean(giou_list)}")
+                all_giou.extend(giou_list)
+                global_step += 1
+                lap("score_and_write")
         if prefetch and hasattr(self.seg_infer, "wait_prefetch"):
             self.seg_infer.wait_prefetch()          # (segment calls no longer join the prefetch thread: nothing of it may outlive run() -- the caller may close the engines next)
         # request-level dispatch across ranks is collective: a rank whose shard had fewer batches than the largest shard joins the

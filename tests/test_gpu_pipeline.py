@@ -195,6 +195,7 @@ def test_pipeline_two_stage_flow_against_oracle(tmp_path, monkeypatch, streamed)
     proc = SyntheticProcessor(geom)
     cfg = _cfg(tmp_path, resp=400, prompt=2200)
     cfg.actor_infer.generating_args["temperature"] = 0
+    cfg["rollout_batch_size"] = 3          # two rollout batches (3 + 1 samples): the streamed order starts the second while the first is still in stage 2
     seen = {"stage2_images": {}, "stage2_text": {}}
 
     w = _scripted_worker(cfg, geom, proc, seen)
@@ -242,9 +243,9 @@ def test_pipeline_two_stage_flow_against_oracle(tmp_path, monkeypatch, streamed)
     assert abs(acc - float(np.mean(want_iou))) < 1e-12 and acc > 0
     assert open(os.path.join(res, "iou_acc.txt")).read() == f"giou_acc: {acc}"
     assert pipe.streamed == streamed
-    if streamed:       # every sample went through the open stream twice: ids 0..3 (stage 1), 4..7 (stage 2), a sample's stage 2 after its stage 1
+    if streamed:       # every sample went through the ONE open stream twice: batch 0 owns ids 0..2 (stage 1) and 3..5 (stage 2), batch 1 ids 6 and 7; a sample's stage 2 after its stage 1
         order = seen["streamed_requests"]
-        assert sorted(order) == list(range(8)) and all(order.index(i) < order.index(4 + i) for i in range(4)), order
+        assert sorted(order) == list(range(8)) and all(order.index(i) < order.index(3 + i) for i in range(3)) and order.index(6) < order.index(7), order
     else:
         assert "streamed_requests" not in seen
 

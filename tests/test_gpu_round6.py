@@ -351,7 +351,7 @@ def test_streamed_and_batch_order_of_the_pipeline_write_the_same_files_on_the_re
         monkeypatch.setenv("SOCIOSEG_STREAM", mode)
         d = tmp_path / f"stream{mode}"
         cfg = _cfg(d, resp=12, prompt=1600)
-        cfg["rollout_batch_size"] = 7
+        cfg["rollout_batch_size"] = 3          # rollout batches of 3 + 3 + 1 samples: the streamed order keeps ONE request stream open across them
         cfg.actor_infer.generating_args["temperature"] = 0
         pipe = SocioSegInferPipeline(cfg)
         acc = pipe.run()
@@ -365,6 +365,6 @@ def test_streamed_and_batch_order_of_the_pipeline_write_the_same_files_on_the_re
                 files[f"{sub}/{n}"] = hashlib.sha256(open(os.path.join(res, sub, n), "rb").read()).hexdigest()
         out[mode] = (acc, files, [g.get("served_as") for g in pipe.actor_infer.strategy.gen_stats])
         pipe.actor_infer.strategy.engine.close()
-    assert out["1"][2] == ["request stream"] and out["0"][2] == [None, None]          # one open server against two generate calls
+    assert out["1"][2] == ["request stream"] and out["0"][2] == [None] * 6             # one open server against two generate calls per rollout batch
     assert out["1"][0] == out["0"][0]
     assert out["1"][1] == out["0"][1], sorted(k for k in out["1"][1] if out["1"][1][k] != out["0"][1].get(k))
