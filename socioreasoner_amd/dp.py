@@ -60,9 +60,11 @@ def init_distributed(backend: str | None = None):
             torch.cuda.set_device(local)
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"), timeout=_PG_TIMEOUT)
         else:
-            if have_gpu:      # more ranks than GPUs: share the devices, exchange over gloo
-                local = local % torch.cuda.device_count()
             dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=_PG_TIMEOUT)
+    # more ranks than GPUs (the development layout over gloo): the ranks share the devices.  Also when the process group was set up by an earlier call
+    # (roll.distributed.scheduler.initialize.init before the pipeline's own): the device index must not depend on who initialised first
+    if torch.cuda.is_available() and not (dist.is_initialized() and dist.get_backend() == "nccl"):
+        local = local % max(torch.cuda.device_count(), 1)
     return rank, world, local
 
 

@@ -368,3 +368,28 @@ def test_streamed_and_batch_order_of_the_pipeline_write_the_same_files_on_the_re
     assert out["1"][2] == ["request stream"] and out["0"][2] == [None] * 6             # one open server against two generate calls per rollout batch
     assert out["1"][0] == out["0"][0]
     assert out["1"][1] == out["0"][1], sorted(k for k in out["1"][1] if out["1"][1][k] != out["0"][1].get(k))
+
+
+def test_two_ranks_run_the_streamed_pipeline_on_their_shards(tmp_path):
+    """examples/infer through torchrun with two ranks (the development layout: gloo, both ranks on this box's one device; on a node the same command is one rank
+    per GPU over RCCL): every rank streams ITS shard of the samples through its own engine -- no collective inside the generation --, the per-sample IoUs are
+    gathered once at the end, and both ranks report the same score.  Also pins the device index of a rank whose process group was set up by
+    roll.distributed.scheduler.initialize.init before the pipeline asked dp.init_distributed (it used to keep LOCAL_RANK as its device ordinal)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(SR_DIST_BACKEND="gloo", SCRIPTED_OBJECTS="2", OUT=str(tmp_path), SOCIOSEG_NUM_SAMPLES="20", ROLLOUT_BATCH="6", NEW_TOKENS="16", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(ROOT, "tools", "run_example_small.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 2 and all(d["streamed"] is True and d["samples"] == 20 for d in lines), lines
+    assert lines[0]["giou_acc"] == lines[1]["giou_acc"]
+    assert all([g.get("served_as") for g in d["generate_calls"]] == ["request stream"] for d in lines)          # one open stream per rank for its 10 samples (batches of 6 + 4)
+    res = os.path.join(str(tmp_path), "result")
+    for sub, n in (("stage1", 40), ("stage2", 40), ("render1", 20), ("render2", 20)):
+        assert len(os.listdir(os.path.join(res, sub))) == n, (sub, len(os.listdir(os.path.join(res, sub))))
+    assert open(os.path.join(res, "iou_acc.txt")).read() == f"giou_acc: {lines[0]['giou_acc']}"
