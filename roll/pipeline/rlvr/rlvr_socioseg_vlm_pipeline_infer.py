@@ -426,15 +426,26 @@ class SocioSegInferPipeline(BasePipeline):
         added as soon as ITS stage-1 answer has been segmented and rendered, while other samples are still in stage 1 -- so the engine's batch rows
         never drain between the stages and the host flow (SAM2 decoding, rendering, prompt building, scoring, file encoding) runs under generation
         instead of between the two generate calls.  Per sample the operations, their order and the files are those of the batch flow.
-        Needs a strategy whose request loop can stay open (`request_stream`); SOCIOSEG_STREAM=0 restores the reference's batch-by-batch order.
+        Needs a strategy whose request loop can stay open (`request_stream`) and a rollout batch of at least two waves of the engine's rows (SOCIOSEG_STREAM=1 forces
+        it, SOCIOSEG_STREAM=0 restores the reference's batch-by-batch order).
         Not with n > 1 sequences per prompt, nor with request-level dispatch across ranks (generate_opt_level >= 1 and more than one rank: that exchange
         is collective per generate call)."""
-        if os.environ.get("SOCIOSEG_STREAM", "1") == "0" or n_ret != 1:
+        flag = os.environ.get("SOCIOSEG_STREAM", "auto")
+        if flag == "0" or n_ret != 1:
             return False
         if int(self.pipeline_config.get("generate_opt_level") or 0) >= 1 and self.world > 1:
             return False
         st = getattr(self.actor_infer, "strategy", None)
-        return bool(getattr(st, "request_stream", False)) and hasattr(self.actor_infer, "start_server")
+        if not (bool(getattr(st, "request_stream", False)) and hasattr(self.actor_infer, "start_server")):
+            return False
+        # auto (SOCIOSEG_STREAM unset): only where there is something to overlap -- a rollout batch of at least two waves of the engine's batch rows.  With one wave
+        # per stage (64 samples in rollout batches of 32 through 32 rows) every sample of a stage finishes in the same decode step, the stage-2 prompts arrive in
+        # bursts the scheduler cuts into part-filled admissions, and the streamed order measured 4.3-4.9 s against 4.6-4.7 s (profiles/r06_pipeline64_ab.txt);
+        # SOCIOSEG_STREAM=1 forces it
+        rows = getattr(st, "max_batch", None)
+        if flag != "1" and rows and self.batch_size < 2 * int(rows):
+            return False
+        return True
 
     @staticmethod
     def _rows(data: DataProto, idx: List[int]) -> DataProto:

@@ -381,7 +381,8 @@ def test_two_ranks_run_the_streamed_pipeline_on_their_shards(tmp_path):
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env.update(SR_DIST_BACKEND="gloo", SCRIPTED_OBJECTS="2", OUT=str(tmp_path), SOCIOSEG_NUM_SAMPLES="20", ROLLOUT_BATCH="6", NEW_TOKENS="16", MASTER_ADDR="127.0.0.1")
+    env.update(SR_DIST_BACKEND="gloo", SCRIPTED_OBJECTS="2", OUT=str(tmp_path), SOCIOSEG_NUM_SAMPLES="20", ROLLOUT_BATCH="6", NEW_TOKENS="16", MASTER_ADDR="127.0.0.1",
+               SOCIOSEG_STREAM="1")          # (forced: rollout batches of 6 through 32 rows would take the batch order on their own)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
                         os.path.join(ROOT, "tools", "run_example_small.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
